@@ -1,0 +1,123 @@
+/* segmm_hip.h -- C ABI of libsegmm_hip.so, the MI355X (gfx950) kernels of the segment-interest training path.
+ *
+ * The reference (hezy18/SegMMInterest) is pure Python/PyTorch and has NO native boundary; its boundary is the
+ * Python plugin surface `MMinterest/models/__init__.py:1-5`.  This header defines the native layer UNDERNEATH that
+ * surface: each entry point replaces the chain of stock ATen ops the reference executes at the
+ * cited file:line.  Host bindings: `segmminterest_amd/hipabi.py` (ctypes); INTEGRATION.md shows the stub a
+ * maintainer of the reference adds.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller (PyTorch); the library allocates nothing persistent,
+ *    keeps no mutable global state and never synchronises: it only enqueues on `stream` (a hipStream_t);
+ *  - fp32 row-major everywhere; feature/leading dimensions must be multiples of 4 floats and 16-byte aligned;
+ *  - return value 0 = ok, negative = error (message via segmm_last_error(), thread local); nothing throws;
+ *  - re-entrant: forward runs on the Python thread, backward on an autograd-engine thread;
+ *  - dropout is a counter-based Philox stream addressed by (seed, site, element index): with p = 0 results are
+ *    bitwise reproducible run to run; with p > 0 they are reproducible for a fixed (seed, site).
+ */
+#ifndef SEGMM_HIP_H
+#define SEGMM_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* segmm_stream_t; /* hipStream_t */
+
+const char* segmm_last_error(void);
+int segmm_abi_version(void);
+
+/* a1 -- trainer L1 normalisation  x / (sum|x| + 1e-6)  (main_for_seq_leave_earlystop_SegMM.py:272-273).
+ * y may be NULL: then only inv_scale[row] = 1/(sum|x|+1e-6) is produced, for the fused a1+a2 GEMM (row_scale). */
+int segmm_l1norm(const float* x, float* y, float* inv_scale, int64_t rows, int D, segmm_stream_t stream);
+
+/* K2/K3/K5/K6 -- every nn.Linear of the path and its gradients (encoder.py:95-104,163-167,183-184,438,445;
+ * kn_util/nn_utils/layers/mlp.py:17-23), on the f32 MFMA.
+ *   layout 0 (NT): C[M,N] = A[M,K] . B[N,K]^T    forward, B = Linear.weight
+ *   layout 1 (NN): C[M,N] = A[M,K] . B[K,N]      dgrad
+ *   layout 2 (TN): C[M,N] = A[K,M]^T . B[K,N]    wgrad (use splits > 1: K is the token dimension)
+ * epilogue, in this order: * row_scale[m]; + bias[n]; activation (0 none, 1 erf-GELU saving the pre-activation to
+ * aux, 2 multiply by GELU'(aux)); dropout(p, seed, site) on element m*N+n; + residual[(m % res_period), n].
+ * residual may alias C (accumulate).  splits > 1: partial slabs in `workspace` (splits*M*N floats), then a
+ * deterministic combine; only `accumulate` (C += result) applies in that mode. */
+int segmm_gemm(int layout, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+               const float* bias, const float* row_scale, const float* residual, int ldr, int res_period,
+               int activation, float* aux, int ldaux, float drop_p, uint64_t seed, uint32_t site, int splits,
+               float* workspace, int accumulate, segmm_stream_t stream);
+
+/* LayerNorm(d, eps) forward/backward (encoder.py:39-40,170-171,185-186,203,206,383-385,455,465).
+ * forward: optional dropout on the output (embedding dropout, encoder.py:461,471).
+ * backward: dy is first multiplied by the forward's output-dropout mask (drop_y_*); dx_drop (may be NULL) receives
+ * dx times the mask of the residual-branch dropout "x = res + dropout(branch)" (drop_b_*), i.e. d(branch).
+ * part_dgamma/part_dbeta: [nparts, d] per-workgroup partials, nparts = segmm_layernorm_bwd_parts(rows). */
+int segmm_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                        int64_t rows, int d, float eps, float drop_p, uint64_t seed, uint32_t site,
+                        segmm_stream_t stream);
+int segmm_layernorm_bwd_parts(int64_t rows);
+int segmm_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                        float* dx, float* dx_drop, float* part_dgamma, float* part_dbeta, int64_t rows, int d,
+                        float drop_y_p, uint32_t drop_y_site, float drop_b_p, uint32_t drop_b_site, uint64_t seed,
+                        segmm_stream_t stream);
+
+/* out[n] (+)= sum_m w[m] * X[m,n]  (bias gradients, LayerNorm partial combine, head weight gradient).
+ * workspace: segmm_colsum_chunks(M) * N floats. */
+int segmm_colsum_chunks(int64_t M);
+int segmm_colsum(const float* X, int ld, const float* w, int64_t M, int N, float* out, int accumulate,
+                 float* workspace, segmm_stream_t stream);
+
+/* K4 -- joint self+cross attention of one side (encoder.py:44-73,138-161).  Queries Qa/Qb (two projections of the
+ * same Lq tokens) against key blocks a (La tokens) and b (Lb tokens); all tensors are [B*L, ld] with head h at
+ * columns [h*dh, (h+1)*dh).  Masks are uint8 (torch.bool).  lse / Dvec: [B, H, Lq] floats. */
+int segmm_attn_fwd(int B, int H, int dh, int Lq, int La, int Lb, const float* Qa, const float* Qb, int ldq,
+                   const float* Ka, const float* Va, int ldka, const float* Kb, const float* Vb, int ldkb,
+                   const uint8_t* mq, const uint8_t* mka, const uint8_t* mkb, float* O, int ldo, float* lse,
+                   float drop_p, uint64_t seed, uint32_t site, segmm_stream_t stream);
+int segmm_attn_bwd(int B, int H, int dh, int Lq, int La, int Lb, const float* Qa, const float* Qb, int ldq,
+                   const float* Ka, const float* Va, int ldka, const float* Kb, const float* Vb, int ldkb,
+                   const uint8_t* mq, const uint8_t* mka, const uint8_t* mkb, const float* lse, const float* dO,
+                   int lddo, float* Dvec, float* dQa, float* dQb, int lddq, float* dKa, float* dVa, int lddka,
+                   float* dKb, float* dVb, int lddkb, float drop_p, uint64_t seed, uint32_t site,
+                   segmm_stream_t stream);
+
+/* K7 -- interest head Linear(d,1) (decoder_leave_focal.py:451,596): out[m] (+)= x[m,:].w (+ bias[0]) and
+ * dx[m,:] (+)= g[m]*w.  segmm_vecsum: deterministic out[0] (+)= sum v. */
+int segmm_rowdot(const float* x, int ld, const float* w, const float* bias, float* out, int64_t rows, int d,
+                 int accumulate, segmm_stream_t stream);
+int segmm_rowscale_bcast(const float* g, const float* w, float* dx, int ld, int64_t rows, int d, int accumulate,
+                         segmm_stream_t stream);
+int segmm_vecsum(const float* v, int64_t n, float* out, int accumulate, segmm_stream_t stream);
+
+/* K2' -- id-mode embeddings (encoder.py:426-435,445,484-486), pre-LayerNorm:
+ *   vid[b,s,:] = cat(item_table[item_id[b]], frame_w*s + frame_b) + vid_pe[s];   usr[b,0,:] = user_table[uid[b]] + usr_pe[0]
+ * backward: dense table gradients accumulated deterministically over batch rows grouped by id
+ * (order/seg_start from a host-side sort), and dpe[s,:] = sum_b dpre[b,s,:]. */
+int segmm_embed_id_vid(const int64_t* item_id, const float* table, int dhalf, const float* frame_w,
+                       const float* frame_b, const float* pe, float* out, int B, int S, segmm_stream_t stream);
+int segmm_embed_id_usr(const int64_t* user_id, const float* table, int d, const float* pe, float* out, int B,
+                       segmm_stream_t stream);
+int segmm_embed_id_bwd(const float* dpre, int tokens_per_row, int ld, int col0, int width, const int32_t* order,
+                       const int32_t* seg_start, const int64_t* ids, float* dtable, int n_unique,
+                       segmm_stream_t stream);
+int segmm_pe_grad(const float* dpre, int ld, int B, int S, int d, float* dpe, int accumulate, segmm_stream_t stream);
+
+/* K8 -- compute_loss forward + backward in one launch (decoder_leave_focal.py:490-572).
+ * part order: 0 interestBPR 1 focal 2 surviveCE 3 interestCE 4 interestKL 5 huber 6 hazard 7 mse 8 mse2.
+ * coef/enabled are host arrays of 9; parts: [B, 9] per-row contributions already divided by the GLOBAL
+ * normalisers, so a column sum (segmm_colsum) over rows -- and over data-parallel ranks -- gives each loss. */
+int segmm_loss_fwd_bwd(int B, int S, const float* logits, const int64_t* gt, const float* bias_w,
+                       const float* bias_b, const float* exposure, const float* coef, const int* enabled,
+                       int rewritten_ce, int rewritten_kl, int rewritten_mse2, int use_mask, float n_valid_bpr,
+                       float B_global, float mask_sum_global, const float* v_all, const float* v2_all, int Bg,
+                       float* logits_out, float* dlogits, float* parts, segmm_stream_t stream);
+
+/* K9 -- fused AdamW over one flat fp32 range (torch.optim.AdamW semantics; main_for_seq_leave_earlystop_SegMM.py:226,299) */
+int segmm_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                float eps, float weight_decay, int step, segmm_stream_t stream);
+
+/* test hook: multiplier (0 or 1/(1-p)) of elements [0,n) of a dropout site */
+int segmm_dropout_mult(float* out, int64_t n, float p, uint64_t seed, uint32_t site, segmm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

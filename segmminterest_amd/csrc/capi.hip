@@ -1,0 +1,387 @@
+// C ABI of libsegmm_hip.so (see include/segmm_hip.h).  Host-side launch logic only: shape checks,
+// grid selection, error reporting.  Nothing here allocates, synchronises or keeps state.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/segmm_hip.h"
+#include "attention.h"
+#include "common.h"
+#include "gemm.h"
+#include "loss.h"
+#include "rowops.h"
+
+thread_local char g_segmm_err[512] = {0};
+
+int segmm_fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_segmm_err, sizeof(g_segmm_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define LAUNCH_CHECK() SEGMM_CHECK_HIP(hipGetLastError())
+
+using namespace segmm;
+
+static int attn_fill(AttnArgs& a, int B, int H, int dh, int Lq, int La, int Lb, const float* Qa, const float* Qb, int ldq,
+                     const float* Ka, const float* Va, int ldka, const float* Kb, const float* Vb, int ldkb,
+                     const uint8_t* mq, const uint8_t* mka, const uint8_t* mkb, float drop_p, uint64_t seed,
+                     uint32_t site) {
+    SEGMM_REQUIRE(Qa && Qb && Ka && Va && Kb && Vb && mq && mka && mkb, "attn: null pointer");
+    SEGMM_REQUIRE(B > 0 && H > 0 && Lq > 0 && La > 0 && Lb > 0, "attn: empty dimension");
+    SEGMM_REQUIRE(dh == 4 || dh == 8 || dh == 16 || dh == 32 || dh == 48 || dh == 64, "attn: head dim %d not built (4,8,16,32,48,64)", dh);
+    SEGMM_REQUIRE(ldq % 4 == 0 && ldka % 4 == 0 && ldkb % 4 == 0, "attn: leading dims %% 4");
+    SEGMM_REQUIRE(aligned16(Qa) && aligned16(Qb) && aligned16(Ka) && aligned16(Va) && aligned16(Kb) && aligned16(Vb), "attn: alignment");
+    const int Tp = ((La + 15) & ~15) + ((Lb + 15) & ~15);
+    SEGMM_REQUIRE(Tp <= 16 * 12, "attn: %d padded keys > 192 not built", Tp);
+    a.B = B; a.H = H; a.Lq = Lq; a.La = La; a.Lb = Lb;
+    a.Qa = Qa; a.Qb = Qb; a.ldq = ldq; a.Ka = Ka; a.Va = Va; a.ldka = ldka; a.Kb = Kb; a.Vb = Vb; a.ldkb = ldkb;
+    a.mq = mq; a.mka = mka; a.mkb = mkb;
+    a.scale = 1.0f / sqrtf((float)dh);
+    a.drop = make_drop(drop_p, seed, site);
+    return 0;
+}
+
+template <int DH>
+static int attn_launch_fwd(const AttnArgs& a, hipStream_t s) {
+    using C = AttnCfg<DH>;
+    const int Tp = ((a.La + 15) & ~15) + ((a.Lb + 15) & ~15);
+    const int qtiles = (a.Lq + 15) / 16;
+    const int nw = qtiles < 4 ? qtiles : 4;
+    const int QB = nw * 16;
+    dim3 grid(a.B * a.H, (a.Lq + QB - 1) / QB), block(64 * nw);
+    const size_t lds = sizeof(float) * (2 * QB * C::LDR + Tp * C::LDMAX) + Tp;
+    if (Tp <= 64) hipLaunchKernelGGL((attn_fwd_kernel<DH, 4>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<DH, 12>), grid, block, lds, s, a);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+template <int DH>
+static int attn_launch_bwd(const AttnArgs& a, hipStream_t s) {
+    using C = AttnCfg<DH>;
+    const int Tp = ((a.La + 15) & ~15) + ((a.Lb + 15) & ~15);
+    {
+        const int qtiles = (a.Lq + 15) / 16;
+        const int nw = qtiles < 4 ? qtiles : 4;
+        const int QB = nw * 16;
+        dim3 grid(a.B * a.H, (a.Lq + QB - 1) / QB), block(64 * nw);
+        const size_t lds = sizeof(float) * (3 * QB * C::LDR + Tp * C::LDMAX) + Tp;
+        if (Tp <= 64) hipLaunchKernelGGL((attn_bwd_dq_kernel<DH, 4>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((attn_bwd_dq_kernel<DH, 12>), grid, block, lds, s, a);
+        LAUNCH_CHECK();
+    }
+    {
+        const int ktiles = Tp / 16;
+        const int nw = ktiles < 4 ? ktiles : 4;
+        const int KB = nw * 16;
+        const int Lq_p = (a.Lq + 15) & ~15;
+        dim3 grid(a.B * a.H, (Tp + KB - 1) / KB), block(64 * nw);
+        const size_t lds = sizeof(float) * (3 * Lq_p * C::LDR + 2 * KB * C::LDR + 2 * Lq_p) + Lq_p + Tp;
+        SEGMM_REQUIRE(lds <= 160 * 1024, "attn_bwd: %zu bytes of LDS needed (Lq=%d)", lds, a.Lq);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH>), grid, block, lds, s, a);
+        LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+#define ATTN_DISPATCH(FN, dh, ...)                  \
+    switch (dh) {                                   \
+        case 4: return FN<4>(__VA_ARGS__);          \
+        case 8: return FN<8>(__VA_ARGS__);          \
+        case 16: return FN<16>(__VA_ARGS__);        \
+        case 32: return FN<32>(__VA_ARGS__);        \
+        case 48: return FN<48>(__VA_ARGS__);        \
+        case 64: return FN<64>(__VA_ARGS__);        \
+        default: return segmm_fail(-1, "attn: head dim %d", dh); \
+    }
+
+__global__ void dropout_mult_kernel(float* out, long long n, DropCfg d) {
+    for (long long q = blockIdx.x * (long long)blockDim.x + threadIdx.x; q < ((n + 3) >> 2); q += (long long)gridDim.x * blockDim.x) {
+        const f32x4 v = drop_apply4(d, (uint64_t)q, f32x4{1.f, 1.f, 1.f, 1.f});
+        for (int k = 0; k < 4; ++k)
+            if (4 * q + k < n) out[4 * q + k] = v[k];
+    }
+}
+
+extern "C" {
+
+const char* segmm_last_error(void) { return g_segmm_err; }
+int segmm_abi_version(void) { return 1; }
+
+int segmm_l1norm(const float* x, float* y, float* inv_scale, int64_t rows, int D, segmm_stream_t stream) {
+    SEGMM_REQUIRE(x && (y || inv_scale), "l1norm: null pointer");
+    SEGMM_REQUIRE(D > 0 && D % 4 == 0 && aligned16(x) && (!y || aligned16(y)), "l1norm: D %% 4 / alignment (D=%d)", D);
+    if (rows <= 0) return 0;
+    const int wpb = 4;
+    hipLaunchKernelGGL(l1norm_kernel, dim3((unsigned)((rows + wpb - 1) / wpb)), dim3(64 * wpb), 0, (hipStream_t)stream,
+                       x, y, inv_scale, (long long)rows, D);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int segmm_gemm(int layout, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+               const float* bias, const float* row_scale, const float* residual, int ldr, int res_period,
+               int activation, float* aux, int ldaux, float drop_p, uint64_t seed, uint32_t site, int splits,
+               float* workspace, int accumulate, segmm_stream_t stream) {
+    SEGMM_REQUIRE(layout >= 0 && layout <= 2, "gemm: bad layout %d", layout);
+    SEGMM_REQUIRE(A && B && C, "gemm: null operand");
+    if (M <= 0 || N <= 0) return 0;
+    SEGMM_REQUIRE(K > 0, "gemm: K=%d", K);
+    SEGMM_REQUIRE(N % 4 == 0 && ldc % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0, "gemm: N/ld not multiples of 4 (N=%d lda=%d ldb=%d ldc=%d)", N, lda, ldb, ldc);
+    SEGMM_REQUIRE(aligned16(A) && aligned16(B) && aligned16(C), "gemm: operands must be 16-byte aligned");
+    if (layout == 0 || layout == 1) SEGMM_REQUIRE(K % 4 == 0, "gemm: K %% 4 != 0 for a k-contiguous operand (K=%d)", K);
+    if (layout == 2) SEGMM_REQUIRE(M % 4 == 0, "gemm: M %% 4 != 0 for the transposed A operand (M=%d)", M);
+    SEGMM_REQUIRE(!bias || aligned16(bias), "gemm: bias alignment");
+    SEGMM_REQUIRE(!residual || (aligned16(residual) && ldr % 4 == 0 && res_period > 0), "gemm: residual alignment/period");
+    SEGMM_REQUIRE(activation == 0 || (aux && aligned16(aux) && ldaux % 4 == 0), "gemm: activation needs aux");
+    SEGMM_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "gemm: dropout p=%f", drop_p);
+    if (splits < 1) splits = 1;
+    GemmArgs g;
+    g.M = M; g.N = N; g.K = K;
+    g.A = A; g.lda = lda; g.B = B; g.ldb = ldb;
+    g.bias = bias; g.row_scale = row_scale;
+    g.residual = residual; g.ldr = ldr; g.res_period = res_period > 0 ? res_period : 1;
+    g.aux = aux; g.ldaux = ldaux; g.epi = activation;
+    g.drop = make_drop(drop_p, seed, site);
+    g.nbm = (M + GBM - 1) / GBM; g.nbn = (N + GBN - 1) / GBN;
+    int ktiles = (K + GBK - 1) / GBK;
+    if (splits > ktiles) splits = ktiles;
+    if (splits > 1) {
+        SEGMM_REQUIRE(workspace && aligned16(workspace), "gemm: split-K needs a workspace");
+        SEGMM_REQUIRE(!bias && !row_scale && !residual && activation == 0 && drop_p == 0.f, "gemm: split-K supports no epilogue");
+        const int tps = (ktiles + splits - 1) / splits;
+        splits = (ktiles + tps - 1) / tps;
+        g.k_per_split = tps * GBK;
+        g.C = workspace; g.ldc = N; g.slab_stride = (long long)M * N;
+    } else {
+        g.k_per_split = ktiles * GBK;
+        g.C = C; g.ldc = ldc; g.slab_stride = 0;
+        if (accumulate) {
+            SEGMM_REQUIRE(!residual, "gemm: accumulate and residual are exclusive");
+            g.residual = C; g.ldr = ldc; g.res_period = M;
+        }
+    }
+    dim3 grid(g.nbm * g.nbn, 1, splits), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (layout == 0) hipLaunchKernelGGL((gemm_f32_mfma<true, true>), grid, block, 0, s, g);
+    else if (layout == 1) hipLaunchKernelGGL((gemm_f32_mfma<true, false>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((gemm_f32_mfma<false, false>), grid, block, 0, s, g);
+    LAUNCH_CHECK();
+    if (splits > 1) {
+        const long long n4 = (long long)M * (N / 4);
+        int blocks = (int)((n4 + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_reduce, dim3(blocks), dim3(256), 0, s, (const float*)workspace, splits,
+                           (long long)M * N, C, ldc, M, N, accumulate);
+        LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+int segmm_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                        int64_t rows, int d, float eps, float drop_p, uint64_t seed, uint32_t site,
+                        segmm_stream_t stream) {
+    SEGMM_REQUIRE(x && gamma && beta && y && mean && rstd, "layernorm_fwd: null pointer");
+    SEGMM_REQUIRE(d > 0 && d % 4 == 0 && d <= 256 * ROW_MAXV, "layernorm_fwd: d=%d unsupported", d);
+    SEGMM_REQUIRE(aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta), "layernorm_fwd: alignment");
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, gamma,
+                       beta, y, mean, rstd, (long long)rows, d, eps, make_drop(drop_p, seed, site));
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int segmm_layernorm_bwd_parts(int64_t rows) {
+    int64_t b = (rows + 3) / 4;
+    if (b > 1024) b = 1024;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+int segmm_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                        float* dx, float* dx_drop, float* part_dgamma, float* part_dbeta, int64_t rows, int d,
+                        float drop_y_p, uint32_t drop_y_site, float drop_b_p, uint32_t drop_b_site, uint64_t seed,
+                        segmm_stream_t stream) {
+    SEGMM_REQUIRE(dy && x && mean && rstd && gamma && dx && part_dgamma && part_dbeta, "layernorm_bwd: null pointer");
+    SEGMM_REQUIRE(d > 0 && d % 4 == 0 && d <= 256 * ROW_MAXV, "layernorm_bwd: d=%d unsupported", d);
+    SEGMM_REQUIRE(aligned16(dy) && aligned16(x) && aligned16(dx) && aligned16(gamma) && (!dx_drop || aligned16(dx_drop)), "layernorm_bwd: alignment");
+    const int parts = segmm_layernorm_bwd_parts(rows);
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(parts), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma, dx,
+                       dx_drop, part_dgamma, part_dbeta, (long long)rows, d, make_drop(drop_y_p, seed, drop_y_site),
+                       make_drop(drop_b_p, seed, drop_b_site));
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int segmm_colsum_chunks(int64_t M) {
+    int64_t c = (M + 255) / 256;
+    if (c > 256) c = 256;
+    if (c < 1) c = 1;
+    return (int)c;
+}
+
+int segmm_colsum(const float* X, int ld, const float* w, int64_t M, int N, float* out, int accumulate,
+                 float* workspace, segmm_stream_t stream) {
+    SEGMM_REQUIRE(X && out && workspace, "colsum: null pointer");
+    SEGMM_REQUIRE(N > 0 && N % 4 == 0 && ld % 4 == 0 && aligned16(X) && aligned16(workspace), "colsum: N/ld %% 4 / alignment (N=%d ld=%d)", N, ld);
+    const int chunks = segmm_colsum_chunks(M);
+    const int rpc = (int)((M + chunks - 1) / chunks);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 255) / 256, chunks), dim3(256), 0, s, X, ld, w, (long long)M, N,
+                       workspace, rpc > 0 ? rpc : 1);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, s, (const float*)workspace, chunks, N, out,
+                       accumulate);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int segmm_attn_fwd(int B, int H, int dh, int Lq, int La, int Lb, const float* Qa, const float* Qb, int ldq,
+                   const float* Ka, const float* Va, int ldka, const float* Kb, const float* Vb, int ldkb,
+                   const uint8_t* mq, const uint8_t* mka, const uint8_t* mkb, float* O, int ldo, float* lse,
+                   float drop_p, uint64_t seed, uint32_t site, segmm_stream_t stream) {
+    AttnArgs a;
+    memset(&a, 0, sizeof(a));
+    int rc = attn_fill(a, B, H, dh, Lq, La, Lb, Qa, Qb, ldq, Ka, Va, ldka, Kb, Vb, ldkb, mq, mka, mkb, drop_p, seed, site);
+    if (rc) return rc;
+    SEGMM_REQUIRE(O && lse && aligned16(O) && ldo % 4 == 0, "attn_fwd: output pointer/alignment");
+    a.O = O; a.ldo = ldo; a.lse = lse;
+    ATTN_DISPATCH(attn_launch_fwd, dh, a, (hipStream_t)stream);
+}
+
+int segmm_attn_bwd(int B, int H, int dh, int Lq, int La, int Lb, const float* Qa, const float* Qb, int ldq,
+                   const float* Ka, const float* Va, int ldka, const float* Kb, const float* Vb, int ldkb,
+                   const uint8_t* mq, const uint8_t* mka, const uint8_t* mkb, const float* lse, const float* dO,
+                   int lddo, float* Dvec, float* dQa, float* dQb, int lddq, float* dKa, float* dVa, int lddka,
+                   float* dKb, float* dVb, int lddkb, float drop_p, uint64_t seed, uint32_t site,
+                   segmm_stream_t stream) {
+    AttnArgs a;
+    memset(&a, 0, sizeof(a));
+    int rc = attn_fill(a, B, H, dh, Lq, La, Lb, Qa, Qb, ldq, Ka, Va, ldka, Kb, Vb, ldkb, mq, mka, mkb, drop_p, seed, site);
+    if (rc) return rc;
+    SEGMM_REQUIRE(lse && dO && Dvec && dQa && dQb && dKa && dVa && dKb && dVb, "attn_bwd: null pointer");
+    SEGMM_REQUIRE(lddo % 4 == 0 && lddq % 4 == 0 && lddka % 4 == 0 && lddkb % 4 == 0, "attn_bwd: leading dims %% 4");
+    SEGMM_REQUIRE(aligned16(dO) && aligned16(dQa) && aligned16(dQb) && aligned16(dKa) && aligned16(dVa) && aligned16(dKb) && aligned16(dVb), "attn_bwd: alignment");
+    a.lse = (float*)lse; a.dO = dO; a.lddo = lddo; a.Dvec = Dvec;
+    a.dQa = dQa; a.dQb = dQb; a.lddq = lddq; a.dKa = dKa; a.dVa = dVa; a.lddka = lddka; a.dKb = dKb; a.dVb = dVb; a.lddkb = lddkb;
+    ATTN_DISPATCH(attn_launch_bwd, dh, a, (hipStream_t)stream);
+}
+
+int segmm_rowdot(const float* x, int ld, const float* w, const float* bias, float* out, int64_t rows, int d,
+                 int accumulate, segmm_stream_t stream) {
+    SEGMM_REQUIRE(x && w && out && d % 4 == 0 && ld % 4 == 0 && aligned16(x) && aligned16(w), "rowdot: pointer/alignment");
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, ld, w, bias, out,
+                       (long long)rows, d, accumulate);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int segmm_rowscale_bcast(const float* g, const float* w, float* dx, int ld, int64_t rows, int d, int accumulate,
+                         segmm_stream_t stream) {
+    SEGMM_REQUIRE(g && w && dx && d % 4 == 0 && ld % 4 == 0 && aligned16(dx) && aligned16(w), "rowscale_bcast: pointer/alignment");
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(rowscale_bcast_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, g, w, dx, ld,
+                       (long long)rows, d, accumulate);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int segmm_vecsum(const float* v, int64_t n, float* out, int accumulate, segmm_stream_t stream) {
+    SEGMM_REQUIRE(v && out, "vecsum: null pointer");
+    hipLaunchKernelGGL(vecsum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, v, (long long)n, out, accumulate);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int segmm_embed_id_vid(const int64_t* item_id, const float* table, int dhalf, const float* frame_w,
+                       const float* frame_b, const float* pe, float* out, int B, int S, segmm_stream_t stream) {
+    SEGMM_REQUIRE(item_id && table && frame_w && frame_b && pe && out, "embed_id_vid: null pointer");
+    SEGMM_REQUIRE(dhalf % 4 == 0 && aligned16(table) && aligned16(frame_w) && aligned16(frame_b) && aligned16(pe) && aligned16(out), "embed_id_vid: d/2 %% 4 / alignment");
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(embed_id_vid_kernel, dim3(B * S), dim3(64), 0, (hipStream_t)stream, (const long long*)item_id, table, dhalf,
+                       frame_w, frame_b, pe, out, B, S);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int segmm_embed_id_usr(const int64_t* user_id, const float* table, int d, const float* pe, float* out, int B,
+                       segmm_stream_t stream) {
+    SEGMM_REQUIRE(user_id && table && pe && out && d % 4 == 0 && aligned16(table) && aligned16(pe) && aligned16(out), "embed_id_usr: pointer/alignment");
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(embed_id_usr_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, (const long long*)user_id, table, d, pe, out, B);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int segmm_embed_id_bwd(const float* dpre, int tokens_per_row, int ld, int col0, int width, const int32_t* order,
+                       const int32_t* seg_start, const int64_t* ids, float* dtable, int n_unique,
+                       segmm_stream_t stream) {
+    SEGMM_REQUIRE(dpre && order && seg_start && ids && dtable, "embed_id_bwd: null pointer");
+    SEGMM_REQUIRE(width % 4 == 0 && ld % 4 == 0 && col0 % 4 == 0 && aligned16(dpre) && aligned16(dtable), "embed_id_bwd: alignment");
+    if (n_unique <= 0) return 0;
+    hipLaunchKernelGGL(embed_id_bwd_kernel, dim3(n_unique), dim3(64), 0, (hipStream_t)stream, dpre, tokens_per_row, tokens_per_row,
+                       ld, col0, width, (const int*)order, (const int*)seg_start, (const long long*)ids, dtable, n_unique);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int segmm_pe_grad(const float* dpre, int ld, int B, int S, int d, float* dpe, int accumulate, segmm_stream_t stream) {
+    SEGMM_REQUIRE(dpre && dpe && d % 4 == 0 && ld % 4 == 0 && aligned16(dpre) && aligned16(dpe), "pe_grad: pointer/alignment");
+    if (S <= 0) return 0;
+    hipLaunchKernelGGL(pe_grad_kernel, dim3(S), dim3(256), 0, (hipStream_t)stream, dpre, ld, B, S, d, dpe, accumulate);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int segmm_loss_fwd_bwd(int B, int S, const float* logits, const int64_t* gt, const float* bias_w,
+                       const float* bias_b, const float* exposure, const float* coef, const int* enabled,
+                       int rewritten_ce, int rewritten_kl, int rewritten_mse2, int use_mask, float n_valid_bpr,
+                       float B_global, float mask_sum_global, const float* v_all, const float* v2_all, int Bg,
+                       float* logits_out, float* dlogits, float* parts, segmm_stream_t stream) {
+    SEGMM_REQUIRE(logits && gt && exposure && coef && enabled && v_all && v2_all && logits_out && parts, "loss: null pointer");
+    SEGMM_REQUIRE(S >= 1 && S <= 64, "loss: S=%d must be in [1,64]", S);
+    SEGMM_REQUIRE((bias_w == nullptr) == (bias_b == nullptr), "loss: bias_w/bias_b must come together");
+    if (B <= 0) return 0;
+    LossArgs a;
+    memset(&a, 0, sizeof(a));
+    a.B = B; a.S = S; a.logits = logits; a.gt = (const long long*)gt; a.bias_w = bias_w; a.bias_b = bias_b;
+    a.exposure = exposure;
+    for (int k = 0; k < L_NPART; ++k) { a.coef[k] = coef[k]; a.enabled[k] = enabled[k]; }
+    a.gt_rewritten_for_ce = rewritten_ce; a.gt_rewritten_for_kl = rewritten_kl; a.gt_rewritten_for_mse2 = rewritten_mse2;
+    a.use_mask = use_mask; a.n_valid_bpr = n_valid_bpr > 0.f ? n_valid_bpr : 1.f; a.B_global = B_global;
+    a.mask_sum_global = mask_sum_global > 0.f ? mask_sum_global : 1.f;
+    a.v_all = v_all; a.v2_all = v2_all; a.Bg = Bg;
+    a.logits_out = logits_out; a.dlogits = dlogits; a.parts = parts;
+    hipLaunchKernelGGL(loss_fwd_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int segmm_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                float eps, float weight_decay, int step, segmm_stream_t stream) {
+    SEGMM_REQUIRE(p && g && m && v && aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v), "adamw: pointer/alignment");
+    SEGMM_REQUIRE(step >= 1, "adamw: step=%d", step);
+    if (n <= 0) return 0;
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    long long blocks = ((n >> 2) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)n, lr, beta1,
+                       beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2));
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int segmm_dropout_mult(float* out, int64_t n, float p, uint64_t seed, uint32_t site, segmm_stream_t stream) {
+    SEGMM_REQUIRE(out && p >= 0.f && p < 1.f, "dropout_mult: bad args");
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(dropout_mult_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, out, (long long)n, make_drop(p, seed, site));
+    LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

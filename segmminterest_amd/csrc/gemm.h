@@ -1,0 +1,197 @@
+// fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, 64 FLOP/clk/SIMD).
+//
+// The segment-interest path is twelve d x d Linear projections per encoder layer;
+// the 1e-4 logit tolerance rules out plain bf16 MFMA, so every contraction runs on the f32-input
+// MFMA.  One kernel template covers the three operand layouts the forward / dgrad / wgrad need:
+//
+//   NT  C[M,N] = A[M,K] . B[N,K]^T      forward of nn.Linear (weight is [out,in])
+//   NN  C[M,N] = A[M,K] . B[K,N]        dgrad: dX = dY . W
+//   TN  C[M,N] = A[K,M]^T . B[K,N]      wgrad: dW = dY^T . X   (split-K over the token dimension)
+//
+// Tile: 128 x 128 x 32 per 256-thread workgroup (4 waves as 2 x 2, each 64 x 64 = 2 x 2 MFMA tiles,
+// 64 accumulator VGPRs).  Global -> register prefetch of tile t+1 overlaps the MFMAs on tile t; LDS
+// rows are padded (+4 floats) so the ds_read_b128 fragment reads are bank-conflict free.  Because the
+// f32 MFMA takes ONE scalar per lane per operand, the k order inside an 8-wide chunk is permuted
+// (lane half h supplies k = 4h..4h+3) so a lane fetches its four k values with one ds_read_b128.
+// The epilogue restages each 32 x 32 accumulator tile through LDS so that global traffic is
+// row-major float4 and one Philox call serves 4 consecutive elements.
+#pragma once
+#include "common.h"
+
+namespace segmm {
+
+constexpr int GBM = 128, GBN = 128, GBK = 32;
+constexpr int GLDK = GBK + 4;    // row stride of a k-contiguous LDS tile  [128][36]
+constexpr int GLDM = GBM + 4;    // row stride of an m-contiguous LDS tile [32][132]
+constexpr int GTILE = (GBM * GLDK > GBK * GLDM) ? GBM * GLDK : GBK * GLDM;   // 4608 floats
+
+enum { EPI_NONE = 0, EPI_GELU = 1, EPI_DGELU = 2 };
+
+struct GemmArgs {
+    int M, N, K;
+    const float* A; int lda;
+    const float* B; int ldb;
+    float* C; int ldc;
+    const float* bias;        // [N] or null
+    const float* row_scale;   // [M] or null: acc *= row_scale[m] (fused L1 normalisation)
+    const float* residual; int ldr; int res_period;   // v += residual[(m % res_period)*ldr + n]
+    float* aux; int ldaux;    // EPI_GELU: pre-activation written; EPI_DGELU: pre-activation read
+    int epi;
+    DropCfg drop;             // applied after the activation, before the residual
+    int k_per_split;          // K range handled by one blockIdx.z (multiple of GBK)
+    long long slab_stride;    // split-K: partial C of split z at C + z*slab_stride, plain store
+    int nbm, nbn;
+};
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmArgs p) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * GTILE];
+    float* As = smem;
+    float* Bs = smem + GTILE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int lb = xcd_remap(blockIdx.x, p.nbm * p.nbn);
+    const int m0 = (lb / p.nbn) * GBM, n0 = (lb % p.nbn) * GBN;
+    const int kbeg = blockIdx.z * p.k_per_split;
+    const int kend = min(p.K, kbeg + p.k_per_split);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 ra[4], rb[4];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int f = tid + 256 * r;
+            if (A_KC) {
+                const int row = f >> 3, gk = k0 + ((f & 7) << 2), gm = m0 + row;
+                ra[r] = (gm < p.M && gk < kend) ? *(const f32x4*)(p.A + (size_t)gm * p.lda + gk) : zero4;
+            } else {
+                const int gk = k0 + (f >> 5), gm = m0 + ((f & 31) << 2);
+                ra[r] = (gm < p.M && gk < kend) ? *(const f32x4*)(p.A + (size_t)gk * p.lda + gm) : zero4;
+            }
+            if (B_KC) {
+                const int row = f >> 3, gk = k0 + ((f & 7) << 2), gn = n0 + row;
+                rb[r] = (gn < p.N && gk < kend) ? *(const f32x4*)(p.B + (size_t)gn * p.ldb + gk) : zero4;
+            } else {
+                const int gk = k0 + (f >> 5), gn = n0 + ((f & 31) << 2);
+                rb[r] = (gn < p.N && gk < kend) ? *(const f32x4*)(p.B + (size_t)gk * p.ldb + gn) : zero4;
+            }
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int f = tid + 256 * r;
+            if (A_KC) *(f32x4*)(As + (f >> 3) * GLDK + ((f & 7) << 2)) = ra[r];
+            else      *(f32x4*)(As + (f >> 5) * GLDM + ((f & 31) << 2)) = ra[r];
+            if (B_KC) *(f32x4*)(Bs + (f >> 3) * GLDK + ((f & 7) << 2)) = rb[r];
+            else      *(f32x4*)(Bs + (f >> 5) * GLDM + ((f & 31) << 2)) = rb[r];
+        }
+    };
+
+    gload(kbeg);
+    lstore();
+    __syncthreads();
+    for (int k0 = kbeg; k0 < kend; k0 += GBK) {
+        const bool more = (k0 + GBK) < kend;
+        if (more) gload(k0 + GBK);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float af[2][4], bf[2][4];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                if (A_KC) {
+                    const f32x4 v = *(const f32x4*)(As + (wm * 64 + t * 32 + li) * GLDK + c * 8 + lh * 4);
+                    af[t][0] = v.x; af[t][1] = v.y; af[t][2] = v.z; af[t][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) af[t][s] = As[(c * 8 + lh * 4 + s) * GLDM + wm * 64 + t * 32 + li];
+                }
+                if (B_KC) {
+                    const f32x4 v = *(const f32x4*)(Bs + (wn * 64 + t * 32 + li) * GLDK + c * 8 + lh * 4);
+                    bf[t][0] = v.x; bf[t][1] = v.y; bf[t][2] = v.z; bf[t][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) bf[t][s] = Bs[(c * 8 + lh * 4 + s) * GLDM + wn * 64 + t * 32 + li];
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        if (more) {
+            lstore();
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: accumulator tile -> LDS (per-wave region) -> row-major float4
+    float* Cs = smem + wave * (32 * 36);
+    const bool split = gridDim.z > 1;
+    float* Cout = p.C + (size_t)blockIdx.z * (size_t)p.slab_stride;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Cs[((r & 3) + 8 * (r >> 2) + 4 * lh) * 36 + li] = acc[i][j][r];
+            __syncthreads();
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int idx = lane + 64 * r4;
+                const int row = idx >> 3, c4 = (idx & 7) << 2;
+                const int gm = m0 + wm * 64 + i * 32 + row, gn = n0 + wn * 64 + j * 32 + c4;
+                if (gm < p.M && gn < p.N) {
+                    f32x4 v = *(const f32x4*)(Cs + row * 36 + c4);
+                    if (!split) {
+                        if (p.row_scale) v *= p.row_scale[gm];
+                        if (p.bias) v += *(const f32x4*)(p.bias + gn);
+                        if (p.epi == EPI_GELU) {
+                            *(f32x4*)(p.aux + (size_t)gm * p.ldaux + gn) = v;
+                            v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
+                        } else if (p.epi == EPI_DGELU) {
+                            const f32x4 g = *(const f32x4*)(p.aux + (size_t)gm * p.ldaux + gn);
+                            v.x *= gelu_erf_grad(g.x); v.y *= gelu_erf_grad(g.y);
+                            v.z *= gelu_erf_grad(g.z); v.w *= gelu_erf_grad(g.w);
+                        }
+                        if (p.drop.p > 0.f) v = drop_apply4(p.drop, ((uint64_t)gm * (uint64_t)p.N + gn) >> 2, v);
+                        if (p.residual) v += *(const f32x4*)(p.residual + (size_t)(gm % p.res_period) * p.ldr + gn);
+                    }
+                    *(f32x4*)(Cout + (size_t)gm * p.ldc + gn) = v;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// C[m,n] (+)= sum_z slabs[z][m,n]   (deterministic split-K combine)
+__global__ __launch_bounds__(256) void splitk_reduce(const float* __restrict__ slabs, int splits, long long slab_stride, float* C, int ldc,
+                              int M, int N, int accumulate) {
+    const int n4 = N >> 2;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < (long long)M * n4;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / n4), n = (int)(i % n4) << 2;
+        f32x4 s = *(const f32x4*)(slabs + (size_t)m * N + n);
+        for (int z = 1; z < splits; ++z) s += *(const f32x4*)(slabs + (size_t)z * slab_stride + (size_t)m * N + n);
+        float* c = C + (size_t)m * ldc + n;
+        if (accumulate) s += *(const f32x4*)c;
+        *(f32x4*)c = s;
+    }
+}
+
+}  // namespace segmm

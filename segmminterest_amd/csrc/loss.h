@@ -1,0 +1,197 @@
+// Leave/skip label losses, forward + backward in one pass, one wave per interaction row.
+// Follows MultiScaleTemporalDetrLeaveFocal.compute_loss (MMinterest/models/decoder_leave_focal.py:490-572)
+// and the loss functions it calls (:35-97, :99-161, :163-221, :273-286), with the literal 40 generalised to S.
+// No host syncs: the reference's .item()/boolean-index/python-row-loop (:175-178, :554-555) become
+// per-row predicates; every cross-row normaliser (valid-row count, batch size, mask count) is an
+// argument so that a data-parallel shard scales its rows by the GLOBAL count.
+#pragma once
+#include "common.h"
+
+namespace segmm {
+
+enum { L_BPR = 0, L_FOCAL, L_SCE, L_ICE, L_IKL, L_HUBER, L_HAZARD, L_MSE, L_MSE2, L_NPART };
+
+struct LossArgs {
+    int B, S;                       // local rows, segments (S <= 64)
+    const float* logits;            // [B,S] head output (before the learnable position bias)
+    const long long* gt;            // [B,S] in {1,0,-1,-2}
+    const float* bias_w;            // [S] or null   learnable_bias (decoder_leave_focal.py:442-444,497-504)
+    const float* bias_b;
+    const float* exposure;          // [S]
+    float coef[L_NPART];            // loss weight if the loss is selected, else 0 (mse/mse2: logged only)
+    int enabled[L_NPART];
+    int gt_rewritten_for_ce;        // 'focal' precedes interestCE in loss_type_list (in-place gt rewrite :534-535)
+    int gt_rewritten_for_kl;
+    int gt_rewritten_for_mse2;
+    int use_mask;                   // model_cfg.mask_loss
+    // global normalisers
+    float n_valid_bpr;              // rows with view_len < S
+    float B_global;
+    float mask_sum_global;
+    const float* v_all;             // [Bg] view lengths of every row of the global batch (huber / mse broadcast)
+    const float* v2_all;            // [Bg] (gt >= 0).sum per row (mse2)
+    int Bg;
+    // outputs
+    float* logits_out;              // [B,S] logits incl. bias
+    float* dlogits;                 // [B,S] d(total loss)/d(logits incl. bias); may be null
+    float* parts;                   // [B, L_NPART] per-row, already normalised, contributions
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float bce_logits(float x, float t) {
+    return fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
+}
+
+__global__ __launch_bounds__(256) void loss_fwd_bwd_kernel(const LossArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= a.B) return;
+    const int S = a.S;
+    const bool in = lane < S;
+    const float Bg = a.B_global;
+    float z = in ? a.logits[(size_t)row * S + lane] : 0.f;
+    if (in && a.bias_w) z += (float)(lane + 1) * a.bias_w[lane] + a.bias_b[lane];
+    const int gt = in ? (int)a.gt[(size_t)row * S + lane] : -2;
+    const bool m = in && gt != -2;
+    const float mf = m ? 1.f : 0.f;
+    const int v = (int)wave_sum((in && gt == 1) ? 1.f : 0.f);       // view length = index of the leave segment
+    const int dur = (int)wave_sum(mf);
+    const float p = sigmoidf_(z);
+    const float logp = in ? logf(p) : 0.f;
+    const float h = wave_scan_incl(logp, lane);
+    const float surv = in ? expf(h) : 0.f;
+    float dz = 0.f;          // d total / d z (this lane's position)
+    float qs = 0.f;          // d total / d surv_j  (survival-based losses share one suffix scan)
+    float part[L_NPART];
+#pragma unroll
+    for (int k = 0; k < L_NPART; ++k) part[k] = 0.f;
+
+    // ---- interestBPR (compute_interest_BPR_all, :163-221)
+    if (a.enabled[L_BPR] && v < S) {
+        const float pos = __shfl(z, v, 64);
+        const bool neg = in && lane != v;
+        const float mx = wave_max(neg ? z : -INFINITY);
+        const float e = neg ? expf(z - mx) : 0.f;
+        const float w = e / wave_sum(e);
+        const float sg = neg ? sigmoidf_(z - pos) : 0.f;
+        const float A = wave_sum(sg * w);
+        const float Ac = fminf(fmaxf(A, 1e-8f), 1.0f - 1e-8f);
+        part[L_BPR] = -logf(Ac) / a.n_valid_bpr;
+        const float dA = (A >= 1e-8f && A <= 1.0f - 1e-8f) ? -1.0f / (A * a.n_valid_bpr) : 0.f;
+        const float dpos = -wave_sum(w * sg * (1.f - sg));
+        float gz = neg ? w * (sg * (1.f - sg) + sg - A) : 0.f;
+        if (lane == v) gz = dpos;
+        dz += a.coef[L_BPR] * dA * gz;
+    }
+    // ---- focal (my_sigmoid_focal_loss :35-59, alpha .5, gamma 2, exposure-corrected p; sum/bsz :536-538)
+    if (a.enabled[L_FOCAL]) {
+        float t = (gt > 0) ? 1.f : 0.f;                  // after the in-place rewrite: >0 -> 1, -1 -> 0
+        const float ex = in ? a.exposure[lane] : 1.f;
+        const float ce = bce_logits(z, t);
+        const float pe = p * ex;
+        const float pt = pe * t + (1.f - pe) * (1.f - t);
+        const float om = 1.f - pt;
+        const float fl = m ? 0.5f * ce * om * om : 0.f;
+        part[L_FOCAL] = wave_sum(fl) / Bg;
+        if (m) {
+            const float dpt = (2.f * t - 1.f) * ex * p * (1.f - p);
+            dz += a.coef[L_FOCAL] * 0.5f * ((p - t) * om * om - 2.f * ce * om * dpt) / Bg;
+        }
+    }
+    // ---- surviveCE (compute_leave_prob_CE :68-97): BCE-with-logits on exp(h_t), masked mean
+    if (a.enabled[L_SCE]) {
+        const float y = (gt == 1) ? 1.f : 0.f;
+        const float ce = m ? bce_logits(surv, y) : 0.f;
+        part[L_SCE] = wave_sum(ce) / a.mask_sum_global;
+        if (m) qs += a.coef[L_SCE] * (sigmoidf_(surv) - y) / a.mask_sum_global;
+    }
+    // ---- interestCE / interestKL (compute_interest_leave_CE :99-161)
+    if (a.enabled[L_ICE] || a.enabled[L_IKL]) {
+        const float mz = wave_max(in ? z : -INFINITY);
+        const float ez = in ? expf(z - mz) : 0.f;
+        const float sz = wave_sum(ez);
+        const float ni = ez / sz;
+        const float logni = z - mz - logf(sz);
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            const int L = which == 0 ? L_ICE : L_IKL;
+            if (!a.enabled[L]) continue;
+            const int rew = which == 0 ? a.gt_rewritten_for_ce : a.gt_rewritten_for_kl;
+            // gt_nonleave = (gt != 0) on the (possibly rewritten) labels
+            const bool nz = in && (rew ? (gt == 1 || gt == -2) : (gt != 0));
+            const float n1 = wave_sum(nz ? 1.f : 0.f);
+            // softmax of a 0/1 vector the way torch does it (subtract the max)
+            const float gmax = n1 > 0.f ? 1.f : 0.f;
+            const float eg = in ? expf((nz ? 1.f : 0.f) - gmax) : 0.f;
+            const float ng = eg / wave_sum(eg);
+            float c, val;
+            if (a.use_mask) {
+                c = m ? ng / (float)dur : 0.f;
+                val = (which == 0) ? -c * logni : (m ? c * (logf(ng) - logni) : 0.f);
+            } else {
+                c = in ? ng : 0.f;
+                val = (which == 0) ? (in ? -ng * logni : 0.f) : (in ? ng * (logf(ng) - logni) : 0.f);
+            }
+            part[L] = wave_sum(val) / Bg;
+            const float csum = wave_sum(c);
+            if (in) dz += a.coef[L] * (ni * csum - c) / Bg;
+        }
+    }
+    // ---- huber (huber_loss :61-66 on [B] vs [B,1] => [B,B] broadcast, :540) and mse / mse2 (:552-558)
+    const float hz = m ? 1.f - surv : 0.f;
+    const float ssum_h = wave_sum(hz);                   // sum of masked hazard
+    const float ssum = wave_sum(m ? surv : 0.f);         // sum of masked survival
+    {
+        const int dlast = dur > 0 ? dur - 1 : S - 1;
+        const float ssum2 = wave_sum(in ? (lane == dlast ? 1.f : (m ? surv : 0.f)) : 0.f);
+        float hub = 0.f, dhub = 0.f, e1 = 0.f, e2 = 0.f;
+        for (int i = lane; i < a.Bg; i += 64) {
+            const float vi = a.v_all[i];
+            if (a.enabled[L_HUBER]) {
+                const float err = ssum_h - vi, ae = fabsf(err);
+                hub += ae < 1.f ? 0.5f * err * err : ae - 0.5f;
+                dhub += ae < 1.f ? err : (err > 0.f ? 1.f : -1.f);
+            }
+            const float d1 = ssum - vi, d2 = ssum2 - a.v2_all[i];
+            e1 += d1 * d1;
+            e2 += d2 * d2;
+        }
+        const float inv = 1.0f / (Bg * Bg);
+        part[L_MSE] = wave_sum(e1) * inv;
+        part[L_MSE2] = wave_sum(e2) * inv;
+        if (a.enabled[L_HUBER]) {
+            part[L_HUBER] = wave_sum(hub) * inv;
+            const float dLds = wave_sum(dhub) * inv;     // d/d(sum of masked hazard)
+            if (m) qs += a.coef[L_HUBER] * (-dLds);
+        }
+    }
+    // ---- hazard (compute_partial_likelihood_loss :273-286)
+    if (a.enabled[L_HAZARD] && v < S) {
+        const float ht = __shfl(hz, v, 64) + 1e-6f;
+        const float R = wave_sum((in && lane >= v) ? hz : 0.f) + 1e-6f;
+        part[L_HAZARD] = -(logf(ht) - logf(R)) / Bg;
+        if (m) {
+            float dh = 0.f;                               // d L / d hz_j
+            if (lane == v) dh -= 1.f / ht;
+            if (lane >= v) dh += 1.f / R;
+            qs += a.coef[L_HAZARD] * (dh / Bg) * (-1.f);  // hz = 1 - surv
+        }
+    }
+    // ---- survival chain: d surv_j / d z_k = surv_j (1 - p_k) for k <= j  => suffix sum over j >= k
+    {
+        const float u = in ? qs * surv : 0.f;
+        const float c = wave_scan_incl(u, lane);
+        const float tot = __shfl(c, 63, 64);
+        if (in) dz += (1.f - p) * (tot - c + u);
+    }
+    if (in) {
+        a.logits_out[(size_t)row * S + lane] = z;
+        if (a.dlogits) a.dlogits[(size_t)row * S + lane] = dz;
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < L_NPART; ++k) a.parts[(size_t)row * L_NPART + k] = part[k];
+    }
+}
+
+}  // namespace segmm

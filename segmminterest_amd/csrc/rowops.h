@@ -1,0 +1,324 @@
+// HBM-bound row kernels of the path: L1 normalisation, LayerNorm forward/backward, column sums,
+// the Linear(d,1) interest head, id-embedding gather, fused multi-tensor AdamW.  All are one-wave-
+// per-row (wave64 shuffle reductions, float4 coalesced traffic, no LDS for the row reduce).
+#pragma once
+#include "common.h"
+
+namespace segmm {
+
+constexpr int ROW_MAXV = 8;      // float4 per lane kept in registers => d <= 2048
+
+// ---------------------------------------------------------------- a1: x / (sum|x| + 1e-6)
+// trainer-side normalisation, main_for_seq_leave_earlystop_SegMM.py:272-273.  If y == null only the
+// reciprocal scale is written (consumed by the GEMM row_scale epilogue: the fused a1+a2 path).
+__global__ __launch_bounds__(256) void l1norm_kernel(const float* __restrict__ x, float* y, float* inv_scale, long long rows, int D) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * D;
+    float s = 0.f;
+    for (int c = lane * 4; c < D; c += 256) {
+        const f32x4 v = *(const f32x4*)(xr + c);
+        s += fabsf(v.x) + fabsf(v.y) + fabsf(v.z) + fabsf(v.w);
+    }
+    s = wave_sum(s);
+    const float inv = 1.0f / (s + 1e-6f);
+    if (inv_scale && lane == 0) inv_scale[row] = inv;
+    if (y) {
+        const float den = s + 1e-6f;
+        for (int c = lane * 4; c < D; c += 256) {
+            f32x4 v = *(const f32x4*)(xr + c);
+            v.x /= den; v.y /= den; v.z /= den; v.w /= den;
+            *(f32x4*)(y + row * D + c) = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- LayerNorm forward (eps 1e-12, encoder.py:39-40)
+// y = LN(x) * gamma + beta, optional dropout on y (embedding, encoder.py:461,471); saves mean / rstd.
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                     const float* __restrict__ beta, float* __restrict__ y, float* mean_out,
+                                     float* rstd_out, long long rows, int d, float eps, DropCfg drop) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * d;
+    f32x4 v[ROW_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < ROW_MAXV; ++i) {
+        const int c = lane * 4 + i * 256;
+        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (c < d) { v[i] = *(const f32x4*)(xr + c); s += v[i].x + v[i].y + v[i].z + v[i].w; }
+    }
+    const float mean = wave_sum(s) / d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < ROW_MAXV; ++i) {
+        const int c = lane * 4 + i * 256;
+        if (c < d) {
+            const f32x4 t = v[i] - mean;
+            q += t.x * t.x + t.y * t.y + t.z * t.z + t.w * t.w;
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / d + eps);
+    if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+#pragma unroll
+    for (int i = 0; i < ROW_MAXV; ++i) {
+        const int c = lane * 4 + i * 256;
+        if (c < d) {
+            f32x4 o = (v[i] - mean) * rstd * *(const f32x4*)(gamma + c) + *(const f32x4*)(beta + c);
+            if (drop.p > 0.f) o = drop_apply4(drop, ((uint64_t)row * d + c) >> 2, o);
+            *(f32x4*)(y + row * d + c) = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- LayerNorm backward
+// dy_eff = dy (.) dropmask (if the forward dropped y);  dx = rstd (g dy - mean(g dy) - xhat mean(g dy xhat)).
+// Outputs: dx; optionally dx_drop = dx (.) dropmask2 (the gradient that continues through the
+// residual branch "x = res + dropout(z)": dz = dx_drop); per-workgroup partial dgamma/dbeta.
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                     const float* __restrict__ gamma, float* __restrict__ dx,
+                                     float* __restrict__ dx_drop, float* __restrict__ part_dgamma,
+                                     float* __restrict__ part_dbeta, long long rows, int d, DropCfg drop_y,
+                                     DropCfg drop_branch) {
+    __shared__ float red[4][2048];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    f32x4 ag[ROW_MAXV], ab[ROW_MAXV], gm[ROW_MAXV];
+#pragma unroll
+    for (int i = 0; i < ROW_MAXV; ++i) {
+        ag[i] = f32x4{0.f, 0.f, 0.f, 0.f}; ab[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int c = lane * 4 + i * 256;
+        gm[i] = (c < d) ? *(const f32x4*)(gamma + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (long long row = (long long)blockIdx.x * nw + wave; row < rows; row += (long long)gridDim.x * nw) {
+        const float mu = mean[row], rs = rstd[row];
+        f32x4 g[ROW_MAXV], xh[ROW_MAXV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < ROW_MAXV; ++i) {
+            const int c = lane * 4 + i * 256;
+            g[i] = f32x4{0.f, 0.f, 0.f, 0.f}; xh[i] = g[i];
+            if (c < d) {
+                f32x4 t = *(const f32x4*)(dy + row * d + c);
+                if (drop_y.p > 0.f) t = drop_apply4(drop_y, ((uint64_t)row * d + c) >> 2, t);
+                xh[i] = (*(const f32x4*)(x + row * d + c) - mu) * rs;
+                ab[i] += t;
+                ag[i] += t * xh[i];
+                g[i] = t * gm[i];
+                s1 += g[i].x + g[i].y + g[i].z + g[i].w;
+                const f32x4 u = g[i] * xh[i];
+                s2 += u.x + u.y + u.z + u.w;
+            }
+        }
+        s1 = wave_sum(s1) / d;
+        s2 = wave_sum(s2) / d;
+#pragma unroll
+        for (int i = 0; i < ROW_MAXV; ++i) {
+            const int c = lane * 4 + i * 256;
+            if (c < d) {
+                const f32x4 o = (g[i] - s1 - xh[i] * s2) * rs;
+                *(f32x4*)(dx + row * d + c) = o;
+                if (dx_drop) {
+                    f32x4 od = o;
+                    if (drop_branch.p > 0.f) od = drop_apply4(drop_branch, ((uint64_t)row * d + c) >> 2, o);
+                    *(f32x4*)(dx_drop + row * d + c) = od;
+                }
+            }
+        }
+    }
+    // cross-wave reduce of the dgamma / dbeta partials, one partial row per workgroup
+    for (int pass = 0; pass < 2; ++pass) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < ROW_MAXV; ++i) {
+            const int c = lane * 4 + i * 256;
+            if (c < d) *(f32x4*)(&red[wave][c]) = pass == 0 ? ag[i] : ab[i];
+        }
+        __syncthreads();
+        float* out = (pass == 0 ? part_dgamma : part_dbeta) + (size_t)blockIdx.x * d;
+        for (int c = threadIdx.x; c < d; c += blockDim.x) {
+            float s = 0.f;
+            for (int w = 0; w < nw; ++w) s += red[w][c];
+            out[c] = s;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- column sums (bias grads, head weight grad)
+// partial[chunk][n] = sum over the chunk's rows of w[m] * X[m][n]   (w optional)
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X, int ld, const float* __restrict__ w, long long M,
+                                      int N, float* __restrict__ partial, int rows_per_chunk) {
+    __shared__ f32x4 red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int n = (blockIdx.x * 64 + tx) * 4;
+    const long long r0 = (long long)blockIdx.y * rows_per_chunk;
+    const long long r1 = min(M, r0 + rows_per_chunk);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (n < N) {
+        for (long long r = r0 + ty; r < r1; r += 4) {
+            f32x4 v = *(const f32x4*)(X + r * ld + n);
+            if (w) v *= w[r];
+            acc += v;
+        }
+    }
+    red[ty][tx] = acc;
+    __syncthreads();
+    if (ty == 0 && n < N) {
+        const f32x4 s = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
+        *(f32x4*)(partial + (size_t)blockIdx.y * N + n) = s;
+    }
+}
+// out[n] (+)= sum_p partial[p][n]
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int P, int N, float* out, int accumulate) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int p = 0; p < P; ++p) s += partial[(size_t)p * N + n];
+    out[n] = accumulate ? out[n] + s : s;
+}
+
+// ---------------------------------------------------------------- interest head: Linear(d,1)  (decoder_leave_focal.py:451,596)
+// out[m] (+)= x[m,:].w (+ bias)
+__global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ x, int ld, const float* __restrict__ w,
+                              const float* __restrict__ bias, float* out, long long rows, int d, int accumulate) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float s = 0.f;
+    for (int c = lane * 4; c < d; c += 256) {
+        const f32x4 a = *(const f32x4*)(x + row * ld + c), b = *(const f32x4*)(w + c);
+        s += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+    }
+    s = wave_sum(s);
+    if (lane == 0) {
+        if (bias) s += bias[0];
+        out[row] = accumulate ? out[row] + s : s;
+    }
+}
+// dx[m,:] (+)= g[m] * w
+__global__ __launch_bounds__(256) void rowscale_bcast_kernel(const float* __restrict__ g, const float* __restrict__ w, float* dx, int ld,
+                                      long long rows, int d, int accumulate) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float gv = g[row];
+    for (int c = lane * 4; c < d; c += 256) {
+        f32x4 v = *(const f32x4*)(w + c) * gv;
+        float* o = dx + row * ld + c;
+        if (accumulate) v += *(const f32x4*)o;
+        *(f32x4*)o = v;
+    }
+}
+// deterministic single-workgroup sum of a vector: out[0] (+)= sum v
+__global__ __launch_bounds__(1024) void vecsum_kernel(const float* __restrict__ v, long long n, float* out, int accumulate) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (long long i = threadIdx.x; i < n; i += blockDim.x) s += v[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+        out[0] = accumulate ? out[0] + t : t;
+    }
+}
+
+// ---------------------------------------------------------------- id-mode embedding (encoder.py:426-435,445,484-486)
+// vid[b,s,:] = cat(E_item[item_id[b]], frame_w * s + frame_b) + pe[s]     (pre-LayerNorm)
+__global__ __launch_bounds__(256) void embed_id_vid_kernel(const long long* __restrict__ item_id, const float* __restrict__ table, int dhalf,
+                                    const float* __restrict__ frame_w, const float* __restrict__ frame_b,
+                                    const float* __restrict__ pe, float* __restrict__ out, int B, int S) {
+    const int d = 2 * dhalf;
+    const long long row = blockIdx.x;       // b*S + s
+    const int b = (int)(row / S), s = (int)(row % S);
+    const long long id = item_id[b];
+    for (int c = threadIdx.x * 4; c < d; c += blockDim.x * 4) {
+        f32x4 v;
+        if (c < dhalf) v = *(const f32x4*)(table + id * dhalf + c);
+        else v = *(const f32x4*)(frame_w + (c - dhalf)) * (float)s + *(const f32x4*)(frame_b + (c - dhalf));
+        v += *(const f32x4*)(pe + (size_t)s * d + c);
+        *(f32x4*)(out + row * d + c) = v;
+    }
+}
+// usr[b,0,:] = E_user[user_id[b]] + pe[0]
+__global__ __launch_bounds__(256) void embed_id_usr_kernel(const long long* __restrict__ user_id, const float* __restrict__ table, int d,
+                                    const float* __restrict__ pe, float* __restrict__ out, int B) {
+    const int b = blockIdx.x;
+    const long long id = user_id[b];
+    for (int c = threadIdx.x * 4; c < d; c += blockDim.x * 4)
+        *(f32x4*)(out + (size_t)b * d + c) = *(const f32x4*)(table + id * d + c) + *(const f32x4*)(pe + c);
+}
+// backward of the gathers: dense table gradients (torch.nn.Embedding semantics), deterministic:
+// one workgroup per batch row b walks ... -> rows with equal ids would race, so the scatter runs over
+// UNIQUE ids: the host passes `order` (batch rows sorted by id) and `seg_start` offsets.
+__global__ __launch_bounds__(256) void embed_id_bwd_kernel(const float* __restrict__ dpre, int row_stride_tokens, int tok_per_row, int ld,
+                                    int col0, int width, const int* __restrict__ order,
+                                    const int* __restrict__ seg_start, const long long* __restrict__ ids,
+                                    float* __restrict__ dtable, int n_unique) {
+    // dtable[id, :] += sum over batch rows with that id, over their tok_per_row tokens, of dpre[token, col0:col0+width]
+    const int u = blockIdx.x;
+    if (u >= n_unique) return;
+    const int s0 = seg_start[u], s1 = seg_start[u + 1];
+    const long long id = ids[order[s0]];
+    for (int c = threadIdx.x * 4; c < width; c += blockDim.x * 4) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int k = s0; k < s1; ++k) {
+            const long long tok0 = (long long)order[k] * row_stride_tokens;
+            for (int t = 0; t < tok_per_row; ++t) acc += *(const f32x4*)(dpre + (tok0 + t) * ld + col0 + c);
+        }
+        float* o = dtable + id * width + c;
+        *(f32x4*)o = *(const f32x4*)o + acc;
+    }
+}
+// frame-position Linear(1, d/2) grads and positional-embedding grads need column sums over b with s fixed:
+// dpe[s, :] = sum_b dpre[b*S+s, :]   (one workgroup per s; deterministic)
+__global__ __launch_bounds__(256) void pe_grad_kernel(const float* __restrict__ dpre, int ld, int B, int S, int d, float* __restrict__ dpe,
+                               int accumulate) {
+    const int s = blockIdx.x;
+    for (int c = threadIdx.x * 4; c < d; c += blockDim.x * 4) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < B; ++b) acc += *(const f32x4*)(dpre + ((size_t)b * S + s) * ld + c);
+        float* o = dpe + (size_t)s * d + c;
+        if (accumulate) acc += *(const f32x4*)o;
+        *(f32x4*)o = acc;
+    }
+}
+
+// ---------------------------------------------------------------- fused AdamW over a flat range (a13 / K9)
+// torch.optim.AdamW single-tensor update order (decoupled decay first), bias corrections passed in.
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                             float* __restrict__ v, long long n, float lr, float b1, float b2, float eps, float wd,
+                             float bc1, float bc2_sqrt) {
+    const long long n4 = n >> 2;
+    const float step = lr / bc1;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        f32x4 pp = ((f32x4*)p)[i];
+        const f32x4 gg = ((const f32x4*)g)[i];
+        f32x4 mm = ((f32x4*)m)[i], vv = ((f32x4*)v)[i];
+        pp *= (1.0f - lr * wd);
+        mm = mm * b1 + gg * (1.0f - b1);
+        vv = vv * b2 + gg * gg * (1.0f - b2);
+        f32x4 den;
+        den.x = sqrtf(vv.x) / bc2_sqrt + eps; den.y = sqrtf(vv.y) / bc2_sqrt + eps;
+        den.z = sqrtf(vv.z) / bc2_sqrt + eps; den.w = sqrtf(vv.w) / bc2_sqrt + eps;
+        pp.x -= step * (mm.x / den.x); pp.y -= step * (mm.y / den.y);
+        pp.z -= step * (mm.z / den.z); pp.w -= step * (mm.w / den.w);
+        ((f32x4*)p)[i] = pp; ((f32x4*)m)[i] = mm; ((f32x4*)v)[i] = vv;
+    }
+    // tail (n % 4)
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const long long i = (n4 << 2) + threadIdx.x;
+        float pp = p[i] * (1.0f - lr * wd);
+        const float gg = g[i];
+        const float mm = m[i] * b1 + gg * (1.0f - b1);
+        const float vv = v[i] * b2 + gg * gg * (1.0f - b2);
+        pp -= step * (mm / (sqrtf(vv) / bc2_sqrt + eps));
+        p[i] = pp; m[i] = mm; v[i] = vv;
+    }
+}
+
+}  // namespace segmm

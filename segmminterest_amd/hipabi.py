@@ -1,0 +1,223 @@
+"""ctypes binding of ``libsegmm_hip.so`` (C ABI declared in ``include/segmm_hip.h``).
+
+PyTorch is only plumbing here: it owns device memory and the HIP stream; every wrapper passes raw
+device pointers, sizes and ``torch.cuda.current_stream()`` through the C ABI.  There is NO fallback:
+if the shared library is missing or a call fails, a ``RuntimeError`` is raised (the product path
+must never run on a silent eager/CPU substitute).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsegmm_hip.so")
+ABI_VERSION = 1
+
+_lib = None
+
+_i, _i64, _f, _u64, _u32, _p = C.c_int, C.c_int64, C.c_float, C.c_uint64, C.c_uint32, C.c_void_p
+
+# name -> argtypes; the single source of truth for the exported symbol set (tests check it against the header)
+SIGNATURES = {
+    "segmm_l1norm": [_p, _p, _p, _i64, _i, _p],
+    "segmm_gemm": [_i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _p, _i, _f, _u64, _u32, _i, _p, _i, _p],
+    "segmm_layernorm_fwd": [_p, _p, _p, _p, _p, _p, _i64, _i, _f, _f, _u64, _u32, _p],
+    "segmm_layernorm_bwd_parts": [_i64],
+    "segmm_layernorm_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _f, _u32, _f, _u32, _u64, _p],
+    "segmm_colsum_chunks": [_i64],
+    "segmm_colsum": [_p, _i, _p, _i64, _i, _p, _i, _p, _p],
+    "segmm_attn_fwd": [_i] * 6 + [_p, _p, _i, _p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _i, _p, _f, _u64, _u32, _p],
+    "segmm_attn_bwd": [_i] * 6 + [_p, _p, _i, _p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _p, _p, _i,
+                                  _p, _p, _i, _f, _u64, _u32, _p],
+    "segmm_rowdot": [_p, _i, _p, _p, _p, _i64, _i, _i, _p],
+    "segmm_rowscale_bcast": [_p, _p, _p, _i, _i64, _i, _i, _p],
+    "segmm_vecsum": [_p, _i64, _p, _i, _p],
+    "segmm_embed_id_vid": [_p, _p, _i, _p, _p, _p, _p, _i, _i, _p],
+    "segmm_embed_id_usr": [_p, _p, _i, _p, _p, _i, _p],
+    "segmm_embed_id_bwd": [_p, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p],
+    "segmm_pe_grad": [_p, _i, _i, _i, _i, _p, _i, _p],
+    "segmm_loss_fwd_bwd": [_i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _f, _p, _p, _i, _p, _p, _p, _p],
+    "segmm_adamw": [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _i, _p],
+    "segmm_dropout_mult": [_p, _i64, _f, _u64, _u32, _p],
+}
+
+
+def lib():
+    """Loads the shared library once; raises if it has not been built (``python -c 'import __graft_entry__ as g; g.build()'``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("segmminterest_amd: %s is missing -- build it with __graft_entry__.build() "
+                           "(hipcc --offload-arch=gfx950); there is no fallback path" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    L.segmm_last_error.restype = C.c_char_p
+    L.segmm_last_error.argtypes = []
+    L.segmm_abi_version.restype = _i
+    L.segmm_abi_version.argtypes = []
+    for name, at in SIGNATURES.items():
+        fn = getattr(L, name)
+        fn.argtypes = at
+        fn.restype = _i
+    if L.segmm_abi_version() != ABI_VERSION:
+        raise RuntimeError("libsegmm_hip.so ABI %d != expected %d: rebuild" % (L.segmm_abi_version(), ABI_VERSION))
+    _lib = L
+    return L
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed (%d): %s" % (what, rc, lib().segmm_last_error().decode()))
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("segmminterest_amd kernels need device tensors (got %s); no CPU fallback" % t.device)
+
+
+def _f32c(t, name="tensor"):
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise RuntimeError("%s must be contiguous float32 (got %s, contiguous=%s)" % (name, t.dtype, t.is_contiguous()))
+    return t
+
+
+LAYOUT_NT, LAYOUT_NN, LAYOUT_TN = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_DGELU = 0, 1, 2
+
+
+def l1norm(x, out=None, inv_scale=None):
+    _dev(x)
+    D = x.shape[-1]
+    rows = x.numel() // D
+    _check(lib().segmm_l1norm(_ptr(x), _ptr(out), _ptr(inv_scale), rows, D, _stream()), "segmm_l1norm")
+
+
+def gemm(layout, M, N, K, A, lda, B, ldb, Cout, ldc, bias=None, row_scale=None, residual=None, ldr=0, res_period=0,
+         activation=0, aux=None, ldaux=0, drop_p=0.0, seed=0, site=0, splits=1, workspace=None, accumulate=False,
+         a_off=0, b_off=0, c_off=0):
+    """Raw strided GEMM; ``*_off`` are element offsets into the tensors (column slices of fused buffers)."""
+    _dev(A, B, Cout)
+    es = 4
+    _check(lib().segmm_gemm(layout, M, N, K, A.data_ptr() + a_off * es, lda, B.data_ptr() + b_off * es, ldb,
+                            Cout.data_ptr() + c_off * es, ldc, _ptr(bias), _ptr(row_scale), _ptr(residual), ldr,
+                            res_period, activation, _ptr(aux), ldaux, float(drop_p), int(seed), int(site),
+                            int(splits), _ptr(workspace), int(bool(accumulate)), _stream()), "segmm_gemm")
+
+
+def layernorm_fwd(x, gamma, beta, y, mean, rstd, eps=1e-12, drop_p=0.0, seed=0, site=0):
+    _dev(x, y)
+    d = x.shape[-1]
+    _check(lib().segmm_layernorm_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd),
+                                     x.numel() // d, d, eps, float(drop_p), int(seed), int(site), _stream()),
+           "segmm_layernorm_fwd")
+
+
+def layernorm_bwd_parts(rows):
+    return lib().segmm_layernorm_bwd_parts(rows)
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dx_drop, part_dgamma, part_dbeta, drop_y_p=0.0, drop_y_site=0,
+                  drop_b_p=0.0, drop_b_site=0, seed=0):
+    _dev(dy, x, dx)
+    d = x.shape[-1]
+    _check(lib().segmm_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(dx), _ptr(dx_drop),
+                                     _ptr(part_dgamma), _ptr(part_dbeta), x.numel() // d, d, float(drop_y_p),
+                                     int(drop_y_site), float(drop_b_p), int(drop_b_site), int(seed), _stream()),
+           "segmm_layernorm_bwd")
+
+
+def colsum_chunks(M):
+    return lib().segmm_colsum_chunks(M)
+
+
+def colsum(X, ld, M, N, out, workspace, w=None, accumulate=False, x_off=0, out_off=0):
+    _dev(X, out, workspace)
+    _check(lib().segmm_colsum(X.data_ptr() + 4 * x_off, ld, _ptr(w), M, N, out.data_ptr() + 4 * out_off,
+                              int(bool(accumulate)), _ptr(workspace), _stream()), "segmm_colsum")
+
+
+def attn_fwd(B, H, dh, Lq, La, Lb, Qa, Qb, ldq, Ka, Va, ldka, Kb, Vb, ldkb, mq, mka, mkb, O, ldo, lse,
+             drop_p=0.0, seed=0, site=0):
+    """Q*/K*/V* are (tensor, element_offset) pairs: column slices of the fused projection buffers."""
+    def P(x):
+        return x[0].data_ptr() + 4 * x[1]
+    _check(lib().segmm_attn_fwd(B, H, dh, Lq, La, Lb, P(Qa), P(Qb), ldq, P(Ka), P(Va), ldka, P(Kb), P(Vb), ldkb,
+                                _ptr(mq), _ptr(mka), _ptr(mkb), _ptr(O), ldo, _ptr(lse), float(drop_p), int(seed),
+                                int(site), _stream()), "segmm_attn_fwd")
+
+
+def attn_bwd(B, H, dh, Lq, La, Lb, Qa, Qb, ldq, Ka, Va, ldka, Kb, Vb, ldkb, mq, mka, mkb, lse, dO, lddo, Dvec,
+             dQa, dQb, lddq, dKa, dVa, lddka, dKb, dVb, lddkb, drop_p=0.0, seed=0, site=0):
+    def P(x):
+        return x[0].data_ptr() + 4 * x[1]
+    _check(lib().segmm_attn_bwd(B, H, dh, Lq, La, Lb, P(Qa), P(Qb), ldq, P(Ka), P(Va), ldka, P(Kb), P(Vb), ldkb,
+                                _ptr(mq), _ptr(mka), _ptr(mkb), _ptr(lse), _ptr(dO), lddo, _ptr(Dvec), P(dQa),
+                                P(dQb), lddq, P(dKa), P(dVa), lddka, P(dKb), P(dVb), lddkb, float(drop_p), int(seed),
+                                int(site), _stream()), "segmm_attn_bwd")
+
+
+def rowdot(x, ld, w, bias, out, rows, d, accumulate=False, x_off=0, w_off=0):
+    _check(lib().segmm_rowdot(x.data_ptr() + 4 * x_off, ld, w.data_ptr() + 4 * w_off, _ptr(bias), _ptr(out), rows, d,
+                              int(bool(accumulate)), _stream()), "segmm_rowdot")
+
+
+def rowscale_bcast(g, w, dx, ld, rows, d, accumulate=False, w_off=0, dx_off=0):
+    _check(lib().segmm_rowscale_bcast(_ptr(g), w.data_ptr() + 4 * w_off, dx.data_ptr() + 4 * dx_off, ld, rows, d,
+                                      int(bool(accumulate)), _stream()), "segmm_rowscale_bcast")
+
+
+def vecsum(v, n, out, accumulate=False):
+    _check(lib().segmm_vecsum(_ptr(v), n, _ptr(out), int(bool(accumulate)), _stream()), "segmm_vecsum")
+
+
+def embed_id_vid(item_id, table, dhalf, frame_w, frame_b, pe, out, B, S):
+    _check(lib().segmm_embed_id_vid(_ptr(item_id), _ptr(table), dhalf, _ptr(frame_w), _ptr(frame_b), _ptr(pe),
+                                    _ptr(out), B, S, _stream()), "segmm_embed_id_vid")
+
+
+def embed_id_usr(user_id, table, d, pe, out, B):
+    _check(lib().segmm_embed_id_usr(_ptr(user_id), _ptr(table), d, _ptr(pe), _ptr(out), B, _stream()),
+           "segmm_embed_id_usr")
+
+
+def embed_id_bwd(dpre, tokens_per_row, ld, col0, width, order, seg_start, ids, dtable, n_unique):
+    _check(lib().segmm_embed_id_bwd(_ptr(dpre), tokens_per_row, ld, col0, width, _ptr(order), _ptr(seg_start),
+                                    _ptr(ids), _ptr(dtable), n_unique, _stream()), "segmm_embed_id_bwd")
+
+
+def pe_grad(dpre, ld, B, S, d, dpe, accumulate=False):
+    _check(lib().segmm_pe_grad(_ptr(dpre), ld, B, S, d, _ptr(dpe), int(bool(accumulate)), _stream()), "segmm_pe_grad")
+
+
+def loss_fwd_bwd(B, S, logits, gt, bias_w, bias_b, exposure, coef, enabled, rew_ce, rew_kl, rew_mse2, use_mask,
+                 n_valid_bpr, B_global, mask_sum_global, v_all, v2_all, Bg, logits_out, dlogits, parts):
+    coef_a = (C.c_float * 9)(*[float(c) for c in coef])
+    en_a = (C.c_int * 9)(*[int(e) for e in enabled])
+    _check(lib().segmm_loss_fwd_bwd(B, S, _ptr(logits), _ptr(gt), _ptr(bias_w), _ptr(bias_b), _ptr(exposure),
+                                    C.cast(coef_a, C.c_void_p), C.cast(en_a, C.c_void_p), int(rew_ce), int(rew_kl),
+                                    int(rew_mse2), int(use_mask), float(n_valid_bpr), float(B_global),
+                                    float(mask_sum_global), _ptr(v_all), _ptr(v2_all), Bg, _ptr(logits_out),
+                                    _ptr(dlogits), _ptr(parts), _stream()), "segmm_loss_fwd_bwd")
+
+
+def adamw(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, p_off=0):
+    _check(lib().segmm_adamw(p.data_ptr() + 4 * p_off, g.data_ptr() + 4 * p_off, m.data_ptr() + 4 * p_off,
+                             v.data_ptr() + 4 * p_off, n, lr, beta1, beta2, eps, weight_decay, step, _stream()),
+           "segmm_adamw")
+
+
+def dropout_mult(out, n, p, seed, site):
+    _check(lib().segmm_dropout_mult(_ptr(out), n, float(p), int(seed), int(site), _stream()), "segmm_dropout_mult")

@@ -1,0 +1,380 @@
+"""Kernel-level parity on the MI355X: every C-ABI op against a torch reference of the same op
+(fp64 where the comparison needs head-room).  Run with ``pytest -m gpu``."""
+import math
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _abi():
+    from segmminterest_amd import hipabi
+    hipabi.lib()
+    return hipabi
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+# ------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (360, 96, 48), (63, 32, 40), (1000, 768, 768), (20480, 768, 768), (7, 4, 4)])
+def test_gemm_nt_bias(M, N, K):
+    H = _abi()
+    A, W, b = _rand(M, K, seed=1), _rand(N, K, seed=2), _rand(N, seed=3)
+    C = torch.empty(M, N, device=DEV)
+    H.gemm(H.LAYOUT_NT, M, N, K, A, K, W, K, C, N, bias=b)
+    ref = (A.double() @ W.double().t() + b.double())
+    err = (C.double() - ref).abs().max().item()
+    assert err < 1e-5 * math.sqrt(K) * 4, err
+
+
+def test_gemm_asymmetric_identity():
+    """A = I with an asymmetric B catches a transposed C/D register map (guide §3)."""
+    H = _abi()
+    n = 128
+    A = torch.eye(n, device=DEV)
+    Bm = (torch.arange(n * n, device=DEV, dtype=torch.float32).view(n, n) % 97) + torch.arange(n, device=DEV)[:, None] * 0.5
+    C = torch.empty(n, n, device=DEV)
+    H.gemm(H.LAYOUT_NN, n, n, n, A, n, Bm, n, C, n)
+    assert torch.equal(C, Bm)
+    H.gemm(H.LAYOUT_NT, n, n, n, A, n, Bm, n, C, n)
+    assert torch.equal(C, Bm.t())
+    H.gemm(H.LAYOUT_TN, n, n, n, Bm, n, A, n, C, n)      # C = Bm^T . I
+    assert torch.equal(C, Bm.t())
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (360, 48, 96), (20480, 768, 3072)])
+def test_gemm_nn(M, N, K):
+    H = _abi()
+    A, Bm = _rand(M, K, seed=4), _rand(K, N, seed=5)
+    C = torch.empty(M, N, device=DEV)
+    H.gemm(H.LAYOUT_NN, M, N, K, A, K, Bm, N, C, N)
+    ref = A.double() @ Bm.double()
+    assert (C.double() - ref).abs().max().item() < 1e-5 * math.sqrt(K) * 4
+
+
+@pytest.mark.parametrize("M,N,K,splits", [(128, 128, 256, 1), (96, 48, 360, 1), (768, 768, 20480, 16), (32, 40, 63, 2), (3072, 768, 5120, 8)])
+def test_gemm_tn_wgrad_splitk(M, N, K, splits):
+    H = _abi()
+    A, Bm = _rand(K, M, seed=6), _rand(K, N, seed=7)
+    C = torch.empty(M, N, device=DEV)
+    ws = torch.empty(max(splits, 1) * M * N, device=DEV)
+    H.gemm(H.LAYOUT_TN, M, N, K, A, M, Bm, N, C, N, splits=splits, workspace=ws)
+    ref = A.double().t() @ Bm.double()
+    assert (C.double() - ref).abs().max().item() < 1e-5 * math.sqrt(K) * 4
+    # accumulate into an existing gradient + run-to-run determinism
+    C2 = C.clone()
+    H.gemm(H.LAYOUT_TN, M, N, K, A, M, Bm, N, C2, N, splits=splits, workspace=ws, accumulate=True)
+    assert (C2.double() - 2 * ref).abs().max().item() < 2e-5 * math.sqrt(K) * 4
+    C3 = torch.empty_like(C)
+    H.gemm(H.LAYOUT_TN, M, N, K, A, M, Bm, N, C3, N, splits=splits, workspace=ws)
+    assert torch.equal(C, C3)
+
+
+def test_gemm_epilogues():
+    H = _abi()
+    M, N, K = 360, 96, 64
+    A, W, b = _rand(M, K, seed=8), _rand(N, K, seed=9, scale=0.3), _rand(N, seed=10)
+    rs = torch.rand(M, device=DEV) + 0.5
+    res = _rand(40, N, seed=11)
+    C = torch.empty(M, N, device=DEV)
+    aux = torch.empty(M, N, device=DEV)
+    # row_scale, bias, GELU (aux = pre-activation), periodic residual
+    H.gemm(H.LAYOUT_NT, M, N, K, A, K, W, K, C, N, bias=b, row_scale=rs, residual=res, ldr=N, res_period=40,
+           activation=H.ACT_GELU, aux=aux, ldaux=N)
+    pre = (A.double() @ W.double().t()) * rs.double()[:, None] + b.double()
+    ref = torch.nn.functional.gelu(pre) + res.double().repeat(M // 40, 1)
+    assert (aux.double() - pre).abs().max().item() < 1e-5
+    assert (C.double() - ref).abs().max().item() < 1e-5
+    # dGELU epilogue: C = (A.W^T) * gelu'(aux)
+    H.gemm(H.LAYOUT_NT, M, N, K, A, K, W, K, C, N, activation=H.ACT_DGELU, aux=aux, ldaux=N)
+    x = pre.clone().requires_grad_(True)
+    torch.nn.functional.gelu(x).sum().backward()
+    ref = (A.double() @ W.double().t()) * x.grad
+    assert (C.double() - ref).abs().max().item() < 1e-5
+    # residual aliasing the output (accumulate)
+    C0 = _rand(M, N, seed=12)
+    C = C0.clone()
+    H.gemm(H.LAYOUT_NT, M, N, K, A, K, W, K, C, N, accumulate=True)
+    assert (C.double() - (C0.double() + A.double() @ W.double().t())).abs().max().item() < 1e-5
+
+
+def test_gemm_strided_views():
+    """Column slices of a fused projection buffer: lda/ldc larger than the logical width."""
+    H = _abi()
+    M, d = 200, 32
+    X = _rand(M, d, seed=13)
+    Wcat = _rand(4 * d, d, seed=14)
+    Y = torch.zeros(M, 4 * d, device=DEV)
+    H.gemm(H.LAYOUT_NT, M, 4 * d, d, X, d, Wcat, d, Y, 4 * d)
+    assert (Y.double() - X.double() @ Wcat.double().t()).abs().max().item() < 1e-5
+    # dgrad from the slice [:, d:2d] only
+    dX = torch.empty(M, d, device=DEV)
+    H.gemm(H.LAYOUT_NN, M, d, d, Y, 4 * d, Wcat, d, dX, d, a_off=d, b_off=d * d)
+    ref = Y[:, d:2 * d].double() @ Wcat[d:2 * d].double()
+    assert (dX.double() - ref).abs().max().item() < 1e-4
+
+
+def test_gemm_dropout_epilogue_matches_mask_hook():
+    H = _abi()
+    M, N, K, p = 256, 64, 32, 0.25
+    A, W = _rand(M, K, seed=15), _rand(N, K, seed=16)
+    C = torch.empty(M, N, device=DEV)
+    H.gemm(H.LAYOUT_NT, M, N, K, A, K, W, K, C, N, drop_p=p, seed=77, site=5)
+    mult = torch.empty(M * N, device=DEV)
+    H.dropout_mult(mult, M * N, p, 77, 5)
+    ref = (A.double() @ W.double().t()) * mult.view(M, N).double()
+    assert (C.double() - ref).abs().max().item() < 1e-5
+    keep = (mult > 0).float().mean().item()
+    assert abs(keep - (1 - p)) < 0.02
+    assert torch.allclose(mult[mult > 0], torch.tensor(1 / (1 - p), device=DEV))
+    mult2 = torch.empty(M * N, device=DEV)
+    H.dropout_mult(mult2, M * N, p, 77, 6)
+    assert not torch.equal(mult, mult2)
+
+
+def test_gemm_rejects_bad_shapes():
+    H = _abi()
+    A = torch.zeros(8, 6, device=DEV)
+    with pytest.raises(RuntimeError):
+        H.gemm(H.LAYOUT_NT, 8, 8, 6, A, 6, A, 6, torch.zeros(8, 8, device=DEV), 8)
+
+
+# ------------------------------------------------------------------ row kernels
+@pytest.mark.parametrize("rows,D", [(37, 48), (20480, 768), (5, 1024)])
+def test_l1norm(rows, D):
+    H = _abi()
+    x = torch.rand(rows, D, device=DEV)
+    x[0] = 0
+    y = torch.empty_like(x)
+    inv = torch.empty(rows, device=DEV)
+    H.l1norm(x, y, inv)
+    ref = x / (x.norm(p=1, dim=-1, keepdim=True) + 1e-6)
+    assert torch.allclose(y, ref, rtol=2e-6, atol=1e-9)
+    assert torch.allclose(inv, 1 / (x.abs().sum(-1) + 1e-6), rtol=2e-6)
+
+
+@pytest.mark.parametrize("rows,d", [(77, 32), (20480, 768), (9, 2048)])
+def test_layernorm_fwd_bwd(rows, d):
+    H = _abi()
+    x = _rand(rows, d, seed=20) * 2 + 0.3
+    gamma, beta = 1 + 0.1 * _rand(d, seed=21), 0.1 * _rand(d, seed=22)
+    y, mean, rstd = torch.empty_like(x), torch.empty(rows, device=DEV), torch.empty(rows, device=DEV)
+    H.layernorm_fwd(x, gamma, beta, y, mean, rstd)
+    xr = x.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xr, (d,), gr, br, 1e-12)
+    assert (y.double() - ref).abs().max().item() < 5e-6
+    dy = _rand(rows, d, seed=23)
+    ref.backward(dy.double())
+    parts = H.layernorm_bwd_parts(rows)
+    dx = torch.empty_like(x)
+    pg, pb = torch.empty(parts, d, device=DEV), torch.empty(parts, d, device=DEV)
+    H.layernorm_bwd(dy, x, mean, rstd, gamma, dx, None, pg, pb)
+    assert (dx.double() - xr.grad).abs().max().item() < 2e-5
+    ws = torch.empty(H.colsum_chunks(parts) * d, device=DEV)
+    dg, db = torch.empty(d, device=DEV), torch.empty(d, device=DEV)
+    H.colsum(pg, d, parts, d, dg, ws)
+    H.colsum(pb, d, parts, d, db, ws)
+    assert (dg.double() - gr.grad).abs().max().item() < 1e-4 * max(1.0, math.sqrt(rows) / 10)
+    assert (db.double() - br.grad).abs().max().item() < 1e-4 * max(1.0, math.sqrt(rows) / 10)
+
+
+def test_layernorm_dropout_roundtrip():
+    H = _abi()
+    rows, d, p = 64, 128, 0.1
+    x = _rand(rows, d, seed=24)
+    gamma, beta = torch.ones(d, device=DEV), torch.zeros(d, device=DEV)
+    y, mean, rstd = torch.empty_like(x), torch.empty(rows, device=DEV), torch.empty(rows, device=DEV)
+    H.layernorm_fwd(x, gamma, beta, y, mean, rstd, drop_p=p, seed=3, site=9)
+    mult = torch.empty(rows * d, device=DEV)
+    H.dropout_mult(mult, rows * d, p, 3, 9)
+    ref = torch.nn.functional.layer_norm(x, (d,), gamma, beta, 1e-12) * mult.view(rows, d)
+    assert torch.allclose(y, ref, atol=1e-5)
+    # backward: dy masked by the same stream; dx_drop masked by the branch stream
+    dy = _rand(rows, d, seed=25)
+    parts = H.layernorm_bwd_parts(rows)
+    dx, dxd = torch.empty_like(x), torch.empty_like(x)
+    pg, pb = torch.empty(parts, d, device=DEV), torch.empty(parts, d, device=DEV)
+    H.layernorm_bwd(dy, x, mean, rstd, gamma, dx, dxd, pg, pb, drop_y_p=p, drop_y_site=9, drop_b_p=p, drop_b_site=4, seed=3)
+    xr = x.double().requires_grad_(True)
+    (torch.nn.functional.layer_norm(xr, (d,), gamma.double(), beta.double(), 1e-12) * mult.view(rows, d).double() * dy.double()).sum().backward()
+    assert (dx.double() - xr.grad).abs().max().item() < 2e-5
+    mult2 = torch.empty(rows * d, device=DEV)
+    H.dropout_mult(mult2, rows * d, p, 3, 4)
+    assert torch.allclose(dxd, dx * mult2.view(rows, d), atol=1e-6)
+
+
+@pytest.mark.parametrize("M,N", [(20480, 768), (37, 40), (5120, 3072)])
+def test_colsum(M, N):
+    H = _abi()
+    X = _rand(M, N, seed=26)
+    w = _rand(M, seed=27)
+    ws = torch.empty(H.colsum_chunks(M) * N, device=DEV)
+    out = torch.empty(N, device=DEV)
+    H.colsum(X, N, M, N, out, ws)
+    assert (out.double() - X.double().sum(0)).abs().max().item() < 1e-4 * math.sqrt(M)
+    H.colsum(X, N, M, N, out, ws, w=w, accumulate=True)
+    ref = X.double().sum(0) + (X.double() * w.double()[:, None]).sum(0)
+    assert (out.double() - ref).abs().max().item() < 2e-4 * math.sqrt(M)
+
+
+def test_rowdot_head():
+    H = _abi()
+    rows, d = 20480, 768
+    x, w, b = _rand(rows, d, seed=28), _rand(d, seed=29, scale=0.05), _rand(1, seed=30)
+    out = torch.empty(rows, device=DEV)
+    H.rowdot(x, d, w, b, out, rows, d)
+    assert (out.double() - (x.double() @ w.double() + b.double())).abs().max().item() < 1e-4
+    g = _rand(rows, seed=31)
+    dx = torch.empty_like(x)
+    H.rowscale_bcast(g, w, dx, d, rows, d)
+    assert torch.allclose(dx, g[:, None] * w[None, :], rtol=1e-6, atol=1e-7)
+    s = torch.zeros(1, device=DEV)
+    H.vecsum(g, rows, s)
+    assert abs(s.item() - g.double().sum().item()) < 1e-2
+
+
+# ------------------------------------------------------------------ attention
+def _attn_ref(Qa, Qb, Ka, Va, Kb, Vb, mq, mka, mkb, H_, mult=None):
+    """fp64 torch restatement of encoder.py:44-73,138-161 for one side."""
+    B, Lq, d = Qa.shape
+    dh = d // H_
+    sp = lambda t: t.view(B, t.shape[1], H_, dh)
+    la = torch.einsum("bqhd,bkhd->bhqk", sp(Qa), sp(Ka))
+    lb = torch.einsum("bqhd,bkhd->bhqk", sp(Qb), sp(Kb))
+    la = torch.where((mq[:, :, None] & mka[:, None, :])[:, None], la, torch.full_like(la, -10000.0))
+    lb = torch.where((mq[:, :, None] & mkb[:, None, :])[:, None], lb, torch.full_like(lb, -10000.0))
+    lg = torch.cat([la, lb], -1)
+    if mult is not None:
+        lg = lg * mult
+    lg = lg / math.sqrt(dh)
+    P = lg.softmax(-1)
+    V = torch.cat([sp(Va), sp(Vb)], 1)
+    return torch.einsum("bhqk,bkhd->bqhd", P, V).reshape(B, Lq, d)
+
+
+@pytest.mark.parametrize("B,H_,dh,Lq,La,Lb", [(3, 4, 8, 40, 40, 10), (2, 16, 4, 40, 40, 100), (2, 2, 48, 40, 40, 100),
+                                              (2, 4, 8, 7, 40, 7), (2, 16, 48, 100, 40, 100), (3, 4, 8, 1, 40, 1),
+                                              (2, 2, 32, 20, 20, 10), (1, 2, 64, 40, 40, 10), (2, 2, 16, 40, 40, 10)])
+def test_attention_fwd_bwd(B, H_, dh, Lq, La, Lb):
+    H = _abi()
+    d = H_ * dh
+    g = torch.Generator().manual_seed(B * 1000 + Lq)
+    mk = lambda L: (torch.randn(B, L, d, generator=g) * 0.7).to(DEV)
+    Qa, Qb, Ka, Va, Kb, Vb = mk(Lq), mk(Lq), mk(La), mk(La), mk(Lb), mk(Lb)
+    mq = (torch.rand(B, Lq, generator=g) < 0.8).to(DEV)
+    mka = (torch.rand(B, La, generator=g) < 0.8).to(DEV)
+    mkb = (torch.rand(B, Lb, generator=g) < 0.7).to(DEV)
+    mq[0, 0] = False
+    mq[-1, -1] = True
+    O = torch.empty(B * Lq, d, device=DEV)
+    lse = torch.empty(B, H_, Lq, device=DEV)
+    z = lambda t: (t, 0)
+    H.attn_fwd(B, H_, dh, Lq, La, Lb, z(Qa), z(Qb), d, z(Ka), z(Va), d, z(Kb), z(Vb), d, mq, mka, mkb, O, d, lse)
+    leaves = [t.double().requires_grad_(True) for t in (Qa, Qb, Ka, Va, Kb, Vb)]
+    ref = _attn_ref(*leaves, mq, mka, mkb, H_)
+    assert (O.view(B, Lq, d).double() - ref).abs().max().item() < 2e-5
+    dO = (torch.randn(B * Lq, d, generator=g)).to(DEV)
+    ref.backward(dO.view(B, Lq, d).double())
+    Dv = torch.empty(B, H_, Lq, device=DEV)
+    outs = [torch.full_like(t, float("nan")) for t in (Qa, Qb, Ka, Va, Kb, Vb)]
+    H.attn_bwd(B, H_, dh, Lq, La, Lb, z(Qa), z(Qb), d, z(Ka), z(Va), d, z(Kb), z(Vb), d, mq, mka, mkb, lse, dO, d, Dv,
+               z(outs[0]), z(outs[1]), d, z(outs[2]), z(outs[3]), d, z(outs[4]), z(outs[5]), d)
+    for name, got, leaf in zip(("dQa", "dQb", "dKa", "dVa", "dKb", "dVb"), outs, leaves):
+        err = (got.double() - leaf.grad).abs().max().item()
+        assert err < 5e-5, (name, err)
+
+
+def test_attention_dropout_consistency():
+    """Train-mode logits dropout: forward equals the reference with the kernel's own mask; the
+    backward regenerates the same mask (checked against autograd through that mask)."""
+    H = _abi()
+    B, H_, dh, Lq, La, Lb, p = 2, 4, 8, 40, 40, 10, 0.1
+    d = H_ * dh
+    g = torch.Generator().manual_seed(5)
+    mk = lambda L: (torch.randn(B, L, d, generator=g) * 0.7).to(DEV)
+    Qa, Qb, Ka, Va, Kb, Vb = mk(Lq), mk(Lq), mk(La), mk(La), mk(Lb), mk(Lb)
+    mq = torch.ones(B, Lq, dtype=torch.bool, device=DEV)
+    mka = (torch.rand(B, La, generator=g) < 0.8).to(DEV)
+    mkb = torch.ones(B, Lb, dtype=torch.bool, device=DEV)
+    O = torch.empty(B * Lq, d, device=DEV)
+    lse = torch.empty(B, H_, Lq, device=DEV)
+    z = lambda t: (t, 0)
+    H.attn_fwd(B, H_, dh, Lq, La, Lb, z(Qa), z(Qb), d, z(Ka), z(Va), d, z(Kb), z(Vb), d, mq, mka, mkb, O, d, lse,
+               drop_p=p, seed=11, site=3)
+    La_p, Lb_p = (La + 15) // 16 * 16, (Lb + 15) // 16 * 16
+    Tp = La_p + Lb_p
+    mult = torch.empty(B * H_ * Lq * Tp, device=DEV)
+    H.dropout_mult(mult, mult.numel(), p, 11, 3)
+    mult = mult.view(B, H_, Lq, Tp)
+    mult = torch.cat([mult[..., :La], mult[..., La_p:La_p + Lb]], -1).double()
+    leaves = [t.double().requires_grad_(True) for t in (Qa, Qb, Ka, Va, Kb, Vb)]
+    ref = _attn_ref(*leaves, mq, mka, mkb, H_, mult=mult)
+    assert (O.view(B, Lq, d).double() - ref).abs().max().item() < 2e-5
+    dO = torch.randn(B * Lq, d, generator=g).to(DEV)
+    ref.backward(dO.view(B, Lq, d).double())
+    Dv = torch.empty(B, H_, Lq, device=DEV)
+    outs = [torch.empty_like(t) for t in (Qa, Qb, Ka, Va, Kb, Vb)]
+    H.attn_bwd(B, H_, dh, Lq, La, Lb, z(Qa), z(Qb), d, z(Ka), z(Va), d, z(Kb), z(Vb), d, mq, mka, mkb, lse, dO, d, Dv,
+               z(outs[0]), z(outs[1]), d, z(outs[2]), z(outs[3]), d, z(outs[4]), z(outs[5]), d, drop_p=p, seed=11, site=3)
+    for got, leaf in zip(outs, leaves):
+        assert (got.double() - leaf.grad).abs().max().item() < 5e-5
+
+
+# ------------------------------------------------------------------ optimiser
+def test_adamw_matches_torch():
+    H = _abi()
+    n = 100003
+    p0 = _rand(n, seed=40)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([ref], lr=1e-3, weight_decay=1e-4)
+    p = p0.clone()
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for step in range(1, 4):
+        gr = _rand(n, seed=40 + step) * (0.1 if step == 2 else 1.0)
+        ref.grad = gr.clone()
+        opt.step()
+        H.adamw(p, gr, m, v, n, 1e-3, 0.9, 0.999, 1e-8, 1e-4, step)
+    assert torch.allclose(p, ref.detach(), rtol=1e-6, atol=1e-7)
+
+
+# ------------------------------------------------------------------ id embedding
+def test_embed_id():
+    H = _abi()
+    B, S, d, n_items, n_users = 6, 40, 32, 50, 20
+    dh = d // 2
+    table, utable = _rand(n_items + 1, dh, seed=50), _rand(n_users + 1, d, seed=51)
+    fw, fb = _rand(dh, seed=52), _rand(dh, seed=53)
+    vpe, upe = _rand(S, d, seed=54), _rand(1, d, seed=55)
+    ids = torch.tensor([3, 7, 3, 50, 1, 7], device=DEV)
+    uids = torch.tensor([1, 2, 1, 20, 5, 5], device=DEV)
+    out = torch.empty(B * S, d, device=DEV)
+    H.embed_id_vid(ids, table, dh, fw, fb, vpe, out, B, S)
+    pos = torch.arange(S, device=DEV, dtype=torch.float32)
+    ref = torch.cat([table[ids][:, None, :].expand(B, S, dh), (pos[:, None] * fw[None] + fb[None])[None].expand(B, S, dh)], -1) + vpe[None]
+    assert torch.allclose(out.view(B, S, d), ref, atol=1e-6)
+    uo = torch.empty(B, d, device=DEV)
+    H.embed_id_usr(uids, utable, d, upe, uo, B)
+    assert torch.allclose(uo, utable[uids] + upe, atol=1e-6)
+    # backward: dense table grads
+    dpre = _rand(B * S, d, seed=56)
+    order = torch.argsort(ids, stable=True).to(torch.int32)
+    uniq, counts = torch.unique_consecutive(ids[order.long()], return_counts=True)
+    seg = torch.zeros(len(uniq) + 1, dtype=torch.int32, device=DEV)
+    seg[1:] = counts.cumsum(0).to(torch.int32)
+    dtab = torch.zeros_like(table)
+    H.embed_id_bwd(dpre, S, d, 0, dh, order, seg, ids, dtab, len(uniq))
+    ref = torch.zeros_like(table)
+    ref.index_add_(0, ids, dpre.view(B, S, d)[:, :, :dh].sum(1))
+    assert torch.allclose(dtab, ref, atol=1e-5)
+    dpe = torch.empty(S, d, device=DEV)
+    H.pe_grad(dpre, d, B, S, d, dpe)
+    assert torch.allclose(dpe, dpre.view(B, S, d).sum(0), atol=1e-5)
