@@ -86,29 +86,40 @@ int segmm_rowdot(const float* x, int ld, const float* w, const float* bias, floa
 int segmm_rowscale_bcast(const float* g, const float* w, float* dx, int ld, int64_t rows, int d, int accumulate,
                          segmm_stream_t stream);
 int segmm_vecsum(const float* v, int64_t n, float* out, int accumulate, segmm_stream_t stream);
+/* bilinear fusion head InteractionAggregation (decoder_leave_focal.py:392-423): out[m] (+)= sum_n a[m,n]*b[m,n] and
+ * out[m,:] (+)= g[m]*X[m,:]; the per-head x_h W_h products run on segmm_gemm. */
+int segmm_rowdot_pair(const float* a, int lda, const float* b, int ldb, float* out, int64_t rows, int d,
+                      int accumulate, segmm_stream_t stream);
+int segmm_rowscale_mat(const float* g, const float* X, int ldx, float* out, int ldo, int64_t rows, int d,
+                       int accumulate, segmm_stream_t stream);
 
 /* K2' -- id-mode embeddings (encoder.py:426-435,445,484-486), pre-LayerNorm:
  *   vid[b,s,:] = cat(item_table[item_id[b]], frame_w*s + frame_b) + vid_pe[s];   usr[b,0,:] = user_table[uid[b]] + usr_pe[0]
  * backward: dense table gradients accumulated deterministically over batch rows grouped by id
- * (order/seg_start from a host-side sort), and dpe[s,:] = sum_b dpre[b,s,:]. */
+ * (order = batch rows sorted by id, from a host-side torch.sort; no data-dependent sizes, no sync),
+ * and dpe[s,:] = sum_b dpre[b,s,:]. */
 int segmm_embed_id_vid(const int64_t* item_id, const float* table, int dhalf, const float* frame_w,
                        const float* frame_b, const float* pe, float* out, int B, int S, segmm_stream_t stream);
 int segmm_embed_id_usr(const int64_t* user_id, const float* table, int d, const float* pe, float* out, int B,
                        segmm_stream_t stream);
 int segmm_embed_id_bwd(const float* dpre, int tokens_per_row, int ld, int col0, int width, const int32_t* order,
-                       const int32_t* seg_start, const int64_t* ids, float* dtable, int n_unique,
-                       segmm_stream_t stream);
+                       const int64_t* ids, float* dtable, int B, segmm_stream_t stream);
 int segmm_pe_grad(const float* dpre, int ld, int B, int S, int d, float* dpe, int accumulate, segmm_stream_t stream);
 
 /* K8 -- compute_loss forward + backward in one launch (decoder_leave_focal.py:490-572).
  * part order: 0 interestBPR 1 focal 2 surviveCE 3 interestCE 4 interestKL 5 huber 6 hazard 7 mse 8 mse2.
- * coef/enabled are host arrays of 9; parts: [B, 9] per-row contributions already divided by the GLOBAL
- * normalisers, so a column sum (segmm_colsum) over rows -- and over data-parallel ranks -- gives each loss. */
+ * coef/enabled are host arrays of 9; parts: [B, 12] (row stride 12, columns 9..11 zero) per-row contributions already divided by the GLOBAL
+ * normalisers, so a column sum (segmm_colsum) over rows -- and over data-parallel ranks -- gives each loss.
+ * segmm_label_stats fills v[B] = #(gt==1), v2[B] = #(gt>=0) (after the optional focal rewrite) and the device
+ * array norms[3] = {#rows with v < S, B, #(gt != -2)}; a data-parallel trainer all-gathers v/v2 and sums norms
+ * over ranks before the loss call, so every rank normalises by the GLOBAL counts without a host sync. */
+int segmm_label_stats(const int64_t* gt, int B, int S, int rewritten, float* v, float* v2, float* norms,
+                      segmm_stream_t stream);
 int segmm_loss_fwd_bwd(int B, int S, const float* logits, const int64_t* gt, const float* bias_w,
                        const float* bias_b, const float* exposure, const float* coef, const int* enabled,
-                       int rewritten_ce, int rewritten_kl, int rewritten_mse2, int use_mask, float n_valid_bpr,
-                       float B_global, float mask_sum_global, const float* v_all, const float* v2_all, int Bg,
-                       float* logits_out, float* dlogits, float* parts, segmm_stream_t stream);
+                       int rewritten_ce, int rewritten_kl, int use_mask, const float* norms, const float* v_all,
+                       const float* v2_all, int Bg, float* logits_out, float* dlogits, float* parts,
+                       segmm_stream_t stream);
 
 /* K9 -- fused AdamW over one flat fp32 range (torch.optim.AdamW semantics; main_for_seq_leave_earlystop_SegMM.py:226,299) */
 int segmm_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,

@@ -174,7 +174,7 @@ def focal_elementwise(logits, targets, exposure, alpha=0.5, gamma=2.0):
     return alpha_t * loss
 
 
-def interest_bpr_all(logits, view_len, S):
+def interest_bpr_all(logits, view_len, S, n_valid_global=None):
     """compute_interest_BPR_all (decoder_leave_focal.py:163-221), 40 generalised to S: rows with
     view_len < S; positive = logit at index view_len; negatives = the other S-1 positions (padding
     included); w = softmax(neg); loss = -mean log clamp(sum sigmoid(neg-pos)*w, 1e-8, 1-1e-8)."""
@@ -188,37 +188,40 @@ def interest_bpr_all(logits, view_len, S):
     neg = z[neg_mask].view(n, S - 1)
     w = (neg - neg.max()).softmax(dim=1)
     soft = (neg - pos[:, None]).sigmoid() * w
-    return -(soft.sum(1)).clamp(min=1e-8, max=1 - 1e-8).log().mean()
+    row = -(soft.sum(1)).clamp(min=1e-8, max=1 - 1e-8).log()
+    return row.mean() if n_valid_global is None else row.sum() / n_valid_global
 
 
-def leave_prob_ce(h_t, y, mask):
+def leave_prob_ce(h_t, y, mask, mask_sum_global=None):
     """compute_leave_prob_CE (decoder_leave_focal.py:68-97): BCE-with-logits on exp(h_t), masked mean."""
     ce = F.binary_cross_entropy_with_logits(torch.exp(h_t), y, reduction="none")
-    return (ce * mask).sum() / mask.sum()
+    return (ce * mask).sum() / (mask.sum() if mask_sum_global is None else mask_sum_global)
 
 
-def interest_leave_ce(logits, gt, mask, kind, use_mask):
+def interest_leave_ce(logits, gt, mask, kind, use_mask, B_global=None):
     """compute_interest_leave_CE (decoder_leave_focal.py:99-161)."""
     ng = (gt != 0).to(logits.dtype).softmax(dim=1)
     ni = logits.softmax(dim=1)
+    Bn = logits.shape[0] if B_global is None else B_global
     if kind == "CE":
         if use_mask:
-            return (-(mask * ng * ni.log()).sum(1) / mask.sum(1)).mean()
-        return -(ng * ni.log()).sum(1).mean()
+            return (-(mask * ng * ni.log()).sum(1) / mask.sum(1)).sum() / Bn
+        return -(ng * ni.log()).sum(1).sum() / Bn
     if use_mask:
         kl = F.kl_div(ni.log(), ng, reduction="none") * mask
-        return (kl.sum(1) / mask.sum(1)).mean()
-    return F.kl_div(ni.log(), ng, reduction="batchmean")
+        return (kl.sum(1) / mask.sum(1)).sum() / Bn
+    return F.kl_div(ni.log(), ng, reduction="sum") / Bn
 
 
-def huber(pred, true, delta=1.0):
+def huber(pred, true, delta=1.0, B_global=None):
     """huber_loss (decoder_leave_focal.py:61-66).  NB the call site passes [B] vs [B,1]
     (decoder_leave_focal.py:540) so the error broadcasts to [B,B]."""
     err = pred - true
-    return torch.where(err.abs() < delta, 0.5 * err ** 2, delta * (err.abs() - 0.5 * delta)).mean()
+    h = torch.where(err.abs() < delta, 0.5 * err ** 2, delta * (err.abs() - 0.5 * delta))
+    return h.mean() if B_global is None else h.sum() / (B_global * B_global)
 
 
-def partial_likelihood(hazard, view_len, S):
+def partial_likelihood(hazard, view_len, S, B_global=None):
     """compute_partial_likelihood_loss (decoder_leave_focal.py:273-286), 40 generalised to S."""
     n = view_len.shape[0]
     ll = hazard.new_zeros(())
@@ -227,14 +230,20 @@ def partial_likelihood(hazard, view_len, S):
         if t == S:
             continue
         ll = ll + torch.log(hazard[i, t] + 1e-6) - torch.log(hazard[i, t:].sum() + 1e-6)
-    return -ll / n
+    return -ll / (n if B_global is None else B_global)
 
 
-def compute_loss(logits_raw, gt, cfg, sd=None):
+def compute_loss(logits_raw, gt, cfg, sd=None, global_stats=None):
     """MultiScaleTemporalDetrLeaveFocal.compute_loss (decoder_leave_focal.py:490-572).
     ``gt`` is modified in place by 'focal' exactly like the reference (lines 534-535), which later
-    losses in ``loss_type_list`` and the returned 'gt' observe."""
+    losses in ``loss_type_list`` and the returned 'gt' observe.
+
+    ``global_stats`` (test hook for the data-parallel claim of SURVEY.md §8(e)) = dict(v_all, v2_all,
+    norms=[rows with view_len<S, rows, mask count]) of the GLOBAL batch: the rows passed in are then one
+    shard, every mean becomes sum/global-count, and the shard losses add up to the full-batch loss."""
     B, S = gt.shape
+    gs = global_stats
+    Bg = None if gs is None else float(gs["norms"][1])
     dt = logits_raw.dtype
     mask = gt != -2
     logits = logits_raw
@@ -258,25 +267,29 @@ def compute_loss(logits_raw, gt, cfg, sd=None):
             gt[gt > 0] = 1
             gt[gt == -1] = 0
             el = focal_elementwise(logits, gt.to(dt), exposure)
-            out["focal"] = el[mask].sum() / B
+            out["focal"] = el[mask].sum() / (B if gs is None else Bg)
         elif name == "huber":
-            out["huber"] = huber(hazard_m.sum(1), view_len_f)
+            out["huber"] = huber(hazard_m.sum(1), view_len_f if gs is None else gs["v_all"].to(dt)[:, None], B_global=Bg)
         elif name == "hazard":
-            out["hazard"] = partial_likelihood(hazard_m, view_len, S)
+            out["hazard"] = partial_likelihood(hazard_m, view_len, S, Bg)
         elif name == "surviveCE":
-            out["surviveCE"] = leave_prob_ce(h_t, gt_binary, mask)
+            out["surviveCE"] = leave_prob_ce(h_t, gt_binary, mask, None if gs is None else float(gs["norms"][2]))
         elif name == "interestBPR":
-            out["interestBPR"] = interest_bpr_all(logits, view_len, S)
+            out["interestBPR"] = interest_bpr_all(logits, view_len, S, None if gs is None else float(gs["norms"][0]))
         elif name == "interestCE":
-            out["interestCE"] = interest_leave_ce(logits, gt, mask, "CE", cfg.get("mask_loss", 0))
+            out["interestCE"] = interest_leave_ce(logits, gt, mask, "CE", cfg.get("mask_loss", 0), Bg)
         elif name == "interestKL":
-            out["interestKL"] = interest_leave_ce(logits, gt, mask, "KL", cfg.get("mask_loss", 0))
+            out["interestKL"] = interest_leave_ce(logits, gt, mask, "KL", cfg.get("mask_loss", 0), Bg)
     # mse / mse2 (lines 552-558): [B] vs [B,1] broadcast -> mean over a [B,B] matrix, logged only
-    out["mse"] = ((survival_m.sum(1)[None, :] - view_len_f) ** 2).mean()
     sm2 = survival_m.clone()
     sm2[torch.arange(B), durations - 1] = 1
     vl2 = (gt >= 0).sum(1, keepdim=True).to(dt)
-    out["mse2"] = ((sm2.sum(1)[None, :] - vl2) ** 2).mean()
+    if gs is None:
+        out["mse"] = ((survival_m.sum(1)[None, :] - view_len_f) ** 2).mean()
+        out["mse2"] = ((sm2.sum(1)[None, :] - vl2) ** 2).mean()
+    else:
+        out["mse"] = ((survival_m.sum(1)[None, :] - gs["v_all"].to(dt)[:, None]) ** 2).sum() / (Bg * Bg)
+        out["mse2"] = ((sm2.sum(1)[None, :] - gs["v2_all"].to(dt)[:, None]) ** 2).sum() / (Bg * Bg)
     total = 0.0
     for name in cfg["loss_type_list"]:
         coef = cfg["loss_weight"]["mse"] if name == "huber" else cfg["loss_weight"][name]   # lines 561-566
@@ -289,7 +302,7 @@ def compute_loss(logits_raw, gt, cfg, sd=None):
 
 # --------------------------------------------------------------------------- whole model
 def model_forward(sd: Dict[str, torch.Tensor], cfg: dict, inp: Dict[str, torch.Tensor], mode="train",
-                  skip_dead=True, drop=None):
+                  skip_dead=True, drop=None, global_stats=None):
     """MultiScaleTemporalDetrLeaveFocal.forward (decoder_leave_focal.py:574-658)."""
     N, h, S = cfg["N"], cfg["h"], cfg["S"]
     u_t, p_t = cfg["user"], cfg["photo"]
@@ -321,19 +334,20 @@ def model_forward(sd: Dict[str, torch.Tensor], cfg: dict, inp: Dict[str, torch.T
         else:
             logits = interaction_aggregation(sd, v1, v2, fh)
     if mode in ("train", "test"):
-        return compute_loss(logits, inp["gt"], cfg, sd)
+        return compute_loss(logits, inp["gt"], cfg, sd, global_stats)
     if cfg.get("learnable_bias", 0):
         pos = torch.arange(S, dtype=logits.dtype)
         logits = logits + ((pos + 1) * sd["bias_weight"] + sd["bias_bias"])
     return {"logits": logits, "gt": inp["gt"]}
 
 
-def forward_backward(sd, cfg, inp, dtype=torch.float32, skip_dead=True):
-    """Eval-mode forward + loss.backward(); returns (outputs, {name: grad or None})."""
+def forward_backward(sd, cfg, inp, dtype=torch.float32, skip_dead=True, drop=None):
+    """Forward + loss.backward(); returns (outputs, {name: grad or None}).  ``drop`` = None is the
+    reference's eval mode; a callable (e.g. ``lambda t: F.dropout(t, 0.1)``) is its train mode."""
     params = {k: v.detach().clone().to(dtype if v.is_floating_point() else v.dtype).requires_grad_(v.is_floating_point())
               for k, v in sd.items()}
     inp = {k: (v.to(dtype) if v.is_floating_point() else v.clone()) for k, v in inp.items()}
-    out = model_forward(params, cfg, inp, "train", skip_dead)
+    out = model_forward(params, cfg, inp, "train", skip_dead, drop)
     out["loss"].backward()
     grads = {k: (p.grad if p.requires_grad else None) for k, p in params.items()}
     return out, grads
@@ -355,14 +369,14 @@ def adamw_step(params, grads, m, v, step, lr=1e-3, wd=1e-4, b1=0.9, b2=0.999, ep
         p.addcdiv_(m[k], denom, value=-lr / bc1)
 
 
-def train_steps(sd, cfg, inp, n_steps, dtype=torch.float32, skip_dead=True, lr=1e-3, wd=1e-4):
+def train_steps(sd, cfg, inp, n_steps, dtype=torch.float32, skip_dead=True, lr=1e-3, wd=1e-4, drop=None):
     """n_steps of zero_grad -> forward -> backward -> AdamW on one batch (main...SegMM.py:269-300)."""
     params = {k: v.detach().clone().to(dtype) if v.is_floating_point() else v.clone() for k, v in sd.items()}
     m = {k: torch.zeros_like(p) for k, p in params.items()}
     v = {k: torch.zeros_like(p) for k, p in params.items()}
     losses = []
     for step in range(1, n_steps + 1):
-        out, grads = forward_backward(params, cfg, inp, dtype, skip_dead)
+        out, grads = forward_backward(params, cfg, inp, dtype, skip_dead, drop)
         losses.append(float(out["loss"].detach()))
         with torch.no_grad():
             adamw_step(params, grads, m, v, step, lr, wd)

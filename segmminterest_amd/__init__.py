@@ -1,1 +1,15 @@
-"""MI355X-native segment-interest training path (drop-in for MMinterest/models)."""
+"""segmminterest_amd -- MI355X-native drop-in for the ``MMinterest/models`` plugin surface.
+
+Mirrors ``MMinterest/models/__init__.py:1-5``: the trainers do
+``from model import MultiScaleTemporalDetrLeaveFocal, SegFormerX, QueryBasedDecoder, main_eval_batch,
+TOP_K_leave, TOP_K_leave_mask`` (main_for_seq_leave_earlystop_SegMM.py:5).
+"""
+from .encoder import (MLP, MLP_Block, SegFormerX, SegFormerXAttention, SegFormerXEncoder,  # noqa: F401
+                      SegFormerXEncoderLayer, SegFormerXFPN, clones)
+from .decoder_leave_focal import InteractionAggregation, MultiScaleTemporalDetrLeaveFocal  # noqa: F401
+from .my_evaluation import TOP_K_leave, TOP_K_leave_mask, draw_hotmap, main_eval_batch  # noqa: F401
+
+
+class QueryBasedDecoder:  # named by the trainers' import line, defined nowhere in the reference
+    def __init__(self, *a, **k):
+        raise NotImplementedError("QueryBasedDecoder does not exist in the reference either (SURVEY.md §8(b))")

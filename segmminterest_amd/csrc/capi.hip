@@ -290,6 +290,26 @@ int segmm_rowscale_bcast(const float* g, const float* w, float* dx, int ld, int6
     return 0;
 }
 
+int segmm_rowdot_pair(const float* a, int lda, const float* b, int ldb, float* out, int64_t rows, int d,
+                      int accumulate, segmm_stream_t stream) {
+    SEGMM_REQUIRE(a && b && out && d % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && aligned16(a) && aligned16(b), "rowdot_pair: pointer/alignment");
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(rowdot_pair_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb, out,
+                       (long long)rows, d, accumulate);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int segmm_rowscale_mat(const float* g, const float* X, int ldx, float* out, int ldo, int64_t rows, int d,
+                       int accumulate, segmm_stream_t stream) {
+    SEGMM_REQUIRE(g && X && out && d % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && aligned16(X) && aligned16(out), "rowscale_mat: pointer/alignment");
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(rowscale_mat_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, g, X, ldx, out, ldo,
+                       (long long)rows, d, accumulate);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 int segmm_vecsum(const float* v, int64_t n, float* out, int accumulate, segmm_stream_t stream) {
     SEGMM_REQUIRE(v && out, "vecsum: null pointer");
     hipLaunchKernelGGL(vecsum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, v, (long long)n, out, accumulate);
@@ -318,13 +338,12 @@ int segmm_embed_id_usr(const int64_t* user_id, const float* table, int d, const 
 }
 
 int segmm_embed_id_bwd(const float* dpre, int tokens_per_row, int ld, int col0, int width, const int32_t* order,
-                       const int32_t* seg_start, const int64_t* ids, float* dtable, int n_unique,
-                       segmm_stream_t stream) {
-    SEGMM_REQUIRE(dpre && order && seg_start && ids && dtable, "embed_id_bwd: null pointer");
+                       const int64_t* ids, float* dtable, int B, segmm_stream_t stream) {
+    SEGMM_REQUIRE(dpre && order && ids && dtable, "embed_id_bwd: null pointer");
     SEGMM_REQUIRE(width % 4 == 0 && ld % 4 == 0 && col0 % 4 == 0 && aligned16(dpre) && aligned16(dtable), "embed_id_bwd: alignment");
-    if (n_unique <= 0) return 0;
-    hipLaunchKernelGGL(embed_id_bwd_kernel, dim3(n_unique), dim3(64), 0, (hipStream_t)stream, dpre, tokens_per_row, tokens_per_row,
-                       ld, col0, width, (const int*)order, (const int*)seg_start, (const long long*)ids, dtable, n_unique);
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(embed_id_bwd_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, dpre, tokens_per_row, ld, col0, width,
+                       (const int*)order, (const long long*)ids, dtable, B);
     LAUNCH_CHECK();
     return 0;
 }
@@ -337,12 +356,20 @@ int segmm_pe_grad(const float* dpre, int ld, int B, int S, int d, float* dpe, in
     return 0;
 }
 
+int segmm_label_stats(const int64_t* gt, int B, int S, int rewritten, float* v, float* v2, float* norms,
+                      segmm_stream_t stream) {
+    SEGMM_REQUIRE(gt && v && v2 && norms && B > 0 && S > 0, "label_stats: bad args");
+    hipLaunchKernelGGL(label_stats_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const long long*)gt, B, S, rewritten, v, v2, norms);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 int segmm_loss_fwd_bwd(int B, int S, const float* logits, const int64_t* gt, const float* bias_w,
                        const float* bias_b, const float* exposure, const float* coef, const int* enabled,
-                       int rewritten_ce, int rewritten_kl, int rewritten_mse2, int use_mask, float n_valid_bpr,
-                       float B_global, float mask_sum_global, const float* v_all, const float* v2_all, int Bg,
-                       float* logits_out, float* dlogits, float* parts, segmm_stream_t stream) {
-    SEGMM_REQUIRE(logits && gt && exposure && coef && enabled && v_all && v2_all && logits_out && parts, "loss: null pointer");
+                       int rewritten_ce, int rewritten_kl, int use_mask, const float* norms, const float* v_all,
+                       const float* v2_all, int Bg, float* logits_out, float* dlogits, float* parts,
+                       segmm_stream_t stream) {
+    SEGMM_REQUIRE(logits && gt && exposure && coef && enabled && norms && v_all && v2_all && logits_out && parts, "loss: null pointer");
     SEGMM_REQUIRE(S >= 1 && S <= 64, "loss: S=%d must be in [1,64]", S);
     SEGMM_REQUIRE((bias_w == nullptr) == (bias_b == nullptr), "loss: bias_w/bias_b must come together");
     if (B <= 0) return 0;
@@ -351,9 +378,8 @@ int segmm_loss_fwd_bwd(int B, int S, const float* logits, const int64_t* gt, con
     a.B = B; a.S = S; a.logits = logits; a.gt = (const long long*)gt; a.bias_w = bias_w; a.bias_b = bias_b;
     a.exposure = exposure;
     for (int k = 0; k < L_NPART; ++k) { a.coef[k] = coef[k]; a.enabled[k] = enabled[k]; }
-    a.gt_rewritten_for_ce = rewritten_ce; a.gt_rewritten_for_kl = rewritten_kl; a.gt_rewritten_for_mse2 = rewritten_mse2;
-    a.use_mask = use_mask; a.n_valid_bpr = n_valid_bpr > 0.f ? n_valid_bpr : 1.f; a.B_global = B_global;
-    a.mask_sum_global = mask_sum_global > 0.f ? mask_sum_global : 1.f;
+    a.gt_rewritten_for_ce = rewritten_ce; a.gt_rewritten_for_kl = rewritten_kl;
+    a.use_mask = use_mask; a.norms = norms;
     a.v_all = v_all; a.v2_all = v2_all; a.Bg = Bg;
     a.logits_out = logits_out; a.dlogits = dlogits; a.parts = parts;
     hipLaunchKernelGGL(loss_fwd_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);

@@ -10,6 +10,7 @@
 namespace segmm {
 
 enum { L_BPR = 0, L_FOCAL, L_SCE, L_ICE, L_IKL, L_HUBER, L_HAZARD, L_MSE, L_MSE2, L_NPART };
+constexpr int L_PSTRIDE = 12;   // row stride of `parts` (padded to a multiple of 4 for the float4 column sum)
 
 struct LossArgs {
     int B, S;                       // local rows, segments (S <= 64)
@@ -24,17 +25,16 @@ struct LossArgs {
     int gt_rewritten_for_kl;
     int gt_rewritten_for_mse2;
     int use_mask;                   // model_cfg.mask_loss
-    // global normalisers
-    float n_valid_bpr;              // rows with view_len < S
-    float B_global;
-    float mask_sum_global;
+    // global normalisers, DEVICE array [3] = {rows with view_len < S, batch rows, sum of (gt != -2)}
+    // (produced by label_stats_kernel, summed over data-parallel ranks by the trainer; no host sync)
+    const float* norms;
     const float* v_all;             // [Bg] view lengths of every row of the global batch (huber / mse broadcast)
     const float* v2_all;            // [Bg] (gt >= 0).sum per row (mse2)
     int Bg;
     // outputs
     float* logits_out;              // [B,S] logits incl. bias
     float* dlogits;                 // [B,S] d(total loss)/d(logits incl. bias); may be null
-    float* parts;                   // [B, L_NPART] per-row, already normalised, contributions
+    float* parts;                   // [B, L_PSTRIDE] per-row, already normalised, contributions (cols >= 9 zero)
 };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -48,7 +48,9 @@ __global__ __launch_bounds__(256) void loss_fwd_bwd_kernel(const LossArgs a) {
     if (row >= a.B) return;
     const int S = a.S;
     const bool in = lane < S;
-    const float Bg = a.B_global;
+    const float n_valid_bpr = fmaxf(a.norms[0], 1.f);
+    const float Bg = a.norms[1];
+    const float mask_sum_global = fmaxf(a.norms[2], 1.f);
     float z = in ? a.logits[(size_t)row * S + lane] : 0.f;
     if (in && a.bias_w) z += (float)(lane + 1) * a.bias_w[lane] + a.bias_b[lane];
     const int gt = in ? (int)a.gt[(size_t)row * S + lane] : -2;
@@ -76,8 +78,8 @@ __global__ __launch_bounds__(256) void loss_fwd_bwd_kernel(const LossArgs a) {
         const float sg = neg ? sigmoidf_(z - pos) : 0.f;
         const float A = wave_sum(sg * w);
         const float Ac = fminf(fmaxf(A, 1e-8f), 1.0f - 1e-8f);
-        part[L_BPR] = -logf(Ac) / a.n_valid_bpr;
-        const float dA = (A >= 1e-8f && A <= 1.0f - 1e-8f) ? -1.0f / (A * a.n_valid_bpr) : 0.f;
+        part[L_BPR] = -logf(Ac) / n_valid_bpr;
+        const float dA = (A >= 1e-8f && A <= 1.0f - 1e-8f) ? -1.0f / (A * n_valid_bpr) : 0.f;
         const float dpos = -wave_sum(w * sg * (1.f - sg));
         float gz = neg ? w * (sg * (1.f - sg) + sg - A) : 0.f;
         if (lane == v) gz = dpos;
@@ -102,8 +104,8 @@ __global__ __launch_bounds__(256) void loss_fwd_bwd_kernel(const LossArgs a) {
     if (a.enabled[L_SCE]) {
         const float y = (gt == 1) ? 1.f : 0.f;
         const float ce = m ? bce_logits(surv, y) : 0.f;
-        part[L_SCE] = wave_sum(ce) / a.mask_sum_global;
-        if (m) qs += a.coef[L_SCE] * (sigmoidf_(surv) - y) / a.mask_sum_global;
+        part[L_SCE] = wave_sum(ce) / mask_sum_global;
+        if (m) qs += a.coef[L_SCE] * (sigmoidf_(surv) - y) / mask_sum_global;
     }
     // ---- interestCE / interestKL (compute_interest_leave_CE :99-161)
     if (a.enabled[L_ICE] || a.enabled[L_IKL]) {
@@ -190,7 +192,36 @@ __global__ __launch_bounds__(256) void loss_fwd_bwd_kernel(const LossArgs a) {
     }
     if (lane == 0) {
 #pragma unroll
-        for (int k = 0; k < L_NPART; ++k) a.parts[(size_t)row * L_NPART + k] = part[k];
+        for (int k = 0; k < L_PSTRIDE; ++k) a.parts[(size_t)row * L_PSTRIDE + k] = k < L_NPART ? part[k] : 0.f;
+    }
+}
+
+// Per-row label statistics (view length v = #(gt==1), v2 = #(gt>=0) on the possibly focal-rewritten
+// labels) and the three cross-row normalisers; one workgroup, deterministic.
+__global__ __launch_bounds__(1024) void label_stats_kernel(const long long* __restrict__ gt, int B, int S, int rewritten,
+                                                           float* __restrict__ v, float* __restrict__ v2,
+                                                           float* __restrict__ norms) {
+    __shared__ float red[2][16];
+    float nvalid = 0.f, msum = 0.f;
+    for (int r = threadIdx.x; r < B; r += blockDim.x) {
+        int c1 = 0, c2 = 0, cm = 0;
+        for (int j = 0; j < S; ++j) {
+            const int g = (int)gt[(size_t)r * S + j];
+            c1 += g == 1;
+            cm += g != -2;
+            c2 += rewritten ? (g != -2) : (g >= 0);
+        }
+        v[r] = (float)c1; v2[r] = (float)c2;
+        nvalid += c1 < S ? 1.f : 0.f;
+        msum += (float)cm;
+    }
+    nvalid = wave_sum(nvalid); msum = wave_sum(msum);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = nvalid; red[1][threadIdx.x >> 6] = msum; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a0 = 0.f, a1 = 0.f;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { a0 += red[0][w]; a1 += red[1][w]; }
+        norms[0] = a0; norms[1] = (float)B; norms[2] = a1;
     }
 }
 

@@ -212,6 +212,34 @@ __global__ __launch_bounds__(256) void rowscale_bcast_kernel(const float* __rest
         *(f32x4*)o = v;
     }
 }
+// out[m] (+)= sum_n a[m,n] * b[m,n]      (bilinear fusion head, decoder_leave_focal.py:417-421)
+__global__ __launch_bounds__(256) void rowdot_pair_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b,
+                                                          int ldb, float* out, long long rows, int d, int accumulate) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float s = 0.f;
+    for (int c = lane * 4; c < d; c += 256) {
+        const f32x4 x = *(const f32x4*)(a + row * lda + c), y = *(const f32x4*)(b + row * ldb + c);
+        s += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+    }
+    s = wave_sum(s);
+    if (lane == 0) out[row] = accumulate ? out[row] + s : s;
+}
+// out[m,:] (+)= g[m] * X[m,:]
+__global__ __launch_bounds__(256) void rowscale_mat_kernel(const float* __restrict__ g, const float* __restrict__ X, int ldx,
+                                                           float* out, int ldo, long long rows, int d, int accumulate) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float gv = g[row];
+    for (int c = lane * 4; c < d; c += 256) {
+        f32x4 v = *(const f32x4*)(X + row * ldx + c) * gv;
+        float* o = out + row * ldo + c;
+        if (accumulate) v += *(const f32x4*)o;
+        *(f32x4*)o = v;
+    }
+}
 // deterministic single-workgroup sum of a vector: out[0] (+)= sum v
 __global__ __launch_bounds__(1024) void vecsum_kernel(const float* __restrict__ v, long long n, float* out, int accumulate) {
     __shared__ float red[16];
@@ -252,22 +280,20 @@ __global__ __launch_bounds__(256) void embed_id_usr_kernel(const long long* __re
     for (int c = threadIdx.x * 4; c < d; c += blockDim.x * 4)
         *(f32x4*)(out + (size_t)b * d + c) = *(const f32x4*)(table + id * d + c) + *(const f32x4*)(pe + c);
 }
-// backward of the gathers: dense table gradients (torch.nn.Embedding semantics), deterministic:
-// one workgroup per batch row b walks ... -> rows with equal ids would race, so the scatter runs over
-// UNIQUE ids: the host passes `order` (batch rows sorted by id) and `seg_start` offsets.
-__global__ __launch_bounds__(256) void embed_id_bwd_kernel(const float* __restrict__ dpre, int row_stride_tokens, int tok_per_row, int ld,
+// backward of the gathers: dense table gradients (torch.nn.Embedding semantics), deterministic and
+// sync-free: `order` = batch rows sorted by id (host-side torch.sort, no size-dependent output).
+// Workgroup k owns sorted position k; it is a segment head iff its id differs from position k-1,
+// and then sums every following row with the same id, in sorted order.
+__global__ __launch_bounds__(256) void embed_id_bwd_kernel(const float* __restrict__ dpre, int tok_per_row, int ld,
                                     int col0, int width, const int* __restrict__ order,
-                                    const int* __restrict__ seg_start, const long long* __restrict__ ids,
-                                    float* __restrict__ dtable, int n_unique) {
-    // dtable[id, :] += sum over batch rows with that id, over their tok_per_row tokens, of dpre[token, col0:col0+width]
-    const int u = blockIdx.x;
-    if (u >= n_unique) return;
-    const int s0 = seg_start[u], s1 = seg_start[u + 1];
-    const long long id = ids[order[s0]];
+                                    const long long* __restrict__ ids, float* __restrict__ dtable, int B) {
+    const int k0 = blockIdx.x;
+    const long long id = ids[order[k0]];
+    if (k0 > 0 && ids[order[k0 - 1]] == id) return;
     for (int c = threadIdx.x * 4; c < width; c += blockDim.x * 4) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int k = s0; k < s1; ++k) {
-            const long long tok0 = (long long)order[k] * row_stride_tokens;
+        for (int k = k0; k < B && ids[order[k]] == id; ++k) {
+            const long long tok0 = (long long)order[k] * tok_per_row;
             for (int t = 0; t < tok_per_row; ++t) acc += *(const f32x4*)(dpre + (tok0 + t) * ld + col0 + c);
         }
         float* o = dtable + id * width + c;

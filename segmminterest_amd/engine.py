@@ -1,0 +1,518 @@
+"""Fused HIP execution of the segment-interest model (host orchestration over the C ABI).
+
+This is the host half of the drop-in: it owns the flat parameter layout, the exact-liveness rule of the
+reference's encoder (layers 0..N-3 both sides, layer N-2 video side only, layer N-1
+dead) and the sequence of kernel launches of the forward and the hand-derived backward.  PyTorch is
+used for memory, streams and the autograd glue (two ``torch.autograd.Function``s: one per backbone, one
+for head+loss); every FLOP of the path runs in ``libsegmm_hip.so``.
+
+Per encoder layer (video side; the user side mirrors it when live), reference file:line in brackets:
+
+    Yv = Xv . [Wq_v2v | Wq_t2v | Wk_v2v | Wv_v2v (| Wk_v2t | Wv_v2t)]^T + b        one fused GEMM  [encoder.py:95-104,50-62]
+    Yu = Xu . [Wk_t2v | Wv_t2v (| Wq_v2t | Wq_t2t | Wk_t2t | Wv_t2t)]^T + b        one fused GEMM
+    Av = attention(Q from Yv, K/V blocks from Yv and Yu, masks, logits dropout)    [encoder.py:64-71,138-156]
+    R1 = Xv + dropout(Av . Wff^T + b) ; X1 = LN(R1)                                GEMM epilogue + LN [:163-171]
+    H  = dropout(gelu(X1 . W0^T + b0)) ; R2 = X1 + dropout(H . W1^T + b1) ; X2 = LN(R2)            [:202-203; mlp.py:17-23]
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import hipabi as H
+
+# dropout site ids (distinct Philox streams): site = backbone*4096 + layer*32 + kind
+K_EMB_V, K_EMB_U, K_ATT_V, K_ATT_U, K_AO_V, K_AO_U, K_MI_V, K_MI_U, K_MO_V, K_MO_U = range(1, 11)
+MLP_INNER_DROPOUT = 0.1      # kn_util MLP default (kn_util/nn_utils/layers/mlp.py:8), never overridden
+
+
+def _site(bb, layer, kind):
+    return bb * 4096 + layer * 32 + kind
+
+
+def _j(prefix, name):
+    return prefix + name
+
+
+# =============================================================================================== parameter store
+def backbone_layout(prefix: str, bb) -> Tuple[List[Tuple[str, List[List[str]]]], None]:
+    """Live parameter groups of one backbone in BACKWARD-completion order, as (bucket, groups).
+    A group is a list of tensors that must be adjacent in memory (a fused GEMM reads them as one)."""
+    N = bb.n_layers
+    buckets = []
+    for i in reversed(range(max(N - 1, 0))):
+        full = i < N - 2
+        L = "%sencoder.layers.%d." % (prefix, i)
+        ca = L + "cross_attn."
+        vidW = [ca + "v2v_proj.0", ca + "t2v_proj.0", ca + "v2v_proj.1", ca + "v2v_proj.2"]
+        usrW = [ca + "t2v_proj.1", ca + "t2v_proj.2"]
+        singles = [ca + "ff_vid", ca + "ln_vid", L + "ff_vid.layers.0", L + "ff_vid.layers.1", L + "ln_vid"]
+        if full:
+            vidW += [ca + "v2t_proj.1", ca + "v2t_proj.2"]
+            usrW += [ca + "v2t_proj.0", ca + "t2t_proj.0", ca + "t2t_proj.1", ca + "t2t_proj.2"]
+            singles += [ca + "ff_usr", ca + "ln_usr", L + "ff_usr.layers.0", L + "ff_usr.layers.1", L + "ln_usr"]
+        groups = [[n + ".weight" for n in vidW], [n + ".bias" for n in vidW],
+                  [n + ".weight" for n in usrW], [n + ".bias" for n in usrW]]
+        for s in singles:
+            groups += [[s + ".weight"], [s + ".bias"]]
+        buckets.append(("%slayer%d" % (prefix, i), groups))
+    emb = [[prefix + "vid_proj.weight"]]
+    if bb.id_vid:
+        emb += [[prefix + "frameid_proj.weight"], [prefix + "frameid_proj.bias"]]
+    else:
+        emb += [[prefix + "vid_proj.bias"]]
+    emb += [[prefix + "vid_pe.weight"], [prefix + "vid_ln.weight"], [prefix + "vid_ln.bias"]]
+    if N >= 2:      # with N == 1 the user embedding only feeds the dead layer
+        emb += [[prefix + "usr_proj.weight"]]
+        if not bb.id_usr:
+            emb += [[prefix + "usr_proj.bias"]]
+        emb += [[prefix + "usr_pe.weight"], [prefix + "usr_ln.weight"], [prefix + "usr_ln.bias"]]
+    buckets.append((prefix + "embed", emb))
+    return buckets
+
+
+class ParamStore:
+    """All parameters of a model re-pointed into ONE flat fp32 buffer: live tensors first (in
+    backward-completion order, bucketed), dead tensors after.  ``nn.Parameter.data`` become views, so
+    ``state_dict`` / ``load_state_dict`` / any torch optimizer keep working, while fused GEMMs read
+    concatenated weights in place and AdamW / the gradient all-reduce see contiguous ranges."""
+
+    def __init__(self, root, standalone_backbone=False):
+        self.root = root
+        self.standalone = standalone_backbone
+        self.flat = None
+        self.gflat = None
+        self.index: Dict[str, Tuple[int, int]] = {}
+        self.buckets: List[Tuple[str, int, int]] = []
+        self.n_live = 0
+        self.live_names: List[str] = []
+        self.scratch: Dict[tuple, torch.Tensor] = {}
+        self._params = None
+        self.bucket_hook = None      # callable(bucket_name): set by the data-parallel trainer
+
+    # -- layout
+    def _layout(self):
+        if self.standalone:
+            return backbone_layout("", self.root)
+        return self.root._param_buckets()
+
+    def ensure(self):
+        params = self._params
+        if params is None:
+            params = self._params = dict(self.root.named_parameters())
+        if self.flat is not None:
+            ok = True
+            base = self.flat.data_ptr()
+            for name, (off, n) in self.index.items():
+                if params[name].data_ptr() != base + 4 * off:
+                    ok = False
+                    break
+            if ok:
+                return
+        self._build(params)
+
+    def _build(self, params):
+        first = next(iter(params.values()))
+        dev = first.device
+        if dev.type != "cuda":
+            raise RuntimeError("segmminterest_amd: the model must be on a HIP device (got %s); there is no CPU path" % dev)
+        for n_, p in params.items():
+            if p.dtype != torch.float32:
+                raise RuntimeError("parameter %s is %s; the path computes in fp32" % (n_, p.dtype))
+        order, buckets, off = [], [], 0
+        seen = set()
+        for bname, groups in self._layout():
+            start = off
+            for grp in groups:
+                off = (off + 3) & ~3
+                for name in grp:
+                    if name not in params:
+                        raise KeyError("layout names unknown parameter %s" % name)
+                    if name in seen:
+                        raise KeyError("parameter %s listed twice" % name)
+                    seen.add(name)
+                    n = params[name].numel()
+                    if len(grp) > 1 and n % 4:
+                        raise RuntimeError("fused group member %s has %d elements (not a multiple of 4)" % (name, n))
+                    order.append((name, off, n))
+                    off += n
+            off = (off + 3) & ~3
+            buckets.append((bname, start, off))
+        n_live = off
+        live_names = [n for n, _, _ in order]
+        for name, p in params.items():
+            if name not in seen:
+                off = (off + 3) & ~3
+                order.append((name, off, p.numel()))
+                off += p.numel()
+        flat = torch.zeros(((off + 3) & ~3,), dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for name, o, n in order:
+                p = params[name]
+                flat[o:o + n].copy_(p.data.reshape(-1))
+                p.data = flat[o:o + n].view(p.shape)
+        self.flat = flat
+        self.gflat = torch.zeros((n_live,), dtype=torch.float32, device=dev)
+        self.index = {name: (o, n) for name, o, n in order}
+        self.buckets = buckets
+        self.n_live = n_live
+        self.live_names = live_names
+        self.scratch = {}
+
+    # -- access
+    def p(self, name) -> torch.Tensor:
+        return self._params[name].data
+
+    def g(self, name, gbuf=None) -> torch.Tensor:
+        o, n = self.index[name]
+        gb = self.gflat if gbuf is None else gbuf
+        return gb[o:o + n].view(self._params[name].shape)
+
+    def buf(self, key, shape, dtype=torch.float32) -> torch.Tensor:
+        """Persistent scratch (single stream => safe to reuse across launches and steps)."""
+        k = (key, tuple(shape), dtype)
+        t = self.scratch.get(k)
+        if t is None:
+            t = self.scratch[k] = torch.empty(shape, dtype=dtype, device=self.flat.device)
+        return t
+
+
+def _empty(ref, *shape, dtype=torch.float32):
+    return torch.empty(shape, dtype=dtype, device=ref.device)
+
+
+def _splits_for(M, N, K):
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    ktiles = (K + 31) // 32
+    return max(1, min(32, ktiles, (1024 + tiles - 1) // tiles))
+
+
+def _wgrad(store, dY, ldy, y_off, X, ldx, x_off, Mrows, n_out, n_in, gW, accumulate=False):
+    """gW[n_out, n_in] (+)= dY[:, y_off:y_off+n_out]^T . X[:, x_off:x_off+n_in]  (split-K over tokens)."""
+    splits = _splits_for(n_out, n_in, Mrows)
+    ws = store.buf("splitk_ws", (max(splits, 1) * n_out * n_in,)) if splits > 1 else None
+    H.gemm(H.LAYOUT_TN, n_out, n_in, Mrows, dY, ldy, X, ldx, gW, n_in, splits=splits, workspace=ws,
+           accumulate=accumulate, a_off=y_off, b_off=x_off)
+
+
+def _colsum(store, X, ld, M, N, out, x_off=0, w=None, accumulate=False):
+    ws = store.buf("colsum_ws", (H.colsum_chunks(M) * N,))
+    H.colsum(X, ld, M, N, out, ws, w=w, accumulate=accumulate, x_off=x_off)
+
+
+def _ln_bwd(store, dy, x, mean, rstd, gname, bname, gbuf, dx, dx_drop, rows, d, drop_y=(0.0, 0), drop_b=(0.0, 0), seed=0):
+    parts = H.layernorm_bwd_parts(rows)
+    pg = store.buf("ln_pg", (parts, d))
+    pb = store.buf("ln_pb", (parts, d))
+    H.layernorm_bwd(dy, x, mean, rstd, store.p(gname), dx, dx_drop, pg, pb, drop_y_p=drop_y[0], drop_y_site=drop_y[1],
+                    drop_b_p=drop_b[0], drop_b_site=drop_b[1], seed=seed)
+    _colsum(store, pg, d, parts, d, store.g(gname, gbuf))
+    _colsum(store, pb, d, parts, d, store.g(bname, gbuf))
+
+
+def _mask_u8(m: torch.Tensor) -> torch.Tensor:
+    m = m.to(torch.bool).contiguous()
+    return m.view(torch.uint8)
+
+
+# =============================================================================================== backbone
+class BackboneRun:
+    """One forward of one backbone; keeps what the backward needs."""
+
+    def __init__(self, store: ParamStore, bb, prefix: str, bb_index: int):
+        self.store, self.bb, self.pre, self.bi = store, bb, prefix, bb_index
+        self.d, self.H, self.N = bb.d_model, bb.nhead, bb.n_layers
+        self.dh = self.d // self.H
+        self.sv = {}
+
+    # ---------------------------------------------------------------- forward
+    def forward(self, usr_feat, usr_mask, vid_feat, vid_mask, train: bool, seed: int):
+        st, bb, P, d = self.store, self.bb, self.pre, self.d
+        p_drop = float(bb.dropout_p) if train else 0.0
+        p_inner = MLP_INNER_DROPOUT if train else 0.0
+        self.p_drop, self.p_inner, self.seed = p_drop, p_inner, seed
+        vm = _mask_u8(vid_mask)
+        B, S = vm.shape
+        if S > bb.max_vid_len:
+            raise RuntimeError("S=%d exceeds max_vid_len=%d" % (S, bb.max_vid_len))
+        if bb.id_usr:
+            if usr_feat.dim() != 1:
+                raise RuntimeError("id-mode user input must be [B] ids (encoder.py:478-481)")
+            Lt = 1
+            um = torch.ones((B, 1), dtype=torch.uint8, device=vm.device)          # encoder.py:481
+        else:
+            if usr_feat.dim() != 3:
+                raise RuntimeError("image-mode user input must be [B,Lt,D]")
+            Lt = usr_feat.shape[1]
+            um = _mask_u8(usr_mask)
+            if Lt > bb.max_usr_len:
+                raise RuntimeError("Lt=%d exceeds max_usr_len=%d" % (Lt, bb.max_usr_len))
+        Mv, Mu = B * S, B * Lt
+        self.B, self.S, self.Lt, self.Mv, self.Mu = B, S, Lt, Mv, Mu
+        self.vm, self.um = vm, um
+        sv = self.sv
+        ref = vm
+        # ---- embedding (encoder.py:425-473)
+        pre_v = _empty(ref, Mv, d)
+        if bb.id_vid:
+            ids = vid_feat.contiguous().to(torch.int64)
+            sv["vid_ids"] = ids
+            H.embed_id_vid(ids, st.p(P + "vid_proj.weight"), d // 2, st.p(P + "frameid_proj.weight"),
+                           st.p(P + "frameid_proj.bias"), st.p(P + "vid_pe.weight"), pre_v, B, S)
+        else:
+            x = vid_feat.contiguous().float()
+            sv["vid_x"] = x
+            Din = x.shape[-1]
+            H.gemm(H.LAYOUT_NT, Mv, d, Din, x, Din, st.p(P + "vid_proj.weight"), Din, pre_v, d,
+                   bias=st.p(P + "vid_proj.bias"), residual=st.p(P + "vid_pe.weight"), ldr=d, res_period=S)
+        Ev, mev, rev = _empty(ref, Mv, d), _empty(ref, Mv), _empty(ref, Mv)
+        H.layernorm_fwd(pre_v, st.p(P + "vid_ln.weight"), st.p(P + "vid_ln.bias"), Ev, mev, rev, drop_p=p_drop, seed=seed,
+                        site=_site(self.bi, 0, K_EMB_V))
+        sv["pre_v"], sv["mev"], sv["rev"] = pre_v, mev, rev
+        pre_u = _empty(ref, Mu, d)
+        if bb.id_usr:
+            uids = usr_feat.contiguous().to(torch.int64)
+            sv["usr_ids"] = uids
+            H.embed_id_usr(uids, st.p(P + "usr_proj.weight"), d, st.p(P + "usr_pe.weight"), pre_u, B)
+        else:
+            xu = usr_feat.contiguous().float()
+            sv["usr_x"] = xu
+            Din = xu.shape[-1]
+            H.gemm(H.LAYOUT_NT, Mu, d, Din, xu, Din, st.p(P + "usr_proj.weight"), Din, pre_u, d,
+                   bias=st.p(P + "usr_proj.bias"), residual=st.p(P + "usr_pe.weight"), ldr=d, res_period=Lt)
+        Eu, meu, reu = _empty(ref, Mu, d), _empty(ref, Mu), _empty(ref, Mu)
+        H.layernorm_fwd(pre_u, st.p(P + "usr_ln.weight"), st.p(P + "usr_ln.bias"), Eu, meu, reu, drop_p=p_drop, seed=seed,
+                        site=_site(self.bi, 0, K_EMB_U))
+        sv["pre_u"], sv["meu"], sv["reu"] = pre_u, meu, reu
+        Xv, Xu = Ev, Eu
+        sv["layers"] = []
+        for i in range(max(self.N - 1, 0)):
+            Xv, Xu = self._layer_fwd(i, Xv, Xu)
+        return Xv.view(B, S, d), Eu.view(B, Lt, d)
+
+    def _side_post(self, i, L, side, X, A, M, kinds):
+        """R1 = X + drop(A.Wff^T+b); X1 = LN(R1); H = drop(gelu(X1.W0^T+b0)); R2 = X1 + drop(H.W1^T+b1); X2 = LN(R2)."""
+        st, d, seed = self.store, self.d, self.seed
+        k_ao, k_mi, k_mo = kinds
+        ca = L + "cross_attn."
+        R1 = _empty(X, M, d)
+        H.gemm(H.LAYOUT_NT, M, d, d, A, d, st.p(ca + "ff_%s.weight" % side), d, R1, d, bias=st.p(ca + "ff_%s.bias" % side),
+               residual=X, ldr=d, res_period=M, drop_p=self.p_drop, seed=seed, site=_site(self.bi, i, k_ao))
+        X1, m1, r1 = _empty(X, M, d), _empty(X, M), _empty(X, M)
+        H.layernorm_fwd(R1, st.p(ca + "ln_%s.weight" % side), st.p(ca + "ln_%s.bias" % side), X1, m1, r1)
+        G, Hh = _empty(X, M, d), _empty(X, M, d)
+        ff = L + "ff_%s.layers." % side
+        H.gemm(H.LAYOUT_NT, M, d, d, X1, d, st.p(ff + "0.weight"), d, Hh, d, bias=st.p(ff + "0.bias"),
+               activation=H.ACT_GELU, aux=G, ldaux=d, drop_p=self.p_inner, seed=seed, site=_site(self.bi, i, k_mi))
+        R2 = _empty(X, M, d)
+        H.gemm(H.LAYOUT_NT, M, d, d, Hh, d, st.p(ff + "1.weight"), d, R2, d, bias=st.p(ff + "1.bias"),
+               residual=X1, ldr=d, res_period=M, drop_p=self.p_drop, seed=seed, site=_site(self.bi, i, k_mo))
+        X2, m2, r2 = _empty(X, M, d), _empty(X, M), _empty(X, M)
+        H.layernorm_fwd(R2, st.p(L + "ln_%s.weight" % side), st.p(L + "ln_%s.bias" % side), X2, m2, r2)
+        return X2, dict(A=A, R1=R1, X1=X1, m1=m1, r1=r1, G=G, Hh=Hh, R2=R2, m2=m2, r2=r2)
+
+    def _layer_fwd(self, i, Xv, Xu):
+        st, d, P = self.store, self.d, self.pre
+        B, S, Lt, Mv, Mu, Hh, dh = self.B, self.S, self.Lt, self.Mv, self.Mu, self.H, self.dh
+        full = i < self.N - 2
+        nv, nu = (6, 6) if full else (4, 2)
+        L = "%sencoder.layers.%d." % (P, i)
+        ca = L + "cross_attn."
+        Yv, Yu = _empty(Xv, Mv, nv * d), _empty(Xv, Mu, nu * d)
+        H.gemm(H.LAYOUT_NT, Mv, nv * d, d, Xv, d, st.p(ca + "v2v_proj.0.weight"), d, Yv, nv * d, bias=st.p(ca + "v2v_proj.0.bias"))
+        H.gemm(H.LAYOUT_NT, Mu, nu * d, d, Xu, d, st.p(ca + "t2v_proj.1.weight"), d, Yu, nu * d, bias=st.p(ca + "t2v_proj.1.bias"))
+        Av, lse_v = _empty(Xv, Mv, d), _empty(Xv, B, Hh, S)
+        H.attn_fwd(B, Hh, dh, S, S, Lt, (Yv, 0), (Yv, d), nv * d, (Yv, 2 * d), (Yv, 3 * d), nv * d, (Yu, 0), (Yu, d), nu * d,
+                   self.vm, self.vm, self.um, Av, d, lse_v, drop_p=self.p_drop, seed=self.seed, site=_site(self.bi, i, K_ATT_V))
+        X2v, sv_v = self._side_post(i, L, "vid", Xv, Av, Mv, (K_AO_V, K_MI_V, K_MO_V))
+        rec = dict(full=full, Xv=Xv, Xu=Xu, Yv=Yv, Yu=Yu, lse_v=lse_v, v=sv_v)
+        X2u = None
+        if full:
+            Au, lse_u = _empty(Xv, Mu, d), _empty(Xv, B, Hh, Lt)
+            H.attn_fwd(B, Hh, dh, Lt, S, Lt, (Yu, 2 * d), (Yu, 3 * d), nu * d, (Yv, 4 * d), (Yv, 5 * d), nv * d,
+                       (Yu, 4 * d), (Yu, 5 * d), nu * d, self.um, self.vm, self.um, Au, d, lse_u, drop_p=self.p_drop,
+                       seed=self.seed, site=_site(self.bi, i, K_ATT_U))
+            X2u, sv_u = self._side_post(i, L, "usr", Xu, Au, Mu, (K_AO_U, K_MI_U, K_MO_U))
+            rec["lse_u"], rec["u"] = lse_u, sv_u
+        self.sv["layers"].append(rec)
+        return X2v, (X2u if full else Xu)
+
+    # ---------------------------------------------------------------- backward
+    def _side_post_bwd(self, i, L, side, sv, dX2, M, kinds, gbuf, tag):
+        """Reverse of _side_post.  Returns (dR1, dA): gradient wrt the residual input X and wrt the attention output."""
+        st, d, seed = self.store, self.d, self.seed
+        k_ao, k_mi, k_mo = kinds
+        ca = L + "cross_attn."
+        ff = L + "ff_%s.layers." % side
+        dR2 = st.buf("dR2" + tag, (M, d))
+        dM = st.buf("dM" + tag, (M, d)) if self.p_drop > 0 else None
+        _ln_bwd(st, dX2, sv["R2"], sv["m2"], sv["r2"], L + "ln_%s.weight" % side, L + "ln_%s.bias" % side, gbuf, dR2, dM, M, d,
+                drop_b=(self.p_drop, _site(self.bi, i, k_mo)), seed=seed)
+        if dM is None:
+            dM = dR2
+        _wgrad(st, dM, d, 0, sv["Hh"], d, 0, M, d, d, st.g(ff + "1.weight", gbuf))
+        _colsum(st, dM, d, M, d, st.g(ff + "1.bias", gbuf))
+        dG = st.buf("dG" + tag, (M, d))
+        H.gemm(H.LAYOUT_NN, M, d, d, dM, d, st.p(ff + "1.weight"), d, dG, d, activation=H.ACT_DGELU, aux=sv["G"], ldaux=d,
+               drop_p=self.p_inner, seed=seed, site=_site(self.bi, i, k_mi))
+        _wgrad(st, dG, d, 0, sv["X1"], d, 0, M, d, d, st.g(ff + "0.weight", gbuf))
+        _colsum(st, dG, d, M, d, st.g(ff + "0.bias", gbuf))
+        dX1 = st.buf("dX1" + tag, (M, d))
+        H.gemm(H.LAYOUT_NN, M, d, d, dG, d, st.p(ff + "0.weight"), d, dX1, d, residual=dR2, ldr=d, res_period=M)
+        dR1 = st.buf("dR1" + tag, (M, d))
+        dZ = st.buf("dZ" + tag, (M, d)) if self.p_drop > 0 else None
+        _ln_bwd(st, dX1, sv["R1"], sv["m1"], sv["r1"], ca + "ln_%s.weight" % side, ca + "ln_%s.bias" % side, gbuf, dR1, dZ, M, d,
+                drop_b=(self.p_drop, _site(self.bi, i, k_ao)), seed=seed)
+        if dZ is None:
+            dZ = dR1
+        _wgrad(st, dZ, d, 0, sv["A"], d, 0, M, d, d, st.g(ca + "ff_%s.weight" % side, gbuf))
+        _colsum(st, dZ, d, M, d, st.g(ca + "ff_%s.bias" % side, gbuf))
+        dA = st.buf("dA" + tag, (M, d))
+        H.gemm(H.LAYOUT_NN, M, d, d, dZ, d, st.p(ca + "ff_%s.weight" % side), d, dA, d)
+        return dR1, dA
+
+    def _layer_bwd(self, i, rec, dXv_out, dXu_out, gbuf):
+        st, d, P = self.store, self.d, self.pre
+        B, S, Lt, Mv, Mu, Hh, dh = self.B, self.S, self.Lt, self.Mv, self.Mu, self.H, self.dh
+        full = rec["full"]
+        nv, nu = (6, 6) if full else (4, 2)
+        L = "%sencoder.layers.%d." % (P, i)
+        ca = L + "cross_attn."
+        Yv, Yu = rec["Yv"], rec["Yu"]
+        dYv, dYu = st.buf("dYv", (Mv, nv * d)), st.buf("dYu", (Mu, nu * d))
+        Dv = st.buf("attnD", (B * Hh * max(S, Lt),))
+        dR1v, dAv = self._side_post_bwd(i, L, "vid", rec["v"], dXv_out, Mv, (K_AO_V, K_MI_V, K_MO_V), gbuf, "v")
+        H.attn_bwd(B, Hh, dh, S, S, Lt, (Yv, 0), (Yv, d), nv * d, (Yv, 2 * d), (Yv, 3 * d), nv * d, (Yu, 0), (Yu, d), nu * d,
+                   self.vm, self.vm, self.um, rec["lse_v"], dAv, d, Dv, (dYv, 0), (dYv, d), nv * d, (dYv, 2 * d), (dYv, 3 * d),
+                   nv * d, (dYu, 0), (dYu, d), nu * d, drop_p=self.p_drop, seed=self.seed, site=_site(self.bi, i, K_ATT_V))
+        dR1u = None
+        if full:
+            dR1u, dAu = self._side_post_bwd(i, L, "usr", rec["u"], dXu_out, Mu, (K_AO_U, K_MI_U, K_MO_U), gbuf, "u")
+            H.attn_bwd(B, Hh, dh, Lt, S, Lt, (Yu, 2 * d), (Yu, 3 * d), nu * d, (Yv, 4 * d), (Yv, 5 * d), nv * d,
+                       (Yu, 4 * d), (Yu, 5 * d), nu * d, self.um, self.vm, self.um, rec["lse_u"], dAu, d, Dv,
+                       (dYu, 2 * d), (dYu, 3 * d), nu * d, (dYv, 4 * d), (dYv, 5 * d), nv * d, (dYu, 4 * d), (dYu, 5 * d), nu * d,
+                       drop_p=self.p_drop, seed=self.seed, site=_site(self.bi, i, K_ATT_U))
+        # fused projection weights / inputs
+        _wgrad(st, dYv, nv * d, 0, rec["Xv"], d, 0, Mv, nv * d, d, _group_view(st, ca + "v2v_proj.0.weight", nv * d * d, gbuf))
+        _colsum(st, dYv, nv * d, Mv, nv * d, _group_view(st, ca + "v2v_proj.0.bias", nv * d, gbuf))
+        _wgrad(st, dYu, nu * d, 0, rec["Xu"], d, 0, Mu, nu * d, d, _group_view(st, ca + "t2v_proj.1.weight", nu * d * d, gbuf))
+        _colsum(st, dYu, nu * d, Mu, nu * d, _group_view(st, ca + "t2v_proj.1.bias", nu * d, gbuf))
+        dXv_in = st.buf("dXv_in%d" % (i & 1), (Mv, d))
+        H.gemm(H.LAYOUT_NN, Mv, d, nv * d, dYv, nv * d, st.p(ca + "v2v_proj.0.weight"), d, dXv_in, d, residual=dR1v, ldr=d, res_period=Mv)
+        dXu_in = st.buf("dXu_in%d" % (i & 1), (Mu, d))
+        if full:
+            H.gemm(H.LAYOUT_NN, Mu, d, nu * d, dYu, nu * d, st.p(ca + "t2v_proj.1.weight"), d, dXu_in, d, residual=dR1u, ldr=d, res_period=Mu)
+        else:
+            H.gemm(H.LAYOUT_NN, Mu, d, nu * d, dYu, nu * d, st.p(ca + "t2v_proj.1.weight"), d, dXu_in, d)
+        return dXv_in, dXu_in
+
+    def backward(self, d_vid_out: torch.Tensor, gbuf: Optional[torch.Tensor] = None, on_bucket=None):
+        """Fills the gradients of every live parameter of this backbone (views of ``gbuf``/store.gflat).
+        ``on_bucket(name)`` is called as soon as a bucket's gradients are complete (DP overlap hook)."""
+        st, bb, P, d, sv = self.store, self.bb, self.pre, self.d, self.sv
+        B, S, Lt, Mv, Mu = self.B, self.S, self.Lt, self.Mv, self.Mu
+        dXv = d_vid_out.contiguous().view(Mv, d)
+        dXu = None
+        for i in reversed(range(max(self.N - 1, 0))):
+            dXv, dXu = self._layer_bwd(i, sv["layers"][i], dXv, dXu, gbuf)
+            if on_bucket is not None:
+                on_bucket("%slayer%d" % (P, i))
+        # ---- embedding backward
+        dpre_v = st.buf("dpre_v", (Mv, d))
+        _ln_bwd(st, dXv, sv["pre_v"], sv["mev"], sv["rev"], P + "vid_ln.weight", P + "vid_ln.bias", gbuf, dpre_v, None, Mv, d,
+                drop_y=(self.p_drop, _site(self.bi, 0, K_EMB_V)), seed=self.seed)
+        self._embed_bwd("vid", dpre_v, B, S, gbuf)
+        if self.N >= 2:
+            dpre_u = st.buf("dpre_u", (Mu, d))
+            _ln_bwd(st, dXu, sv["pre_u"], sv["meu"], sv["reu"], P + "usr_ln.weight", P + "usr_ln.bias", gbuf, dpre_u, None, Mu, d,
+                    drop_y=(self.p_drop, _site(self.bi, 0, K_EMB_U)), seed=self.seed)
+            self._embed_bwd("usr", dpre_u, B, Lt, gbuf)
+        if on_bucket is not None:
+            on_bucket(P + "embed")
+
+    def _embed_bwd(self, side, dpre, B, L, gbuf):
+        st, bb, P, d, sv = self.store, self.bb, self.pre, self.d, self.sv
+        M = B * L
+        is_id = bb.id_vid if side == "vid" else bb.id_usr
+        gpe = st.g(P + "%s_pe.weight" % side, gbuf)
+        H.pe_grad(dpre, d, B, L, d, gpe)
+        if gpe.shape[0] > L:
+            gpe[L:].zero_()
+        gtab = st.g(P + "%s_proj.weight" % side, gbuf)
+        if is_id:
+            ids = sv["%s_ids" % side]
+            order = torch.argsort(ids, stable=True).to(torch.int32)
+            gtab.zero_()
+            width = d // 2 if side == "vid" else d
+            H.embed_id_bwd(dpre, L, d, 0, width, order, ids, gtab, B)
+            if side == "vid":
+                dh_ = d // 2
+                pos = st.buf("arangeS", (L,))
+                pos.copy_(torch.arange(L, device=pos.device, dtype=torch.float32))
+                _colsum(st, gpe, d, L, dh_, st.g(P + "frameid_proj.bias", gbuf), x_off=dh_)
+                _colsum(st, gpe, d, L, dh_, st.g(P + "frameid_proj.weight", gbuf).view(-1), x_off=dh_, w=pos)
+        else:
+            x = sv["%s_x" % side]
+            Din = x.shape[-1]
+            _wgrad(st, dpre, d, 0, x, Din, 0, M, d, Din, gtab)
+            _colsum(st, dpre, d, M, d, st.g(P + "%s_proj.bias" % side, gbuf))
+
+
+def _group_view(store, first_name, numel, gbuf):
+    """Gradient view spanning a fused (adjacent) parameter group that starts at ``first_name``."""
+    o, _ = store.index[first_name]
+    gb = store.gflat if gbuf is None else gbuf
+    return gb[o:o + numel]
+
+
+# =============================================================================================== autograd glue
+_STEP_SEED = [0x5E6D0001]
+
+
+def next_seed() -> int:
+    """A fresh dropout seed per training forward, drawn from torch's CPU generator so that
+    ``torch.manual_seed`` makes train-mode runs reproducible."""
+    return int(torch.randint(0, 2 ** 62, (1,)).item())
+
+
+class BackboneFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, store, bb, prefix, bb_index, usr_feat, usr_mask, vid_feat, vid_mask, train, seed, *params):
+        run = BackboneRun(store, bb, prefix, bb_index)
+        vid, usr = run.forward(usr_feat, usr_mask, vid_feat, vid_mask, train, seed)
+        ctx.run = run
+        ctx.store = store
+        ctx.names = [n for n in store.live_names if n.startswith(prefix)] if prefix else list(store.live_names)
+        ctx.mark_non_differentiable(usr)
+        return vid, usr
+
+    @staticmethod
+    def backward(ctx, d_vid, d_usr):
+        run, store = ctx.run, ctx.store
+        gbuf = _pick_gbuf(store, ctx.names)
+        run.backward(d_vid, gbuf, on_bucket=store.bucket_hook if gbuf is None else None)
+        ctx.run = None
+        grads = tuple(store.g(n, gbuf) for n in ctx.names)
+        return (None,) * 10 + grads
+
+
+def _pick_gbuf(store, names):
+    """Use the store's flat gradient buffer unless a parameter still holds a .grad that aliases it
+    (gradient accumulation over several backward calls): then compute into a fresh buffer."""
+    base, end = store.gflat.data_ptr(), store.gflat.data_ptr() + 4 * store.gflat.numel()
+    for n in names[:1] + names[-1:]:
+        g = store._params[n].grad
+        if g is not None and base <= g.data_ptr() < end:
+            return torch.zeros_like(store.gflat)
+    return None
+
+
+def backbone_apply(store, bb, prefix, usr_feat, usr_mask, vid_feat, vid_mask, training, bb_index=0, seed=None):
+    store.ensure()
+    if seed is None:
+        seed = next_seed() if training else 0
+    names = [n for n in store.live_names if n.startswith(prefix)] if prefix else list(store.live_names)
+    params = [store._params[n] for n in names]
+    return BackboneFn.apply(store, bb, prefix, bb_index, usr_feat, usr_mask, vid_feat, vid_mask, bool(training), int(seed), *params)

@@ -36,11 +36,14 @@ SIGNATURES = {
     "segmm_rowdot": [_p, _i, _p, _p, _p, _i64, _i, _i, _p],
     "segmm_rowscale_bcast": [_p, _p, _p, _i, _i64, _i, _i, _p],
     "segmm_vecsum": [_p, _i64, _p, _i, _p],
+    "segmm_rowdot_pair": [_p, _i, _p, _i, _p, _i64, _i, _i, _p],
+    "segmm_rowscale_mat": [_p, _p, _i, _p, _i, _i64, _i, _i, _p],
     "segmm_embed_id_vid": [_p, _p, _i, _p, _p, _p, _p, _i, _i, _p],
     "segmm_embed_id_usr": [_p, _p, _i, _p, _p, _i, _p],
-    "segmm_embed_id_bwd": [_p, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p],
+    "segmm_embed_id_bwd": [_p, _i, _i, _i, _i, _p, _p, _p, _i, _p],
     "segmm_pe_grad": [_p, _i, _i, _i, _i, _p, _i, _p],
-    "segmm_loss_fwd_bwd": [_i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _f, _p, _p, _i, _p, _p, _p, _p],
+    "segmm_label_stats": [_p, _i, _i, _i, _p, _p, _p, _p],
+    "segmm_loss_fwd_bwd": [_i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p],
     "segmm_adamw": [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _i, _p],
     "segmm_dropout_mult": [_p, _i64, _f, _u64, _u32, _p],
 }
@@ -94,6 +97,7 @@ def _f32c(t, name="tensor"):
     return t
 
 
+GEMM_PROFILE = None       # bench.py sets this to a list to time every GEMM launch with HIP events
 LAYOUT_NT, LAYOUT_NN, LAYOUT_TN = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_DGELU = 0, 1, 2
 
@@ -111,10 +115,18 @@ def gemm(layout, M, N, K, A, lda, B, ldb, Cout, ldc, bias=None, row_scale=None, 
     """Raw strided GEMM; ``*_off`` are element offsets into the tensors (column slices of fused buffers)."""
     _dev(A, B, Cout)
     es = 4
+    prof = GEMM_PROFILE
+    if prof is not None:          # bench.py: HIP events on the launch stream around the dominant kernel
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
     _check(lib().segmm_gemm(layout, M, N, K, A.data_ptr() + a_off * es, lda, B.data_ptr() + b_off * es, ldb,
                             Cout.data_ptr() + c_off * es, ldc, _ptr(bias), _ptr(row_scale), _ptr(residual), ldr,
                             res_period, activation, _ptr(aux), ldaux, float(drop_p), int(seed), int(site),
                             int(splits), _ptr(workspace), int(bool(accumulate)), _stream()), "segmm_gemm")
+    if prof is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        prof.append((layout, M, N, K, e0, e1))
 
 
 def layernorm_fwd(x, gamma, beta, y, mean, rstd, eps=1e-12, drop_p=0.0, seed=0, site=0):
@@ -179,6 +191,16 @@ def rowscale_bcast(g, w, dx, ld, rows, d, accumulate=False, w_off=0, dx_off=0):
                                       int(bool(accumulate)), _stream()), "segmm_rowscale_bcast")
 
 
+def rowdot_pair(a, lda, b, ldb, out, rows, d, accumulate=False, a_off=0, b_off=0):
+    _check(lib().segmm_rowdot_pair(a.data_ptr() + 4 * a_off, lda, b.data_ptr() + 4 * b_off, ldb, _ptr(out), rows, d,
+                                   int(bool(accumulate)), _stream()), "segmm_rowdot_pair")
+
+
+def rowscale_mat(g, X, ldx, out, ldo, rows, d, accumulate=False):
+    _check(lib().segmm_rowscale_mat(_ptr(g), _ptr(X), ldx, _ptr(out), ldo, rows, d, int(bool(accumulate)), _stream()),
+           "segmm_rowscale_mat")
+
+
 def vecsum(v, n, out, accumulate=False):
     _check(lib().segmm_vecsum(_ptr(v), n, _ptr(out), int(bool(accumulate)), _stream()), "segmm_vecsum")
 
@@ -193,23 +215,27 @@ def embed_id_usr(user_id, table, d, pe, out, B):
            "segmm_embed_id_usr")
 
 
-def embed_id_bwd(dpre, tokens_per_row, ld, col0, width, order, seg_start, ids, dtable, n_unique):
-    _check(lib().segmm_embed_id_bwd(_ptr(dpre), tokens_per_row, ld, col0, width, _ptr(order), _ptr(seg_start),
-                                    _ptr(ids), _ptr(dtable), n_unique, _stream()), "segmm_embed_id_bwd")
+def embed_id_bwd(dpre, tokens_per_row, ld, col0, width, order, ids, dtable, B):
+    _check(lib().segmm_embed_id_bwd(_ptr(dpre), tokens_per_row, ld, col0, width, _ptr(order), _ptr(ids), _ptr(dtable),
+                                    B, _stream()), "segmm_embed_id_bwd")
 
 
 def pe_grad(dpre, ld, B, S, d, dpe, accumulate=False):
     _check(lib().segmm_pe_grad(_ptr(dpre), ld, B, S, d, _ptr(dpe), int(bool(accumulate)), _stream()), "segmm_pe_grad")
 
 
-def loss_fwd_bwd(B, S, logits, gt, bias_w, bias_b, exposure, coef, enabled, rew_ce, rew_kl, rew_mse2, use_mask,
-                 n_valid_bpr, B_global, mask_sum_global, v_all, v2_all, Bg, logits_out, dlogits, parts):
+def label_stats(gt, B, S, rewritten, v, v2, norms):
+    _check(lib().segmm_label_stats(_ptr(gt), B, S, int(rewritten), _ptr(v), _ptr(v2), _ptr(norms), _stream()),
+           "segmm_label_stats")
+
+
+def loss_fwd_bwd(B, S, logits, gt, bias_w, bias_b, exposure, coef, enabled, rew_ce, rew_kl, use_mask, norms, v_all,
+                 v2_all, Bg, logits_out, dlogits, parts):
     coef_a = (C.c_float * 9)(*[float(c) for c in coef])
     en_a = (C.c_int * 9)(*[int(e) for e in enabled])
     _check(lib().segmm_loss_fwd_bwd(B, S, _ptr(logits), _ptr(gt), _ptr(bias_w), _ptr(bias_b), _ptr(exposure),
                                     C.cast(coef_a, C.c_void_p), C.cast(en_a, C.c_void_p), int(rew_ce), int(rew_kl),
-                                    int(rew_mse2), int(use_mask), float(n_valid_bpr), float(B_global),
-                                    float(mask_sum_global), _ptr(v_all), _ptr(v2_all), Bg, _ptr(logits_out),
+                                    int(use_mask), _ptr(norms), _ptr(v_all), _ptr(v2_all), Bg, _ptr(logits_out),
                                     _ptr(dlogits), _ptr(parts), _stream()), "segmm_loss_fwd_bwd")
 
 

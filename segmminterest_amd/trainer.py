@@ -1,0 +1,285 @@
+"""Training step of ``MMinterest/main_for_seq_leave_earlystop_SegMM.py:269-300`` on the HIP engine,
+single GPU or data-parallel over the GPUs of one node (one process per GPU, RCCL over xGMI).
+
+The reference trainer is single-process (DistributedDataParallel is imported at :13 and never used);
+data parallelism is what this build adds:
+
+* rows of the global batch are sharded contiguously over ranks, parameters are replicated;
+* every cross-row normaliser of the losses (valid-row count of interestBPR, batch size, mask count) is
+  made GLOBAL before the loss kernel runs -- one tiny all-reduce of 3 floats and one all-gather of the
+  per-row view lengths -- so the sum of the per-rank gradients equals the single-process gradient of
+  the whole batch exactly (no averaging step afterwards);
+* gradients live in one flat buffer laid out in backward-completion order; each bucket (head, layer
+  N-2, ..., layer 0, embedding) is all-reduced (SUM) asynchronously the moment its last gradient has
+  been written, overlapping the remaining backward; the fused AdamW waits for the last bucket.
+
+``init_model`` mirrors the reference's model construction (:60-130).
+"""
+from __future__ import annotations
+
+import argparse
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import hipabi as H
+from .decoder_leave_focal import MultiScaleTemporalDetrLeaveFocal
+from .encoder import SegFormerX
+
+
+# ------------------------------------------------------------------------------------------------ model factory
+def init_model(args, reader=None, n_users: Optional[int] = None, n_items: Optional[int] = None,
+               input_dim: int = 1024, max_vid_len: int = 40, max_usr_len: int = 100):
+    """init_model(args, reader) of the reference trainer (main_for_seq_leave_earlystop_SegMM.py:60-130).
+    ``reader`` only needs ``n_users`` / ``n_items``; feature width and lengths default to the
+    reference's hard-coded 1024 / 40 / 100 and are overridable for synthetic configs."""
+    n_users = reader.n_users if reader is not None else n_users
+    n_items = reader.n_items if reader is not None else n_items
+    N, d, h = args.num_layers_enc, args.d_model, args.nhead
+
+    def backbone(user_id_max, video_id_max, usr_len):
+        return SegFormerX(d_model_in=d, d_model_lvls=[d] * N, num_head_lvls=[h] * N, ff_dim_lvls=[d] * N,
+                          input_vid_dim=input_dim, input_usr_dim=input_dim, max_vid_len=max_vid_len, max_usr_len=usr_len,
+                          sr_ratio_lvls=[1] * N, use_patch_merge=[False] * N, output_layers=[-1], model_cfg=args,
+                          user_id_max=user_id_max, video_id_max=video_id_max, use_pe=getattr(args, "use_pe", 1))
+
+    u, p = args.input_type["user"], args.input_type["photo"]
+    if u == "both" or p == "both":
+        um1, ul1, um2, ul2 = {"both": (-1, max_usr_len, n_users, 1), "id": (n_users, 1, n_users, 1),
+                              "image": (-1, max_usr_len, -1, max_usr_len)}[u]
+        vm1, vm2 = {"both": (-1, n_items), "id": (n_items, n_items), "image": (-1, -1)}[p]
+        return MultiScaleTemporalDetrLeaveFocal(backbone(um1, vm1, ul1), backbone(um2, vm2, ul2), None, nn.Identity(), args)
+    um1, ul1 = (n_users, 1) if u == "id" else (-1, max_usr_len)
+    vm1 = n_items if p == "id" else -1
+    return MultiScaleTemporalDetrLeaveFocal(backbone(um1, vm1, ul1), None, None, nn.Identity(), args)
+
+
+def default_args(**over):
+    """The reference's argparse defaults that the model reads (main_for_seq_leave_earlystop_SegMM.py:478-575)."""
+    a = argparse.Namespace(debug=0, num_layers_enc=6, ablation_type="ours", d_model=512, nhead=16,
+                           input_type={"user": "both", "photo": "both"}, learnable_bias=0, exposure_prob=[1.0] * 40,
+                           fusion_heads=2, loss_type_list=["interestBPR"],
+                           loss_weight={"focal": 1.0, "mse": 1.0, "hazard": 1.0, "surviveCE": 1.0, "interestBPR": 1.0,
+                                        "interestCE": 1.0, "interestKL": 1.0},
+                           mask_loss=0, use_pe=1, learning_rate=1e-3, weight_decay=1e-4)
+    for k, v in over.items():
+        setattr(a, k, v)
+    return a
+
+
+# ------------------------------------------------------------------------------------------------ optimizer
+class FusedAdamW:
+    """torch.optim.AdamW semantics (lr 1e-3, wd 1e-4, betas (.9,.999), eps 1e-8 at
+    main_for_seq_leave_earlystop_SegMM.py:226) as ONE kernel over the contiguous live range of the
+    flat parameter buffer.  Dead parameters (no gradient in the reference either) are never touched."""
+
+    def __init__(self, model, lr=1e-3, weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-8):
+        self.model, self.lr, self.wd, self.betas, self.eps = model, lr, weight_decay, betas, eps
+        self.step_count = 0
+        self.m = self.v = None
+        self._flat_id = None
+
+    def _state(self):
+        st = self.model._store
+        st.ensure()
+        if self.m is None or self._flat_id != st.flat.data_ptr():
+            self.m = torch.zeros(st.n_live, device=st.flat.device)
+            self.v = torch.zeros(st.n_live, device=st.flat.device)
+            self._flat_id = st.flat.data_ptr()
+        return st
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.model.parameters():
+            p.grad = None
+
+    def step(self, gbuf=None):
+        st = self._state()
+        self.step_count += 1
+        g = st.gflat if gbuf is None else gbuf
+        H.adamw(st.flat, g, self.m, self.v, st.n_live, self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.step_count)
+
+    def state_dict(self):
+        """torch.optim.AdamW-format state (keyed by the index of the parameter in model.parameters()),
+        so a checkpoint written here resumes under the reference's optimizer and vice versa."""
+        st = self._state()
+        names = [n for n, _ in self.model.named_parameters()]
+        state = {}
+        for i, n in enumerate(names):
+            if n in st.live_names:
+                o, k = st.index[n]
+                shape = st._params[n].shape
+                state[i] = {"step": torch.tensor(float(self.step_count)), "exp_avg": self.m[o:o + k].view(shape).clone(),
+                            "exp_avg_sq": self.v[o:o + k].view(shape).clone()}
+        group = {"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.wd, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "params": list(range(len(names)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        st = self._state()
+        names = [n for n, _ in self.model.named_parameters()]
+        self.m.zero_()
+        self.v.zero_()
+        steps = set()
+        for i, s in sd["state"].items():
+            n = names[int(i)]
+            if n in st.live_names:
+                o, k = st.index[n]
+                self.m[o:o + k].copy_(s["exp_avg"].reshape(-1))
+                self.v[o:o + k].copy_(s["exp_avg_sq"].reshape(-1))
+                steps.add(int(float(s["step"])))
+        self.step_count = max(steps) if steps else 0
+        g = sd["param_groups"][0]
+        self.lr, self.wd, self.betas, self.eps = g["lr"], g["weight_decay"], tuple(g["betas"]), g["eps"]
+
+
+# ------------------------------------------------------------------------------------------------ communication
+class DPComm:
+    """The three collectives of a data-parallel step (engine-agnostic; works on any torch.distributed
+    backend, ``nccl`` = RCCL on the GPU box, ``gloo`` in the CPU tests)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.pending = []
+
+    def global_label_stats(self, v, v2, norms):
+        """(v_all, v2_all, norms_global): all-gather the per-row view lengths, sum the 3 normalisers."""
+        if self.world == 1:
+            return v, v2, norms
+        both = torch.stack([v, v2])                               # [2, B_local]; every rank holds the same B_local
+        gathered = torch.empty((self.world * 2, both.shape[1]), dtype=both.dtype, device=both.device)
+        self.dist.all_gather_into_tensor(gathered, both, group=self.group)
+        gathered = gathered.view(self.world, 2, both.shape[1])
+        norms_g = norms.clone()
+        self.dist.all_reduce(norms_g, op=self.dist.ReduceOp.SUM, group=self.group)
+        return gathered[:, 0].reshape(-1).contiguous(), gathered[:, 1].reshape(-1).contiguous(), norms_g
+
+    def reduce_bucket(self, flat_grad, start, end):
+        """Asynchronous SUM all-reduce of one contiguous gradient bucket (gradients are already
+        normalised by global counts, so SUM -- not mean -- reproduces the single-process gradient)."""
+        if self.world == 1 or end <= start:
+            return
+        self.pending.append(self.dist.all_reduce(flat_grad[start:end], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        for w in self.pending:
+            w.wait()
+        self.pending = []
+
+    def sum_scalar(self, t):
+        if self.world > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return t
+
+
+def shard_rows(n_rows: int, world: int, rank: int):
+    """Contiguous row block of ``rank``; the first ``n_rows % world`` ranks get one more."""
+    base, rem = divmod(n_rows, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+# ------------------------------------------------------------------------------------------------ trainer
+class Trainer:
+    """zero_grad -> L1-normalise -> forward -> backward (-> bucketed all-reduce) -> AdamW, i.e. the body of
+    the reference's hot loop (main_for_seq_leave_earlystop_SegMM.py:269-300) minus its host syncs.
+    Gradient clipping is a no-op in the reference (exhausted generator at :298) and is therefore absent."""
+
+    def __init__(self, model, lr=1e-3, weight_decay=1e-4, comm: Optional[DPComm] = None, overlap=True):
+        self.model = model
+        self.opt = FusedAdamW(model, lr=lr, weight_decay=weight_decay)
+        self.comm = comm if comm is not None else DPComm()
+        self.overlap = overlap
+        st = model._store
+        model._dp_hook = self.comm.global_label_stats if self.comm.world > 1 else None
+        st.bucket_hook = self._on_bucket if self.comm.world > 1 else None
+        self._norm = {}
+
+    def _on_bucket(self, name):
+        st = self.model._store
+        if not self.overlap:
+            return
+        for b, s, e in st.buckets:
+            if b == name:
+                self.comm.reduce_bucket(st.gflat, s, e)
+                return
+
+    def normalize(self, key, x):
+        """a1: x / (sum|x| + 1e-6) over the feature dim, into a persistent buffer."""
+        buf = self._norm.get(key)
+        if buf is None or buf.shape != x.shape or buf.device != x.device:
+            buf = self._norm[key] = torch.empty_like(x)
+        H.l1norm(x, buf)
+        return buf
+
+    def train_step(self, batch: Dict[str, torch.Tensor]):
+        model, st = self.model, self.model._store
+        model.train()
+        self.opt.zero_grad()
+        it = model.input_type
+        usr = self.normalize("user", batch["user"]) if it["user"] != "id" else None
+        vid = self.normalize("photo", batch["photo"]) if it["photo"] != "id" else None
+        out = model(usr_image=usr, usr_id=batch["user_identity_id"], usr_mask=batch["user_mask"], vid_image=vid,
+                    vid_id=batch["photo_identity_id"], vid_mask=batch["photo_mask"], gt=batch["label"], mode="train")
+        out["loss"].backward()
+        if self.comm.world > 1:
+            if not self.overlap:
+                self.comm.reduce_bucket(st.gflat, 0, st.n_live)
+            self.comm.finish()
+        self.opt.step()
+        return out
+
+    @torch.no_grad()
+    def eval_step(self, batch, mode="inference"):
+        model = self.model
+        model.eval()
+        it = model.input_type
+        usr = self.normalize("user", batch["user"]) if it["user"] != "id" else None
+        vid = self.normalize("photo", batch["photo"]) if it["photo"] != "id" else None
+        return model(usr_image=usr, usr_id=batch["user_identity_id"], usr_mask=batch["user_mask"], vid_image=vid,
+                     vid_id=batch["photo_identity_id"], vid_mask=batch["photo_mask"], gt=batch["label"], mode=mode)
+
+
+class CheckPointer:
+    """kn_util CheckPointer file format (kn_util/nn_utils/checkpoint.py:11-75): a dict
+    {model, optimizer, num_epochs, metrics} in ckpt-latest.pth and ckpt-best-ep{E}-{metric}.pth."""
+
+    def __init__(self, monitor, work_dir, mode="min", **_ignored):
+        import os
+        self.monitor, self.work_dir, self.mode, self.best_metric = monitor, work_dir, mode, None
+        os.makedirs(work_dir, exist_ok=True)
+        self.ckpt_latest = os.path.join(work_dir, "ckpt-latest.pth")
+        self.ckpt_best = os.path.join(work_dir, "ckpt-best-ep{}-{}.pth")
+
+    def better(self, new, orig):
+        if orig is None:
+            return True
+        return new < orig if self.mode == "min" else new > orig
+
+    def save_checkpoint(self, model, optimizer, num_epochs, metric_vals=None, **_):
+        import glob
+        import os
+        sd = dict(model={k: v.detach().cpu().clone() for k, v in model.state_dict().items()},
+                  optimizer=optimizer.state_dict(), num_epochs=num_epochs, metrics=metric_vals)
+        torch.save(sd, self.ckpt_latest)
+        if metric_vals and self.better(metric_vals[self.monitor], self.best_metric):
+            self.best_metric = metric_vals[self.monitor]
+            for f in glob.glob(self.ckpt_best.format("*", "*")):
+                os.remove(f)
+            torch.save(sd, self.ckpt_best.format(num_epochs, round(float(self.best_metric), 6)))
+            return True
+        return False
+
+    def load_checkpoint(self, model, optimizer, mode="latest", **_):
+        import glob
+        fn = self.ckpt_latest if mode == "latest" else glob.glob(self.ckpt_best.format("*", "*"))[0]
+        sd = torch.load(fn, map_location="cpu", weights_only=False)
+        model.load_state_dict(sd["model"])
+        if optimizer is not None:
+            optimizer.load_state_dict(sd["optimizer"])
+        return sd

@@ -23,3 +23,42 @@ def load_case(name):
     nograd = json.loads(str(z["nograd"]))
     extra = {"adam_loss3": float(z["adam_loss3"])} if "adam_loss3" in z.files else {}
     return cfg, grp, nograd, extra
+
+
+def build_model(cfg, device=None):
+    """Builds the segmminterest_amd facade exactly like the reference's init_model builds its model
+    (main_for_seq_leave_earlystop_SegMM.py:60-130), from a golden-fixture cfg dict."""
+    import argparse
+    import segmminterest_amd as M
+    S, N, d, h = cfg["S"], cfg["N"], cfg["d"], cfg["h"]
+    args = argparse.Namespace(debug=0, num_layers_enc=N, ablation_type="ours", d_model=d, nhead=h,
+                              input_type={"user": cfg["user"], "photo": cfg["photo"]},
+                              learnable_bias=cfg.get("learnable_bias", 0), exposure_prob=cfg["exposure_prob"],
+                              fusion_heads=cfg.get("fusion_heads", 2), loss_type_list=cfg["loss_type_list"],
+                              loss_weight=cfg["loss_weight"], mask_loss=cfg.get("mask_loss", 0), use_pe=1)
+
+    def backbone(user_id_max, video_id_max, max_usr_len):
+        return M.SegFormerX(d_model_in=d, d_model_lvls=[d] * N, num_head_lvls=[h] * N, ff_dim_lvls=[d] * N,
+                            input_vid_dim=max(cfg["D_in"], 1), input_usr_dim=max(cfg["D_in"], 1), max_vid_len=S,
+                            max_usr_len=max_usr_len, sr_ratio_lvls=[1] * N, use_patch_merge=[False] * N,
+                            output_layers=[-1], model_cfg=args, user_id_max=user_id_max, video_id_max=video_id_max, use_pe=1)
+
+    nu, ni = cfg.get("n_users", 0), cfg.get("n_items", 0)
+    u, p = cfg["user"], cfg["photo"]
+    if u == "both" or p == "both":
+        um1, ul1, um2, ul2 = {"both": (-1, cfg["Lt"], nu, 1), "id": (nu, 1, nu, 1), "image": (-1, cfg["Lt"], -1, cfg["Lt"])}[u]
+        vm1, vm2 = {"both": (-1, ni), "id": (ni, ni), "image": (-1, -1)}[p]
+        model = M.MultiScaleTemporalDetrLeaveFocal(backbone(um1, vm1, ul1), backbone(um2, vm2, ul2), None, torch.nn.Identity(), args)
+    else:
+        um1, ul1 = (nu, 1) if u == "id" else (-1, cfg["Lt"])
+        vm1 = ni if p == "id" else -1
+        model = M.MultiScaleTemporalDetrLeaveFocal(backbone(um1, vm1, ul1), None, None, torch.nn.Identity(), args)
+    if device is not None:
+        model = model.to(device)
+    return model
+
+
+def call_model(model, inp, mode="train", device=None):
+    kw = {k: (v.to(device) if device is not None else v) for k, v in inp.items()}
+    return model(usr_image=kw["usr_image"], usr_id=kw["usr_id"], usr_mask=kw["usr_mask"], vid_image=kw["vid_image"],
+                 vid_id=kw["vid_id"], vid_mask=kw["vid_mask"], gt=kw["gt"].clone(), mode=mode)

@@ -1,0 +1,84 @@
+"""Data-parallel logic on CPU with the gloo backend, world_size 2 (the N>1 path of SURVEY.md §8(e)):
+the three collectives of DPComm, and the claim they rest on -- per-shard losses normalised by the GLOBAL
+label statistics sum to the single-process loss and gradient (checked with the CPU oracle)."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import ROOT, load_case
+
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sys.path.insert(0, ROOT)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import segmm_oracle as O
+        from segmminterest_amd.trainer import DPComm, shard_rows
+        torch.set_num_threads(1)
+        comm = DPComm()
+        assert comm.world == world and comm.rank == rank
+        cfg, g, _, _ = load_case("img_d32_N3_alllosses")
+        inp = {k: t[:8] for k, t in g["in"].items()}        # equal shards (the trainer's weak-scaling contract)
+        B = inp["gt"].shape[0]
+        s, e = shard_rows(B, world, rank)
+        gt = inp["gt"]
+        # label statistics of this shard, then made global
+        v = (gt[s:e] == 1).sum(1).float()
+        v2 = (gt[s:e] >= 0).sum(1).float()
+        norms = torch.tensor([float((v < cfg["S"]).sum()), float(e - s), float((gt[s:e] != -2).sum())])
+        v_all, v2_all, norms_g = comm.global_label_stats(v, v2, norms)
+        assert torch.equal(v_all, (gt == 1).sum(1).float())
+        assert torch.equal(v2_all, (gt >= 0).sum(1).float())
+        assert norms_g.tolist() == [float(((gt == 1).sum(1) < cfg["S"]).sum()), float(B), float((gt != -2).sum())]
+        # shard forward/backward with global normalisers; sum over ranks == full batch
+        shard = {k: val[s:e].clone() for k, val in inp.items()}
+        params = {k: t.clone().requires_grad_(t.is_floating_point()) for k, t in g["sd"].items()}
+        out = O.model_forward(params, cfg, shard, "train", global_stats=dict(v_all=v_all, v2_all=v2_all, norms=norms_g))
+        out["loss"].backward()
+        names = [k for k, p in params.items() if p.grad is not None]
+        flat = torch.cat([params[k].grad.reshape(-1) for k in names])
+        half = flat.numel() // 2
+        comm.reduce_bucket(flat, 0, half)            # two async buckets, like the trainer
+        comm.reduce_bucket(flat, half, flat.numel())
+        comm.finish()
+        loss = comm.sum_scalar(out["loss"].detach().clone())
+        if rank == 0:
+            ref_out, ref_grads = O.forward_backward(g["sd"], cfg, inp)       # single process, whole batch
+            ref_flat = torch.cat([ref_grads[k].reshape(-1) for k in names])
+            q.put((float(loss), float(ref_out["loss"]), float((flat - ref_flat).abs().max()), float(ref_flat.abs().max())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dp_world2_gloo_matches_single_process():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 1000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    loss, ref_loss, gerr, gmax = q.get(timeout=5)
+    assert abs(loss - ref_loss) < 1e-4 * max(1.0, abs(ref_loss))
+    assert gerr < 1e-4 * gmax
+
+
+def test_shard_rows_cover_batch():
+    from segmminterest_amd.trainer import shard_rows
+    for n in (1, 7, 512, 2048):
+        for w in (1, 2, 3, 8):
+            spans = [shard_rows(n, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(e - s for s, e in spans) - min(e - s for s, e in spans) <= 1
