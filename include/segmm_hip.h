@@ -67,7 +67,8 @@ int segmm_colsum(const float* X, int ld, const float* w, int64_t M, int N, float
 
 /* K4 -- joint self+cross attention of one side (encoder.py:44-73,138-161).  Queries Qa/Qb (two projections of the
  * same Lq tokens) against key blocks a (La tokens) and b (Lb tokens); all tensors are [B*L, ld] with head h at
- * columns [h*dh, (h+1)*dh).  Masks are uint8 (torch.bool).  lse / Dvec: [B, H, Lq] floats. */
+ * columns [h*dh, (h+1)*dh).  Masks are uint8 (torch.bool).  lse: [2, B, H, Lq] floats
+ * (plane 0 = softmax row max, plane 1 = 1/row sum, written by the forward); Dvec: [B, H, Lq] floats. */
 int segmm_attn_fwd(int B, int H, int dh, int Lq, int La, int Lb, const float* Qa, const float* Qb, int ldq,
                    const float* Ka, const float* Va, int ldka, const float* Kb, const float* Vb, int ldkb,
                    const uint8_t* mq, const uint8_t* mka, const uint8_t* mkb, float* O, int ldo, float* lse,

@@ -31,7 +31,10 @@ struct AttnArgs {
     const float *Kb, *Vb; int ldkb;     // [B*Lb, ldkb]
     const uint8_t *mq, *mka, *mkb;      // [B,Lq] [B,La] [B,Lb]; nonzero = valid token
     float* O; int ldo;                  // [B*Lq, ldo]
-    float* lse;                         // [B,H,Lq]  log-sum-exp of the scaled logits
+    float* lse;                         // [2,B,H,Lq] softmax row statistics: plane 0 = row max, plane 1 = 1/sum.
+                                        // Kept as the PAIR (not max+log(sum)): a padded query row has every
+                                        // logit at -10000*scale ~ -1e3, where one fp32 ulp of a merged
+                                        // log-sum-exp is ~1e-4 and would put a 1e-4 relative error on P.
     float scale;
     DropCfg drop;
     // backward
@@ -56,13 +59,31 @@ template <int DH> struct AttnCfg {
 template <int DH>
 __device__ __forceinline__ void stage_rows(float* dst, int lds, const float* src, size_t ld, int col0, int row_base,
                                            int nrows, int nvalid, int tid, int nthr) {
-    constexpr int KS = DH / 4;
-    for (int idx = tid; idx < nrows * KS; idx += nthr) {
-        const int r = idx / KS, c4 = (idx % KS) * 4;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (r < nvalid) v = *(const f32x4*)(src + (size_t)(row_base + r) * ld + col0 + c4);
-        float* d = dst + r * lds + c4;
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    // U loads are issued back to back before the first LDS store, so their latencies overlap (a
+    // one-load-per-iteration loop was latency-serialised: 3 waves per workgroup cannot hide it).
+    constexpr int KS = DH / 4, U = 8;
+    const int total = nrows * KS;
+    for (int base = tid; base < total; base += nthr * U) {
+        f32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = base + u * nthr;
+            v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (idx < total) {
+                const int r = idx / KS, c4 = (idx % KS) * 4;
+                if (r < nvalid) v[u] = *(const f32x4*)(src + (size_t)(row_base + r) * ld + col0 + c4);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = base + u * nthr;
+            if (idx < total) {
+                const int r = idx / KS, c4 = (idx % KS) * 4;
+                float2* d = (float2*)(dst + r * lds + c4);      // row strides are even => 8-byte aligned
+                d[0] = make_float2(v[u].x, v[u].y);
+                d[1] = make_float2(v[u].z, v[u].w);
+            }
+        }
     }
 }
 
@@ -178,7 +199,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
-    if (g == 0 && q_in) p.lse[(size_t)bh * p.Lq + qi] = mx + logf(sum);
+    if (g == 0 && q_in) {
+        p.lse[(size_t)bh * p.Lq + qi] = mx;
+        p.lse[(size_t)p.B * p.H * p.Lq + (size_t)bh * p.Lq + qi] = inv;
+    }
 
     __syncthreads();      // every wave is done reading K
     stage_keys<DH>(KVs, C::LDC, p.Va, p.ldka, p.Vb, p.ldkb, b, p.La, p.Lb, La_p, Lb_p, col0, tid, nthr);
@@ -239,7 +263,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
     const int qi = q_blk + wave * 16 + l15;
     const bool q_in = qi < p.Lq;
     const bool q_ok = q_in && p.mq[(size_t)b * p.Lq + (q_in ? qi : 0)] != 0;
-    const float lse = q_in ? p.lse[(size_t)bh * p.Lq + qi] : 0.f;
+    const float row_mx = q_in ? p.lse[(size_t)bh * p.Lq + qi] : 0.f;
+    const float row_inv = q_in ? p.lse[(size_t)p.B * p.H * p.Lq + (size_t)bh * p.Lq + qi] : 0.f;
 
     f32x4 P[NT], fac[NT];     // P^T and d(logit)/d(raw) factor
 #pragma unroll
@@ -277,7 +302,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
                 const uint32_t k = (kb >> (8 * r)) & 0xff;
                 const bool valid = q_ok && k == 1;
                 const float v = logit_xform(P[t][r], valid, mult[r], p.scale);
-                P[t][r] = (k == 2) ? 0.f : expf(v - lse);
+                P[t][r] = (k == 2) ? 0.f : expf(v - row_mx) * row_inv;
                 fac[t][r] = valid ? mult[r] * p.scale : 0.f;
             }
         }
@@ -369,7 +394,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
     float* Ks = dOs + Lq_p * C::LDR;
     float* Vs = Ks + KB * C::LDR;
     float* lses = Vs + KB * C::LDR;
-    float* Ds = lses + Lq_p;
+    float* invs = lses + Lq_p;
+    float* Ds = invs + Lq_p;
     uint8_t* qm = (uint8_t*)(Ds + Lq_p);
     uint8_t* km = qm + Lq_p;
     const int col0 = h * DH;
@@ -400,6 +426,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
     for (int i = tid; i < Lq_p; i += nthr) {
         const bool in = i < p.Lq;
         lses[i] = in ? p.lse[(size_t)bh * p.Lq + i] : 0.f;
+        invs[i] = in ? p.lse[(size_t)p.B * p.H * p.Lq + (size_t)bh * p.Lq + i] : 0.f;
         Ds[i] = in ? p.Dvec[(size_t)bh * p.Lq + i] : 0.f;
         qm[i] = in ? (p.mq[(size_t)b * p.Lq + i] ? 1 : 0) : 2;
     }
@@ -442,7 +469,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
             float mult = 1.f;
             if (p.drop.p > 0.f && qf != 2) mult = drop_mult1(p.drop, ((uint64_t)bh * p.Lq + qi) * Tp + jp);
             const float v = logit_xform(s[r], valid, mult, p.scale);
-            const float pr = (kflag == 2 || qf == 2) ? 0.f : expf(v - lses[qi]);
+            const float pr = (kflag == 2 || qf == 2) ? 0.f : expf(v - lses[qi]) * invs[qi];
             Pv[r] = pr;
             dSv[r] = valid ? pr * (dp[r] - Ds[qi]) * mult * p.scale : 0.f;
         }

@@ -79,7 +79,7 @@ static int attn_launch_bwd(const AttnArgs& a, hipStream_t s) {
         const int KB = nw * 16;
         const int Lq_p = (a.Lq + 15) & ~15;
         dim3 grid(a.B * a.H, (Tp + KB - 1) / KB), block(64 * nw);
-        const size_t lds = sizeof(float) * (3 * Lq_p * C::LDR + 2 * KB * C::LDR + 2 * Lq_p) + Lq_p + Tp;
+        const size_t lds = sizeof(float) * (3 * Lq_p * C::LDR + 2 * KB * C::LDR + 3 * Lq_p) + Lq_p + Tp;
         SEGMM_REQUIRE(lds <= 160 * 1024, "attn_bwd: %zu bytes of LDS needed (Lq=%d)", lds, a.Lq);
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH>), grid, block, lds, s, a);
         LAUNCH_CHECK();
@@ -218,7 +218,7 @@ int segmm_layernorm_bwd(const float* dy, const float* x, const float* mean, cons
 
 int segmm_colsum_chunks(int64_t M) {
     int64_t c = (M + 255) / 256;
-    if (c > 256) c = 256;
+    if (c > 64) c = 64;
     if (c < 1) c = 1;
     return (int)c;
 }
@@ -226,7 +226,7 @@ int segmm_colsum_chunks(int64_t M) {
 int segmm_colsum(const float* X, int ld, const float* w, int64_t M, int N, float* out, int accumulate,
                  float* workspace, segmm_stream_t stream) {
     SEGMM_REQUIRE(X && out && workspace, "colsum: null pointer");
-    SEGMM_REQUIRE(N > 0 && N % 4 == 0 && ld % 4 == 0 && aligned16(X) && aligned16(workspace), "colsum: N/ld %% 4 / alignment (N=%d ld=%d)", N, ld);
+    SEGMM_REQUIRE(N > 0 && N % 4 == 0 && ld % 4 == 0 && aligned16(X) && aligned16(workspace) && aligned16(out), "colsum: N/ld %% 4 / alignment (N=%d ld=%d)", N, ld);
     const int chunks = segmm_colsum_chunks(M);
     const int rpc = (int)((M + chunks - 1) / chunks);
     hipStream_t s = (hipStream_t)stream;

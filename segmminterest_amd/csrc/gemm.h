@@ -9,7 +9,8 @@
 //   TN  C[M,N] = A[K,M]^T . B[K,N]      wgrad: dW = dY^T . X   (split-K over the token dimension)
 //
 // Tile: 128 x 128 x 32 per 256-thread workgroup (4 waves as 2 x 2, each 64 x 64 = 2 x 2 MFMA tiles,
-// 64 accumulator VGPRs).  Global -> register prefetch of tile t+1 overlaps the MFMAs on tile t; LDS
+// 64 accumulator VGPRs), 2 workgroups per CU.  Two-stage LDS ring with one barrier per k-tile; tile
+// t+2 travels HBM -> registers while tile t+1 moves registers -> LDS and tile t is multiplied; LDS
 // rows are padded (+4 floats) so the ds_read_b128 fragment reads are bank-conflict free.  Because the
 // f32 MFMA takes ONE scalar per lane per operand, the k order inside an 8-wide chunk is permuted
 // (lane half h supplies k = 4h..4h+3) so a lane fetches its four k values with one ds_read_b128.
@@ -45,9 +46,7 @@ struct GemmArgs {
 
 template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmArgs p) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * GTILE];
-    float* As = smem;
-    float* Bs = smem + GTILE;
+    __shared__ __attribute__((aligned(16))) float smem[4 * GTILE];      // 2 stages x (A tile, B tile) = 73.7 KB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
@@ -64,79 +63,114 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // ---- staging coordinates of this thread (4 float4 of A and of B per k-tile), hoisted out of the loop.
+    // Out-of-range rows / k are CLAMPED to a valid address and zeroed by a select, so the loop body is
+    // branch-free straight-line code (one scheduling region per phase).
     f32x4 ra[4], rb[4];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-
+    const float* pa[4];
+    const float* pb[4];
+    int ka[4], kb[4];            // k offset of the element inside a k-tile
+    bool va[4], vb[4];           // row (m / n) in range
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int f = tid + 256 * r;
+        if (A_KC) {
+            const int gm = m0 + (f >> 3);
+            ka[r] = (f & 7) << 2; va[r] = gm < p.M;
+            pa[r] = p.A + (size_t)min(gm, p.M - 1) * p.lda;
+        } else {
+            const int gm = m0 + ((f & 31) << 2);
+            ka[r] = f >> 5; va[r] = gm < p.M;
+            pa[r] = p.A + min(gm, p.M - 4);
+        }
+        if (B_KC) {
+            const int gn = n0 + (f >> 3);
+            kb[r] = (f & 7) << 2; vb[r] = gn < p.N;
+            pb[r] = p.B + (size_t)min(gn, p.N - 1) * p.ldb;
+        } else {
+            const int gn = n0 + ((f & 31) << 2);
+            kb[r] = f >> 5; vb[r] = gn < p.N;
+            pb[r] = p.B + min(gn, p.N - 4);
+        }
+    }
+    const int kclampA = A_KC ? kend - 4 : kend - 1, kclampB = B_KC ? kend - 4 : kend - 1;
     auto gload = [&](int k0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int f = tid + 256 * r;
-            if (A_KC) {
-                const int row = f >> 3, gk = k0 + ((f & 7) << 2), gm = m0 + row;
-                ra[r] = (gm < p.M && gk < kend) ? *(const f32x4*)(p.A + (size_t)gm * p.lda + gk) : zero4;
-            } else {
-                const int gk = k0 + (f >> 5), gm = m0 + ((f & 31) << 2);
-                ra[r] = (gm < p.M && gk < kend) ? *(const f32x4*)(p.A + (size_t)gk * p.lda + gm) : zero4;
-            }
-            if (B_KC) {
-                const int row = f >> 3, gk = k0 + ((f & 7) << 2), gn = n0 + row;
-                rb[r] = (gn < p.N && gk < kend) ? *(const f32x4*)(p.B + (size_t)gn * p.ldb + gk) : zero4;
-            } else {
-                const int gk = k0 + (f >> 5), gn = n0 + ((f & 31) << 2);
-                rb[r] = (gn < p.N && gk < kend) ? *(const f32x4*)(p.B + (size_t)gk * p.ldb + gn) : zero4;
-            }
+            const int gka = k0 + ka[r], gkb = k0 + kb[r];
+            const f32x4 xa = A_KC ? *(const f32x4*)(pa[r] + min(gka, kclampA))
+                                  : *(const f32x4*)(pa[r] + (size_t)min(gka, kclampA) * p.lda);
+            const f32x4 xb = B_KC ? *(const f32x4*)(pb[r] + min(gkb, kclampB))
+                                  : *(const f32x4*)(pb[r] + (size_t)min(gkb, kclampB) * p.ldb);
+            ra[r] = xa;          // raw: the zeroing select happens at lstore time, so nothing consumes
+            rb[r] = xb;          // the loaded registers (=> no s_waitcnt vmcnt) until a whole tile later
         }
     };
-    auto lstore = [&]() {
+    auto lstore = [&](int k0, float* As_, float* Bs_) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int f = tid + 256 * r;
-            if (A_KC) *(f32x4*)(As + (f >> 3) * GLDK + ((f & 7) << 2)) = ra[r];
-            else      *(f32x4*)(As + (f >> 5) * GLDM + ((f & 31) << 2)) = ra[r];
-            if (B_KC) *(f32x4*)(Bs + (f >> 3) * GLDK + ((f & 7) << 2)) = rb[r];
-            else      *(f32x4*)(Bs + (f >> 5) * GLDM + ((f & 31) << 2)) = rb[r];
+            const f32x4 xa = (va[r] && k0 + ka[r] < kend) ? ra[r] : zero4;
+            const f32x4 xb = (vb[r] && k0 + kb[r] < kend) ? rb[r] : zero4;
+            if (A_KC) *(f32x4*)(As_ + (f >> 3) * GLDK + ((f & 7) << 2)) = xa;
+            else      *(f32x4*)(As_ + (f >> 5) * GLDM + ((f & 31) << 2)) = xa;
+            if (B_KC) *(f32x4*)(Bs_ + (f >> 3) * GLDK + ((f & 7) << 2)) = xb;
+            else      *(f32x4*)(Bs_ + (f >> 5) * GLDM + ((f & 31) << 2)) = xb;
+        }
+    };
+    auto read_frag = [&](const float* As_, const float* Bs_, int c, float (&af)[2][4], float (&bf)[2][4]) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (A_KC) {
+                const f32x4 v = *(const f32x4*)(As_ + (wm * 64 + t * 32 + li) * GLDK + c * 8 + lh * 4);
+                af[t][0] = v.x; af[t][1] = v.y; af[t][2] = v.z; af[t][3] = v.w;
+            } else {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) af[t][s] = As_[(c * 8 + lh * 4 + s) * GLDM + wm * 64 + t * 32 + li];
+            }
+            if (B_KC) {
+                const f32x4 v = *(const f32x4*)(Bs_ + (wn * 64 + t * 32 + li) * GLDK + c * 8 + lh * 4);
+                bf[t][0] = v.x; bf[t][1] = v.y; bf[t][2] = v.z; bf[t][3] = v.w;
+            } else {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) bf[t][s] = Bs_[(c * 8 + lh * 4 + s) * GLDM + wn * 64 + t * 32 + li];
+            }
         }
     };
 
+    // ---- main loop: 2-stage LDS ring, ONE barrier per k-tile.  Inside a tile the four 8-deep chunks are
+    // software-pipelined: the LDS reads of chunk c+1, the LDS stores of tile t+1 (chunk 1) and the global
+    // loads of tile t+2 (chunk 2) are issued BEFORE the 16 MFMAs of chunk c, so they fly under them
+    // (an f32 MFMA occupies the matrix pipe for 64 cycles; everything else issues in its shadow).
+    const int ntiles = (kend - kbeg + GBK - 1) / GBK;
     gload(kbeg);
-    lstore();
+    lstore(kbeg, smem, smem + GTILE);
+    gload(kbeg + GBK);
     __syncthreads();
-    for (int k0 = kbeg; k0 < kend; k0 += GBK) {
-        const bool more = (k0 + GBK) < kend;
-        if (more) gload(k0 + GBK);
+    for (int t = 0; t < ntiles; ++t) {
+        const float* Ac = smem + (t & 1) * (2 * GTILE);
+        const float* Bc = Ac + GTILE;
+        float* An = smem + ((t + 1) & 1) * (2 * GTILE);
+        float* Bn = An + GTILE;
+        float af[2][2][4], bf[2][2][4];
+        read_frag(Ac, Bc, 0, af[0], bf[0]);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            float af[2][4], bf[2][4];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                if (A_KC) {
-                    const f32x4 v = *(const f32x4*)(As + (wm * 64 + t * 32 + li) * GLDK + c * 8 + lh * 4);
-                    af[t][0] = v.x; af[t][1] = v.y; af[t][2] = v.z; af[t][3] = v.w;
-                } else {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) af[t][s] = As[(c * 8 + lh * 4 + s) * GLDM + wm * 64 + t * 32 + li];
-                }
-                if (B_KC) {
-                    const f32x4 v = *(const f32x4*)(Bs + (wn * 64 + t * 32 + li) * GLDK + c * 8 + lh * 4);
-                    bf[t][0] = v.x; bf[t][1] = v.y; bf[t][2] = v.z; bf[t][3] = v.w;
-                } else {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) bf[t][s] = Bs[(c * 8 + lh * 4 + s) * GLDM + wn * 64 + t * 32 + li];
-                }
-            }
+            if (c < 3) read_frag(Ac, Bc, c + 1, af[(c + 1) & 1], bf[(c + 1) & 1]);
+            if (c == 1) lstore(kbeg + (t + 1) * GBK, An, Bn);        // tile t+1: registers -> other stage
+            if (c == 2) gload(kbeg + (t + 2) * GBK);                 // tile t+2: HBM/L2 -> registers
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c & 1][i][s], bf[c & 1][j][s], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
-        if (more) {
-            lstore();
-            __syncthreads();
-        }
     }
 
     // ---- epilogue: accumulator tile -> LDS (per-wave region) -> row-major float4

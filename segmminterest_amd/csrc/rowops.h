@@ -173,11 +173,21 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
 }
 // out[n] (+)= sum_p partial[p][n]
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int P, int N, float* out, int accumulate) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
-    float s = 0.f;
-    for (int p = 0; p < P; ++p) s += partial[(size_t)p * N + n];
-    out[n] = accumulate ? out[n] + s : s;
+    // 64 float4 columns x 4 partial-row lanes per workgroup: the P partials of a column are summed by 4
+    // threads in a fixed order (deterministic), not by one thread walking P dependent loads.
+    __shared__ f32x4 red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int n = (blockIdx.x * 64 + tx) * 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (n < N)
+        for (int p = ty; p < P; p += 4) acc += *(const f32x4*)(partial + (size_t)p * N + n);
+    red[ty][tx] = acc;
+    __syncthreads();
+    if (ty == 0 && n < N) {
+        f32x4 s = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+        if (accumulate) s += *(const f32x4*)(out + n);
+        *(f32x4*)(out + n) = s;
+    }
 }
 
 // ---------------------------------------------------------------- interest head: Linear(d,1)  (decoder_leave_focal.py:451,596)

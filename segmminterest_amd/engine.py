@@ -323,14 +323,14 @@ class BackboneRun:
         Yv, Yu = _empty(Xv, Mv, nv * d), _empty(Xv, Mu, nu * d)
         H.gemm(H.LAYOUT_NT, Mv, nv * d, d, Xv, d, st.p(ca + "v2v_proj.0.weight"), d, Yv, nv * d, bias=st.p(ca + "v2v_proj.0.bias"))
         H.gemm(H.LAYOUT_NT, Mu, nu * d, d, Xu, d, st.p(ca + "t2v_proj.1.weight"), d, Yu, nu * d, bias=st.p(ca + "t2v_proj.1.bias"))
-        Av, lse_v = _empty(Xv, Mv, d), _empty(Xv, B, Hh, S)
+        Av, lse_v = _empty(Xv, Mv, d), _empty(Xv, 2, B, Hh, S)
         H.attn_fwd(B, Hh, dh, S, S, Lt, (Yv, 0), (Yv, d), nv * d, (Yv, 2 * d), (Yv, 3 * d), nv * d, (Yu, 0), (Yu, d), nu * d,
                    self.vm, self.vm, self.um, Av, d, lse_v, drop_p=self.p_drop, seed=self.seed, site=_site(self.bi, i, K_ATT_V))
         X2v, sv_v = self._side_post(i, L, "vid", Xv, Av, Mv, (K_AO_V, K_MI_V, K_MO_V))
         rec = dict(full=full, Xv=Xv, Xu=Xu, Yv=Yv, Yu=Yu, lse_v=lse_v, v=sv_v)
         X2u = None
         if full:
-            Au, lse_u = _empty(Xv, Mu, d), _empty(Xv, B, Hh, Lt)
+            Au, lse_u = _empty(Xv, Mu, d), _empty(Xv, 2, B, Hh, Lt)
             H.attn_fwd(B, Hh, dh, Lt, S, Lt, (Yu, 2 * d), (Yu, 3 * d), nu * d, (Yv, 4 * d), (Yv, 5 * d), nv * d,
                        (Yu, 4 * d), (Yu, 5 * d), nu * d, self.um, self.vm, self.um, Au, d, lse_u, drop_p=self.p_drop,
                        seed=self.seed, site=_site(self.bi, i, K_ATT_U))
@@ -437,7 +437,7 @@ class BackboneRun:
         M = B * L
         is_id = bb.id_vid if side == "vid" else bb.id_usr
         gpe = st.g(P + "%s_pe.weight" % side, gbuf)
-        H.pe_grad(dpre, d, B, L, d, gpe)
+        _colsum(st, dpre, L * d, B, L * d, gpe)          # dpe[s,:] = sum_b dpre[b,s,:]: a column sum of the [B, L*d] view
         if gpe.shape[0] > L:
             gpe[L:].zero_()
         gtab = st.g(P + "%s_proj.weight" % side, gbuf)

@@ -64,14 +64,20 @@ def test_adamw_steps_torch_optimizer_dropin(name):
 
     def check(k, got, ref, base, steps):
         # Adam normalises g/sqrt(v): where the gradient is rounding noise its SIGN decides a full
-        # lr-sized step, so such elements can only be pinned to lr*steps (same rule as the oracle test).
+        # lr-sized step in either direction, so such elements can only be pinned to 2*lr*steps.
         if k not in g["grad"]:
             assert torch.equal(got, ref), k
             return
-        solid = g["grad"][k].abs() > 1e-5
+        gabs = g["grad"][k].abs()
+        solid = gabs > max(1e-5, 2e-3 * float(gabs.max()))
         err = (got - ref).abs()
-        lim = torch.where(solid, torch.full_like(err, base), torch.full_like(err, 1.1e-3 * steps)) + 1e-4 * ref.abs()
-        assert bool((err <= lim).all()), (steps, k, float(err.max()))
+        lim = torch.where(solid, torch.full_like(err, base), torch.full_like(err, 2.2e-3 * steps)) + 1e-4 * ref.abs()
+        bad = err > lim
+        if bool(bad.any()):
+            i = int((err - lim).argmax())
+            msg = "step %d %s: elem %d err %.3e lim %.3e |g_ref| %.3e gmax %.3e" % (
+                steps, k, i, float(err.view(-1)[i]), float(lim.view(-1)[i]), float(gabs.view(-1)[i]), float(gabs.max()))
+            raise AssertionError(msg)
     for step in range(1, 4):
         opt.zero_grad()
         out = call_model(model, g["in"], "train", DEV)
@@ -103,9 +109,10 @@ def test_fused_adamw_optimizer_matches_reference(name):
         if k in nograd:
             assert torch.equal(got, g["sd"][k]), k
             continue
-        solid = g["grad"][k].abs() > 1e-5
+        gabs = g["grad"][k].abs()
+        solid = gabs > max(1e-5, 2e-3 * float(gabs.max()))
         err = (got - ref[k]).abs()
-        lim = torch.where(solid, torch.full_like(err, 1e-4), torch.full_like(err, 3.3e-3)) + 1e-4 * ref[k].abs()
+        lim = torch.where(solid, torch.full_like(err, 1e-4), torch.full_like(err, 6.6e-3)) + 1e-4 * ref[k].abs()
         assert bool((err <= lim).all()), (k, float(err.max()))
     # optimizer state round-trips through the torch.optim.AdamW state_dict format
     sd = opt.state_dict()

@@ -276,7 +276,7 @@ def test_attention_fwd_bwd(B, H_, dh, Lq, La, Lb):
     mq[0, 0] = False
     mq[-1, -1] = True
     O = torch.empty(B * Lq, d, device=DEV)
-    lse = torch.empty(B, H_, Lq, device=DEV)
+    lse = torch.empty(2, B, H_, Lq, device=DEV)
     z = lambda t: (t, 0)
     H.attn_fwd(B, H_, dh, Lq, La, Lb, z(Qa), z(Qb), d, z(Ka), z(Va), d, z(Kb), z(Vb), d, mq, mka, mkb, O, d, lse)
     leaves = [t.double().requires_grad_(True) for t in (Qa, Qb, Ka, Va, Kb, Vb)]
@@ -306,7 +306,7 @@ def test_attention_dropout_consistency():
     mka = (torch.rand(B, La, generator=g) < 0.8).to(DEV)
     mkb = torch.ones(B, Lb, dtype=torch.bool, device=DEV)
     O = torch.empty(B * Lq, d, device=DEV)
-    lse = torch.empty(B, H_, Lq, device=DEV)
+    lse = torch.empty(2, B, H_, Lq, device=DEV)
     z = lambda t: (t, 0)
     H.attn_fwd(B, H_, dh, Lq, La, Lb, z(Qa), z(Qb), d, z(Ka), z(Va), d, z(Kb), z(Vb), d, mq, mka, mkb, O, d, lse,
                drop_p=p, seed=11, site=3)
