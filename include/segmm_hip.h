@@ -12,7 +12,7 @@
  *  - fp32 row-major everywhere; feature/leading dimensions must be multiples of 4 floats and 16-byte aligned;
  *  - return value 0 = ok, negative = error (message via segmm_last_error(), thread local); nothing throws;
  *  - re-entrant: forward runs on the Python thread, backward on an autograd-engine thread;
- *  - dropout is a counter-based Philox stream addressed by (seed, site, element index): with p = 0 results are
+ *  - dropout is a counter-based hash stream addressed by (seed, site, element index): with p = 0 results are
  *    bitwise reproducible run to run; with p > 0 they are reproducible for a fixed (seed, site).
  */
 #ifndef SEGMM_HIP_H
@@ -39,11 +39,14 @@ int segmm_l1norm(const float* x, float* y, float* inv_scale, int64_t rows, int D
  * epilogue, in this order: * row_scale[m]; + bias[n]; activation (0 none, 1 erf-GELU saving the pre-activation to
  * aux, 2 multiply by GELU'(aux)); dropout(p, seed, site) on element m*N+n; + residual[(m % res_period), n].
  * residual may alias C (accumulate).  splits > 1: partial slabs in `workspace` (splits*M*N floats), then a
- * deterministic combine; only `accumulate` (C += result) applies in that mode. */
+ * deterministic combine; only `accumulate` (C += result) applies in that mode.
+ * engine 0: v_mfma_f32_32x32x2_f32 (exact fp32 products).  engine 1: "bf16x6" -- operands are split exactly into
+ * three bf16 terms on the fly and six v_mfma_f32_32x32x16_bf16 partial products are accumulated in fp32 (error below
+ * that of a plain fp32 GEMM, 2.67x less matrix-pipe time); same layouts, epilogue and split-K. */
 int segmm_gemm(int layout, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                const float* bias, const float* row_scale, const float* residual, int ldr, int res_period,
                int activation, float* aux, int ldaux, float drop_p, uint64_t seed, uint32_t site, int splits,
-               float* workspace, int accumulate, segmm_stream_t stream);
+               float* workspace, int accumulate, int engine, segmm_stream_t stream);
 
 /* LayerNorm(d, eps) forward/backward (encoder.py:39-40,170-171,185-186,203,206,383-385,455,465).
  * forward: optional dropout on the output (embedding dropout, encoder.py:461,471).

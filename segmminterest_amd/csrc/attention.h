@@ -8,17 +8,22 @@
 //     logits = dropout(logits) / sqrt(dh)        dropout BEFORE the scale, fills included
 //     out    = softmax(logits) . [Va ; Vb]
 //
-// One workgroup = one (batch row, head) x up to 64 queries; each wave owns 16 queries and all keys.
-// The product is computed TRANSPOSED (S^T = K.Q^T) so the MFMA result has the query on the lane
-// (lane&15) and 4 consecutive keys in the 4 result registers: the softmax row-reduce is register-local
-// plus two wave shuffles, and P^T feeds the second product (O^T = V^T.P^T) straight from registers --
-// the reduction index of an f32 MFMA operand is free to permute, so "key = 4*lanegroup + step" needs no
-// cross-lane move.  The backward is two kernels, both recomputing S from Q,K and the saved
-// log-sum-exp: a query-major one (dQ, writes D = rowsum(P*dP)) and a key-major one (dK, dV) whose
-// reductions over queries stay inside one wave => no atomics, bitwise reproducible.
+// One workgroup (always 4 waves) = one (batch row, head) x up to 64 queries; each wave owns 16 queries
+// and all keys.  The product is computed TRANSPOSED (S^T = K.Q^T) so the MFMA result has the query on
+// the lane (lane&15) and 4 consecutive keys in the 4 result registers: the softmax row-reduce is
+// register-local plus two wave shuffles, and P^T feeds the second product (O^T = V^T.P^T) straight from
+// registers -- the reduction index of an f32 MFMA operand is free to permute, so
+// "key = 4*lanegroup + step" needs no cross-lane move.  The backward is two kernels, both recomputing S
+// from Q, K and the saved softmax row statistics: a query-major one (dQ, writes D = rowsum(P*dP)) and a
+// key-major one (dK, dV) whose reductions over queries stay inside one wave => no atomics, bitwise
+// reproducible.
+//
+// Staging: these kernels are latency-bound (a head is only 40 x 140 x 48), so every global->LDS phase
+// issues ALL of its loads into registers first (one memory round trip per phase), and the next phase's
+// operand (V after K, K again after V) is prefetched into registers while the current MFMAs run.
 //
 // Key blocks are padded separately to multiples of 16 (pad keys get probability 0); the dropout
-// stream is indexed by (b, h, query, padded key) so 4 consecutive keys share one Philox call.
+// stream is indexed by (b, h, query, padded key) so 4 consecutive keys share one hash call.
 #pragma once
 #include "common.h"
 
@@ -45,6 +50,9 @@ struct AttnArgs {
     float *dKb, *dVb; int lddkb;
 };
 
+constexpr int ATT_THREADS = 256;        // 4 waves, fixed: the register-batched staging sizes depend on it
+constexpr int ATT_QB = 64;              // queries (fwd, dQ) / keys (dK,dV) per workgroup
+
 __device__ __forceinline__ int round16(int x) { return (x + 15) & ~15; }
 
 template <int DH> struct AttnCfg {
@@ -53,52 +61,63 @@ template <int DH> struct AttnCfg {
     static constexpr int LDR = DH + 2;                      // "row on lane&15" reads: stride = 2 mod 4
     static constexpr int LDC = DH + ((DH % 8 == 0) ? 4 : 0);  // "column on lane&15" reads: stride = 4 mod 8
     static constexpr int LDMAX = LDR > LDC ? LDR : LDC;
+    static constexpr int UQ = (ATT_QB * KS + ATT_THREADS - 1) / ATT_THREADS;    // float4 per thread for 64 rows
 };
 
-// rows [r0, r0+nrows) of a [*, ld] matrix (columns col0..col0+DH) -> LDS [nrows][lds]; rows >= nvalid are zero
-template <int DH>
-__device__ __forceinline__ void stage_rows(float* dst, int lds, const float* src, size_t ld, int col0, int row_base,
-                                           int nrows, int nvalid, int tid, int nthr) {
-    // U loads are issued back to back before the first LDS store, so their latencies overlap (a
-    // one-load-per-iteration loop was latency-serialised: 3 waves per workgroup cannot hide it).
-    constexpr int KS = DH / 4, U = 8;
-    const int total = nrows * KS;
-    for (int base = tid; base < total; base += nthr * U) {
-        f32x4 v[U];
+// ---- register-batched staging: U float4 per thread cover nrows x DH floats; all loads first, stores later
+template <int DH, int U>
+__device__ __forceinline__ void rows_load(f32x4 (&v)[U], const float* src, size_t ld, int col0, int row_base, int nrows,
+                                          int nvalid, int tid) {
+    constexpr int KS = DH / 4;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int idx = base + u * nthr;
-            v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (idx < total) {
-                const int r = idx / KS, c4 = (idx % KS) * 4;
-                if (r < nvalid) v[u] = *(const f32x4*)(src + (size_t)(row_base + r) * ld + col0 + c4);
-            }
+    for (int u = 0; u < U; ++u) {
+        const int idx = tid + u * ATT_THREADS;
+        v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (idx < nrows * KS) {
+            const int r = idx / KS, c4 = (idx % KS) * 4;
+            if (r < nvalid) v[u] = *(const f32x4*)(src + (size_t)(row_base + r) * ld + col0 + c4);
         }
+    }
+}
+// padded key index space: rows [j0, j0+nrows): block a occupies [0, La_p), block b [La_p, La_p+Lb_p)
+template <int DH, int U>
+__device__ __forceinline__ void keys_load(f32x4 (&v)[U], const float* A, int lda, const float* Bm, int ldb, int b, int La,
+                                          int Lb, int La_p, int j0, int nrows, int col0, int tid) {
+    constexpr int KS = DH / 4;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int idx = base + u * nthr;
-            if (idx < total) {
-                const int r = idx / KS, c4 = (idx % KS) * 4;
-                float2* d = (float2*)(dst + r * lds + c4);      // row strides are even => 8-byte aligned
-                d[0] = make_float2(v[u].x, v[u].y);
-                d[1] = make_float2(v[u].z, v[u].w);
+    for (int u = 0; u < U; ++u) {
+        const int idx = tid + u * ATT_THREADS;
+        v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (idx < nrows * KS) {
+            const int j = j0 + idx / KS, c4 = (idx % KS) * 4;
+            if (j < La_p) {
+                if (j < La) v[u] = *(const f32x4*)(A + (size_t)(b * La + j) * lda + col0 + c4);
+            } else {
+                const int jb = j - La_p;
+                if (jb < Lb) v[u] = *(const f32x4*)(Bm + (size_t)(b * Lb + jb) * ldb + col0 + c4);
             }
         }
     }
 }
-
-// key-block staging: padded block a then padded block b
-template <int DH>
-__device__ __forceinline__ void stage_keys(float* dst, int lds, const float* A, int lda, const float* Bm, int ldb,
-                                           int b, int La, int Lb, int La_p, int Lb_p, int col0, int tid, int nthr) {
-    stage_rows<DH>(dst, lds, A, lda, col0, b * La, La_p, La, tid, nthr);
-    stage_rows<DH>(dst + La_p * lds, lds, Bm, ldb, col0, b * Lb, Lb_p, Lb, tid, nthr);
+template <int DH, int U>
+__device__ __forceinline__ void rows_store(const f32x4 (&v)[U], float* dst, int lds, int nrows, int tid) {
+    constexpr int KS = DH / 4;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int idx = tid + u * ATT_THREADS;
+        if (idx < nrows * KS) {
+            const int r = idx / KS, c4 = (idx % KS) * 4;
+            float2* d = (float2*)(dst + r * lds + c4);      // row strides are even => 8-byte aligned
+            d[0] = make_float2(v[u].x, v[u].y);
+            d[1] = make_float2(v[u].z, v[u].w);
+        }
+    }
 }
 
 // kmask[jp] : 1 valid, 0 masked token (-10000 fill), 2 alignment pad (probability 0)
 __device__ __forceinline__ void stage_kmask(uint8_t* km, const uint8_t* mka, const uint8_t* mkb, int b, int La, int Lb,
-                                            int La_p, int Lb_p, int tid, int nthr) {
-    for (int j = tid; j < La_p + Lb_p; j += nthr) {
+                                            int La_p, int Lb_p, int tid) {
+    for (int j = tid; j < La_p + Lb_p; j += ATT_THREADS) {
         uint8_t v;
         if (j < La_p) v = (j < La) ? (mka[(size_t)b * La + j] ? 1 : 0) : 2;
         else { const int jb = j - La_p; v = (jb < Lb) ? (mkb[(size_t)b * Lb + jb] ? 1 : 0) : 2; }
@@ -108,105 +127,136 @@ __device__ __forceinline__ void stage_kmask(uint8_t* km, const uint8_t* mka, con
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
-// scaled/masked/dropped logit and its derivative factor wrt the raw QK^T value
+// exp via v_exp_f32 (2 instructions instead of ~25 for expf): arguments are <= 0 here (x - rowmax), the
+// relative error is ~1e-6 at |x| < 20 and anything below -87 flushes to 0 exactly like expf.
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+
+// scaled/masked/dropped logit
 __device__ __forceinline__ float logit_xform(float s, bool valid, float mult, float scale) {
     return (valid ? s : -10000.0f) * mult * scale;
 }
 
-// ------------------------------------------------------------------------------------------ forward
+// S^T tiles of one wave: acc[t][r] = sum_c K[16t + 4g + r][c] Q[query][c]  (query = lane&15).
+// Two key tiles are interleaved so that consecutive MFMAs hit different accumulators (the 16x16x4 f32
+// MFMA has a 40-cycle dependent latency against a 32-cycle issue).
 template <int DH, int NT>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
+__device__ __forceinline__ void qk_tiles(f32x4 (&acc)[NT], const float* Qsa, const float* Qsb, const float* Ks, int nt,
+                                         int nta, int wave, int l15, int g) {
     using C = AttnCfg<DH>;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
-    const int l15 = lane & 15, g = lane >> 4;
-    const int bh = blockIdx.x, b = bh / p.H, h = bh % p.H;
-    const int QB = nw * 16, q_blk = blockIdx.y * QB;
-    const int La_p = round16(p.La), Lb_p = round16(p.Lb), Tp = La_p + Lb_p, nta = La_p >> 4, nt = Tp >> 4;
-    float* Qsa = smem;
-    float* Qsb = Qsa + QB * C::LDR;
-    float* KVs = Qsb + QB * C::LDR;
-    uint8_t* km = (uint8_t*)(KVs + Tp * C::LDMAX);
-    const int col0 = h * DH;
-    const int nq_valid = max(0, min(QB, p.Lq - q_blk));
-
-    stage_rows<DH>(Qsa, C::LDR, p.Qa, p.ldq, col0, b * p.Lq + q_blk, QB, nq_valid, tid, nthr);
-    stage_rows<DH>(Qsb, C::LDR, p.Qb, p.ldq, col0, b * p.Lq + q_blk, QB, nq_valid, tid, nthr);
-    stage_keys<DH>(KVs, C::LDR, p.Ka, p.ldka, p.Kb, p.ldkb, b, p.La, p.Lb, La_p, Lb_p, col0, tid, nthr);
-    stage_kmask(km, p.mka, p.mkb, b, p.La, p.Lb, La_p, Lb_p, tid, nthr);
-    __syncthreads();
-
-    const int qi = q_blk + wave * 16 + l15;          // this lane's query
-    const bool q_in = qi < p.Lq;
-    const bool q_ok = q_in && p.mq[(size_t)b * p.Lq + (q_in ? qi : 0)] != 0;
-
-    f32x4 acc[NT];
+    float qa[C::KS], qb[C::KS];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    {
-        float qa[C::KS], qb[C::KS];
+    for (int c = 0; c < C::KS; ++c) {
+        qa[c] = Qsa[(wave * 16 + l15) * C::LDR + 4 * c + g];
+        qb[c] = Qsb[(wave * 16 + l15) * C::LDR + 4 * c + g];
+    }
 #pragma unroll
-        for (int c = 0; c < C::KS; ++c) {
-            qa[c] = Qsa[(wave * 16 + l15) * C::LDR + 4 * c + g];
-            qb[c] = Qsb[(wave * 16 + l15) * C::LDR + 4 * c + g];
-        }
+    for (int t = 0; t < NT; t += 2) {
+        if (t < nt) {
+            const bool two = (t + 1 < nt) && (t + 1 < NT);
+            const bool isa0 = t < nta, isa1 = (t + 1) < nta;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            if (t < nt) {
-                const bool isa = t < nta;
-#pragma unroll
-                for (int c = 0; c < C::KS; ++c) {
-                    const float a = KVs[(16 * t + l15) * C::LDR + 4 * c + g];
-                    acc[t] = MFMA16(a, isa ? qa[c] : qb[c], acc[t]);
+            for (int c = 0; c < C::KS; ++c) {
+                const float a0 = Ks[(16 * t + l15) * C::LDR + 4 * c + g];
+                acc[t] = MFMA16(a0, isa0 ? qa[c] : qb[c], acc[t]);
+                if (t + 1 < NT) {
+                    if (two) {
+                        const float a1 = Ks[(16 * (t + 1) + l15) * C::LDR + 4 * c + g];
+                        acc[t + 1] = MFMA16(a1, isa1 ? qa[c] : qb[c], acc[t + 1]);
+                    }
                 }
             }
         }
     }
-    // mask fill, dropout, scale; acc[t][r] is key jp = 16t + 4g + r of query qi
-    float mx = -INFINITY;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        if (t < nt) {
-            const uint32_t kb = *(const uint32_t*)(km + 16 * t + 4 * g);
-            f32x4 mult = {1.f, 1.f, 1.f, 1.f};
-            if (p.drop.p > 0.f)
-                mult = drop_apply4(p.drop, (((uint64_t)bh * p.Lq + (q_in ? qi : 0)) * Tp + 16 * t + 4 * g) >> 2,
-                                   f32x4{1.f, 1.f, 1.f, 1.f});
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const uint32_t k = (kb >> (8 * r)) & 0xff;
-                float v = logit_xform(acc[t][r], q_ok && k == 1, mult[r], p.scale);
-                if (k == 2) v = -INFINITY;
-                acc[t][r] = v;
-                mx = fmaxf(mx, v);
-            }
-        }
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    float sum = 0.f;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        if (t < nt) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float e = expf(acc[t][r] - mx);
-                acc[t][r] = e;
-                sum += e;
-            }
-        }
-    }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
-    const float inv = 1.0f / sum;
-    if (g == 0 && q_in) {
-        p.lse[(size_t)bh * p.Lq + qi] = mx;
-        p.lse[(size_t)p.B * p.H * p.Lq + (size_t)bh * p.Lq + qi] = inv;
-    }
+}
 
-    __syncthreads();      // every wave is done reading K
-    stage_keys<DH>(KVs, C::LDC, p.Va, p.ldka, p.Vb, p.ldkb, b, p.La, p.Lb, La_p, Lb_p, col0, tid, nthr);
+// ------------------------------------------------------------------------------------------ forward
+template <int DH, int NT>
+__global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const AttnArgs p) {
+    using C = AttnCfg<DH>;
+    constexpr int UK = (NT * 16 * C::KS + ATT_THREADS - 1) / ATT_THREADS;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    // XCD-aware: the heads of one batch row read interleaved 4*DH-byte slices of the same token rows, so
+    // consecutive (b,h) must share an L2 or every shared cache line is fetched from HBM once per XCD
+    const int bh = xcd_remap(blockIdx.x, gridDim.x), b = bh / p.H, h = bh % p.H;
+    const int q_blk = blockIdx.y * ATT_QB;
+    const int La_p = round16(p.La), Lb_p = round16(p.Lb), Tp = La_p + Lb_p, nta = La_p >> 4, nt = Tp >> 4;
+    float* Qsa = smem;
+    float* Qsb = Qsa + ATT_QB * C::LDR;
+    float* KVs = Qsb + ATT_QB * C::LDR;
+    uint8_t* km = (uint8_t*)(KVs + Tp * C::LDMAX);
+    const int col0 = h * DH;
+    const int nq_valid = max(0, min(ATT_QB, p.Lq - q_blk));
+
+    f32x4 rqa[C::UQ], rqb[C::UQ], rk[UK];
+    rows_load<DH, C::UQ>(rqa, p.Qa, p.ldq, col0, b * p.Lq + q_blk, ATT_QB, nq_valid, tid);
+    rows_load<DH, C::UQ>(rqb, p.Qb, p.ldq, col0, b * p.Lq + q_blk, ATT_QB, nq_valid, tid);
+    keys_load<DH, UK>(rk, p.Ka, p.ldka, p.Kb, p.ldkb, b, p.La, p.Lb, La_p, 0, Tp, col0, tid);
+    stage_kmask(km, p.mka, p.mkb, b, p.La, p.Lb, La_p, Lb_p, tid);
+    rows_store<DH, C::UQ>(rqa, Qsa, C::LDR, ATT_QB, tid);
+    rows_store<DH, C::UQ>(rqb, Qsb, C::LDR, ATT_QB, tid);
+    rows_store<DH, UK>(rk, KVs, C::LDR, Tp, tid);
     __syncthreads();
+    keys_load<DH, UK>(rk, p.Va, p.ldka, p.Vb, p.ldkb, b, p.La, p.Lb, La_p, 0, Tp, col0, tid);     // V prefetch, lands under QK^T + softmax
+
+    const int qi = q_blk + wave * 16 + l15;          // this lane's query
+    const bool q_in = qi < p.Lq;
+    const bool q_ok = q_in && p.mq[(size_t)b * p.Lq + (q_in ? qi : 0)] != 0;
+    const bool wave_on = q_blk + wave * 16 < p.Lq;   // wave-uniform: waves past Lq only help staging
+
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float inv = 0.f;
+    if (wave_on) {
+        qk_tiles<DH, NT>(acc, Qsa, Qsb, KVs, nt, nta, wave, l15, g);
+        // mask fill, dropout, scale; acc[t][r] is key jp = 16t + 4g + r of query qi
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (t < nt) {
+                const uint32_t kb = *(const uint32_t*)(km + 16 * t + 4 * g);
+                f32x4 mult = {1.f, 1.f, 1.f, 1.f};
+                if (p.drop.p > 0.f)
+                    mult = drop_apply4(p.drop, (((uint64_t)bh * p.Lq + (q_in ? qi : 0)) * Tp + 16 * t + 4 * g) >> 2,
+                                       f32x4{1.f, 1.f, 1.f, 1.f});
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const uint32_t k = (kb >> (8 * r)) & 0xff;
+                    float v = logit_xform(acc[t][r], q_ok && k == 1, mult[r], p.scale);
+                    if (k == 2) v = -INFINITY;
+                    acc[t][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (t < nt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = fast_exp(acc[t][r] - mx);
+                    acc[t][r] = e;
+                    sum += e;
+                }
+            }
+        }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        inv = 1.0f / sum;
+        if (g == 0 && q_in) {
+            p.lse[(size_t)bh * p.Lq + qi] = mx;
+            p.lse[(size_t)p.B * p.H * p.Lq + (size_t)bh * p.Lq + qi] = inv;
+        }
+    }
+    __syncthreads();      // every wave is done reading K
+    rows_store<DH, UK>(rk, KVs, C::LDC, Tp, tid);
+    __syncthreads();
+    if (!wave_on) return;
 
     f32x4 o[C::CT];
 #pragma unroll
@@ -237,112 +287,116 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
 
 // ------------------------------------------------------------------------------------------ backward: dQ (+ D)
 template <int DH, int NT>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
+__global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(const AttnArgs p) {
     using C = AttnCfg<DH>;
+    constexpr int UK = (NT * 16 * C::KS + ATT_THREADS - 1) / ATT_THREADS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
-    const int bh = blockIdx.x, b = bh / p.H, h = bh % p.H;
-    const int QB = nw * 16, q_blk = blockIdx.y * QB;
+    // XCD-aware: the heads of one batch row read interleaved 4*DH-byte slices of the same token rows, so
+    // consecutive (b,h) must share an L2 or every shared cache line is fetched from HBM once per XCD
+    const int bh = xcd_remap(blockIdx.x, gridDim.x), b = bh / p.H, h = bh % p.H;
+    const int q_blk = blockIdx.y * ATT_QB;
     const int La_p = round16(p.La), Lb_p = round16(p.Lb), Tp = La_p + Lb_p, nta = La_p >> 4, nt = Tp >> 4;
     float* Qsa = smem;
-    float* Qsb = Qsa + QB * C::LDR;
-    float* dOs = Qsb + QB * C::LDR;
-    float* KVs = dOs + QB * C::LDR;
+    float* Qsb = Qsa + ATT_QB * C::LDR;
+    float* dOs = Qsb + ATT_QB * C::LDR;
+    float* KVs = dOs + ATT_QB * C::LDR;
     uint8_t* km = (uint8_t*)(KVs + Tp * C::LDMAX);
     const int col0 = h * DH;
-    const int nq_valid = max(0, min(QB, p.Lq - q_blk));
+    const int nq_valid = max(0, min(ATT_QB, p.Lq - q_blk));
 
-    stage_rows<DH>(Qsa, C::LDR, p.Qa, p.ldq, col0, b * p.Lq + q_blk, QB, nq_valid, tid, nthr);
-    stage_rows<DH>(Qsb, C::LDR, p.Qb, p.ldq, col0, b * p.Lq + q_blk, QB, nq_valid, tid, nthr);
-    stage_rows<DH>(dOs, C::LDR, p.dO, p.lddo, col0, b * p.Lq + q_blk, QB, nq_valid, tid, nthr);
-    stage_keys<DH>(KVs, C::LDR, p.Ka, p.ldka, p.Kb, p.ldkb, b, p.La, p.Lb, La_p, Lb_p, col0, tid, nthr);
-    stage_kmask(km, p.mka, p.mkb, b, p.La, p.Lb, La_p, Lb_p, tid, nthr);
+    f32x4 rk[UK];
+    {
+        f32x4 rqa[C::UQ], rqb[C::UQ], rdo[C::UQ];
+        rows_load<DH, C::UQ>(rqa, p.Qa, p.ldq, col0, b * p.Lq + q_blk, ATT_QB, nq_valid, tid);
+        rows_load<DH, C::UQ>(rqb, p.Qb, p.ldq, col0, b * p.Lq + q_blk, ATT_QB, nq_valid, tid);
+        rows_load<DH, C::UQ>(rdo, p.dO, p.lddo, col0, b * p.Lq + q_blk, ATT_QB, nq_valid, tid);
+        keys_load<DH, UK>(rk, p.Ka, p.ldka, p.Kb, p.ldkb, b, p.La, p.Lb, La_p, 0, Tp, col0, tid);
+        stage_kmask(km, p.mka, p.mkb, b, p.La, p.Lb, La_p, Lb_p, tid);
+        rows_store<DH, C::UQ>(rqa, Qsa, C::LDR, ATT_QB, tid);
+        rows_store<DH, C::UQ>(rqb, Qsb, C::LDR, ATT_QB, tid);
+        rows_store<DH, C::UQ>(rdo, dOs, C::LDR, ATT_QB, tid);
+        rows_store<DH, UK>(rk, KVs, C::LDR, Tp, tid);
+    }
     __syncthreads();
+    keys_load<DH, UK>(rk, p.Va, p.ldka, p.Vb, p.ldkb, b, p.La, p.Lb, La_p, 0, Tp, col0, tid);      // V prefetch
 
     const int qi = q_blk + wave * 16 + l15;
     const bool q_in = qi < p.Lq;
     const bool q_ok = q_in && p.mq[(size_t)b * p.Lq + (q_in ? qi : 0)] != 0;
+    const bool wave_on = q_blk + wave * 16 < p.Lq;
     const float row_mx = q_in ? p.lse[(size_t)bh * p.Lq + qi] : 0.f;
     const float row_inv = q_in ? p.lse[(size_t)p.B * p.H * p.Lq + (size_t)bh * p.Lq + qi] : 0.f;
 
-    f32x4 P[NT], fac[NT];     // P^T and d(logit)/d(raw) factor
+    f32x4 P[NT], dS[NT];              // P^T, dP^T -> dS^T
+    uint64_t live = 0;                // bit 4t+r: d(logit)/d(raw) != 0 (valid pair AND kept by dropout); the factor
+                                      // itself is the constant drop.scale * scale, so no per-element array is kept
 #pragma unroll
-    for (int t = 0; t < NT; ++t) P[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    {
-        float qa[C::KS], qb[C::KS];
-#pragma unroll
-        for (int c = 0; c < C::KS; ++c) {
-            qa[c] = Qsa[(wave * 16 + l15) * C::LDR + 4 * c + g];
-            qb[c] = Qsb[(wave * 16 + l15) * C::LDR + 4 * c + g];
-        }
+    for (int t = 0; t < NT; ++t) { P[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dS[t] = P[t]; }
+    if (wave_on) {
+        qk_tiles<DH, NT>(P, Qsa, Qsb, KVs, nt, nta, wave, l15, g);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             if (t < nt) {
-                const bool isa = t < nta;
+                const uint32_t kb = *(const uint32_t*)(km + 16 * t + 4 * g);
+                f32x4 mult = {1.f, 1.f, 1.f, 1.f};
+                if (p.drop.p > 0.f)
+                    mult = drop_apply4(p.drop, (((uint64_t)bh * p.Lq + (q_in ? qi : 0)) * Tp + 16 * t + 4 * g) >> 2,
+                                       f32x4{1.f, 1.f, 1.f, 1.f});
 #pragma unroll
-                for (int c = 0; c < C::KS; ++c) {
-                    const float a = KVs[(16 * t + l15) * C::LDR + 4 * c + g];
-                    P[t] = MFMA16(a, isa ? qa[c] : qb[c], P[t]);
+                for (int r = 0; r < 4; ++r) {
+                    const uint32_t k = (kb >> (8 * r)) & 0xff;
+                    const bool valid = q_ok && k == 1;
+                    const float v = logit_xform(P[t][r], valid, mult[r], p.scale);
+                    P[t][r] = (k == 2) ? 0.f : fast_exp(v - row_mx) * row_inv;
+                    if (valid && mult[r] != 0.f) live |= 1ull << (4 * t + r);
                 }
             }
         }
     }
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        fac[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (t < nt) {
-            const uint32_t kb = *(const uint32_t*)(km + 16 * t + 4 * g);
-            f32x4 mult = {1.f, 1.f, 1.f, 1.f};
-            if (p.drop.p > 0.f)
-                mult = drop_apply4(p.drop, (((uint64_t)bh * p.Lq + (q_in ? qi : 0)) * Tp + 16 * t + 4 * g) >> 2,
-                                   f32x4{1.f, 1.f, 1.f, 1.f});
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const uint32_t k = (kb >> (8 * r)) & 0xff;
-                const bool valid = q_ok && k == 1;
-                const float v = logit_xform(P[t][r], valid, mult[r], p.scale);
-                P[t][r] = (k == 2) ? 0.f : expf(v - row_mx) * row_inv;
-                fac[t][r] = valid ? mult[r] * p.scale : 0.f;
-            }
-        }
-    }
     __syncthreads();
-    stage_keys<DH>(KVs, C::LDR, p.Va, p.ldka, p.Vb, p.ldkb, b, p.La, p.Lb, La_p, Lb_p, col0, tid, nthr);
+    rows_store<DH, UK>(rk, KVs, C::LDR, Tp, tid);                                                   // V (row-on-lane layout)
     __syncthreads();
-    // dP^T = V . dO^T ; D = sum_j P dP ; dS^T = P (dP - D) * fac
-    f32x4 dS[NT];
+    keys_load<DH, UK>(rk, p.Ka, p.ldka, p.Kb, p.ldkb, b, p.La, p.Lb, La_p, 0, Tp, col0, tid);      // K again, for dQ
     float Dq = 0.f;
-    {
+    if (wave_on) {
+        // dP^T = V . dO^T ; D = sum_j P dP ; dS^T = P (dP - D) * fac
         float dof[C::KS];
 #pragma unroll
         for (int c = 0; c < C::KS; ++c) dof[c] = dOs[(wave * 16 + l15) * C::LDR + 4 * c + g];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            dS[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < NT; t += 2) {
             if (t < nt) {
+                const bool two = (t + 1 < nt) && (t + 1 < NT);
 #pragma unroll
                 for (int c = 0; c < C::KS; ++c) {
-                    const float a = KVs[(16 * t + l15) * C::LDR + 4 * c + g];
-                    dS[t] = MFMA16(a, dof[c], dS[t]);
+                    dS[t] = MFMA16(KVs[(16 * t + l15) * C::LDR + 4 * c + g], dof[c], dS[t]);
+                    if (t + 1 < NT) {
+                        if (two) dS[t + 1] = MFMA16(KVs[(16 * (t + 1) + l15) * C::LDR + 4 * c + g], dof[c], dS[t + 1]);
+                    }
                 }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) Dq += P[t][r] * dS[t][r];
             }
         }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            if (t < nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Dq += P[t][r] * dS[t][r];
+        Dq += __shfl_xor(Dq, 16, 64);
+        Dq += __shfl_xor(Dq, 32, 64);
+        if (g == 0 && q_in) p.Dvec[(size_t)bh * p.Lq + qi] = Dq;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            if (t < nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    dS[t][r] = ((live >> (4 * t + r)) & 1ull) ? P[t][r] * (dS[t][r] - Dq) * (p.drop.scale * p.scale) : 0.f;
     }
-    Dq += __shfl_xor(Dq, 16, 64);
-    Dq += __shfl_xor(Dq, 32, 64);
-    if (g == 0 && q_in) p.Dvec[(size_t)bh * p.Lq + qi] = Dq;
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-        if (t < nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) dS[t][r] = P[t][r] * (dS[t][r] - Dq) * fac[t][r];
-
     __syncthreads();
-    stage_keys<DH>(KVs, C::LDC, p.Ka, p.ldka, p.Kb, p.ldkb, b, p.La, p.Lb, La_p, Lb_p, col0, tid, nthr);
+    rows_store<DH, UK>(rk, KVs, C::LDC, Tp, tid);                                                   // K (column-on-lane layout)
     __syncthreads();
+    if (!wave_on) return;
     // dQ^T[c][query] = sum_key K[key][c] dS^T[key][query]; block a keys -> dQa, block b keys -> dQb
     f32x4 da[C::CT], db[C::CT];
 #pragma unroll
@@ -376,61 +430,53 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------ backward: dK, dV
-// One wave owns 16 keys (one padded key tile) and walks all query tiles.
-template <int DH>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
+// One wave owns 16 keys (one padded key tile) and walks all query tiles.  NQT = upper bound of query tiles
+// (Lq <= 16*NQT); every operand of the workgroup is fetched in ONE batch of loads.
+template <int DH, int NQT>
+__global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkv_kernel(const AttnArgs p) {
     using C = AttnCfg<DH>;
+    constexpr int ULQ = (NQT * 16 * C::KS + ATT_THREADS - 1) / ATT_THREADS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
-    const int bh = blockIdx.x, b = bh / p.H, h = bh % p.H;
+    // XCD-aware: the heads of one batch row read interleaved 4*DH-byte slices of the same token rows, so
+    // consecutive (b,h) must share an L2 or every shared cache line is fetched from HBM once per XCD
+    const int bh = xcd_remap(blockIdx.x, gridDim.x), b = bh / p.H, h = bh % p.H;
     const int La_p = round16(p.La), Lb_p = round16(p.Lb), Tp = La_p + Lb_p, nta = La_p >> 4, nt = Tp >> 4;
     const int Lq_p = round16(p.Lq), nqt = Lq_p >> 4;
-    const int KB = nw * 16;                         // keys per workgroup
-    const int k_blk = blockIdx.y * KB;              // first padded key of this workgroup
+    const int k_blk = blockIdx.y * ATT_QB;          // first padded key of this workgroup
     float* Qsa = smem;
     float* Qsb = Qsa + Lq_p * C::LDR;
     float* dOs = Qsb + Lq_p * C::LDR;
     float* Ks = dOs + Lq_p * C::LDR;
-    float* Vs = Ks + KB * C::LDR;
-    float* lses = Vs + KB * C::LDR;
+    float* Vs = Ks + ATT_QB * C::LDR;
+    float* lses = Vs + ATT_QB * C::LDR;
     float* invs = lses + Lq_p;
     float* Ds = invs + Lq_p;
     uint8_t* qm = (uint8_t*)(Ds + Lq_p);
     uint8_t* km = qm + Lq_p;
     const int col0 = h * DH;
-
-    stage_rows<DH>(Qsa, C::LDR, p.Qa, p.ldq, col0, b * p.Lq, Lq_p, p.Lq, tid, nthr);
-    stage_rows<DH>(Qsb, C::LDR, p.Qb, p.ldq, col0, b * p.Lq, Lq_p, p.Lq, tid, nthr);
-    stage_rows<DH>(dOs, C::LDR, p.dO, p.lddo, col0, b * p.Lq, Lq_p, p.Lq, tid, nthr);
-    // this workgroup's keys (padded index space)
-    for (int idx = tid; idx < KB * C::KS; idx += nthr) {
-        const int r = idx / C::KS, c4 = (idx % C::KS) * 4, jp = k_blk + r;
-        f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
-        if (jp < La_p) {
-            if (jp < p.La) {
-                kv = *(const f32x4*)(p.Ka + (size_t)(b * p.La + jp) * p.ldka + col0 + c4);
-                vv = *(const f32x4*)(p.Va + (size_t)(b * p.La + jp) * p.ldka + col0 + c4);
-            }
-        } else if (jp < Tp) {
-            const int jb = jp - La_p;
-            if (jb < p.Lb) {
-                kv = *(const f32x4*)(p.Kb + (size_t)(b * p.Lb + jb) * p.ldkb + col0 + c4);
-                vv = *(const f32x4*)(p.Vb + (size_t)(b * p.Lb + jb) * p.ldkb + col0 + c4);
-            }
+    {
+        f32x4 rqa[ULQ], rqb[ULQ], rdo[ULQ], rkk[C::UQ], rvv[C::UQ];
+        rows_load<DH, ULQ>(rqa, p.Qa, p.ldq, col0, b * p.Lq, Lq_p, p.Lq, tid);
+        rows_load<DH, ULQ>(rqb, p.Qb, p.ldq, col0, b * p.Lq, Lq_p, p.Lq, tid);
+        rows_load<DH, ULQ>(rdo, p.dO, p.lddo, col0, b * p.Lq, Lq_p, p.Lq, tid);
+        keys_load<DH, C::UQ>(rkk, p.Ka, p.ldka, p.Kb, p.ldkb, b, p.La, p.Lb, La_p, k_blk, ATT_QB, col0, tid);
+        keys_load<DH, C::UQ>(rvv, p.Va, p.ldka, p.Vb, p.ldkb, b, p.La, p.Lb, La_p, k_blk, ATT_QB, col0, tid);
+        for (int i = tid; i < Lq_p; i += ATT_THREADS) {
+            const bool in = i < p.Lq;
+            lses[i] = in ? p.lse[(size_t)bh * p.Lq + i] : 0.f;
+            invs[i] = in ? p.lse[(size_t)p.B * p.H * p.Lq + (size_t)bh * p.Lq + i] : 0.f;
+            Ds[i] = in ? p.Dvec[(size_t)bh * p.Lq + i] : 0.f;
+            qm[i] = in ? (p.mq[(size_t)b * p.Lq + i] ? 1 : 0) : 2;
         }
-        float* dk = Ks + r * C::LDR + c4; float* dv = Vs + r * C::LDR + c4;
-        dk[0] = kv.x; dk[1] = kv.y; dk[2] = kv.z; dk[3] = kv.w;
-        dv[0] = vv.x; dv[1] = vv.y; dv[2] = vv.z; dv[3] = vv.w;
+        stage_kmask(km, p.mka, p.mkb, b, p.La, p.Lb, La_p, Lb_p, tid);
+        rows_store<DH, ULQ>(rqa, Qsa, C::LDR, Lq_p, tid);
+        rows_store<DH, ULQ>(rqb, Qsb, C::LDR, Lq_p, tid);
+        rows_store<DH, ULQ>(rdo, dOs, C::LDR, Lq_p, tid);
+        rows_store<DH, C::UQ>(rkk, Ks, C::LDR, ATT_QB, tid);
+        rows_store<DH, C::UQ>(rvv, Vs, C::LDR, ATT_QB, tid);
     }
-    for (int i = tid; i < Lq_p; i += nthr) {
-        const bool in = i < p.Lq;
-        lses[i] = in ? p.lse[(size_t)bh * p.Lq + i] : 0.f;
-        invs[i] = in ? p.lse[(size_t)p.B * p.H * p.Lq + (size_t)bh * p.Lq + i] : 0.f;
-        Ds[i] = in ? p.Dvec[(size_t)bh * p.Lq + i] : 0.f;
-        qm[i] = in ? (p.mq[(size_t)b * p.Lq + i] ? 1 : 0) : 2;
-    }
-    stage_kmask(km, p.mka, p.mkb, b, p.La, p.Lb, La_p, Lb_p, tid, nthr);
     __syncthreads();
 
     const int jt = (k_blk >> 4) + wave;             // this wave's key tile
@@ -451,7 +497,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
     for (int ct = 0; ct < C::CT; ++ct) { dk[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
     for (int qt = 0; qt < nqt; ++qt) {
-        // S[query 16qt+4g+r][key jp] and dP likewise
+        // S[query 16qt+4g+r][key jp] and dP likewise (two independent accumulators, interleaved)
         f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < C::KS; ++c) {
@@ -469,7 +515,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
             float mult = 1.f;
             if (p.drop.p > 0.f && qf != 2) mult = drop_mult1(p.drop, ((uint64_t)bh * p.Lq + qi) * Tp + jp);
             const float v = logit_xform(s[r], valid, mult, p.scale);
-            const float pr = (kflag == 2 || qf == 2) ? 0.f : expf(v - lses[qi]) * invs[qi];
+            const float pr = (kflag == 2 || qf == 2) ? 0.f : fast_exp(v - lses[qi]) * invs[qi];
             Pv[r] = pr;
             dSv[r] = valid ? pr * (dp[r] - Ds[qi]) * mult * p.scale : 0.f;
         }

@@ -8,6 +8,7 @@
 #include "attention.h"
 #include "common.h"
 #include "gemm.h"
+#include "gemm_bf16x6.h"
 #include "loss.h"
 #include "rowops.h"
 
@@ -48,11 +49,8 @@ template <int DH>
 static int attn_launch_fwd(const AttnArgs& a, hipStream_t s) {
     using C = AttnCfg<DH>;
     const int Tp = ((a.La + 15) & ~15) + ((a.Lb + 15) & ~15);
-    const int qtiles = (a.Lq + 15) / 16;
-    const int nw = qtiles < 4 ? qtiles : 4;
-    const int QB = nw * 16;
-    dim3 grid(a.B * a.H, (a.Lq + QB - 1) / QB), block(64 * nw);
-    const size_t lds = sizeof(float) * (2 * QB * C::LDR + Tp * C::LDMAX) + Tp;
+    dim3 grid(a.B * a.H, (a.Lq + ATT_QB - 1) / ATT_QB), block(ATT_THREADS);
+    const size_t lds = sizeof(float) * (2 * ATT_QB * C::LDR + Tp * C::LDMAX) + Tp;
     if (Tp <= 64) hipLaunchKernelGGL((attn_fwd_kernel<DH, 4>), grid, block, lds, s, a);
     else hipLaunchKernelGGL((attn_fwd_kernel<DH, 12>), grid, block, lds, s, a);
     LAUNCH_CHECK();
@@ -64,24 +62,20 @@ static int attn_launch_bwd(const AttnArgs& a, hipStream_t s) {
     using C = AttnCfg<DH>;
     const int Tp = ((a.La + 15) & ~15) + ((a.Lb + 15) & ~15);
     {
-        const int qtiles = (a.Lq + 15) / 16;
-        const int nw = qtiles < 4 ? qtiles : 4;
-        const int QB = nw * 16;
-        dim3 grid(a.B * a.H, (a.Lq + QB - 1) / QB), block(64 * nw);
-        const size_t lds = sizeof(float) * (3 * QB * C::LDR + Tp * C::LDMAX) + Tp;
+        dim3 grid(a.B * a.H, (a.Lq + ATT_QB - 1) / ATT_QB), block(ATT_THREADS);
+        const size_t lds = sizeof(float) * (3 * ATT_QB * C::LDR + Tp * C::LDMAX) + Tp;
         if (Tp <= 64) hipLaunchKernelGGL((attn_bwd_dq_kernel<DH, 4>), grid, block, lds, s, a);
         else hipLaunchKernelGGL((attn_bwd_dq_kernel<DH, 12>), grid, block, lds, s, a);
         LAUNCH_CHECK();
     }
     {
-        const int ktiles = Tp / 16;
-        const int nw = ktiles < 4 ? ktiles : 4;
-        const int KB = nw * 16;
         const int Lq_p = (a.Lq + 15) & ~15;
-        dim3 grid(a.B * a.H, (Tp + KB - 1) / KB), block(64 * nw);
-        const size_t lds = sizeof(float) * (3 * Lq_p * C::LDR + 2 * KB * C::LDR + 3 * Lq_p) + Lq_p + Tp;
+        SEGMM_REQUIRE(Lq_p <= 128, "attn_bwd: %d queries > 128 not built", a.Lq);
+        dim3 grid(a.B * a.H, (Tp + ATT_QB - 1) / ATT_QB), block(ATT_THREADS);
+        const size_t lds = sizeof(float) * (3 * Lq_p * C::LDR + 2 * ATT_QB * C::LDR + 3 * Lq_p) + Lq_p + Tp;
         SEGMM_REQUIRE(lds <= 160 * 1024, "attn_bwd: %zu bytes of LDS needed (Lq=%d)", lds, a.Lq);
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH>), grid, block, lds, s, a);
+        if (Lq_p <= 64) hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH, 4>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH, 8>), grid, block, lds, s, a);
         LAUNCH_CHECK();
     }
     return 0;
@@ -125,8 +119,9 @@ int segmm_l1norm(const float* x, float* y, float* inv_scale, int64_t rows, int D
 int segmm_gemm(int layout, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                const float* bias, const float* row_scale, const float* residual, int ldr, int res_period,
                int activation, float* aux, int ldaux, float drop_p, uint64_t seed, uint32_t site, int splits,
-               float* workspace, int accumulate, segmm_stream_t stream) {
+               float* workspace, int accumulate, int engine, segmm_stream_t stream) {
     SEGMM_REQUIRE(layout >= 0 && layout <= 2, "gemm: bad layout %d", layout);
+    SEGMM_REQUIRE(engine == 0 || engine == 1, "gemm: engine %d (0 = f32 MFMA, 1 = bf16x6 split MFMA)", engine);
     SEGMM_REQUIRE(A && B && C, "gemm: null operand");
     if (M <= 0 || N <= 0) return 0;
     SEGMM_REQUIRE(K > 0, "gemm: K=%d", K);
@@ -166,9 +161,15 @@ int segmm_gemm(int layout, int M, int N, int K, const float* A, int lda, const f
     }
     dim3 grid(g.nbm * g.nbn, 1, splits), block(256);
     hipStream_t s = (hipStream_t)stream;
-    if (layout == 0) hipLaunchKernelGGL((gemm_f32_mfma<true, true>), grid, block, 0, s, g);
-    else if (layout == 1) hipLaunchKernelGGL((gemm_f32_mfma<true, false>), grid, block, 0, s, g);
-    else hipLaunchKernelGGL((gemm_f32_mfma<false, false>), grid, block, 0, s, g);
+    if (engine == 0) {
+        if (layout == 0) hipLaunchKernelGGL((gemm_f32_mfma<true, true>), grid, block, 0, s, g);
+        else if (layout == 1) hipLaunchKernelGGL((gemm_f32_mfma<true, false>), grid, block, 0, s, g);
+        else hipLaunchKernelGGL((gemm_f32_mfma<false, false>), grid, block, 0, s, g);
+    } else {
+        if (layout == 0) hipLaunchKernelGGL((gemm_bf16x6_mfma<true, true>), grid, block, 0, s, g);
+        else if (layout == 1) hipLaunchKernelGGL((gemm_bf16x6_mfma<true, false>), grid, block, 0, s, g);
+        else hipLaunchKernelGGL((gemm_bf16x6_mfma<false, false>), grid, block, 0, s, g);
+    }
     LAUNCH_CHECK();
     if (splits > 1) {
         const long long n4 = (long long)M * (N / 4);

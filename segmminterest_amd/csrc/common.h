@@ -23,56 +23,56 @@ int segmm_fail(int code, const char* fmt, ...);
 
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
-// ---------------------------------------------------------------- Philox4x32-10 counter RNG
+// ---------------------------------------------------------------- counter-based dropout stream
 // Dropout masks are a pure function of (seed, site, element index), so the backward kernels
-// regenerate them instead of storing them.  One call yields 4 x 32 bits = 4 consecutive elements.
+// regenerate them instead of storing them.  The generator is a stateless integer hash (two chained
+// rounds of a 32-bit avalanche mix, ~14 VALU ops) that yields 4 x 16 random bits for the 4 consecutive
+// elements of one "quad"; the first version used Philox4x32-10 (~120 ops per quad), which made the
+// attention kernels VALU-bound (rocprof: 23 VALU instructions per MFMA).  16 bits per element
+// quantise the drop probability to 1/65536 (0.1 -> 6554/65536 = 0.100006); the rescale uses the
+// quantised value, so E[mask] = 1 exactly.
 struct DropCfg {
     float p;              // drop probability (0 => disabled)
-    float scale;          // 1/(1-p)
-    uint32_t thresh;      // keep iff r >= thresh, thresh = p * 2^32
+    float scale;          // 1/(1-p_quantised)
+    uint32_t thresh;      // keep iff r16 >= thresh, thresh = round(p * 65536)
     uint32_t seed_lo, seed_hi;
     uint32_t site;        // distinct per dropout site in the model
 };
 
-__device__ __forceinline__ uint4 philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2,
-                                               uint32_t c3) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
-        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    return make_uint4(c0, c1, c2, c3);
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
 }
-
-// keep-mask bits for the 4 elements [4*q, 4*q+3] of a site (q = element_index / 4)
-__device__ __forceinline__ uint4 drop_rand4(const DropCfg& d, uint64_t q) {
-    return philox4x32_10(d.seed_lo, d.seed_hi, (uint32_t)q, (uint32_t)(q >> 32), d.site, 0x5e6d3u);
+// 64 random bits for the 4 elements [4*q, 4*q+3] of a site (q = element_index / 4)
+__device__ __forceinline__ uint2 drop_rand_quad(const DropCfg& d, uint64_t q) {
+    const uint32_t k = d.seed_lo ^ (d.site * 0x9E3779B9u) ^ ((uint32_t)(q >> 32) * 0x85EBCA6Bu);
+    const uint32_t a = mix32((uint32_t)q ^ k);
+    const uint32_t b = mix32(a ^ d.seed_hi ^ 0x68E31DA4u);
+    return make_uint2(a, b);
 }
 __device__ __forceinline__ f32x4 drop_apply4(const DropCfg& d, uint64_t q, f32x4 v) {
-    const uint4 r = drop_rand4(d, q);
-    v.x = (r.x >= d.thresh) ? v.x * d.scale : 0.f;
-    v.y = (r.y >= d.thresh) ? v.y * d.scale : 0.f;
-    v.z = (r.z >= d.thresh) ? v.z * d.scale : 0.f;
-    v.w = (r.w >= d.thresh) ? v.w * d.scale : 0.f;
+    const uint2 r = drop_rand_quad(d, q);
+    v.x = ((r.x & 0xffffu) >= d.thresh) ? v.x * d.scale : 0.f;
+    v.y = ((r.x >> 16) >= d.thresh) ? v.y * d.scale : 0.f;
+    v.z = ((r.y & 0xffffu) >= d.thresh) ? v.z * d.scale : 0.f;
+    v.w = ((r.y >> 16) >= d.thresh) ? v.w * d.scale : 0.f;
     return v;
 }
 // multiplier (0 or scale) of one element
 __device__ __forceinline__ float drop_mult1(const DropCfg& d, uint64_t elem) {
-    const uint4 r = drop_rand4(d, elem >> 2);
+    const uint2 r = drop_rand_quad(d, elem >> 2);
     const uint32_t lane = (uint32_t)(elem & 3);
-    const uint32_t x = lane == 0 ? r.x : lane == 1 ? r.y : lane == 2 ? r.z : r.w;
+    const uint32_t w = lane < 2 ? r.x : r.y;
+    const uint32_t x = (lane & 1) ? (w >> 16) : (w & 0xffffu);
     return (x >= d.thresh) ? d.scale : 0.f;
 }
 
 static inline DropCfg make_drop(float p, uint64_t seed, uint32_t site) {
     DropCfg d;
     d.p = p;
-    d.scale = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
-    double t = (double)p * 4294967296.0;
-    d.thresh = p <= 0.f ? 0u : (t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t);
+    double t = (double)p * 65536.0 + 0.5;
+    d.thresh = p <= 0.f ? 0u : (t >= 65535.0 ? 65535u : (uint32_t)t);
+    d.scale = p > 0.f ? (float)(65536.0 / (65536.0 - (double)d.thresh)) : 1.0f;
     d.seed_lo = (uint32_t)seed;
     d.seed_hi = (uint32_t)(seed >> 32);
     d.site = site;

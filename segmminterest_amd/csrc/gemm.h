@@ -15,7 +15,7 @@
 // f32 MFMA takes ONE scalar per lane per operand, the k order inside an 8-wide chunk is permuted
 // (lane half h supplies k = 4h..4h+3) so a lane fetches its four k values with one ds_read_b128.
 // The epilogue restages each 32 x 32 accumulator tile through LDS so that global traffic is
-// row-major float4 and one Philox call serves 4 consecutive elements.
+// row-major float4 and one dropout-hash call serves 4 consecutive elements.
 #pragma once
 #include "common.h"
 

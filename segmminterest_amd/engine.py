@@ -16,14 +16,16 @@ Per encoder layer (video side; the user side mirrors it when live), reference fi
 """
 from __future__ import annotations
 
+import contextlib
 import math
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
 
 from . import hipabi as H
 
-# dropout site ids (distinct Philox streams): site = backbone*4096 + layer*32 + kind
+# dropout site ids (distinct hash streams): site = backbone*4096 + layer*32 + kind
 K_EMB_V, K_EMB_U, K_ATT_V, K_ATT_U, K_AO_V, K_AO_U, K_MI_V, K_MI_U, K_MO_V, K_MO_U = range(1, 11)
 MLP_INNER_DROPOUT = 0.1      # kn_util MLP default (kn_util/nn_utils/layers/mlp.py:8), never overridden
 
@@ -91,6 +93,15 @@ class ParamStore:
         self.scratch: Dict[tuple, torch.Tensor] = {}
         self._params = None
         self.bucket_hook = None      # callable(bucket_name): set by the data-parallel trainer
+        self._side_stream = None
+        self._on_side = False
+        self.overlap = os.environ.get("SEGMM_OVERLAP", "1") != "0"
+
+    # -- second HIP stream for weight/bias gradients (see class SideWork)
+    def side_stream(self):
+        if self._side_stream is None or self._side_stream.device != self.flat.device:
+            self._side_stream = torch.cuda.Stream(device=self.flat.device)
+        return self._side_stream
 
     # -- layout
     def _layout(self):
@@ -189,16 +200,44 @@ def _splits_for(M, N, K):
     return max(1, min(32, ktiles, (1024 + tiles - 1) // tiles))
 
 
+@contextlib.contextmanager
+def side_work(store):
+    """Weight- and bias-gradient launches of a Linear are independent of its input-gradient GEMM.  They are
+    enqueued on a second HIP stream (forked from the main stream here, joined by ``join_side``) so that
+    their workgroups fill the CUs that the last, partial round of a 960-workgroup dgrad GEMM leaves idle
+    (profiles/README.md: 1.875 rounds on 512 slots).  Buffers these launches read carry the layer index in
+    their scratch name, so the main stream never overwrites them before the join."""
+    if not store.overlap:
+        yield
+        return
+    main = torch.cuda.current_stream()
+    side = store.side_stream()
+    ev = torch.cuda.Event()
+    ev.record(main)
+    side.wait_event(ev)
+    store._on_side = True
+    try:
+        with torch.cuda.stream(side):
+            yield
+    finally:
+        store._on_side = False
+
+
+def join_side(store):
+    if store.overlap and store._side_stream is not None:
+        torch.cuda.current_stream().wait_stream(store._side_stream)
+
+
 def _wgrad(store, dY, ldy, y_off, X, ldx, x_off, Mrows, n_out, n_in, gW, accumulate=False):
     """gW[n_out, n_in] (+)= dY[:, y_off:y_off+n_out]^T . X[:, x_off:x_off+n_in]  (split-K over tokens)."""
     splits = _splits_for(n_out, n_in, Mrows)
-    ws = store.buf("splitk_ws", (max(splits, 1) * n_out * n_in,)) if splits > 1 else None
+    ws = store.buf("splitk_ws_side" if store._on_side else "splitk_ws", (max(splits, 1) * n_out * n_in,)) if splits > 1 else None
     H.gemm(H.LAYOUT_TN, n_out, n_in, Mrows, dY, ldy, X, ldx, gW, n_in, splits=splits, workspace=ws,
            accumulate=accumulate, a_off=y_off, b_off=x_off)
 
 
 def _colsum(store, X, ld, M, N, out, x_off=0, w=None, accumulate=False):
-    ws = store.buf("colsum_ws", (H.colsum_chunks(M) * N,))
+    ws = store.buf("colsum_ws_side" if store._on_side else "colsum_ws", (H.colsum_chunks(M) * N,))
     H.colsum(X, ld, M, N, out, ws, w=w, accumulate=accumulate, x_off=x_off)
 
 
@@ -352,13 +391,15 @@ class BackboneRun:
                 drop_b=(self.p_drop, _site(self.bi, i, k_mo)), seed=seed)
         if dM is None:
             dM = dR2
-        _wgrad(st, dM, d, 0, sv["Hh"], d, 0, M, d, d, st.g(ff + "1.weight", gbuf))
-        _colsum(st, dM, d, M, d, st.g(ff + "1.bias", gbuf))
+        with side_work(st):
+            _wgrad(st, dM, d, 0, sv["Hh"], d, 0, M, d, d, st.g(ff + "1.weight", gbuf))
+            _colsum(st, dM, d, M, d, st.g(ff + "1.bias", gbuf))
         dG = st.buf("dG" + tag, (M, d))
         H.gemm(H.LAYOUT_NN, M, d, d, dM, d, st.p(ff + "1.weight"), d, dG, d, activation=H.ACT_DGELU, aux=sv["G"], ldaux=d,
                drop_p=self.p_inner, seed=seed, site=_site(self.bi, i, k_mi))
-        _wgrad(st, dG, d, 0, sv["X1"], d, 0, M, d, d, st.g(ff + "0.weight", gbuf))
-        _colsum(st, dG, d, M, d, st.g(ff + "0.bias", gbuf))
+        with side_work(st):
+            _wgrad(st, dG, d, 0, sv["X1"], d, 0, M, d, d, st.g(ff + "0.weight", gbuf))
+            _colsum(st, dG, d, M, d, st.g(ff + "0.bias", gbuf))
         dX1 = st.buf("dX1" + tag, (M, d))
         H.gemm(H.LAYOUT_NN, M, d, d, dG, d, st.p(ff + "0.weight"), d, dX1, d, residual=dR2, ldr=d, res_period=M)
         dR1 = st.buf("dR1" + tag, (M, d))
@@ -367,8 +408,9 @@ class BackboneRun:
                 drop_b=(self.p_drop, _site(self.bi, i, k_ao)), seed=seed)
         if dZ is None:
             dZ = dR1
-        _wgrad(st, dZ, d, 0, sv["A"], d, 0, M, d, d, st.g(ca + "ff_%s.weight" % side, gbuf))
-        _colsum(st, dZ, d, M, d, st.g(ca + "ff_%s.bias" % side, gbuf))
+        with side_work(st):
+            _wgrad(st, dZ, d, 0, sv["A"], d, 0, M, d, d, st.g(ca + "ff_%s.weight" % side, gbuf))
+            _colsum(st, dZ, d, M, d, st.g(ca + "ff_%s.bias" % side, gbuf))
         dA = st.buf("dA" + tag, (M, d))
         H.gemm(H.LAYOUT_NN, M, d, d, dZ, d, st.p(ca + "ff_%s.weight" % side), d, dA, d)
         return dR1, dA
@@ -381,24 +423,25 @@ class BackboneRun:
         L = "%sencoder.layers.%d." % (P, i)
         ca = L + "cross_attn."
         Yv, Yu = rec["Yv"], rec["Yu"]
-        dYv, dYu = st.buf("dYv", (Mv, nv * d)), st.buf("dYu", (Mu, nu * d))
+        dYv, dYu = st.buf("dYv%d" % i, (Mv, nv * d)), st.buf("dYu%d" % i, (Mu, nu * d))
         Dv = st.buf("attnD", (B * Hh * max(S, Lt),))
-        dR1v, dAv = self._side_post_bwd(i, L, "vid", rec["v"], dXv_out, Mv, (K_AO_V, K_MI_V, K_MO_V), gbuf, "v")
+        dR1v, dAv = self._side_post_bwd(i, L, "vid", rec["v"], dXv_out, Mv, (K_AO_V, K_MI_V, K_MO_V), gbuf, "v%d" % i)
         H.attn_bwd(B, Hh, dh, S, S, Lt, (Yv, 0), (Yv, d), nv * d, (Yv, 2 * d), (Yv, 3 * d), nv * d, (Yu, 0), (Yu, d), nu * d,
                    self.vm, self.vm, self.um, rec["lse_v"], dAv, d, Dv, (dYv, 0), (dYv, d), nv * d, (dYv, 2 * d), (dYv, 3 * d),
                    nv * d, (dYu, 0), (dYu, d), nu * d, drop_p=self.p_drop, seed=self.seed, site=_site(self.bi, i, K_ATT_V))
         dR1u = None
         if full:
-            dR1u, dAu = self._side_post_bwd(i, L, "usr", rec["u"], dXu_out, Mu, (K_AO_U, K_MI_U, K_MO_U), gbuf, "u")
+            dR1u, dAu = self._side_post_bwd(i, L, "usr", rec["u"], dXu_out, Mu, (K_AO_U, K_MI_U, K_MO_U), gbuf, "u%d" % i)
             H.attn_bwd(B, Hh, dh, Lt, S, Lt, (Yu, 2 * d), (Yu, 3 * d), nu * d, (Yv, 4 * d), (Yv, 5 * d), nv * d,
                        (Yu, 4 * d), (Yu, 5 * d), nu * d, self.um, self.vm, self.um, rec["lse_u"], dAu, d, Dv,
                        (dYu, 2 * d), (dYu, 3 * d), nu * d, (dYv, 4 * d), (dYv, 5 * d), nv * d, (dYu, 4 * d), (dYu, 5 * d), nu * d,
                        drop_p=self.p_drop, seed=self.seed, site=_site(self.bi, i, K_ATT_U))
         # fused projection weights / inputs
-        _wgrad(st, dYv, nv * d, 0, rec["Xv"], d, 0, Mv, nv * d, d, _group_view(st, ca + "v2v_proj.0.weight", nv * d * d, gbuf))
-        _colsum(st, dYv, nv * d, Mv, nv * d, _group_view(st, ca + "v2v_proj.0.bias", nv * d, gbuf))
-        _wgrad(st, dYu, nu * d, 0, rec["Xu"], d, 0, Mu, nu * d, d, _group_view(st, ca + "t2v_proj.1.weight", nu * d * d, gbuf))
-        _colsum(st, dYu, nu * d, Mu, nu * d, _group_view(st, ca + "t2v_proj.1.bias", nu * d, gbuf))
+        with side_work(st):
+            _wgrad(st, dYv, nv * d, 0, rec["Xv"], d, 0, Mv, nv * d, d, _group_view(st, ca + "v2v_proj.0.weight", nv * d * d, gbuf))
+            _colsum(st, dYv, nv * d, Mv, nv * d, _group_view(st, ca + "v2v_proj.0.bias", nv * d, gbuf))
+            _wgrad(st, dYu, nu * d, 0, rec["Xu"], d, 0, Mu, nu * d, d, _group_view(st, ca + "t2v_proj.1.weight", nu * d * d, gbuf))
+            _colsum(st, dYu, nu * d, Mu, nu * d, _group_view(st, ca + "t2v_proj.1.bias", nu * d, gbuf))
         dXv_in = st.buf("dXv_in%d" % (i & 1), (Mv, d))
         H.gemm(H.LAYOUT_NN, Mv, d, nv * d, dYv, nv * d, st.p(ca + "v2v_proj.0.weight"), d, dXv_in, d, residual=dR1v, ldr=d, res_period=Mv)
         dXu_in = st.buf("dXu_in%d" % (i & 1), (Mu, d))
@@ -418,6 +461,7 @@ class BackboneRun:
         for i in reversed(range(max(self.N - 1, 0))):
             dXv, dXu = self._layer_bwd(i, sv["layers"][i], dXv, dXu, gbuf)
             if on_bucket is not None:
+                join_side(st)
                 on_bucket("%slayer%d" % (P, i))
         # ---- embedding backward
         dpre_v = st.buf("dpre_v", (Mv, d))
@@ -429,6 +473,7 @@ class BackboneRun:
             _ln_bwd(st, dXu, sv["pre_u"], sv["meu"], sv["reu"], P + "usr_ln.weight", P + "usr_ln.bias", gbuf, dpre_u, None, Mu, d,
                     drop_y=(self.p_drop, _site(self.bi, 0, K_EMB_U)), seed=self.seed)
             self._embed_bwd("usr", dpre_u, B, Lt, gbuf)
+        join_side(st)
         if on_bucket is not None:
             on_bucket(P + "embed")
 
@@ -456,8 +501,9 @@ class BackboneRun:
         else:
             x = sv["%s_x" % side]
             Din = x.shape[-1]
-            _wgrad(st, dpre, d, 0, x, Din, 0, M, d, Din, gtab)
-            _colsum(st, dpre, d, M, d, st.g(P + "%s_proj.bias" % side, gbuf))
+            with side_work(st):
+                _wgrad(st, dpre, d, 0, x, Din, 0, M, d, Din, gtab)
+                _colsum(st, dpre, d, M, d, st.g(P + "%s_proj.bias" % side, gbuf))
 
 
 def _group_view(store, first_name, numel, gbuf):

@@ -24,7 +24,7 @@ _i, _i64, _f, _u64, _u32, _p = C.c_int, C.c_int64, C.c_float, C.c_uint64, C.c_ui
 # name -> argtypes; the single source of truth for the exported symbol set (tests check it against the header)
 SIGNATURES = {
     "segmm_l1norm": [_p, _p, _p, _i64, _i, _p],
-    "segmm_gemm": [_i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _p, _i, _f, _u64, _u32, _i, _p, _i, _p],
+    "segmm_gemm": [_i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _p, _i, _f, _u64, _u32, _i, _p, _i, _i, _p],
     "segmm_layernorm_fwd": [_p, _p, _p, _p, _p, _p, _i64, _i, _f, _f, _u64, _u32, _p],
     "segmm_layernorm_bwd_parts": [_i64],
     "segmm_layernorm_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _f, _u32, _f, _u32, _u64, _p],
@@ -98,6 +98,10 @@ def _f32c(t, name="tensor"):
 
 
 GEMM_PROFILE = None       # bench.py sets this to a list to time every GEMM launch with HIP events
+ENGINE_F32, ENGINE_BF16X6 = 0, 1
+# default engine of gemm(): the exact 3-way bf16 split on the bf16 matrix cores (fp32-class accuracy, faster);
+# SEGMM_GEMM=f32 selects the f32-input MFMA kernel instead (A/B and parity cross-checks)
+GEMM_ENGINE = {"f32": 0, "bf16x6": 1}[os.environ.get("SEGMM_GEMM", "bf16x6")]
 LAYOUT_NT, LAYOUT_NN, LAYOUT_TN = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_DGELU = 0, 1, 2
 
@@ -111,7 +115,7 @@ def l1norm(x, out=None, inv_scale=None):
 
 def gemm(layout, M, N, K, A, lda, B, ldb, Cout, ldc, bias=None, row_scale=None, residual=None, ldr=0, res_period=0,
          activation=0, aux=None, ldaux=0, drop_p=0.0, seed=0, site=0, splits=1, workspace=None, accumulate=False,
-         a_off=0, b_off=0, c_off=0):
+         a_off=0, b_off=0, c_off=0, engine=None):
     """Raw strided GEMM; ``*_off`` are element offsets into the tensors (column slices of fused buffers)."""
     _dev(A, B, Cout)
     es = 4
@@ -122,7 +126,8 @@ def gemm(layout, M, N, K, A, lda, B, ldb, Cout, ldc, bias=None, row_scale=None, 
     _check(lib().segmm_gemm(layout, M, N, K, A.data_ptr() + a_off * es, lda, B.data_ptr() + b_off * es, ldb,
                             Cout.data_ptr() + c_off * es, ldc, _ptr(bias), _ptr(row_scale), _ptr(residual), ldr,
                             res_period, activation, _ptr(aux), ldaux, float(drop_p), int(seed), int(site),
-                            int(splits), _ptr(workspace), int(bool(accumulate)), _stream()), "segmm_gemm")
+                            int(splits), _ptr(workspace), int(bool(accumulate)),
+                            GEMM_ENGINE if engine is None else int(engine), _stream()), "segmm_gemm")
     if prof is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()

@@ -146,17 +146,33 @@ class DPComm:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.pending = []
+        # gloo has no device collectives for every op: device tensors are staged through the host.
+        # Only the test harness uses that (two ranks sharing one GPU); production is nccl = RCCL.
+        self.host_staged = dist.is_initialized() and dist.get_backend(group) == "gloo"
+
+    def _all_reduce(self, t, async_op=False):
+        if self.host_staged and t.is_cuda:
+            h = t.cpu()
+            self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM, group=self.group)
+            t.copy_(h)
+            return None
+        return self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group, async_op=async_op)
 
     def global_label_stats(self, v, v2, norms):
         """(v_all, v2_all, norms_global): all-gather the per-row view lengths, sum the 3 normalisers."""
         if self.world == 1:
             return v, v2, norms
         both = torch.stack([v, v2])                               # [2, B_local]; every rank holds the same B_local
-        gathered = torch.empty((self.world * 2, both.shape[1]), dtype=both.dtype, device=both.device)
-        self.dist.all_gather_into_tensor(gathered, both, group=self.group)
+        if self.host_staged and both.is_cuda:
+            hg = torch.empty((self.world * 2, both.shape[1]), dtype=both.dtype)
+            self.dist.all_gather_into_tensor(hg, both.cpu(), group=self.group)
+            gathered = hg.to(both.device)
+        else:
+            gathered = torch.empty((self.world * 2, both.shape[1]), dtype=both.dtype, device=both.device)
+            self.dist.all_gather_into_tensor(gathered, both, group=self.group)
         gathered = gathered.view(self.world, 2, both.shape[1])
         norms_g = norms.clone()
-        self.dist.all_reduce(norms_g, op=self.dist.ReduceOp.SUM, group=self.group)
+        self._all_reduce(norms_g)
         return gathered[:, 0].reshape(-1).contiguous(), gathered[:, 1].reshape(-1).contiguous(), norms_g
 
     def reduce_bucket(self, flat_grad, start, end):
@@ -164,7 +180,9 @@ class DPComm:
         normalised by global counts, so SUM -- not mean -- reproduces the single-process gradient)."""
         if self.world == 1 or end <= start:
             return
-        self.pending.append(self.dist.all_reduce(flat_grad[start:end], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
+        w = self._all_reduce(flat_grad[start:end], async_op=True)
+        if w is not None:
+            self.pending.append(w)
 
     def finish(self):
         for w in self.pending:
@@ -173,7 +191,7 @@ class DPComm:
 
     def sum_scalar(self, t):
         if self.world > 1:
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+            self._all_reduce(t)
         return t
 
 
@@ -190,8 +208,9 @@ class Trainer:
     the reference's hot loop (main_for_seq_leave_earlystop_SegMM.py:269-300) minus its host syncs.
     Gradient clipping is a no-op in the reference (exhausted generator at :298) and is therefore absent."""
 
-    def __init__(self, model, lr=1e-3, weight_decay=1e-4, comm: Optional[DPComm] = None, overlap=True):
+    def __init__(self, model, lr=1e-3, weight_decay=1e-4, comm: Optional[DPComm] = None, overlap=True, dropout=True):
         self.model = model
+        self.dropout = dropout      # False: run the step in eval mode (deterministic; used by the DP equivalence tests)
         self.opt = FusedAdamW(model, lr=lr, weight_decay=weight_decay)
         self.comm = comm if comm is not None else DPComm()
         self.overlap = overlap
@@ -219,7 +238,7 @@ class Trainer:
 
     def train_step(self, batch: Dict[str, torch.Tensor]):
         model, st = self.model, self.model._store
-        model.train()
+        model.train(self.dropout)
         self.opt.zero_grad()
         it = model.input_type
         usr = self.normalize("user", batch["user"]) if it["user"] != "id" else None

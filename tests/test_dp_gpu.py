@@ -1,0 +1,74 @@
+"""Data-parallel trainer end to end on the GPU box: two ranks share the single GPU (gloo, host-staged
+collectives -- RCCL refuses two ranks on one device), each running the full HIP path on its row shard.
+After 2 steps the parameters must equal a single-process run on the whole batch: this exercises the global
+loss normalisers, the bucket hooks fired from inside the backward, the SUM all-reduce and the fused AdamW."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from helpers import ROOT, build_model, load_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _batch(cfg, B):
+    from segmminterest_amd.synth import make_batch
+    return make_batch(B, cfg["S"], cfg["Lt"], cfg["D_in"], n_users=cfg.get("n_users", 5) or 5, n_items=cfg.get("n_items", 5) or 5, seed=21)
+
+
+def _run(rank, world, port, name, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from segmminterest_amd.trainer import DPComm, Trainer, shard_rows
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        cfg, g, _, _ = load_case(name)
+        model = build_model(cfg)
+        model.load_state_dict(g["sd"])
+        model = model.cuda()
+        tr = Trainer(model, comm=DPComm(), overlap=True, dropout=False)
+        full = _batch(cfg, 16)
+        s, e = shard_rows(16, world, rank)
+        shard = {k: v[s:e].cuda() for k, v in full.items()}
+        losses, gflat = [], None
+        for i in range(2):
+            out = tr.train_step(shard)
+            losses.append(float(tr.comm.sum_scalar(out["loss"].detach().clone())))
+            if i == 0:
+                gflat = model._store.gflat.detach().cpu().numpy().copy()      # the all-reduced gradients of step 1
+        if rank == 0:
+            q.put((losses, gflat, {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}))   # numpy: no torch shm handles
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["img_d32_N3_alllosses", "both_fh2"])
+def test_two_ranks_equal_single_process(name):
+    ctx = mp.get_context("spawn")
+    results = {}
+    for world in (1, 2):
+        q = ctx.Queue()
+        port = 29600 + (os.getpid() + world) % 300
+        procs = [ctx.Process(target=_run, args=(r, world, port, name, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = q.get(timeout=240)
+        for p in procs:
+            p.join(60)
+            assert p.exitcode == 0
+        results[world] = res
+    (l1, g1, sd1), (l2, g2, sd2) = results[1], results[2]
+    for a, b in zip(l1, l2):
+        assert abs(a - b) <= 1e-5 * max(1.0, abs(a)), (l1, l2)
+    g1, g2 = torch.from_numpy(g1), torch.from_numpy(g2)
+    assert float((g1 - g2).abs().max()) <= 1e-4 * float(g1.abs().max()), "summed shard gradients != whole-batch gradients"
+    for k in sd1:     # after 2 AdamW steps; lr-sized slack for elements whose gradient is rounding noise (Adam sign flips)
+        assert torch.allclose(torch.from_numpy(sd1[k]), torch.from_numpy(sd2[k]), rtol=1e-4, atol=4.5e-3), k

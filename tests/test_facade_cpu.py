@@ -69,7 +69,7 @@ def test_c_abi_exports_every_declared_symbol():
     L = hipabi.lib()
     assert L.segmm_abi_version() == hipabi.ABI_VERSION
     # argument validation works without touching the GPU
-    assert L.segmm_gemm(7, 1, 4, 4, None, 4, None, 4, None, 4, None, None, None, 0, 0, 0, None, 0, 0.0, 0, 0, 1, None, 0, None) != 0
+    assert L.segmm_gemm(7, 1, 4, 4, None, 4, None, 4, None, 4, None, None, None, 0, 0, 0, None, 0, 0.0, 0, 0, 1, None, 0, 0, None) != 0
     assert b"layout" in L.segmm_last_error()
 
 

@@ -375,3 +375,54 @@ def test_embed_id():
     dpe = torch.empty(S, d, device=DEV)
     H.pe_grad(dpre, d, B, S, d, dpe)
     assert torch.allclose(dpe, dpre.view(B, S, d).sum(0), atol=1e-5)
+
+
+# ------------------------------------------------------------------ bf16x6 split-MFMA engine
+@pytest.mark.parametrize("lay,M,N,K,splits", [("NT", 360, 96, 48, 1), ("NT", 20480, 768, 768, 1), ("NT", 63, 32, 40, 1),
+                                              ("NN", 360, 48, 96, 1), ("NN", 20480, 768, 3072, 1),
+                                              ("TN", 96, 48, 360, 1), ("TN", 768, 768, 20480, 16), ("TN", 32, 40, 63, 2)])
+def test_gemm_bf16x6_matches_fp64_like_fp32(lay, M, N, K, splits):
+    """engine 1: exact 3-way bf16 split, six partial products, fp32 accumulation -- must be at least as close
+    to the fp64 product as the f32-MFMA engine (same tolerance), on every operand layout."""
+    H = _abi()
+    L = {"NT": 0, "NN": 1, "TN": 2}[lay]
+    g = torch.Generator().manual_seed(M + N + K)
+    rnd = lambda *s: (torch.randn(*s, generator=g) * torch.exp(torch.randn(*s, generator=g))).to(DEV)   # wide dynamic range
+    if lay == "NT":
+        A, Bm = rnd(M, K), rnd(N, K); lda, ldb = K, K; ref = A.double() @ Bm.double().t()
+    elif lay == "NN":
+        A, Bm = rnd(M, K), rnd(K, N); lda, ldb = K, N; ref = A.double() @ Bm.double()
+    else:
+        A, Bm = rnd(K, M), rnd(K, N); lda, ldb = M, N; ref = A.double().t() @ Bm.double()
+    ws = torch.empty(max(splits, 1) * M * N, device=DEV)
+    outs = {}
+    for eng in (H.ENGINE_F32, H.ENGINE_BF16X6):
+        C = torch.full((M, N), float("nan"), device=DEV)
+        H.gemm(L, M, N, K, A, lda, Bm, ldb, C, N, splits=splits, workspace=ws, engine=eng)
+        outs[eng] = C
+    scale = ref.abs().mean().item()
+    e32 = (outs[H.ENGINE_F32].double() - ref).abs().max().item() / scale
+    e6 = (outs[H.ENGINE_BF16X6].double() - ref).abs().max().item() / scale
+    assert e6 < 2e-5 * math.sqrt(K), (e6, e32)
+    assert e6 <= 2.0 * e32 + 1e-7, ("bf16x6 less accurate than fp32 MFMA", e6, e32)
+
+
+def test_gemm_bf16x6_identity_exact_and_epilogue():
+    H = _abi()
+    n = 128
+    A = torch.eye(n, device=DEV)
+    Bm = (torch.randn(n, n, device=DEV) * 3.7)
+    C = torch.empty(n, n, device=DEV)
+    H.gemm(H.LAYOUT_NN, n, n, n, A, n, Bm, n, C, n, engine=H.ENGINE_BF16X6)
+    assert torch.equal(C, Bm)                      # hi + mid + lo reassembles every fp32 value exactly
+    H.gemm(H.LAYOUT_TN, n, n, n, Bm, n, A, n, C, n, engine=H.ENGINE_BF16X6)
+    assert torch.equal(C, Bm.t())
+    M, N, K = 360, 96, 64
+    X, W, b = _rand(M, K, seed=8), _rand(N, K, seed=9, scale=0.3), _rand(N, seed=10)
+    res = _rand(40, N, seed=11)
+    out, aux = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+    H.gemm(H.LAYOUT_NT, M, N, K, X, K, W, K, out, N, bias=b, residual=res, ldr=N, res_period=40, activation=H.ACT_GELU,
+           aux=aux, ldaux=N, engine=H.ENGINE_BF16X6)
+    pre = X.double() @ W.double().t() + b.double()
+    assert (aux.double() - pre).abs().max().item() < 1e-5
+    assert (out.double() - (torch.nn.functional.gelu(pre) + res.double().repeat(M // 40, 1))).abs().max().item() < 1e-5

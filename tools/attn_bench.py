@@ -1,0 +1,38 @@
+"""Micro-benchmark of the attention kernels at BASELINE config 2 (video side: Lq=40, keys 40+100, h=16, dh=48)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from segmminterest_amd import hipabi as H
+
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+p_drop = float(sys.argv[2]) if len(sys.argv) > 2 else 0.1
+B, Hh, dh, Lq, La, Lb = 512, 16, 48, int(os.environ.get("LQ", 40)), 40, 100
+d = Hh * dh
+dev = "cuda"
+Yv = torch.randn(B * La, 4 * d, device=dev)
+Yu = torch.randn(B * Lb, 2 * d, device=dev)
+Qsrc = Yv if Lq == La else torch.randn(B * Lq, 4 * d, device=dev)
+vm = (torch.rand(B, La, device=dev) < 0.8).view(torch.uint8) if False else (torch.rand(B, La, device=dev) < 0.8).to(torch.uint8)
+um = (torch.rand(B, Lb, device=dev) < 0.8).to(torch.uint8)
+qm = vm if Lq == La else (torch.rand(B, Lq, device=dev) < 0.8).to(torch.uint8)
+O = torch.empty(B * Lq, d, device=dev); lse = torch.empty(2, B, Hh, Lq, device=dev)
+dO = torch.randn(B * Lq, d, device=dev); Dv = torch.empty(B, Hh, Lq, device=dev)
+dYv = torch.empty_like(Yv); dYu = torch.empty_like(Yu); dQs = dYv if Lq == La else torch.empty_like(Qsrc)
+fwd = lambda: H.attn_fwd(B, Hh, dh, Lq, La, Lb, (Qsrc, 0), (Qsrc, d), 4 * d, (Yv, 2 * d), (Yv, 3 * d), 4 * d, (Yu, 0), (Yu, d), 2 * d,
+                         qm, vm, um, O, d, lse, drop_p=p_drop, seed=1, site=3)
+bwd = lambda: H.attn_bwd(B, Hh, dh, Lq, La, Lb, (Qsrc, 0), (Qsrc, d), 4 * d, (Yv, 2 * d), (Yv, 3 * d), 4 * d, (Yu, 0), (Yu, d), 2 * d,
+                         qm, vm, um, lse, dO, d, Dv, (dQs, 0), (dQs, d), 4 * d, (dYv, 2 * d), (dYv, 3 * d), 4 * d, (dYu, 0), (dYu, d), 2 * d,
+                         drop_p=p_drop, seed=1, site=3)
+T = La + Lb
+for name, fn, flops in (("fwd", fwd, 4.0 * dh * Lq * T), ("bwd(dq+dkv)", bwd, 14.0 * dh * Lq * T)):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / iters
+    print("attn %-12s p=%.2f Lq=%d  %8.1f us  %6.2f TFLOP/s (unpadded algorithmic)" % (name, p_drop, Lq, us, flops * B * Hh / us / 1e6))

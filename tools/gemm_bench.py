@@ -27,7 +27,8 @@ for lay, M, N, K in shapes:
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     splits = max(1, min(32, (K + 31) // 32, (1024 + tiles - 1) // tiles)) if lay == "TN" else 1
     ws = torch.empty(splits * M * N, device=dev) if splits > 1 else None
-    run = lambda: H.gemm(L, M, N, K, A, lda, B, ldb, C, N, splits=splits, workspace=ws)
+    eng = {"f32": 0, "bf16x6": 1}[os.environ.get("SEGMM_GEMM", "f32")]
+    run = lambda: H.gemm(L, M, N, K, A, lda, B, ldb, C, N, splits=splits, workspace=ws, engine=eng)
     for _ in range(3):
         run()
     torch.cuda.synchronize()
@@ -38,4 +39,4 @@ for lay, M, N, K in shapes:
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / iters
-    print("%-22s splits %2d  %8.1f us  %6.1f TFLOP/s  (%.1f%% of 157.3)" % (tag, splits, us, 2.0 * M * N * K / us / 1e6, 2.0 * M * N * K / us / 1e6 / 1.573))
+    print(os.environ.get("SEGMM_GEMM", "f32"), "%-22s splits %2d  %8.1f us  %6.1f TFLOP/s  (%.1f%% of 157.3)" % (tag, splits, us, 2.0 * M * N * K / us / 1e6, 2.0 * M * N * K / us / 1e6 / 1.573))
