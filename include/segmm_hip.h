@@ -48,6 +48,22 @@ int segmm_gemm(int layout, int M, int N, int K, const float* A, int lda, const f
                int activation, float* aux, int ldaux, float drop_p, uint64_t seed, uint32_t site, int splits,
                float* workspace, int accumulate, int engine, segmm_stream_t stream);
 
+/* Same GEMM on the bf16x6 engine with optional PRE-SPLIT operands: a_planes / b_planes point at bf16 planes
+ * [nplanes][rows][ld] (plane p at base + p*pstride elements, rows k-contiguous, NT layout only) produced by
+ * segmm_split3 / segmm_split3_transpose -- the main loop then does no conversion work for that operand.  Weights are
+ * split once per optimizer step; W^T planes turn the dgrad (dX = dY.W) into the NT form as well.
+ * nplanes = 2 keeps only hi and mid (three partial products, ~2e-5 relative error): offered for weight gradients,
+ * which are leaves of the backward graph. */
+int segmm_gemm_x(int layout, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                 const float* bias, const float* row_scale, const float* residual, int ldr, int res_period,
+                 int activation, float* aux, int ldaux, float drop_p, uint64_t seed, uint32_t site, int splits,
+                 float* workspace, int accumulate, const uint16_t* a_planes, int64_t a_pstride,
+                 const uint16_t* b_planes, int64_t b_pstride, int nplanes, segmm_stream_t stream);
+/* exact split x = hi + mid + lo into three bf16 planes: planes[p*pstride + i] (flat), or the transposed copy
+ * planes[p*pstride + c*R + r] of an [R, C] row-major matrix with leading dimension ld. */
+int segmm_split3(const float* x, uint16_t* planes, int64_t n, int64_t pstride, segmm_stream_t stream);
+int segmm_split3_transpose(const float* x, int R, int C, int ld, uint16_t* planes, int64_t pstride, segmm_stream_t stream);
+
 /* LayerNorm(d, eps) forward/backward (encoder.py:39-40,170-171,185-186,203,206,383-385,455,465).
  * forward: optional dropout on the output (embedding dropout, encoder.py:461,471).
  * backward: dy is first multiplied by the forward's output-dropout mask (drop_y_*); dx_drop (may be NULL) receives

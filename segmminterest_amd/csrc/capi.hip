@@ -116,11 +116,20 @@ int segmm_l1norm(const float* x, float* y, float* inv_scale, int64_t rows, int D
     return 0;
 }
 
-int segmm_gemm(int layout, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-               const float* bias, const float* row_scale, const float* residual, int ldr, int res_period,
-               int activation, float* aux, int ldaux, float drop_p, uint64_t seed, uint32_t site, int splits,
-               float* workspace, int accumulate, int engine, segmm_stream_t stream) {
+static int gemm_impl(int layout, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                     const float* bias, const float* row_scale, const float* residual, int ldr, int res_period,
+                     int activation, float* aux, int ldaux, float drop_p, uint64_t seed, uint32_t site, int splits,
+                     float* workspace, int accumulate, int engine, const uint16_t* a_planes, long long a_pstride,
+                     const uint16_t* b_planes, long long b_pstride, int nplanes, segmm_stream_t stream) {
     SEGMM_REQUIRE(layout >= 0 && layout <= 2, "gemm: bad layout %d", layout);
+    SEGMM_REQUIRE(nplanes == 3 || nplanes == 2, "gemm: nplanes %d (3 = six products, 2 = three products)", nplanes);
+    if (a_planes || b_planes) {
+        SEGMM_REQUIRE(engine == 1 && layout == 0, "gemm: pre-split operands need engine 1 and the NT layout");
+        SEGMM_REQUIRE(K % 8 == 0 && (!a_planes || (lda % 8 == 0 && aligned16(a_planes) && a_pstride % 8 == 0)) &&
+                      (!b_planes || (ldb % 8 == 0 && aligned16(b_planes) && b_pstride % 8 == 0)), "gemm: plane operands need K, ld, stride %% 8 == 0 and 16-byte alignment");
+    }
+    if (a_planes && !A) A = (const float*)a_planes;      // only the planes are read
+    if (b_planes && !B) B = (const float*)b_planes;
     SEGMM_REQUIRE(engine == 0 || engine == 1, "gemm: engine %d (0 = f32 MFMA, 1 = bf16x6 split MFMA)", engine);
     SEGMM_REQUIRE(A && B && C, "gemm: null operand");
     if (M <= 0 || N <= 0) return 0;
@@ -166,9 +175,25 @@ int segmm_gemm(int layout, int M, int N, int K, const float* A, int lda, const f
         else if (layout == 1) hipLaunchKernelGGL((gemm_f32_mfma<true, false>), grid, block, 0, s, g);
         else hipLaunchKernelGGL((gemm_f32_mfma<false, false>), grid, block, 0, s, g);
     } else {
-        if (layout == 0) hipLaunchKernelGGL((gemm_bf16x6_mfma<true, true>), grid, block, 0, s, g);
-        else if (layout == 1) hipLaunchKernelGGL((gemm_bf16x6_mfma<true, false>), grid, block, 0, s, g);
-        else hipLaunchKernelGGL((gemm_bf16x6_mfma<false, false>), grid, block, 0, s, g);
+        GemmPlanes q;
+        q.Ap = (const __bf16*)a_planes; q.a_pstride = a_pstride;
+        q.Bp = (const __bf16*)b_planes; q.b_pstride = b_pstride;
+#define X6(AK, BK, AP, BP, NP) hipLaunchKernelGGL((gemm_bf16x6_mfma<AK, BK, AP, BP, NP>), grid, block, 0, s, g, q)
+        if (nplanes == 3) {
+            if (layout == 0) {
+                if (a_planes && b_planes) X6(true, true, true, true, 3);
+                else if (b_planes) X6(true, true, false, true, 3);
+                else if (a_planes) X6(true, true, true, false, 3);
+                else X6(true, true, false, false, 3);
+            } else if (layout == 1) X6(true, false, false, false, 3);
+            else X6(false, false, false, false, 3);
+        } else {
+            SEGMM_REQUIRE(!a_planes && !b_planes, "gemm: nplanes 2 is implemented for fp32 operands only");
+            if (layout == 0) X6(true, true, false, false, 2);
+            else if (layout == 1) X6(true, false, false, false, 2);
+            else X6(false, false, false, false, 2);
+        }
+#undef X6
     }
     LAUNCH_CHECK();
     if (splits > 1) {
@@ -179,6 +204,41 @@ int segmm_gemm(int layout, int M, int N, int K, const float* A, int lda, const f
                            (long long)M * N, C, ldc, M, N, accumulate);
         LAUNCH_CHECK();
     }
+    return 0;
+}
+
+int segmm_gemm(int layout, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+               const float* bias, const float* row_scale, const float* residual, int ldr, int res_period,
+               int activation, float* aux, int ldaux, float drop_p, uint64_t seed, uint32_t site, int splits,
+               float* workspace, int accumulate, int engine, segmm_stream_t stream) {
+    return gemm_impl(layout, M, N, K, A, lda, B, ldb, C, ldc, bias, row_scale, residual, ldr, res_period, activation, aux, ldaux,
+                     drop_p, seed, site, splits, workspace, accumulate, engine, nullptr, 0, nullptr, 0, 3, stream);
+}
+
+int segmm_gemm_x(int layout, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                 const float* bias, const float* row_scale, const float* residual, int ldr, int res_period,
+                 int activation, float* aux, int ldaux, float drop_p, uint64_t seed, uint32_t site, int splits,
+                 float* workspace, int accumulate, const uint16_t* a_planes, int64_t a_pstride,
+                 const uint16_t* b_planes, int64_t b_pstride, int nplanes, segmm_stream_t stream) {
+    return gemm_impl(layout, M, N, K, A, lda, B, ldb, C, ldc, bias, row_scale, residual, ldr, res_period, activation, aux, ldaux,
+                     drop_p, seed, site, splits, workspace, accumulate, 1, a_planes, a_pstride, b_planes, b_pstride, nplanes, stream);
+}
+
+int segmm_split3(const float* x, uint16_t* planes, int64_t n, int64_t pstride, segmm_stream_t stream) {
+    SEGMM_REQUIRE(x && planes && n % 4 == 0 && pstride % 4 == 0 && aligned16(x) && (((uintptr_t)planes) & 7) == 0, "split3: n/stride %% 4 and alignment");
+    if (n <= 0) return 0;
+    long long blocks = (n / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(split3_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (__bf16*)planes, (long long)n, (long long)pstride);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int segmm_split3_transpose(const float* x, int R, int Cc, int ld, uint16_t* planes, int64_t pstride, segmm_stream_t stream) {
+    SEGMM_REQUIRE(x && planes && R > 0 && Cc > 0 && ld >= Cc, "split3_transpose: bad args");
+    hipLaunchKernelGGL(split3_transpose_kernel, dim3((Cc + 31) / 32, (R + 31) / 32), dim3(256), 0, (hipStream_t)stream, x, R, Cc, ld,
+                       (__bf16*)planes, (long long)pstride);
+    LAUNCH_CHECK();
     return 0;
 }
 

@@ -96,6 +96,14 @@ class ParamStore:
         self._side_stream = None
         self._on_side = False
         self.overlap = os.environ.get("SEGMM_OVERLAP", "1") != "0"
+        # pre-split bf16 planes of the weights for the bf16x6 GEMM engine: W planes (forward) and W^T planes (dgrad
+        # in the NT form), refreshed when the parameters change (one split pass per optimizer step)
+        self.use_planes = H.GEMM_ENGINE == H.ENGINE_BF16X6 and os.environ.get("SEGMM_PLANES", "1") != "0"
+        self.wgrad_planes = 2 if os.environ.get("SEGMM_WGRAD", "x6") == "x3" else 3      # x3 = opt-in, see DESIGN.md
+        self.wplanes = self.wTplanes = None
+        self.fused_version = 0
+        self._planes_key = None
+        self._transposes: List[Tuple[int, int, int]] = []
 
     # -- second HIP stream for weight/bias gradients (see class SideWork)
     def side_stream(self):
@@ -121,8 +129,26 @@ class ParamStore:
                     ok = False
                     break
             if ok:
+                self.refresh_planes()
                 return
         self._build(params)
+        self.refresh_planes()
+
+    def refresh_planes(self):
+        if not self.use_planes:
+            return
+        # staleness: in-place updates through torch (optimizer.step, load_state_dict) bump the parameters' version
+        # counters; the fused AdamW kernel bumps ``fused_version`` itself
+        key = (self.flat._version, self.fused_version, self.flat.data_ptr(), sum(self._params[n]._version for n in self.live_names))
+        if key == self._planes_key:
+            return
+        if self.wplanes is None or self.wplanes.shape[1] != self.n_live or self.wplanes.device != self.flat.device:
+            self.wplanes = torch.empty((3, self.n_live), dtype=torch.bfloat16, device=self.flat.device)
+            self.wTplanes = torch.empty((3, self.n_live), dtype=torch.bfloat16, device=self.flat.device)
+        H.split3(self.flat, self.wplanes, self.n_live)
+        for off, R, Cc in self._transposes:
+            H.split3_transpose(self.flat, R, Cc, Cc, self.wTplanes, x_off=off, p_off=off)
+        self._planes_key = key
 
     def _build(self, params):
         first = next(iter(params.values()))
@@ -137,7 +163,7 @@ class ParamStore:
         for bname, groups in self._layout():
             start = off
             for grp in groups:
-                off = (off + 3) & ~3
+                off = (off + 7) & ~7          # 8 floats: 32-byte fp32 alignment = 16-byte alignment of the bf16 planes
                 for name in grp:
                     if name not in params:
                         raise KeyError("layout names unknown parameter %s" % name)
@@ -149,7 +175,7 @@ class ParamStore:
                         raise RuntimeError("fused group member %s has %d elements (not a multiple of 4)" % (name, n))
                     order.append((name, off, n))
                     off += n
-            off = (off + 3) & ~3
+            off = (off + 7) & ~7
             buckets.append((bname, start, off))
         n_live = off
         live_names = [n for n, _, _ in order]
@@ -171,6 +197,15 @@ class ParamStore:
         self.n_live = n_live
         self.live_names = live_names
         self.scratch = {}
+        # weight matrices whose transpose is needed by the input-gradient GEMMs: every fused projection group and
+        # every d x d Linear inside an encoder layer (the embedding / head weights have no dgrad GEMM)
+        self._transposes = []
+        for _, groups in self._layout():
+            for grp in groups:
+                n0 = grp[0]
+                if n0.endswith(".weight") and ".encoder.layers." in "." + n0 and params[n0].dim() == 2 and "ln_" not in n0:
+                    self._transposes.append((self.index[n0][0], sum(params[n].shape[0] for n in grp), params[n0].shape[1]))
+        self._planes_key = None
 
     # -- access
     def p(self, name) -> torch.Tensor:
@@ -233,7 +268,23 @@ def _wgrad(store, dY, ldy, y_off, X, ldx, x_off, Mrows, n_out, n_in, gW, accumul
     splits = _splits_for(n_out, n_in, Mrows)
     ws = store.buf("splitk_ws_side" if store._on_side else "splitk_ws", (max(splits, 1) * n_out * n_in,)) if splits > 1 else None
     H.gemm(H.LAYOUT_TN, n_out, n_in, Mrows, dY, ldy, X, ldx, gW, n_in, splits=splits, workspace=ws,
-           accumulate=accumulate, a_off=y_off, b_off=x_off)
+           accumulate=accumulate, a_off=y_off, b_off=x_off, nplanes=store.wgrad_planes if H.GEMM_ENGINE == H.ENGINE_BF16X6 else 3)
+
+
+def _lin_fwd(store, M, N, K, X, wname, out, ldo, **kw):
+    """out[M,N] = X[M,K] . W[N,K]^T (+ epilogue); W = the parameter (or fused group starting at) ``wname``."""
+    if store.use_planes and K % 8 == 0:
+        kw["b_planes"] = (store.wplanes, store.index[wname][0])
+    H.gemm(H.LAYOUT_NT, M, N, K, X, K, store.p(wname), K, out, ldo, **kw)
+
+
+def _lin_dgrad(store, M, n_in, n_out, dY, wname, out, **kw):
+    """out[M,n_in] = dY[M,n_out] . W[n_out,n_in] (+ epilogue).  With W^T planes this is the NT form (both operands
+    k-contiguous), otherwise the NN layout on the fp32 weights."""
+    if store.use_planes and n_out % 8 == 0:
+        H.gemm(H.LAYOUT_NT, M, n_in, n_out, dY, n_out, None, n_out, out, n_in, b_planes=(store.wTplanes, store.index[wname][0]), **kw)
+    else:
+        H.gemm(H.LAYOUT_NN, M, n_in, n_out, dY, n_out, store.p(wname), n_in, out, n_in, **kw)
 
 
 def _colsum(store, X, ld, M, N, out, x_off=0, w=None, accumulate=False):
@@ -304,8 +355,8 @@ class BackboneRun:
             x = vid_feat.contiguous().float()
             sv["vid_x"] = x
             Din = x.shape[-1]
-            H.gemm(H.LAYOUT_NT, Mv, d, Din, x, Din, st.p(P + "vid_proj.weight"), Din, pre_v, d,
-                   bias=st.p(P + "vid_proj.bias"), residual=st.p(P + "vid_pe.weight"), ldr=d, res_period=S)
+            _lin_fwd(st, Mv, d, Din, x, P + "vid_proj.weight", pre_v, d,
+                     bias=st.p(P + "vid_proj.bias"), residual=st.p(P + "vid_pe.weight"), ldr=d, res_period=S)
         Ev, mev, rev = _empty(ref, Mv, d), _empty(ref, Mv), _empty(ref, Mv)
         H.layernorm_fwd(pre_v, st.p(P + "vid_ln.weight"), st.p(P + "vid_ln.bias"), Ev, mev, rev, drop_p=p_drop, seed=seed,
                         site=_site(self.bi, 0, K_EMB_V))
@@ -319,8 +370,8 @@ class BackboneRun:
             xu = usr_feat.contiguous().float()
             sv["usr_x"] = xu
             Din = xu.shape[-1]
-            H.gemm(H.LAYOUT_NT, Mu, d, Din, xu, Din, st.p(P + "usr_proj.weight"), Din, pre_u, d,
-                   bias=st.p(P + "usr_proj.bias"), residual=st.p(P + "usr_pe.weight"), ldr=d, res_period=Lt)
+            _lin_fwd(st, Mu, d, Din, xu, P + "usr_proj.weight", pre_u, d,
+                     bias=st.p(P + "usr_proj.bias"), residual=st.p(P + "usr_pe.weight"), ldr=d, res_period=Lt)
         Eu, meu, reu = _empty(ref, Mu, d), _empty(ref, Mu), _empty(ref, Mu)
         H.layernorm_fwd(pre_u, st.p(P + "usr_ln.weight"), st.p(P + "usr_ln.bias"), Eu, meu, reu, drop_p=p_drop, seed=seed,
                         site=_site(self.bi, 0, K_EMB_U))
@@ -337,16 +388,16 @@ class BackboneRun:
         k_ao, k_mi, k_mo = kinds
         ca = L + "cross_attn."
         R1 = _empty(X, M, d)
-        H.gemm(H.LAYOUT_NT, M, d, d, A, d, st.p(ca + "ff_%s.weight" % side), d, R1, d, bias=st.p(ca + "ff_%s.bias" % side),
+        _lin_fwd(st, M, d, d, A, ca + "ff_%s.weight" % side, R1, d, bias=st.p(ca + "ff_%s.bias" % side),
                residual=X, ldr=d, res_period=M, drop_p=self.p_drop, seed=seed, site=_site(self.bi, i, k_ao))
         X1, m1, r1 = _empty(X, M, d), _empty(X, M), _empty(X, M)
         H.layernorm_fwd(R1, st.p(ca + "ln_%s.weight" % side), st.p(ca + "ln_%s.bias" % side), X1, m1, r1)
         G, Hh = _empty(X, M, d), _empty(X, M, d)
         ff = L + "ff_%s.layers." % side
-        H.gemm(H.LAYOUT_NT, M, d, d, X1, d, st.p(ff + "0.weight"), d, Hh, d, bias=st.p(ff + "0.bias"),
+        _lin_fwd(st, M, d, d, X1, ff + "0.weight", Hh, d, bias=st.p(ff + "0.bias"),
                activation=H.ACT_GELU, aux=G, ldaux=d, drop_p=self.p_inner, seed=seed, site=_site(self.bi, i, k_mi))
         R2 = _empty(X, M, d)
-        H.gemm(H.LAYOUT_NT, M, d, d, Hh, d, st.p(ff + "1.weight"), d, R2, d, bias=st.p(ff + "1.bias"),
+        _lin_fwd(st, M, d, d, Hh, ff + "1.weight", R2, d, bias=st.p(ff + "1.bias"),
                residual=X1, ldr=d, res_period=M, drop_p=self.p_drop, seed=seed, site=_site(self.bi, i, k_mo))
         X2, m2, r2 = _empty(X, M, d), _empty(X, M), _empty(X, M)
         H.layernorm_fwd(R2, st.p(L + "ln_%s.weight" % side), st.p(L + "ln_%s.bias" % side), X2, m2, r2)
@@ -360,8 +411,8 @@ class BackboneRun:
         L = "%sencoder.layers.%d." % (P, i)
         ca = L + "cross_attn."
         Yv, Yu = _empty(Xv, Mv, nv * d), _empty(Xv, Mu, nu * d)
-        H.gemm(H.LAYOUT_NT, Mv, nv * d, d, Xv, d, st.p(ca + "v2v_proj.0.weight"), d, Yv, nv * d, bias=st.p(ca + "v2v_proj.0.bias"))
-        H.gemm(H.LAYOUT_NT, Mu, nu * d, d, Xu, d, st.p(ca + "t2v_proj.1.weight"), d, Yu, nu * d, bias=st.p(ca + "t2v_proj.1.bias"))
+        _lin_fwd(st, Mv, nv * d, d, Xv, ca + "v2v_proj.0.weight", Yv, nv * d, bias=st.p(ca + "v2v_proj.0.bias"))
+        _lin_fwd(st, Mu, nu * d, d, Xu, ca + "t2v_proj.1.weight", Yu, nu * d, bias=st.p(ca + "t2v_proj.1.bias"))
         Av, lse_v = _empty(Xv, Mv, d), _empty(Xv, 2, B, Hh, S)
         H.attn_fwd(B, Hh, dh, S, S, Lt, (Yv, 0), (Yv, d), nv * d, (Yv, 2 * d), (Yv, 3 * d), nv * d, (Yu, 0), (Yu, d), nu * d,
                    self.vm, self.vm, self.um, Av, d, lse_v, drop_p=self.p_drop, seed=self.seed, site=_site(self.bi, i, K_ATT_V))
@@ -395,13 +446,13 @@ class BackboneRun:
             _wgrad(st, dM, d, 0, sv["Hh"], d, 0, M, d, d, st.g(ff + "1.weight", gbuf))
             _colsum(st, dM, d, M, d, st.g(ff + "1.bias", gbuf))
         dG = st.buf("dG" + tag, (M, d))
-        H.gemm(H.LAYOUT_NN, M, d, d, dM, d, st.p(ff + "1.weight"), d, dG, d, activation=H.ACT_DGELU, aux=sv["G"], ldaux=d,
+        _lin_dgrad(st, M, d, d, dM, ff + "1.weight", dG, activation=H.ACT_DGELU, aux=sv["G"], ldaux=d,
                drop_p=self.p_inner, seed=seed, site=_site(self.bi, i, k_mi))
         with side_work(st):
             _wgrad(st, dG, d, 0, sv["X1"], d, 0, M, d, d, st.g(ff + "0.weight", gbuf))
             _colsum(st, dG, d, M, d, st.g(ff + "0.bias", gbuf))
         dX1 = st.buf("dX1" + tag, (M, d))
-        H.gemm(H.LAYOUT_NN, M, d, d, dG, d, st.p(ff + "0.weight"), d, dX1, d, residual=dR2, ldr=d, res_period=M)
+        _lin_dgrad(st, M, d, d, dG, ff + "0.weight", dX1, residual=dR2, ldr=d, res_period=M)
         dR1 = st.buf("dR1" + tag, (M, d))
         dZ = st.buf("dZ" + tag, (M, d)) if self.p_drop > 0 else None
         _ln_bwd(st, dX1, sv["R1"], sv["m1"], sv["r1"], ca + "ln_%s.weight" % side, ca + "ln_%s.bias" % side, gbuf, dR1, dZ, M, d,
@@ -412,7 +463,7 @@ class BackboneRun:
             _wgrad(st, dZ, d, 0, sv["A"], d, 0, M, d, d, st.g(ca + "ff_%s.weight" % side, gbuf))
             _colsum(st, dZ, d, M, d, st.g(ca + "ff_%s.bias" % side, gbuf))
         dA = st.buf("dA" + tag, (M, d))
-        H.gemm(H.LAYOUT_NN, M, d, d, dZ, d, st.p(ca + "ff_%s.weight" % side), d, dA, d)
+        _lin_dgrad(st, M, d, d, dZ, ca + "ff_%s.weight" % side, dA)
         return dR1, dA
 
     def _layer_bwd(self, i, rec, dXv_out, dXu_out, gbuf):
@@ -443,12 +494,12 @@ class BackboneRun:
             _wgrad(st, dYu, nu * d, 0, rec["Xu"], d, 0, Mu, nu * d, d, _group_view(st, ca + "t2v_proj.1.weight", nu * d * d, gbuf))
             _colsum(st, dYu, nu * d, Mu, nu * d, _group_view(st, ca + "t2v_proj.1.bias", nu * d, gbuf))
         dXv_in = st.buf("dXv_in%d" % (i & 1), (Mv, d))
-        H.gemm(H.LAYOUT_NN, Mv, d, nv * d, dYv, nv * d, st.p(ca + "v2v_proj.0.weight"), d, dXv_in, d, residual=dR1v, ldr=d, res_period=Mv)
+        _lin_dgrad(st, Mv, d, nv * d, dYv, ca + "v2v_proj.0.weight", dXv_in, residual=dR1v, ldr=d, res_period=Mv)
         dXu_in = st.buf("dXu_in%d" % (i & 1), (Mu, d))
         if full:
-            H.gemm(H.LAYOUT_NN, Mu, d, nu * d, dYu, nu * d, st.p(ca + "t2v_proj.1.weight"), d, dXu_in, d, residual=dR1u, ldr=d, res_period=Mu)
+            _lin_dgrad(st, Mu, d, nu * d, dYu, ca + "t2v_proj.1.weight", dXu_in, residual=dR1u, ldr=d, res_period=Mu)
         else:
-            H.gemm(H.LAYOUT_NN, Mu, d, nu * d, dYu, nu * d, st.p(ca + "t2v_proj.1.weight"), d, dXu_in, d)
+            _lin_dgrad(st, Mu, d, nu * d, dYu, ca + "t2v_proj.1.weight", dXu_in)
         return dXv_in, dXu_in
 
     def backward(self, d_vid_out: torch.Tensor, gbuf: Optional[torch.Tensor] = None, on_bucket=None):

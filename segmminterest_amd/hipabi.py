@@ -25,6 +25,10 @@ _i, _i64, _f, _u64, _u32, _p = C.c_int, C.c_int64, C.c_float, C.c_uint64, C.c_ui
 SIGNATURES = {
     "segmm_l1norm": [_p, _p, _p, _i64, _i, _p],
     "segmm_gemm": [_i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _p, _i, _f, _u64, _u32, _i, _p, _i, _i, _p],
+    "segmm_gemm_x": [_i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _p, _i, _f, _u64, _u32, _i, _p, _i,
+                     _p, _i64, _p, _i64, _i, _p],
+    "segmm_split3": [_p, _p, _i64, _i64, _p],
+    "segmm_split3_transpose": [_p, _i, _i, _i, _p, _i64, _p],
     "segmm_layernorm_fwd": [_p, _p, _p, _p, _p, _p, _i64, _i, _f, _f, _u64, _u32, _p],
     "segmm_layernorm_bwd_parts": [_i64],
     "segmm_layernorm_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _f, _u32, _f, _u32, _u64, _p],
@@ -115,23 +119,49 @@ def l1norm(x, out=None, inv_scale=None):
 
 def gemm(layout, M, N, K, A, lda, B, ldb, Cout, ldc, bias=None, row_scale=None, residual=None, ldr=0, res_period=0,
          activation=0, aux=None, ldaux=0, drop_p=0.0, seed=0, site=0, splits=1, workspace=None, accumulate=False,
-         a_off=0, b_off=0, c_off=0, engine=None):
-    """Raw strided GEMM; ``*_off`` are element offsets into the tensors (column slices of fused buffers)."""
-    _dev(A, B, Cout)
+         a_off=0, b_off=0, c_off=0, engine=None, a_planes=None, b_planes=None, nplanes=3):
+    """Raw strided GEMM; ``*_off`` are element offsets into the tensors (column slices of fused buffers).
+    ``a_planes`` / ``b_planes`` = (bf16 planes tensor [nplanes, ...], element offset): pre-split operand (bf16x6 engine, NT)."""
+    _dev(Cout)
     es = 4
     prof = GEMM_PROFILE
     if prof is not None:          # bench.py: HIP events on the launch stream around the dominant kernel
         e0 = torch.cuda.Event(enable_timing=True)
         e0.record()
-    _check(lib().segmm_gemm(layout, M, N, K, A.data_ptr() + a_off * es, lda, B.data_ptr() + b_off * es, ldb,
-                            Cout.data_ptr() + c_off * es, ldc, _ptr(bias), _ptr(row_scale), _ptr(residual), ldr,
-                            res_period, activation, _ptr(aux), ldaux, float(drop_p), int(seed), int(site),
-                            int(splits), _ptr(workspace), int(bool(accumulate)),
-                            GEMM_ENGINE if engine is None else int(engine), _stream()), "segmm_gemm")
+    eng = GEMM_ENGINE if engine is None else int(engine)
+    if a_planes is None and b_planes is None and nplanes == 3:
+        _check(lib().segmm_gemm(layout, M, N, K, A.data_ptr() + a_off * es, lda, B.data_ptr() + b_off * es, ldb,
+                                Cout.data_ptr() + c_off * es, ldc, _ptr(bias), _ptr(row_scale), _ptr(residual), ldr,
+                                res_period, activation, _ptr(aux), ldaux, float(drop_p), int(seed), int(site),
+                                int(splits), _ptr(workspace), int(bool(accumulate)), eng, _stream()), "segmm_gemm")
+    else:
+        if eng != ENGINE_BF16X6:
+            raise RuntimeError("pre-split operands / nplanes=2 need the bf16x6 engine")
+        ap = None if a_planes is None else a_planes[0].data_ptr() + 2 * a_planes[1]
+        aps = 0 if a_planes is None else a_planes[0].stride(0)
+        bp = None if b_planes is None else b_planes[0].data_ptr() + 2 * b_planes[1]
+        bps = 0 if b_planes is None else b_planes[0].stride(0)
+        _check(lib().segmm_gemm_x(layout, M, N, K, None if A is None else A.data_ptr() + a_off * es, lda,
+                                  None if B is None else B.data_ptr() + b_off * es, ldb,
+                                  Cout.data_ptr() + c_off * es, ldc, _ptr(bias), _ptr(row_scale), _ptr(residual), ldr,
+                                  res_period, activation, _ptr(aux), ldaux, float(drop_p), int(seed), int(site),
+                                  int(splits), _ptr(workspace), int(bool(accumulate)), ap, aps, bp, bps, int(nplanes),
+                                  _stream()), "segmm_gemm_x")
     if prof is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
         prof.append((layout, M, N, K, e0, e1))
+
+
+def split3(x, planes, n, x_off=0, p_off=0):
+    """planes[p, p_off + i] = p-th bf16 term of x.flat[x_off + i]; planes is a [3, size] bf16 tensor."""
+    _check(lib().segmm_split3(x.data_ptr() + 4 * x_off, planes.data_ptr() + 2 * p_off, n, planes.stride(0), _stream()), "segmm_split3")
+
+
+def split3_transpose(x, R, Cc, ld, planes, x_off=0, p_off=0):
+    """planes[p, p_off + c*R + r] = p-th bf16 term of x.flat[x_off + r*ld + c]."""
+    _check(lib().segmm_split3_transpose(x.data_ptr() + 4 * x_off, R, Cc, ld, planes.data_ptr() + 2 * p_off, planes.stride(0),
+                                        _stream()), "segmm_split3_transpose")
 
 
 def layernorm_fwd(x, gamma, beta, y, mean, rstd, eps=1e-12, drop_p=0.0, seed=0, site=0):

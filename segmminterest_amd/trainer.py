@@ -98,6 +98,7 @@ class FusedAdamW:
         self.step_count += 1
         g = st.gflat if gbuf is None else gbuf
         H.adamw(st.flat, g, self.m, self.v, st.n_live, self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.step_count)
+        st.fused_version += 1          # the pre-split weight planes of the bf16x6 GEMM engine are now stale
 
     def state_dict(self):
         """torch.optim.AdamW-format state (keyed by the index of the parameter in model.parameters()),
