@@ -159,9 +159,11 @@ def main():
             cur_e = max(cur_e, e_)
     gemm_ms += cur_e - cur_s
     achieved = flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-    engine = "bf16x6" if hipabi.GEMM_ENGINE == hipabi.ENGINE_BF16X6 else "f32"
+    engine = {hipabi.ENGINE_F32: "f32", hipabi.ENGINE_BF16X6: "bf16x6", hipabi.ENGINE_F16X3: "f16x3"}[hipabi.GEMM_ENGINE]
     if engine == "bf16x6":      # 6 bf16 partial products per algorithmic product
         peak, kname = PEAK_BF16_MFMA_TFLOPS / 6.0, "gemm_bf16x6_mfma (6 x v_mfma_f32_32x32x16_bf16 per product, exact 3-way bf16 split; NT/NN/TN incl. split-K combine)"
+    elif engine == "f16x3":     # 3 fp16 partial products per algorithmic product (fp16 MFMA = the bf16 rate)
+        peak, kname = PEAK_BF16_MFMA_TFLOPS / 3.0, "gemm_bf16x6_mfma<F16> (3 x v_mfma_f32_32x32x16_f16 per product, scaled 2-term fp16 split = 22-bit operands; NT/NN/TN incl. split-K combine)"
     else:
         peak, kname = PEAK_F32_MFMA_TFLOPS, "gemm_f32_mfma (v_mfma_f32_32x32x2_f32; NT/NN/TN launches incl. split-K combine)"
     rows_per_s = world * B * args.steps / elapsed
@@ -172,7 +174,8 @@ def main():
             "metric": "train interactions/sec (segment-Transformer, B=512·S=40·D=768)",
             "value": round(rows_per_s, 2), "unit": "interactions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if engine == "f32" else "f32 (products via exact bf16x3 split, fp32 accumulate)", "data": "synthetic",
+            "dtype": {"f32": "f32", "bf16x6": "f32 (products via exact bf16x3 split, fp32 accumulate)",
+                      "f16x3": "f32 (products via scaled fp16x2 split, 22-bit operands, fp32 accumulate)"}[engine], "data": "synthetic",
             "config": {"workload": "BASELINE config 2: synthetic SegMM B=%d/GPU x S=%d x D=%d, h=%d, %d-layer segment encoder, image/image, "
                                    "Lt=%d user tokens, interestBPR, dropout 0.1, AdamW" % (B, S, D, h, N, Lt),
                        "rows_per_gpu": B, "global_batch": B * world, "segments": S, "feat_dim": D, "user_tokens": Lt, "layers": N,
@@ -186,7 +189,7 @@ def main():
                          "frac": round(achieved / peak, 4), "traffic": None,
                          "launches": len(prof), "gemm_busy_ms_per_step": round(gemm_ms / args.steps, 4),
                          "note": "achieved = algorithmic 2MNK of every GEMM launch in the timed region / union of their HIP-event intervals; "
-                                 "peak = dense MFMA peak of the instruction used" + (" / 6 partial products" if engine == "bf16x6" else "")},
+                                 "peak = dense MFMA peak of the instruction used" + {"bf16x6": " / 6 partial products", "f16x3": " / 3 partial products", "f32": ""}[engine]},
         }
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(args, S, D, Lt, N, h)

@@ -59,6 +59,31 @@ int segmm_gemm_x(int layout, int M, int N, int K, const float* A, int lda, const
                  int activation, float* aux, int ldaux, float drop_p, uint64_t seed, uint32_t site, int splits,
                  float* workspace, int accumulate, const uint16_t* a_planes, int64_t a_pstride,
                  const uint16_t* b_planes, int64_t b_pstride, int nplanes, segmm_stream_t stream);
+
+/* fp16x3 engine: x*s = hi + lo in two fp16 terms (22 mantissa bits), s a per-tensor power of two derived inside the
+ * kernel from PARTIAL MAXIMA of |x| (a_amax[0..a_namax), b_amax[0..b_namax), device arrays written by
+ * segmm_absmax or by the operand's producer; no host sync); three products hh + hl + lh on
+ * v_mfma_f32_32x32x16_f16, per-product error <= 3 * 2^-22.  Half the matrix-pipe work of segmm_gemm_x.
+ * Optional pre-split operands are fp16 planes [2][rows][ld] from segmm_split2h / segmm_split2h_transpose made with
+ * the SAME partial maxima that are passed here.  All layouts, epilogues and split-K as segmm_gemm. */
+int segmm_gemm_h(int layout, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                 const float* bias, const float* row_scale, const float* residual, int ldr, int res_period,
+                 int activation, float* aux, int ldaux, float drop_p, uint64_t seed, uint32_t site, int splits,
+                 float* workspace, int accumulate, const uint16_t* a_planes, int64_t a_pstride,
+                 const uint16_t* b_planes, int64_t b_pstride, const float* a_amax, int a_namax, const float* b_amax,
+                 int b_namax, float* c_amax, segmm_stream_t stream);
+/* Producer side of those partial maxima.  segmm_gemm_h (c_amax), segmm_layernorm_fwd/bwd (amax), segmm_attn_fwd
+ * (amax_o) and segmm_attn_bwd (amax_q / amax_ka / amax_kb) take OPTIONAL arrays of SEGMM_AMAX_SLOTS floats that
+ * the CALLER HAS ZEROED; each wave folds the maximum of what it stored into one slot with an integer atomic max on
+ * the float bits (exact, order-independent, so results stay bitwise reproducible).  Several producers may share
+ * one array (the attention backward of both sides writes column blocks of the same dY buffer). */
+#define SEGMM_AMAX_SLOTS 256
+/* out[0..nparts) = partial maxima of |x| over the [rows, cols] view with row stride ld (1 <= nparts <= 1024). */
+int segmm_absmax(const float* x, int64_t rows, int cols, int ld, float* out, int nparts, segmm_stream_t stream);
+int segmm_split2h(const float* x, uint16_t* planes, int64_t n, int64_t pstride, const float* amax, int namax,
+                  segmm_stream_t stream);
+int segmm_split2h_transpose(const float* x, int R, int Cc, int ld, uint16_t* planes, int64_t pstride,
+                            const float* amax, int namax, segmm_stream_t stream);
 /* exact split x = hi + mid + lo into three bf16 planes: planes[p*pstride + i] (flat), or the transposed copy
  * planes[p*pstride + c*R + r] of an [R, C] row-major matrix with leading dimension ld. */
 int segmm_split3(const float* x, uint16_t* planes, int64_t n, int64_t pstride, segmm_stream_t stream);
@@ -70,13 +95,13 @@ int segmm_split3_transpose(const float* x, int R, int C, int ld, uint16_t* plane
  * dx times the mask of the residual-branch dropout "x = res + dropout(branch)" (drop_b_*), i.e. d(branch).
  * part_dgamma/part_dbeta: [nparts, d] per-workgroup partials, nparts = segmm_layernorm_bwd_parts(rows). */
 int segmm_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
-                        int64_t rows, int d, float eps, float drop_p, uint64_t seed, uint32_t site,
+                        int64_t rows, int d, float eps, float drop_p, uint64_t seed, uint32_t site, float* amax,
                         segmm_stream_t stream);
 int segmm_layernorm_bwd_parts(int64_t rows);
 int segmm_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                         float* dx, float* dx_drop, float* part_dgamma, float* part_dbeta, int64_t rows, int d,
                         float drop_y_p, uint32_t drop_y_site, float drop_b_p, uint32_t drop_b_site, uint64_t seed,
-                        segmm_stream_t stream);
+                        float* amax, segmm_stream_t stream);
 
 /* out[n] (+)= sum_m w[m] * X[m,n]  (bias gradients, LayerNorm partial combine, head weight gradient).
  * workspace: segmm_colsum_chunks(M) * N floats. */
@@ -91,13 +116,13 @@ int segmm_colsum(const float* X, int ld, const float* w, int64_t M, int N, float
 int segmm_attn_fwd(int B, int H, int dh, int Lq, int La, int Lb, const float* Qa, const float* Qb, int ldq,
                    const float* Ka, const float* Va, int ldka, const float* Kb, const float* Vb, int ldkb,
                    const uint8_t* mq, const uint8_t* mka, const uint8_t* mkb, float* O, int ldo, float* lse,
-                   float drop_p, uint64_t seed, uint32_t site, segmm_stream_t stream);
+                   float drop_p, uint64_t seed, uint32_t site, float* amax_o, segmm_stream_t stream);
 int segmm_attn_bwd(int B, int H, int dh, int Lq, int La, int Lb, const float* Qa, const float* Qb, int ldq,
                    const float* Ka, const float* Va, int ldka, const float* Kb, const float* Vb, int ldkb,
                    const uint8_t* mq, const uint8_t* mka, const uint8_t* mkb, const float* lse, const float* dO,
                    int lddo, float* Dvec, float* dQa, float* dQb, int lddq, float* dKa, float* dVa, int lddka,
                    float* dKb, float* dVb, int lddkb, float drop_p, uint64_t seed, uint32_t site,
-                   segmm_stream_t stream);
+                   float* amax_q, float* amax_ka, float* amax_kb, segmm_stream_t stream);
 
 /* K7 -- interest head Linear(d,1) (decoder_leave_focal.py:451,596): out[m] (+)= x[m,:].w (+ bias[0]) and
  * dx[m,:] (+)= g[m]*w.  segmm_vecsum: deterministic out[0] (+)= sum v. */

@@ -48,6 +48,9 @@ struct AttnArgs {
     float *dQa, *dQb; int lddq;
     float *dKa, *dVa; int lddka;
     float *dKb, *dVb; int lddkb;
+    // optional partial maxima (AMAX_SLOTS each, common.h) of what the kernels write, for the fp16x3 GEMM engine:
+    float* amax_o;                      // forward: |O|
+    float *amax_q, *amax_ka, *amax_kb;  // backward: |dQa|,|dQb| ; |dKa|,|dVa| ; |dKb|,|dVb|
 };
 
 constexpr int ATT_THREADS = 256;        // 4 waves, fixed: the register-batched staging sizes depend on it
@@ -276,13 +279,18 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const AttnArgs p)
             }
         }
     }
+    float am = 0.f;
     if (q_in) {
 #pragma unroll
         for (int ct = 0; ct < C::CT; ++ct) {
             const int c = 16 * ct + 4 * g;
-            if (c < DH) *(f32x4*)(p.O + (size_t)(b * p.Lq + qi) * p.ldo + col0 + c) = o[ct];
+            if (c < DH) {
+                *(f32x4*)(p.O + (size_t)(b * p.Lq + qi) * p.ldo + col0 + c) = o[ct];
+                am = absmax4(am, o[ct]);
+            }
         }
     }
+    if (p.amax_o) amax_commit(p.amax_o, am, (blockIdx.x * gridDim.y + blockIdx.y) * 4 + wave);
 }
 
 // ------------------------------------------------------------------------------------------ backward: dQ (+ D)
@@ -417,6 +425,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(const AttnArgs
             }
         }
     }
+    float am = 0.f;
     if (q_in) {
 #pragma unroll
         for (int ct = 0; ct < C::CT; ++ct) {
@@ -424,9 +433,11 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(const AttnArgs
             if (c < DH) {
                 *(f32x4*)(p.dQa + (size_t)(b * p.Lq + qi) * p.lddq + col0 + c) = da[ct];
                 *(f32x4*)(p.dQb + (size_t)(b * p.Lq + qi) * p.lddq + col0 + c) = db[ct];
+                am = absmax4(absmax4(am, da[ct]), db[ct]);
             }
         }
     }
+    if (p.amax_q) amax_commit(p.amax_q, am, (blockIdx.x * gridDim.y + blockIdx.y) * 4 + wave);
 }
 
 // ------------------------------------------------------------------------------------------ backward: dK, dV
@@ -536,6 +547,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkv_kernel(const AttnArg
     const bool ka = jp < La_p;
     const int jloc = ka ? jp : jp - La_p;
     const bool real = ka ? (jloc < p.La) : (jloc < p.Lb);
+    float am = 0.f;
     if (real) {
         float* dKp = ka ? p.dKa + (size_t)(b * p.La + jloc) * p.lddka : p.dKb + (size_t)(b * p.Lb + jloc) * p.lddkb;
         float* dVp = ka ? p.dVa + (size_t)(b * p.La + jloc) * p.lddka : p.dVb + (size_t)(b * p.Lb + jloc) * p.lddkb;
@@ -545,9 +557,12 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkv_kernel(const AttnArg
             if (c < DH) {
                 *(f32x4*)(dKp + col0 + c) = dk[ct];
                 *(f32x4*)(dVp + col0 + c) = dv[ct];
+                am = absmax4(absmax4(am, dk[ct]), dv[ct]);
             }
         }
     }
+    float* slot = isa ? p.amax_ka : p.amax_kb;          // wave-uniform: a key tile lies in one block
+    if (slot) amax_commit(slot, am, (blockIdx.x * gridDim.y + blockIdx.y) * 4 + wave);
 }
 
 }  // namespace segmm

@@ -103,7 +103,7 @@ __global__ void dropout_mult_kernel(float* out, long long n, DropCfg d) {
 extern "C" {
 
 const char* segmm_last_error(void) { return g_segmm_err; }
-int segmm_abi_version(void) { return 1; }
+int segmm_abi_version(void) { return 2; }
 
 int segmm_l1norm(const float* x, float* y, float* inv_scale, int64_t rows, int D, segmm_stream_t stream) {
     SEGMM_REQUIRE(x && (y || inv_scale), "l1norm: null pointer");
@@ -120,17 +120,22 @@ static int gemm_impl(int layout, int M, int N, int K, const float* A, int lda, c
                      const float* bias, const float* row_scale, const float* residual, int ldr, int res_period,
                      int activation, float* aux, int ldaux, float drop_p, uint64_t seed, uint32_t site, int splits,
                      float* workspace, int accumulate, int engine, const uint16_t* a_planes, long long a_pstride,
-                     const uint16_t* b_planes, long long b_pstride, int nplanes, segmm_stream_t stream) {
+                     const uint16_t* b_planes, long long b_pstride, int nplanes, const float* a_amax, int a_namax,
+                     const float* b_amax, int b_namax, float* c_amax, segmm_stream_t stream) {
     SEGMM_REQUIRE(layout >= 0 && layout <= 2, "gemm: bad layout %d", layout);
+    if (engine == 2) nplanes = 2;
     SEGMM_REQUIRE(nplanes == 3 || nplanes == 2, "gemm: nplanes %d (3 = six products, 2 = three products)", nplanes);
+    if (engine == 2)
+        SEGMM_REQUIRE(a_amax && b_amax && a_namax > 0 && b_namax > 0 && a_namax <= 1024 && b_namax <= 1024,
+                      "gemm: the fp16x3 engine needs the partial maxima of both operands (1..1024 each)");
     if (a_planes || b_planes) {
-        SEGMM_REQUIRE(engine == 1 && layout == 0, "gemm: pre-split operands need engine 1 and the NT layout");
+        SEGMM_REQUIRE((engine == 1 || engine == 2) && layout == 0, "gemm: pre-split operands need engine 1/2 and the NT layout");
         SEGMM_REQUIRE(K % 8 == 0 && (!a_planes || (lda % 8 == 0 && aligned16(a_planes) && a_pstride % 8 == 0)) &&
                       (!b_planes || (ldb % 8 == 0 && aligned16(b_planes) && b_pstride % 8 == 0)), "gemm: plane operands need K, ld, stride %% 8 == 0 and 16-byte alignment");
     }
     if (a_planes && !A) A = (const float*)a_planes;      // only the planes are read
     if (b_planes && !B) B = (const float*)b_planes;
-    SEGMM_REQUIRE(engine == 0 || engine == 1, "gemm: engine %d (0 = f32 MFMA, 1 = bf16x6 split MFMA)", engine);
+    SEGMM_REQUIRE(engine >= 0 && engine <= 2, "gemm: engine %d (0 = f32 MFMA, 1 = bf16x6 split MFMA, 2 = fp16x3 split MFMA)", engine);
     SEGMM_REQUIRE(A && B && C, "gemm: null operand");
     if (M <= 0 || N <= 0) return 0;
     SEGMM_REQUIRE(K > 0, "gemm: K=%d", K);
@@ -150,12 +155,25 @@ static int gemm_impl(int layout, int M, int N, int K, const float* A, int lda, c
     g.residual = residual; g.ldr = ldr; g.res_period = res_period > 0 ? res_period : 1;
     g.aux = aux; g.ldaux = ldaux; g.epi = activation;
     g.drop = make_drop(drop_p, seed, site);
+    g.amax_out = c_amax;
+    {   // extents of the operand views (rows x ld, last row only as wide as it is read); the split engines address
+        // them through 32-bit buffer offsets, tile overhang included
+        const size_t a_rows = layout == 2 ? (size_t)K : (size_t)M, a_cols = layout == 2 ? (size_t)M : (size_t)K;
+        const size_t b_rows = layout == 0 ? (size_t)N : (size_t)K, b_cols = layout == 0 ? (size_t)K : (size_t)N;
+        const size_t a_ext = ((a_rows - 1) * lda + a_cols) * 4, b_ext = ((b_rows - 1) * ldb + b_cols) * 4;
+        const size_t a_reach = (layout == 2 ? (size_t)K + GBK : (size_t)((M + GBM - 1) / GBM) * GBM) * lda * 4 + 4096;
+        const size_t b_reach = (layout == 0 ? (size_t)((N + GBN - 1) / GBN) * GBN : (size_t)K + GBK) * ldb * 4 + 4096;
+        if (engine != 0)
+            SEGMM_REQUIRE(a_reach < (1ull << 32) && b_reach < (1ull << 32), "gemm: operand view above the 4 GiB buffer-addressing window of the split engines (%zu / %zu bytes)", a_reach, b_reach);
+        g.a_bytes = (uint32_t)(a_ext < (1ull << 32) ? a_ext : 0xffffffffull);
+        g.b_bytes = (uint32_t)(b_ext < (1ull << 32) ? b_ext : 0xffffffffull);
+    }
     g.nbm = (M + GBM - 1) / GBM; g.nbn = (N + GBN - 1) / GBN;
     int ktiles = (K + GBK - 1) / GBK;
     if (splits > ktiles) splits = ktiles;
     if (splits > 1) {
         SEGMM_REQUIRE(workspace && aligned16(workspace), "gemm: split-K needs a workspace");
-        SEGMM_REQUIRE(!bias && !row_scale && !residual && activation == 0 && drop_p == 0.f, "gemm: split-K supports no epilogue");
+        SEGMM_REQUIRE(!bias && !row_scale && !residual && activation == 0 && drop_p == 0.f && !c_amax, "gemm: split-K supports no epilogue");
         const int tps = (ktiles + splits - 1) / splits;
         splits = (ktiles + tps - 1) / tps;
         g.k_per_split = tps * GBK;
@@ -178,8 +196,18 @@ static int gemm_impl(int layout, int M, int N, int K, const float* A, int lda, c
         GemmPlanes q;
         q.Ap = (const __bf16*)a_planes; q.a_pstride = a_pstride;
         q.Bp = (const __bf16*)b_planes; q.b_pstride = b_pstride;
+        q.a_amax = a_amax; q.a_namax = a_namax; q.b_amax = b_amax; q.b_namax = b_namax;
 #define X6(AK, BK, AP, BP, NP) hipLaunchKernelGGL((gemm_bf16x6_mfma<AK, BK, AP, BP, NP>), grid, block, 0, s, g, q)
-        if (nplanes == 3) {
+#define H3(AK, BK, AP, BP) hipLaunchKernelGGL((gemm_bf16x6_mfma<AK, BK, AP, BP, 2, true>), grid, block, 0, s, g, q)
+        if (engine == 2) {
+            if (layout == 0) {
+                if (a_planes && b_planes) H3(true, true, true, true);
+                else if (b_planes) H3(true, true, false, true);
+                else if (a_planes) H3(true, true, true, false);
+                else H3(true, true, false, false);
+            } else if (layout == 1) H3(true, false, false, false);
+            else H3(false, false, false, false);
+        } else if (nplanes == 3) {
             if (layout == 0) {
                 if (a_planes && b_planes) X6(true, true, true, true, 3);
                 else if (b_planes) X6(true, true, false, true, 3);
@@ -194,6 +222,7 @@ static int gemm_impl(int layout, int M, int N, int K, const float* A, int lda, c
             else X6(false, false, false, false, 2);
         }
 #undef X6
+#undef H3
     }
     LAUNCH_CHECK();
     if (splits > 1) {
@@ -212,7 +241,7 @@ int segmm_gemm(int layout, int M, int N, int K, const float* A, int lda, const f
                int activation, float* aux, int ldaux, float drop_p, uint64_t seed, uint32_t site, int splits,
                float* workspace, int accumulate, int engine, segmm_stream_t stream) {
     return gemm_impl(layout, M, N, K, A, lda, B, ldb, C, ldc, bias, row_scale, residual, ldr, res_period, activation, aux, ldaux,
-                     drop_p, seed, site, splits, workspace, accumulate, engine, nullptr, 0, nullptr, 0, 3, stream);
+                     drop_p, seed, site, splits, workspace, accumulate, engine, nullptr, 0, nullptr, 0, 3, nullptr, 0, nullptr, 0, nullptr, stream);
 }
 
 int segmm_gemm_x(int layout, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
@@ -221,7 +250,45 @@ int segmm_gemm_x(int layout, int M, int N, int K, const float* A, int lda, const
                  float* workspace, int accumulate, const uint16_t* a_planes, int64_t a_pstride,
                  const uint16_t* b_planes, int64_t b_pstride, int nplanes, segmm_stream_t stream) {
     return gemm_impl(layout, M, N, K, A, lda, B, ldb, C, ldc, bias, row_scale, residual, ldr, res_period, activation, aux, ldaux,
-                     drop_p, seed, site, splits, workspace, accumulate, 1, a_planes, a_pstride, b_planes, b_pstride, nplanes, stream);
+                     drop_p, seed, site, splits, workspace, accumulate, 1, a_planes, a_pstride, b_planes, b_pstride, nplanes,
+                     nullptr, 0, nullptr, 0, nullptr, stream);
+}
+
+int segmm_gemm_h(int layout, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                 const float* bias, const float* row_scale, const float* residual, int ldr, int res_period,
+                 int activation, float* aux, int ldaux, float drop_p, uint64_t seed, uint32_t site, int splits,
+                 float* workspace, int accumulate, const uint16_t* a_planes, int64_t a_pstride,
+                 const uint16_t* b_planes, int64_t b_pstride, const float* a_amax, int a_namax, const float* b_amax,
+                 int b_namax, float* c_amax, segmm_stream_t stream) {
+    return gemm_impl(layout, M, N, K, A, lda, B, ldb, C, ldc, bias, row_scale, residual, ldr, res_period, activation, aux, ldaux,
+                     drop_p, seed, site, splits, workspace, accumulate, 2, a_planes, a_pstride, b_planes, b_pstride, 2,
+                     a_amax, a_namax, b_amax, b_namax, c_amax, stream);
+}
+
+int segmm_absmax(const float* x, int64_t rows, int cols, int ld, float* out, int nparts, segmm_stream_t stream) {
+    SEGMM_REQUIRE(x && out && rows >= 0 && cols > 0 && cols % 4 == 0 && ld % 4 == 0 && ld >= cols && aligned16(x), "absmax: cols/ld %% 4, alignment");
+    SEGMM_REQUIRE(nparts >= 1 && nparts <= 1024, "absmax: 1..1024 partials");
+    hipLaunchKernelGGL(absmax_partial_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)stream, x, (long long)rows, cols, ld, out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int segmm_split2h(const float* x, uint16_t* planes, int64_t n, int64_t pstride, const float* amax, int namax, segmm_stream_t stream) {
+    SEGMM_REQUIRE(x && planes && amax && namax >= 1 && namax <= 1024 && n % 4 == 0 && pstride % 4 == 0 && aligned16(x) && (((uintptr_t)planes) & 7) == 0, "split2h: n/stride %% 4, alignment, partial maxima");
+    if (n <= 0) return 0;
+    long long blocks = (n / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(splith_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (__bf16*)planes, (long long)n, (long long)pstride, amax, namax);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int segmm_split2h_transpose(const float* x, int R, int Cc, int ld, uint16_t* planes, int64_t pstride, const float* amax, int namax, segmm_stream_t stream) {
+    SEGMM_REQUIRE(x && planes && amax && namax >= 1 && namax <= 1024 && R > 0 && Cc > 0 && ld >= Cc, "split2h_transpose: bad args");
+    hipLaunchKernelGGL((split3_transpose_kernel<true>), dim3((Cc + 31) / 32, (R + 31) / 32), dim3(256), 0, (hipStream_t)stream, x, R, Cc, ld,
+                       (__bf16*)planes, (long long)pstride, amax, namax);
+    LAUNCH_CHECK();
+    return 0;
 }
 
 int segmm_split3(const float* x, uint16_t* planes, int64_t n, int64_t pstride, segmm_stream_t stream) {
@@ -236,21 +303,21 @@ int segmm_split3(const float* x, uint16_t* planes, int64_t n, int64_t pstride, s
 
 int segmm_split3_transpose(const float* x, int R, int Cc, int ld, uint16_t* planes, int64_t pstride, segmm_stream_t stream) {
     SEGMM_REQUIRE(x && planes && R > 0 && Cc > 0 && ld >= Cc, "split3_transpose: bad args");
-    hipLaunchKernelGGL(split3_transpose_kernel, dim3((Cc + 31) / 32, (R + 31) / 32), dim3(256), 0, (hipStream_t)stream, x, R, Cc, ld,
-                       (__bf16*)planes, (long long)pstride);
+    hipLaunchKernelGGL((split3_transpose_kernel<false>), dim3((Cc + 31) / 32, (R + 31) / 32), dim3(256), 0, (hipStream_t)stream, x, R, Cc, ld,
+                       (__bf16*)planes, (long long)pstride, (const float*)nullptr, 0);
     LAUNCH_CHECK();
     return 0;
 }
 
 int segmm_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
-                        int64_t rows, int d, float eps, float drop_p, uint64_t seed, uint32_t site,
+                        int64_t rows, int d, float eps, float drop_p, uint64_t seed, uint32_t site, float* amax,
                         segmm_stream_t stream) {
     SEGMM_REQUIRE(x && gamma && beta && y && mean && rstd, "layernorm_fwd: null pointer");
     SEGMM_REQUIRE(d > 0 && d % 4 == 0 && d <= 256 * ROW_MAXV, "layernorm_fwd: d=%d unsupported", d);
     SEGMM_REQUIRE(aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta), "layernorm_fwd: alignment");
     if (rows <= 0) return 0;
     hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, gamma,
-                       beta, y, mean, rstd, (long long)rows, d, eps, make_drop(drop_p, seed, site));
+                       beta, y, mean, rstd, (long long)rows, d, eps, make_drop(drop_p, seed, site), amax);
     LAUNCH_CHECK();
     return 0;
 }
@@ -265,14 +332,14 @@ int segmm_layernorm_bwd_parts(int64_t rows) {
 int segmm_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                         float* dx, float* dx_drop, float* part_dgamma, float* part_dbeta, int64_t rows, int d,
                         float drop_y_p, uint32_t drop_y_site, float drop_b_p, uint32_t drop_b_site, uint64_t seed,
-                        segmm_stream_t stream) {
+                        float* amax, segmm_stream_t stream) {
     SEGMM_REQUIRE(dy && x && mean && rstd && gamma && dx && part_dgamma && part_dbeta, "layernorm_bwd: null pointer");
     SEGMM_REQUIRE(d > 0 && d % 4 == 0 && d <= 256 * ROW_MAXV, "layernorm_bwd: d=%d unsupported", d);
     SEGMM_REQUIRE(aligned16(dy) && aligned16(x) && aligned16(dx) && aligned16(gamma) && (!dx_drop || aligned16(dx_drop)), "layernorm_bwd: alignment");
     const int parts = segmm_layernorm_bwd_parts(rows);
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(parts), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma, dx,
                        dx_drop, part_dgamma, part_dbeta, (long long)rows, d, make_drop(drop_y_p, seed, drop_y_site),
-                       make_drop(drop_b_p, seed, drop_b_site));
+                       make_drop(drop_b_p, seed, drop_b_site), amax);
     LAUNCH_CHECK();
     return 0;
 }
@@ -303,13 +370,13 @@ int segmm_colsum(const float* X, int ld, const float* w, int64_t M, int N, float
 int segmm_attn_fwd(int B, int H, int dh, int Lq, int La, int Lb, const float* Qa, const float* Qb, int ldq,
                    const float* Ka, const float* Va, int ldka, const float* Kb, const float* Vb, int ldkb,
                    const uint8_t* mq, const uint8_t* mka, const uint8_t* mkb, float* O, int ldo, float* lse,
-                   float drop_p, uint64_t seed, uint32_t site, segmm_stream_t stream) {
+                   float drop_p, uint64_t seed, uint32_t site, float* amax_o, segmm_stream_t stream) {
     AttnArgs a;
     memset(&a, 0, sizeof(a));
     int rc = attn_fill(a, B, H, dh, Lq, La, Lb, Qa, Qb, ldq, Ka, Va, ldka, Kb, Vb, ldkb, mq, mka, mkb, drop_p, seed, site);
     if (rc) return rc;
     SEGMM_REQUIRE(O && lse && aligned16(O) && ldo % 4 == 0, "attn_fwd: output pointer/alignment");
-    a.O = O; a.ldo = ldo; a.lse = lse;
+    a.O = O; a.ldo = ldo; a.lse = lse; a.amax_o = amax_o;
     ATTN_DISPATCH(attn_launch_fwd, dh, a, (hipStream_t)stream);
 }
 
@@ -318,7 +385,7 @@ int segmm_attn_bwd(int B, int H, int dh, int Lq, int La, int Lb, const float* Qa
                    const uint8_t* mq, const uint8_t* mka, const uint8_t* mkb, const float* lse, const float* dO,
                    int lddo, float* Dvec, float* dQa, float* dQb, int lddq, float* dKa, float* dVa, int lddka,
                    float* dKb, float* dVb, int lddkb, float drop_p, uint64_t seed, uint32_t site,
-                   segmm_stream_t stream) {
+                   float* amax_q, float* amax_ka, float* amax_kb, segmm_stream_t stream) {
     AttnArgs a;
     memset(&a, 0, sizeof(a));
     int rc = attn_fill(a, B, H, dh, Lq, La, Lb, Qa, Qb, ldq, Ka, Va, ldka, Kb, Vb, ldkb, mq, mka, mkb, drop_p, seed, site);
@@ -328,6 +395,7 @@ int segmm_attn_bwd(int B, int H, int dh, int Lq, int La, int Lb, const float* Qa
     SEGMM_REQUIRE(aligned16(dO) && aligned16(dQa) && aligned16(dQb) && aligned16(dKa) && aligned16(dVa) && aligned16(dKb) && aligned16(dVb), "attn_bwd: alignment");
     a.lse = (float*)lse; a.dO = dO; a.lddo = lddo; a.Dvec = Dvec;
     a.dQa = dQa; a.dQb = dQb; a.lddq = lddq; a.dKa = dKa; a.dVa = dVa; a.lddka = lddka; a.dKb = dKb; a.dVb = dVb; a.lddkb = lddkb;
+    a.amax_q = amax_q; a.amax_ka = amax_ka; a.amax_kb = amax_kb;
     ATTN_DISPATCH(attn_launch_bwd, dh, a, (hipStream_t)stream);
 }
 

@@ -98,6 +98,19 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+// ---- running max|x| of a tensor, for the fp16x3 GEMM engine's per-tensor scale.  A producer kernel keeps a
+// per-lane running maximum of what it stores and folds it, once per wave, into one of AMAX_SLOTS partial maxima
+// with an INTEGER atomic max on the float bits (non-negative floats order like unsigned ints: exact, and
+// independent of the order of arrival).  The slot array is zeroed by the host before the producer runs; the
+// consuming GEMM reduces the slots itself.
+constexpr int AMAX_SLOTS = 256;
+__device__ __forceinline__ float absmax4(float m, f32x4 v) {
+    return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+}
+__device__ __forceinline__ void amax_commit(float* slots, float m, unsigned key) {
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomicMax((unsigned int*)slots + (key & (AMAX_SLOTS - 1)), __float_as_uint(m));
+}
 // inclusive prefix sum across the 64 lanes
 __device__ __forceinline__ float wave_scan_incl(float v, int lane) {
 #pragma unroll

@@ -42,6 +42,8 @@ struct GemmArgs {
     int k_per_split;          // K range handled by one blockIdx.z (multiple of GBK)
     long long slab_stride;    // split-K: partial C of split z at C + z*slab_stride, plain store
     int nbm, nbn;
+    uint32_t a_bytes, b_bytes;  // extents of the A / B views in bytes of fp32 (split engines: buffer-load range check)
+    float* amax_out;          // optional: AMAX_SLOTS partial maxima of |C| (after the epilogue), see common.h
 };
 
 template <bool A_KC, bool B_KC>
@@ -176,6 +178,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmArgs p) {
     // ---- epilogue: accumulator tile -> LDS (per-wave region) -> row-major float4
     float* Cs = smem + wave * (32 * 36);
     const bool split = gridDim.z > 1;
+    float am = 0.f;
     float* Cout = p.C + (size_t)blockIdx.z * (size_t)p.slab_stride;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -206,11 +209,13 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmArgs p) {
                         if (p.residual) v += *(const f32x4*)(p.residual + (size_t)(gm % p.res_period) * p.ldr + gn);
                     }
                     *(f32x4*)(Cout + (size_t)gm * p.ldc + gn) = v;
+                    am = absmax4(am, v);
                 }
             }
             __syncthreads();
         }
     }
+    if (p.amax_out) amax_commit(p.amax_out, am, blockIdx.x * 4 + wave);
 }
 
 // C[m,n] (+)= sum_z slabs[z][m,n]   (deterministic split-K combine)

@@ -20,22 +20,67 @@
 // planes [128 rows][32 k] of bf16 with an 80-byte row stride (conflict-free ds_read_b128 of the 8-element
 // MFMA fragments).  fp32 operands whose k index is NOT contiguous in memory (B of NN, A and B of TN) are
 // transposed in registers: a thread owns a 4(k) x 4(m) micro-block and writes 4-element k runs.
+//
+// F16 = true selects the fp16x3 engine: x*s = hi + lo with two fp16 terms (11 + 11 mantissa bits, residual
+// <= 2^-22 |x|), s a per-tensor power of two that puts max|x| in [2^14, 2^15) so neither term leaves the fp16
+// range (elements below 2^-18 max keep an absolute error of 2^-40 max), three products hh + hl + lh on
+// v_mfma_f32_32x32x16_f16 (fp16 x fp16 is exact in fp32), result scaled back by 1/(sa sb) in the epilogue.
+// Per-product error <= 3 * 2^-22: the same order as the fp32 accumulation error of either other engine
+// (measured vs fp64 in tests/test_ops_gpu.py).  Half the matrix-pipe work and 2/3 of the LDS traffic of bf16x6.
+// max|x| comes as an array of partial maxima written by the operand's producer (or segmm_absmax): no host
+// sync, no atomics; every workgroup reduces the (<= 1024) partials itself.
 #pragma once
+#include <type_traits>
+
 #include "gemm.h"
 
 namespace segmm {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int XRS = 40;                          // plane row stride in bf16 elements (80 bytes)
 constexpr int XPLANE = GBM * XRS;                // 5120 bf16 per plane
 
-struct GemmPlanes {                              // optional pre-split operands (bf16 planes, k-contiguous rows)
+struct GemmPlanes {                              // optional pre-split operands (16-bit planes, k-contiguous rows)
     const __bf16* Ap; long long a_pstride;       // plane p of A at Ap + p * a_pstride, row stride = GemmArgs.lda
     const __bf16* Bp; long long b_pstride;
+    const float* a_amax; int a_namax;            // fp16x3 engine: partial maxima of |A| and |B| (>= 0, any count <= 1024)
+    const float* b_amax; int b_namax;
 };
+
+// power of two s with amax * s in [2^14, 2^15); exponent clamped to +-60 so that 1/(sa sb) stays finite
+__device__ __forceinline__ float f16_scale_of(float amax) {
+    const uint32_t u = __float_as_uint(amax);
+    if (!(amax > 0.f) || (u >> 23) == 0xff) return 1.f;
+    int se = 14 - ((int)(u >> 23) - 127);
+    se = max(-60, min(60, se));
+    return __uint_as_float((uint32_t)(se + 127) << 23);
+}
+// (x0, x1) * s -> packed fp16 (hi0, hi1), (lo0, lo1); hi + lo = x s up to 2^-22 |x s|.
+// Four VALU instructions per pair: v_fma_mix{lo,hi}_f16 multiply in fp32, round ONCE to fp16 and write one half
+// of the destination, and take the fp16 hi term straight back as the addend of the lo term
+// (lo = rn16(x s - hi), the fma is exact before that rounding).
+__device__ __forceinline__ void splith_pair(float x0, float x1, float s, uint32_t& ph, uint32_t& pl) {
+    uint32_t h, l;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(x0), "v"(s));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(x1), "v"(s));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(x0), "v"(s), "v"(h));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(x1), "v"(s), "v"(h));
+    ph = h;
+    pl = l;
+}
+// raw buffer resource over [p, p + bytes): loads beyond it return 0 (hardware range check)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
 
 // exact 3-way split of two floats -> packed (hi0,hi1), (mid0,mid1), (lo0,lo1)
 __device__ __forceinline__ void split3_pair(float x0, float x1, uint32_t& ph, uint32_t& pm, uint32_t& pl) {
@@ -51,9 +96,15 @@ __device__ __forceinline__ void split2_pair(float x0, float x1, uint32_t& ph, ui
     pm = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{r0, r1}, bf16x2));
 }
 // four consecutive-k floats of one row -> one 8-byte store per plane
-template <int NPL>
-__device__ __forceinline__ void split_store4(__bf16* plane0, int off, f32x4 v) {
-    if (NPL == 3) {
+template <int NPL, bool F16>
+__device__ __forceinline__ void split_store4(__bf16* plane0, int off, f32x4 v, float s) {
+    if (F16) {
+        uint32_t h0, l0, h1, l1;
+        splith_pair(v.x, v.y, s, h0, l0);
+        splith_pair(v.z, v.w, s, h1, l1);
+        *(uint2*)(plane0 + off) = make_uint2(h0, h1);
+        *(uint2*)(plane0 + XPLANE + off) = make_uint2(l0, l1);
+    } else if (NPL == 3) {
         uint32_t h0, m0, l0, h1, m1, l1;
         split3_pair(v.x, v.y, h0, m0, l0);
         split3_pair(v.z, v.w, h1, m1, l1);
@@ -69,12 +120,19 @@ __device__ __forceinline__ void split_store4(__bf16* plane0, int off, f32x4 v) {
     }
 }
 
-template <bool A_KC, bool B_KC, bool A_PRE, bool B_PRE, int NPL>
-__global__ __launch_bounds__(256) void gemm_bf16x6_mfma(const GemmArgs p, const GemmPlanes q) {
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma_x(f32x4 a, f32x4 b, f32x16 c) {
+    if (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+template <bool A_KC, bool B_KC, bool A_PRE, bool B_PRE, int NPL, bool F16 = false>
+__global__ __launch_bounds__(256, 2) void gemm_bf16x6_mfma(const GemmArgs p, const GemmPlanes q) {
     static_assert(!A_PRE || A_KC, "pre-split operands are k-contiguous");
     static_assert(!B_PRE || B_KC, "pre-split operands are k-contiguous");
+    static_assert(!F16 || NPL == 2, "the fp16 engine has two planes per operand");
     constexpr int XOPER = NPL * XPLANE;
-    __shared__ __attribute__((aligned(16))) __bf16 smem[2 * 3 * XPLANE];      // 61 440 B (epilogue needs 18 KB of it)
+    __shared__ __attribute__((aligned(16))) __bf16 smem[2 * NPL * XPLANE];    // 61 440 B (NPL 3) / 40 960 B (NPL 2); the epilogue needs 18 KB of it
     __bf16* As = smem;
     __bf16* Bs = smem + XOPER;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -93,167 +151,191 @@ __global__ __launch_bounds__(256) void gemm_bf16x6_mfma(const GemmArgs p, const 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // ---- staging coordinates (clamped addresses + zeroing select, branch-free like gemm_f32_mfma)
+    float sa = 1.f, sb = 1.f;                // fp16 engine: per-tensor power-of-two scales from the partial maxima
+    if (F16) {
+        float ma = 0.f, mb = 0.f;
+        for (int i = tid; i < q.a_namax; i += 256) ma = fmaxf(ma, q.a_amax[i]);
+        for (int i = tid; i < q.b_namax; i += 256) mb = fmaxf(mb, q.b_amax[i]);
+        ma = wave_max(ma); mb = wave_max(mb);
+        float* red = (float*)smem;
+        if (lane == 0) { red[wave] = ma; red[4 + wave] = mb; }
+        __syncthreads();
+        sa = f16_scale_of(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+        sb = f16_scale_of(fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7])));
+        __syncthreads();
+    }
+
+    // ---- staging through BUFFER loads: one resource descriptor per operand (plane), a per-thread byte offset
+    // computed once, and the k position as the instruction's SCALAR offset -- no per-tile address arithmetic, and
+    // reads past the end of an operand return 0 instead of faulting.  Rows >= M (N) of a tile may therefore hold
+    // whatever lies behind the operand inside its extent: they only reach accumulator rows that are never stored.
+    // Only a partial last k-tile of a k-contiguous operand needs zeroing (uniform branch, tail tile only); a
+    // k-strided operand runs off the end of its extent there and reads zeros.
     //  fp32 k-contiguous: 4 float4 per thread, f = tid + 256 r -> (row f>>3, k 4*(f&7))
     //  fp32 k-strided   : one 4(k) x 4(m) micro-block per thread: k4 = tid>>5, m4 = tid&31; load r = k row
-    //  pre-split planes : per plane 128 rows x 4 chunks of 8 bf16; f = tid + 256 r (r < 2) -> (row f>>2, chunk f&3)
+    //  pre-split planes : per plane 128 rows x 4 chunks of 8 halves; f = tid + 256 r (r < 2) -> (row f>>2, chunk f&3)
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    f32x4 ra[4], rb[4];                      // fp32 operand registers
-    f32x4 qa[A_PRE ? 2 * NPL : 1], qb[B_PRE ? 2 * NPL : 1];     // pre-split operand registers (16 B = 8 bf16 each)
-    const float* pa[4];
-    const float* pb[4];
-    const __bf16* pqa[2];
-    const __bf16* pqb[2];
+    struct Stage {                           // one k-tile in flight between global memory and LDS
+        f32x4 ra[4], rb[4];                  // fp32 operand registers
+        f32x4 qa[A_PRE ? 2 * NPL : 1], qb[B_PRE ? 2 * NPL : 1];     // pre-split operand registers (16 B = 8 x 16 bit each)
+    };
+    Stage R0;
+    __amdgpu_buffer_rsrc_t rsA[A_PRE ? NPL : 1], rsB[B_PRE ? NPL : 1];
+    uint32_t voa[4], vob[4];                 // byte offsets of this thread's loads at k = 0
     int ka[4], kb[4];
-    bool va[4], vb[4];
+    if (A_PRE) {
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) rsA[pl] = make_rsrc(q.Ap + (size_t)pl * q.a_pstride, p.a_bytes >> 1);
+    } else {
+        rsA[0] = make_rsrc(p.A, p.a_bytes);
+    }
+    if (B_PRE) {
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) rsB[pl] = make_rsrc(q.Bp + (size_t)pl * q.b_pstride, p.b_bytes >> 1);
+    } else {
+        rsB[0] = make_rsrc(p.B, p.b_bytes);
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int f = tid + 256 * r;
         if (A_PRE) {
-            if (r < 2) {
-                const int gm = m0 + (f >> 2);
-                ka[r] = (f & 3) << 3; va[r] = gm < p.M;
-                pqa[r] = q.Ap + (size_t)min(gm, p.M - 1) * p.lda;
-            }
+            ka[r] = (f & 3) << 3;
+            voa[r] = ((uint32_t)(m0 + (f >> 2)) * (uint32_t)p.lda + ka[r]) * 2u;
         } else if (A_KC) {
-            const int gm = m0 + (f >> 3);
-            ka[r] = (f & 7) << 2; va[r] = gm < p.M;
-            pa[r] = p.A + (size_t)min(gm, p.M - 1) * p.lda;
+            ka[r] = (f & 7) << 2;
+            voa[r] = ((uint32_t)(m0 + (f >> 3)) * (uint32_t)p.lda + ka[r]) * 4u;
         } else {
-            const int gm = m0 + ((tid & 31) << 2);
-            ka[r] = ((tid >> 5) << 2) + r; va[r] = gm < p.M;
-            pa[r] = p.A + min(gm, p.M - 4);
+            ka[r] = ((tid >> 5) << 2) + r;
+            voa[r] = ((uint32_t)ka[r] * (uint32_t)p.lda + m0 + ((tid & 31) << 2)) * 4u;
         }
         if (B_PRE) {
-            if (r < 2) {
-                const int gn = n0 + (f >> 2);
-                kb[r] = (f & 3) << 3; vb[r] = gn < p.N;
-                pqb[r] = q.Bp + (size_t)min(gn, p.N - 1) * p.ldb;
-            }
+            kb[r] = (f & 3) << 3;
+            vob[r] = ((uint32_t)(n0 + (f >> 2)) * (uint32_t)p.ldb + kb[r]) * 2u;
         } else if (B_KC) {
-            const int gn = n0 + (f >> 3);
-            kb[r] = (f & 7) << 2; vb[r] = gn < p.N;
-            pb[r] = p.B + (size_t)min(gn, p.N - 1) * p.ldb;
+            kb[r] = (f & 7) << 2;
+            vob[r] = ((uint32_t)(n0 + (f >> 3)) * (uint32_t)p.ldb + kb[r]) * 4u;
         } else {
-            const int gn = n0 + ((tid & 31) << 2);
-            kb[r] = ((tid >> 5) << 2) + r; vb[r] = gn < p.N;
-            pb[r] = p.B + min(gn, p.N - 4);
+            kb[r] = ((tid >> 5) << 2) + r;
+            vob[r] = ((uint32_t)kb[r] * (uint32_t)p.ldb + n0 + ((tid & 31) << 2)) * 4u;
         }
     }
-    const int kclampA = A_PRE ? kend - 8 : (A_KC ? kend - 4 : kend - 1);
-    const int kclampB = B_PRE ? kend - 8 : (B_KC ? kend - 4 : kend - 1);
-    auto gload = [&](int k0) {
+    auto gload = [&](Stage& R, int k0) {
+        const uint32_t sa_off = A_PRE ? (uint32_t)k0 * 2u : (A_KC ? (uint32_t)k0 * 4u : (uint32_t)k0 * (uint32_t)p.lda * 4u);
+        const uint32_t sb_off = B_PRE ? (uint32_t)k0 * 2u : (B_KC ? (uint32_t)k0 * 4u : (uint32_t)k0 * (uint32_t)p.ldb * 4u);
         if (A_PRE) {
 #pragma unroll
             for (int r = 0; r < 2; ++r)
 #pragma unroll
-                for (int pl = 0; pl < NPL; ++pl)
-                    qa[r * NPL + pl] = *(const f32x4*)(pqa[r] + (size_t)pl * q.a_pstride + min(k0 + ka[r], kclampA));
+                for (int pl = 0; pl < NPL; ++pl) R.qa[r * NPL + pl] = buf_load4(rsA[pl], voa[r], sa_off);
         } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int gk = min(k0 + ka[r], kclampA);
-                ra[r] = A_KC ? *(const f32x4*)(pa[r] + gk) : *(const f32x4*)(pa[r] + (size_t)gk * p.lda);
-            }
+            for (int r = 0; r < 4; ++r) R.ra[r] = buf_load4(rsA[0], voa[r], sa_off);
         }
         if (B_PRE) {
 #pragma unroll
             for (int r = 0; r < 2; ++r)
 #pragma unroll
-                for (int pl = 0; pl < NPL; ++pl)
-                    qb[r * NPL + pl] = *(const f32x4*)(pqb[r] + (size_t)pl * q.b_pstride + min(k0 + kb[r], kclampB));
+                for (int pl = 0; pl < NPL; ++pl) R.qb[r * NPL + pl] = buf_load4(rsB[pl], vob[r], sb_off);
         } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int gk = min(k0 + kb[r], kclampB);
-                rb[r] = B_KC ? *(const f32x4*)(pb[r] + gk) : *(const f32x4*)(pb[r] + (size_t)gk * p.ldb);
-            }
+            for (int r = 0; r < 4; ++r) R.rb[r] = buf_load4(rsB[0], vob[r], sb_off);
         }
     };
-    // registers -> bf16 planes in LDS (rows = m or n)
-    auto lstore = [&](int k0) {
+    // registers -> 16-bit planes in LDS (rows = m or n).  TAIL: the tile crosses kend (last tile, K % 32 != 0)
+    auto lstore = [&](const Stage& R, int k0, auto tail) {
+        constexpr bool TAIL = decltype(tail)::value;
         if (A_PRE) {
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const int f = tid + 256 * r;
-                const bool ok = va[r] && k0 + ka[r] < kend;
+                const bool ok = !TAIL || k0 + ka[r] < kend;
 #pragma unroll
                 for (int pl = 0; pl < NPL; ++pl)
-                    *(f32x4*)(As + pl * XPLANE + (f >> 2) * XRS + ((f & 3) << 3)) = ok ? qa[r * NPL + pl] : zero4;
+                    *(f32x4*)(As + pl * XPLANE + (f >> 2) * XRS + ((f & 3) << 3)) = ok ? R.qa[r * NPL + pl] : zero4;
             }
         } else if (A_KC) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int f = tid + 256 * r;
-                split_store4<NPL>(As, (f >> 3) * XRS + ((f & 7) << 2), (va[r] && k0 + ka[r] < kend) ? ra[r] : zero4);
+                split_store4<NPL, F16>(As, (f >> 3) * XRS + ((f & 7) << 2), (!TAIL || k0 + ka[r] < kend) ? R.ra[r] : zero4, sa);
             }
         } else {        // ra[r] = row k (4*k4 + r), columns m = 4*m4 .. +3  -> transpose 4x4 in registers
-            f32x4 x[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) x[r] = (va[r] && k0 + ka[r] < kend) ? ra[r] : zero4;
             const int mrow = (tid & 31) << 2, kcol = (tid >> 5) << 2;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) split_store4<NPL>(As, (mrow + j) * XRS + kcol, f32x4{x[0][j], x[1][j], x[2][j], x[3][j]});
+            for (int j = 0; j < 4; ++j)
+                split_store4<NPL, F16>(As, (mrow + j) * XRS + kcol, f32x4{R.ra[0][j], R.ra[1][j], R.ra[2][j], R.ra[3][j]}, sa);
         }
         if (B_PRE) {
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const int f = tid + 256 * r;
-                const bool ok = vb[r] && k0 + kb[r] < kend;
+                const bool ok = !TAIL || k0 + kb[r] < kend;
 #pragma unroll
                 for (int pl = 0; pl < NPL; ++pl)
-                    *(f32x4*)(Bs + pl * XPLANE + (f >> 2) * XRS + ((f & 3) << 3)) = ok ? qb[r * NPL + pl] : zero4;
+                    *(f32x4*)(Bs + pl * XPLANE + (f >> 2) * XRS + ((f & 3) << 3)) = ok ? R.qb[r * NPL + pl] : zero4;
             }
         } else if (B_KC) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int f = tid + 256 * r;
-                split_store4<NPL>(Bs, (f >> 3) * XRS + ((f & 7) << 2), (vb[r] && k0 + kb[r] < kend) ? rb[r] : zero4);
+                split_store4<NPL, F16>(Bs, (f >> 3) * XRS + ((f & 7) << 2), (!TAIL || k0 + kb[r] < kend) ? R.rb[r] : zero4, sb);
             }
         } else {
-            f32x4 x[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) x[r] = (vb[r] && k0 + kb[r] < kend) ? rb[r] : zero4;
             const int nrow = (tid & 31) << 2, kcol = (tid >> 5) << 2;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) split_store4<NPL>(Bs, (nrow + j) * XRS + kcol, f32x4{x[0][j], x[1][j], x[2][j], x[3][j]});
+            for (int j = 0; j < 4; ++j)
+                split_store4<NPL, F16>(Bs, (nrow + j) * XRS + kcol, f32x4{R.rb[0][j], R.rb[1][j], R.rb[2][j], R.rb[3][j]}, sb);
         }
     };
+    auto lstore_at = [&](const Stage& R, int k0) {
+        if (k0 + GBK <= kend) lstore(R, k0, std::false_type{});
+        else lstore(R, k0, std::true_type{});
+    };
 
-    gload(kbeg);
-    lstore(kbeg);
-    __syncthreads();
-    for (int k0 = kbeg; k0 < kend; k0 += GBK) {
-        gload(k0 + GBK);                       // next tile HBM/L2 -> registers (clamped past the end), lands under the MFMAs
+    auto mma = [&]() {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {          // two K=16 steps per tile
-            bf16x8 fa[2][NPL], fb[2][NPL];
+            f32x4 fa[2][NPL], fb[2][NPL];     // 8 sixteen-bit k values per lane
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int pl = 0; pl < NPL; ++pl) {
-                    fa[t][pl] = *(const bf16x8*)(As + pl * XPLANE + (wm * 64 + t * 32 + li) * XRS + s * 16 + lh * 8);
-                    fb[t][pl] = *(const bf16x8*)(Bs + pl * XPLANE + (wn * 64 + t * 32 + li) * XRS + s * 16 + lh * 8);
+                    fa[t][pl] = *(const f32x4*)(As + pl * XPLANE + (wm * 64 + t * 32 + li) * XRS + s * 16 + lh * 8);
+                    fb[t][pl] = *(const f32x4*)(Bs + pl * XPLANE + (wn * 64 + t * 32 + li) * XRS + s * 16 + lh * 8);
                 }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     f32x16 c = acc[i][j];
-                    if (NPL == 3) {             // smallest terms first
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], c, 0, 0, 0);           // mid.mid
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][NPL - 1], fb[j][0], c, 0, 0, 0);     // lo.hi
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][NPL - 1], c, 0, 0, 0);     // hi.lo
+                    if (F16) {
+                        c = mfma_x<true>(fa[i][1], fb[j][0], c);                // lo.hi
+                        c = mfma_x<true>(fa[i][0], fb[j][1], c);                // hi.lo
+                        c = mfma_x<true>(fa[i][0], fb[j][0], c);                // hi.hi
+                    } else {
+                        if (NPL == 3) {         // smallest terms first
+                            c = mfma_x<false>(fa[i][1], fb[j][1], c);           // mid.mid
+                            c = mfma_x<false>(fa[i][NPL - 1], fb[j][0], c);     // lo.hi
+                            c = mfma_x<false>(fa[i][0], fb[j][NPL - 1], c);     // hi.lo
+                        }
+                        c = mfma_x<false>(fa[i][1], fb[j][0], c);               // mid.hi
+                        c = mfma_x<false>(fa[i][0], fb[j][1], c);               // hi.mid
+                        c = mfma_x<false>(fa[i][0], fb[j][0], c);               // hi.hi
                     }
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], c, 0, 0, 0);               // mid.hi
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], c, 0, 0, 0);               // hi.mid
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], c, 0, 0, 0);               // hi.hi
                     acc[i][j] = c;
                 }
         }
+    };
+    gload(R0, kbeg);
+    lstore_at(R0, kbeg);
+    __syncthreads();
+    for (int k0 = kbeg; k0 < kend; k0 += GBK) {
+        gload(R0, k0 + GBK);                   // next tile L2/HBM -> registers, lands under the MFMAs
+        __builtin_amdgcn_sched_barrier(0);     // (the scheduler would otherwise sink the loads below the MFMAs to save registers)
+        mma();
         __syncthreads();
         if (k0 + GBK < kend) {
-            lstore(k0 + GBK);
+            lstore_at(R0, k0 + GBK);
             __syncthreads();
         }
     }
@@ -261,7 +343,9 @@ __global__ __launch_bounds__(256) void gemm_bf16x6_mfma(const GemmArgs p, const 
     // ---- epilogue: identical to gemm_f32_mfma (the 32x32 C/D register map does not depend on the input type)
     float* Cs = (float*)smem + wave * (32 * 36);
     const bool split = gridDim.z > 1;
+    float am = 0.f;
     float* Cout = p.C + (size_t)blockIdx.z * (size_t)p.slab_stride;
+    const float inv_a = 1.f / sa, inv_b = 1.f / sb;      // exact powers of two
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -276,6 +360,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x6_mfma(const GemmArgs p, const 
                 const int gm = m0 + wm * 64 + i * 32 + row, gn = n0 + wn * 64 + j * 32 + c4;
                 if (gm < p.M && gn < p.N) {
                     f32x4 v = *(const f32x4*)(Cs + row * 36 + c4);
+                    if (F16) v = (v * inv_a) * inv_b;
                     if (!split) {
                         if (p.row_scale) v *= p.row_scale[gm];
                         if (p.bias) v += *(const f32x4*)(p.bias + gn);
@@ -291,11 +376,13 @@ __global__ __launch_bounds__(256) void gemm_bf16x6_mfma(const GemmArgs p, const 
                         if (p.residual) v += *(const f32x4*)(p.residual + (size_t)(gm % p.res_period) * p.ldr + gn);
                     }
                     *(f32x4*)(Cout + (size_t)gm * p.ldc + gn) = v;
+                    am = absmax4(am, v);
                 }
             }
             __syncthreads();
         }
     }
+    if (p.amax_out) amax_commit(p.amax_out, am, blockIdx.x * 4 + wave);
 }
 
 // ---------------------------------------------------------------- producers of pre-split planes
@@ -312,10 +399,59 @@ __global__ __launch_bounds__(256) void split3_flat_kernel(const float* __restric
         *(uint2*)(planes + 2 * pstride + i) = make_uint2(l0, l1);
     }
 }
+// fp16 engine: planes[0/1][i] = hi / lo of x[i] * s, s from the partial maxima (one scale for the whole buffer)
+__global__ __launch_bounds__(256) void splith_flat_kernel(const float* __restrict__ x, __bf16* __restrict__ planes,
+                                                          long long n, long long pstride, const float* __restrict__ amax, int namax) {
+    __shared__ float red[4];
+    float m = 0.f;
+    for (int i = threadIdx.x; i < namax; i += 256) m = fmaxf(m, amax[i]);
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    const float s = f16_scale_of(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+    for (long long i = (blockIdx.x * (long long)blockDim.x + threadIdx.x) * 4; i < n; i += (long long)gridDim.x * blockDim.x * 4) {
+        const f32x4 v = *(const f32x4*)(x + i);
+        uint32_t h0, l0, h1, l1;
+        splith_pair(v.x, v.y, s, h0, l0);
+        splith_pair(v.z, v.w, s, h1, l1);
+        *(uint2*)(planes + i) = make_uint2(h0, h1);
+        *(uint2*)(planes + pstride + i) = make_uint2(l0, l1);
+    }
+}
+// partial maxima of |x| over an [rows, cols] view (row stride ld): out[blockIdx.x], gridDim.x partials
+__global__ __launch_bounds__(256) void absmax_partial_kernel(const float* __restrict__ x, long long rows, int cols, int ld,
+                                                             float* __restrict__ out) {
+    __shared__ float red[4];
+    const int c4n = cols >> 2;
+    const long long n4 = rows * c4n;
+    float m = 0.f;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / c4n;
+        const int c = (int)(i - r * c4n) << 2;
+        const f32x4 v = *(const f32x4*)(x + r * ld + c);
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
 // planes[p][c * R + r] = p-th term of x[r * ld + c]   (transposed copy of an [R, C] matrix; 32 x 32 tiles through LDS)
+template <bool F16>
 __global__ __launch_bounds__(256) void split3_transpose_kernel(const float* __restrict__ x, int R, int Cc, int ld,
-                                                               __bf16* __restrict__ planes, long long pstride) {
+                                                               __bf16* __restrict__ planes, long long pstride,
+                                                               const float* __restrict__ amax, int namax) {
     __shared__ float tile[32][33];
+    __shared__ float red[4];
+    float s = 1.f;
+    if (F16) {
+        float m = 0.f;
+        for (int i = threadIdx.x; i < namax; i += 256) m = fmaxf(m, amax[i]);
+        m = wave_max(m);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+        __syncthreads();
+        s = f16_scale_of(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+    }
     const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;        // 32 x 8
 #pragma unroll
@@ -329,12 +465,18 @@ __global__ __launch_bounds__(256) void split3_transpose_kernel(const float* __re
         const int c = c0 + ty + 8 * k, r = r0 + tx;                // output row = c, column = r (contiguous over tx)
         if (c < Cc && r < R) {
             const float v = tile[tx][ty + 8 * k];
-            const __bf16 h = (__bf16)v;
-            const float r1 = v - (float)h;
-            const __bf16 m = (__bf16)r1;
-            const __bf16 l = (__bf16)(r1 - (float)m);
             const size_t o = (size_t)c * R + r;
-            planes[o] = h; planes[pstride + o] = m; planes[2 * pstride + o] = l;
+            if (F16) {
+                const _Float16 h = (_Float16)(v * s);
+                const _Float16 l = (_Float16)__builtin_fmaf(v, s, -(float)h);
+                ((_Float16*)planes)[o] = h; ((_Float16*)planes)[pstride + o] = l;
+            } else {
+                const __bf16 h = (__bf16)v;
+                const float r1 = v - (float)h;
+                const __bf16 m = (__bf16)r1;
+                const __bf16 l = (__bf16)(r1 - (float)m);
+                planes[o] = h; planes[pstride + o] = m; planes[2 * pstride + o] = l;
+            }
         }
     }
 }

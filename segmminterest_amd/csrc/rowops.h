@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void l1norm_kernel(const float* __restrict__ x
 // y = LN(x) * gamma + beta, optional dropout on y (embedding, encoder.py:461,471); saves mean / rstd.
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                      const float* __restrict__ beta, float* __restrict__ y, float* mean_out,
-                                     float* rstd_out, long long rows, int d, float eps, DropCfg drop) {
+                                     float* rstd_out, long long rows, int d, float eps, DropCfg drop, float* amax) {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -63,6 +63,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     }
     const float rstd = rsqrtf(wave_sum(q) / d + eps);
     if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+    float am = 0.f;
 #pragma unroll
     for (int i = 0; i < ROW_MAXV; ++i) {
         const int c = lane * 4 + i * 256;
@@ -70,8 +71,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
             f32x4 o = (v[i] - mean) * rstd * *(const f32x4*)(gamma + c) + *(const f32x4*)(beta + c);
             if (drop.p > 0.f) o = drop_apply4(drop, ((uint64_t)row * d + c) >> 2, o);
             *(f32x4*)(y + row * d + c) = o;
+            am = absmax4(am, o);
         }
     }
+    if (amax) amax_commit(amax, am, (unsigned)row);
 }
 
 // ---------------------------------------------------------------- LayerNorm backward
@@ -83,8 +86,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                      const float* __restrict__ gamma, float* __restrict__ dx,
                                      float* __restrict__ dx_drop, float* __restrict__ part_dgamma,
                                      float* __restrict__ part_dbeta, long long rows, int d, DropCfg drop_y,
-                                     DropCfg drop_branch) {
+                                     DropCfg drop_branch, float* amax) {
     __shared__ float red[4][2048];
+    float am = 0.f;          // max |dx_drop| (or |dx| when there is no dropped copy): the tensor the GEMMs consume
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     f32x4 ag[ROW_MAXV], ab[ROW_MAXV], gm[ROW_MAXV];
 #pragma unroll
@@ -121,14 +125,16 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
             if (c < d) {
                 const f32x4 o = (g[i] - s1 - xh[i] * s2) * rs;
                 *(f32x4*)(dx + row * d + c) = o;
+                f32x4 od = o;
                 if (dx_drop) {
-                    f32x4 od = o;
                     if (drop_branch.p > 0.f) od = drop_apply4(drop_branch, ((uint64_t)row * d + c) >> 2, o);
                     *(f32x4*)(dx_drop + row * d + c) = od;
                 }
+                am = absmax4(am, od);
             }
         }
     }
+    if (amax) amax_commit(amax, am, blockIdx.x * nw + wave);
     // cross-wave reduce of the dgamma / dbeta partials, one partial row per workgroup
     for (int pass = 0; pass < 2; ++pass) {
         __syncthreads();

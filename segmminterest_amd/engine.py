@@ -98,7 +98,11 @@ class ParamStore:
         self.overlap = os.environ.get("SEGMM_OVERLAP", "1") != "0"
         # pre-split bf16 planes of the weights for the bf16x6 GEMM engine: W planes (forward) and W^T planes (dgrad
         # in the NT form), refreshed when the parameters change (one split pass per optimizer step)
-        self.use_planes = H.GEMM_ENGINE == H.ENGINE_BF16X6 and os.environ.get("SEGMM_PLANES", "1") != "0"
+        # (fp16x3 engine: two fp16 planes scaled by one power of two derived from ``wamax``, the partial maxima of
+        # |parameters|, which the GEMMs also need for weights they read as fp32)
+        self.engine_h = H.GEMM_ENGINE == H.ENGINE_F16X3
+        self.use_planes = H.GEMM_ENGINE in (H.ENGINE_BF16X6, H.ENGINE_F16X3) and os.environ.get("SEGMM_PLANES", "1") != "0"
+        self.wamax = None
         self.wgrad_planes = 2 if os.environ.get("SEGMM_WGRAD", "x6") == "x3" else 3      # x3 = opt-in, see DESIGN.md
         self.wplanes = self.wTplanes = None
         self.fused_version = 0
@@ -135,19 +139,31 @@ class ParamStore:
         self.refresh_planes()
 
     def refresh_planes(self):
-        if not self.use_planes:
+        if not (self.use_planes or self.engine_h):
             return
         # staleness: in-place updates through torch (optimizer.step, load_state_dict) bump the parameters' version
         # counters; the fused AdamW kernel bumps ``fused_version`` itself
         key = (self.flat._version, self.fused_version, self.flat.data_ptr(), sum(self._params[n]._version for n in self.live_names))
         if key == self._planes_key:
             return
-        if self.wplanes is None or self.wplanes.shape[1] != self.n_live or self.wplanes.device != self.flat.device:
-            self.wplanes = torch.empty((3, self.n_live), dtype=torch.bfloat16, device=self.flat.device)
-            self.wTplanes = torch.empty((3, self.n_live), dtype=torch.bfloat16, device=self.flat.device)
-        H.split3(self.flat, self.wplanes, self.n_live)
-        for off, R, Cc in self._transposes:
-            H.split3_transpose(self.flat, R, Cc, Cc, self.wTplanes, x_off=off, p_off=off)
+        dev = self.flat.device
+        if self.engine_h:
+            if self.wamax is None or self.wamax.device != dev:
+                self.wamax = torch.empty((H.AMAX_PARTS,), dtype=torch.float32, device=dev)
+            H.absmax(self.flat, 1, self.n_live, self.n_live, out=self.wamax)
+        if self.use_planes:
+            npl, dt = (2, torch.float16) if self.engine_h else (3, torch.bfloat16)
+            if self.wplanes is None or self.wplanes.shape != (npl, self.n_live) or self.wplanes.device != dev or self.wplanes.dtype != dt:
+                self.wplanes = torch.empty((npl, self.n_live), dtype=dt, device=dev)
+                self.wTplanes = torch.empty((npl, self.n_live), dtype=dt, device=dev)
+            if self.engine_h:
+                H.split2h(self.flat, self.wplanes, self.n_live, self.wamax)
+                for off, R, Cc in self._transposes:
+                    H.split2h_transpose(self.flat, R, Cc, Cc, self.wTplanes, self.wamax, x_off=off, p_off=off)
+            else:
+                H.split3(self.flat, self.wplanes, self.n_live)
+                for off, R, Cc in self._transposes:
+                    H.split3_transpose(self.flat, R, Cc, Cc, self.wTplanes, x_off=off, p_off=off)
         self._planes_key = key
 
     def _build(self, params):
@@ -263,28 +279,50 @@ def join_side(store):
         torch.cuda.current_stream().wait_stream(store._side_stream)
 
 
-def _wgrad(store, dY, ldy, y_off, X, ldx, x_off, Mrows, n_out, n_in, gW, accumulate=False):
+class AmaxArena:
+    """fp16x3 engine: zeroed [AMAX_SLOTS] rows, one per tensor that a GEMM will read; its producer kernel folds
+    max|x| into the row (hipabi / common.h), the consuming GEMMs derive the tensor's power-of-two scale from it.
+    One allocation + one fill per forward and per backward; ``new()`` returns None on the other engines, which
+    turns every amax argument into a no-op."""
+
+    def __init__(self, store, n):
+        self.t = torch.zeros((n, H.AMAX_SLOTS), dtype=torch.float32, device=store.flat.device) if store.engine_h else None
+        self.i = 0
+
+    def new(self):
+        if self.t is None:
+            return None
+        if self.i >= self.t.shape[0]:
+            raise RuntimeError("AmaxArena exhausted (%d rows)" % self.t.shape[0])
+        r = self.t[self.i]
+        self.i += 1
+        return r
+
+
+def _wgrad(store, dY, ldy, y_off, X, ldx, x_off, Mrows, n_out, n_in, gW, accumulate=False, a_amax=None, b_amax=None):
     """gW[n_out, n_in] (+)= dY[:, y_off:y_off+n_out]^T . X[:, x_off:x_off+n_in]  (split-K over tokens)."""
     splits = _splits_for(n_out, n_in, Mrows)
     ws = store.buf("splitk_ws_side" if store._on_side else "splitk_ws", (max(splits, 1) * n_out * n_in,)) if splits > 1 else None
     H.gemm(H.LAYOUT_TN, n_out, n_in, Mrows, dY, ldy, X, ldx, gW, n_in, splits=splits, workspace=ws,
-           accumulate=accumulate, a_off=y_off, b_off=x_off, nplanes=store.wgrad_planes if H.GEMM_ENGINE == H.ENGINE_BF16X6 else 3)
+           accumulate=accumulate, a_off=y_off, b_off=x_off, nplanes=store.wgrad_planes if H.GEMM_ENGINE == H.ENGINE_BF16X6 else 3,
+           a_amax=a_amax, b_amax=b_amax)
 
 
 def _lin_fwd(store, M, N, K, X, wname, out, ldo, **kw):
     """out[M,N] = X[M,K] . W[N,K]^T (+ epilogue); W = the parameter (or fused group starting at) ``wname``."""
     if store.use_planes and K % 8 == 0:
         kw["b_planes"] = (store.wplanes, store.index[wname][0])
-    H.gemm(H.LAYOUT_NT, M, N, K, X, K, store.p(wname), K, out, ldo, **kw)
+    H.gemm(H.LAYOUT_NT, M, N, K, X, K, store.p(wname), K, out, ldo, b_amax=store.wamax, **kw)
 
 
 def _lin_dgrad(store, M, n_in, n_out, dY, wname, out, **kw):
     """out[M,n_in] = dY[M,n_out] . W[n_out,n_in] (+ epilogue).  With W^T planes this is the NT form (both operands
     k-contiguous), otherwise the NN layout on the fp32 weights."""
     if store.use_planes and n_out % 8 == 0:
-        H.gemm(H.LAYOUT_NT, M, n_in, n_out, dY, n_out, None, n_out, out, n_in, b_planes=(store.wTplanes, store.index[wname][0]), **kw)
+        H.gemm(H.LAYOUT_NT, M, n_in, n_out, dY, n_out, None, n_out, out, n_in, b_planes=(store.wTplanes, store.index[wname][0]),
+               b_amax=store.wamax, **kw)
     else:
-        H.gemm(H.LAYOUT_NN, M, n_in, n_out, dY, n_out, store.p(wname), n_in, out, n_in, **kw)
+        H.gemm(H.LAYOUT_NN, M, n_in, n_out, dY, n_out, store.p(wname), n_in, out, n_in, b_amax=store.wamax, **kw)
 
 
 def _colsum(store, X, ld, M, N, out, x_off=0, w=None, accumulate=False):
@@ -292,12 +330,13 @@ def _colsum(store, X, ld, M, N, out, x_off=0, w=None, accumulate=False):
     H.colsum(X, ld, M, N, out, ws, w=w, accumulate=accumulate, x_off=x_off)
 
 
-def _ln_bwd(store, dy, x, mean, rstd, gname, bname, gbuf, dx, dx_drop, rows, d, drop_y=(0.0, 0), drop_b=(0.0, 0), seed=0):
+def _ln_bwd(store, dy, x, mean, rstd, gname, bname, gbuf, dx, dx_drop, rows, d, drop_y=(0.0, 0), drop_b=(0.0, 0), seed=0,
+            amax=None):
     parts = H.layernorm_bwd_parts(rows)
     pg = store.buf("ln_pg", (parts, d))
     pb = store.buf("ln_pb", (parts, d))
     H.layernorm_bwd(dy, x, mean, rstd, store.p(gname), dx, dx_drop, pg, pb, drop_y_p=drop_y[0], drop_y_site=drop_y[1],
-                    drop_b_p=drop_b[0], drop_b_site=drop_b[1], seed=seed)
+                    drop_b_p=drop_b[0], drop_b_site=drop_b[1], seed=seed, amax=amax)
     _colsum(store, pg, d, parts, d, store.g(gname, gbuf))
     _colsum(store, pb, d, parts, d, store.g(bname, gbuf))
 
@@ -344,6 +383,7 @@ class BackboneRun:
         self.vm, self.um = vm, um
         sv = self.sv
         ref = vm
+        am = self.am = AmaxArena(st, 6 + 12 * max(self.N - 1, 0))
         # ---- embedding (encoder.py:425-473)
         pre_v = _empty(ref, Mv, d)
         if bb.id_vid:
@@ -355,11 +395,13 @@ class BackboneRun:
             x = vid_feat.contiguous().float()
             sv["vid_x"] = x
             Din = x.shape[-1]
-            _lin_fwd(st, Mv, d, Din, x, P + "vid_proj.weight", pre_v, d,
+            sv["am_vid_x"] = H.absmax(x, Mv, Din, Din) if st.engine_h else None      # external input: its own pass
+            _lin_fwd(st, Mv, d, Din, x, P + "vid_proj.weight", pre_v, d, a_amax=sv["am_vid_x"],
                      bias=st.p(P + "vid_proj.bias"), residual=st.p(P + "vid_pe.weight"), ldr=d, res_period=S)
         Ev, mev, rev = _empty(ref, Mv, d), _empty(ref, Mv), _empty(ref, Mv)
+        am_v = am.new()
         H.layernorm_fwd(pre_v, st.p(P + "vid_ln.weight"), st.p(P + "vid_ln.bias"), Ev, mev, rev, drop_p=p_drop, seed=seed,
-                        site=_site(self.bi, 0, K_EMB_V))
+                        site=_site(self.bi, 0, K_EMB_V), amax=am_v)
         sv["pre_v"], sv["mev"], sv["rev"] = pre_v, mev, rev
         pre_u = _empty(ref, Mu, d)
         if bb.id_usr:
@@ -370,100 +412,108 @@ class BackboneRun:
             xu = usr_feat.contiguous().float()
             sv["usr_x"] = xu
             Din = xu.shape[-1]
-            _lin_fwd(st, Mu, d, Din, xu, P + "usr_proj.weight", pre_u, d,
+            sv["am_usr_x"] = H.absmax(xu, Mu, Din, Din) if st.engine_h else None
+            _lin_fwd(st, Mu, d, Din, xu, P + "usr_proj.weight", pre_u, d, a_amax=sv["am_usr_x"],
                      bias=st.p(P + "usr_proj.bias"), residual=st.p(P + "usr_pe.weight"), ldr=d, res_period=Lt)
         Eu, meu, reu = _empty(ref, Mu, d), _empty(ref, Mu), _empty(ref, Mu)
+        am_u = am.new()
         H.layernorm_fwd(pre_u, st.p(P + "usr_ln.weight"), st.p(P + "usr_ln.bias"), Eu, meu, reu, drop_p=p_drop, seed=seed,
-                        site=_site(self.bi, 0, K_EMB_U))
+                        site=_site(self.bi, 0, K_EMB_U), amax=am_u)
         sv["pre_u"], sv["meu"], sv["reu"] = pre_u, meu, reu
         Xv, Xu = Ev, Eu
         sv["layers"] = []
         for i in range(max(self.N - 1, 0)):
-            Xv, Xu = self._layer_fwd(i, Xv, Xu)
+            Xv, Xu, am_v, am_u = self._layer_fwd(i, Xv, Xu, am_v, am_u)
         return Xv.view(B, S, d), Eu.view(B, Lt, d)
 
-    def _side_post(self, i, L, side, X, A, M, kinds):
+    def _side_post(self, i, L, side, X, A, M, kinds, am_A):
         """R1 = X + drop(A.Wff^T+b); X1 = LN(R1); H = drop(gelu(X1.W0^T+b0)); R2 = X1 + drop(H.W1^T+b1); X2 = LN(R2)."""
-        st, d, seed = self.store, self.d, self.seed
+        st, d, seed, am = self.store, self.d, self.seed, self.am
         k_ao, k_mi, k_mo = kinds
         ca = L + "cross_attn."
         R1 = _empty(X, M, d)
-        _lin_fwd(st, M, d, d, A, ca + "ff_%s.weight" % side, R1, d, bias=st.p(ca + "ff_%s.bias" % side),
+        _lin_fwd(st, M, d, d, A, ca + "ff_%s.weight" % side, R1, d, bias=st.p(ca + "ff_%s.bias" % side), a_amax=am_A,
                residual=X, ldr=d, res_period=M, drop_p=self.p_drop, seed=seed, site=_site(self.bi, i, k_ao))
         X1, m1, r1 = _empty(X, M, d), _empty(X, M), _empty(X, M)
-        H.layernorm_fwd(R1, st.p(ca + "ln_%s.weight" % side), st.p(ca + "ln_%s.bias" % side), X1, m1, r1)
+        am_X1, am_Hh, am_X2 = am.new(), am.new(), am.new()
+        H.layernorm_fwd(R1, st.p(ca + "ln_%s.weight" % side), st.p(ca + "ln_%s.bias" % side), X1, m1, r1, amax=am_X1)
         G, Hh = _empty(X, M, d), _empty(X, M, d)
         ff = L + "ff_%s.layers." % side
-        _lin_fwd(st, M, d, d, X1, ff + "0.weight", Hh, d, bias=st.p(ff + "0.bias"),
+        _lin_fwd(st, M, d, d, X1, ff + "0.weight", Hh, d, bias=st.p(ff + "0.bias"), a_amax=am_X1, c_amax=am_Hh,
                activation=H.ACT_GELU, aux=G, ldaux=d, drop_p=self.p_inner, seed=seed, site=_site(self.bi, i, k_mi))
         R2 = _empty(X, M, d)
-        _lin_fwd(st, M, d, d, Hh, ff + "1.weight", R2, d, bias=st.p(ff + "1.bias"),
+        _lin_fwd(st, M, d, d, Hh, ff + "1.weight", R2, d, bias=st.p(ff + "1.bias"), a_amax=am_Hh,
                residual=X1, ldr=d, res_period=M, drop_p=self.p_drop, seed=seed, site=_site(self.bi, i, k_mo))
         X2, m2, r2 = _empty(X, M, d), _empty(X, M), _empty(X, M)
-        H.layernorm_fwd(R2, st.p(L + "ln_%s.weight" % side), st.p(L + "ln_%s.bias" % side), X2, m2, r2)
-        return X2, dict(A=A, R1=R1, X1=X1, m1=m1, r1=r1, G=G, Hh=Hh, R2=R2, m2=m2, r2=r2)
+        H.layernorm_fwd(R2, st.p(L + "ln_%s.weight" % side), st.p(L + "ln_%s.bias" % side), X2, m2, r2, amax=am_X2)
+        return X2, am_X2, dict(A=A, R1=R1, X1=X1, m1=m1, r1=r1, G=G, Hh=Hh, R2=R2, m2=m2, r2=r2, am_A=am_A, am_X1=am_X1,
+                               am_Hh=am_Hh)
 
-    def _layer_fwd(self, i, Xv, Xu):
-        st, d, P = self.store, self.d, self.pre
+    def _layer_fwd(self, i, Xv, Xu, am_Xv, am_Xu):
+        st, d, P, am = self.store, self.d, self.pre, self.am
         B, S, Lt, Mv, Mu, Hh, dh = self.B, self.S, self.Lt, self.Mv, self.Mu, self.H, self.dh
         full = i < self.N - 2
         nv, nu = (6, 6) if full else (4, 2)
         L = "%sencoder.layers.%d." % (P, i)
         ca = L + "cross_attn."
         Yv, Yu = _empty(Xv, Mv, nv * d), _empty(Xv, Mu, nu * d)
-        _lin_fwd(st, Mv, nv * d, d, Xv, ca + "v2v_proj.0.weight", Yv, nv * d, bias=st.p(ca + "v2v_proj.0.bias"))
-        _lin_fwd(st, Mu, nu * d, d, Xu, ca + "t2v_proj.1.weight", Yu, nu * d, bias=st.p(ca + "t2v_proj.1.bias"))
+        _lin_fwd(st, Mv, nv * d, d, Xv, ca + "v2v_proj.0.weight", Yv, nv * d, bias=st.p(ca + "v2v_proj.0.bias"), a_amax=am_Xv)
+        _lin_fwd(st, Mu, nu * d, d, Xu, ca + "t2v_proj.1.weight", Yu, nu * d, bias=st.p(ca + "t2v_proj.1.bias"), a_amax=am_Xu)
         Av, lse_v = _empty(Xv, Mv, d), _empty(Xv, 2, B, Hh, S)
+        am_Av = am.new()
         H.attn_fwd(B, Hh, dh, S, S, Lt, (Yv, 0), (Yv, d), nv * d, (Yv, 2 * d), (Yv, 3 * d), nv * d, (Yu, 0), (Yu, d), nu * d,
-                   self.vm, self.vm, self.um, Av, d, lse_v, drop_p=self.p_drop, seed=self.seed, site=_site(self.bi, i, K_ATT_V))
-        X2v, sv_v = self._side_post(i, L, "vid", Xv, Av, Mv, (K_AO_V, K_MI_V, K_MO_V))
-        rec = dict(full=full, Xv=Xv, Xu=Xu, Yv=Yv, Yu=Yu, lse_v=lse_v, v=sv_v)
-        X2u = None
+                   self.vm, self.vm, self.um, Av, d, lse_v, drop_p=self.p_drop, seed=self.seed, site=_site(self.bi, i, K_ATT_V),
+                   amax_o=am_Av)
+        X2v, am_X2v, sv_v = self._side_post(i, L, "vid", Xv, Av, Mv, (K_AO_V, K_MI_V, K_MO_V), am_Av)
+        rec = dict(full=full, Xv=Xv, Xu=Xu, Yv=Yv, Yu=Yu, lse_v=lse_v, v=sv_v, am_Xv=am_Xv, am_Xu=am_Xu)
+        X2u = am_X2u = None
         if full:
             Au, lse_u = _empty(Xv, Mu, d), _empty(Xv, 2, B, Hh, Lt)
+            am_Au = am.new()
             H.attn_fwd(B, Hh, dh, Lt, S, Lt, (Yu, 2 * d), (Yu, 3 * d), nu * d, (Yv, 4 * d), (Yv, 5 * d), nv * d,
                        (Yu, 4 * d), (Yu, 5 * d), nu * d, self.um, self.vm, self.um, Au, d, lse_u, drop_p=self.p_drop,
-                       seed=self.seed, site=_site(self.bi, i, K_ATT_U))
-            X2u, sv_u = self._side_post(i, L, "usr", Xu, Au, Mu, (K_AO_U, K_MI_U, K_MO_U))
+                       seed=self.seed, site=_site(self.bi, i, K_ATT_U), amax_o=am_Au)
+            X2u, am_X2u, sv_u = self._side_post(i, L, "usr", Xu, Au, Mu, (K_AO_U, K_MI_U, K_MO_U), am_Au)
             rec["lse_u"], rec["u"] = lse_u, sv_u
         self.sv["layers"].append(rec)
-        return X2v, (X2u if full else Xu)
+        return X2v, (X2u if full else Xu), am_X2v, (am_X2u if full else am_Xu)
 
     # ---------------------------------------------------------------- backward
     def _side_post_bwd(self, i, L, side, sv, dX2, M, kinds, gbuf, tag):
         """Reverse of _side_post.  Returns (dR1, dA): gradient wrt the residual input X and wrt the attention output."""
-        st, d, seed = self.store, self.d, self.seed
+        st, d, seed, am = self.store, self.d, self.seed, self.amb
         k_ao, k_mi, k_mo = kinds
         ca = L + "cross_attn."
         ff = L + "ff_%s.layers." % side
+        am_dM, am_dG, am_dZ = am.new(), am.new(), am.new()
         dR2 = st.buf("dR2" + tag, (M, d))
         dM = st.buf("dM" + tag, (M, d)) if self.p_drop > 0 else None
         _ln_bwd(st, dX2, sv["R2"], sv["m2"], sv["r2"], L + "ln_%s.weight" % side, L + "ln_%s.bias" % side, gbuf, dR2, dM, M, d,
-                drop_b=(self.p_drop, _site(self.bi, i, k_mo)), seed=seed)
+                drop_b=(self.p_drop, _site(self.bi, i, k_mo)), seed=seed, amax=am_dM)
         if dM is None:
             dM = dR2
         with side_work(st):
-            _wgrad(st, dM, d, 0, sv["Hh"], d, 0, M, d, d, st.g(ff + "1.weight", gbuf))
+            _wgrad(st, dM, d, 0, sv["Hh"], d, 0, M, d, d, st.g(ff + "1.weight", gbuf), a_amax=am_dM, b_amax=sv["am_Hh"])
             _colsum(st, dM, d, M, d, st.g(ff + "1.bias", gbuf))
         dG = st.buf("dG" + tag, (M, d))
-        _lin_dgrad(st, M, d, d, dM, ff + "1.weight", dG, activation=H.ACT_DGELU, aux=sv["G"], ldaux=d,
+        _lin_dgrad(st, M, d, d, dM, ff + "1.weight", dG, activation=H.ACT_DGELU, aux=sv["G"], ldaux=d, a_amax=am_dM, c_amax=am_dG,
                drop_p=self.p_inner, seed=seed, site=_site(self.bi, i, k_mi))
         with side_work(st):
-            _wgrad(st, dG, d, 0, sv["X1"], d, 0, M, d, d, st.g(ff + "0.weight", gbuf))
+            _wgrad(st, dG, d, 0, sv["X1"], d, 0, M, d, d, st.g(ff + "0.weight", gbuf), a_amax=am_dG, b_amax=sv["am_X1"])
             _colsum(st, dG, d, M, d, st.g(ff + "0.bias", gbuf))
         dX1 = st.buf("dX1" + tag, (M, d))
-        _lin_dgrad(st, M, d, d, dG, ff + "0.weight", dX1, residual=dR2, ldr=d, res_period=M)
+        _lin_dgrad(st, M, d, d, dG, ff + "0.weight", dX1, residual=dR2, ldr=d, res_period=M, a_amax=am_dG)
         dR1 = st.buf("dR1" + tag, (M, d))
         dZ = st.buf("dZ" + tag, (M, d)) if self.p_drop > 0 else None
         _ln_bwd(st, dX1, sv["R1"], sv["m1"], sv["r1"], ca + "ln_%s.weight" % side, ca + "ln_%s.bias" % side, gbuf, dR1, dZ, M, d,
-                drop_b=(self.p_drop, _site(self.bi, i, k_ao)), seed=seed)
+                drop_b=(self.p_drop, _site(self.bi, i, k_ao)), seed=seed, amax=am_dZ)
         if dZ is None:
             dZ = dR1
         with side_work(st):
-            _wgrad(st, dZ, d, 0, sv["A"], d, 0, M, d, d, st.g(ca + "ff_%s.weight" % side, gbuf))
+            _wgrad(st, dZ, d, 0, sv["A"], d, 0, M, d, d, st.g(ca + "ff_%s.weight" % side, gbuf), a_amax=am_dZ, b_amax=sv["am_A"])
             _colsum(st, dZ, d, M, d, st.g(ca + "ff_%s.bias" % side, gbuf))
         dA = st.buf("dA" + tag, (M, d))
-        _lin_dgrad(st, M, d, d, dZ, ca + "ff_%s.weight" % side, dA)
+        _lin_dgrad(st, M, d, d, dZ, ca + "ff_%s.weight" % side, dA, a_amax=am_dZ)
         return dR1, dA
 
     def _layer_bwd(self, i, rec, dXv_out, dXu_out, gbuf):
@@ -476,30 +526,35 @@ class BackboneRun:
         Yv, Yu = rec["Yv"], rec["Yu"]
         dYv, dYu = st.buf("dYv%d" % i, (Mv, nv * d)), st.buf("dYu%d" % i, (Mu, nu * d))
         Dv = st.buf("attnD", (B * Hh * max(S, Lt),))
+        am_dYv, am_dYu = self.amb.new(), self.amb.new()      # one per fused dY buffer: both attentions fold into them
         dR1v, dAv = self._side_post_bwd(i, L, "vid", rec["v"], dXv_out, Mv, (K_AO_V, K_MI_V, K_MO_V), gbuf, "v%d" % i)
         H.attn_bwd(B, Hh, dh, S, S, Lt, (Yv, 0), (Yv, d), nv * d, (Yv, 2 * d), (Yv, 3 * d), nv * d, (Yu, 0), (Yu, d), nu * d,
                    self.vm, self.vm, self.um, rec["lse_v"], dAv, d, Dv, (dYv, 0), (dYv, d), nv * d, (dYv, 2 * d), (dYv, 3 * d),
-                   nv * d, (dYu, 0), (dYu, d), nu * d, drop_p=self.p_drop, seed=self.seed, site=_site(self.bi, i, K_ATT_V))
+                   nv * d, (dYu, 0), (dYu, d), nu * d, drop_p=self.p_drop, seed=self.seed, site=_site(self.bi, i, K_ATT_V),
+                   amax_q=am_dYv, amax_ka=am_dYv, amax_kb=am_dYu)
         dR1u = None
         if full:
             dR1u, dAu = self._side_post_bwd(i, L, "usr", rec["u"], dXu_out, Mu, (K_AO_U, K_MI_U, K_MO_U), gbuf, "u%d" % i)
             H.attn_bwd(B, Hh, dh, Lt, S, Lt, (Yu, 2 * d), (Yu, 3 * d), nu * d, (Yv, 4 * d), (Yv, 5 * d), nv * d,
                        (Yu, 4 * d), (Yu, 5 * d), nu * d, self.um, self.vm, self.um, rec["lse_u"], dAu, d, Dv,
                        (dYu, 2 * d), (dYu, 3 * d), nu * d, (dYv, 4 * d), (dYv, 5 * d), nv * d, (dYu, 4 * d), (dYu, 5 * d), nu * d,
-                       drop_p=self.p_drop, seed=self.seed, site=_site(self.bi, i, K_ATT_U))
+                       drop_p=self.p_drop, seed=self.seed, site=_site(self.bi, i, K_ATT_U),
+                       amax_q=am_dYu, amax_ka=am_dYv, amax_kb=am_dYu)
         # fused projection weights / inputs
         with side_work(st):
-            _wgrad(st, dYv, nv * d, 0, rec["Xv"], d, 0, Mv, nv * d, d, _group_view(st, ca + "v2v_proj.0.weight", nv * d * d, gbuf))
+            _wgrad(st, dYv, nv * d, 0, rec["Xv"], d, 0, Mv, nv * d, d, _group_view(st, ca + "v2v_proj.0.weight", nv * d * d, gbuf),
+                   a_amax=am_dYv, b_amax=rec["am_Xv"])
             _colsum(st, dYv, nv * d, Mv, nv * d, _group_view(st, ca + "v2v_proj.0.bias", nv * d, gbuf))
-            _wgrad(st, dYu, nu * d, 0, rec["Xu"], d, 0, Mu, nu * d, d, _group_view(st, ca + "t2v_proj.1.weight", nu * d * d, gbuf))
+            _wgrad(st, dYu, nu * d, 0, rec["Xu"], d, 0, Mu, nu * d, d, _group_view(st, ca + "t2v_proj.1.weight", nu * d * d, gbuf),
+                   a_amax=am_dYu, b_amax=rec["am_Xu"])
             _colsum(st, dYu, nu * d, Mu, nu * d, _group_view(st, ca + "t2v_proj.1.bias", nu * d, gbuf))
         dXv_in = st.buf("dXv_in%d" % (i & 1), (Mv, d))
-        _lin_dgrad(st, Mv, d, nv * d, dYv, ca + "v2v_proj.0.weight", dXv_in, residual=dR1v, ldr=d, res_period=Mv)
+        _lin_dgrad(st, Mv, d, nv * d, dYv, ca + "v2v_proj.0.weight", dXv_in, residual=dR1v, ldr=d, res_period=Mv, a_amax=am_dYv)
         dXu_in = st.buf("dXu_in%d" % (i & 1), (Mu, d))
         if full:
-            _lin_dgrad(st, Mu, d, nu * d, dYu, ca + "t2v_proj.1.weight", dXu_in, residual=dR1u, ldr=d, res_period=Mu)
+            _lin_dgrad(st, Mu, d, nu * d, dYu, ca + "t2v_proj.1.weight", dXu_in, residual=dR1u, ldr=d, res_period=Mu, a_amax=am_dYu)
         else:
-            _lin_dgrad(st, Mu, d, nu * d, dYu, ca + "t2v_proj.1.weight", dXu_in)
+            _lin_dgrad(st, Mu, d, nu * d, dYu, ca + "t2v_proj.1.weight", dXu_in, a_amax=am_dYu)
         return dXv_in, dXu_in
 
     def backward(self, d_vid_out: torch.Tensor, gbuf: Optional[torch.Tensor] = None, on_bucket=None):
@@ -509,6 +564,7 @@ class BackboneRun:
         B, S, Lt, Mv, Mu = self.B, self.S, self.Lt, self.Mv, self.Mu
         dXv = d_vid_out.contiguous().view(Mv, d)
         dXu = None
+        self.amb = AmaxArena(st, 4 + 8 * max(self.N - 1, 0))
         for i in reversed(range(max(self.N - 1, 0))):
             dXv, dXu = self._layer_bwd(i, sv["layers"][i], dXv, dXu, gbuf)
             if on_bucket is not None:
@@ -516,19 +572,21 @@ class BackboneRun:
                 on_bucket("%slayer%d" % (P, i))
         # ---- embedding backward
         dpre_v = st.buf("dpre_v", (Mv, d))
+        am_dv = self.amb.new()
         _ln_bwd(st, dXv, sv["pre_v"], sv["mev"], sv["rev"], P + "vid_ln.weight", P + "vid_ln.bias", gbuf, dpre_v, None, Mv, d,
-                drop_y=(self.p_drop, _site(self.bi, 0, K_EMB_V)), seed=self.seed)
-        self._embed_bwd("vid", dpre_v, B, S, gbuf)
+                drop_y=(self.p_drop, _site(self.bi, 0, K_EMB_V)), seed=self.seed, amax=am_dv)
+        self._embed_bwd("vid", dpre_v, B, S, gbuf, am_dv)
         if self.N >= 2:
             dpre_u = st.buf("dpre_u", (Mu, d))
+            am_du = self.amb.new()
             _ln_bwd(st, dXu, sv["pre_u"], sv["meu"], sv["reu"], P + "usr_ln.weight", P + "usr_ln.bias", gbuf, dpre_u, None, Mu, d,
-                    drop_y=(self.p_drop, _site(self.bi, 0, K_EMB_U)), seed=self.seed)
-            self._embed_bwd("usr", dpre_u, B, Lt, gbuf)
+                    drop_y=(self.p_drop, _site(self.bi, 0, K_EMB_U)), seed=self.seed, amax=am_du)
+            self._embed_bwd("usr", dpre_u, B, Lt, gbuf, am_du)
         join_side(st)
         if on_bucket is not None:
             on_bucket(P + "embed")
 
-    def _embed_bwd(self, side, dpre, B, L, gbuf):
+    def _embed_bwd(self, side, dpre, B, L, gbuf, am_dpre=None):
         st, bb, P, d, sv = self.store, self.bb, self.pre, self.d, self.sv
         M = B * L
         is_id = bb.id_vid if side == "vid" else bb.id_usr
@@ -553,7 +611,7 @@ class BackboneRun:
             x = sv["%s_x" % side]
             Din = x.shape[-1]
             with side_work(st):
-                _wgrad(st, dpre, d, 0, x, Din, 0, M, d, Din, gtab)
+                _wgrad(st, dpre, d, 0, x, Din, 0, M, d, Din, gtab, a_amax=am_dpre, b_amax=sv["am_%s_x" % side])
                 _colsum(st, dpre, d, M, d, st.g(P + "%s_proj.bias" % side, gbuf))
 
 

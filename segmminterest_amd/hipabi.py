@@ -15,7 +15,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsegmm_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _lib = None
 
@@ -27,16 +27,21 @@ SIGNATURES = {
     "segmm_gemm": [_i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _p, _i, _f, _u64, _u32, _i, _p, _i, _i, _p],
     "segmm_gemm_x": [_i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _p, _i, _f, _u64, _u32, _i, _p, _i,
                      _p, _i64, _p, _i64, _i, _p],
+    "segmm_gemm_h": [_i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _p, _i, _f, _u64, _u32, _i, _p, _i,
+                     _p, _i64, _p, _i64, _p, _i, _p, _i, _p, _p],
+    "segmm_absmax": [_p, _i64, _i, _i, _p, _i, _p],
+    "segmm_split2h": [_p, _p, _i64, _i64, _p, _i, _p],
+    "segmm_split2h_transpose": [_p, _i, _i, _i, _p, _i64, _p, _i, _p],
     "segmm_split3": [_p, _p, _i64, _i64, _p],
     "segmm_split3_transpose": [_p, _i, _i, _i, _p, _i64, _p],
-    "segmm_layernorm_fwd": [_p, _p, _p, _p, _p, _p, _i64, _i, _f, _f, _u64, _u32, _p],
+    "segmm_layernorm_fwd": [_p, _p, _p, _p, _p, _p, _i64, _i, _f, _f, _u64, _u32, _p, _p],
     "segmm_layernorm_bwd_parts": [_i64],
-    "segmm_layernorm_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _f, _u32, _f, _u32, _u64, _p],
+    "segmm_layernorm_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _f, _u32, _f, _u32, _u64, _p, _p],
     "segmm_colsum_chunks": [_i64],
     "segmm_colsum": [_p, _i, _p, _i64, _i, _p, _i, _p, _p],
-    "segmm_attn_fwd": [_i] * 6 + [_p, _p, _i, _p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _i, _p, _f, _u64, _u32, _p],
+    "segmm_attn_fwd": [_i] * 6 + [_p, _p, _i, _p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _i, _p, _f, _u64, _u32, _p, _p],
     "segmm_attn_bwd": [_i] * 6 + [_p, _p, _i, _p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _p, _p, _i,
-                                  _p, _p, _i, _f, _u64, _u32, _p],
+                                  _p, _p, _i, _f, _u64, _u32, _p, _p, _p, _p],
     "segmm_rowdot": [_p, _i, _p, _p, _p, _i64, _i, _i, _p],
     "segmm_rowscale_bcast": [_p, _p, _p, _i, _i64, _i, _i, _p],
     "segmm_vecsum": [_p, _i64, _p, _i, _p],
@@ -102,10 +107,13 @@ def _f32c(t, name="tensor"):
 
 
 GEMM_PROFILE = None       # bench.py sets this to a list to time every GEMM launch with HIP events
-ENGINE_F32, ENGINE_BF16X6 = 0, 1
+ENGINE_F32, ENGINE_BF16X6, ENGINE_F16X3 = 0, 1, 2
 # default engine of gemm(): the exact 3-way bf16 split on the bf16 matrix cores (fp32-class accuracy, faster);
-# SEGMM_GEMM=f32 selects the f32-input MFMA kernel instead (A/B and parity cross-checks)
-GEMM_ENGINE = {"f32": 0, "bf16x6": 1}[os.environ.get("SEGMM_GEMM", "bf16x6")]
+# SEGMM_GEMM=f32 selects the f32-input MFMA kernel instead (A/B and parity cross-checks), SEGMM_GEMM=f16x3 the
+# scaled two-term fp16 split (22-bit operands, three products)
+GEMM_ENGINE = {"f32": 0, "bf16x6": 1, "f16x3": 2}[os.environ.get("SEGMM_GEMM", "bf16x6")]
+AMAX_SLOTS = 256          # partial maxima per tensor written by the fused producers (SEGMM_AMAX_SLOTS)
+AMAX_PARTS = 1024         # ... and by the stand-alone absmax() pass
 LAYOUT_NT, LAYOUT_NN, LAYOUT_TN = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_DGELU = 0, 1, 2
 
@@ -119,9 +127,12 @@ def l1norm(x, out=None, inv_scale=None):
 
 def gemm(layout, M, N, K, A, lda, B, ldb, Cout, ldc, bias=None, row_scale=None, residual=None, ldr=0, res_period=0,
          activation=0, aux=None, ldaux=0, drop_p=0.0, seed=0, site=0, splits=1, workspace=None, accumulate=False,
-         a_off=0, b_off=0, c_off=0, engine=None, a_planes=None, b_planes=None, nplanes=3):
+         a_off=0, b_off=0, c_off=0, engine=None, a_planes=None, b_planes=None, nplanes=3, a_amax=None, b_amax=None, c_amax=None):
     """Raw strided GEMM; ``*_off`` are element offsets into the tensors (column slices of fused buffers).
-    ``a_planes`` / ``b_planes`` = (bf16 planes tensor [nplanes, ...], element offset): pre-split operand (bf16x6 engine, NT)."""
+    ``a_planes`` / ``b_planes`` = (16-bit planes tensor [nplanes, ...], element offset): pre-split operand (NT only).
+    ``a_amax`` / ``b_amax`` (fp16x3 engine): float32 vectors of partial maxima of |A| / |B|; computed here with
+    :func:`absmax` when the caller has none.  ``c_amax``: zeroed [AMAX_SLOTS] vector that receives the partial
+    maxima of |C| (ignored by the other engines: nothing consumes it there)."""
     _dev(Cout)
     es = 4
     prof = GEMM_PROFILE
@@ -129,7 +140,27 @@ def gemm(layout, M, N, K, A, lda, B, ldb, Cout, ldc, bias=None, row_scale=None, 
         e0 = torch.cuda.Event(enable_timing=True)
         e0.record()
     eng = GEMM_ENGINE if engine is None else int(engine)
-    if a_planes is None and b_planes is None and nplanes == 3:
+    if eng == ENGINE_F16X3:
+        if a_amax is None:
+            if a_planes is not None:
+                raise RuntimeError("pre-split fp16 planes need the partial maxima they were made with")
+            a_amax = absmax(A, K if layout == LAYOUT_TN else M, M if layout == LAYOUT_TN else K, lda, off=a_off)
+        if b_amax is None:
+            if b_planes is not None:
+                raise RuntimeError("pre-split fp16 planes need the partial maxima they were made with")
+            b_amax = absmax(B, N if layout == LAYOUT_NT else K, K if layout == LAYOUT_NT else N, ldb, off=b_off)
+        ap = None if a_planes is None else a_planes[0].data_ptr() + 2 * a_planes[1]
+        aps = 0 if a_planes is None else a_planes[0].stride(0)
+        bp = None if b_planes is None else b_planes[0].data_ptr() + 2 * b_planes[1]
+        bps = 0 if b_planes is None else b_planes[0].stride(0)
+        _check(lib().segmm_gemm_h(layout, M, N, K, None if A is None else A.data_ptr() + a_off * es, lda,
+                                  None if B is None else B.data_ptr() + b_off * es, ldb,
+                                  Cout.data_ptr() + c_off * es, ldc, _ptr(bias), _ptr(row_scale), _ptr(residual), ldr,
+                                  res_period, activation, _ptr(aux), ldaux, float(drop_p), int(seed), int(site),
+                                  int(splits), _ptr(workspace), int(bool(accumulate)), ap, aps, bp, bps,
+                                  a_amax.data_ptr(), a_amax.numel(), b_amax.data_ptr(), b_amax.numel(), _ptr(c_amax),
+                                  _stream()), "segmm_gemm_h")
+    elif a_planes is None and b_planes is None and nplanes == 3:
         _check(lib().segmm_gemm(layout, M, N, K, A.data_ptr() + a_off * es, lda, B.data_ptr() + b_off * es, ldb,
                                 Cout.data_ptr() + c_off * es, ldc, _ptr(bias), _ptr(row_scale), _ptr(residual), ldr,
                                 res_period, activation, _ptr(aux), ldaux, float(drop_p), int(seed), int(site),
@@ -153,6 +184,26 @@ def gemm(layout, M, N, K, A, lda, B, ldb, Cout, ldc, bias=None, row_scale=None, 
         prof.append((layout, M, N, K, e0, e1))
 
 
+def absmax(x, rows, cols, ld, off=0, out=None):
+    """Partial maxima of |x| over the [rows, cols] view (row stride ld) starting ``off`` elements into x."""
+    if out is None:
+        out = torch.empty(AMAX_PARTS, dtype=torch.float32, device=x.device)
+    _check(lib().segmm_absmax(x.data_ptr() + 4 * off, rows, cols, ld, out.data_ptr(), out.numel(), _stream()), "segmm_absmax")
+    return out
+
+
+def split2h(x, planes, n, amax, x_off=0, p_off=0):
+    """planes[0/1, p_off + i] = fp16 hi / lo of x.flat[x_off + i] * s(amax); planes is a [2, size] 16-bit tensor."""
+    _check(lib().segmm_split2h(x.data_ptr() + 4 * x_off, planes.data_ptr() + 2 * p_off, n, planes.stride(0),
+                               amax.data_ptr(), amax.numel(), _stream()), "segmm_split2h")
+
+
+def split2h_transpose(x, R, Cc, ld, planes, amax, x_off=0, p_off=0):
+    """planes[0/1, p_off + c*R + r] = fp16 hi / lo of x.flat[x_off + r*ld + c] * s(amax)."""
+    _check(lib().segmm_split2h_transpose(x.data_ptr() + 4 * x_off, R, Cc, ld, planes.data_ptr() + 2 * p_off, planes.stride(0),
+                                         amax.data_ptr(), amax.numel(), _stream()), "segmm_split2h_transpose")
+
+
 def split3(x, planes, n, x_off=0, p_off=0):
     """planes[p, p_off + i] = p-th bf16 term of x.flat[x_off + i]; planes is a [3, size] bf16 tensor."""
     _check(lib().segmm_split3(x.data_ptr() + 4 * x_off, planes.data_ptr() + 2 * p_off, n, planes.stride(0), _stream()), "segmm_split3")
@@ -164,11 +215,11 @@ def split3_transpose(x, R, Cc, ld, planes, x_off=0, p_off=0):
                                         _stream()), "segmm_split3_transpose")
 
 
-def layernorm_fwd(x, gamma, beta, y, mean, rstd, eps=1e-12, drop_p=0.0, seed=0, site=0):
+def layernorm_fwd(x, gamma, beta, y, mean, rstd, eps=1e-12, drop_p=0.0, seed=0, site=0, amax=None):
     _dev(x, y)
     d = x.shape[-1]
     _check(lib().segmm_layernorm_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd),
-                                     x.numel() // d, d, eps, float(drop_p), int(seed), int(site), _stream()),
+                                     x.numel() // d, d, eps, float(drop_p), int(seed), int(site), _ptr(amax), _stream()),
            "segmm_layernorm_fwd")
 
 
@@ -177,12 +228,12 @@ def layernorm_bwd_parts(rows):
 
 
 def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dx_drop, part_dgamma, part_dbeta, drop_y_p=0.0, drop_y_site=0,
-                  drop_b_p=0.0, drop_b_site=0, seed=0):
+                  drop_b_p=0.0, drop_b_site=0, seed=0, amax=None):
     _dev(dy, x, dx)
     d = x.shape[-1]
     _check(lib().segmm_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(dx), _ptr(dx_drop),
                                      _ptr(part_dgamma), _ptr(part_dbeta), x.numel() // d, d, float(drop_y_p),
-                                     int(drop_y_site), float(drop_b_p), int(drop_b_site), int(seed), _stream()),
+                                     int(drop_y_site), float(drop_b_p), int(drop_b_site), int(seed), _ptr(amax), _stream()),
            "segmm_layernorm_bwd")
 
 
@@ -197,23 +248,24 @@ def colsum(X, ld, M, N, out, workspace, w=None, accumulate=False, x_off=0, out_o
 
 
 def attn_fwd(B, H, dh, Lq, La, Lb, Qa, Qb, ldq, Ka, Va, ldka, Kb, Vb, ldkb, mq, mka, mkb, O, ldo, lse,
-             drop_p=0.0, seed=0, site=0):
+             drop_p=0.0, seed=0, site=0, amax_o=None):
     """Q*/K*/V* are (tensor, element_offset) pairs: column slices of the fused projection buffers."""
     def P(x):
         return x[0].data_ptr() + 4 * x[1]
     _check(lib().segmm_attn_fwd(B, H, dh, Lq, La, Lb, P(Qa), P(Qb), ldq, P(Ka), P(Va), ldka, P(Kb), P(Vb), ldkb,
                                 _ptr(mq), _ptr(mka), _ptr(mkb), _ptr(O), ldo, _ptr(lse), float(drop_p), int(seed),
-                                int(site), _stream()), "segmm_attn_fwd")
+                                int(site), _ptr(amax_o), _stream()), "segmm_attn_fwd")
 
 
 def attn_bwd(B, H, dh, Lq, La, Lb, Qa, Qb, ldq, Ka, Va, ldka, Kb, Vb, ldkb, mq, mka, mkb, lse, dO, lddo, Dvec,
-             dQa, dQb, lddq, dKa, dVa, lddka, dKb, dVb, lddkb, drop_p=0.0, seed=0, site=0):
+             dQa, dQb, lddq, dKa, dVa, lddka, dKb, dVb, lddkb, drop_p=0.0, seed=0, site=0, amax_q=None, amax_ka=None,
+             amax_kb=None):
     def P(x):
         return x[0].data_ptr() + 4 * x[1]
     _check(lib().segmm_attn_bwd(B, H, dh, Lq, La, Lb, P(Qa), P(Qb), ldq, P(Ka), P(Va), ldka, P(Kb), P(Vb), ldkb,
                                 _ptr(mq), _ptr(mka), _ptr(mkb), _ptr(lse), _ptr(dO), lddo, _ptr(Dvec), P(dQa),
                                 P(dQb), lddq, P(dKa), P(dVa), lddka, P(dKb), P(dVb), lddkb, float(drop_p), int(seed),
-                                int(site), _stream()), "segmm_attn_bwd")
+                                int(site), _ptr(amax_q), _ptr(amax_ka), _ptr(amax_kb), _stream()), "segmm_attn_bwd")
 
 
 def rowdot(x, ld, w, bias, out, rows, d, accumulate=False, x_off=0, w_off=0):

@@ -426,3 +426,138 @@ def test_gemm_bf16x6_identity_exact_and_epilogue():
     pre = X.double() @ W.double().t() + b.double()
     assert (aux.double() - pre).abs().max().item() < 1e-5
     assert (out.double() - (torch.nn.functional.gelu(pre) + res.double().repeat(M // 40, 1))).abs().max().item() < 1e-5
+
+
+# ------------------------------------------------------------------ fp16x3 split-MFMA engine (scaled two-term fp16 split)
+@pytest.mark.parametrize("lay,M,N,K,splits", [("NT", 360, 96, 48, 1), ("NT", 20480, 768, 768, 1), ("NT", 63, 32, 40, 1),
+                                              ("NN", 360, 48, 96, 1), ("NN", 20480, 768, 3072, 1),
+                                              ("TN", 96, 48, 360, 1), ("TN", 768, 768, 20480, 16), ("TN", 32, 40, 63, 2)])
+@pytest.mark.parametrize("kind", ["wide", "tiny", "huge"])
+def test_gemm_f16x3_matches_fp64_like_fp32(lay, M, N, K, splits, kind):
+    """engine 2: x*s = hi + lo in fp16 (per-tensor power-of-two scale from max|x|), three partial products, fp32
+    accumulation.  Must be as close to the fp64 product as the f32-MFMA engine on every layout, for operands with a
+    wide dynamic range and for magnitudes far outside the fp16 range (gradients ~1e-9, activations ~1e6)."""
+    H = _abi()
+    L = {"NT": 0, "NN": 1, "TN": 2}[lay]
+    g = torch.Generator().manual_seed(M + N + K)
+    mag = {"wide": 1.0, "tiny": 1e-9, "huge": 1e6}[kind]
+    rnd = lambda *s: (torch.randn(*s, generator=g) * torch.exp(torch.randn(*s, generator=g)) * mag).to(DEV)
+    if lay == "NT":
+        A, Bm = rnd(M, K), rnd(N, K); lda, ldb = K, K; ref = A.double() @ Bm.double().t()
+    elif lay == "NN":
+        A, Bm = rnd(M, K), rnd(K, N); lda, ldb = K, N; ref = A.double() @ Bm.double()
+    else:
+        A, Bm = rnd(K, M), rnd(K, N); lda, ldb = M, N; ref = A.double().t() @ Bm.double()
+    ws = torch.empty(max(splits, 1) * M * N, device=DEV)
+    outs = {}
+    for eng in (H.ENGINE_F32, H.ENGINE_F16X3):
+        C = torch.full((M, N), float("nan"), device=DEV)
+        H.gemm(L, M, N, K, A, lda, Bm, ldb, C, N, splits=splits, workspace=ws, engine=eng)
+        outs[eng] = C
+    scale = ref.abs().mean().item()
+    e32 = (outs[H.ENGINE_F32].double() - ref).abs()
+    e3 = (outs[H.ENGINE_F16X3].double() - ref).abs()
+    assert e3.max().item() / scale < 2e-5 * math.sqrt(K), (e3.max().item() / scale, e32.max().item() / scale)
+    assert e3.max().item() <= 2.0 * e32.max().item() + 1e-7 * scale, ("fp16x3 max error above the fp32 MFMA's", e3.max().item() / scale, e32.max().item() / scale)
+    assert e3.mean().item() <= 1.25 * e32.mean().item() + 1e-9 * scale, ("fp16x3 mean error above the fp32 MFMA's", e3.mean().item() / scale, e32.mean().item() / scale)
+
+
+def test_gemm_f16x3_small_elements_next_to_large_ones():
+    """One scale per tensor: elements 2^-30 below the maximum must still contribute with an error far below
+    their own size (fp16 subnormals keep an ABSOLUTE error of 2^-40 max)."""
+    H = _abi()
+    M, N, K = 128, 128, 64
+    A = torch.zeros(M, K, device=DEV)
+    A[:, 0] = 1.0e3
+    A[:, 1:] = torch.rand(M, K - 1, device=DEV) * 1e-5 + 1e-6        # ~2^-27 .. 2^-30 of the maximum
+    Bm = torch.zeros(N, K, device=DEV)
+    Bm[:, 1:] = torch.rand(N, K - 1, device=DEV) + 0.5                # column 0 of B is zero: only the small terms count
+    C = torch.empty(M, N, device=DEV)
+    H.gemm(H.LAYOUT_NT, M, N, K, A, K, Bm, K, C, N, engine=H.ENGINE_F16X3)
+    ref = A.double() @ Bm.double().t()
+    assert ((C.double() - ref).abs() / ref.abs()).max().item() < 1e-4      # small terms: >= 13 correct bits each
+    A[:, 0] = 0.0
+    H.gemm(H.LAYOUT_NT, M, N, K, A, K, Bm, K, C, N, engine=H.ENGINE_F16X3)  # same data rescaled by its own maximum
+    assert ((C.double() - ref).abs() / ref.abs()).max().item() < 2e-6
+
+
+def test_gemm_f16x3_planes_epilogue_and_zero():
+    H = _abi()
+    M, N, K = 360, 96, 64
+    X, W, b = _rand(M, K, seed=8), _rand(N, K, seed=9, scale=0.3), _rand(N, seed=10)
+    res = _rand(40, N, seed=11)
+    out, aux = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+    wam = H.absmax(W, N, K, K)
+    assert wam.numel() == H.AMAX_PARTS and abs(wam.max().item() - W.abs().max().item()) == 0.0
+    planes = torch.empty(2, N * K, dtype=torch.float16, device=DEV)
+    H.split2h(W, planes, N * K, wam)
+    s = 2.0 ** (14 - math.floor(math.log2(W.abs().max().item())))
+    assert torch.equal(planes[0].view(N, K), (W * s).half())
+    assert (planes[0].double() + planes[1].double() - (W * s).double().view(-1)).abs().max().item() <= 2.0 ** -21 * (W * s).abs().max().item()
+    cam = torch.zeros(H.AMAX_SLOTS, device=DEV)
+    H.gemm(H.LAYOUT_NT, M, N, K, X, K, None, K, out, N, bias=b, residual=res, ldr=N, res_period=40, activation=H.ACT_GELU,
+           aux=aux, ldaux=N, engine=H.ENGINE_F16X3, b_planes=(planes, 0), b_amax=wam, c_amax=cam)
+    pre = X.double() @ W.double().t() + b.double()
+    assert (aux.double() - pre).abs().max().item() < 1e-5
+    assert (out.double() - (torch.nn.functional.gelu(pre) + res.double().repeat(M // 40, 1))).abs().max().item() < 1e-5
+    assert cam.max().item() == out.abs().max().item()              # fused partial maxima of |C|
+    out2 = torch.empty(M, N, device=DEV)
+    H.gemm(H.LAYOUT_NT, M, N, K, X, K, W, K, out2, N, bias=b, residual=res, ldr=N, res_period=40, activation=H.ACT_GELU,
+           aux=aux, ldaux=N, engine=H.ENGINE_F16X3)
+    assert torch.equal(out, out2)                                   # pre-split planes == split on the fly
+    # W^T planes: dX = dY . W in the NT form
+    dY = _rand(M, N, seed=12)
+    wT = torch.empty(2, N * K, dtype=torch.float16, device=DEV)
+    H.split2h_transpose(W, N, K, K, wT, wam)
+    dX = torch.empty(M, K, device=DEV)
+    H.gemm(H.LAYOUT_NT, M, K, N, dY, N, None, N, dX, K, engine=H.ENGINE_F16X3, b_planes=(wT, 0), b_amax=wam)
+    assert (dX.double() - dY.double() @ W.double()).abs().max().item() < 2e-5
+    # all-zero operand: scale falls back to 1, result exactly zero
+    Z = torch.zeros(M, K, device=DEV)
+    H.gemm(H.LAYOUT_NT, M, N, K, Z, K, W, K, out2, N, engine=H.ENGINE_F16X3)
+    assert torch.equal(out2, torch.zeros_like(out2))
+
+
+def test_fused_amax_producers():
+    """LayerNorm forward/backward and attention forward/backward fold max|output| into a zeroed slot array."""
+    H = _abi()
+    rows, d = 333, 96
+    x = _rand(rows, d, seed=30) * 3
+    gamma, beta = 1 + 0.1 * _rand(d, seed=31), 0.1 * _rand(d, seed=32)
+    y, mean, rstd = torch.empty_like(x), torch.empty(rows, device=DEV), torch.empty(rows, device=DEV)
+    am = torch.zeros(H.AMAX_SLOTS, device=DEV)
+    H.layernorm_fwd(x, gamma, beta, y, mean, rstd, drop_p=0.1, seed=5, site=3, amax=am)
+    assert am.max().item() == y.abs().max().item()
+    dy = _rand(rows, d, seed=33) * 1e-6
+    parts = H.layernorm_bwd_parts(rows)
+    dx, dxd = torch.empty_like(x), torch.empty_like(x)
+    pg, pb = torch.empty(parts, d, device=DEV), torch.empty(parts, d, device=DEV)
+    am.zero_()
+    H.layernorm_bwd(dy, x, mean, rstd, gamma, dx, dxd, pg, pb, drop_b_p=0.1, drop_b_site=4, seed=5, amax=am)
+    assert am.max().item() == dxd.abs().max().item()
+    am.zero_()
+    H.layernorm_bwd(dy, x, mean, rstd, gamma, dx, None, pg, pb, amax=am)
+    assert am.max().item() == dx.abs().max().item()
+    B, H_, dh, Lq, La, Lb = 2, 4, 8, 40, 40, 10
+    dm = H_ * dh
+    g = torch.Generator().manual_seed(7)
+    mk = lambda L: (torch.randn(B, L, dm, generator=g) * 0.7).to(DEV)
+    Qa, Qb, Ka, Va, Kb, Vb = mk(Lq), mk(Lq), mk(La), mk(La), mk(Lb), mk(Lb)
+    mq = (torch.rand(B, Lq, generator=g) < 0.8).to(DEV)
+    mka = (torch.rand(B, La, generator=g) < 0.8).to(DEV)
+    mkb = (torch.rand(B, Lb, generator=g) < 0.7).to(DEV)
+    O = torch.empty(B * Lq, dm, device=DEV)
+    lse = torch.empty(2, B, H_, Lq, device=DEV)
+    z = lambda t: (t, 0)
+    am.zero_()
+    H.attn_fwd(B, H_, dh, Lq, La, Lb, z(Qa), z(Qb), dm, z(Ka), z(Va), dm, z(Kb), z(Vb), dm, mq, mka, mkb, O, dm, lse, amax_o=am)
+    assert am.max().item() == O.abs().max().item()
+    dO = torch.randn(B * Lq, dm, generator=g).to(DEV)
+    Dv = torch.empty(B, H_, Lq, device=DEV)
+    outs = [torch.empty_like(t) for t in (Qa, Qb, Ka, Va, Kb, Vb)]
+    aq, aka, akb = (torch.zeros(H.AMAX_SLOTS, device=DEV) for _ in range(3))
+    H.attn_bwd(B, H_, dh, Lq, La, Lb, z(Qa), z(Qb), dm, z(Ka), z(Va), dm, z(Kb), z(Vb), dm, mq, mka, mkb, lse, dO, dm, Dv,
+               z(outs[0]), z(outs[1]), dm, z(outs[2]), z(outs[3]), dm, z(outs[4]), z(outs[5]), dm, amax_q=aq, amax_ka=aka, amax_kb=akb)
+    assert aq.max().item() == max(outs[0].abs().max().item(), outs[1].abs().max().item())
+    assert aka.max().item() == max(outs[2].abs().max().item(), outs[3].abs().max().item())
+    assert akb.max().item() == max(outs[4].abs().max().item(), outs[5].abs().max().item())

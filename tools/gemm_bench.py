@@ -27,8 +27,16 @@ for lay, M, N, K in shapes:
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     splits = max(1, min(32, (K + 31) // 32, (1024 + tiles - 1) // tiles)) if lay == "TN" else 1
     ws = torch.empty(splits * M * N, device=dev) if splits > 1 else None
-    eng = {"f32": 0, "bf16x6": 1}[os.environ.get("SEGMM_GEMM", "f32")]
-    run = lambda: H.gemm(L, M, N, K, A, lda, B, ldb, C, N, splits=splits, workspace=ws, engine=eng)
+    eng = {"f32": 0, "bf16x6": 1, "f16x3": 2}[os.environ.get("SEGMM_GEMM", "f32")]
+    kw = {}
+    if eng == 2:        # partial maxima precomputed (the fused producers supply them in the model); weights pre-split for NT
+        kw["a_amax"] = H.absmax(A, A.shape[0], A.shape[1], lda)
+        kw["b_amax"] = H.absmax(B, B.shape[0], B.shape[1], ldb)
+        if lay == "NT" and os.environ.get("SEGMM_PLANES", "1") != "0":
+            planes = torch.empty(2, N * K, dtype=torch.float16, device=dev)
+            H.split2h(B, planes, N * K, kw["b_amax"])
+            kw["b_planes"] = (planes, 0)
+    run = lambda: H.gemm(L, M, N, K, A, lda, B, ldb, C, N, splits=splits, workspace=ws, engine=eng, **kw)
     for _ in range(3):
         run()
     torch.cuda.synchronize()
