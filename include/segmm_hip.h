@@ -93,14 +93,16 @@ int segmm_split3_transpose(const float* x, int R, int C, int ld, uint16_t* plane
  * forward: optional dropout on the output (embedding dropout, encoder.py:461,471).
  * backward: dy is first multiplied by the forward's output-dropout mask (drop_y_*); dx_drop (may be NULL) receives
  * dx times the mask of the residual-branch dropout "x = res + dropout(branch)" (drop_b_*), i.e. d(branch).
- * part_dgamma/part_dbeta: [nparts, d] per-workgroup partials, nparts = segmm_layernorm_bwd_parts(rows). */
+ * part_dgamma/part_dbeta: [nparts, d] per-workgroup partials, nparts = segmm_layernorm_bwd_parts(rows).
+ * part_dsum (optional, same shape): partial column sums of the forwarded gradient (dx_drop if given, else dx) =
+ * the bias gradient of the Linear whose output entered the LayerNorm through the residual branch. */
 int segmm_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                         int64_t rows, int d, float eps, float drop_p, uint64_t seed, uint32_t site, float* amax,
                         segmm_stream_t stream);
 int segmm_layernorm_bwd_parts(int64_t rows);
 int segmm_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
-                        float* dx, float* dx_drop, float* part_dgamma, float* part_dbeta, int64_t rows, int d,
-                        float drop_y_p, uint32_t drop_y_site, float drop_b_p, uint32_t drop_b_site, uint64_t seed,
+                        float* dx, float* dx_drop, float* part_dgamma, float* part_dbeta, float* part_dsum, int64_t rows,
+                        int d, float drop_y_p, uint32_t drop_y_site, float drop_b_p, uint32_t drop_b_site, uint64_t seed,
                         float* amax, segmm_stream_t stream);
 
 /* out[n] (+)= sum_m w[m] * X[m,n]  (bias gradients, LayerNorm partial combine, head weight gradient).

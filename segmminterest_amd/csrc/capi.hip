@@ -103,7 +103,7 @@ __global__ void dropout_mult_kernel(float* out, long long n, DropCfg d) {
 extern "C" {
 
 const char* segmm_last_error(void) { return g_segmm_err; }
-int segmm_abi_version(void) { return 2; }
+int segmm_abi_version(void) { return 3; }
 
 int segmm_l1norm(const float* x, float* y, float* inv_scale, int64_t rows, int D, segmm_stream_t stream) {
     SEGMM_REQUIRE(x && (y || inv_scale), "l1norm: null pointer");
@@ -316,37 +316,41 @@ int segmm_layernorm_fwd(const float* x, const float* gamma, const float* beta, f
     SEGMM_REQUIRE(d > 0 && d % 4 == 0 && d <= 256 * ROW_MAXV, "layernorm_fwd: d=%d unsupported", d);
     SEGMM_REQUIRE(aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta), "layernorm_fwd: alignment");
     if (rows <= 0) return 0;
-    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, gamma,
-                       beta, y, mean, rstd, (long long)rows, d, eps, make_drop(drop_p, seed, site), amax);
+    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    const DropCfg dc = make_drop(drop_p, seed, site);
+#define LNF(V) hipLaunchKernelGGL((layernorm_fwd_kernel<V>), grid, block, 0, (hipStream_t)stream, x, gamma, beta, y, mean, rstd, (long long)rows, d, eps, dc, amax)
+    if (d <= 256) LNF(1); else if (d <= 512) LNF(2); else if (d <= 768) LNF(3); else if (d <= 1024) LNF(4); else LNF(8);
+#undef LNF
     LAUNCH_CHECK();
     return 0;
 }
 
 int segmm_layernorm_bwd_parts(int64_t rows) {
     int64_t b = (rows + 3) / 4;
-    if (b > 1024) b = 1024;
+    if (b > 2048) b = 2048;
     if (b < 1) b = 1;
     return (int)b;
 }
 
 int segmm_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
-                        float* dx, float* dx_drop, float* part_dgamma, float* part_dbeta, int64_t rows, int d,
-                        float drop_y_p, uint32_t drop_y_site, float drop_b_p, uint32_t drop_b_site, uint64_t seed,
+                        float* dx, float* dx_drop, float* part_dgamma, float* part_dbeta, float* part_dsum, int64_t rows,
+                        int d, float drop_y_p, uint32_t drop_y_site, float drop_b_p, uint32_t drop_b_site, uint64_t seed,
                         float* amax, segmm_stream_t stream) {
     SEGMM_REQUIRE(dy && x && mean && rstd && gamma && dx && part_dgamma && part_dbeta, "layernorm_bwd: null pointer");
     SEGMM_REQUIRE(d > 0 && d % 4 == 0 && d <= 256 * ROW_MAXV, "layernorm_bwd: d=%d unsupported", d);
     SEGMM_REQUIRE(aligned16(dy) && aligned16(x) && aligned16(dx) && aligned16(gamma) && (!dx_drop || aligned16(dx_drop)), "layernorm_bwd: alignment");
     const int parts = segmm_layernorm_bwd_parts(rows);
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(parts), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma, dx,
-                       dx_drop, part_dgamma, part_dbeta, (long long)rows, d, make_drop(drop_y_p, seed, drop_y_site),
-                       make_drop(drop_b_p, seed, drop_b_site), amax);
+    const DropCfg dy_ = make_drop(drop_y_p, seed, drop_y_site), db_ = make_drop(drop_b_p, seed, drop_b_site);
+#define LNB(V) hipLaunchKernelGGL((layernorm_bwd_kernel<V>), dim3(parts), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma, dx, dx_drop, part_dgamma, part_dbeta, part_dsum, (long long)rows, d, dy_, db_, amax)
+    if (d <= 256) LNB(1); else if (d <= 512) LNB(2); else if (d <= 768) LNB(3); else if (d <= 1024) LNB(4); else LNB(8);
+#undef LNB
     LAUNCH_CHECK();
     return 0;
 }
 
 int segmm_colsum_chunks(int64_t M) {
-    int64_t c = (M + 255) / 256;
-    if (c > 64) c = 64;
+    int64_t c = (M + 63) / 64;          // >= 64 rows per chunk; up to 256 chunks so that a 768-column sum still fills the chip
+    if (c > 256) c = 256;
     if (c < 1) c = 1;
     return (int)c;
 }

@@ -36,6 +36,9 @@ __global__ __launch_bounds__(256) void l1norm_kernel(const float* __restrict__ x
 
 // ---------------------------------------------------------------- LayerNorm forward (eps 1e-12, encoder.py:39-40)
 // y = LN(x) * gamma + beta, optional dropout on y (embedding, encoder.py:461,471); saves mean / rstd.
+// V = float4 per lane (d <= 256 V): the row lives in 4V registers, so the register count -- and with it the
+// number of rows in flight per CU, which is what hides the HBM latency of this streaming kernel -- follows d.
+template <int V>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                      const float* __restrict__ beta, float* __restrict__ y, float* mean_out,
                                      float* rstd_out, long long rows, int d, float eps, DropCfg drop, float* amax) {
@@ -43,10 +46,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float* xr = x + row * d;
-    f32x4 v[ROW_MAXV];
+    f32x4 v[V];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < ROW_MAXV; ++i) {
+    for (int i = 0; i < V; ++i) {
         const int c = lane * 4 + i * 256;
         v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (c < d) { v[i] = *(const f32x4*)(xr + c); s += v[i].x + v[i].y + v[i].z + v[i].w; }
@@ -54,7 +57,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     const float mean = wave_sum(s) / d;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < ROW_MAXV; ++i) {
+    for (int i = 0; i < V; ++i) {
         const int c = lane * 4 + i * 256;
         if (c < d) {
             const f32x4 t = v[i] - mean;
@@ -65,7 +68,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
     float am = 0.f;
 #pragma unroll
-    for (int i = 0; i < ROW_MAXV; ++i) {
+    for (int i = 0; i < V; ++i) {
         const int c = lane * 4 + i * 256;
         if (c < d) {
             f32x4 o = (v[i] - mean) * rstd * *(const f32x4*)(gamma + c) + *(const f32x4*)(beta + c);
@@ -80,29 +83,32 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 // ---------------------------------------------------------------- LayerNorm backward
 // dy_eff = dy (.) dropmask (if the forward dropped y);  dx = rstd (g dy - mean(g dy) - xhat mean(g dy xhat)).
 // Outputs: dx; optionally dx_drop = dx (.) dropmask2 (the gradient that continues through the
-// residual branch "x = res + dropout(z)": dz = dx_drop); per-workgroup partial dgamma/dbeta.
+// residual branch "x = res + dropout(z)": dz = dx_drop); per-workgroup partial dgamma / dbeta and, optionally,
+// the partial COLUMN SUMS of the forwarded gradient (dx_drop, or dx without it) -- the bias gradient of the
+// Linear that produced z, which would otherwise cost a second pass over that tensor.
+template <int V>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                      const float* __restrict__ gamma, float* __restrict__ dx,
                                      float* __restrict__ dx_drop, float* __restrict__ part_dgamma,
-                                     float* __restrict__ part_dbeta, long long rows, int d, DropCfg drop_y,
-                                     DropCfg drop_branch, float* amax) {
-    __shared__ float red[4][2048];
+                                     float* __restrict__ part_dbeta, float* __restrict__ part_dsum, long long rows, int d,
+                                     DropCfg drop_y, DropCfg drop_branch, float* amax) {
+    __shared__ float red[4][V * 256];
     float am = 0.f;          // max |dx_drop| (or |dx| when there is no dropped copy): the tensor the GEMMs consume
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    f32x4 ag[ROW_MAXV], ab[ROW_MAXV], gm[ROW_MAXV];
+    f32x4 ag[V], ab[V], as[V], gm[V];
 #pragma unroll
-    for (int i = 0; i < ROW_MAXV; ++i) {
-        ag[i] = f32x4{0.f, 0.f, 0.f, 0.f}; ab[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < V; ++i) {
+        ag[i] = f32x4{0.f, 0.f, 0.f, 0.f}; ab[i] = ag[i]; as[i] = ag[i];
         const int c = lane * 4 + i * 256;
         gm[i] = (c < d) ? *(const f32x4*)(gamma + c) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     for (long long row = (long long)blockIdx.x * nw + wave; row < rows; row += (long long)gridDim.x * nw) {
         const float mu = mean[row], rs = rstd[row];
-        f32x4 g[ROW_MAXV], xh[ROW_MAXV];
+        f32x4 g[V], xh[V];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < ROW_MAXV; ++i) {
+        for (int i = 0; i < V; ++i) {
             const int c = lane * 4 + i * 256;
             g[i] = f32x4{0.f, 0.f, 0.f, 0.f}; xh[i] = g[i];
             if (c < d) {
@@ -120,7 +126,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         s1 = wave_sum(s1) / d;
         s2 = wave_sum(s2) / d;
 #pragma unroll
-        for (int i = 0; i < ROW_MAXV; ++i) {
+        for (int i = 0; i < V; ++i) {
             const int c = lane * 4 + i * 256;
             if (c < d) {
                 const f32x4 o = (g[i] - s1 - xh[i] * s2) * rs;
@@ -130,21 +136,22 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                     if (drop_branch.p > 0.f) od = drop_apply4(drop_branch, ((uint64_t)row * d + c) >> 2, o);
                     *(f32x4*)(dx_drop + row * d + c) = od;
                 }
+                as[i] += od;
                 am = absmax4(am, od);
             }
         }
     }
     if (amax) amax_commit(amax, am, blockIdx.x * nw + wave);
-    // cross-wave reduce of the dgamma / dbeta partials, one partial row per workgroup
-    for (int pass = 0; pass < 2; ++pass) {
+    // cross-wave reduce of the partials, one partial row per workgroup
+    for (int pass = 0; pass < (part_dsum ? 3 : 2); ++pass) {
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < ROW_MAXV; ++i) {
+        for (int i = 0; i < V; ++i) {
             const int c = lane * 4 + i * 256;
-            if (c < d) *(f32x4*)(&red[wave][c]) = pass == 0 ? ag[i] : ab[i];
+            if (c < d) *(f32x4*)(&red[wave][c]) = pass == 0 ? ag[i] : (pass == 1 ? ab[i] : as[i]);
         }
         __syncthreads();
-        float* out = (pass == 0 ? part_dgamma : part_dbeta) + (size_t)blockIdx.x * d;
+        float* out = (pass == 0 ? part_dgamma : (pass == 1 ? part_dbeta : part_dsum)) + (size_t)blockIdx.x * d;
         for (int c = threadIdx.x; c < d; c += blockDim.x) {
             float s = 0.f;
             for (int w = 0; w < nw; ++w) s += red[w][c];

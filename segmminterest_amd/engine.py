@@ -331,14 +331,20 @@ def _colsum(store, X, ld, M, N, out, x_off=0, w=None, accumulate=False):
 
 
 def _ln_bwd(store, dy, x, mean, rstd, gname, bname, gbuf, dx, dx_drop, rows, d, drop_y=(0.0, 0), drop_b=(0.0, 0), seed=0,
-            amax=None):
+            amax=None, dsum_to=None):
+    """LayerNorm backward + its affine gradients.  ``dsum_to``: gradient tensor that receives the column sums of the
+    forwarded gradient (dx_drop, or dx): the bias gradient of the Linear feeding this LayerNorm's residual branch,
+    accumulated inside the same kernel instead of by a second pass over [rows, d]."""
     parts = H.layernorm_bwd_parts(rows)
     pg = store.buf("ln_pg", (parts, d))
     pb = store.buf("ln_pb", (parts, d))
+    ps = store.buf("ln_ps", (parts, d)) if dsum_to is not None else None
     H.layernorm_bwd(dy, x, mean, rstd, store.p(gname), dx, dx_drop, pg, pb, drop_y_p=drop_y[0], drop_y_site=drop_y[1],
-                    drop_b_p=drop_b[0], drop_b_site=drop_b[1], seed=seed, amax=amax)
+                    drop_b_p=drop_b[0], drop_b_site=drop_b[1], seed=seed, amax=amax, part_dsum=ps)
     _colsum(store, pg, d, parts, d, store.g(gname, gbuf))
     _colsum(store, pb, d, parts, d, store.g(bname, gbuf))
+    if ps is not None:
+        _colsum(store, ps, d, parts, d, dsum_to)
 
 
 def _mask_u8(m: torch.Tensor) -> torch.Tensor:
@@ -489,12 +495,11 @@ class BackboneRun:
         dR2 = st.buf("dR2" + tag, (M, d))
         dM = st.buf("dM" + tag, (M, d)) if self.p_drop > 0 else None
         _ln_bwd(st, dX2, sv["R2"], sv["m2"], sv["r2"], L + "ln_%s.weight" % side, L + "ln_%s.bias" % side, gbuf, dR2, dM, M, d,
-                drop_b=(self.p_drop, _site(self.bi, i, k_mo)), seed=seed, amax=am_dM)
+                drop_b=(self.p_drop, _site(self.bi, i, k_mo)), seed=seed, amax=am_dM, dsum_to=st.g(ff + "1.bias", gbuf))
         if dM is None:
             dM = dR2
         with side_work(st):
             _wgrad(st, dM, d, 0, sv["Hh"], d, 0, M, d, d, st.g(ff + "1.weight", gbuf), a_amax=am_dM, b_amax=sv["am_Hh"])
-            _colsum(st, dM, d, M, d, st.g(ff + "1.bias", gbuf))
         dG = st.buf("dG" + tag, (M, d))
         _lin_dgrad(st, M, d, d, dM, ff + "1.weight", dG, activation=H.ACT_DGELU, aux=sv["G"], ldaux=d, a_amax=am_dM, c_amax=am_dG,
                drop_p=self.p_inner, seed=seed, site=_site(self.bi, i, k_mi))
@@ -506,12 +511,12 @@ class BackboneRun:
         dR1 = st.buf("dR1" + tag, (M, d))
         dZ = st.buf("dZ" + tag, (M, d)) if self.p_drop > 0 else None
         _ln_bwd(st, dX1, sv["R1"], sv["m1"], sv["r1"], ca + "ln_%s.weight" % side, ca + "ln_%s.bias" % side, gbuf, dR1, dZ, M, d,
-                drop_b=(self.p_drop, _site(self.bi, i, k_ao)), seed=seed, amax=am_dZ)
+                drop_b=(self.p_drop, _site(self.bi, i, k_ao)), seed=seed, amax=am_dZ,
+                dsum_to=st.g(ca + "ff_%s.bias" % side, gbuf))
         if dZ is None:
             dZ = dR1
         with side_work(st):
             _wgrad(st, dZ, d, 0, sv["A"], d, 0, M, d, d, st.g(ca + "ff_%s.weight" % side, gbuf), a_amax=am_dZ, b_amax=sv["am_A"])
-            _colsum(st, dZ, d, M, d, st.g(ca + "ff_%s.bias" % side, gbuf))
         dA = st.buf("dA" + tag, (M, d))
         _lin_dgrad(st, M, d, d, dZ, ca + "ff_%s.weight" % side, dA, a_amax=am_dZ)
         return dR1, dA
@@ -612,7 +617,9 @@ class BackboneRun:
             Din = x.shape[-1]
             with side_work(st):
                 _wgrad(st, dpre, d, 0, x, Din, 0, M, d, Din, gtab, a_amax=am_dpre, b_amax=sv["am_%s_x" % side])
-                _colsum(st, dpre, d, M, d, st.g(P + "%s_proj.bias" % side, gbuf))
+                # bias gradient = sum over all tokens of dpre = sum over positions of the positional-embedding
+                # gradient just computed ([L, d] instead of a second pass over [B*L, d])
+                _colsum(st, gpe, d, L, d, st.g(P + "%s_proj.bias" % side, gbuf))
 
 
 def _group_view(store, first_name, numel, gbuf):

@@ -14,8 +14,8 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsegmm_hip.so")
-ABI_VERSION = 2
+LIB_PATH = os.environ.get("SEGMM_LIB") or os.path.join(_HERE, "libsegmm_hip.so")      # SEGMM_LIB: A/B builds of the kernels
+ABI_VERSION = 3
 
 _lib = None
 
@@ -36,7 +36,7 @@ SIGNATURES = {
     "segmm_split3_transpose": [_p, _i, _i, _i, _p, _i64, _p],
     "segmm_layernorm_fwd": [_p, _p, _p, _p, _p, _p, _i64, _i, _f, _f, _u64, _u32, _p, _p],
     "segmm_layernorm_bwd_parts": [_i64],
-    "segmm_layernorm_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _f, _u32, _f, _u32, _u64, _p, _p],
+    "segmm_layernorm_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _f, _u32, _f, _u32, _u64, _p, _p],
     "segmm_colsum_chunks": [_i64],
     "segmm_colsum": [_p, _i, _p, _i64, _i, _p, _i, _p, _p],
     "segmm_attn_fwd": [_i] * 6 + [_p, _p, _i, _p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _i, _p, _f, _u64, _u32, _p, _p],
@@ -108,10 +108,11 @@ def _f32c(t, name="tensor"):
 
 GEMM_PROFILE = None       # bench.py sets this to a list to time every GEMM launch with HIP events
 ENGINE_F32, ENGINE_BF16X6, ENGINE_F16X3 = 0, 1, 2
-# default engine of gemm(): the exact 3-way bf16 split on the bf16 matrix cores (fp32-class accuracy, faster);
-# SEGMM_GEMM=f32 selects the f32-input MFMA kernel instead (A/B and parity cross-checks), SEGMM_GEMM=f16x3 the
-# scaled two-term fp16 split (22-bit operands, three products)
-GEMM_ENGINE = {"f32": 0, "bf16x6": 1, "f16x3": 2}[os.environ.get("SEGMM_GEMM", "bf16x6")]
+# default engine of gemm(): the scaled two-term fp16 split on the fp16 matrix cores (22-bit operands, three exact
+# partial products, fp32 accumulation: measured error vs fp64 at or below the f32-MFMA kernel's on every layout).
+# SEGMM_GEMM=bf16x6 selects the exact 3-way bf16 split (six products), SEGMM_GEMM=f32 the f32-input MFMA kernel
+# (A/B and parity cross-checks)
+GEMM_ENGINE = {"f32": 0, "bf16x6": 1, "f16x3": 2}[os.environ.get("SEGMM_GEMM", "f16x3")]
 AMAX_SLOTS = 256          # partial maxima per tensor written by the fused producers (SEGMM_AMAX_SLOTS)
 AMAX_PARTS = 1024         # ... and by the stand-alone absmax() pass
 LAYOUT_NT, LAYOUT_NN, LAYOUT_TN = 0, 1, 2
@@ -228,11 +229,11 @@ def layernorm_bwd_parts(rows):
 
 
 def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dx_drop, part_dgamma, part_dbeta, drop_y_p=0.0, drop_y_site=0,
-                  drop_b_p=0.0, drop_b_site=0, seed=0, amax=None):
+                  drop_b_p=0.0, drop_b_site=0, seed=0, amax=None, part_dsum=None):
     _dev(dy, x, dx)
     d = x.shape[-1]
     _check(lib().segmm_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(dx), _ptr(dx_drop),
-                                     _ptr(part_dgamma), _ptr(part_dbeta), x.numel() // d, d, float(drop_y_p),
+                                     _ptr(part_dgamma), _ptr(part_dbeta), _ptr(part_dsum), x.numel() // d, d, float(drop_y_p),
                                      int(drop_y_site), float(drop_b_p), int(drop_b_site), int(seed), _ptr(amax), _stream()),
            "segmm_layernorm_bwd")
 

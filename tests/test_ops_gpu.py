@@ -161,7 +161,7 @@ def test_l1norm(rows, D):
     assert torch.allclose(inv, 1 / (x.abs().sum(-1) + 1e-6), rtol=2e-6)
 
 
-@pytest.mark.parametrize("rows,d", [(77, 32), (20480, 768), (9, 2048)])
+@pytest.mark.parametrize("rows,d", [(77, 32), (20480, 768), (9, 2048), (301, 512), (130, 1024), (50, 260)])
 def test_layernorm_fwd_bwd(rows, d):
     H = _abi()
     x = _rand(rows, d, seed=20) * 2 + 0.3
@@ -533,8 +533,11 @@ def test_fused_amax_producers():
     dx, dxd = torch.empty_like(x), torch.empty_like(x)
     pg, pb = torch.empty(parts, d, device=DEV), torch.empty(parts, d, device=DEV)
     am.zero_()
-    H.layernorm_bwd(dy, x, mean, rstd, gamma, dx, dxd, pg, pb, drop_b_p=0.1, drop_b_site=4, seed=5, amax=am)
+    ps = torch.empty(parts, d, device=DEV)
+    H.layernorm_bwd(dy, x, mean, rstd, gamma, dx, dxd, pg, pb, drop_b_p=0.1, drop_b_site=4, seed=5, amax=am, part_dsum=ps)
     assert am.max().item() == dxd.abs().max().item()
+    # fused column sums of the forwarded gradient (= bias gradient of the Linear in front of the residual add)
+    assert (ps.double().sum(0) - dxd.double().sum(0)).abs().max().item() < 1e-5 * dxd.abs().sum(0).max().item() + 1e-12
     am.zero_()
     H.layernorm_bwd(dy, x, mean, rstd, gamma, dx, None, pg, pb, amax=am)
     assert am.max().item() == dx.abs().max().item()

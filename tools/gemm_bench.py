@@ -23,6 +23,8 @@ for lay, M, N, K in shapes:
         A, B = torch.randn(M, K, device=dev), torch.randn(K, N, device=dev); lda, ldb = K, N
     else:
         A, B = torch.randn(K, M, device=dev), torch.randn(K, N, device=dev); lda, ldb = M, N
+    if os.environ.get("ZERO") == "1":       # data-dependent power: all-zero operands toggle no datapath bits
+        A.zero_(); B.zero_()
     C = torch.empty(M, N, device=dev)
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     splits = max(1, min(32, (K + 31) // 32, (1024 + tiles - 1) // tiles)) if lay == "TN" else 1
