@@ -121,8 +121,8 @@ int segmm_attn_fwd(int B, int H, int dh, int Lq, int La, int Lb, const float* Qa
                    float drop_p, uint64_t seed, uint32_t site, float* amax_o, segmm_stream_t stream);
 int segmm_attn_bwd(int B, int H, int dh, int Lq, int La, int Lb, const float* Qa, const float* Qb, int ldq,
                    const float* Ka, const float* Va, int ldka, const float* Kb, const float* Vb, int ldkb,
-                   const uint8_t* mq, const uint8_t* mka, const uint8_t* mkb, const float* lse, const float* dO,
-                   int lddo, float* Dvec, float* dQa, float* dQb, int lddq, float* dKa, float* dVa, int lddka,
+                   const uint8_t* mq, const uint8_t* mka, const uint8_t* mkb, const float* lse, const float* O, int ldo,
+                   const float* dO, int lddo, float* Dvec, float* dQa, float* dQb, int lddq, float* dKa, float* dVa, int lddka,
                    float* dKb, float* dVb, int lddkb, float drop_p, uint64_t seed, uint32_t site,
                    float* amax_q, float* amax_ka, float* amax_kb, segmm_stream_t stream);
 
@@ -144,13 +144,15 @@ int segmm_rowscale_mat(const float* g, const float* X, int ldx, float* out, int 
  *   vid[b,s,:] = cat(item_table[item_id[b]], frame_w*s + frame_b) + vid_pe[s];   usr[b,0,:] = user_table[uid[b]] + usr_pe[0]
  * backward: dense table gradients accumulated deterministically over batch rows grouped by id
  * (order = batch rows sorted by id, from a host-side torch.sort; no data-dependent sizes, no sync),
- * and dpe[s,:] = sum_b dpre[b,s,:]. */
+ * and dpe[s,:] = sum_b dpre[b,s,:].  n_rows = rows of the table: an id outside [0, n_rows) (torch.nn.Embedding raises
+ * on it) never touches memory -- its forward row is filled with NaN so the loss shows it, its backward is skipped. */
 int segmm_embed_id_vid(const int64_t* item_id, const float* table, int dhalf, const float* frame_w,
-                       const float* frame_b, const float* pe, float* out, int B, int S, segmm_stream_t stream);
-int segmm_embed_id_usr(const int64_t* user_id, const float* table, int d, const float* pe, float* out, int B,
+                       const float* frame_b, const float* pe, float* out, int B, int S, int64_t n_rows,
                        segmm_stream_t stream);
+int segmm_embed_id_usr(const int64_t* user_id, const float* table, int d, const float* pe, float* out, int B,
+                       int64_t n_rows, segmm_stream_t stream);
 int segmm_embed_id_bwd(const float* dpre, int tokens_per_row, int ld, int col0, int width, const int32_t* order,
-                       const int64_t* ids, float* dtable, int B, segmm_stream_t stream);
+                       const int64_t* ids, float* dtable, int B, int64_t n_rows, segmm_stream_t stream);
 int segmm_pe_grad(const float* dpre, int ld, int B, int S, int d, float* dpe, int accumulate, segmm_stream_t stream);
 
 /* K8 -- compute_loss forward + backward in one launch (decoder_leave_focal.py:490-572).

@@ -8,19 +8,29 @@
 //     logits = dropout(logits) / sqrt(dh)        dropout BEFORE the scale, fills included
 //     out    = softmax(logits) . [Va ; Vb]
 //
-// One workgroup (always 4 waves) = one (batch row, head) x up to 64 queries; each wave owns 16 queries
-// and all keys.  The product is computed TRANSPOSED (S^T = K.Q^T) so the MFMA result has the query on
-// the lane (lane&15) and 4 consecutive keys in the 4 result registers: the softmax row-reduce is
-// register-local plus two wave shuffles, and P^T feeds the second product (O^T = V^T.P^T) straight from
-// registers -- the reduction index of an f32 MFMA operand is free to permute, so
-// "key = 4*lanegroup + step" needs no cross-lane move.  The backward is two kernels, both recomputing S
-// from Q, K and the saved softmax row statistics: a query-major one (dQ, writes D = rowsum(P*dP)) and a
-// key-major one (dK, dV) whose reductions over queries stay inside one wave => no atomics, bitwise
-// reproducible.
-//
-// Staging: these kernels are latency-bound (a head is only 40 x 140 x 48), so every global->LDS phase
-// issues ALL of its loads into registers first (one memory round trip per phase), and the next phase's
-// operand (V after K, K again after V) is prefetched into registers while the current MFMAs run.
+// A head here is tiny (40 queries x 140 keys x 48 dims, 69 KB of operands) and there are B*H = 8192 of them,
+// so the kernels are organised for LATENCY, not for reuse: ONE WAVE owns one 16-row tile (16 queries of a
+// (b, h) in the forward and the dQ kernel, 16 keys in the dK/dV kernel) and runs start to finish without
+// LDS staging and without workgroup barriers (the only shared data is the key-mask byte vector).  Every
+// MFMA operand is fetched from global memory directly in fragment form with vector BUFFER loads (one resource
+// descriptor per tensor, a per-lane byte offset computed once, the key tile as the scalar offset: no per-tile
+// address arithmetic; pad keys of a partial tile read the rows behind the block -- finite data or, past the end
+// of the tensor, zeros -- and get probability 0), which works because two index orders are free to choose:
+//   * the REDUCTION index of a product: lane (row, g) of a 16x16x4 operand holds, for step j = 4i + e, element
+//     k = 16i + 4g + e -- so a lane reads one float4 per 16-float segment of its row (3 for dh = 48), the four
+//     g-lanes of a row read one contiguous 64-byte line per instruction, and both operands use the same
+//     permutation;
+//   * the OUTPUT column order of O^T = V^T.P^T (and dQ, dK, dV): column tile ct, lane column c maps to head
+//     column CT*c + ct, so a lane reads CT contiguous floats of a V row and ends up owning the dh/4
+//     contiguous output columns [g*dh/4, (g+1)*dh/4) of its query row -> float4 stores.
+// The score product is computed TRANSPOSED (S^T = K.Q^T): the MFMA result has the query on lane&15 and four
+// consecutive keys in its four registers, so the softmax row reduce is register-local plus two wave
+// shuffles and P^T feeds the second product straight from registers.
+// The backward is two kernels, both recomputing S from Q, K and the saved softmax row statistics: a
+// query-major one (dQ; D = rowsum(P*dP) = rowsum(dO*O) comes from the saved forward output, which makes it a
+// single pass over the key tiles) and a key-major one (dK, dV) whose reductions over queries stay inside one
+// wave => no atomics, bitwise reproducible.  K/V rows are re-read by the waves of the other
+// query tiles of the same head (L1/L2 hits: the 4 waves of a workgroup work on the same head).
 //
 // Key blocks are padded separately to multiples of 16 (pad keys get probability 0); the dropout
 // stream is indexed by (b, h, query, padded key) so 4 consecutive keys share one hash call.
@@ -35,7 +45,7 @@ struct AttnArgs {
     const float *Ka, *Va; int ldka;     // [B*La, ldka]
     const float *Kb, *Vb; int ldkb;     // [B*Lb, ldkb]
     const uint8_t *mq, *mka, *mkb;      // [B,Lq] [B,La] [B,Lb]; nonzero = valid token
-    float* O; int ldo;                  // [B*Lq, ldo]
+    float* O; int ldo;                  // [B*Lq, ldo]  (forward: output; backward: the saved forward output, read)
     float* lse;                         // [2,B,H,Lq] softmax row statistics: plane 0 = row max, plane 1 = 1/sum.
                                         // Kept as the PAIR (not max+log(sum)): a padded query row has every
                                         // logit at -10000*scale ~ -1e3, where one fp32 ulp of a merged
@@ -48,79 +58,110 @@ struct AttnArgs {
     float *dQa, *dQb; int lddq;
     float *dKa, *dVa; int lddka;
     float *dKb, *dVb; int lddkb;
+    uint32_t ka_bytes, kb_bytes, q_bytes, do_bytes;   // extents of the K/V (block a, b), Q and dO views (buffer range check)
     // optional partial maxima (AMAX_SLOTS each, common.h) of what the kernels write, for the fp16x3 GEMM engine:
     float* amax_o;                      // forward: |O|
     float *amax_q, *amax_ka, *amax_kb;  // backward: |dQa|,|dQb| ; |dKa|,|dVa| ; |dKb|,|dVb|
 };
 
-constexpr int ATT_THREADS = 256;        // 4 waves, fixed: the register-batched staging sizes depend on it
-constexpr int ATT_QB = 64;              // queries (fwd, dQ) / keys (dK,dV) per workgroup
+constexpr int ATT_MAX_THREADS = 320;    // up to 5 waves = 5 row tiles of one (b, h) per workgroup (host picks 1..5)
 
 __device__ __forceinline__ int round16(int x) { return (x + 15) & ~15; }
 
 template <int DH> struct AttnCfg {
-    static constexpr int KS = DH / 4;                       // k-steps over the head dim
+    static constexpr int KS = DH / 4;                       // MFMA k-steps = floats per lane of a row fragment
     static constexpr int CT = (DH + 15) / 16;               // 16-wide column tiles of the head dim
-    static constexpr int LDR = DH + 2;                      // "row on lane&15" reads: stride = 2 mod 4
-    static constexpr int LDC = DH + ((DH % 8 == 0) ? 4 : 0);  // "column on lane&15" reads: stride = 4 mod 8
-    static constexpr int LDMAX = LDR > LDC ? LDR : LDC;
-    static constexpr int UQ = (ATT_QB * KS + ATT_THREADS - 1) / ATT_THREADS;    // float4 per thread for 64 rows
+    // float offset inside a row of lane-group g's first fragment element (see frag_load)
+    __device__ static constexpr int row_off(int g) { return (KS % 4 == 0) ? 4 * g : KS * g; }
 };
 
-// ---- register-batched staging: U float4 per thread cover nrows x DH floats; all loads first, stores later
-template <int DH, int U>
-__device__ __forceinline__ void rows_load(f32x4 (&v)[U], const float* src, size_t ld, int col0, int row_base, int nrows,
-                                          int nvalid, int tid) {
+// Row fragment.  Lane (row, g) takes, from every 16-float segment i of its row, the 4 floats [16i + 4g, 16i + 4g + 4):
+// its reduction index for step j = 4i + e is k = 16i + 4g + e.  (Not "KS contiguous floats per lane": then the four
+// g-lanes of a row would touch four different cache lines in every load instruction; this way one instruction reads
+// ONE 64-byte line per row.)  voff = byte offset of (row, column row_off(g)) in the tensor, soff = uniform byte offset.
+template <int DH>
+__device__ __forceinline__ void frag_load(float (&f)[DH / 4], __amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
     constexpr int KS = DH / 4;
+    if (KS % 4 == 0) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int idx = tid + u * ATT_THREADS;
-        v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (idx < nrows * KS) {
-            const int r = idx / KS, c4 = (idx % KS) * 4;
-            if (r < nvalid) v[u] = *(const f32x4*)(src + (size_t)(row_base + r) * ld + col0 + c4);
+        for (int i = 0; i < KS / 4; ++i) {
+            const f32x4 v = buf_load4(r, voff + 64 * i, soff);
+            f[4 * i] = v.x; f[4 * i + 1] = v.y; f[4 * i + 2] = v.z; f[4 * i + 3] = v.w;
         }
+    } else if (KS == 2) {
+        typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+        const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0);
+        f[0] = __uint_as_float(v.x); f[1 % KS] = __uint_as_float(v.y);
+    } else {
+#pragma unroll
+        for (int i = 0; i < KS; ++i) f[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff + 4 * i, (int)soff, 0));
     }
 }
-// padded key index space: rows [j0, j0+nrows): block a occupies [0, La_p), block b [La_p, La_p+Lb_p)
-template <int DH, int U>
-__device__ __forceinline__ void keys_load(f32x4 (&v)[U], const float* A, int lda, const float* Bm, int ldb, int b, int La,
-                                          int Lb, int La_p, int j0, int nrows, int col0, int tid) {
+// the same fragment through a plain pointer (already at the lane's first element): once-per-wave query-side rows
+template <int DH>
+__device__ __forceinline__ void frag_load_ptr(float (&f)[DH / 4], const float* q) {
     constexpr int KS = DH / 4;
+    if (KS % 4 == 0) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int idx = tid + u * ATT_THREADS;
-        v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (idx < nrows * KS) {
-            const int j = j0 + idx / KS, c4 = (idx % KS) * 4;
-            if (j < La_p) {
-                if (j < La) v[u] = *(const f32x4*)(A + (size_t)(b * La + j) * lda + col0 + c4);
-            } else {
-                const int jb = j - La_p;
-                if (jb < Lb) v[u] = *(const f32x4*)(Bm + (size_t)(b * Lb + jb) * ldb + col0 + c4);
-            }
+        for (int i = 0; i < KS / 4; ++i) {
+            const f32x4 v = *(const f32x4*)(q + 16 * i);
+            f[4 * i] = v.x; f[4 * i + 1] = v.y; f[4 * i + 2] = v.z; f[4 * i + 3] = v.w;
         }
+    } else {
+#pragma unroll
+        for (int i = 0; i < KS; ++i) f[i] = q[i];
     }
 }
-template <int DH, int U>
-__device__ __forceinline__ void rows_store(const f32x4 (&v)[U], float* dst, int lds, int nrows, int tid) {
-    constexpr int KS = DH / 4;
+// Column fragment: lane (c, .) takes the CT contiguous floats [CT*c, CT*c + CT) of a row = its column of every
+// column tile.  voff = byte offset of (row, column CT*c).
+template <int DH>
+__device__ __forceinline__ void col_load(float (&f)[(DH + 15) / 16], __amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, int c) {
+    constexpr int CT = (DH + 15) / 16;
+    typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+    typedef unsigned int u32x3_t __attribute__((ext_vector_type(3)));
+    if (CT * c < DH) {
+        if (CT == 4) {
+            const f32x4 v = buf_load4(r, voff, soff);
+            f[0] = v.x; f[1 % CT] = v.y; f[2 % CT] = v.z; f[3 % CT] = v.w;
+        } else if (CT == 3) {
+            const u32x3_t v = __builtin_amdgcn_raw_buffer_load_b96(r, (int)voff, (int)soff, 0);
+            f[0] = __uint_as_float(v.x); f[1 % CT] = __uint_as_float(v.y); f[2 % CT] = __uint_as_float(v.z);
+        } else if (CT == 2) {
+            const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0);
+            f[0] = __uint_as_float(v.x); f[1 % CT] = __uint_as_float(v.y);
+        } else {
+            f[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+        }
+    } else {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int idx = tid + u * ATT_THREADS;
-        if (idx < nrows * KS) {
-            const int r = idx / KS, c4 = (idx % KS) * 4;
-            float2* d = (float2*)(dst + r * lds + c4);      // row strides are even => 8-byte aligned
-            d[0] = make_float2(v[u].x, v[u].y);
-            d[1] = make_float2(v[u].z, v[u].w);
+        for (int i = 0; i < CT; ++i) f[i] = 0.f;
+    }
+}
+// result of a column-permuted product: lane (., g) register r of tile ct is head column CT*(4g + r) + ct, i.e. the
+// lane owns the 4*CT contiguous columns starting at 4*CT*g
+template <int DH>
+__device__ __forceinline__ float col_store(float* rowp, const f32x4 (&o)[(DH + 15) / 16], int g, float am) {
+    constexpr int CT = (DH + 15) / 16;
+    if (4 * CT * g < DH) {
+        float t[4 * CT];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) t[CT * r + ct] = o[ct][r];
+#pragma unroll
+        for (int i = 0; i < CT; ++i) {
+            const f32x4 v = {t[4 * i], t[4 * i + 1], t[4 * i + 2], t[4 * i + 3]};
+            *(f32x4*)(rowp + 4 * CT * g + 4 * i) = v;
+            am = absmax4(am, v);
         }
     }
+    return am;
 }
 
 // kmask[jp] : 1 valid, 0 masked token (-10000 fill), 2 alignment pad (probability 0)
 __device__ __forceinline__ void stage_kmask(uint8_t* km, const uint8_t* mka, const uint8_t* mkb, int b, int La, int Lb,
-                                            int La_p, int Lb_p, int tid) {
-    for (int j = tid; j < La_p + Lb_p; j += ATT_THREADS) {
+                                            int La_p, int Lb_p) {
+    for (int j = threadIdx.x; j < La_p + Lb_p; j += blockDim.x) {
         uint8_t v;
         if (j < La_p) v = (j < La) ? (mka[(size_t)b * La + j] ? 1 : 0) : 2;
         else { const int jb = j - La_p; v = (jb < Lb) ? (mkb[(size_t)b * Lb + jb] ? 1 : 0) : 2; }
@@ -139,411 +180,389 @@ __device__ __forceinline__ float logit_xform(float s, bool valid, float mult, fl
     return (valid ? s : -10000.0f) * mult * scale;
 }
 
-// S^T tiles of one wave: acc[t][r] = sum_c K[16t + 4g + r][c] Q[query][c]  (query = lane&15).
-// Two key tiles are interleaved so that consecutive MFMAs hit different accumulators (the 16x16x4 f32
-// MFMA has a 40-cycle dependent latency against a 32-cycle issue).
-template <int DH, int NT>
-__device__ __forceinline__ void qk_tiles(f32x4 (&acc)[NT], const float* Qsa, const float* Qsb, const float* Ks, int nt,
-                                         int nta, int wave, int l15, int g) {
-    using C = AttnCfg<DH>;
-    float qa[C::KS], qb[C::KS];
-#pragma unroll
-    for (int c = 0; c < C::KS; ++c) {
-        qa[c] = Qsa[(wave * 16 + l15) * C::LDR + 4 * c + g];
-        qb[c] = Qsb[(wave * 16 + l15) * C::LDR + 4 * c + g];
+// The two key blocks of one batch row, as seen by one lane: resources of the K and V tensors of each block, the
+// lane's byte offsets at key 0 of the row (row-fragment form: key = lane&15; column-fragment form: key = 4*(lane>>4))
+// and the row pitch.  tile() yields the operands of padded key tile t; which block it is in is wave-uniform.
+template <int DH>
+struct KeyBlocks {
+    __amdgpu_buffer_rsrc_t ka, va, kb, vb;
+    uint32_t row_a, row_b, col_a, col_b;     // lane byte offsets
+    uint32_t pitch_a, pitch_b;               // bytes per key row
+    int nta;
+    __device__ __forceinline__ void init(const AttnArgs& p, int b, int col0, int l15, int g) {
+        using C = AttnCfg<DH>;
+        ka = make_rsrc(p.Ka, p.ka_bytes); va = make_rsrc(p.Va, p.ka_bytes);
+        kb = make_rsrc(p.Kb, p.kb_bytes); vb = make_rsrc(p.Vb, p.kb_bytes);
+        pitch_a = (uint32_t)p.ldka * 4u; pitch_b = (uint32_t)p.ldkb * 4u;
+        row_a = ((uint32_t)(b * p.La + l15) * (uint32_t)p.ldka + col0 + C::row_off(g)) * 4u;
+        row_b = ((uint32_t)(b * p.Lb + l15) * (uint32_t)p.ldkb + col0 + C::row_off(g)) * 4u;
+        col_a = ((uint32_t)(b * p.La + 4 * g) * (uint32_t)p.ldka + col0 + C::CT * l15) * 4u;
+        col_b = ((uint32_t)(b * p.Lb + 4 * g) * (uint32_t)p.ldkb + col0 + C::CT * l15) * 4u;
+        nta = round16(p.La) >> 4;
     }
-#pragma unroll
-    for (int t = 0; t < NT; t += 2) {
-        if (t < nt) {
-            const bool two = (t + 1 < nt) && (t + 1 < NT);
-            const bool isa0 = t < nta, isa1 = (t + 1) < nta;
-#pragma unroll
-            for (int c = 0; c < C::KS; ++c) {
-                const float a0 = Ks[(16 * t + l15) * C::LDR + 4 * c + g];
-                acc[t] = MFMA16(a0, isa0 ? qa[c] : qb[c], acc[t]);
-                if (t + 1 < NT) {
-                    if (two) {
-                        const float a1 = Ks[(16 * (t + 1) + l15) * C::LDR + 4 * c + g];
-                        acc[t + 1] = MFMA16(a1, isa1 ? qa[c] : qb[c], acc[t + 1]);
-                    }
-                }
-            }
-        }
-    }
-}
+};
 
 // ------------------------------------------------------------------------------------------ forward
 template <int DH, int NT>
-__global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const AttnArgs p) {
+__global__ __launch_bounds__(ATT_MAX_THREADS) void attn_fwd_kernel(const AttnArgs p) {
     using C = AttnCfg<DH>;
-    constexpr int UK = (NT * 16 * C::KS + ATT_THREADS - 1) / ATT_THREADS;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    extern __shared__ uint8_t km[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     // XCD-aware: the heads of one batch row read interleaved 4*DH-byte slices of the same token rows, so
     // consecutive (b,h) must share an L2 or every shared cache line is fetched from HBM once per XCD
     const int bh = xcd_remap(blockIdx.x, gridDim.x), b = bh / p.H, h = bh % p.H;
-    const int q_blk = blockIdx.y * ATT_QB;
     const int La_p = round16(p.La), Lb_p = round16(p.Lb), Tp = La_p + Lb_p, nta = La_p >> 4, nt = Tp >> 4;
-    float* Qsa = smem;
-    float* Qsb = Qsa + ATT_QB * C::LDR;
-    float* KVs = Qsb + ATT_QB * C::LDR;
-    uint8_t* km = (uint8_t*)(KVs + Tp * C::LDMAX);
     const int col0 = h * DH;
-    const int nq_valid = max(0, min(ATT_QB, p.Lq - q_blk));
-
-    f32x4 rqa[C::UQ], rqb[C::UQ], rk[UK];
-    rows_load<DH, C::UQ>(rqa, p.Qa, p.ldq, col0, b * p.Lq + q_blk, ATT_QB, nq_valid, tid);
-    rows_load<DH, C::UQ>(rqb, p.Qb, p.ldq, col0, b * p.Lq + q_blk, ATT_QB, nq_valid, tid);
-    keys_load<DH, UK>(rk, p.Ka, p.ldka, p.Kb, p.ldkb, b, p.La, p.Lb, La_p, 0, Tp, col0, tid);
-    stage_kmask(km, p.mka, p.mkb, b, p.La, p.Lb, La_p, Lb_p, tid);
-    rows_store<DH, C::UQ>(rqa, Qsa, C::LDR, ATT_QB, tid);
-    rows_store<DH, C::UQ>(rqb, Qsb, C::LDR, ATT_QB, tid);
-    rows_store<DH, UK>(rk, KVs, C::LDR, Tp, tid);
+    stage_kmask(km, p.mka, p.mkb, b, p.La, p.Lb, La_p, Lb_p);
     __syncthreads();
-    keys_load<DH, UK>(rk, p.Va, p.ldka, p.Vb, p.ldkb, b, p.La, p.Lb, La_p, 0, Tp, col0, tid);     // V prefetch, lands under QK^T + softmax
-
-    const int qi = q_blk + wave * 16 + l15;          // this lane's query
+    const int qt = blockIdx.y * wpb + wave;          // this wave's query tile
+    if (16 * qt >= p.Lq) return;
+    const int qi = 16 * qt + l15;                    // this lane's query
     const bool q_in = qi < p.Lq;
-    const bool q_ok = q_in && p.mq[(size_t)b * p.Lq + (q_in ? qi : 0)] != 0;
-    const bool wave_on = q_blk + wave * 16 < p.Lq;   // wave-uniform: waves past Lq only help staging
+    const size_t qrow = (size_t)b * p.Lq + min(qi, p.Lq - 1);
+    const bool q_ok = q_in && p.mq[qrow] != 0;
+    KeyBlocks<DH> kbk;
+    kbk.init(p, b, col0, l15, g);
 
+    float qa[C::KS], qb[C::KS];
+    frag_load_ptr<DH>(qa, p.Qa + qrow * p.ldq + col0 + C::row_off(g));
+    frag_load_ptr<DH>(qb, p.Qb + qrow * p.ldq + col0 + C::row_off(g));
     f32x4 acc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float inv = 0.f;
-    if (wave_on) {
-        qk_tiles<DH, NT>(acc, Qsa, Qsb, KVs, nt, nta, wave, l15, g);
-        // mask fill, dropout, scale; acc[t][r] is key jp = 16t + 4g + r of query qi
-        float mx = -INFINITY;
+    {   // S^T tiles: acc[t][r] = sum_c K[16t + 4g + r][c] Q[query][c]; next tile's K fragment in flight under the MFMAs
+        float kf[2][C::KS];
+        frag_load<DH>(kf[0], nta > 0 ? kbk.ka : kbk.kb, nta > 0 ? kbk.row_a : kbk.row_b, 0);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
+            acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (t < nt) {
-                const uint32_t kb = *(const uint32_t*)(km + 16 * t + 4 * g);
-                f32x4 mult = {1.f, 1.f, 1.f, 1.f};
-                if (p.drop.p > 0.f)
-                    mult = drop_apply4(p.drop, (((uint64_t)bh * p.Lq + (q_in ? qi : 0)) * Tp + 16 * t + 4 * g) >> 2,
-                                       f32x4{1.f, 1.f, 1.f, 1.f});
+                if (t + 1 < NT && t + 1 < nt) {
+                    if (t + 1 < nta) frag_load<DH>(kf[(t + 1) & 1], kbk.ka, kbk.row_a, (uint32_t)(16 * (t + 1)) * kbk.pitch_a);
+                    else frag_load<DH>(kf[(t + 1) & 1], kbk.kb, kbk.row_b, (uint32_t)(16 * (t + 1 - nta)) * kbk.pitch_b);
+                }
+                if (t < nta) {       // wave-uniform: no per-element select of the query projection
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const uint32_t k = (kb >> (8 * r)) & 0xff;
-                    float v = logit_xform(acc[t][r], q_ok && k == 1, mult[r], p.scale);
-                    if (k == 2) v = -INFINITY;
-                    acc[t][r] = v;
-                    mx = fmaxf(mx, v);
+                    for (int c = 0; c < C::KS; ++c) acc[t] = MFMA16(kf[t & 1][c], qa[c], acc[t]);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < C::KS; ++c) acc[t] = MFMA16(kf[t & 1][c], qb[c], acc[t]);
                 }
             }
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        float sum = 0.f;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            if (t < nt) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float e = fast_exp(acc[t][r] - mx);
-                    acc[t][r] = e;
-                    sum += e;
-                }
-            }
-        }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
-        inv = 1.0f / sum;
-        if (g == 0 && q_in) {
-            p.lse[(size_t)bh * p.Lq + qi] = mx;
-            p.lse[(size_t)p.B * p.H * p.Lq + (size_t)bh * p.Lq + qi] = inv;
         }
     }
-    __syncthreads();      // every wave is done reading K
-    rows_store<DH, UK>(rk, KVs, C::LDC, Tp, tid);
-    __syncthreads();
-    if (!wave_on) return;
+    // first V rows on their way while the softmax runs
+    float vf[2][4][C::CT];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        if (nta > 0) col_load<DH>(vf[0][s], kbk.va, kbk.col_a, (uint32_t)s * kbk.pitch_a, l15);
+        else col_load<DH>(vf[0][s], kbk.vb, kbk.col_b, (uint32_t)s * kbk.pitch_b, l15);
+    }
 
+    // mask fill, dropout, scale; acc[t][r] is key jp = 16t + 4g + r of query qi
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (t < nt) {
+            const uint32_t kb = *(const uint32_t*)(km + 16 * t + 4 * g);
+            f32x4 mult = {1.f, 1.f, 1.f, 1.f};
+            if (p.drop.p > 0.f)
+                mult = drop_apply4(p.drop, (((uint64_t)bh * p.Lq + (q_in ? qi : 0)) * Tp + 16 * t + 4 * g) >> 2,
+                                   f32x4{1.f, 1.f, 1.f, 1.f});
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t k = (kb >> (8 * r)) & 0xff;
+                float v = logit_xform(acc[t][r], q_ok && k == 1, mult[r], p.scale);
+                if (k == 2) v = -INFINITY;
+                acc[t][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (t < nt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = fast_exp(acc[t][r] - mx);
+                acc[t][r] = e;
+                sum += e;
+            }
+        }
+    }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    if (g == 0 && q_in) {
+        p.lse[(size_t)bh * p.Lq + qi] = mx;
+        p.lse[(size_t)p.B * p.H * p.Lq + (size_t)bh * p.Lq + qi] = inv;
+    }
+
+    // O^T[c][query] = sum_key V[key][c] P^T[key][query]; step s of tile t contracts keys 16t + 4g + s
     f32x4 o[C::CT];
 #pragma unroll
     for (int ct = 0; ct < C::CT; ++ct) o[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         if (t < nt) {
+            if (t + 1 < NT && t + 1 < nt) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    if (t + 1 < nta) col_load<DH>(vf[(t + 1) & 1][s], kbk.va, kbk.col_a, (uint32_t)(16 * (t + 1) + s) * kbk.pitch_a, l15);
+                    else col_load<DH>(vf[(t + 1) & 1][s], kbk.vb, kbk.col_b, (uint32_t)(16 * (t + 1 - nta) + s) * kbk.pitch_b, l15);
+                }
+            }
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const float pb = acc[t][s] * inv;            // P^T[key 16t+4g+s][query]
 #pragma unroll
-                for (int ct = 0; ct < C::CT; ++ct) {
-                    const int c = 16 * ct + l15;
-                    const float a = (c < DH) ? KVs[(16 * t + 4 * g + s) * C::LDC + c] : 0.f;
-                    o[ct] = MFMA16(a, pb, o[ct]);
-                }
+                for (int ct = 0; ct < C::CT; ++ct) o[ct] = MFMA16(vf[t & 1][s][ct], pb, o[ct]);
             }
         }
     }
     float am = 0.f;
-    if (q_in) {
-#pragma unroll
-        for (int ct = 0; ct < C::CT; ++ct) {
-            const int c = 16 * ct + 4 * g;
-            if (c < DH) {
-                *(f32x4*)(p.O + (size_t)(b * p.Lq + qi) * p.ldo + col0 + c) = o[ct];
-                am = absmax4(am, o[ct]);
-            }
-        }
-    }
-    if (p.amax_o) amax_commit(p.amax_o, am, (blockIdx.x * gridDim.y + blockIdx.y) * 4 + wave);
+    if (q_in) am = col_store<DH>(p.O + qrow * p.ldo + col0, o, g, am);
+    if (p.amax_o) amax_commit(p.amax_o, am, (blockIdx.x * gridDim.y + blockIdx.y) * wpb + wave);
 }
 
 // ------------------------------------------------------------------------------------------ backward: dQ (+ D)
+// D[q] = sum_j P[q][j] dP[q][j] = sum_c dO[q][c] O[q][c] (O = P.V with the very same P), so with the saved forward
+// output the kernel is ONE pass over the key tiles with nothing but the dQ accumulators carried along:
+//   S^T_t = K_t.Q^T -> P^T_t ;  dP^T_t = V_t.dO^T ;  dS^T_t = P^T_t (dP^T_t - D) fac ;  dQ^T += K_t^T . dS^T_t
 template <int DH, int NT>
-__global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(const AttnArgs p) {
+__global__ __launch_bounds__(ATT_MAX_THREADS) void attn_bwd_dq_kernel(const AttnArgs p) {
     using C = AttnCfg<DH>;
-    constexpr int UK = (NT * 16 * C::KS + ATT_THREADS - 1) / ATT_THREADS;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    extern __shared__ uint8_t km[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     const int l15 = lane & 15, g = lane >> 4;
-    // XCD-aware: the heads of one batch row read interleaved 4*DH-byte slices of the same token rows, so
-    // consecutive (b,h) must share an L2 or every shared cache line is fetched from HBM once per XCD
     const int bh = xcd_remap(blockIdx.x, gridDim.x), b = bh / p.H, h = bh % p.H;
-    const int q_blk = blockIdx.y * ATT_QB;
     const int La_p = round16(p.La), Lb_p = round16(p.Lb), Tp = La_p + Lb_p, nta = La_p >> 4, nt = Tp >> 4;
-    float* Qsa = smem;
-    float* Qsb = Qsa + ATT_QB * C::LDR;
-    float* dOs = Qsb + ATT_QB * C::LDR;
-    float* KVs = dOs + ATT_QB * C::LDR;
-    uint8_t* km = (uint8_t*)(KVs + Tp * C::LDMAX);
     const int col0 = h * DH;
-    const int nq_valid = max(0, min(ATT_QB, p.Lq - q_blk));
-
-    f32x4 rk[UK];
-    {
-        f32x4 rqa[C::UQ], rqb[C::UQ], rdo[C::UQ];
-        rows_load<DH, C::UQ>(rqa, p.Qa, p.ldq, col0, b * p.Lq + q_blk, ATT_QB, nq_valid, tid);
-        rows_load<DH, C::UQ>(rqb, p.Qb, p.ldq, col0, b * p.Lq + q_blk, ATT_QB, nq_valid, tid);
-        rows_load<DH, C::UQ>(rdo, p.dO, p.lddo, col0, b * p.Lq + q_blk, ATT_QB, nq_valid, tid);
-        keys_load<DH, UK>(rk, p.Ka, p.ldka, p.Kb, p.ldkb, b, p.La, p.Lb, La_p, 0, Tp, col0, tid);
-        stage_kmask(km, p.mka, p.mkb, b, p.La, p.Lb, La_p, Lb_p, tid);
-        rows_store<DH, C::UQ>(rqa, Qsa, C::LDR, ATT_QB, tid);
-        rows_store<DH, C::UQ>(rqb, Qsb, C::LDR, ATT_QB, tid);
-        rows_store<DH, C::UQ>(rdo, dOs, C::LDR, ATT_QB, tid);
-        rows_store<DH, UK>(rk, KVs, C::LDR, Tp, tid);
-    }
+    stage_kmask(km, p.mka, p.mkb, b, p.La, p.Lb, La_p, Lb_p);
     __syncthreads();
-    keys_load<DH, UK>(rk, p.Va, p.ldka, p.Vb, p.ldkb, b, p.La, p.Lb, La_p, 0, Tp, col0, tid);      // V prefetch
-
-    const int qi = q_blk + wave * 16 + l15;
+    const int qt = blockIdx.y * wpb + wave;
+    if (16 * qt >= p.Lq) return;
+    const int qi = 16 * qt + l15;
     const bool q_in = qi < p.Lq;
-    const bool q_ok = q_in && p.mq[(size_t)b * p.Lq + (q_in ? qi : 0)] != 0;
-    const bool wave_on = q_blk + wave * 16 < p.Lq;
+    const size_t qrow = (size_t)b * p.Lq + min(qi, p.Lq - 1);
+    const bool q_ok = q_in && p.mq[qrow] != 0;
     const float row_mx = q_in ? p.lse[(size_t)bh * p.Lq + qi] : 0.f;
     const float row_inv = q_in ? p.lse[(size_t)p.B * p.H * p.Lq + (size_t)bh * p.Lq + qi] : 0.f;
+    KeyBlocks<DH> kbk;
+    kbk.init(p, b, col0, l15, g);
 
-    f32x4 P[NT], dS[NT];              // P^T, dP^T -> dS^T
-    uint64_t live = 0;                // bit 4t+r: d(logit)/d(raw) != 0 (valid pair AND kept by dropout); the factor
-                                      // itself is the constant drop.scale * scale, so no per-element array is kept
-#pragma unroll
-    for (int t = 0; t < NT; ++t) { P[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dS[t] = P[t]; }
-    if (wave_on) {
-        qk_tiles<DH, NT>(P, Qsa, Qsb, KVs, nt, nta, wave, l15, g);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            if (t < nt) {
-                const uint32_t kb = *(const uint32_t*)(km + 16 * t + 4 * g);
-                f32x4 mult = {1.f, 1.f, 1.f, 1.f};
-                if (p.drop.p > 0.f)
-                    mult = drop_apply4(p.drop, (((uint64_t)bh * p.Lq + (q_in ? qi : 0)) * Tp + 16 * t + 4 * g) >> 2,
-                                       f32x4{1.f, 1.f, 1.f, 1.f});
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const uint32_t k = (kb >> (8 * r)) & 0xff;
-                    const bool valid = q_ok && k == 1;
-                    const float v = logit_xform(P[t][r], valid, mult[r], p.scale);
-                    P[t][r] = (k == 2) ? 0.f : fast_exp(v - row_mx) * row_inv;
-                    if (valid && mult[r] != 0.f) live |= 1ull << (4 * t + r);
-                }
-            }
-        }
-    }
-    __syncthreads();
-    rows_store<DH, UK>(rk, KVs, C::LDR, Tp, tid);                                                   // V (row-on-lane layout)
-    __syncthreads();
-    keys_load<DH, UK>(rk, p.Ka, p.ldka, p.Kb, p.ldkb, b, p.La, p.Lb, La_p, 0, Tp, col0, tid);      // K again, for dQ
+    float qa[C::KS], qb[C::KS], dof[C::KS];
     float Dq = 0.f;
-    if (wave_on) {
-        // dP^T = V . dO^T ; D = sum_j P dP ; dS^T = P (dP - D) * fac
-        float dof[C::KS];
+    {
+        const size_t ro = col0 + C::row_off(g);
+        float of[C::KS];
+        frag_load_ptr<DH>(qa, p.Qa + qrow * p.ldq + ro);
+        frag_load_ptr<DH>(qb, p.Qb + qrow * p.ldq + ro);
+        frag_load_ptr<DH>(dof, p.dO + qrow * p.lddo + ro);
+        frag_load_ptr<DH>(of, p.O + qrow * p.ldo + ro);
 #pragma unroll
-        for (int c = 0; c < C::KS; ++c) dof[c] = dOs[(wave * 16 + l15) * C::LDR + 4 * c + g];
-#pragma unroll
-        for (int t = 0; t < NT; t += 2) {
-            if (t < nt) {
-                const bool two = (t + 1 < nt) && (t + 1 < NT);
-#pragma unroll
-                for (int c = 0; c < C::KS; ++c) {
-                    dS[t] = MFMA16(KVs[(16 * t + l15) * C::LDR + 4 * c + g], dof[c], dS[t]);
-                    if (t + 1 < NT) {
-                        if (two) dS[t + 1] = MFMA16(KVs[(16 * (t + 1) + l15) * C::LDR + 4 * c + g], dof[c], dS[t + 1]);
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-            if (t < nt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) Dq += P[t][r] * dS[t][r];
+        for (int c = 0; c < C::KS; ++c) Dq += dof[c] * of[c];
         Dq += __shfl_xor(Dq, 16, 64);
         Dq += __shfl_xor(Dq, 32, 64);
         if (g == 0 && q_in) p.Dvec[(size_t)bh * p.Lq + qi] = Dq;
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-            if (t < nt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    dS[t][r] = ((live >> (4 * t + r)) & 1ull) ? P[t][r] * (dS[t][r] - Dq) * (p.drop.scale * p.scale) : 0.f;
     }
-    __syncthreads();
-    rows_store<DH, UK>(rk, KVs, C::LDC, Tp, tid);                                                   // K (column-on-lane layout)
-    __syncthreads();
-    if (!wave_on) return;
-    // dQ^T[c][query] = sum_key K[key][c] dS^T[key][query]; block a keys -> dQa, block b keys -> dQb
+    const float fac = p.drop.scale * p.scale;        // d(logit)/d(raw) of a live, kept element
+
+    // K and V row fragments of the NEXT tile are fetched under the current tile's MFMAs (two buffers); the K column
+    // fragments of the current tile are fetched at its start and land under its 24 score MFMAs and the softmax
+    float kf[2][C::KS], vr[2][C::KS], kc[4][C::CT];
+    auto fetch_rows = [&](int buf, int t) {
+        if (t < nta) {
+            const uint32_t so = (uint32_t)(16 * t) * kbk.pitch_a;
+            frag_load<DH>(kf[buf], kbk.ka, kbk.row_a, so);
+            frag_load<DH>(vr[buf], kbk.va, kbk.row_a, so);
+        } else {
+            const uint32_t so = (uint32_t)(16 * (t - nta)) * kbk.pitch_b;
+            frag_load<DH>(kf[buf], kbk.kb, kbk.row_b, so);
+            frag_load<DH>(vr[buf], kbk.vb, kbk.row_b, so);
+        }
+    };
+    auto fetch_cols = [&](int t) {
+        if (t < nta) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) col_load<DH>(kc[s], kbk.ka, kbk.col_a, (uint32_t)(16 * t + s) * kbk.pitch_a, l15);
+        } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) col_load<DH>(kc[s], kbk.kb, kbk.col_b, (uint32_t)(16 * (t - nta) + s) * kbk.pitch_b, l15);
+        }
+    };
     f32x4 da[C::CT], db[C::CT];
 #pragma unroll
     for (int ct = 0; ct < C::CT; ++ct) { da[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; db[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    fetch_rows(0, 0);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         if (t < nt) {
+            if (t + 1 < NT && t + 1 < nt) fetch_rows((t + 1) & 1, t + 1);
+            fetch_cols(t);
             const bool isa = t < nta;
+            f32x4 P = {0.f, 0.f, 0.f, 0.f}, dS = {0.f, 0.f, 0.f, 0.f};
+            if (isa) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-#pragma unroll
-                for (int ct = 0; ct < C::CT; ++ct) {
-                    const int c = 16 * ct + l15;
-                    const float a = (c < DH) ? KVs[(16 * t + 4 * g + s) * C::LDC + c] : 0.f;
-                    if (isa) da[ct] = MFMA16(a, dS[t][s], da[ct]);
-                    else     db[ct] = MFMA16(a, dS[t][s], db[ct]);
+                for (int c = 0; c < C::KS; ++c) {
+                    P = MFMA16(kf[t & 1][c], qa[c], P);
+                    dS = MFMA16(vr[t & 1][c], dof[c], dS);
                 }
+            } else {
+#pragma unroll
+                for (int c = 0; c < C::KS; ++c) {
+                    P = MFMA16(kf[t & 1][c], qb[c], P);
+                    dS = MFMA16(vr[t & 1][c], dof[c], dS);
+                }
+            }
+            const uint32_t kb = *(const uint32_t*)(km + 16 * t + 4 * g);
+            f32x4 mult = {1.f, 1.f, 1.f, 1.f};
+            if (p.drop.p > 0.f)
+                mult = drop_apply4(p.drop, (((uint64_t)bh * p.Lq + (q_in ? qi : 0)) * Tp + 16 * t + 4 * g) >> 2,
+                                   f32x4{1.f, 1.f, 1.f, 1.f});
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t k = (kb >> (8 * r)) & 0xff;
+                const bool valid = q_ok && k == 1;
+                const float v = logit_xform(P[r], valid, mult[r], p.scale);
+                const float pr = (k == 2) ? 0.f : fast_exp(v - row_mx) * row_inv;
+                dS[r] = (valid && mult[r] != 0.f) ? pr * (dS[r] - Dq) * fac : 0.f;
+            }
+            // dQ^T[c][query] += sum_key K[key][c] dS^T[key][query]; block a keys -> dQa, block b keys -> dQb
+            if (isa) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int ct = 0; ct < C::CT; ++ct) da[ct] = MFMA16(kc[s][ct], dS[s], da[ct]);
+            } else {
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int ct = 0; ct < C::CT; ++ct) db[ct] = MFMA16(kc[s][ct], dS[s], db[ct]);
             }
         }
     }
     float am = 0.f;
     if (q_in) {
-#pragma unroll
-        for (int ct = 0; ct < C::CT; ++ct) {
-            const int c = 16 * ct + 4 * g;
-            if (c < DH) {
-                *(f32x4*)(p.dQa + (size_t)(b * p.Lq + qi) * p.lddq + col0 + c) = da[ct];
-                *(f32x4*)(p.dQb + (size_t)(b * p.Lq + qi) * p.lddq + col0 + c) = db[ct];
-                am = absmax4(absmax4(am, da[ct]), db[ct]);
-            }
-        }
+        am = col_store<DH>(p.dQa + qrow * p.lddq + col0, da, g, am);
+        am = col_store<DH>(p.dQb + qrow * p.lddq + col0, db, g, am);
     }
-    if (p.amax_q) amax_commit(p.amax_q, am, (blockIdx.x * gridDim.y + blockIdx.y) * 4 + wave);
+    if (p.amax_q) amax_commit(p.amax_q, am, (blockIdx.x * gridDim.y + blockIdx.y) * wpb + wave);
 }
 
 // ------------------------------------------------------------------------------------------ backward: dK, dV
-// One wave owns 16 keys (one padded key tile) and walks all query tiles.  NQT = upper bound of query tiles
-// (Lq <= 16*NQT); every operand of the workgroup is fetched in ONE batch of loads.
+// One wave owns 16 keys (one padded key tile) and walks all query tiles.  The per-query statistics (row max,
+// 1/sum, D, mask flag) are staged in LDS once per workgroup (reading them per wave straight from global memory
+// was measured 12 % slower).
+// NQT > 0: number of query tiles known at compile time (fully unrolled); NQT = 0: runtime loop.
 template <int DH, int NQT>
-__global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkv_kernel(const AttnArgs p) {
+__global__ __launch_bounds__(ATT_MAX_THREADS) void attn_bwd_dkv_kernel(const AttnArgs p) {
     using C = AttnCfg<DH>;
-    constexpr int ULQ = (NQT * 16 * C::KS + ATT_THREADS - 1) / ATT_THREADS;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     const int l15 = lane & 15, g = lane >> 4;
-    // XCD-aware: the heads of one batch row read interleaved 4*DH-byte slices of the same token rows, so
-    // consecutive (b,h) must share an L2 or every shared cache line is fetched from HBM once per XCD
     const int bh = xcd_remap(blockIdx.x, gridDim.x), b = bh / p.H, h = bh % p.H;
     const int La_p = round16(p.La), Lb_p = round16(p.Lb), Tp = La_p + Lb_p, nta = La_p >> 4, nt = Tp >> 4;
-    const int Lq_p = round16(p.Lq), nqt = Lq_p >> 4;
-    const int k_blk = blockIdx.y * ATT_QB;          // first padded key of this workgroup
-    float* Qsa = smem;
-    float* Qsb = Qsa + Lq_p * C::LDR;
-    float* dOs = Qsb + Lq_p * C::LDR;
-    float* Ks = dOs + Lq_p * C::LDR;
-    float* Vs = Ks + ATT_QB * C::LDR;
-    float* lses = Vs + ATT_QB * C::LDR;
-    float* invs = lses + Lq_p;
-    float* Ds = invs + Lq_p;
-    uint8_t* qm = (uint8_t*)(Ds + Lq_p);
-    uint8_t* km = qm + Lq_p;
+    const int Lq_p = round16(p.Lq), nqt = NQT > 0 ? NQT : (Lq_p >> 4);
     const int col0 = h * DH;
-    {
-        f32x4 rqa[ULQ], rqb[ULQ], rdo[ULQ], rkk[C::UQ], rvv[C::UQ];
-        rows_load<DH, ULQ>(rqa, p.Qa, p.ldq, col0, b * p.Lq, Lq_p, p.Lq, tid);
-        rows_load<DH, ULQ>(rqb, p.Qb, p.ldq, col0, b * p.Lq, Lq_p, p.Lq, tid);
-        rows_load<DH, ULQ>(rdo, p.dO, p.lddo, col0, b * p.Lq, Lq_p, p.Lq, tid);
-        keys_load<DH, C::UQ>(rkk, p.Ka, p.ldka, p.Kb, p.ldkb, b, p.La, p.Lb, La_p, k_blk, ATT_QB, col0, tid);
-        keys_load<DH, C::UQ>(rvv, p.Va, p.ldka, p.Vb, p.ldkb, b, p.La, p.Lb, La_p, k_blk, ATT_QB, col0, tid);
-        for (int i = tid; i < Lq_p; i += ATT_THREADS) {
-            const bool in = i < p.Lq;
-            lses[i] = in ? p.lse[(size_t)bh * p.Lq + i] : 0.f;
-            invs[i] = in ? p.lse[(size_t)p.B * p.H * p.Lq + (size_t)bh * p.Lq + i] : 0.f;
-            Ds[i] = in ? p.Dvec[(size_t)bh * p.Lq + i] : 0.f;
-            qm[i] = in ? (p.mq[(size_t)b * p.Lq + i] ? 1 : 0) : 2;
-        }
-        stage_kmask(km, p.mka, p.mkb, b, p.La, p.Lb, La_p, Lb_p, tid);
-        rows_store<DH, ULQ>(rqa, Qsa, C::LDR, Lq_p, tid);
-        rows_store<DH, ULQ>(rqb, Qsb, C::LDR, Lq_p, tid);
-        rows_store<DH, ULQ>(rdo, dOs, C::LDR, Lq_p, tid);
-        rows_store<DH, C::UQ>(rkk, Ks, C::LDR, ATT_QB, tid);
-        rows_store<DH, C::UQ>(rvv, Vs, C::LDR, ATT_QB, tid);
+    float* s_mx = smem_f;                   // [Lq_p] row max
+    float* s_inv = s_mx + Lq_p;             // [Lq_p] 1 / row sum
+    float* s_D = s_inv + Lq_p;              // [Lq_p] rowsum(P dP)
+    uint8_t* qm = (uint8_t*)(s_D + Lq_p);   // [Lq_p] 1 valid query, 0 masked, 2 pad
+    uint8_t* km = qm + Lq_p;                // [Tp]
+    for (int i = threadIdx.x; i < Lq_p; i += blockDim.x) {
+        const bool in = i < p.Lq;
+        s_mx[i] = in ? p.lse[(size_t)bh * p.Lq + i] : 0.f;
+        s_inv[i] = in ? p.lse[(size_t)p.B * p.H * p.Lq + (size_t)bh * p.Lq + i] : 0.f;
+        s_D[i] = in ? p.Dvec[(size_t)bh * p.Lq + i] : 0.f;
+        qm[i] = in ? (p.mq[(size_t)b * p.Lq + i] ? 1 : 0) : 2;
     }
+    stage_kmask(km, p.mka, p.mkb, b, p.La, p.Lb, La_p, Lb_p);
     __syncthreads();
-
-    const int jt = (k_blk >> 4) + wave;             // this wave's key tile
+    const int jt = blockIdx.y * wpb + wave;         // this wave's key tile
     if (jt >= nt) return;
     const bool isa = jt < nta;
     const int jp = 16 * jt + l15;                   // this lane's key (padded index)
     const uint8_t kflag = km[jp];
-    const float* Qs = isa ? Qsa : Qsb;
+    KeyBlocks<DH> kbk;
+    kbk.init(p, b, col0, l15, g);
 
     float kf[C::KS], vf[C::KS];
-#pragma unroll
-    for (int c = 0; c < C::KS; ++c) {
-        kf[c] = Ks[(wave * 16 + l15) * C::LDR + 4 * c + g];
-        vf[c] = Vs[(wave * 16 + l15) * C::LDR + 4 * c + g];
+    if (isa) {
+        frag_load<DH>(kf, kbk.ka, kbk.row_a, (uint32_t)(16 * jt) * kbk.pitch_a);
+        frag_load<DH>(vf, kbk.va, kbk.row_a, (uint32_t)(16 * jt) * kbk.pitch_a);
+    } else {
+        frag_load<DH>(kf, kbk.kb, kbk.row_b, (uint32_t)(16 * (jt - nta)) * kbk.pitch_b);
+        frag_load<DH>(vf, kbk.vb, kbk.row_b, (uint32_t)(16 * (jt - nta)) * kbk.pitch_b);
     }
+    // query-side tensors: Q (the projection of this key block) and dO; lane offsets at query tile 0
+    const __amdgpu_buffer_rsrc_t rq = make_rsrc(isa ? p.Qa : p.Qb, p.q_bytes), rdo = make_rsrc(p.dO, p.do_bytes);
+    const uint32_t pitch_q = (uint32_t)p.ldq * 4u, pitch_do = (uint32_t)p.lddo * 4u;
+    const uint32_t qrow_off = ((uint32_t)(b * p.Lq + l15) * (uint32_t)p.ldq + col0 + C::row_off(g)) * 4u;
+    const uint32_t dorow_off = ((uint32_t)(b * p.Lq + l15) * (uint32_t)p.lddo + col0 + C::row_off(g)) * 4u;
+    const uint32_t qcol_off = ((uint32_t)(b * p.Lq + 4 * g) * (uint32_t)p.ldq + col0 + C::CT * l15) * 4u;
+    const uint32_t docol_off = ((uint32_t)(b * p.Lq + 4 * g) * (uint32_t)p.lddo + col0 + C::CT * l15) * 4u;
+    const float fscale = p.scale;
+
     f32x4 dk[C::CT], dv[C::CT];
 #pragma unroll
     for (int ct = 0; ct < C::CT; ++ct) { dk[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-    for (int qt = 0; qt < nqt; ++qt) {
+    auto tile = [&](int qt) {
+        // row fragments of this query tile (lane&15 = query) for S and dP, column fragments (4 queries 4g+s) for dK, dV;
+        // queries past Lq read the rows behind (finite, or zeros past the end) and are masked below
+        float qf[C::KS], dof[C::KS];
+        frag_load<DH>(qf, rq, qrow_off, (uint32_t)(16 * qt) * pitch_q);
+        frag_load<DH>(dof, rdo, dorow_off, (uint32_t)(16 * qt) * pitch_do);
+        float qc[4][C::CT], doc[4][C::CT];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            col_load<DH>(qc[s], rq, qcol_off, (uint32_t)(16 * qt + s) * pitch_q, l15);
+            col_load<DH>(doc[s], rdo, docol_off, (uint32_t)(16 * qt + s) * pitch_do, l15);
+        }
+        // statistics of this lane's 4 queries (16qt + 4g + r)
+        const f32x4 mxq = *(const f32x4*)(s_mx + 16 * qt + 4 * g), invq = *(const f32x4*)(s_inv + 16 * qt + 4 * g);
+        const f32x4 Dq = *(const f32x4*)(s_D + 16 * qt + 4 * g);
+        const uint32_t qfl = *(const uint32_t*)(qm + 16 * qt + 4 * g);
         // S[query 16qt+4g+r][key jp] and dP likewise (two independent accumulators, interleaved)
         f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < C::KS; ++c) {
-            const float qa = Qs[(16 * qt + l15) * C::LDR + 4 * c + g];
-            const float da = dOs[(16 * qt + l15) * C::LDR + 4 * c + g];
-            s = MFMA16(qa, kf[c], s);
-            dp = MFMA16(da, vf[c], dp);
+            s = MFMA16(qf[c], kf[c], s);
+            dp = MFMA16(dof[c], vf[c], dp);
         }
         f32x4 Pv, dSv;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int qi = 16 * qt + 4 * g + r;
-            const uint8_t qf = qm[qi];
-            const bool valid = (qf == 1) && (kflag == 1);
+            const uint32_t qf_ = (qfl >> (8 * r)) & 0xff;
+            const bool valid = (qf_ == 1) && (kflag == 1);
             float mult = 1.f;
-            if (p.drop.p > 0.f && qf != 2) mult = drop_mult1(p.drop, ((uint64_t)bh * p.Lq + qi) * Tp + jp);
-            const float v = logit_xform(s[r], valid, mult, p.scale);
-            const float pr = (kflag == 2 || qf == 2) ? 0.f : fast_exp(v - lses[qi]) * invs[qi];
+            if (p.drop.p > 0.f && qf_ != 2) mult = drop_mult1(p.drop, ((uint64_t)bh * p.Lq + qi) * Tp + jp);
+            const float v = logit_xform(s[r], valid, mult, fscale);
+            const float pr = (kflag == 2 || qf_ == 2) ? 0.f : fast_exp(v - mxq[r]) * invq[r];
             Pv[r] = pr;
-            dSv[r] = valid ? pr * (dp[r] - Ds[qi]) * mult * p.scale : 0.f;
+            dSv[r] = valid ? pr * (dp[r] - Dq[r]) * mult * fscale : 0.f;
         }
         // dV^T[c][key] += dO[query][c] P[query][key];  dK^T[c][key] += Q[query][c] dS[query][key]
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
 #pragma unroll
             for (int ct = 0; ct < C::CT; ++ct) {
-                const int c = 16 * ct + l15;
-                const float ao = (c < DH) ? dOs[(16 * qt + 4 * g + s4) * C::LDR + c] : 0.f;
-                const float aq = (c < DH) ? Qs[(16 * qt + 4 * g + s4) * C::LDR + c] : 0.f;
-                dv[ct] = MFMA16(ao, Pv[s4], dv[ct]);
-                dk[ct] = MFMA16(aq, dSv[s4], dk[ct]);
+                dv[ct] = MFMA16(doc[s4][ct], Pv[s4], dv[ct]);
+                dk[ct] = MFMA16(qc[s4][ct], dSv[s4], dk[ct]);
             }
         }
+    };
+    if (NQT > 0) {
+#pragma unroll
+        for (int qt = 0; qt < NQT; ++qt) tile(qt);
+    } else {
+        for (int qt = 0; qt < nqt; ++qt) tile(qt);
     }
-    // store: rows = key jp, columns col0 + 16ct + 4g + r
+    // store: row = key jp, this lane's 4*CT contiguous columns
     const bool ka = jp < La_p;
     const int jloc = ka ? jp : jp - La_p;
     const bool real = ka ? (jloc < p.La) : (jloc < p.Lb);
@@ -551,18 +570,11 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkv_kernel(const AttnArg
     if (real) {
         float* dKp = ka ? p.dKa + (size_t)(b * p.La + jloc) * p.lddka : p.dKb + (size_t)(b * p.Lb + jloc) * p.lddkb;
         float* dVp = ka ? p.dVa + (size_t)(b * p.La + jloc) * p.lddka : p.dVb + (size_t)(b * p.Lb + jloc) * p.lddkb;
-#pragma unroll
-        for (int ct = 0; ct < C::CT; ++ct) {
-            const int c = 16 * ct + 4 * g;
-            if (c < DH) {
-                *(f32x4*)(dKp + col0 + c) = dk[ct];
-                *(f32x4*)(dVp + col0 + c) = dv[ct];
-                am = absmax4(absmax4(am, dk[ct]), dv[ct]);
-            }
-        }
+        am = col_store<DH>(dKp + col0, dk, g, am);
+        am = col_store<DH>(dVp + col0, dv, g, am);
     }
     float* slot = isa ? p.amax_ka : p.amax_kb;          // wave-uniform: a key tile lies in one block
-    if (slot) amax_commit(slot, am, (blockIdx.x * gridDim.y + blockIdx.y) * 4 + wave);
+    if (slot) amax_commit(slot, am, (blockIdx.x * gridDim.y + blockIdx.y) * wpb + wave);
 }
 
 }  // namespace segmm

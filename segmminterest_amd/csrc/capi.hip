@@ -42,40 +42,55 @@ static int attn_fill(AttnArgs& a, int B, int H, int dh, int Lq, int La, int Lb, 
     a.mq = mq; a.mka = mka; a.mkb = mkb;
     a.scale = 1.0f / sqrtf((float)dh);
     a.drop = make_drop(drop_p, seed, site);
+    {   // K/V/Q views are addressed through 32-bit buffer offsets (tile overhang of 15 rows included)
+        const size_t ka = ((size_t)B * La - 1) * ldka + (size_t)H * dh, kb = ((size_t)B * Lb - 1) * ldkb + (size_t)H * dh;
+        const size_t q = ((size_t)B * Lq - 1) * ldq + (size_t)H * dh;
+        SEGMM_REQUIRE(((size_t)B * La + 16) * ldka * 4 < (1ull << 32) && ((size_t)B * Lb + 16) * ldkb * 4 < (1ull << 32) &&
+                      ((size_t)B * Lq + 16) * ldq * 4 < (1ull << 32), "attn: a K/V/Q view exceeds the 4 GiB buffer-addressing window");
+        a.ka_bytes = (uint32_t)(ka * 4); a.kb_bytes = (uint32_t)(kb * 4); a.q_bytes = (uint32_t)(q * 4);
+    }
     return 0;
+}
+
+// waves per workgroup for n row tiles of one (b, h): every wave of the workgroup busy, up to 5
+static int attn_wpb(int n) {
+    if (n <= 5) return n;
+    for (int w = 5; w >= 3; --w)
+        if (n % w == 0) return w;
+    return 4;
 }
 
 template <int DH>
 static int attn_launch_fwd(const AttnArgs& a, hipStream_t s) {
-    using C = AttnCfg<DH>;
     const int Tp = ((a.La + 15) & ~15) + ((a.Lb + 15) & ~15);
-    dim3 grid(a.B * a.H, (a.Lq + ATT_QB - 1) / ATT_QB), block(ATT_THREADS);
-    const size_t lds = sizeof(float) * (2 * ATT_QB * C::LDR + Tp * C::LDMAX) + Tp;
-    if (Tp <= 64) hipLaunchKernelGGL((attn_fwd_kernel<DH, 4>), grid, block, lds, s, a);
-    else hipLaunchKernelGGL((attn_fwd_kernel<DH, 12>), grid, block, lds, s, a);
+    const int nqt = (a.Lq + 15) / 16, wpb = attn_wpb(nqt);
+    dim3 grid(a.B * a.H, (nqt + wpb - 1) / wpb), block(64 * wpb);       // one wave per 16-query tile
+    if (Tp <= 64) hipLaunchKernelGGL((attn_fwd_kernel<DH, 4>), grid, block, Tp, s, a);
+    else if (Tp <= 160) hipLaunchKernelGGL((attn_fwd_kernel<DH, 10>), grid, block, Tp, s, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<DH, 12>), grid, block, Tp, s, a);
     LAUNCH_CHECK();
     return 0;
 }
 
 template <int DH>
 static int attn_launch_bwd(const AttnArgs& a, hipStream_t s) {
-    using C = AttnCfg<DH>;
     const int Tp = ((a.La + 15) & ~15) + ((a.Lb + 15) & ~15);
     {
-        dim3 grid(a.B * a.H, (a.Lq + ATT_QB - 1) / ATT_QB), block(ATT_THREADS);
-        const size_t lds = sizeof(float) * (3 * ATT_QB * C::LDR + Tp * C::LDMAX) + Tp;
-        if (Tp <= 64) hipLaunchKernelGGL((attn_bwd_dq_kernel<DH, 4>), grid, block, lds, s, a);
-        else hipLaunchKernelGGL((attn_bwd_dq_kernel<DH, 12>), grid, block, lds, s, a);
+        const int nqt = (a.Lq + 15) / 16, wpb = attn_wpb(nqt);
+        dim3 grid(a.B * a.H, (nqt + wpb - 1) / wpb), block(64 * wpb);
+        if (Tp <= 64) hipLaunchKernelGGL((attn_bwd_dq_kernel<DH, 4>), grid, block, Tp, s, a);
+        else if (Tp <= 160) hipLaunchKernelGGL((attn_bwd_dq_kernel<DH, 10>), grid, block, Tp, s, a);
+        else hipLaunchKernelGGL((attn_bwd_dq_kernel<DH, 12>), grid, block, Tp, s, a);
         LAUNCH_CHECK();
     }
     {
+        const int nt = Tp / 16, wpb = attn_wpb(nt);
+        dim3 grid(a.B * a.H, (nt + wpb - 1) / wpb), block(64 * wpb);   // one wave per 16-key tile
         const int Lq_p = (a.Lq + 15) & ~15;
-        SEGMM_REQUIRE(Lq_p <= 128, "attn_bwd: %d queries > 128 not built", a.Lq);
-        dim3 grid(a.B * a.H, (Tp + ATT_QB - 1) / ATT_QB), block(ATT_THREADS);
-        const size_t lds = sizeof(float) * (3 * Lq_p * C::LDR + 2 * ATT_QB * C::LDR + 3 * Lq_p) + Lq_p + Tp;
-        SEGMM_REQUIRE(lds <= 160 * 1024, "attn_bwd: %zu bytes of LDS needed (Lq=%d)", lds, a.Lq);
-        if (Lq_p <= 64) hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH, 4>), grid, block, lds, s, a);
-        else hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH, 8>), grid, block, lds, s, a);
+        const size_t lds = (size_t)Lq_p * 13 + Tp;                    // 3 float vectors + query flags + key flags
+        if (Lq_p == 48) hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH, 3>), grid, block, lds, s, a);
+        else if (Lq_p == 16) hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH, 1>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH, 0>), grid, block, lds, s, a);
         LAUNCH_CHECK();
     }
     return 0;
@@ -103,7 +118,7 @@ __global__ void dropout_mult_kernel(float* out, long long n, DropCfg d) {
 extern "C" {
 
 const char* segmm_last_error(void) { return g_segmm_err; }
-int segmm_abi_version(void) { return 3; }
+int segmm_abi_version(void) { return 5; }
 
 int segmm_l1norm(const float* x, float* y, float* inv_scale, int64_t rows, int D, segmm_stream_t stream) {
     SEGMM_REQUIRE(x && (y || inv_scale), "l1norm: null pointer");
@@ -386,18 +401,20 @@ int segmm_attn_fwd(int B, int H, int dh, int Lq, int La, int Lb, const float* Qa
 
 int segmm_attn_bwd(int B, int H, int dh, int Lq, int La, int Lb, const float* Qa, const float* Qb, int ldq,
                    const float* Ka, const float* Va, int ldka, const float* Kb, const float* Vb, int ldkb,
-                   const uint8_t* mq, const uint8_t* mka, const uint8_t* mkb, const float* lse, const float* dO,
-                   int lddo, float* Dvec, float* dQa, float* dQb, int lddq, float* dKa, float* dVa, int lddka,
+                   const uint8_t* mq, const uint8_t* mka, const uint8_t* mkb, const float* lse, const float* O, int ldo,
+                   const float* dO, int lddo, float* Dvec, float* dQa, float* dQb, int lddq, float* dKa, float* dVa, int lddka,
                    float* dKb, float* dVb, int lddkb, float drop_p, uint64_t seed, uint32_t site,
                    float* amax_q, float* amax_ka, float* amax_kb, segmm_stream_t stream) {
     AttnArgs a;
     memset(&a, 0, sizeof(a));
     int rc = attn_fill(a, B, H, dh, Lq, La, Lb, Qa, Qb, ldq, Ka, Va, ldka, Kb, Vb, ldkb, mq, mka, mkb, drop_p, seed, site);
     if (rc) return rc;
-    SEGMM_REQUIRE(lse && dO && Dvec && dQa && dQb && dKa && dVa && dKb && dVb, "attn_bwd: null pointer");
-    SEGMM_REQUIRE(lddo % 4 == 0 && lddq % 4 == 0 && lddka % 4 == 0 && lddkb % 4 == 0, "attn_bwd: leading dims %% 4");
-    SEGMM_REQUIRE(aligned16(dO) && aligned16(dQa) && aligned16(dQb) && aligned16(dKa) && aligned16(dVa) && aligned16(dKb) && aligned16(dVb), "attn_bwd: alignment");
-    a.lse = (float*)lse; a.dO = dO; a.lddo = lddo; a.Dvec = Dvec;
+    SEGMM_REQUIRE(lse && O && dO && Dvec && dQa && dQb && dKa && dVa && dKb && dVb, "attn_bwd: null pointer");
+    SEGMM_REQUIRE(lddo % 4 == 0 && ldo % 4 == 0 && lddq % 4 == 0 && lddka % 4 == 0 && lddkb % 4 == 0, "attn_bwd: leading dims %% 4");
+    SEGMM_REQUIRE(aligned16(O) && aligned16(dO) && aligned16(dQa) && aligned16(dQb) && aligned16(dKa) && aligned16(dVa) && aligned16(dKb) && aligned16(dVb), "attn_bwd: alignment");
+    a.lse = (float*)lse; a.O = (float*)O; a.ldo = ldo; a.dO = dO; a.lddo = lddo; a.Dvec = Dvec;
+    SEGMM_REQUIRE(((size_t)B * Lq + 16) * lddo * 4 < (1ull << 32), "attn_bwd: dO exceeds the 4 GiB buffer-addressing window");
+    a.do_bytes = (uint32_t)((((size_t)B * Lq - 1) * lddo + (size_t)H * dh) * 4);
     a.dQa = dQa; a.dQb = dQb; a.lddq = lddq; a.dKa = dKa; a.dVa = dVa; a.lddka = lddka; a.dKb = dKb; a.dVb = dVb; a.lddkb = lddkb;
     a.amax_q = amax_q; a.amax_ka = amax_ka; a.amax_kb = amax_kb;
     ATTN_DISPATCH(attn_launch_bwd, dh, a, (hipStream_t)stream);
@@ -451,32 +468,32 @@ int segmm_vecsum(const float* v, int64_t n, float* out, int accumulate, segmm_st
 }
 
 int segmm_embed_id_vid(const int64_t* item_id, const float* table, int dhalf, const float* frame_w,
-                       const float* frame_b, const float* pe, float* out, int B, int S, segmm_stream_t stream) {
-    SEGMM_REQUIRE(item_id && table && frame_w && frame_b && pe && out, "embed_id_vid: null pointer");
+                       const float* frame_b, const float* pe, float* out, int B, int S, int64_t n_rows, segmm_stream_t stream) {
+    SEGMM_REQUIRE(item_id && table && frame_w && frame_b && pe && out && n_rows > 0, "embed_id_vid: null pointer / empty table");
     SEGMM_REQUIRE(dhalf % 4 == 0 && aligned16(table) && aligned16(frame_w) && aligned16(frame_b) && aligned16(pe) && aligned16(out), "embed_id_vid: d/2 %% 4 / alignment");
     if (B <= 0) return 0;
     hipLaunchKernelGGL(embed_id_vid_kernel, dim3(B * S), dim3(64), 0, (hipStream_t)stream, (const long long*)item_id, table, dhalf,
-                       frame_w, frame_b, pe, out, B, S);
+                       frame_w, frame_b, pe, out, B, S, (long long)n_rows);
     LAUNCH_CHECK();
     return 0;
 }
 
 int segmm_embed_id_usr(const int64_t* user_id, const float* table, int d, const float* pe, float* out, int B,
-                       segmm_stream_t stream) {
-    SEGMM_REQUIRE(user_id && table && pe && out && d % 4 == 0 && aligned16(table) && aligned16(pe) && aligned16(out), "embed_id_usr: pointer/alignment");
+                       int64_t n_rows, segmm_stream_t stream) {
+    SEGMM_REQUIRE(user_id && table && pe && out && n_rows > 0 && d % 4 == 0 && aligned16(table) && aligned16(pe) && aligned16(out), "embed_id_usr: pointer/alignment");
     if (B <= 0) return 0;
-    hipLaunchKernelGGL(embed_id_usr_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, (const long long*)user_id, table, d, pe, out, B);
+    hipLaunchKernelGGL(embed_id_usr_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, (const long long*)user_id, table, d, pe, out, B, (long long)n_rows);
     LAUNCH_CHECK();
     return 0;
 }
 
 int segmm_embed_id_bwd(const float* dpre, int tokens_per_row, int ld, int col0, int width, const int32_t* order,
-                       const int64_t* ids, float* dtable, int B, segmm_stream_t stream) {
-    SEGMM_REQUIRE(dpre && order && ids && dtable, "embed_id_bwd: null pointer");
+                       const int64_t* ids, float* dtable, int B, int64_t n_rows, segmm_stream_t stream) {
+    SEGMM_REQUIRE(dpre && order && ids && dtable && n_rows > 0, "embed_id_bwd: null pointer / empty table");
     SEGMM_REQUIRE(width % 4 == 0 && ld % 4 == 0 && col0 % 4 == 0 && aligned16(dpre) && aligned16(dtable), "embed_id_bwd: alignment");
     if (B <= 0) return 0;
     hipLaunchKernelGGL(embed_id_bwd_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, dpre, tokens_per_row, ld, col0, width,
-                       (const int*)order, (const long long*)ids, dtable, B);
+                       (const int*)order, (const long long*)ids, dtable, B, (long long)n_rows);
     LAUNCH_CHECK();
     return 0;
 }

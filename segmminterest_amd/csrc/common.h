@@ -121,6 +121,16 @@ __device__ __forceinline__ float wave_scan_incl(float v, int lane) {
     return v;
 }
 
+// ---- raw buffer addressing: one resource descriptor (4 SGPRs) per tensor, a 32-bit per-lane byte offset and a
+// scalar byte offset per access -- no 64-bit per-lane address arithmetic, and reads beyond [p, p + bytes) return 0
+// (hardware range check) instead of faulting.  Tensors addressed this way must be smaller than 4 GiB.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+
 // XCD-aware bijective remap of a linear workgroup id (hardware deals consecutive ids round-robin over
 // the 8 XCDs): gives every XCD a contiguous chunk of logical ids so tiles that share an operand panel
 // hit the same L2.  Speed only; any mapping is correct.

@@ -73,15 +73,6 @@ __device__ __forceinline__ void splith_pair(float x0, float x1, float s, uint32_
     ph = h;
     pl = l;
 }
-// raw buffer resource over [p, p + bytes): loads beyond it return 0 (hardware range check)
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint32_t bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
-}
-__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
-    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
-}
-
 // exact 3-way split of two floats -> packed (hi0,hi1), (mid0,mid1), (lo0,lo1)
 __device__ __forceinline__ void split3_pair(float x0, float x1, uint32_t& ph, uint32_t& pm, uint32_t& pl) {
     ph = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{x0, x1}, bf16x2));

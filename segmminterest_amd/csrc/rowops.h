@@ -282,14 +282,16 @@ __global__ __launch_bounds__(1024) void vecsum_kernel(const float* __restrict__ 
 // vid[b,s,:] = cat(E_item[item_id[b]], frame_w * s + frame_b) + pe[s]     (pre-LayerNorm)
 __global__ __launch_bounds__(256) void embed_id_vid_kernel(const long long* __restrict__ item_id, const float* __restrict__ table, int dhalf,
                                     const float* __restrict__ frame_w, const float* __restrict__ frame_b,
-                                    const float* __restrict__ pe, float* __restrict__ out, int B, int S) {
+                                    const float* __restrict__ pe, float* __restrict__ out, int B, int S, long long n_rows) {
     const int d = 2 * dhalf;
     const long long row = blockIdx.x;       // b*S + s
     const int b = (int)(row / S), s = (int)(row % S);
     const long long id = item_id[b];
+    const bool ok = id >= 0 && id < n_rows;  // torch.nn.Embedding raises on such an id; here the row is poisoned with NaN
+    const float nan = __uint_as_float(0x7fc00000u);
     for (int c = threadIdx.x * 4; c < d; c += blockDim.x * 4) {
         f32x4 v;
-        if (c < dhalf) v = *(const f32x4*)(table + id * dhalf + c);
+        if (c < dhalf) v = ok ? *(const f32x4*)(table + id * dhalf + c) : f32x4{nan, nan, nan, nan};
         else v = *(const f32x4*)(frame_w + (c - dhalf)) * (float)s + *(const f32x4*)(frame_b + (c - dhalf));
         v += *(const f32x4*)(pe + (size_t)s * d + c);
         *(f32x4*)(out + row * d + c) = v;
@@ -297,11 +299,13 @@ __global__ __launch_bounds__(256) void embed_id_vid_kernel(const long long* __re
 }
 // usr[b,0,:] = E_user[user_id[b]] + pe[0]
 __global__ __launch_bounds__(256) void embed_id_usr_kernel(const long long* __restrict__ user_id, const float* __restrict__ table, int d,
-                                    const float* __restrict__ pe, float* __restrict__ out, int B) {
+                                    const float* __restrict__ pe, float* __restrict__ out, int B, long long n_rows) {
     const int b = blockIdx.x;
     const long long id = user_id[b];
+    const bool ok = id >= 0 && id < n_rows;
+    const float nan = __uint_as_float(0x7fc00000u);
     for (int c = threadIdx.x * 4; c < d; c += blockDim.x * 4)
-        *(f32x4*)(out + (size_t)b * d + c) = *(const f32x4*)(table + id * d + c) + *(const f32x4*)(pe + c);
+        *(f32x4*)(out + (size_t)b * d + c) = (ok ? *(const f32x4*)(table + id * d + c) : f32x4{nan, nan, nan, nan}) + *(const f32x4*)(pe + c);
 }
 // backward of the gathers: dense table gradients (torch.nn.Embedding semantics), deterministic and
 // sync-free: `order` = batch rows sorted by id (host-side torch.sort, no size-dependent output).
@@ -309,9 +313,10 @@ __global__ __launch_bounds__(256) void embed_id_usr_kernel(const long long* __re
 // and then sums every following row with the same id, in sorted order.
 __global__ __launch_bounds__(256) void embed_id_bwd_kernel(const float* __restrict__ dpre, int tok_per_row, int ld,
                                     int col0, int width, const int* __restrict__ order,
-                                    const long long* __restrict__ ids, float* __restrict__ dtable, int B) {
+                                    const long long* __restrict__ ids, float* __restrict__ dtable, int B, long long n_rows) {
     const int k0 = blockIdx.x;
     const long long id = ids[order[k0]];
+    if (id < 0 || id >= n_rows) return;      // out-of-range id: its forward row was poisoned, nothing to scatter
     if (k0 > 0 && ids[order[k0 - 1]] == id) return;
     for (int c = threadIdx.x * 4; c < width; c += blockDim.x * 4) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};

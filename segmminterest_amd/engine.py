@@ -534,14 +534,14 @@ class BackboneRun:
         am_dYv, am_dYu = self.amb.new(), self.amb.new()      # one per fused dY buffer: both attentions fold into them
         dR1v, dAv = self._side_post_bwd(i, L, "vid", rec["v"], dXv_out, Mv, (K_AO_V, K_MI_V, K_MO_V), gbuf, "v%d" % i)
         H.attn_bwd(B, Hh, dh, S, S, Lt, (Yv, 0), (Yv, d), nv * d, (Yv, 2 * d), (Yv, 3 * d), nv * d, (Yu, 0), (Yu, d), nu * d,
-                   self.vm, self.vm, self.um, rec["lse_v"], dAv, d, Dv, (dYv, 0), (dYv, d), nv * d, (dYv, 2 * d), (dYv, 3 * d),
+                   self.vm, self.vm, self.um, rec["lse_v"], rec["v"]["A"], d, dAv, d, Dv, (dYv, 0), (dYv, d), nv * d, (dYv, 2 * d), (dYv, 3 * d),
                    nv * d, (dYu, 0), (dYu, d), nu * d, drop_p=self.p_drop, seed=self.seed, site=_site(self.bi, i, K_ATT_V),
                    amax_q=am_dYv, amax_ka=am_dYv, amax_kb=am_dYu)
         dR1u = None
         if full:
             dR1u, dAu = self._side_post_bwd(i, L, "usr", rec["u"], dXu_out, Mu, (K_AO_U, K_MI_U, K_MO_U), gbuf, "u%d" % i)
             H.attn_bwd(B, Hh, dh, Lt, S, Lt, (Yu, 2 * d), (Yu, 3 * d), nu * d, (Yv, 4 * d), (Yv, 5 * d), nv * d,
-                       (Yu, 4 * d), (Yu, 5 * d), nu * d, self.um, self.vm, self.um, rec["lse_u"], dAu, d, Dv,
+                       (Yu, 4 * d), (Yu, 5 * d), nu * d, self.um, self.vm, self.um, rec["lse_u"], rec["u"]["A"], d, dAu, d, Dv,
                        (dYu, 2 * d), (dYu, 3 * d), nu * d, (dYv, 4 * d), (dYv, 5 * d), nv * d, (dYu, 4 * d), (dYu, 5 * d), nu * d,
                        drop_p=self.p_drop, seed=self.seed, site=_site(self.bi, i, K_ATT_U),
                        amax_q=am_dYu, amax_ka=am_dYv, amax_kb=am_dYu)

@@ -15,7 +15,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SEGMM_LIB") or os.path.join(_HERE, "libsegmm_hip.so")      # SEGMM_LIB: A/B builds of the kernels
-ABI_VERSION = 3
+ABI_VERSION = 5
 
 _lib = None
 
@@ -40,16 +40,16 @@ SIGNATURES = {
     "segmm_colsum_chunks": [_i64],
     "segmm_colsum": [_p, _i, _p, _i64, _i, _p, _i, _p, _p],
     "segmm_attn_fwd": [_i] * 6 + [_p, _p, _i, _p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _i, _p, _f, _u64, _u32, _p, _p],
-    "segmm_attn_bwd": [_i] * 6 + [_p, _p, _i, _p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _p, _p, _i,
+    "segmm_attn_bwd": [_i] * 6 + [_p, _p, _i, _p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _i, _p, _i, _p, _p, _p, _i, _p, _p, _i,
                                   _p, _p, _i, _f, _u64, _u32, _p, _p, _p, _p],
     "segmm_rowdot": [_p, _i, _p, _p, _p, _i64, _i, _i, _p],
     "segmm_rowscale_bcast": [_p, _p, _p, _i, _i64, _i, _i, _p],
     "segmm_vecsum": [_p, _i64, _p, _i, _p],
     "segmm_rowdot_pair": [_p, _i, _p, _i, _p, _i64, _i, _i, _p],
     "segmm_rowscale_mat": [_p, _p, _i, _p, _i, _i64, _i, _i, _p],
-    "segmm_embed_id_vid": [_p, _p, _i, _p, _p, _p, _p, _i, _i, _p],
-    "segmm_embed_id_usr": [_p, _p, _i, _p, _p, _i, _p],
-    "segmm_embed_id_bwd": [_p, _i, _i, _i, _i, _p, _p, _p, _i, _p],
+    "segmm_embed_id_vid": [_p, _p, _i, _p, _p, _p, _p, _i, _i, _i64, _p],
+    "segmm_embed_id_usr": [_p, _p, _i, _p, _p, _i, _i64, _p],
+    "segmm_embed_id_bwd": [_p, _i, _i, _i, _i, _p, _p, _p, _i, _i64, _p],
     "segmm_pe_grad": [_p, _i, _i, _i, _i, _p, _i, _p],
     "segmm_label_stats": [_p, _i, _i, _i, _p, _p, _p, _p],
     "segmm_loss_fwd_bwd": [_i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p],
@@ -258,13 +258,13 @@ def attn_fwd(B, H, dh, Lq, La, Lb, Qa, Qb, ldq, Ka, Va, ldka, Kb, Vb, ldkb, mq, 
                                 int(site), _ptr(amax_o), _stream()), "segmm_attn_fwd")
 
 
-def attn_bwd(B, H, dh, Lq, La, Lb, Qa, Qb, ldq, Ka, Va, ldka, Kb, Vb, ldkb, mq, mka, mkb, lse, dO, lddo, Dvec,
+def attn_bwd(B, H, dh, Lq, La, Lb, Qa, Qb, ldq, Ka, Va, ldka, Kb, Vb, ldkb, mq, mka, mkb, lse, O, ldo, dO, lddo, Dvec,
              dQa, dQb, lddq, dKa, dVa, lddka, dKb, dVb, lddkb, drop_p=0.0, seed=0, site=0, amax_q=None, amax_ka=None,
              amax_kb=None):
     def P(x):
         return x[0].data_ptr() + 4 * x[1]
     _check(lib().segmm_attn_bwd(B, H, dh, Lq, La, Lb, P(Qa), P(Qb), ldq, P(Ka), P(Va), ldka, P(Kb), P(Vb), ldkb,
-                                _ptr(mq), _ptr(mka), _ptr(mkb), _ptr(lse), _ptr(dO), lddo, _ptr(Dvec), P(dQa),
+                                _ptr(mq), _ptr(mka), _ptr(mkb), _ptr(lse), _ptr(O), ldo, _ptr(dO), lddo, _ptr(Dvec), P(dQa),
                                 P(dQb), lddq, P(dKa), P(dVa), lddka, P(dKb), P(dVb), lddkb, float(drop_p), int(seed),
                                 int(site), _ptr(amax_q), _ptr(amax_ka), _ptr(amax_kb), _stream()), "segmm_attn_bwd")
 
@@ -295,17 +295,17 @@ def vecsum(v, n, out, accumulate=False):
 
 def embed_id_vid(item_id, table, dhalf, frame_w, frame_b, pe, out, B, S):
     _check(lib().segmm_embed_id_vid(_ptr(item_id), _ptr(table), dhalf, _ptr(frame_w), _ptr(frame_b), _ptr(pe),
-                                    _ptr(out), B, S, _stream()), "segmm_embed_id_vid")
+                                    _ptr(out), B, S, table.shape[0], _stream()), "segmm_embed_id_vid")
 
 
 def embed_id_usr(user_id, table, d, pe, out, B):
-    _check(lib().segmm_embed_id_usr(_ptr(user_id), _ptr(table), d, _ptr(pe), _ptr(out), B, _stream()),
+    _check(lib().segmm_embed_id_usr(_ptr(user_id), _ptr(table), d, _ptr(pe), _ptr(out), B, table.shape[0], _stream()),
            "segmm_embed_id_usr")
 
 
 def embed_id_bwd(dpre, tokens_per_row, ld, col0, width, order, ids, dtable, B):
     _check(lib().segmm_embed_id_bwd(_ptr(dpre), tokens_per_row, ld, col0, width, _ptr(order), _ptr(ids), _ptr(dtable),
-                                    B, _stream()), "segmm_embed_id_bwd")
+                                    B, dtable.shape[0], _stream()), "segmm_embed_id_bwd")
 
 
 def pe_grad(dpre, ld, B, S, d, dpe, accumulate=False):

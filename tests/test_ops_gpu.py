@@ -286,7 +286,7 @@ def test_attention_fwd_bwd(B, H_, dh, Lq, La, Lb):
     ref.backward(dO.view(B, Lq, d).double())
     Dv = torch.empty(B, H_, Lq, device=DEV)
     outs = [torch.full_like(t, float("nan")) for t in (Qa, Qb, Ka, Va, Kb, Vb)]
-    H.attn_bwd(B, H_, dh, Lq, La, Lb, z(Qa), z(Qb), d, z(Ka), z(Va), d, z(Kb), z(Vb), d, mq, mka, mkb, lse, dO, d, Dv,
+    H.attn_bwd(B, H_, dh, Lq, La, Lb, z(Qa), z(Qb), d, z(Ka), z(Va), d, z(Kb), z(Vb), d, mq, mka, mkb, lse, O, d, dO, d, Dv,
                z(outs[0]), z(outs[1]), d, z(outs[2]), z(outs[3]), d, z(outs[4]), z(outs[5]), d)
     for name, got, leaf in zip(("dQa", "dQb", "dKa", "dVa", "dKb", "dVb"), outs, leaves):
         err = (got.double() - leaf.grad).abs().max().item()
@@ -323,7 +323,7 @@ def test_attention_dropout_consistency():
     ref.backward(dO.view(B, Lq, d).double())
     Dv = torch.empty(B, H_, Lq, device=DEV)
     outs = [torch.empty_like(t) for t in (Qa, Qb, Ka, Va, Kb, Vb)]
-    H.attn_bwd(B, H_, dh, Lq, La, Lb, z(Qa), z(Qb), d, z(Ka), z(Va), d, z(Kb), z(Vb), d, mq, mka, mkb, lse, dO, d, Dv,
+    H.attn_bwd(B, H_, dh, Lq, La, Lb, z(Qa), z(Qb), d, z(Ka), z(Va), d, z(Kb), z(Vb), d, mq, mka, mkb, lse, O, d, dO, d, Dv,
                z(outs[0]), z(outs[1]), d, z(outs[2]), z(outs[3]), d, z(outs[4]), z(outs[5]), d, drop_p=p, seed=11, site=3)
     for got, leaf in zip(outs, leaves):
         assert (got.double() - leaf.grad).abs().max().item() < 5e-5
@@ -375,6 +375,21 @@ def test_embed_id():
     dpe = torch.empty(S, d, device=DEV)
     H.pe_grad(dpre, d, B, S, d, dpe)
     assert torch.allclose(dpe, dpre.view(B, S, d).sum(0), atol=1e-5)
+    # ids outside the table (torch.nn.Embedding raises): no memory is touched, the forward rows are NaN, the
+    # backward skips them
+    bad = torch.tensor([3, 10 ** 9, -1, 51, 1, 7], device=DEV)
+    H.embed_id_vid(bad, table, dh, fw, fb, vpe, out, B, S)
+    o = out.view(B, S, d)
+    assert torch.isnan(o[[1, 2, 3], :, :dh]).all() and torch.isfinite(o[[0, 4, 5]]).all() and torch.isfinite(o[:, :, dh:]).all()
+    ubad = torch.tensor([1, 21, 1, -5, 5, 5], device=DEV)
+    H.embed_id_usr(ubad, utable, d, upe, uo, B)
+    assert torch.isnan(uo[[1, 3]]).all() and torch.isfinite(uo[[0, 2, 4, 5]]).all()
+    dtab.zero_()
+    H.embed_id_bwd(dpre, S, d, 0, dh, torch.argsort(bad, stable=True).to(torch.int32), bad, dtab, B)
+    ok = torch.tensor([0, 4, 5], device=DEV)
+    ref = torch.zeros_like(table)
+    ref.index_add_(0, bad[ok], dpre.view(B, S, d)[ok][:, :, :dh].sum(1))
+    assert torch.allclose(dtab, ref, atol=1e-5)
 
 
 # ------------------------------------------------------------------ bf16x6 split-MFMA engine
@@ -559,7 +574,7 @@ def test_fused_amax_producers():
     Dv = torch.empty(B, H_, Lq, device=DEV)
     outs = [torch.empty_like(t) for t in (Qa, Qb, Ka, Va, Kb, Vb)]
     aq, aka, akb = (torch.zeros(H.AMAX_SLOTS, device=DEV) for _ in range(3))
-    H.attn_bwd(B, H_, dh, Lq, La, Lb, z(Qa), z(Qb), dm, z(Ka), z(Va), dm, z(Kb), z(Vb), dm, mq, mka, mkb, lse, dO, dm, Dv,
+    H.attn_bwd(B, H_, dh, Lq, La, Lb, z(Qa), z(Qb), dm, z(Ka), z(Va), dm, z(Kb), z(Vb), dm, mq, mka, mkb, lse, O, dm, dO, dm, Dv,
                z(outs[0]), z(outs[1]), dm, z(outs[2]), z(outs[3]), dm, z(outs[4]), z(outs[5]), dm, amax_q=aq, amax_ka=aka, amax_kb=akb)
     assert aq.max().item() == max(outs[0].abs().max().item(), outs[1].abs().max().item())
     assert aka.max().item() == max(outs[2].abs().max().item(), outs[3].abs().max().item())
