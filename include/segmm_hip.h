@@ -174,6 +174,34 @@ int segmm_loss_fwd_bwd(int B, int S, const float* logits, const int64_t* gt, con
 int segmm_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                 float eps, float weight_decay, int step, segmm_stream_t stream);
 
+
+/* ---- the callers either side of the training step -------------------------------------------
+ * (f)-2 on-device evaluation (my_evaluation.py:73-231, SegRec/main.py:101-117).  Integer results only: for the same
+ * float inputs they are bit-exact against numpy/sklearn.
+ * segmm_rank_leave: TOP_K_leave (masked = 0: row valid iff view_len < seq_valid) / TOP_K_leave_mask (masked = 1: row
+ *   valid iff view_len != #unpadded, padded positions score 1.1).  x [B, ldx] interests, gt [B, S] in {1,0,-1,-2},
+ *   perm [B, S] int32 candidate permutations or null.  ranks[B]: 1-based rank of the leave segment in ascending
+ *   order with ties by the lower candidate index (np.argsort), 0 for invalid rows; hist[S + 1] (caller-zeroed) is
+ *   incremented at [rank].
+ * segmm_auc_counts: per segment s (elements seg_off[s] .. seg_off[s+1]) out[s] = {U2, npos, nneg}, U2 = sum over
+ *   positives of 2 * #(negatives below) + #(negatives equal); AUC = U2 / (2 npos nneg) = sklearn.roc_auc_score.
+ *   label: 1 positive, 0 negative, other values ignored.  One segment = ProbAUC of a batch; one per user = wuAUC.
+ * segmm_survival: surv = exp(cumsum(log interest)) (sequential fp32 sum) and the AUC label of each cell. */
+int segmm_rank_leave(const float* x, int ldx, const int64_t* gt, const int32_t* perm, int B, int S, int masked, int seq_valid,
+                     int32_t* ranks, int32_t* hist, segmm_stream_t stream);
+int segmm_auc_counts(const float* score, const int8_t* label, const int64_t* seg_off, int n_seg, int64_t* out,
+                     segmm_stream_t stream);
+int segmm_survival(const float* interest, int ld, const int64_t* gt, float* surv, int8_t* label, int B, int S,
+                   segmm_stream_t stream);
+/* (f)-1 resident-table feature gather (dataloader_SegMM.py:271-362 + the trainer's L1 normalisation): out[r, :] =
+ * table[idx[r], :] (/ (sum|.| + 1e-6) if normalize), mask[r] = 1, for idx[r] in [0, n_lines); zeros / 0 otherwise. */
+int segmm_gather_l1(const float* table, int64_t n_lines, int D, const int64_t* idx, int64_t rows, int normalize, float* out,
+                    uint8_t* mask, segmm_stream_t stream);
+/* (f)-3 SegRec weighted head (ClipRec.forward, SegRec/models/context/ClipRec.py:163-181): out[r] = sum_seg pred[r, seg] *
+ * weight[r, seg] * (seg < duration[r]); weight == null: ones, duration == null: no duration mask. */
+int segmm_segment_weighted_sum(const float* pred, const float* weight, const int64_t* duration, int64_t rows, int S, float* out,
+                               segmm_stream_t stream);
+
 /* test hook: multiplier (0 or 1/(1-p)) of elements [0,n) of a dropout site */
 int segmm_dropout_mult(float* out, int64_t n, float p, uint64_t seed, uint32_t site, segmm_stream_t stream);
 

@@ -7,6 +7,7 @@
 #include "../../include/segmm_hip.h"
 #include "attention.h"
 #include "common.h"
+#include "evalops.h"
 #include "gemm.h"
 #include "gemm_bf16x6.h"
 #include "loss.h"
@@ -118,7 +119,7 @@ __global__ void dropout_mult_kernel(float* out, long long n, DropCfg d) {
 extern "C" {
 
 const char* segmm_last_error(void) { return g_segmm_err; }
-int segmm_abi_version(void) { return 5; }
+int segmm_abi_version(void) { return 6; }
 
 int segmm_l1norm(const float* x, float* y, float* inv_scale, int64_t rows, int D, segmm_stream_t stream) {
     SEGMM_REQUIRE(x && (y || inv_scale), "l1norm: null pointer");
@@ -556,6 +557,57 @@ int segmm_dropout_mult(float* out, int64_t n, float p, uint64_t seed, uint32_t s
     SEGMM_REQUIRE(out && p >= 0.f && p < 1.f, "dropout_mult: bad args");
     if (n <= 0) return 0;
     hipLaunchKernelGGL(dropout_mult_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, out, (long long)n, make_drop(p, seed, site));
+    LAUNCH_CHECK();
+    return 0;
+}
+
+
+int segmm_rank_leave(const float* x, int ldx, const int64_t* gt, const int32_t* perm, int B, int S, int masked, int seq_valid,
+                     int32_t* ranks, int32_t* hist, segmm_stream_t stream) {
+    SEGMM_REQUIRE(x && gt && ranks && hist && S > 0 && ldx >= S, "rank_leave: null pointer / S / ldx");
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(rank_leave_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, (const long long*)gt,
+                       (const int*)perm, B, S, masked, seq_valid, (int*)ranks, (int*)hist);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int segmm_auc_counts(const float* score, const int8_t* label, const int64_t* seg_off, int n_seg, int64_t* out,
+                     segmm_stream_t stream) {
+    SEGMM_REQUIRE(score && label && seg_off && out, "auc_counts: null pointer");
+    if (n_seg <= 0) return 0;
+    hipLaunchKernelGGL(auc_counts_kernel, dim3(n_seg), dim3(256), 0, (hipStream_t)stream, score, (const signed char*)label,
+                       (const long long*)seg_off, (long long*)out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int segmm_survival(const float* interest, int ld, const int64_t* gt, float* surv, int8_t* label, int B, int S,
+                   segmm_stream_t stream) {
+    SEGMM_REQUIRE(interest && gt && surv && label && S > 0 && ld >= S, "survival: null pointer / S / ld");
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(survival_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, interest, ld, (const long long*)gt,
+                       surv, (signed char*)label, B, S);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int segmm_gather_l1(const float* table, int64_t n_lines, int D, const int64_t* idx, int64_t rows, int normalize, float* out,
+                    uint8_t* mask, segmm_stream_t stream) {
+    SEGMM_REQUIRE(table && idx && out && n_lines > 0 && D > 0 && D % 4 == 0 && aligned16(table) && aligned16(out), "gather_l1: pointer / D %% 4 / alignment");
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(gather_l1_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, table, (long long)n_lines, D,
+                       (const long long*)idx, (long long)rows, normalize, out, mask);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int segmm_segment_weighted_sum(const float* pred, const float* weight, const int64_t* duration, int64_t rows, int S, float* out,
+                               segmm_stream_t stream) {
+    SEGMM_REQUIRE(pred && out && S > 0, "segment_weighted_sum: null pointer / S");
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(segment_weighted_sum_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, pred, weight,
+                       (const long long*)duration, (long long)rows, S, out);
     LAUNCH_CHECK();
     return 0;
 }

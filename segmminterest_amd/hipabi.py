@@ -15,7 +15,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SEGMM_LIB") or os.path.join(_HERE, "libsegmm_hip.so")      # SEGMM_LIB: A/B builds of the kernels
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _lib = None
 
@@ -55,6 +55,11 @@ SIGNATURES = {
     "segmm_loss_fwd_bwd": [_i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p],
     "segmm_adamw": [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _i, _p],
     "segmm_dropout_mult": [_p, _i64, _f, _u64, _u32, _p],
+    "segmm_rank_leave": [_p, _i, _p, _p, _i, _i, _i, _i, _p, _p, _p],
+    "segmm_auc_counts": [_p, _p, _p, _i, _p, _p],
+    "segmm_survival": [_p, _i, _p, _p, _p, _i, _i, _p],
+    "segmm_gather_l1": [_p, _i64, _i, _p, _i64, _i, _p, _p, _p],
+    "segmm_segment_weighted_sum": [_p, _p, _p, _i64, _i, _p, _p],
 }
 
 
@@ -335,3 +340,68 @@ def adamw(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, p_off=0):
 
 def dropout_mult(out, n, p, seed, site):
     _check(lib().segmm_dropout_mult(_ptr(out), n, float(p), int(seed), int(site), _stream()), "segmm_dropout_mult")
+
+
+# ------------------------------------------------------------------ evaluation, gather, SegRec head
+def rank_leave(x, gt, perm=None, masked=False, seq_valid=None):
+    """(ranks int32 [B], hist int32 [S+1]) of the leave segment; see segmm_rank_leave in include/segmm_hip.h."""
+    _dev(x, gt)
+    B, S = gt.shape
+    if x.dtype != torch.float32 or x.stride(-1) != 1 or gt.dtype != torch.int64 or not gt.is_contiguous():
+        raise RuntimeError("rank_leave: x float32 with unit inner stride, gt contiguous int64")
+    if perm is not None and (perm.dtype != torch.int32 or not perm.is_contiguous() or perm.shape != gt.shape):
+        raise RuntimeError("rank_leave: perm must be a contiguous int32 [B, S] tensor")
+    ranks = torch.empty(B, dtype=torch.int32, device=x.device)
+    hist = torch.zeros(S + 1, dtype=torch.int32, device=x.device)
+    _check(lib().segmm_rank_leave(_ptr(x), x.stride(0), _ptr(gt), _ptr(perm), B, S, int(bool(masked)),
+                                  S if seq_valid is None else int(seq_valid), _ptr(ranks), _ptr(hist), _stream()), "segmm_rank_leave")
+    return ranks, hist
+
+
+def auc_counts(score, label, seg_off):
+    """int64 [n_seg, 3] = (U2, npos, nneg) per segment; label int8 (1 / 0 / other = ignored)."""
+    _dev(score, label, seg_off)
+    if score.dtype != torch.float32 or label.dtype != torch.int8 or seg_off.dtype != torch.int64:
+        raise RuntimeError("auc_counts: score float32, label int8, seg_off int64")
+    n_seg = seg_off.numel() - 1
+    out = torch.zeros((max(n_seg, 0), 3), dtype=torch.int64, device=score.device)
+    _check(lib().segmm_auc_counts(_ptr(score.contiguous()), _ptr(label.contiguous()), _ptr(seg_off.contiguous()), n_seg, _ptr(out),
+                                  _stream()), "segmm_auc_counts")
+    return out
+
+
+def survival(interest, gt):
+    """(surv float32 [B, S], label int8 [B, S]) for ProbAUC."""
+    _dev(interest, gt)
+    B, S = gt.shape
+    surv = torch.empty((B, S), dtype=torch.float32, device=interest.device)
+    label = torch.empty((B, S), dtype=torch.int8, device=interest.device)
+    _check(lib().segmm_survival(_ptr(interest), interest.stride(0), _ptr(gt.contiguous()), _ptr(surv), _ptr(label), B, S, _stream()),
+           "segmm_survival")
+    return surv, label
+
+
+def gather_l1(table, idx, normalize=True, out=None, mask=None):
+    """out[..., :] = (L1-normalised) table[idx[...]], mask[...] = idx in range; idx int64 of any shape."""
+    _dev(table, idx)
+    D = table.shape[1]
+    rows = idx.numel()
+    if out is None:
+        out = torch.empty(tuple(idx.shape) + (D,), dtype=torch.float32, device=table.device)
+    if mask is None:
+        mask = torch.empty(tuple(idx.shape), dtype=torch.uint8, device=table.device)
+    _check(lib().segmm_gather_l1(_ptr(_f32c(table, "table")), table.shape[0], D, _ptr(idx.contiguous()), rows, int(bool(normalize)),
+                                 _ptr(out), _ptr(mask), _stream()), "segmm_gather_l1")
+    return out, mask.view(torch.bool)
+
+
+def segment_weighted_sum(pred, weight=None, duration=None):
+    """sum_seg pred * weight * (seg < duration) over the last axis."""
+    _dev(pred)
+    S = pred.shape[-1]
+    rows = pred.numel() // S
+    out = torch.empty(pred.shape[:-1], dtype=torch.float32, device=pred.device)
+    _check(lib().segmm_segment_weighted_sum(_ptr(_f32c(pred, "pred")), _ptr(None if weight is None else _f32c(weight, "weight")),
+                                            _ptr(None if duration is None else duration.contiguous()), rows, S, _ptr(out), _stream()),
+           "segmm_segment_weighted_sum")
+    return out

@@ -4,8 +4,12 @@ Same function names, arguments and returned keys as the reference (my_evaluation
 Ranks are computed as integer counts ("how many entries sort before the target", ties broken by the
 lower index -- what ``np.argsort`` does on these sizes, SURVEY.md §7), so HR@k / NDCG@k are bit-exact;
 with ``permutation=1`` the same ``np.random`` stream is consumed (one ``np.random.permutation(seq_len)``
-per valid row, seed 42 at import like my_evaluation.py:14-15).  These run on the host like the
-reference's; an on-device rank kernel is the next row of the scope table.
+per valid row, seed 42 at import like my_evaluation.py:14-15).
+
+Device path: when the interests / labels are HIP tensors, the ``*_device`` functions and
+``main_eval_batch`` compute the integer ranks and the AUC pair counts with the kernels of ``csrc/evalops.h``
+(bit-exact integers; only B view lengths go to the host -- for the np.random permutation parity -- and B ranks or
+three counters come back), instead of moving [B, S] interests, labels and masks to the host like the reference.
 """
 from __future__ import annotations
 
@@ -67,6 +71,62 @@ def TOP_K_leave_mask(interests, view_lengths, mask_batch, permutation=1):
     """Same with padded positions pushed to the end (interest 1.1) and fully-watched rows dropped
     (my_evaluation.py:137-178)."""
     return _evaluations(_topk(interests, view_lengths, mask_batch, permutation, masked=True))
+
+
+def TOP_K_leave_device(interests: torch.Tensor, gt: torch.Tensor, permutation=1, masked=False, seq_valid=None, test=0):
+    """TOP_K_leave / TOP_K_leave_mask on the device: interests [B, S] float32 and labels gt [B, S] int64 stay in HBM.
+    Returns the same dict (same float arithmetic on the same integer ranks).  With ``permutation`` the host draws the
+    candidate shuffles from np.random exactly as the host path does (one permutation per VALID row, in row order)."""
+    from . import hipabi as H
+    B, S = gt.shape
+    x = interests.detach()
+    if x.dtype != torch.float32:
+        x = x.float()
+    if x.stride(-1) != 1:
+        x = x.contiguous()
+    gt = gt.contiguous()
+    perm = None
+    if permutation:
+        vl = (gt == 1).sum(1)
+        valid = (vl != (gt != -2).sum(1)) if masked else (vl < (S if seq_valid is None else seq_valid))
+        n = int(valid.sum().item())
+        pv = np.array([np.random.permutation(S) for _ in range(n)], dtype=np.int32).reshape(n, S)
+        perm = torch.zeros((B, S), dtype=torch.int32, device=x.device)
+        perm[valid] = torch.from_numpy(pv).to(x.device)
+    ranks, _hist = H.rank_leave(x, gt, perm=perm, masked=masked, seq_valid=seq_valid)
+    r = ranks.cpu().numpy().astype(np.int64)
+    ev = _evaluations(r[r > 0])
+    if test:
+        return ev, torch.argmin(x, dim=1).cpu().numpy()
+    return ev
+
+
+def ProbAUC_batch_device(interests: torch.Tensor, gt: torch.Tensor, survival=None):
+    """ProbAUC_batch (my_evaluation.py:73-80) from integer pair counts computed on the device."""
+    from . import hipabi as H
+    x = interests.detach().float()
+    if x.stride(-1) != 1:
+        x = x.contiguous()
+    surv, label = H.survival(x, gt.contiguous())
+    if survival is not None:          # test_type == "old": the interests already are survival probabilities
+        surv = survival.detach().float().contiguous()
+    seg = torch.tensor([0, surv.numel()], dtype=torch.int64, device=surv.device)
+    u2, npos, nneg = (int(v) for v in H.auc_counts(surv.view(-1), label.view(-1), seg)[0].tolist())
+    return u2 / (2.0 * npos * nneg)
+
+
+def wuAUC_device(labels: torch.Tensor, scores: torch.Tensor, users: torch.Tensor):
+    """Sample-weighted per-user AUC (SegRec/main.py:101-117) with the per-user pair counts computed on the device."""
+    from . import hipabi as H
+    order = torch.sort(users, stable=True).indices
+    u, counts = torch.unique_consecutive(users[order], return_counts=True)
+    seg = torch.zeros(u.numel() + 1, dtype=torch.int64, device=users.device)
+    seg[1:] = torch.cumsum(counts, 0)
+    c = H.auc_counts(scores[order].float().contiguous(), labels[order].to(torch.int8).contiguous(), seg).cpu().numpy().astype(np.float64)
+    n = counts.cpu().numpy().astype(np.float64)
+    ok = (c[:, 1] > 0) & (c[:, 2] > 0)
+    auc = c[ok, 0] / (2.0 * c[ok, 1] * c[ok, 2])
+    return float((n[ok] * auc).sum() / n[ok].sum())
 
 
 def auc_rank_sum(labels, scores):
@@ -137,10 +197,25 @@ def main_eval_batch(args, interests, ground_truths, pred_labels, results_list, t
         survival_probs = interests
     else:
         survival_probs = torch.exp(torch.cumsum(torch.log(interests), dim=1))
-    view_lengths = (ground_truths == 1).sum(dim=1, keepdim=True).cpu().numpy()
+    on_device = interests.is_cuda and ground_truths.is_cuda
     if "ProbAUC" in results_list:
-        results_list["ProbAUC"].append(float(ProbAUC_batch(survival_probs, ground_truths, mask_batch)))
-    if "TOP_K" in results_list:
+        if on_device:
+            results_list["ProbAUC"].append(float(ProbAUC_batch_device(interests, ground_truths,
+                                                                      survival=interests if test_type == "old" else None)))
+        else:
+            results_list["ProbAUC"].append(float(ProbAUC_batch(survival_probs, ground_truths, mask_batch)))
+    if "TOP_K" in results_list and on_device:
+        out = TOP_K_leave_device(interests, ground_truths, permutation=args.TOP_K_permutation, masked=bool(args.TOP_K_mask),
+                                 test=1 if ("TOP1MSE" in results_list and not args.TOP_K_mask) else 0)
+        if isinstance(out, tuple):
+            evaluations, top1 = out
+            results_list["TOP1MSE"].append(top1)
+        else:
+            evaluations = out
+        for k, v in evaluations.items():
+            results_list.setdefault(k, []).append(float(v))
+    elif "TOP_K" in results_list:
+        view_lengths = (ground_truths == 1).sum(dim=1, keepdim=True).cpu().numpy()
         x = interests.cpu().detach().numpy()
         mb = mask_batch.cpu().detach().numpy()
         if args.TOP_K_mask:

@@ -209,8 +209,13 @@ class Trainer:
     the reference's hot loop (main_for_seq_leave_earlystop_SegMM.py:269-300) minus its host syncs.
     Gradient clipping is a no-op in the reference (exhausted generator at :298) and is therefore absent."""
 
-    def __init__(self, model, lr=1e-3, weight_decay=1e-4, comm: Optional[DPComm] = None, overlap=True, dropout=True):
+    def __init__(self, model, lr=1e-3, weight_decay=1e-4, comm: Optional[DPComm] = None, overlap=True, dropout=True,
+                 feature_table=None):
         self.model = model
+        # SURVEY.md §8(f)-1: with a device-resident feature table the batch carries INDEX lists ("photo_idx" [B, S],
+        # "user_idx" [B, Lt], -1 = padding) instead of feature tensors; gather + pad + mask + L1 normalisation is one
+        # HBM-bound kernel (segmm_gather_l1) and the 573 KB/row host->device copy disappears
+        self.feature_table = feature_table
         self.dropout = dropout      # False: run the step in eval mode (deterministic; used by the DP equivalence tests)
         self.opt = FusedAdamW(model, lr=lr, weight_decay=weight_decay)
         self.comm = comm if comm is not None else DPComm()
@@ -237,15 +242,31 @@ class Trainer:
         H.l1norm(x, buf)
         return buf
 
+    def _features(self, batch):
+        """(usr, usr_mask, vid, vid_mask): L1-normalised feature tensors of a batch, from the tensors it carries or --
+        index batches -- gathered from the resident table."""
+        it = self.model.input_type
+        usr = vid = None
+        um, vm = batch.get("user_mask"), batch.get("photo_mask")
+        if it["user"] != "id":
+            if "user_idx" in batch:
+                usr, um = self.feature_table.gather("user", batch["user_idx"])
+            else:
+                usr = self.normalize("user", batch["user"])
+        if it["photo"] != "id":
+            if "photo_idx" in batch:
+                vid, vm = self.feature_table.gather("photo", batch["photo_idx"])
+            else:
+                vid = self.normalize("photo", batch["photo"])
+        return usr, um, vid, vm
+
     def train_step(self, batch: Dict[str, torch.Tensor]):
         model, st = self.model, self.model._store
         model.train(self.dropout)
         self.opt.zero_grad()
-        it = model.input_type
-        usr = self.normalize("user", batch["user"]) if it["user"] != "id" else None
-        vid = self.normalize("photo", batch["photo"]) if it["photo"] != "id" else None
-        out = model(usr_image=usr, usr_id=batch["user_identity_id"], usr_mask=batch["user_mask"], vid_image=vid,
-                    vid_id=batch["photo_identity_id"], vid_mask=batch["photo_mask"], gt=batch["label"], mode="train")
+        usr, um, vid, vm = self._features(batch)
+        out = model(usr_image=usr, usr_id=batch["user_identity_id"], usr_mask=um, vid_image=vid,
+                    vid_id=batch["photo_identity_id"], vid_mask=vm, gt=batch["label"], mode="train")
         out["loss"].backward()
         if self.comm.world > 1:
             if not self.overlap:
@@ -258,11 +279,37 @@ class Trainer:
     def eval_step(self, batch, mode="inference"):
         model = self.model
         model.eval()
-        it = model.input_type
-        usr = self.normalize("user", batch["user"]) if it["user"] != "id" else None
-        vid = self.normalize("photo", batch["photo"]) if it["photo"] != "id" else None
-        return model(usr_image=usr, usr_id=batch["user_identity_id"], usr_mask=batch["user_mask"], vid_image=vid,
-                     vid_id=batch["photo_identity_id"], vid_mask=batch["photo_mask"], gt=batch["label"], mode=mode)
+        usr, um, vid, vm = self._features(batch)
+        return model(usr_image=usr, usr_id=batch["user_identity_id"], usr_mask=um, vid_image=vid,
+                     vid_id=batch["photo_identity_id"], vid_mask=vm, gt=batch["label"], mode=mode)
+
+
+    @torch.no_grad()
+    def valid_model(self, batches, metrics=("valid_loss", "HR@1", "HR@3", "HR@5", "HR@10", "NDCG@1", "NDCG@3", "NDCG@5", "NDCG@10"),
+                    permutation=1, top_k_mask=False):
+        """``valid_model`` of the reference trainer (main_for_seq_leave_earlystop_SegMM.py:132-186): eval-mode forward
+        with ``mode="train"`` (loss + logits), interests = sigmoid(logits) * exposure_prob, leave-rank metrics per batch,
+        mean over batches.  The ranks are computed on the device (csrc/evalops.h); only B integers per batch reach the
+        host instead of the [B, S] interests, labels and masks."""
+        from .my_evaluation import TOP_K_leave_device
+        model = self.model
+        exposure = None
+        acc = {k: [] for k in metrics}
+        for batch in batches:
+            out = self.eval_step(batch, mode="train")
+            logits, gt = out["logits"], out["gt"]
+            if exposure is None:
+                exposure = torch.tensor(model.exposure_prob, dtype=torch.float32, device=logits.device)[: logits.shape[1]]
+            interests = torch.sigmoid(logits) * exposure
+            ev = TOP_K_leave_device(interests, gt, permutation=permutation, masked=top_k_mask)
+            for k in acc:
+                if k == "valid_loss":
+                    acc[k].append(float(out["loss"]))
+                elif k in out and k not in ("gt", "logits"):
+                    acc[k].append(float(out[k]))
+                elif k in ev:
+                    acc[k].append(float(ev[k]))
+        return {k: (sum(v) / len(v) if v else float("nan")) for k, v in acc.items()}
 
 
 class CheckPointer:

@@ -1,0 +1,206 @@
+"""SURVEY.md §8(f) rows on the MI355X: on-device evaluation (integer ranks / AUC pair counts, bit-exact against the
+numpy oracle), resident-table feature gather, SegRec weighted head."""
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+
+def _abi():
+    from segmminterest_amd import hipabi
+    hipabi.lib()
+    return hipabi
+
+
+def _labels(B, S, seed):
+    from segmminterest_amd.synth import make_labels
+    return make_labels(B, S, torch.Generator().manual_seed(seed))[0]
+
+
+@pytest.mark.parametrize("B,S", [(64, 40), (513, 40), (37, 20), (5, 100)])
+@pytest.mark.parametrize("masked", [False, True])
+@pytest.mark.parametrize("permutation", [0, 1])
+def test_rank_leave_bit_exact_vs_oracle(B, S, masked, permutation):
+    """Integer ranks of the leave segment: device kernel == numpy oracle (oracle/segmm_oracle.py::top_k_leave restates
+    my_evaluation.py:137-231), including ties (quantised interests), padded rows and shuffled candidates."""
+    H = _abi()
+    from oracle import segmm_oracle as O
+    from segmminterest_amd import my_evaluation as E
+    gt = _labels(B, S, seed=B + S)
+    g = torch.Generator().manual_seed(B * 7 + S)
+    x = (torch.rand(B, S, generator=g) * 8).round() / 8 * 0.9 + 0.05          # many exact ties
+    vl = (gt == 1).sum(1, keepdim=True).numpy()
+    mb = (gt != -2).numpy()
+    np.random.seed(123)
+    want = O.top_k_leave(x.numpy(), vl, mb, permutation=permutation, S=S, masked=masked)
+    np.random.seed(123)
+    got = E.TOP_K_leave_device(x.to(DEV), gt.to(DEV), permutation=permutation, masked=masked)
+    assert set(got) == set(want)
+    for k in want:
+        assert float(got[k]) == float(want[k]), (k, got[k], want[k])
+    # raw ranks, no permutation: every row against a direct count
+    ranks, hist = H.rank_leave(x.to(DEV), gt.to(DEV), masked=masked)
+    r = ranks.cpu().numpy()
+    xs = np.where(mb, x.numpy(), 1.1) if masked else x.numpy()
+    v = vl.reshape(-1)
+    valid = (v != mb.sum(1)) if masked else (v < S)
+    for b in range(B):
+        if not valid[b]:
+            assert r[b] == 0
+            continue
+        t = v[b]
+        want_r = 1 + int(((xs[b] < xs[b, t]) | ((xs[b] == xs[b, t]) & (np.arange(S) < t))).sum())
+        assert r[b] == want_r
+    assert hist.cpu().numpy().sum() == B and hist[0].item() == int((~valid).sum())
+
+
+def test_auc_counts_and_probauc():
+    H = _abi()
+    from oracle import segmm_oracle as O
+    from segmminterest_amd import my_evaluation as E
+    B, S = 300, 40
+    gt = _labels(B, S, seed=9)
+    g = torch.Generator().manual_seed(4)
+    interests = (torch.rand(B, S, generator=g) * 0.98 + 0.01)
+    interests[:, ::7] = 0.5                                                  # ties
+    surv, label = H.survival(interests.to(DEV), gt.to(DEV))
+    ref_surv = torch.exp(torch.cumsum(torch.log(interests), 1))
+    assert torch.allclose(surv.cpu(), ref_surv, rtol=1e-4, atol=1e-30)     # exp(h) with |h| up to ~40: a 1-ulp change of h is 4e-6 relative
+    lab = label.cpu().numpy().reshape(-1)
+    assert ((lab == -1) == (gt.numpy().reshape(-1) == -2)).all() and ((lab == 1) == (gt.numpy().reshape(-1) == 1)).all()
+    # integer pair counts against a direct numpy count on the SAME survival values
+    s = surv.cpu().numpy().reshape(-1).astype(np.float64)
+    pos, neg = s[lab == 1], s[lab == 0]
+    seg = torch.tensor([0, B * S], dtype=torch.int64, device=DEV)
+    u2, npos, nneg = H.auc_counts(surv.view(-1), label.view(-1), seg)[0].tolist()
+    less = (neg[None, :] < pos[:, None]).sum()
+    eq = (neg[None, :] == pos[:, None]).sum()
+    assert (u2, npos, nneg) == (2 * int(less) + int(eq), len(pos), len(neg))
+    auc = u2 / (2.0 * npos * nneg)
+    m = lab >= 0
+    assert abs(auc - O.auc_rank_sum(lab[m] == 1, s[m])) < 1e-12            # = sklearn.roc_auc_score (midranks)
+    assert abs(E.ProbAUC_batch_device(interests.to(DEV), gt.to(DEV)) - auc) == 0.0
+
+
+def test_wuauc_device_matches_oracle():
+    from oracle import segmm_oracle as O
+    from segmminterest_amd import my_evaluation as E
+    _abi()
+    g = torch.Generator().manual_seed(11)
+    n = 5000
+    users = torch.randint(0, 300, (n,), generator=g)
+    labels = (torch.rand(n, generator=g) < 0.3).long()
+    labels[users == 7] = 1                                                   # a single-class user: skipped
+    scores = (torch.rand(n, generator=g) * 50).round() / 50                  # ties
+    want = O.wuauc(labels.numpy(), scores.numpy().astype(np.float64), users.numpy())
+    got = E.wuAUC_device(labels.to(DEV), scores.to(DEV), users.to(DEV))
+    assert abs(got - want) < 1e-12
+
+
+def test_gather_l1_matches_host_pipeline():
+    H = _abi()
+    g = torch.Generator().manual_seed(2)
+    n_lines, D, B, S, Lt = 1000, 768, 33, 40, 100
+    table = torch.rand(n_lines, D, generator=g)
+    idx_v = torch.randint(0, n_lines, (B, S), generator=g)
+    idx_u = torch.randint(0, n_lines, (B, Lt), generator=g)
+    dur = torch.randint(2, S + 1, (B,), generator=g)
+    idx_v[torch.arange(S)[None, :] >= dur[:, None]] = -1                     # collator padding
+    idx_u[:, 60:] = -1
+    idx_u[0, 3] = n_lines + 5                                                # out of range = padding, never read
+    out, mask = H.gather_l1(table.to(DEV), idx_v.to(DEV))
+    ref = table[idx_v.clamp(0, n_lines - 1)]
+    ref = ref / (ref.abs().sum(-1, keepdim=True) + 1e-6)
+    ok = (idx_v >= 0) & (idx_v < n_lines)
+    ref[~ok] = 0
+    assert torch.equal(mask.cpu(), ok)
+    assert torch.allclose(out.cpu(), ref, rtol=2e-6, atol=0)
+    out_u, mask_u = H.gather_l1(table.to(DEV), idx_u.to(DEV), normalize=False)
+    oku = (idx_u >= 0) & (idx_u < n_lines)
+    refu = table[idx_u.clamp(0, n_lines - 1)]
+    refu[~oku] = 0
+    assert torch.equal(out_u.cpu(), refu) and torch.equal(mask_u.cpu(), oku)
+
+
+def test_index_batches_train_like_feature_batches():
+    """A Trainer fed with index batches + a resident table takes the same step as one fed with the gathered,
+    host-padded feature tensors (the reference's DataCollator contract)."""
+    _abi()
+    from segmminterest_amd.feature_store import ResidentFeatureTable
+    from segmminterest_amd.synth import make_batch
+    from segmminterest_amd.trainer import Trainer, default_args, init_model
+    B, S, Lt, D, N = 16, 40, 10, 64, 2
+    g = torch.Generator().manual_seed(5)
+    table = torch.rand(500, D, generator=g)
+    base = make_batch(B, S, Lt, D, seed=77)
+    idx_v = torch.randint(0, 500, (B, S), generator=g)
+    idx_v[~base["photo_mask"]] = -1
+    idx_u = torch.randint(0, 500, (B, Lt), generator=g)
+    idx_u[~base["user_mask"]] = -1
+    feat = dict(base)
+    feat["photo"] = torch.where((idx_v >= 0)[..., None], table[idx_v.clamp(0)], torch.zeros(()))
+    feat["user"] = torch.where((idx_u >= 0)[..., None], table[idx_u.clamp(0)], torch.zeros(()))
+    idxb = {k: v for k, v in base.items() if k not in ("photo", "user", "photo_mask", "user_mask")}
+    idxb["photo_idx"], idxb["user_idx"] = idx_v, idx_u
+    margs = default_args(num_layers_enc=N, d_model=D, nhead=4, input_type={"user": "image", "photo": "image"}, exposure_prob=[1.0] * S)
+    outs = []
+    for batch, ft in ((feat, None), (idxb, table)):
+        torch.manual_seed(1)
+        model = init_model(margs, n_users=1, n_items=1, input_dim=D, max_vid_len=S, max_usr_len=Lt).to(DEV)
+        tr = Trainer(model, dropout=False, feature_table=None if ft is None else ResidentFeatureTable(ft.to(DEV)))
+        o = tr.train_step({k: v.to(DEV) for k, v in batch.items()})
+        outs.append((float(o["loss"]), o["logits"].detach().cpu(), model._store.flat.detach().cpu().clone()))
+    assert abs(outs[0][0] - outs[1][0]) < 1e-6
+    assert torch.allclose(outs[0][1], outs[1][1], atol=1e-5)
+    assert torch.allclose(outs[0][2], outs[1][2], atol=1e-5)
+
+
+def test_segment_weighted_sum_matches_cliprec():
+    H = _abi()
+    g = torch.Generator().manual_seed(8)
+    Bn, I, S = 31, 7, 40
+    pred = torch.randn(Bn, I, S, generator=g)
+    w = torch.rand(Bn, I, S, generator=g)
+    dur = torch.randint(0, S + 1, (Bn, I), generator=g)
+    mask = (torch.arange(S)[None, None, :] < dur[..., None]).float()          # ClipRec.py:171-173
+    ref = (pred * w * mask).sum(-1)                                           # ClipRec.py:178-180
+    got = H.segment_weighted_sum(pred.to(DEV), w.to(DEV), dur.to(DEV))
+    assert torch.allclose(got.cpu(), ref, atol=2e-5)
+    got1 = H.segment_weighted_sum(pred.to(DEV))
+    assert torch.allclose(got1.cpu(), pred.sum(-1), atol=2e-5)
+
+
+def test_valid_model_matches_host_metrics():
+    """Trainer.valid_model (device ranks) == the reference's host loop over the same batches."""
+    _abi()
+    from segmminterest_amd import my_evaluation as E
+    from segmminterest_amd.synth import make_batch
+    from segmminterest_amd.trainer import Trainer, default_args, init_model
+    B, S, Lt, D, N = 48, 40, 10, 64, 2
+    margs = default_args(num_layers_enc=N, d_model=D, nhead=4, input_type={"user": "image", "photo": "image"}, exposure_prob=[0.9] * S)
+    torch.manual_seed(3)
+    model = init_model(margs, n_users=1, n_items=1, input_dim=D, max_vid_len=S, max_usr_len=Lt).to(DEV)
+    tr = Trainer(model)
+    batches = [{k: v.to(DEV) for k, v in make_batch(B, S, Lt, D, seed=100 + i).items()} for i in range(3)]
+    np.random.seed(7)
+    got = tr.valid_model(batches, permutation=1)
+    np.random.seed(7)
+    acc = {}
+    for b in batches:
+        out = tr.eval_step(b, mode="train")
+        interests = torch.sigmoid(out["logits"]) * torch.tensor(model.exposure_prob, device=DEV)
+        gt = out["gt"]
+        ev = E.TOP_K_leave(interests.cpu().numpy(), (gt == 1).sum(1, keepdim=True).cpu().numpy(), (gt != -2).cpu().numpy(), permutation=1)
+        for k, v in ev.items():
+            acc.setdefault(k, []).append(float(v))
+        acc.setdefault("valid_loss", []).append(float(out["loss"]))
+    for k, v in acc.items():
+        assert got[k] == sum(v) / len(v), k
