@@ -245,10 +245,13 @@ def _empty(ref, *shape, dtype=torch.float32):
     return torch.empty(shape, dtype=dtype, device=ref.device)
 
 
+_SPLIT_TARGET = int(os.environ.get("SEGMM_SPLIT_TARGET", "1024"))     # workgroups a split-K weight gradient aims for
+
+
 def _splits_for(M, N, K):
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     ktiles = (K + 31) // 32
-    return max(1, min(32, ktiles, (1024 + tiles - 1) // tiles))
+    return max(1, min(32, ktiles, (_SPLIT_TARGET + tiles - 1) // tiles))
 
 
 @contextlib.contextmanager
@@ -635,8 +638,11 @@ _STEP_SEED = [0x5E6D0001]
 
 def next_seed() -> int:
     """A fresh dropout seed per training forward, drawn from torch's CPU generator so that
-    ``torch.manual_seed`` makes train-mode runs reproducible."""
-    return int(torch.randint(0, 2 ** 62, (1,)).item())
+    ``torch.manual_seed`` makes train-mode runs reproducible.  Data-parallel ranks seed torch identically (identical
+    replicas), so the rank is mixed in: every rank drops different elements of its own rows."""
+    s = int(torch.randint(0, 2 ** 62, (1,)).item())
+    rank = int(os.environ.get("RANK", "0"))
+    return (s ^ (rank * 0x9E3779B97F4A7C15)) & (2 ** 62 - 1) if rank else s
 
 
 class BackboneFn(torch.autograd.Function):
