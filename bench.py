@@ -172,9 +172,9 @@ def main():
     achieved = flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     engine = {hipabi.ENGINE_F32: "f32", hipabi.ENGINE_BF16X6: "bf16x6", hipabi.ENGINE_F16X3: "f16x3"}[hipabi.GEMM_ENGINE]
     if engine == "bf16x6":      # 6 bf16 partial products per algorithmic product
-        peak, kname = PEAK_BF16_MFMA_TFLOPS / 6.0, "gemm_bf16x6_mfma (6 x v_mfma_f32_32x32x16_bf16 per product, exact 3-way bf16 split; NT/NN/TN incl. split-K combine)"
+        peak, kname = PEAK_BF16_MFMA_TFLOPS / 6.0, "gemm_split_mfma (6 x v_mfma_f32_32x32x16_bf16 per product, exact 3-way bf16 split; NT/NN/TN incl. split-K combine)"
     elif engine == "f16x3":     # 3 fp16 partial products per algorithmic product (fp16 MFMA = the bf16 rate)
-        peak, kname = PEAK_BF16_MFMA_TFLOPS / 3.0, "gemm_bf16x6_mfma<F16> (3 x v_mfma_f32_32x32x16_f16 per product, scaled 2-term fp16 split = 22-bit operands; NT/NN/TN incl. split-K combine)"
+        peak, kname = PEAK_BF16_MFMA_TFLOPS / 3.0, "gemm_split_mfma<F16> (3 x v_mfma_f32_32x32x16_f16 per product, scaled 2-term fp16 split = 22-bit operands; NT/NN/TN incl. split-K combine)"
     else:
         peak, kname = PEAK_F32_MFMA_TFLOPS, "gemm_f32_mfma (v_mfma_f32_32x32x2_f32; NT/NN/TN launches incl. split-K combine)"
     rows_per_s = world * B * args.steps / elapsed

@@ -9,7 +9,7 @@
 #include "common.h"
 #include "evalops.h"
 #include "gemm.h"
-#include "gemm_bf16x6.h"
+#include "gemm_split.h"
 #include "loss.h"
 #include "rowops.h"
 
@@ -213,8 +213,8 @@ static int gemm_impl(int layout, int M, int N, int K, const float* A, int lda, c
         q.Ap = (const __bf16*)a_planes; q.a_pstride = a_pstride;
         q.Bp = (const __bf16*)b_planes; q.b_pstride = b_pstride;
         q.a_amax = a_amax; q.a_namax = a_namax; q.b_amax = b_amax; q.b_namax = b_namax;
-#define X6(AK, BK, AP, BP, NP) hipLaunchKernelGGL((gemm_bf16x6_mfma<AK, BK, AP, BP, NP>), grid, block, 0, s, g, q)
-#define H3(AK, BK, AP, BP) hipLaunchKernelGGL((gemm_bf16x6_mfma<AK, BK, AP, BP, 2, true>), grid, block, 0, s, g, q)
+#define X6(AK, BK, AP, BP, NP) hipLaunchKernelGGL((gemm_split_mfma<AK, BK, AP, BP, NP>), grid, block, 0, s, g, q)
+#define H3(AK, BK, AP, BP) hipLaunchKernelGGL((gemm_split_mfma<AK, BK, AP, BP, 2, true>), grid, block, 0, s, g, q)
         if (engine == 2) {
             if (layout == 0) {
                 if (a_planes && b_planes) H3(true, true, true, true);

@@ -1,34 +1,30 @@
-// fp32-accurate GEMM on the bf16 matrix cores: every fp32 operand is split EXACTLY into three bf16
-// terms (x = hi + mid + lo, 8 + 8 + 8 mantissa bits) and the product is formed from the six largest
-// partial products, accumulated in fp32 by v_mfma_f32_32x32x16_bf16:
+// fp32-accurate GEMM on the 16-bit matrix cores: the fp32 operands are split into a few 16-bit terms, the largest
+// partial products run on v_mfma_f32_32x32x16_{f16,bf16} (16-bit x 16-bit products are EXACT in fp32) and are
+// accumulated in fp32.  One kernel template, two engines:
 //
-//     a.b ~= ah.bh + (ah.bm + am.bh) + (ah.bl + al.bh + am.bm)        dropped terms <= 2^-24 |a||b|
+//  F16 = true, NPL = 2  -- the fp16x3 engine (default of the host facade):
+//     x*s = hi + lo with two fp16 terms (11 + 11 mantissa bits, residual <= 2^-22 |x|), s a per-tensor power of two
+//     that puts max|x| in [2^14, 2^15) so that neither term leaves the fp16 range (elements more than 2^18 below the
+//     maximum keep an ABSOLUTE error of 2^-40 max: fp16 subnormals); three products  hh + hl + lh ; the result is
+//     scaled back by the exact 1/(sa sb) in the epilogue.  Per-product error <= 3 * 2^-22, the order of ONE fp32
+//     accumulation rounding; measured error vs fp64 at or below the f32-MFMA GEMM's on every layout
+//     (tests/test_ops_gpu.py::test_gemm_f16x3_*).  96 matrix-pipe cycles per 32 x 32 x 16 block against 512 for the
+//     fp32 MFMA.  max|x| arrives as an array of partial maxima written by the operand's producer (or segmm_absmax):
+//     no host sync, no float atomics; every workgroup reduces the (<= 1024) partials itself.
+//  F16 = false, NPL = 3 -- the bf16x6 engine: x = hi + mid + lo EXACTLY in three bf16 terms (8 + 8 + 8 bits, bf16 has
+//     the fp32 exponent range: no scaling), six products  hh + (hm + mh) + (hl + lh + mm), dropped terms <= 2^-24;
+//     192 cycles per block.  NPL = 2 with bf16 (hh + hm + mh, ~2e-5) is an opt-in for weight gradients only.
 //
-// bf16 x bf16 products are exact in fp32, so the only errors are the dropped 2^-24 terms and the fp32
-// accumulation itself: measured error vs fp64 is BELOW that of the f32-MFMA GEMM on every layout
-// (tests/test_ops_gpu.py::test_gemm_bf16x6_*).  Cost: 6 bf16 MFMAs (32 cycles each, K = 16) replace 8 f32
-// MFMAs (64 cycles each, K = 2): 192 vs 512 matrix-pipe cycles per 32 x 32 x 16 block = 2.67x the fp32-MFMA
-// roofline (SURVEY.md §7 "hard parts": split-bf16, decided by measurement).
+// Operands arrive either as fp32 (split ON THE FLY between the register prefetch and the LDS store: four
+// v_fma_mix per element pair for fp16, see splith_pair) or PRE-SPLIT as 16-bit planes [NPL][rows][ld] written once by
+// segmm_split* (weights: one split pass per optimizer step, W and W^T) -- then the main loop has no VALU work for
+// that operand at all.
 //
-// Operands arrive either as fp32 (split ON THE FLY while a k-tile moves registers -> LDS, 6 VALU ops per
-// element) or PRE-SPLIT as bf16 planes [NPL][rows][ld] written once by their producer (weights: one split
-// pass per optimizer step) -- then the main loop has no VALU work for that operand at all.
-// NPL = 3 gives the six-product form above; NPL = 2 (hi, mid only; products hh + hm + mh, error ~2e-5) is
-// offered for weight gradients, which are leaves of the backward graph (nothing propagates their error).
-//
-// Tile 128 x 128 x 32, 256 threads (2 x 2 waves, 64 x 64 each), 2 workgroups per CU.  LDS: per operand NPL
-// planes [128 rows][32 k] of bf16 with an 80-byte row stride (conflict-free ds_read_b128 of the 8-element
-// MFMA fragments).  fp32 operands whose k index is NOT contiguous in memory (B of NN, A and B of TN) are
-// transposed in registers: a thread owns a 4(k) x 4(m) micro-block and writes 4-element k runs.
-//
-// F16 = true selects the fp16x3 engine: x*s = hi + lo with two fp16 terms (11 + 11 mantissa bits, residual
-// <= 2^-22 |x|), s a per-tensor power of two that puts max|x| in [2^14, 2^15) so neither term leaves the fp16
-// range (elements below 2^-18 max keep an absolute error of 2^-40 max), three products hh + hl + lh on
-// v_mfma_f32_32x32x16_f16 (fp16 x fp16 is exact in fp32), result scaled back by 1/(sa sb) in the epilogue.
-// Per-product error <= 3 * 2^-22: the same order as the fp32 accumulation error of either other engine
-// (measured vs fp64 in tests/test_ops_gpu.py).  Half the matrix-pipe work and 2/3 of the LDS traffic of bf16x6.
-// max|x| comes as an array of partial maxima written by the operand's producer (or segmm_absmax): no host
-// sync, no atomics; every workgroup reduces the (<= 1024) partials itself.
+// Tile 128 x 128 x 32, 256 threads (2 x 2 waves, 64 x 64 each), 3 workgroups per CU for NPL = 2 (166 VGPR, 40 KB
+// LDS).  LDS: per operand NPL planes [128 rows][32 k] of 16-bit values with an 80-byte row stride (conflict-free
+// ds_read_b128 of the 8-element MFMA fragments).  fp32 operands whose k index is NOT contiguous in memory (B of NN,
+// A and B of TN) are transposed in registers: a thread owns a 4(k) x 4(m) micro-block and writes 4-element k runs.
+// Global -> register staging uses buffer loads (see the main loop); measurements in profiles/README.md.
 #pragma once
 #include <type_traits>
 
@@ -118,7 +114,7 @@ __device__ __forceinline__ f32x16 mfma_x(f32x4 a, f32x4 b, f32x16 c) {
 }
 
 template <bool A_KC, bool B_KC, bool A_PRE, bool B_PRE, int NPL, bool F16 = false>
-__global__ __launch_bounds__(256, 2) void gemm_bf16x6_mfma(const GemmArgs p, const GemmPlanes q) {
+__global__ __launch_bounds__(256, 2) void gemm_split_mfma(const GemmArgs p, const GemmPlanes q) {
     static_assert(!A_PRE || A_KC, "pre-split operands are k-contiguous");
     static_assert(!B_PRE || B_KC, "pre-split operands are k-contiguous");
     static_assert(!F16 || NPL == 2, "the fp16 engine has two planes per operand");
