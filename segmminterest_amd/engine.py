@@ -96,6 +96,7 @@ class ParamStore:
         self._side_stream = None
         self._on_side = False
         self.overlap = os.environ.get("SEGMM_OVERLAP", "1") != "0"
+        self.defer_wgrad = os.environ.get("SEGMM_DEFER_WGRAD", "0") != "0"     # measured: no gain (kept as a knob)
         # pre-split bf16 planes of the weights for the bf16x6 GEMM engine: W planes (forward) and W^T planes (dgrad
         # in the NT form), refreshed when the parameters change (one split pass per optimizer step)
         # (fp16x3 engine: two fp16 planes scaled by one power of two derived from ``wamax``, the partial maxima of
@@ -112,7 +113,9 @@ class ParamStore:
     # -- second HIP stream for weight/bias gradients (see class SideWork)
     def side_stream(self):
         if self._side_stream is None or self._side_stream.device != self.flat.device:
-            self._side_stream = torch.cuda.Stream(device=self.flat.device)
+            # LOWEST priority: the side stream's weight-gradient GEMMs fill idle CUs, they must not starve the main
+            # stream's kernels (a 49 us LayerNorm backward was seen taking 470 us next to a same-priority GEMM)
+            self._side_stream = torch.cuda.Stream(device=self.flat.device, priority=int(os.environ.get("SEGMM_SIDE_PRIORITY", "1")))
         return self._side_stream
 
     # -- layout
@@ -275,6 +278,25 @@ def side_work(store):
             yield
     finally:
         store._on_side = False
+
+
+def side_or_defer(store, fn, deferred):
+    """Run ``fn`` (weight/bias-gradient launches) on the side stream now, or park it in ``deferred`` to be flushed later
+    with ``flush_deferred`` -- used to move GEMM work next to the latency-bound attention backward instead of next to
+    other GEMMs (two MFMA-bound kernels side by side gain nothing, a GEMM next to the attention kernels is free)."""
+    if deferred is not None and store.overlap:
+        deferred.append(fn)
+        return
+    with side_work(store):
+        fn()
+
+
+def flush_deferred(store, deferred):
+    if deferred:
+        with side_work(store):
+            for fn in deferred:
+                fn()
+        deferred.clear()
 
 
 def join_side(store):
@@ -488,7 +510,7 @@ class BackboneRun:
         return X2v, (X2u if full else Xu), am_X2v, (am_X2u if full else am_Xu)
 
     # ---------------------------------------------------------------- backward
-    def _side_post_bwd(self, i, L, side, sv, dX2, M, kinds, gbuf, tag):
+    def _side_post_bwd(self, i, L, side, sv, dX2, M, kinds, gbuf, tag, deferred=None):
         """Reverse of _side_post.  Returns (dR1, dA): gradient wrt the residual input X and wrt the attention output."""
         st, d, seed, am = self.store, self.d, self.seed, self.amb
         k_ao, k_mi, k_mo = kinds
@@ -501,14 +523,15 @@ class BackboneRun:
                 drop_b=(self.p_drop, _site(self.bi, i, k_mo)), seed=seed, amax=am_dM, dsum_to=st.g(ff + "1.bias", gbuf))
         if dM is None:
             dM = dR2
-        with side_work(st):
-            _wgrad(st, dM, d, 0, sv["Hh"], d, 0, M, d, d, st.g(ff + "1.weight", gbuf), a_amax=am_dM, b_amax=sv["am_Hh"])
+        side_or_defer(st, lambda: _wgrad(st, dM, d, 0, sv["Hh"], d, 0, M, d, d, st.g(ff + "1.weight", gbuf), a_amax=am_dM,
+                                         b_amax=sv["am_Hh"]), deferred)
         dG = st.buf("dG" + tag, (M, d))
         _lin_dgrad(st, M, d, d, dM, ff + "1.weight", dG, activation=H.ACT_DGELU, aux=sv["G"], ldaux=d, a_amax=am_dM, c_amax=am_dG,
                drop_p=self.p_inner, seed=seed, site=_site(self.bi, i, k_mi))
-        with side_work(st):
+        def _w0():
             _wgrad(st, dG, d, 0, sv["X1"], d, 0, M, d, d, st.g(ff + "0.weight", gbuf), a_amax=am_dG, b_amax=sv["am_X1"])
             _colsum(st, dG, d, M, d, st.g(ff + "0.bias", gbuf))
+        side_or_defer(st, _w0, deferred)
         dX1 = st.buf("dX1" + tag, (M, d))
         _lin_dgrad(st, M, d, d, dG, ff + "0.weight", dX1, residual=dR2, ldr=d, res_period=M, a_amax=am_dG)
         dR1 = st.buf("dR1" + tag, (M, d))
@@ -518,8 +541,8 @@ class BackboneRun:
                 dsum_to=st.g(ca + "ff_%s.bias" % side, gbuf))
         if dZ is None:
             dZ = dR1
-        with side_work(st):
-            _wgrad(st, dZ, d, 0, sv["A"], d, 0, M, d, d, st.g(ca + "ff_%s.weight" % side, gbuf), a_amax=am_dZ, b_amax=sv["am_A"])
+        side_or_defer(st, lambda: _wgrad(st, dZ, d, 0, sv["A"], d, 0, M, d, d, st.g(ca + "ff_%s.weight" % side, gbuf),
+                                         a_amax=am_dZ, b_amax=sv["am_A"]), deferred)
         dA = st.buf("dA" + tag, (M, d))
         _lin_dgrad(st, M, d, d, dZ, ca + "ff_%s.weight" % side, dA, a_amax=am_dZ)
         return dR1, dA
@@ -535,14 +558,17 @@ class BackboneRun:
         dYv, dYu = st.buf("dYv%d" % i, (Mv, nv * d)), st.buf("dYu%d" % i, (Mu, nu * d))
         Dv = st.buf("attnD", (B * Hh * max(S, Lt),))
         am_dYv, am_dYu = self.amb.new(), self.amb.new()      # one per fused dY buffer: both attentions fold into them
-        dR1v, dAv = self._side_post_bwd(i, L, "vid", rec["v"], dXv_out, Mv, (K_AO_V, K_MI_V, K_MO_V), gbuf, "v%d" % i)
+        deferred = [] if st.defer_wgrad else None
+        dR1v, dAv = self._side_post_bwd(i, L, "vid", rec["v"], dXv_out, Mv, (K_AO_V, K_MI_V, K_MO_V), gbuf, "v%d" % i, deferred)
+        flush_deferred(st, deferred)          # the three weight-gradient GEMMs of this side run under the attention backward
         H.attn_bwd(B, Hh, dh, S, S, Lt, (Yv, 0), (Yv, d), nv * d, (Yv, 2 * d), (Yv, 3 * d), nv * d, (Yu, 0), (Yu, d), nu * d,
                    self.vm, self.vm, self.um, rec["lse_v"], rec["v"]["A"], d, dAv, d, Dv, (dYv, 0), (dYv, d), nv * d, (dYv, 2 * d), (dYv, 3 * d),
                    nv * d, (dYu, 0), (dYu, d), nu * d, drop_p=self.p_drop, seed=self.seed, site=_site(self.bi, i, K_ATT_V),
                    amax_q=am_dYv, amax_ka=am_dYv, amax_kb=am_dYu)
         dR1u = None
         if full:
-            dR1u, dAu = self._side_post_bwd(i, L, "usr", rec["u"], dXu_out, Mu, (K_AO_U, K_MI_U, K_MO_U), gbuf, "u%d" % i)
+            dR1u, dAu = self._side_post_bwd(i, L, "usr", rec["u"], dXu_out, Mu, (K_AO_U, K_MI_U, K_MO_U), gbuf, "u%d" % i, deferred)
+            flush_deferred(st, deferred)
             H.attn_bwd(B, Hh, dh, Lt, S, Lt, (Yu, 2 * d), (Yu, 3 * d), nu * d, (Yv, 4 * d), (Yv, 5 * d), nv * d,
                        (Yu, 4 * d), (Yu, 5 * d), nu * d, self.um, self.vm, self.um, rec["lse_u"], rec["u"]["A"], d, dAu, d, Dv,
                        (dYu, 2 * d), (dYu, 3 * d), nu * d, (dYv, 4 * d), (dYv, 5 * d), nv * d, (dYu, 4 * d), (dYu, 5 * d), nu * d,
