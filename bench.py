@@ -147,6 +147,7 @@ def main():
     # step (measured: 6.79 ms/step with them, 6.48 without) -- `value` is the un-instrumented rate.
     psteps = min(args.steps, 10)
     hipabi.GEMM_PROFILE = prof = []
+    hipabi.ATTN_PROFILE = aprof = []
     barrier()
     tp0 = time.perf_counter()
     for _ in range(psteps):
@@ -154,6 +155,12 @@ def main():
     barrier()
     prof_elapsed = time.perf_counter() - tp0
     hipabi.GEMM_PROFILE = None
+    hipabi.ATTN_PROFILE = None
+    # the segment attention (QK^T / AV) on its own: algorithmic FLOPs (unpadded: 4 dh Lq T forward, 14 dh Lq T backward
+    # per (b, head)) over the HIP-event time of its launches, against the fp32 MFMA peak its v_mfma_f32_16x16x4_f32 has
+    att_ms = sum(e0.elapsed_time(e1) for (*_, e0, e1) in aprof)
+    att_flops = sum((4.0 if k == "fwd" else 14.0) * dh_ * Lq_ * (La_ + Lb_) * B_ * H_ for (k, B_, H_, dh_, Lq_, La_, Lb_, _, _) in aprof)
+    att_tf = att_flops / (att_ms * 1e-3) / 1e12 if att_ms > 0 else 0.0
 
     # Dominant kernel = the GEMM.  Weight-gradient GEMMs run on a second stream concurrently with the
     # input-gradient GEMMs, so per-launch durations overlap: time = length of the UNION of the launch intervals
@@ -203,6 +210,11 @@ def main():
                          "note": "achieved = algorithmic 2MNK of every GEMM launch of the instrumented pass (same steps, run right after the timed region) / union of their HIP-event intervals; "
                                  "peak = dense MFMA peak of the instruction used" + {"bf16x6": " / 6 partial products", "f16x3": " / 3 partial products", "f32": ""}[engine]},
         }
+        rec["roofline_attention"] = {"bound": "mfma", "kernel": "attn_fwd + attn_bwd_dq + attn_bwd_dkv (v_mfma_f32_16x16x4_f32, exact fp32)",
+                                     "achieved": round(att_tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                     "frac": round(att_tf / PEAK_F32_MFMA_TFLOPS, 4), "ms_per_step": round(att_ms / psteps, 4),
+                                     "note": "unpadded algorithmic FLOPs; the kernels pad 40 queries to 48 and 140 keys to 160, rocprof "
+                                             "SQ_VALU_MFMA_BUSY_CYCLES gives 39 % / 37 % / 23 % matrix-pipe occupancy (profiles/README.md)"}
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(args, S, D, Lt, N, h)
         print(json.dumps(rec), flush=True)

@@ -96,7 +96,8 @@ class ParamStore:
         self._side_stream = None
         self._on_side = False
         self.overlap = os.environ.get("SEGMM_OVERLAP", "1") != "0"
-        self.defer_wgrad = os.environ.get("SEGMM_DEFER_WGRAD", "0") != "0"     # measured: no gain (kept as a knob)
+        self.defer_wgrad = os.environ.get("SEGMM_DEFER_WGRAD", "0") != "0"
+        self.tail_balance = os.environ.get("SEGMM_TAIL_BALANCE", "1") != "0"     # measured: no gain (kept as a knob)
         # pre-split bf16 planes of the weights for the bf16x6 GEMM engine: W planes (forward) and W^T planes (dgrad
         # in the NT form), refreshed when the parameters change (one split pass per optimizer step)
         # (fp16x3 engine: two fp16 planes scaled by one power of two derived from ``wamax``, the partial maxima of
@@ -109,6 +110,7 @@ class ParamStore:
         self.fused_version = 0
         self._planes_key = None
         self._transposes: List[Tuple[int, int, int]] = []
+        self._plane_ranges: List[Tuple[int, int]] = []
 
     # -- second HIP stream for weight/bias gradients (see class SideWork)
     def side_stream(self):
@@ -150,22 +152,28 @@ class ParamStore:
         if key == self._planes_key:
             return
         dev = self.flat.device
+        # only parameters that ARE GEMM operands are scanned / split (an id-mode item table of 90 M floats is neither)
+        ranges = self._plane_ranges
         if self.engine_h:
             if self.wamax is None or self.wamax.device != dev:
-                self.wamax = torch.empty((H.AMAX_PARTS,), dtype=torch.float32, device=dev)
-            H.absmax(self.flat, 1, self.n_live, self.n_live, out=self.wamax)
+                self.wamax = torch.zeros((H.AMAX_PARTS,), dtype=torch.float32, device=dev)
+            per = H.AMAX_PARTS // max(len(ranges), 1)
+            for i, (off, n) in enumerate(ranges):
+                H.absmax(self.flat, 1, n, n, off=off, out=self.wamax[i * per:(i + 1) * per])
         if self.use_planes:
             npl, dt = (2, torch.float16) if self.engine_h else (3, torch.bfloat16)
             if self.wplanes is None or self.wplanes.shape != (npl, self.n_live) or self.wplanes.device != dev or self.wplanes.dtype != dt:
                 self.wplanes = torch.empty((npl, self.n_live), dtype=dt, device=dev)
                 self.wTplanes = torch.empty((npl, self.n_live), dtype=dt, device=dev)
-            if self.engine_h:
-                H.split2h(self.flat, self.wplanes, self.n_live, self.wamax)
-                for off, R, Cc in self._transposes:
+            for off, n in ranges:
+                if self.engine_h:
+                    H.split2h(self.flat, self.wplanes, n, self.wamax, x_off=off, p_off=off)
+                else:
+                    H.split3(self.flat, self.wplanes, n, x_off=off, p_off=off)
+            for off, R, Cc in self._transposes:
+                if self.engine_h:
                     H.split2h_transpose(self.flat, R, Cc, Cc, self.wTplanes, self.wamax, x_off=off, p_off=off)
-            else:
-                H.split3(self.flat, self.wplanes, self.n_live)
-                for off, R, Cc in self._transposes:
+                else:
                     H.split3_transpose(self.flat, R, Cc, Cc, self.wTplanes, x_off=off, p_off=off)
         self._planes_key = key
 
@@ -224,6 +232,27 @@ class ParamStore:
                 n0 = grp[0]
                 if n0.endswith(".weight") and ".encoder.layers." in "." + n0 and params[n0].dim() == 2 and "ln_" not in n0:
                     self._transposes.append((self.index[n0][0], sum(params[n].shape[0] for n in grp), params[n0].shape[1]))
+        # flat ranges read by GEMMs as the weight operand: the encoder-layer buckets and the input
+        # projections when they are Linears (image mode); Embedding tables, positional tables and the head are not
+        ranges = [(s0, e0 - s0) for bname, s0, e0 in buckets if not bname.endswith("embed") and bname != "head" and e0 > s0]
+        for name in live_names:
+            if name.endswith("vid_proj.weight") or name.endswith("usr_proj.weight"):
+                mod = dict(self.root.named_modules()).get(name.rsplit(".", 1)[0])
+                if isinstance(mod, torch.nn.Linear):
+                    o, n = self.index[name]
+                    ranges.append((o, (n + 7) & ~7))
+        # merge into at most 8 ranges (one slice of the partial-maxima array each)
+        ranges.sort()
+        merged = []
+        for o, n in ranges:
+            if merged and o <= merged[-1][0] + merged[-1][1]:
+                merged[-1] = (merged[-1][0], max(merged[-1][1], o + n - merged[-1][0]))
+            else:
+                merged.append((o, n))
+        while len(merged) > 8:
+            a, b = merged[-2], merged[-1]
+            merged[-2:] = [(a[0], b[0] + b[1] - a[0])]
+        self._plane_ranges = [(o, min(n, n_live - o)) for o, n in merged]
         self._planes_key = None
 
     # -- access
@@ -604,18 +633,19 @@ class BackboneRun:
             if on_bucket is not None:
                 join_side(st)
                 on_bucket("%slayer%d" % (P, i))
-        # ---- embedding backward
-        dpre_v = st.buf("dpre_v", (Mv, d))
-        am_dv = self.amb.new()
-        _ln_bwd(st, dXv, sv["pre_v"], sv["mev"], sv["rev"], P + "vid_ln.weight", P + "vid_ln.bias", gbuf, dpre_v, None, Mv, d,
-                drop_y=(self.p_drop, _site(self.bi, 0, K_EMB_V)), seed=self.seed, amax=am_dv)
-        self._embed_bwd("vid", dpre_v, B, S, gbuf, am_dv)
+        # ---- embedding backward.  User side first: its weight gradient (the larger one) queues on the side stream
+        # behind the projection weight gradients still running there, the video side's runs on the main stream.
         if self.N >= 2:
             dpre_u = st.buf("dpre_u", (Mu, d))
             am_du = self.amb.new()
             _ln_bwd(st, dXu, sv["pre_u"], sv["meu"], sv["reu"], P + "usr_ln.weight", P + "usr_ln.bias", gbuf, dpre_u, None, Mu, d,
                     drop_y=(self.p_drop, _site(self.bi, 0, K_EMB_U)), seed=self.seed, amax=am_du)
             self._embed_bwd("usr", dpre_u, B, Lt, gbuf, am_du)
+        dpre_v = st.buf("dpre_v", (Mv, d))
+        am_dv = self.amb.new()
+        _ln_bwd(st, dXv, sv["pre_v"], sv["mev"], sv["rev"], P + "vid_ln.weight", P + "vid_ln.bias", gbuf, dpre_v, None, Mv, d,
+                drop_y=(self.p_drop, _site(self.bi, 0, K_EMB_V)), seed=self.seed, amax=am_dv)
+        self._embed_bwd("vid", dpre_v, B, S, gbuf, am_dv)
         join_side(st)
         if on_bucket is not None:
             on_bucket(P + "embed")
@@ -644,7 +674,11 @@ class BackboneRun:
         else:
             x = sv["%s_x" % side]
             Din = x.shape[-1]
-            with side_work(st):
+            # The backward ends with the side stream still working through the big projection weight gradients while the
+            # main stream runs dry: the video-side embedding weight gradient (the main stream's last GEMM-sized job
+            # before the user side) therefore runs on the MAIN stream, the user-side one on the side stream.
+            ctx = contextlib.nullcontext() if (side == "vid" and st.tail_balance) else side_work(st)
+            with ctx:
                 _wgrad(st, dpre, d, 0, x, Din, 0, M, d, Din, gtab, a_amax=am_dpre, b_amax=sv["am_%s_x" % side])
                 # bias gradient = sum over all tokens of dpre = sum over positions of the positional-embedding
                 # gradient just computed ([L, d] instead of a second pass over [B*L, d])

@@ -112,6 +112,7 @@ def _f32c(t, name="tensor"):
 
 
 GEMM_PROFILE = None       # bench.py sets this to a list to time every GEMM launch with HIP events
+ATTN_PROFILE = None       # ... and every attention launch: (kind, B, H, dh, Lq, La, Lb, event0, event1)
 ENGINE_F32, ENGINE_BF16X6, ENGINE_F16X3 = 0, 1, 2
 # default engine of gemm(): the scaled two-term fp16 split on the fp16 matrix cores (22-bit operands, three exact
 # partial products, fp32 accumulation: measured error vs fp64 at or below the f32-MFMA kernel's on every layout).
@@ -258,9 +259,17 @@ def attn_fwd(B, H, dh, Lq, La, Lb, Qa, Qb, ldq, Ka, Va, ldka, Kb, Vb, ldkb, mq, 
     """Q*/K*/V* are (tensor, element_offset) pairs: column slices of the fused projection buffers."""
     def P(x):
         return x[0].data_ptr() + 4 * x[1]
+    prof = ATTN_PROFILE
+    if prof is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
     _check(lib().segmm_attn_fwd(B, H, dh, Lq, La, Lb, P(Qa), P(Qb), ldq, P(Ka), P(Va), ldka, P(Kb), P(Vb), ldkb,
                                 _ptr(mq), _ptr(mka), _ptr(mkb), _ptr(O), ldo, _ptr(lse), float(drop_p), int(seed),
                                 int(site), _ptr(amax_o), _stream()), "segmm_attn_fwd")
+    if prof is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        prof.append(("fwd", B, H, dh, Lq, La, Lb, e0, e1))
 
 
 def attn_bwd(B, H, dh, Lq, La, Lb, Qa, Qb, ldq, Ka, Va, ldka, Kb, Vb, ldkb, mq, mka, mkb, lse, O, ldo, dO, lddo, Dvec,
@@ -268,10 +277,18 @@ def attn_bwd(B, H, dh, Lq, La, Lb, Qa, Qb, ldq, Ka, Va, ldka, Kb, Vb, ldkb, mq, 
              amax_kb=None):
     def P(x):
         return x[0].data_ptr() + 4 * x[1]
+    prof = ATTN_PROFILE
+    if prof is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
     _check(lib().segmm_attn_bwd(B, H, dh, Lq, La, Lb, P(Qa), P(Qb), ldq, P(Ka), P(Va), ldka, P(Kb), P(Vb), ldkb,
                                 _ptr(mq), _ptr(mka), _ptr(mkb), _ptr(lse), _ptr(O), ldo, _ptr(dO), lddo, _ptr(Dvec), P(dQa),
                                 P(dQb), lddq, P(dKa), P(dVa), lddka, P(dKb), P(dVb), lddkb, float(drop_p), int(seed),
                                 int(site), _ptr(amax_q), _ptr(amax_ka), _ptr(amax_kb), _stream()), "segmm_attn_bwd")
+    if prof is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        prof.append(("bwd", B, H, dh, Lq, La, Lb, e0, e1))
 
 
 def rowdot(x, ld, w, bias, out, rows, d, accumulate=False, x_off=0, w_off=0):

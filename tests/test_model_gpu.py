@@ -263,3 +263,89 @@ def test_full_width_config_vs_oracle(B, S, Lt, D, N):
         else:
             scale = max(float(rgrads[k].abs().max()), 1e-7)
             assert float((p.grad.cpu() - rgrads[k]).abs().max()) <= 2e-4 * scale + 1e-7, k
+
+
+def _ref_args(N, d, h, S, user, photo):
+    import argparse
+    return argparse.Namespace(debug=0, num_layers_enc=N, ablation_type="ours", d_model=d, nhead=h,
+                              input_type={"user": user, "photo": photo}, learnable_bias=0, exposure_prob=[1.0] * S,
+                              fusion_heads=2, loss_type_list=["interestBPR"], loss_weight={"interestBPR": 1.0, "mse": 1.0}, mask_loss=0)
+
+
+@pytest.mark.parametrize("case", ["config3_id_d512_N4_S20", "config5_Din1536_d768"])
+def test_baseline_config_widths_vs_oracle(case):
+    """BASELINE configs 3 and 5 at their widths, at a batch the CPU oracle finishes in seconds:
+    config 3 = id mode (item / user embedding tables), d = 512, h = 16 (dh = 32), N = 4, S = 20, Lt = 1;
+    config 5 = mixed visual+audio features D_in = 1536 projected to d = 768, N = 2, S = 40, Lt = 100."""
+    import segmm_oracle as O
+    import segmminterest_amd as M
+    from segmminterest_amd.synth import make_batch, l1_normalize
+    torch.manual_seed(0)
+    if case.startswith("config3"):
+        B, S, Lt, Din, d, N, h, user, photo, nu, ni = 48, 20, 1, 4, 512, 4, 16, "id", "id", 200, 1000
+    else:
+        B, S, Lt, Din, d, N, h, user, photo, nu, ni = 24, 40, 100, 1536, 768, 2, 16, "image", "image", 1, 1
+    args = _ref_args(N, d, h, S, user, photo)
+    bb = M.SegFormerX(d_model_in=d, d_model_lvls=[d] * N, num_head_lvls=[h] * N, ff_dim_lvls=[d] * N, input_vid_dim=Din,
+                      input_usr_dim=Din, max_vid_len=S, max_usr_len=Lt, sr_ratio_lvls=[1] * N, use_patch_merge=[False] * N,
+                      output_layers=[-1], model_cfg=args, user_id_max=nu if user == "id" else -1,
+                      video_id_max=ni if photo == "id" else -1)
+    model = M.MultiScaleTemporalDetrLeaveFocal(bb, None, None, torch.nn.Identity(), args)
+    with torch.no_grad():
+        for n_, p in model.named_parameters():
+            if p.dim() == 2 and ".encoder.layers." in n_ and "ln_" not in n_:
+                p.mul_(2.0)
+            if n_.endswith("vid_proj.weight") or n_.endswith("usr_proj.weight"):
+                p.mul_(100.0 if user == "image" else 6.0)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    b = make_batch(B, S, Lt, Din, n_users=nu, n_items=ni, seed=5, allow_full_len=(S == 40))
+    inp = dict(usr_image=l1_normalize(b["user"]), usr_id=b["user_identity_id"], usr_mask=b["user_mask"],
+               vid_image=l1_normalize(b["photo"]), vid_id=b["photo_identity_id"], vid_mask=b["photo_mask"], gt=b["label"])
+    cfg = dict(N=N, h=h, S=S, user=user, photo=photo, loss_type_list=["interestBPR"], loss_weight={"interestBPR": 1.0, "mse": 1.0},
+               exposure_prob=[1.0] * S)
+    ref, rgrads = O.forward_backward(sd, cfg, inp)
+    model = model.cuda().eval()
+    out = call_model(model, inp, "train", DEV)
+    assert (out["logits"].cpu() - ref["logits"].detach()).abs().max().item() < 1e-4
+    assert abs(float(out["loss"]) - float(ref["loss"])) < 1e-4
+    out["loss"].backward()
+    for k, p in model.named_parameters():
+        if rgrads[k] is None:
+            assert p.grad is None, k
+        else:
+            scale = max(float(rgrads[k].abs().max()), 1e-7)
+            assert float((p.grad.cpu() - rgrads[k]).abs().max()) <= 3e-4 * scale + 1e-7, k
+
+
+def test_full_size_batch_matches_oracle_on_a_row_subset():
+    """BASELINE config 2 at FULL size (B = 512, S = 40, Lt = 100, D = 768, N = 2) on the device; interaction rows are
+    independent in inference, so the CPU oracle only has to run a 12-row subset of the same batch: logits within 1e-4."""
+    import segmm_oracle as O
+    import segmminterest_amd as M
+    from segmminterest_amd.synth import make_batch, l1_normalize
+    torch.manual_seed(1)
+    B, S, Lt, D, N, h = 512, 40, 100, 768, 2, 16
+    args = _ref_args(N, D, h, S, "image", "image")
+    bb = M.SegFormerX(d_model_in=D, d_model_lvls=[D] * N, num_head_lvls=[h] * N, ff_dim_lvls=[D] * N, input_vid_dim=D,
+                      input_usr_dim=D, max_vid_len=S, max_usr_len=Lt, sr_ratio_lvls=[1] * N, use_patch_merge=[False] * N,
+                      output_layers=[-1], model_cfg=args)
+    model = M.MultiScaleTemporalDetrLeaveFocal(bb, None, None, torch.nn.Identity(), args)
+    with torch.no_grad():
+        for n_, p in model.named_parameters():
+            if p.dim() == 2 and ".encoder.layers." in n_ and "ln_" not in n_:
+                p.mul_(2.0)
+            if n_.endswith("vid_proj.weight") or n_.endswith("usr_proj.weight"):
+                p.mul_(100.0)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    b = make_batch(B, S, Lt, D, seed=11)
+    inp = dict(usr_image=l1_normalize(b["user"]), usr_id=b["user_identity_id"], usr_mask=b["user_mask"],
+               vid_image=l1_normalize(b["photo"]), vid_id=b["photo_identity_id"], vid_mask=b["photo_mask"], gt=b["label"])
+    model = model.cuda().eval()
+    got = call_model(model, inp, "inference", DEV)["logits"].cpu()
+    rows = torch.tensor([0, 1, 2, 63, 64, 127, 255, 256, 300, 400, 510, 511])
+    sub = {k: v[rows] for k, v in inp.items()}
+    cfg = dict(N=N, h=h, S=S, user="image", photo="image", loss_type_list=["interestBPR"], loss_weight={"interestBPR": 1.0, "mse": 1.0},
+               exposure_prob=[1.0] * S)
+    ref = O.model_forward(sd, cfg, sub, mode="inference")["logits"]
+    assert (got[rows] - ref.detach()).abs().max().item() < 1e-4
+    assert got.shape == (B, S) and torch.isfinite(got).all()
