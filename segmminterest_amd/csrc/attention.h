@@ -58,6 +58,7 @@ struct AttnArgs {
     float *dQa, *dQb; int lddq;
     float *dKa, *dVa; int lddka;
     float *dKb, *dVb; int lddkb;
+    int hpb;                            // adjacent heads per workgroup (divides H); waves per workgroup = hpb * row tiles
     uint32_t ka_bytes, kb_bytes, q_bytes, do_bytes;   // extents of the K/V (block a, b), Q and dO views (buffer range check)
     // optional partial maxima (AMAX_SLOTS each, common.h) of what the kernels write, for the fp16x3 GEMM engine:
     float* amax_o;                      // forward: |O|
@@ -69,7 +70,8 @@ struct AttnArgs {
                                         // 1 -> 225 us, 2 -> 237 us, 3 -> 236 us (fewer resident waves cost more than
                                         // the extra loads in flight gain)
 #endif
-constexpr int ATT_MAX_THREADS = 320;    // up to 5 waves = 5 row tiles of one (b, h) per workgroup (host picks 1..5)
+constexpr int ATT_MAX_THREADS = 320;    // forward: up to 5 waves = 5 row tiles of one (b, h) per workgroup
+constexpr int ATT_BWD_THREADS = 768;    // backward kernels need ~160 registers: at most 12 waves per workgroup
 
 __device__ __forceinline__ int round16(int x) { return (x + 15) & ~15; }
 
@@ -212,16 +214,17 @@ template <int DH, int NT>
 __global__ __launch_bounds__(ATT_MAX_THREADS) void attn_fwd_kernel(const AttnArgs p) {
     using C = AttnCfg<DH>;
     extern __shared__ uint8_t km[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    // A workgroup = p.hpb ADJACENT heads of one batch row x wq row tiles: the heads read interleaved 4*DH-byte slices of
+    // the same token rows, so their loads, issued together, touch each DRAM page / cache line once instead of once per
+    // head at unrelated times.  XCD-aware block order keeps the remaining head groups of a batch row on one L2.
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6, wq = wpb / p.hpb;
     const int l15 = lane & 15, g = lane >> 4;
-    // XCD-aware: the heads of one batch row read interleaved 4*DH-byte slices of the same token rows, so
-    // consecutive (b,h) must share an L2 or every shared cache line is fetched from HBM once per XCD
-    const int bh = xcd_remap(blockIdx.x, gridDim.x), b = bh / p.H, h = bh % p.H;
+    const int bh = xcd_remap(blockIdx.x, gridDim.x) * p.hpb + wave / wq, b = bh / p.H, h = bh % p.H;
     const int La_p = round16(p.La), Lb_p = round16(p.Lb), Tp = La_p + Lb_p, nta = La_p >> 4, nt = Tp >> 4;
     const int col0 = h * DH;
     stage_kmask(km, p.mka, p.mkb, b, p.La, p.Lb, La_p, Lb_p);
     __syncthreads();
-    const int qt = blockIdx.y * wpb + wave;          // this wave's query tile
+    const int qt = blockIdx.y * wq + wave % wq;      // this wave's query tile
     if (16 * qt >= p.Lq) return;
     const int qi = 16 * qt + l15;                    // this lane's query
     const bool q_in = qi < p.Lq;
@@ -340,17 +343,17 @@ __global__ __launch_bounds__(ATT_MAX_THREADS) void attn_fwd_kernel(const AttnArg
 // output the kernel is ONE pass over the key tiles with nothing but the dQ accumulators carried along:
 //   S^T_t = K_t.Q^T -> P^T_t ;  dP^T_t = V_t.dO^T ;  dS^T_t = P^T_t (dP^T_t - D) fac ;  dQ^T += K_t^T . dS^T_t
 template <int DH, int NT>
-__global__ __launch_bounds__(ATT_MAX_THREADS) void attn_bwd_dq_kernel(const AttnArgs p) {
+__global__ __launch_bounds__(ATT_BWD_THREADS) void attn_bwd_dq_kernel(const AttnArgs p) {
     using C = AttnCfg<DH>;
     extern __shared__ uint8_t km[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6, wq = wpb / p.hpb;
     const int l15 = lane & 15, g = lane >> 4;
-    const int bh = xcd_remap(blockIdx.x, gridDim.x), b = bh / p.H, h = bh % p.H;
+    const int bh = xcd_remap(blockIdx.x, gridDim.x) * p.hpb + wave / wq, b = bh / p.H, h = bh % p.H;
     const int La_p = round16(p.La), Lb_p = round16(p.Lb), Tp = La_p + Lb_p, nta = La_p >> 4, nt = Tp >> 4;
     const int col0 = h * DH;
     stage_kmask(km, p.mka, p.mkb, b, p.La, p.Lb, La_p, Lb_p);
     __syncthreads();
-    const int qt = blockIdx.y * wpb + wave;
+    const int qt = blockIdx.y * wq + wave % wq;
     if (16 * qt >= p.Lq) return;
     const int qi = 16 * qt + l15;
     const bool q_in = qi < p.Lq;
@@ -466,30 +469,36 @@ __global__ __launch_bounds__(ATT_MAX_THREADS) void attn_bwd_dq_kernel(const Attn
 // was measured 12 % slower).
 // NQT > 0: number of query tiles known at compile time (fully unrolled); NQT = 0: runtime loop.
 template <int DH, int NQT>
-__global__ __launch_bounds__(ATT_MAX_THREADS) void attn_bwd_dkv_kernel(const AttnArgs p) {
+__global__ __launch_bounds__(ATT_BWD_THREADS) void attn_bwd_dkv_kernel(const AttnArgs p) {
     using C = AttnCfg<DH>;
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6, wq = wpb / p.hpb;
     const int l15 = lane & 15, g = lane >> 4;
-    const int bh = xcd_remap(blockIdx.x, gridDim.x), b = bh / p.H, h = bh % p.H;
+    const int bh = xcd_remap(blockIdx.x, gridDim.x) * p.hpb + wave / wq, b = bh / p.H, h = bh % p.H;
     const int La_p = round16(p.La), Lb_p = round16(p.Lb), Tp = La_p + Lb_p, nta = La_p >> 4, nt = Tp >> 4;
     const int Lq_p = round16(p.Lq), nqt = NQT > 0 ? NQT : (Lq_p >> 4);
     const int col0 = h * DH;
-    float* s_mx = smem_f;                   // [Lq_p] row max
-    float* s_inv = s_mx + Lq_p;             // [Lq_p] 1 / row sum
-    float* s_D = s_inv + Lq_p;              // [Lq_p] rowsum(P dP)
-    uint8_t* qm = (uint8_t*)(s_D + Lq_p);   // [Lq_p] 1 valid query, 0 masked, 2 pad
+    const int hi = wave / wq;               // this wave's head inside the workgroup's head group
+    float* s_mx = smem_f + hi * 3 * Lq_p;   // per head: [Lq_p] row max, [Lq_p] 1 / row sum, [Lq_p] rowsum(P dP)
+    float* s_inv = s_mx + Lq_p;
+    float* s_D = s_inv + Lq_p;
+    uint8_t* qm = (uint8_t*)(smem_f + p.hpb * 3 * Lq_p);   // [Lq_p] 1 valid query, 0 masked, 2 pad (same for every head)
     uint8_t* km = qm + Lq_p;                // [Tp]
-    for (int i = threadIdx.x; i < Lq_p; i += blockDim.x) {
-        const bool in = i < p.Lq;
-        s_mx[i] = in ? p.lse[(size_t)bh * p.Lq + i] : 0.f;
-        s_inv[i] = in ? p.lse[(size_t)p.B * p.H * p.Lq + (size_t)bh * p.Lq + i] : 0.f;
-        s_D[i] = in ? p.Dvec[(size_t)bh * p.Lq + i] : 0.f;
-        qm[i] = in ? (p.mq[(size_t)b * p.Lq + i] ? 1 : 0) : 2;
+    {
+        const int bh0 = bh - hi;
+        for (int i = threadIdx.x; i < p.hpb * Lq_p; i += blockDim.x) {
+            const int hh = i / Lq_p, q = i - hh * Lq_p;
+            const bool in = q < p.Lq;
+            float* base = smem_f + hh * 3 * Lq_p;
+            base[q] = in ? p.lse[(size_t)(bh0 + hh) * p.Lq + q] : 0.f;
+            base[Lq_p + q] = in ? p.lse[(size_t)p.B * p.H * p.Lq + (size_t)(bh0 + hh) * p.Lq + q] : 0.f;
+            base[2 * Lq_p + q] = in ? p.Dvec[(size_t)(bh0 + hh) * p.Lq + q] : 0.f;
+        }
+        for (int q = threadIdx.x; q < Lq_p; q += blockDim.x) qm[q] = q < p.Lq ? (p.mq[(size_t)b * p.Lq + q] ? 1 : 0) : 2;
     }
     stage_kmask(km, p.mka, p.mkb, b, p.La, p.Lb, La_p, Lb_p);
     __syncthreads();
-    const int jt = blockIdx.y * wpb + wave;         // this wave's key tile
+    const int jt = blockIdx.y * wq + wave % wq;     // this wave's key tile
     if (jt >= nt) return;
     const bool isa = jt < nta;
     const int jp = 16 * jt + l15;                   // this lane's key (padded index)

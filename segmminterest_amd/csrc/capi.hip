@@ -3,6 +3,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 
 #include "../../include/segmm_hip.h"
 #include "attention.h"
@@ -53,19 +54,34 @@ static int attn_fill(AttnArgs& a, int B, int H, int dh, int Lq, int La, int Lb, 
     return 0;
 }
 
-// waves per workgroup for n row tiles of one (b, h): every wave of the workgroup busy, up to 5
-static int attn_wpb(int n) {
-    if (n <= 5) return n;
-    for (int w = 5; w >= 3; --w)
-        if (n % w == 0) return w;
-    return 4;
+// workgroup shape for n row tiles per head: wq tiles x hpb adjacent heads, at most max_waves waves, every wave busy
+static void attn_shape(int n, int H, int max_waves, int want_default, const char* env, int& wq, int& hpb) {
+    wq = n;
+    if (n > 5) {
+        wq = 4;
+        for (int w = 5; w >= 3; --w)
+            if (n % w == 0) { wq = w; break; }
+    }
+    hpb = 1;
+    const char* e = getenv(env);          // A/B knob (SEGMM_ATT_HPB_FWD / _DQ / _DKV = "heads[,tiles]")
+    int want = want_default;
+    if (e && atoi(e) > 0) {
+        want = atoi(e);
+        const char* c = strchr(e, ',');
+        if (c && atoi(c + 1) > 0 && atoi(c + 1) <= n) wq = atoi(c + 1);
+    }
+    for (int c = want; c >= 1; --c)
+        if (H % c == 0 && c * wq <= max_waves) { hpb = c; break; }
 }
 
 template <int DH>
-static int attn_launch_fwd(const AttnArgs& a, hipStream_t s) {
+static int attn_launch_fwd(AttnArgs& a, hipStream_t s) {
     const int Tp = ((a.La + 15) & ~15) + ((a.Lb + 15) & ~15);
-    const int nqt = (a.Lq + 15) / 16, wpb = attn_wpb(nqt);
-    dim3 grid(a.B * a.H, (nqt + wpb - 1) / wpb), block(64 * wpb);       // one wave per 16-query tile
+    const int nqt = (a.Lq + 15) / 16;
+    int wq, hpb;
+    attn_shape(nqt, a.H, 5, 1, "SEGMM_ATT_HPB_FWD", wq, hpb);          // measured: grouping heads does not pay in the forward
+    a.hpb = hpb;
+    dim3 grid(a.B * a.H / hpb, (nqt + wq - 1) / wq), block(64 * wq * hpb);       // one wave per 16-query tile of a head
     if (Tp <= 64) hipLaunchKernelGGL((attn_fwd_kernel<DH, 4>), grid, block, Tp, s, a);
     else if (Tp <= 160) hipLaunchKernelGGL((attn_fwd_kernel<DH, 10>), grid, block, Tp, s, a);
     else hipLaunchKernelGGL((attn_fwd_kernel<DH, 12>), grid, block, Tp, s, a);
@@ -74,21 +90,30 @@ static int attn_launch_fwd(const AttnArgs& a, hipStream_t s) {
 }
 
 template <int DH>
-static int attn_launch_bwd(const AttnArgs& a, hipStream_t s) {
+static int attn_launch_bwd(AttnArgs& a, hipStream_t s) {
     const int Tp = ((a.La + 15) & ~15) + ((a.Lb + 15) & ~15);
     {
-        const int nqt = (a.Lq + 15) / 16, wpb = attn_wpb(nqt);
-        dim3 grid(a.B * a.H, (nqt + wpb - 1) / wpb), block(64 * wpb);
+        const int nqt = (a.Lq + 15) / 16;
+        int wq, hpb;
+        attn_shape(nqt, a.H, 12, 1, "SEGMM_ATT_HPB_DQ", wq, hpb);
+        a.hpb = hpb;
+        dim3 grid(a.B * a.H / hpb, (nqt + wq - 1) / wq), block(64 * wq * hpb);
         if (Tp <= 64) hipLaunchKernelGGL((attn_bwd_dq_kernel<DH, 4>), grid, block, Tp, s, a);
         else if (Tp <= 160) hipLaunchKernelGGL((attn_bwd_dq_kernel<DH, 10>), grid, block, Tp, s, a);
         else hipLaunchKernelGGL((attn_bwd_dq_kernel<DH, 12>), grid, block, Tp, s, a);
         LAUNCH_CHECK();
     }
     {
-        const int nt = Tp / 16, wpb = attn_wpb(nt);
-        dim3 grid(a.B * a.H, (nt + wpb - 1) / wpb), block(64 * wpb);   // one wave per 16-key tile
+        const int nt = Tp / 16;
+        int wq, hpb;
+        attn_shape(nt, a.H, 12, 1, "SEGMM_ATT_HPB_DKV", wq, hpb);
+        // small workgroups: at 3 waves/SIMD a CU holds 12 waves = six 2-wave groups, but only two 5-wave ones
+        // (measured for 10 key tiles: 2 waves 533 us, 1 wave 544, 4 waves 611, 5 waves 722)
+        if (!getenv("SEGMM_ATT_HPB_DKV")) wq = nt >= 2 ? 2 : 1;
+        a.hpb = hpb;
+        dim3 grid(a.B * a.H / hpb, (nt + wq - 1) / wq), block(64 * wq * hpb);   // one wave per 16-key tile of a head
         const int Lq_p = (a.Lq + 15) & ~15;
-        const size_t lds = (size_t)Lq_p * 13 + Tp;                    // 3 float vectors + query flags + key flags
+        const size_t lds = (size_t)hpb * Lq_p * 12 + Lq_p + Tp;          // per head 3 float vectors; query flags; key flags
         if (Lq_p == 48) hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH, 3>), grid, block, lds, s, a);
         else if (Lq_p == 16) hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH, 1>), grid, block, lds, s, a);
         else hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH, 0>), grid, block, lds, s, a);
