@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                      float* __restrict__ dx_drop, float* __restrict__ part_dgamma,
                                      float* __restrict__ part_dbeta, float* __restrict__ part_dsum, long long rows, int d,
                                      DropCfg drop_y, DropCfg drop_branch, float* amax) {
-    __shared__ float red[4][V * 256];
+    __shared__ f32x4 red[4][64];
     float am = 0.f;          // max |dx_drop| (or |dx| when there is no dropped copy): the tensor the GEMMs consume
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     f32x4 ag[V], ab[V], as[V], gm[V];
@@ -142,20 +142,22 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         }
     }
     if (amax) amax_commit(amax, am, blockIdx.x * nw + wave);
-    // cross-wave reduce of the partials, one partial row per workgroup
+    // cross-wave reduce of the partials, one partial row per workgroup.  One 256-column chunk at a time through a 4 KB
+    // buffer: the kernel usually runs NEXT TO a GEMM that holds 120 of the CU's 160 KB of LDS, and a 12 KB buffer
+    // would cap it at three workgroups per CU there.
     for (int pass = 0; pass < (part_dsum ? 3 : 2); ++pass) {
-        __syncthreads();
+        float* out = (pass == 0 ? part_dgamma : (pass == 1 ? part_dbeta : part_dsum)) + (size_t)blockIdx.x * d;
 #pragma unroll
         for (int i = 0; i < V; ++i) {
             const int c = lane * 4 + i * 256;
-            if (c < d) *(f32x4*)(&red[wave][c]) = pass == 0 ? ag[i] : (pass == 1 ? ab[i] : as[i]);
-        }
-        __syncthreads();
-        float* out = (pass == 0 ? part_dgamma : (pass == 1 ? part_dbeta : part_dsum)) + (size_t)blockIdx.x * d;
-        for (int c = threadIdx.x; c < d; c += blockDim.x) {
-            float s = 0.f;
-            for (int w = 0; w < nw; ++w) s += red[w][c];
-            out[c] = s;
+            __syncthreads();
+            red[wave][lane] = pass == 0 ? ag[i] : (pass == 1 ? ab[i] : as[i]);
+            __syncthreads();
+            if (wave == 0 && c < d) {
+                f32x4 s4 = red[0][lane];
+                for (int w = 1; w < nw; ++w) s4 += red[w][lane];
+                *(f32x4*)(out + c) = s4;
+            }
         }
     }
 }

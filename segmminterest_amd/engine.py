@@ -97,7 +97,8 @@ class ParamStore:
         self._on_side = False
         self.overlap = os.environ.get("SEGMM_OVERLAP", "1") != "0"
         self.defer_wgrad = os.environ.get("SEGMM_DEFER_WGRAD", "0") != "0"
-        self.tail_balance = os.environ.get("SEGMM_TAIL_BALANCE", "1") != "0"     # measured: no gain (kept as a knob)
+        self.tail_balance = os.environ.get("SEGMM_TAIL_BALANCE", "1") != "0"
+        self.ln_side = os.environ.get("SEGMM_LN_SIDE", "0") != "0"      # measured: -2 % (kept as a knob)     # measured: no gain (kept as a knob)
         # pre-split bf16 planes of the weights for the bf16x6 GEMM engine: W planes (forward) and W^T planes (dgrad
         # in the NT form), refreshed when the parameters change (one split pass per optimizer step)
         # (fp16x3 engine: two fp16 planes scaled by one power of two derived from ``wamax``, the partial maxima of
@@ -390,15 +391,18 @@ def _ln_bwd(store, dy, x, mean, rstd, gname, bname, gbuf, dx, dx_drop, rows, d, 
     forwarded gradient (dx_drop, or dx): the bias gradient of the Linear feeding this LayerNorm's residual branch,
     accumulated inside the same kernel instead of by a second pass over [rows, d]."""
     parts = H.layernorm_bwd_parts(rows)
-    pg = store.buf("ln_pg", (parts, d))
-    pb = store.buf("ln_pb", (parts, d))
-    ps = store.buf("ln_ps", (parts, d)) if dsum_to is not None else None
+    # partial buffers named after the parameter so that their reductions MAY run on the side stream (SEGMM_LN_SIDE=1;
+    # measured 2 % slower than keeping these tiny launches on the main stream, so off by default)
+    pg = store.buf("ln_pg:" + gname, (parts, d))
+    pb = store.buf("ln_pb:" + gname, (parts, d))
+    ps = store.buf("ln_ps:" + gname, (parts, d)) if dsum_to is not None else None
     H.layernorm_bwd(dy, x, mean, rstd, store.p(gname), dx, dx_drop, pg, pb, drop_y_p=drop_y[0], drop_y_site=drop_y[1],
                     drop_b_p=drop_b[0], drop_b_site=drop_b[1], seed=seed, amax=amax, part_dsum=ps)
-    _colsum(store, pg, d, parts, d, store.g(gname, gbuf))
-    _colsum(store, pb, d, parts, d, store.g(bname, gbuf))
-    if ps is not None:
-        _colsum(store, ps, d, parts, d, dsum_to)
+    with (side_work(store) if store.ln_side else contextlib.nullcontext()):
+        _colsum(store, pg, d, parts, d, store.g(gname, gbuf))
+        _colsum(store, pb, d, parts, d, store.g(bname, gbuf))
+        if ps is not None:
+            _colsum(store, ps, d, parts, d, dsum_to)
 
 
 def _mask_u8(m: torch.Tensor) -> torch.Tensor:
