@@ -185,6 +185,16 @@ def main():
     else:
         peak, kname = PEAK_F32_MFMA_TFLOPS, "gemm_f32_mfma (v_mfma_f32_32x32x2_f32; NT/NN/TN launches incl. split-K combine)"
     rows_per_s = world * B * args.steps / elapsed
+    # HBM-side bytes per GEMM launch: PMC counters cannot be read from inside the process, so the figure comes from the
+    # committed pass of tools/traffic_pass.sh over this same command (profiles/hbm_traffic.json; null when absent)
+    alg_bytes = sum(4.0 * (M * K + Nn * K + M * Nn) for (_, M, Nn, K, _, _) in prof) / max(len(prof), 1)
+    traffic, traffic_note = None, ""
+    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "hbm_traffic.json")
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            tj = json.load(f)
+        traffic = round(tj["hbm_bytes_per_launch"])
+        traffic_note = "; traffic = mean HBM-side bytes per GEMM launch from profiles/hbm_traffic.json (" + tj["method"] + ")"
     ftrain = f_train_flops(D, D, S, Lt, N)
 
     if rank == 0:
@@ -204,11 +214,12 @@ def main():
                        "step_frac_of_f32_mfma_peak": round(rows_per_s / world * ftrain / (PEAK_F32_MFMA_TFLOPS * 1e12), 4)},
             "roofline": {"bound": "mfma", "kernel": kname,
                          "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4), "traffic": None,
+                         "frac": round(achieved / peak, 4), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": round(alg_bytes),
                          "launches": len(prof), "profiled_steps": psteps, "gemm_busy_ms_per_step": round(gemm_ms / psteps, 4),
                          "ms_per_step_with_events": round(1e3 * prof_elapsed / psteps, 4),
                          "note": "achieved = algorithmic 2MNK of every GEMM launch of the instrumented pass (same steps, run right after the timed region) / union of their HIP-event intervals; "
-                                 "peak = dense MFMA peak of the instruction used" + {"bf16x6": " / 6 partial products", "f16x3": " / 3 partial products", "f32": ""}[engine]},
+                                 "peak = dense MFMA peak of the instruction used" + {"bf16x6": " / 6 partial products", "f16x3": " / 3 partial products", "f32": ""}[engine] + traffic_note},
         }
         rec["roofline_attention"] = {"bound": "mfma", "kernel": "attn_fwd + attn_bwd_dq + attn_bwd_dkv (v_mfma_f32_16x16x4_f32, exact fp32)",
                                      "achieved": round(att_tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",

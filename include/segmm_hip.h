@@ -37,7 +37,7 @@ int segmm_l1norm(const float* x, float* y, float* inv_scale, int64_t rows, int D
  *   layout 1 (NN): C[M,N] = A[M,K] . B[K,N]      dgrad
  *   layout 2 (TN): C[M,N] = A[K,M]^T . B[K,N]    wgrad (use splits > 1: K is the token dimension)
  * epilogue, in this order: * row_scale[m]; + bias[n]; activation (0 none, 1 erf-GELU saving the pre-activation to
- * aux, 2 multiply by GELU'(aux)); dropout(p, seed, site) on element m*N+n; + residual[(m % res_period), n].
+ * aux, 2 multiply by GELU'(aux), 3 ReLU, 4 zero where aux <= 0 -- ReLU backward, aux = the forward output); dropout(p, seed, site) on element m*N+n; + residual[(m % res_period), n].
  * residual may alias C (accumulate).  splits > 1: partial slabs in `workspace` (splits*M*N floats), then a
  * deterministic combine; only `accumulate` (C += result) applies in that mode.
  * engine 0: v_mfma_f32_32x32x2_f32 (exact fp32 products).  engine 1: "bf16x6" -- operands are split exactly into
@@ -141,14 +141,15 @@ int segmm_rowscale_mat(const float* g, const float* X, int ldx, float* out, int 
                        int accumulate, segmm_stream_t stream);
 
 /* K2' -- id-mode embeddings (encoder.py:426-435,445,484-486), pre-LayerNorm:
- *   vid[b,s,:] = cat(item_table[item_id[b]], frame_w*s + frame_b) + vid_pe[s];   usr[b,0,:] = user_table[uid[b]] + usr_pe[0]
+ *   vid[b,s,:] = cat(item_table[item_id[b]], frame_w*pos[b,s] + frame_b) + vid_pe[s];   usr[b,0,:] = user_table[uid[b]] + usr_pe[0]
+ *   (frame_pos = null: pos[b,s] = s; the 'noPos' ablation passes per-row shuffled positions [B*S], encoder.py:428-429)
  * backward: dense table gradients accumulated deterministically over batch rows grouped by id
  * (order = batch rows sorted by id, from a host-side torch.sort; no data-dependent sizes, no sync),
  * and dpe[s,:] = sum_b dpre[b,s,:].  n_rows = rows of the table: an id outside [0, n_rows) (torch.nn.Embedding raises
  * on it) never touches memory -- its forward row is filled with NaN so the loss shows it, its backward is skipped. */
 int segmm_embed_id_vid(const int64_t* item_id, const float* table, int dhalf, const float* frame_w,
-                       const float* frame_b, const float* pe, float* out, int B, int S, int64_t n_rows,
-                       segmm_stream_t stream);
+                       const float* frame_b, const float* pe, const float* frame_pos, float* out, int B, int S,
+                       int64_t n_rows, segmm_stream_t stream);
 int segmm_embed_id_usr(const int64_t* user_id, const float* table, int d, const float* pe, float* out, int B,
                        int64_t n_rows, segmm_stream_t stream);
 int segmm_embed_id_bwd(const float* dpre, int tokens_per_row, int ld, int col0, int width, const int32_t* order,
@@ -201,6 +202,11 @@ int segmm_gather_l1(const float* table, int64_t n_lines, int D, const int64_t* i
  * weight[r, seg] * (seg < duration[r]); weight == null: ones, duration == null: no duration mask. */
 int segmm_segment_weighted_sum(const float* pred, const float* weight, const int64_t* duration, int64_t rows, int S, float* out,
                                segmm_stream_t stream);
+
+/* CrossMLP ablation (encoder.py:392-396,503-506): nn.AdaptiveAvgPool1d(bins) over the token axis of cat(U[B,Lu,d], V[B,Lv,d]):
+ * out[b,i,:] = mean of tokens [floor(i T/bins), ceil((i+1) T/bins)), T = Lu+Lv; and its backward (dU, dV overwritten). */
+int segmm_pool_tokens(const float* U, int Lu, const float* V, int Lv, float* out, int B, int d, int bins, segmm_stream_t stream);
+int segmm_pool_tokens_bwd(const float* dOut, float* dU, int Lu, float* dV, int Lv, int B, int d, int bins, segmm_stream_t stream);
 
 /* test hook: multiplier (0 or 1/(1-p)) of elements [0,n) of a dropout site */
 int segmm_dropout_mult(float* out, int64_t n, float p, uint64_t seed, uint32_t site, segmm_stream_t stream);

@@ -72,6 +72,25 @@ CASES = {
                       loss="interestBPR", fusion_heads=-2, n_users=50, n_items=200),
     "uimg_pid_fh2": dict(user="image", photo="both", d=32, h=4, N=2, S=40, Lt=10, D_in=48, B=8,
                          loss="interestBPR", fusion_heads=4, n_users=50, n_items=200),
+    # ablation variants (--ablation_type, main...SegMM.py:529; encoder.py:108-135,172-173,392-400,428-429,503-511)
+    "abl_crossatt_N3": dict(user="image", photo="image", d=32, h=4, N=3, S=40, Lt=10, D_in=48, B=8,
+                            loss="interestBPR", ablation="CrossAtt", adam=True),
+    "abl_selfatt_N3": dict(user="image", photo="image", d=32, h=4, N=3, S=40, Lt=10, D_in=48, B=8,
+                           loss="interestBPR", ablation="SelfAtt", adam=True),
+    "abl_nouser_selfatt_N2": dict(user="image", photo="image", d=32, h=4, N=2, S=40, Lt=10, D_in=48, B=8,
+                                  loss="interestBPR", ablation="noUser_SelfAtt"),
+    "abl_nopos_id_N2": dict(user="id", photo="id", d=32, h=4, N=2, S=40, Lt=1, D_in=0, B=8,
+                            loss="interestBPR", n_users=50, n_items=200, ablation="noPos", fwd_seed=4242, adam=True),
+    "abl_crossatt_id_N3": dict(user="id", photo="id", d=32, h=4, N=3, S=40, Lt=1, D_in=0, B=8,
+                               loss="interestBPR", n_users=50, n_items=200, ablation="CrossAtt"),
+    "abl_selfmlp_N4": dict(user="image", photo="image", d=32, h=4, N=4, S=40, Lt=10, D_in=48, B=8,
+                           loss="interestBPR", ablation="SelfMLP", adam=True),
+    "abl_crossmlp_N5_Lt100": dict(user="image", photo="image", d=32, h=4, N=5, S=40, Lt=100, D_in=48, B=6,
+                                  loss="interestBPR", ablation="CrossMLP", adam=True),
+    "abl_crossmlp_N2": dict(user="image", photo="image", d=32, h=4, N=2, S=40, Lt=10, D_in=48, B=8,
+                            loss="interestBPR", ablation="CrossMLP"),
+    "abl_woatt_N2": dict(user="image", photo="image", d=32, h=4, N=2, S=40, Lt=10, D_in=48, B=8,
+                         loss="interestBPR", ablation="w/oAtt"),
 }
 
 
@@ -85,7 +104,7 @@ def build_reference_model(c, enc, dec):
     else:
         exposure = [1.0] * S
     loss_list = [x.strip() for x in c["loss"].split(",")]
-    cfg = ap.Namespace(debug=0, num_layers_enc=c["N"], ablation_type="ours", d_model=c["d"], nhead=c["h"],
+    cfg = ap.Namespace(debug=0, num_layers_enc=c["N"], ablation_type=c.get("ablation", "ours"), d_model=c["d"], nhead=c["h"],
                        input_type={"user": c["user"], "photo": c["photo"]},
                        learnable_bias=c.get("learnable_bias", 0), exposure_prob=exposure,
                        fusion_heads=c.get("fusion_heads", 2), loss_type_list=loss_list,
@@ -141,8 +160,13 @@ def perturb(model, seed):
                 p.mul_(10.0)
 
 
+FWD_SEED = [None]      # 'noPos' draws torch.randperm in every forward: reseeded so that the fixture is reproducible
+
+
 def run_model(model, inp, mode="train"):
     buf = io.StringIO()
+    if FWD_SEED[0] is not None:
+        torch.manual_seed(FWD_SEED[0])
     with contextlib.redirect_stdout(buf):
         out = model(usr_image=inp["usr_image"], usr_id=inp["usr_id"], usr_mask=inp["usr_mask"],
                     vid_image=inp["vid_image"], vid_id=inp["vid_id"], vid_mask=inp["vid_mask"],
@@ -177,9 +201,10 @@ def gen_case(name, c, enc, dec, outdir):
     model, cfg = build_reference_model(c, enc, dec)
     perturb(model, seed=11 + len(name))
     model.eval()
+    FWD_SEED[0] = c.get("fwd_seed")
     inp = make_inputs(c, seed=1234 + len(name))
-    blob = {"cfg": np.array(json.dumps(dict(c, exposure_prob=list(cfg.exposure_prob),
-                                            loss_weight=cfg.loss_weight)))}
+    blob = {"cfg": np.array(json.dumps(dict(c, exposure_prob=list(cfg.exposure_prob), loss_weight=cfg.loss_weight,
+                                            ablation_type=cfg.ablation_type)))}
     for k, v in model.state_dict().items():
         blob["sd/" + k] = v.detach().numpy().copy()
     for k, v in inp.items():

@@ -50,33 +50,46 @@ def attn_logits(sd, proj, feat_k, mask_k, feat_q, mask_q, nhead):
     return torch.where(m, logits, torch.full_like(logits, -10000.0))
 
 
-def cross_attention(sd, pre, vid, vid_mask, usr, usr_mask, nhead, need_usr=True, drop=None):
-    """SegFormerXAttention.forward, ablation 'ours', sr_ratio=1 (encoder.py:75-175).
+def attn_mode(abl: str) -> str:
+    """Key blocks of the ablation variants (encoder.py:108-161): 'CrossAtt' in type -> the other side's keys only,
+    'SelfAtt' in type -> the own side's keys only (and the user branch returns None, :172-173), else both."""
+    return "cross" if "CrossAtt" in abl else ("self" if "SelfAtt" in abl else "joint")
+
+
+def cross_attention(sd, pre, vid, vid_mask, usr, usr_mask, nhead, need_usr=True, drop=None, mode="joint"):
+    """SegFormerXAttention.forward, sr_ratio=1 (encoder.py:75-175); ``mode`` from :func:`attn_mode`.
 
     ``drop`` is None (eval) or a callable applying dropout; note the reference drops the RAW
     logits (mask fills included) BEFORE the 1/sqrt(dh) scale and the softmax (encoder.py:144-146).
+    Projections whose result the reference computes but never uses (e.g. v2v under CrossAtt) are skipped.
     """
     B, Lv, d = vid.shape
     Lt = usr.shape[1]
     dh = d // nhead
     do = drop if drop is not None else (lambda t: t)
-    v2v_val = _lin(sd, pre + ".v2v_proj.2", vid)
-    t2v_val = _lin(sd, pre + ".t2v_proj.2", usr)
-    v2v = attn_logits(sd, pre + ".v2v_proj", vid, vid_mask, vid, vid_mask, nhead)
-    t2v = attn_logits(sd, pre + ".t2v_proj", usr, usr_mask, vid, vid_mask, nhead)
-    v_val = torch.cat([v2v_val, t2v_val], 1).view(B, Lv + Lt, nhead, dh)
-    v_logits = do(torch.cat([v2v, t2v], -1)) / math.sqrt(dh)
+    vals, logits = [], []
+    if mode != "cross":
+        vals.append(_lin(sd, pre + ".v2v_proj.2", vid))
+        logits.append(attn_logits(sd, pre + ".v2v_proj", vid, vid_mask, vid, vid_mask, nhead))
+    if mode != "self":
+        vals.append(_lin(sd, pre + ".t2v_proj.2", usr))
+        logits.append(attn_logits(sd, pre + ".t2v_proj", usr, usr_mask, vid, vid_mask, nhead))
+    v_val = torch.cat(vals, 1)
+    v_val = v_val.view(B, v_val.shape[1], nhead, dh)
+    v_logits = do(torch.cat(logits, -1)) / math.sqrt(dh)
     vid_ = torch.einsum("bhqk,bkhd->bqhd", F.softmax(v_logits, -1), v_val).reshape(B, Lv, d)
     vid_ = do(_lin(sd, pre + ".ff_vid", vid_))
     vid_out = _ln(sd, pre + ".ln_vid", vid + vid_)
     usr_out = None
-    if need_usr:
-        v2t_val = _lin(sd, pre + ".v2t_proj.2", vid)
-        t2t_val = _lin(sd, pre + ".t2t_proj.2", usr)
-        v2t = attn_logits(sd, pre + ".v2t_proj", vid, vid_mask, usr, usr_mask, nhead)
-        t2t = attn_logits(sd, pre + ".t2t_proj", usr, usr_mask, usr, usr_mask, nhead)
-        t_val = torch.cat([v2t_val, t2t_val], 1).view(B, Lv + Lt, nhead, dh)
-        t_logits = do(torch.cat([v2t, t2t], -1)) / math.sqrt(dh)
+    if need_usr and mode != "self":          # SelfAtt: the user branch is computed and thrown away (encoder.py:172-173)
+        vals = [_lin(sd, pre + ".v2t_proj.2", vid)]
+        logits = [attn_logits(sd, pre + ".v2t_proj", vid, vid_mask, usr, usr_mask, nhead)]
+        if mode == "joint":
+            vals.append(_lin(sd, pre + ".t2t_proj.2", usr))
+            logits.append(attn_logits(sd, pre + ".t2t_proj", usr, usr_mask, usr, usr_mask, nhead))
+        t_val = torch.cat(vals, 1)
+        t_val = t_val.view(B, t_val.shape[1], nhead, dh)
+        t_logits = do(torch.cat(logits, -1)) / math.sqrt(dh)
         usr_ = torch.einsum("bhqk,bkhd->bqhd", F.softmax(t_logits, -1), t_val).reshape(B, Lt, d)
         usr_ = do(_lin(sd, pre + ".ff_usr", usr_))
         usr_out = _ln(sd, pre + ".ln_usr", usr + usr_)
@@ -90,23 +103,28 @@ def mlp_gelu(sd, pre, x, drop=None):
     return _lin(sd, pre + ".layers.1", do(F.gelu(_lin(sd, pre + ".layers.0", x))))
 
 
-def encoder_layer(sd, pre, usr, usr_mask, vid, vid_mask, nhead, need_usr=True, drop=None):
+def encoder_layer(sd, pre, usr, usr_mask, vid, vid_mask, nhead, need_usr=True, drop=None, mode="joint"):
     """SegFormerXEncoderLayer.forward (encoder.py:189-208): post-LN attention block then post-LN FFN."""
     do = drop if drop is not None else (lambda t: t)
-    vid, usr_new = cross_attention(sd, pre + ".cross_attn", vid, vid_mask, usr, usr_mask, nhead, need_usr, drop)
+    vid, usr_new = cross_attention(sd, pre + ".cross_attn", vid, vid_mask, usr, usr_mask, nhead, need_usr, drop, mode)
     vid = _ln(sd, pre + ".ln_vid", vid + do(mlp_gelu(sd, pre + ".ff_vid", vid, drop)))
     if usr_new is not None:
         usr_new = _ln(sd, pre + ".ln_usr", usr_new + do(mlp_gelu(sd, pre + ".ff_usr", usr_new, drop)))
     return vid, usr_new
 
 
-def embedding(sd, pre, usr_feat, vid_feat, drop=None):
+def embedding(sd, pre, usr_feat, vid_feat, drop=None, abl="ours"):
     """SegFormerX._get_embedding with use_pe=1 (encoder.py:425-473).  2-D inputs are id tensors
-    ([B,S] item ids broadcast over segments / [B,1] user id), 3-D inputs are features."""
+    ([B,S] item ids broadcast over segments / [B,1] user id), 3-D inputs are features.  'noPos' in the ablation
+    type: the segment positions of every row are a fresh ``torch.randperm`` (global CPU generator, :428-429)."""
     do = drop if drop is not None else (lambda t: t)
     if vid_feat.dim() == 2:
         B, Lv = vid_feat.shape
-        pos = torch.arange(Lv, dtype=sd[pre + ".frameid_proj.weight"].dtype)[None, :, None].expand(B, Lv, 1)
+        wdt = sd[pre + ".frameid_proj.weight"].dtype
+        if "noPos" in abl:
+            pos = torch.stack([torch.randperm(Lv) for _ in range(B)]).to(wdt)[:, :, None]
+        else:
+            pos = torch.arange(Lv, dtype=wdt)[None, :, None].expand(B, Lv, 1)
         v = torch.cat([F.embedding(vid_feat, sd[pre + ".vid_proj.weight"]),
                        _lin(sd, pre + ".frameid_proj", pos)], -1)
     else:
@@ -120,21 +138,39 @@ def embedding(sd, pre, usr_feat, vid_feat, drop=None):
     return v, u
 
 
+def mlp_block(sd, pre, x, drop=None):
+    """MLP_Block.forward (encoder.py:210-252) as SegFormerX builds it (:392-400): [Linear, ReLU, Dropout(p)] per hidden
+    unit, then the output Linear.  The Sequential indices of the Linears are read off the state_dict keys."""
+    do = drop if drop is not None else (lambda t: t)
+    idx = sorted({int(k[len(pre) + 1:].split(".")[0]) for k in sd if k.startswith(pre + ".") and k.endswith(".weight")})
+    for i in idx[:-1]:
+        x = do(F.relu(_lin(sd, "%s.%d" % (pre, i), x)))
+    return _lin(sd, "%s.%d" % (pre, idx[-1]), x)
+
+
 def backbone_forward(sd, pre, usr_feat, usr_mask, vid_feat, vid_mask, N, nhead, S,
-                     skip_dead=True, drop=None):
+                     skip_dead=True, drop=None, abl="ours"):
     """SegFormerX.forward + SegFormerXEncoder.forward with output_layers=[-1]
     (encoder.py:475-520, 302-324).  The encoder records the INPUT of every layer
     (encoder.py:316-319) and [-1] selects the input of the last layer, so layer N-1 is dead and
     layer N-2 is live on the video side only; ``skip_dead=False`` executes them anyway, like the
-    reference does, without changing any output."""
+    reference does, without changing any output.  ``abl`` = model_cfg.ablation_type (:387-400,503-511)."""
     if usr_feat.dim() == 1:                       # encoder.py:478-481
         usr_feat = usr_feat[:, None]
         usr_mask = torch.ones(usr_feat.shape, dtype=torch.bool)
     if vid_feat.dim() == 1:                       # encoder.py:484-486 (40 generalised to S)
         vid_feat = vid_feat[:, None].repeat(1, S)
     usr_mask = usr_mask.bool()
-    vid, usr = embedding(sd, pre, usr_feat, vid_feat, drop)
+    vid, usr = embedding(sd, pre, usr_feat, vid_feat, drop, abl)
     usr_emb = usr
+    if abl == "CrossMLP":                         # encoder.py:503-506: MLP over cat(user, video) tokens, pooled to 40 tokens
+        z = mlp_block(sd, pre + ".encoder_mlp.mlp", torch.cat((usr, vid), dim=-2), drop)
+        return F.adaptive_avg_pool1d(z.permute(0, 2, 1), 40).permute(0, 2, 1), usr_emb
+    if abl == "SelfMLP":                          # :507-509
+        return mlp_block(sd, pre + ".encoder_mlp.mlp", vid, drop), usr_emb
+    if abl == "w/oAtt":                           # :510-511
+        return vid, usr_emb
+    mode = attn_mode(abl)
     out = None
     for i in range(N):
         if i == N - 1:
@@ -143,7 +179,7 @@ def backbone_forward(sd, pre, usr_feat, usr_mask, vid_feat, vid_mask, N, nhead, 
                 break
         need_usr = (i < N - 2) or not skip_dead
         vid, usr_new = encoder_layer(sd, "%s.encoder.layers.%d" % (pre, i), usr, usr_mask, vid, vid_mask,
-                                     nhead, need_usr, drop)
+                                     nhead, need_usr, drop, mode)
         if usr_new is not None:
             usr = usr_new
     return out, usr_emb
@@ -306,6 +342,9 @@ def model_forward(sd: Dict[str, torch.Tensor], cfg: dict, inp: Dict[str, torch.T
     """MultiScaleTemporalDetrLeaveFocal.forward (decoder_leave_focal.py:574-658)."""
     N, h, S = cfg["N"], cfg["h"], cfg["S"]
     u_t, p_t = cfg["user"], cfg["photo"]
+    abl = cfg.get("ablation_type", "ours")
+    if cfg.get("fwd_seed") is not None:      # fixture hook: the 'noPos' goldens reseed torch before every forward
+        torch.manual_seed(cfg["fwd_seed"])
 
     def pick(kind, image, ident, which):
         if kind == "both":
@@ -315,15 +354,15 @@ def model_forward(sd: Dict[str, torch.Tensor], cfg: dict, inp: Dict[str, torch.T
     if u_t != "both" and p_t != "both":
         vid, _ = backbone_forward(sd, "backbone1", pick(u_t, inp["usr_image"], inp["usr_id"], 1), inp["usr_mask"],
                                   pick(p_t, inp["vid_image"], inp["vid_id"], 1), inp["vid_mask"], N, h, S,
-                                  skip_dead, drop)
+                                  skip_dead, drop, abl)
         logits = _lin(sd, "stage_mlp1", vid).squeeze(-1)
     else:
         v1, _ = backbone_forward(sd, "backbone1", pick(u_t, inp["usr_image"], inp["usr_id"], 1), inp["usr_mask"],
                                  pick(p_t, inp["vid_image"], inp["vid_id"], 1), inp["vid_mask"], N, h, S,
-                                 skip_dead, drop)
+                                 skip_dead, drop, abl)
         v2, _ = backbone_forward(sd, "backbone2", pick(u_t, inp["usr_image"], inp["usr_id"], 2), inp["usr_mask"],
                                  pick(p_t, inp["vid_image"], inp["vid_id"], 2), inp["vid_mask"], N, h, S,
-                                 skip_dead, drop)
+                                 skip_dead, drop, abl)
         fh = cfg.get("fusion_heads", 2)
         if fh in (-2, -3):
             logits = _lin(sd, "stage_mlp1", v1 + v2).squeeze(-1)

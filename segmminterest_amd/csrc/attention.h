@@ -182,8 +182,13 @@ __device__ __forceinline__ void stage_kmask(uint8_t* km, const uint8_t* mka, con
 // relative error is ~1e-6 at |x| < 20 and anything below -87 flushes to 0 exactly like expf.
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
 
-// scaled/masked/dropped logit
+// scaled/masked/dropped logit.  The products must be ROUNDED fp32 values, identically in every kernel: with contraction on,
+// the compiler folds the last multiply into the caller's "v - rowmax" as fma(t, scale, -rowmax) in some kernels and not in
+// others; for a masked query row (every logit -10000*scale = -3535.5.., ulp 2.4e-4) the backward then recomputed
+// exp(v - rowmax) as exp(+-1e-4) instead of exp(0) against the forward's 1/sum: a 1e-4 relative error on the probabilities
+// of padded rows (measured on dV, tools/attn_err_probe.py).
 __device__ __forceinline__ float logit_xform(float s, bool valid, float mult, float scale) {
+#pragma clang fp contract(off)
     return (valid ? s : -10000.0f) * mult * scale;
 }
 
@@ -457,8 +462,8 @@ __global__ __launch_bounds__(ATT_BWD_THREADS) void attn_bwd_dq_kernel(const Attn
     }
     float am = 0.f;
     if (q_in) {
-        am = col_store<DH>(p.dQa + qrow * p.lddq + col0, da, g, am);
-        am = col_store<DH>(p.dQb + qrow * p.lddq + col0, db, g, am);
+        if (p.dQa) am = col_store<DH>(p.dQa + qrow * p.lddq + col0, da, g, am);      // null: empty key block (ablations)
+        if (p.dQb) am = col_store<DH>(p.dQb + qrow * p.lddq + col0, db, g, am);
     }
     if (p.amax_q) amax_commit(p.amax_q, am, (blockIdx.x * gridDim.y + blockIdx.y) * wpb + wave);
 }

@@ -32,8 +32,13 @@ static int attn_fill(AttnArgs& a, int B, int H, int dh, int Lq, int La, int Lb, 
                      const float* Ka, const float* Va, int ldka, const float* Kb, const float* Vb, int ldkb,
                      const uint8_t* mq, const uint8_t* mka, const uint8_t* mkb, float drop_p, uint64_t seed,
                      uint32_t site) {
+    SEGMM_REQUIRE(B > 0 && H > 0 && Lq > 0 && La >= 0 && Lb >= 0 && La + Lb > 0, "attn: empty dimension");
+    // One key block may be EMPTY (La == 0 or Lb == 0): the CrossAtt / SelfAtt ablations of the reference attend to one
+    // block only (encoder.py:108-135).  Its pointers may then be null; reads are aliased to the other block's tensors
+    // (never dereferenced for a key tile, the query fragment of the empty block is loaded but unused).
+    if (La == 0) { Qa = Qb; Ka = Kb; Va = Vb; ldka = ldkb; mka = mkb; }
+    if (Lb == 0) { Qb = Qa; Kb = Ka; Vb = Va; ldkb = ldka; mkb = mka; }
     SEGMM_REQUIRE(Qa && Qb && Ka && Va && Kb && Vb && mq && mka && mkb, "attn: null pointer");
-    SEGMM_REQUIRE(B > 0 && H > 0 && Lq > 0 && La > 0 && Lb > 0, "attn: empty dimension");
     SEGMM_REQUIRE(dh == 4 || dh == 8 || dh == 16 || dh == 32 || dh == 48 || dh == 64, "attn: head dim %d not built (4,8,16,32,48,64)", dh);
     SEGMM_REQUIRE(ldq % 4 == 0 && ldka % 4 == 0 && ldkb % 4 == 0, "attn: leading dims %% 4");
     SEGMM_REQUIRE(aligned16(Qa) && aligned16(Qb) && aligned16(Ka) && aligned16(Va) && aligned16(Kb) && aligned16(Vb), "attn: alignment");
@@ -45,7 +50,7 @@ static int attn_fill(AttnArgs& a, int B, int H, int dh, int Lq, int La, int Lb, 
     a.scale = 1.0f / sqrtf((float)dh);
     a.drop = make_drop(drop_p, seed, site);
     {   // K/V/Q views are addressed through 32-bit buffer offsets (tile overhang of 15 rows included)
-        const size_t ka = ((size_t)B * La - 1) * ldka + (size_t)H * dh, kb = ((size_t)B * Lb - 1) * ldkb + (size_t)H * dh;
+        const size_t ka = La ? ((size_t)B * La - 1) * ldka + (size_t)H * dh : 0, kb = Lb ? ((size_t)B * Lb - 1) * ldkb + (size_t)H * dh : 0;
         const size_t q = ((size_t)B * Lq - 1) * ldq + (size_t)H * dh;
         SEGMM_REQUIRE(((size_t)B * La + 16) * ldka * 4 < (1ull << 32) && ((size_t)B * Lb + 16) * ldkb * 4 < (1ull << 32) &&
                       ((size_t)B * Lq + 16) * ldq * 4 < (1ull << 32), "attn: a K/V/Q view exceeds the 4 GiB buffer-addressing window");
@@ -144,7 +149,7 @@ __global__ void dropout_mult_kernel(float* out, long long n, DropCfg d) {
 extern "C" {
 
 const char* segmm_last_error(void) { return g_segmm_err; }
-int segmm_abi_version(void) { return 6; }
+int segmm_abi_version(void) { return 7; }
 
 int segmm_l1norm(const float* x, float* y, float* inv_scale, int64_t rows, int D, segmm_stream_t stream) {
     SEGMM_REQUIRE(x && (y || inv_scale), "l1norm: null pointer");
@@ -186,7 +191,8 @@ static int gemm_impl(int layout, int M, int N, int K, const float* A, int lda, c
     if (layout == 2) SEGMM_REQUIRE(M % 4 == 0, "gemm: M %% 4 != 0 for the transposed A operand (M=%d)", M);
     SEGMM_REQUIRE(!bias || aligned16(bias), "gemm: bias alignment");
     SEGMM_REQUIRE(!residual || (aligned16(residual) && ldr % 4 == 0 && res_period > 0), "gemm: residual alignment/period");
-    SEGMM_REQUIRE(activation == 0 || (aux && aligned16(aux) && ldaux % 4 == 0), "gemm: activation needs aux");
+    SEGMM_REQUIRE(activation >= 0 && activation <= 4, "gemm: activation %d", activation);
+    SEGMM_REQUIRE(activation == 0 || activation == EPI_RELU || (aux && aligned16(aux) && ldaux % 4 == 0), "gemm: activation needs aux");
     SEGMM_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "gemm: dropout p=%f", drop_p);
     if (splits < 1) splits = 1;
     GemmArgs g;
@@ -435,9 +441,12 @@ int segmm_attn_bwd(int B, int H, int dh, int Lq, int La, int Lb, const float* Qa
     memset(&a, 0, sizeof(a));
     int rc = attn_fill(a, B, H, dh, Lq, La, Lb, Qa, Qb, ldq, Ka, Va, ldka, Kb, Vb, ldkb, mq, mka, mkb, drop_p, seed, site);
     if (rc) return rc;
-    SEGMM_REQUIRE(lse && O && dO && Dvec && dQa && dQb && dKa && dVa && dKb && dVb, "attn_bwd: null pointer");
+    SEGMM_REQUIRE(lse && O && dO && Dvec, "attn_bwd: null pointer");
+    SEGMM_REQUIRE((La == 0 || (dQa && dKa && dVa)) && (Lb == 0 || (dQb && dKb && dVb)), "attn_bwd: null gradient pointer of a non-empty key block");
+    if (La == 0) { dQa = nullptr; dKa = dKb; dVa = dVb; lddka = lddkb; }      // dQ of an empty block is not written
+    if (Lb == 0) { dQb = nullptr; dKb = dKa; dVb = dVa; lddkb = lddka; }
     SEGMM_REQUIRE(lddo % 4 == 0 && ldo % 4 == 0 && lddq % 4 == 0 && lddka % 4 == 0 && lddkb % 4 == 0, "attn_bwd: leading dims %% 4");
-    SEGMM_REQUIRE(aligned16(O) && aligned16(dO) && aligned16(dQa) && aligned16(dQb) && aligned16(dKa) && aligned16(dVa) && aligned16(dKb) && aligned16(dVb), "attn_bwd: alignment");
+    SEGMM_REQUIRE(aligned16(O) && aligned16(dO) && (!dQa || aligned16(dQa)) && (!dQb || aligned16(dQb)) && aligned16(dKa) && aligned16(dVa) && aligned16(dKb) && aligned16(dVb), "attn_bwd: alignment");
     a.lse = (float*)lse; a.O = (float*)O; a.ldo = ldo; a.dO = dO; a.lddo = lddo; a.Dvec = Dvec;
     SEGMM_REQUIRE(((size_t)B * Lq + 16) * lddo * 4 < (1ull << 32), "attn_bwd: dO exceeds the 4 GiB buffer-addressing window");
     a.do_bytes = (uint32_t)((((size_t)B * Lq - 1) * lddo + (size_t)H * dh) * 4);
@@ -494,12 +503,13 @@ int segmm_vecsum(const float* v, int64_t n, float* out, int accumulate, segmm_st
 }
 
 int segmm_embed_id_vid(const int64_t* item_id, const float* table, int dhalf, const float* frame_w,
-                       const float* frame_b, const float* pe, float* out, int B, int S, int64_t n_rows, segmm_stream_t stream) {
+                       const float* frame_b, const float* pe, const float* frame_pos, float* out, int B, int S, int64_t n_rows,
+                       segmm_stream_t stream) {
     SEGMM_REQUIRE(item_id && table && frame_w && frame_b && pe && out && n_rows > 0, "embed_id_vid: null pointer / empty table");
     SEGMM_REQUIRE(dhalf % 4 == 0 && aligned16(table) && aligned16(frame_w) && aligned16(frame_b) && aligned16(pe) && aligned16(out), "embed_id_vid: d/2 %% 4 / alignment");
     if (B <= 0) return 0;
     hipLaunchKernelGGL(embed_id_vid_kernel, dim3(B * S), dim3(64), 0, (hipStream_t)stream, (const long long*)item_id, table, dhalf,
-                       frame_w, frame_b, pe, out, B, S, (long long)n_rows);
+                       frame_w, frame_b, pe, frame_pos, out, B, S, (long long)n_rows);
     LAUNCH_CHECK();
     return 0;
 }
@@ -633,6 +643,25 @@ int segmm_segment_weighted_sum(const float* pred, const float* weight, const int
     if (rows <= 0) return 0;
     hipLaunchKernelGGL(segment_weighted_sum_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, pred, weight,
                        (const long long*)duration, (long long)rows, S, out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int segmm_pool_tokens(const float* U, int Lu, const float* V, int Lv, float* out, int B, int d, int bins, segmm_stream_t stream) {
+    SEGMM_REQUIRE(U && V && out && Lu > 0 && Lv > 0 && bins > 0 && d % 4 == 0 && aligned16(U) && aligned16(V) && aligned16(out),
+                  "pool_tokens: pointer/alignment");
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(pool_tokens_kernel, dim3((unsigned)(B * bins)), dim3(256), 0, (hipStream_t)stream, U, Lu, V, Lv, out, d, bins);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int segmm_pool_tokens_bwd(const float* dOut, float* dU, int Lu, float* dV, int Lv, int B, int d, int bins, segmm_stream_t stream) {
+    SEGMM_REQUIRE(dOut && dU && dV && Lu > 0 && Lv > 0 && bins > 0 && d % 4 == 0 && aligned16(dOut) && aligned16(dU) && aligned16(dV),
+                  "pool_tokens_bwd: pointer/alignment");
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(pool_tokens_bwd_kernel, dim3((unsigned)(B * (Lu + Lv))), dim3(256), 0, (hipStream_t)stream, dOut, dU, Lu, dV, Lv,
+                       d, bins);
     LAUNCH_CHECK();
     return 0;
 }

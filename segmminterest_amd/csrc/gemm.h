@@ -26,7 +26,7 @@ constexpr int GLDK = GBK + 4;    // row stride of a k-contiguous LDS tile  [128]
 constexpr int GLDM = GBM + 4;    // row stride of an m-contiguous LDS tile [32][132]
 constexpr int GTILE = (GBM * GLDK > GBK * GLDM) ? GBM * GLDK : GBK * GLDM;   // 4608 floats
 
-enum { EPI_NONE = 0, EPI_GELU = 1, EPI_DGELU = 2 };
+enum { EPI_NONE = 0, EPI_GELU = 1, EPI_DGELU = 2, EPI_RELU = 3, EPI_DRELU = 4 };
 
 struct GemmArgs {
     int M, N, K;
@@ -204,6 +204,12 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmArgs p) {
                             const f32x4 g = *(const f32x4*)(p.aux + (size_t)gm * p.ldaux + gn);
                             v.x *= gelu_erf_grad(g.x); v.y *= gelu_erf_grad(g.y);
                             v.z *= gelu_erf_grad(g.z); v.w *= gelu_erf_grad(g.w);
+                        } else if (p.epi == EPI_RELU) {
+                            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                        } else if (p.epi == EPI_DRELU) {      // aux = the forward OUTPUT (post-ReLU, post-dropout): > 0 iff z > 0 and kept
+                            const f32x4 g = *(const f32x4*)(p.aux + (size_t)gm * p.ldaux + gn);
+                            v.x = g.x > 0.f ? v.x : 0.f; v.y = g.y > 0.f ? v.y : 0.f;
+                            v.z = g.z > 0.f ? v.z : 0.f; v.w = g.w > 0.f ? v.w : 0.f;
                         }
                         if (p.drop.p > 0.f) v = drop_apply4(p.drop, ((uint64_t)gm * (uint64_t)p.N + gn) >> 2, v);
                         if (p.residual) v += *(const f32x4*)(p.residual + (size_t)(gm % p.res_period) * p.ldr + gn);

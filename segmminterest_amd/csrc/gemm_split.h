@@ -360,6 +360,12 @@ __global__ __launch_bounds__(256, 2) void gemm_split_mfma(const GemmArgs p, cons
                             const f32x4 g = *(const f32x4*)(p.aux + (size_t)gm * p.ldaux + gn);
                             v.x *= gelu_erf_grad(g.x); v.y *= gelu_erf_grad(g.y);
                             v.z *= gelu_erf_grad(g.z); v.w *= gelu_erf_grad(g.w);
+                        } else if (p.epi == EPI_RELU) {
+                            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                        } else if (p.epi == EPI_DRELU) {      // aux = the forward OUTPUT (post-ReLU, post-dropout): > 0 iff z > 0 and kept
+                            const f32x4 g = *(const f32x4*)(p.aux + (size_t)gm * p.ldaux + gn);
+                            v.x = g.x > 0.f ? v.x : 0.f; v.y = g.y > 0.f ? v.y : 0.f;
+                            v.z = g.z > 0.f ? v.z : 0.f; v.w = g.w > 0.f ? v.w : 0.f;
                         }
                         if (p.drop.p > 0.f) v = drop_apply4(p.drop, ((uint64_t)gm * (uint64_t)p.N + gn) >> 2, v);
                         if (p.residual) v += *(const f32x4*)(p.residual + (size_t)(gm % p.res_period) * p.ldr + gn);

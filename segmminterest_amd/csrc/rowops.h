@@ -281,20 +281,22 @@ __global__ __launch_bounds__(1024) void vecsum_kernel(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------- id-mode embedding (encoder.py:426-435,445,484-486)
-// vid[b,s,:] = cat(E_item[item_id[b]], frame_w * s + frame_b) + pe[s]     (pre-LayerNorm)
+// vid[b,s,:] = cat(E_item[item_id[b]], frame_w * pos[b,s] + frame_b) + pe[s]     (pre-LayerNorm; pos[b,s] = s unless given)
 __global__ __launch_bounds__(256) void embed_id_vid_kernel(const long long* __restrict__ item_id, const float* __restrict__ table, int dhalf,
                                     const float* __restrict__ frame_w, const float* __restrict__ frame_b,
-                                    const float* __restrict__ pe, float* __restrict__ out, int B, int S, long long n_rows) {
+                                    const float* __restrict__ pe, const float* __restrict__ frame_pos,
+                                    float* __restrict__ out, int B, int S, long long n_rows) {
     const int d = 2 * dhalf;
     const long long row = blockIdx.x;       // b*S + s
     const int b = (int)(row / S), s = (int)(row % S);
+    const float fpos = frame_pos ? frame_pos[row] : (float)s;     // 'noPos' ablation: shuffled positions (encoder.py:428-429)
     const long long id = item_id[b];
     const bool ok = id >= 0 && id < n_rows;  // torch.nn.Embedding raises on such an id; here the row is poisoned with NaN
     const float nan = __uint_as_float(0x7fc00000u);
     for (int c = threadIdx.x * 4; c < d; c += blockDim.x * 4) {
         f32x4 v;
         if (c < dhalf) v = ok ? *(const f32x4*)(table + id * dhalf + c) : f32x4{nan, nan, nan, nan};
-        else v = *(const f32x4*)(frame_w + (c - dhalf)) * (float)s + *(const f32x4*)(frame_b + (c - dhalf));
+        else v = *(const f32x4*)(frame_w + (c - dhalf)) * fpos + *(const f32x4*)(frame_b + (c - dhalf));
         v += *(const f32x4*)(pe + (size_t)s * d + c);
         *(f32x4*)(out + row * d + c) = v;
     }
@@ -374,6 +376,47 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
         const float vv = v[i] * b2 + gg * gg * (1.0f - b2);
         pp -= step * (mm / (sqrtf(vv) / bc2_sqrt + eps));
         p[i] = pp; m[i] = mm; v[i] = vv;
+    }
+}
+
+// ---------------------------------------------------------------- CrossMLP ablation: AdaptiveAvgPool1d over tokens
+// out[b, i, :] = mean over t in [floor(i T / bins), ceil((i+1) T / bins)) of cat(U[b], V[b])[t, :], T = Lu + Lv
+// (encoder.py:396,503-506: nn.AdaptiveAvgPool1d(40) over the token axis of the concatenated user and video tokens;
+// neighbouring bins overlap when T is not a multiple of bins).
+__device__ __forceinline__ void pool_bin(int i, int T, int bins, int& t0, int& t1) {
+    t0 = (int)(((long long)i * T) / bins);
+    t1 = (int)((((long long)(i + 1)) * T + bins - 1) / bins);
+}
+__global__ __launch_bounds__(256) void pool_tokens_kernel(const float* __restrict__ U, int Lu, const float* __restrict__ V, int Lv,
+                                                          float* __restrict__ out, int d, int bins) {
+    const int b = blockIdx.x / bins, i = blockIdx.x % bins, T = Lu + Lv;
+    int t0, t1;
+    pool_bin(i, T, bins, t0, t1);
+    for (int c = threadIdx.x * 4; c < d; c += blockDim.x * 4) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int t = t0; t < t1; ++t)
+            acc += t < Lu ? *(const f32x4*)(U + ((size_t)b * Lu + t) * d + c) : *(const f32x4*)(V + ((size_t)b * Lv + (t - Lu)) * d + c);
+        const float n = (float)(t1 - t0);
+        *(f32x4*)(out + (size_t)blockIdx.x * d + c) = f32x4{acc.x / n, acc.y / n, acc.z / n, acc.w / n};
+    }
+}
+// dU / dV[b, t, :] = sum over the bins i that contain t of dOut[b, i, :] / |bin i|   (fixed order: deterministic)
+__global__ __launch_bounds__(256) void pool_tokens_bwd_kernel(const float* __restrict__ dOut, float* __restrict__ dU, int Lu,
+                                                              float* __restrict__ dV, int Lv, int d, int bins) {
+    const int T = Lu + Lv, b = blockIdx.x / T, t = blockIdx.x % T;
+    float* dst = t < Lu ? dU + ((size_t)b * Lu + t) * d : dV + ((size_t)b * Lv + (t - Lu)) * d;
+    for (int c = threadIdx.x * 4; c < d; c += blockDim.x * 4) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < bins; ++i) {
+            int t0, t1;
+            pool_bin(i, T, bins, t0, t1);
+            if (t >= t0 && t < t1) {
+                const f32x4 g = *(const f32x4*)(dOut + ((size_t)b * bins + i) * d + c);
+                const float n = (float)(t1 - t0);
+                acc += f32x4{g.x / n, g.y / n, g.z / n, g.w / n};
+            }
+        }
+        *(f32x4*)(dst + c) = acc;
     }
 }
 

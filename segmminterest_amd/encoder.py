@@ -108,17 +108,23 @@ class SegFormerXEncoder(_FusedOnly):
             nn.Conv1d(dims[i - 1], dims[i], kernel_size=3, stride=2, padding=1) for i in range(1, len(dims))])
 
 
-class MLP_Block(nn.Module):
-    """Generic MLP of the ablation variants (encoder.py:210-252); plain torch, not on the hot path."""
+class MLP_Block(_FusedOnly):
+    """Parameter container of the ablation variants' MLP (encoder.py:210-252): same constructor and ``mlp.{i}`` state_dict
+    keys; ``SegFormerX`` runs it inside the HIP engine (``engine.BackboneRun._mlp_fwd``)."""
 
     def __init__(self, input_dim, hidden_units=[], hidden_activations="ReLU", output_dim=None, output_activation=None,
                  dropout_rates=0.0, batch_norm=False, layer_norm=False, norm_before_activation=True, use_bias=True):
         super().__init__()
+        if batch_norm or layer_norm or output_activation is not None or output_dim is None:
+            raise NotImplementedError("MLP_Block: only the form SegFormerX builds (Linear/ReLU/Dropout + output Linear, "
+                                      "encoder.py:392-400) runs in the HIP engine")
         hidden_units = list(hidden_units)
         if not isinstance(dropout_rates, list):
             dropout_rates = [dropout_rates] * len(hidden_units)
         if not isinstance(hidden_activations, list):
             hidden_activations = [hidden_activations] * len(hidden_units)
+        if any(a != "ReLU" for a in hidden_activations):
+            raise NotImplementedError("MLP_Block: hidden activation must be ReLU")
         acts = [getattr(nn, a)() for a in hidden_activations]
         dims = [input_dim] + hidden_units
         mods = []
@@ -138,8 +144,11 @@ class MLP_Block(nn.Module):
             mods.append(getattr(nn, output_activation)())
         self.mlp = nn.Sequential(*mods)
 
-    def forward(self, x):
-        return self.mlp(x)
+
+# --ablation_type choices of the trainers (main...SegMM.py:529).  Model side: 'CrossAtt' / 'SelfAtt' restrict the key
+# blocks (encoder.py:108-135), 'noPos' shuffles the id-mode segment positions (:428-429), the *MLP / w/oAtt variants replace
+# the encoder (:392-400,503-511); 'noUser' is applied by the trainer (random user inputs, main...SegMM.py:275-280).
+ABLATION_TYPES = ("ours", "CrossAtt", "SelfAtt", "noPos", "noUser", "SelfMLP", "CrossMLP", "noUser_SelfAtt", "w/oAtt")
 
 
 class SegFormerX(nn.Module):
@@ -178,11 +187,20 @@ class SegFormerX(nn.Module):
         self.usr_ln = nn.LayerNorm(d, eps=1e-12)
         self.dropout_p = dropout
         self.ablation_type = getattr(model_cfg, "ablation_type", "ours") if model_cfg is not None else "ours"
-        if self.ablation_type != "ours":
-            raise NotImplementedError("ablation_type=%r: only the primary 'ours' path is built in HIP (SURVEY.md §8(a) notes)"
-                                      % self.ablation_type)
-        self.encoder = SegFormerXEncoder(d, list(d_model_lvls), list(num_head_lvls), list(sr_ratio_lvls),
-                                         list(ff_dim_lvls), list(use_patch_merge), dropout, self.ablation_type)
+        if self.ablation_type not in ABLATION_TYPES:
+            raise ValueError("ablation_type=%r not in %s (main...SegMM.py:529)" % (self.ablation_type, ABLATION_TYPES))
+        # encoder.py:392-409: the MLP ablations build encoder_mlp INSTEAD of the encoder (w/oAtt builds it and never calls it)
+        lvls = list(d_model_lvls)
+        if self.ablation_type == "CrossMLP":
+            self.encoder_mlp = MLP_Block(input_dim=lvls[0], output_dim=lvls[0], hidden_units=lvls[2:-2],
+                                         hidden_activations="ReLU", dropout_rates=dropout, batch_norm=0)
+            self.encoder_pooling = nn.AdaptiveAvgPool1d(40)
+        elif self.ablation_type in ("SelfMLP", "w/oAtt"):
+            self.encoder_mlp = MLP_Block(input_dim=lvls[0], output_dim=lvls[0], hidden_units=lvls[1:-1],
+                                         hidden_activations="ReLU", dropout_rates=dropout, batch_norm=0)
+        else:
+            self.encoder = SegFormerXEncoder(d, lvls, list(num_head_lvls), list(sr_ratio_lvls),
+                                             list(ff_dim_lvls), list(use_patch_merge), dropout, self.ablation_type)
         self.output_layers = list(range(len(sr_ratio_lvls))) if output_layers is None else list(output_layers)
         if self.output_layers != [-1]:
             raise NotImplementedError("output_layers must be [-1] as in the reference trainers (main...SegMM.py:95)")

@@ -39,34 +39,77 @@ def _j(prefix, name):
 
 
 # =============================================================================================== parameter store
+MLP_VARIANTS = ("CrossMLP", "SelfMLP", "w/oAtt")       # ablations that replace the encoder (encoder.py:392-400,503-511)
+K_MLP0 = 11                                             # dropout kinds 11.. : hidden layers of the ablation MLP_Block
+POOL_BINS = 40                                          # nn.AdaptiveAvgPool1d(40), encoder.py:396
+
+
+def attn_mode(bb) -> str:
+    """Which key blocks a query attends to (encoder.py:108-161): 'joint' = [video | user] keys (the model proper, also
+    'noPos' / 'noUser'), 'cross' = the OTHER side's keys only ('CrossAtt'), 'self' = the own side's keys only
+    ('SelfAtt', 'noUser_SelfAtt'; the user branch then returns None and user tokens never change, :172-173,316-319)."""
+    t = getattr(bb, "ablation_type", "ours")
+    return "cross" if "CrossAtt" in t else ("self" if "SelfAtt" in t else "joint")
+
+
+def layer_plan(mode: str, full: bool) -> Tuple[List[str], List[str]]:
+    """(vid_projs, usr_projs): the Linears of ``cross_attn`` that are LIVE and read video tokens / user tokens, in the order
+    they are fused into one GEMM each (xxx_proj.0 = query, .1 = key, .2 = value projection; t2v = user keys for video
+    queries, v2t = video keys for user queries).  ``full``: the user side of this layer is live as well."""
+    if mode == "joint":
+        vid = ["v2v_proj.0", "t2v_proj.0", "v2v_proj.1", "v2v_proj.2"] + (["v2t_proj.1", "v2t_proj.2"] if full else [])
+        usr = ["t2v_proj.1", "t2v_proj.2"] + (["v2t_proj.0", "t2t_proj.0", "t2t_proj.1", "t2t_proj.2"] if full else [])
+    elif mode == "cross":
+        vid = ["t2v_proj.0"] + (["v2t_proj.1", "v2t_proj.2"] if full else [])
+        usr = ["t2v_proj.1", "t2v_proj.2"] + (["v2t_proj.0"] if full else [])
+    else:
+        vid, usr = ["v2v_proj.0", "v2v_proj.1", "v2v_proj.2"], []
+    return vid, usr
+
+
+def mlp_linears(bb) -> List[str]:
+    """Names (relative to the backbone) of the Linears of the ablation ``encoder_mlp`` in forward order; the last one is the
+    output Linear, the others are followed by ReLU (+ Dropout when dropout > 0) -- encoder.py:210-252."""
+    return ["encoder_mlp.mlp.%d" % i for i, m in enumerate(bb.encoder_mlp.mlp) if isinstance(m, torch.nn.Linear)]
+
+
 def backbone_layout(prefix: str, bb) -> Tuple[List[Tuple[str, List[List[str]]]], None]:
     """Live parameter groups of one backbone in BACKWARD-completion order, as (bucket, groups).
     A group is a list of tensors that must be adjacent in memory (a fused GEMM reads them as one)."""
     N = bb.n_layers
+    abl = getattr(bb, "ablation_type", "ours")
+    mode = attn_mode(bb)
     buckets = []
-    for i in reversed(range(max(N - 1, 0))):
-        full = i < N - 2
-        L = "%sencoder.layers.%d." % (prefix, i)
-        ca = L + "cross_attn."
-        vidW = [ca + "v2v_proj.0", ca + "t2v_proj.0", ca + "v2v_proj.1", ca + "v2v_proj.2"]
-        usrW = [ca + "t2v_proj.1", ca + "t2v_proj.2"]
-        singles = [ca + "ff_vid", ca + "ln_vid", L + "ff_vid.layers.0", L + "ff_vid.layers.1", L + "ln_vid"]
-        if full:
-            vidW += [ca + "v2t_proj.1", ca + "v2t_proj.2"]
-            usrW += [ca + "v2t_proj.0", ca + "t2t_proj.0", ca + "t2t_proj.1", ca + "t2t_proj.2"]
-            singles += [ca + "ff_usr", ca + "ln_usr", L + "ff_usr.layers.0", L + "ff_usr.layers.1", L + "ln_usr"]
-        groups = [[n + ".weight" for n in vidW], [n + ".bias" for n in vidW],
-                  [n + ".weight" for n in usrW], [n + ".bias" for n in usrW]]
-        for s in singles:
-            groups += [[s + ".weight"], [s + ".bias"]]
-        buckets.append(("%slayer%d" % (prefix, i), groups))
+    usr_live = N >= 2 and mode != "self"       # with N == 1 (or SelfAtt) the user embedding only feeds dead compute
+    if abl in MLP_VARIANTS:
+        usr_live = abl == "CrossMLP"
+        if abl != "w/oAtt":                    # w/oAtt builds encoder_mlp but never calls it (encoder.py:397-400,510-511)
+            groups = []
+            for n in reversed(mlp_linears(bb)):
+                groups += [[prefix + n + ".weight"], [prefix + n + ".bias"]]
+            buckets.append((prefix + "mlp", groups))
+    else:
+        for i in reversed(range(max(N - 1, 0))):
+            full = i < N - 2 and mode != "self"
+            L = "%sencoder.layers.%d." % (prefix, i)
+            ca = L + "cross_attn."
+            vidP, usrP = layer_plan(mode, full)
+            singles = [ca + "ff_vid", ca + "ln_vid", L + "ff_vid.layers.0", L + "ff_vid.layers.1", L + "ln_vid"]
+            if full:
+                singles += [ca + "ff_usr", ca + "ln_usr", L + "ff_usr.layers.0", L + "ff_usr.layers.1", L + "ln_usr"]
+            groups = [[ca + n + ".weight" for n in vidP], [ca + n + ".bias" for n in vidP]]
+            if usrP:
+                groups += [[ca + n + ".weight" for n in usrP], [ca + n + ".bias" for n in usrP]]
+            for s in singles:
+                groups += [[s + ".weight"], [s + ".bias"]]
+            buckets.append(("%slayer%d" % (prefix, i), groups))
     emb = [[prefix + "vid_proj.weight"]]
     if bb.id_vid:
         emb += [[prefix + "frameid_proj.weight"], [prefix + "frameid_proj.bias"]]
     else:
         emb += [[prefix + "vid_proj.bias"]]
     emb += [[prefix + "vid_pe.weight"], [prefix + "vid_ln.weight"], [prefix + "vid_ln.bias"]]
-    if N >= 2:      # with N == 1 the user embedding only feeds the dead layer
+    if usr_live:
         emb += [[prefix + "usr_proj.weight"]]
         if not bb.id_usr:
             emb += [[prefix + "usr_proj.bias"]]
@@ -231,7 +274,8 @@ class ParamStore:
         for _, groups in self._layout():
             for grp in groups:
                 n0 = grp[0]
-                if n0.endswith(".weight") and ".encoder.layers." in "." + n0 and params[n0].dim() == 2 and "ln_" not in n0:
+                if n0.endswith(".weight") and (".encoder.layers." in "." + n0 or ".encoder_mlp.mlp." in "." + n0) \
+                        and params[n0].dim() == 2 and "ln_" not in n0:
                     self._transposes.append((self.index[n0][0], sum(params[n].shape[0] for n in grp), params[n0].shape[1]))
         # flat ranges read by GEMMs as the weight operand: the encoder-layer buckets and the input
         # projections when they are Linears (image mode); Embedding tables, positional tables and the head are not
@@ -419,6 +463,8 @@ class BackboneRun:
         self.d, self.H, self.N = bb.d_model, bb.nhead, bb.n_layers
         self.dh = self.d // self.H
         self.sv = {}
+        self.abl = getattr(bb, "ablation_type", "ours")
+        self.mode = attn_mode(bb)
 
     # ---------------------------------------------------------------- forward
     def forward(self, usr_feat, usr_mask, vid_feat, vid_mask, train: bool, seed: int):
@@ -453,8 +499,13 @@ class BackboneRun:
         if bb.id_vid:
             ids = vid_feat.contiguous().to(torch.int64)
             sv["vid_ids"] = ids
+            fpos = None
+            if "noPos" in self.abl:      # a fresh shuffle of the segment positions per row and per call, from torch's CPU
+                # generator exactly like the reference (encoder.py:428-429: B x torch.randperm(Lv))
+                fpos = torch.stack([torch.randperm(S) for _ in range(B)]).float().to(ids.device).contiguous()
+            sv["frame_pos"] = fpos
             H.embed_id_vid(ids, st.p(P + "vid_proj.weight"), d // 2, st.p(P + "frameid_proj.weight"),
-                           st.p(P + "frameid_proj.bias"), st.p(P + "vid_pe.weight"), pre_v, B, S)
+                           st.p(P + "frameid_proj.bias"), st.p(P + "vid_pe.weight"), pre_v, B, S, frame_pos=fpos)
         else:
             x = vid_feat.contiguous().float()
             sv["vid_x"] = x
@@ -486,9 +537,61 @@ class BackboneRun:
         sv["pre_u"], sv["meu"], sv["reu"] = pre_u, meu, reu
         Xv, Xu = Ev, Eu
         sv["layers"] = []
+        if self.abl in MLP_VARIANTS:
+            return self._mlp_variant_fwd(Ev, Eu, am_v, am_u).view(B, -1, d), Eu.view(B, Lt, d)
         for i in range(max(self.N - 1, 0)):
             Xv, Xu, am_v, am_u = self._layer_fwd(i, Xv, Xu, am_v, am_u)
         return Xv.view(B, S, d), Eu.view(B, Lt, d)
+
+    # ---------------------------------------------------------------- MLP ablations (encoder.py:392-400,503-511)
+    def _mlp_fwd(self, X, M, am_X, tok):
+        """encoder_mlp on M tokens: [Linear -> ReLU -> Dropout] x n_hidden, Linear.  ``tok`` (0 video, 1 user) separates the
+        dropout streams of the two token sets of CrossMLP.  Returns (Z, saved hidden activations)."""
+        st, d, P = self.store, self.d, self.pre
+        lins = mlp_linears(self.bb)
+        if len(lins) - 1 > 20:
+            raise RuntimeError("encoder_mlp with %d hidden layers: dropout-site space holds 20" % (len(lins) - 1))
+        hs, am = [(X, am_X)], am_X
+        for k, n in enumerate(lins[:-1]):
+            Hk, am_k = _empty(X, M, d), self.am.new()
+            _lin_fwd(st, M, d, d, hs[-1][0], P + n + ".weight", Hk, d, bias=st.p(P + n + ".bias"), a_amax=hs[-1][1], c_amax=am_k,
+                     activation=H.ACT_RELU, drop_p=self.p_drop, seed=self.seed, site=_site(self.bi, tok, K_MLP0 + k))
+            hs.append((Hk, am_k))
+        Z = _empty(X, M, d)
+        _lin_fwd(st, M, d, d, hs[-1][0], P + lins[-1] + ".weight", Z, d, bias=st.p(P + lins[-1] + ".bias"), a_amax=hs[-1][1])
+        return Z, hs
+
+    def _mlp_bwd(self, dZ, hs, M, tok, gbuf, accumulate, tag):
+        """Reverse of _mlp_fwd; weight/bias gradients are ACCUMULATED when ``accumulate`` (second token set of CrossMLP).
+        Returns the gradient wrt the MLP input."""
+        st, d, P = self.store, self.d, self.pre
+        lins = mlp_linears(self.bb)
+        g = dZ
+        for k in reversed(range(len(lins))):
+            n = lins[k]
+            Xin = hs[k][0]
+            _wgrad(st, g, d, 0, Xin, d, 0, M, d, d, st.g(P + n + ".weight", gbuf), accumulate=accumulate)
+            _colsum(st, g, d, M, d, st.g(P + n + ".bias", gbuf), accumulate=accumulate)
+            gin = st.buf("mlp_g%d%s" % (k & 1, tag), (M, d))
+            if k > 0:       # through Dropout and ReLU of hidden layer k-1: aux = its saved output (> 0 iff live and kept)
+                _lin_dgrad(st, M, d, d, g, P + n + ".weight", gin, activation=H.ACT_DRELU, aux=hs[k][0], ldaux=d,
+                           drop_p=self.p_drop, seed=self.seed, site=_site(self.bi, tok, K_MLP0 + k - 1))
+            else:
+                _lin_dgrad(st, M, d, d, g, P + n + ".weight", gin)
+            g = gin
+        return g
+
+    def _mlp_variant_fwd(self, Ev, Eu, am_v, am_u):
+        sv, B, S, Lt, d = self.sv, self.B, self.S, self.Lt, self.d
+        if self.abl == "w/oAtt":
+            return Ev
+        Zv, sv["mlp_v"] = self._mlp_fwd(Ev, self.Mv, am_v, 0)
+        if self.abl == "SelfMLP":
+            return Zv
+        Zu, sv["mlp_u"] = self._mlp_fwd(Eu, self.Mu, am_u, 1)
+        out = _empty(Ev, B * POOL_BINS, d)
+        H.pool_tokens(Zu, Lt, Zv, S, out, B, d, POOL_BINS)       # AdaptiveAvgPool1d(40) over cat(user, video) tokens
+        return out
 
     def _side_post(self, i, L, side, X, A, M, kinds, am_A):
         """R1 = X + drop(A.Wff^T+b); X1 = LN(R1); H = drop(gelu(X1.W0^T+b0)); R2 = X1 + drop(H.W1^T+b1); X2 = LN(R2)."""
@@ -513,29 +616,51 @@ class BackboneRun:
         return X2, am_X2, dict(A=A, R1=R1, X1=X1, m1=m1, r1=r1, G=G, Hh=Hh, R2=R2, m2=m2, r2=r2, am_A=am_A, am_X1=am_X1,
                                am_Hh=am_Hh)
 
+    def _attn_views(self, full, Yv, Yu, nv, nu):
+        """Column slices of the fused projection buffers (or of their gradients) as the attention kernels take them:
+        for the video queries and, when the layer is full, for the user queries.  An empty key block is (None, ..., 0)."""
+        d, S, Lt, mode = self.d, self.S, self.Lt, self.mode
+        vidP, usrP = layer_plan(mode, full)
+        cv = {n: (Yv, k * d) for k, n in enumerate(vidP)}
+        cu = {n: (Yu, k * d) for k, n in enumerate(usrP)}
+        ldv, ldu = nv * d, max(nu, 1) * d
+        g = lambda c, n: c.get(n)
+        vq = dict(Qa=g(cv, "v2v_proj.0"), Qb=g(cv, "t2v_proj.0"), ldq=ldv, Ka=g(cv, "v2v_proj.1"), Va=g(cv, "v2v_proj.2"), ldka=ldv,
+                  Kb=g(cu, "t2v_proj.1"), Vb=g(cu, "t2v_proj.2"), ldkb=ldu, La=0 if mode == "cross" else S, Lb=0 if mode == "self" else Lt)
+        uq = None
+        if full:
+            uq = dict(Qa=g(cu, "v2t_proj.0"), Qb=g(cu, "t2t_proj.0"), ldq=ldu, Ka=g(cv, "v2t_proj.1"), Va=g(cv, "v2t_proj.2"), ldka=ldv,
+                      Kb=g(cu, "t2t_proj.1"), Vb=g(cu, "t2t_proj.2"), ldkb=ldu, La=S, Lb=0 if mode == "cross" else Lt)
+        return vq, uq
+
     def _layer_fwd(self, i, Xv, Xu, am_Xv, am_Xu):
         st, d, P, am = self.store, self.d, self.pre, self.am
         B, S, Lt, Mv, Mu, Hh, dh = self.B, self.S, self.Lt, self.Mv, self.Mu, self.H, self.dh
-        full = i < self.N - 2
-        nv, nu = (6, 6) if full else (4, 2)
+        full = i < self.N - 2 and self.mode != "self"
+        vidP, usrP = layer_plan(self.mode, full)
+        nv, nu = len(vidP), len(usrP)
         L = "%sencoder.layers.%d." % (P, i)
         ca = L + "cross_attn."
-        Yv, Yu = _empty(Xv, Mv, nv * d), _empty(Xv, Mu, nu * d)
-        _lin_fwd(st, Mv, nv * d, d, Xv, ca + "v2v_proj.0.weight", Yv, nv * d, bias=st.p(ca + "v2v_proj.0.bias"), a_amax=am_Xv)
-        _lin_fwd(st, Mu, nu * d, d, Xu, ca + "t2v_proj.1.weight", Yu, nu * d, bias=st.p(ca + "t2v_proj.1.bias"), a_amax=am_Xu)
+        Yv = _empty(Xv, Mv, nv * d)
+        _lin_fwd(st, Mv, nv * d, d, Xv, ca + vidP[0] + ".weight", Yv, nv * d, bias=st.p(ca + vidP[0] + ".bias"), a_amax=am_Xv)
+        Yu = None
+        if nu:
+            Yu = _empty(Xv, Mu, nu * d)
+            _lin_fwd(st, Mu, nu * d, d, Xu, ca + usrP[0] + ".weight", Yu, nu * d, bias=st.p(ca + usrP[0] + ".bias"), a_amax=am_Xu)
+        vq, uq = self._attn_views(full, Yv, Yu, nv, nu)
         Av, lse_v = _empty(Xv, Mv, d), _empty(Xv, 2, B, Hh, S)
         am_Av = am.new()
-        H.attn_fwd(B, Hh, dh, S, S, Lt, (Yv, 0), (Yv, d), nv * d, (Yv, 2 * d), (Yv, 3 * d), nv * d, (Yu, 0), (Yu, d), nu * d,
-                   self.vm, self.vm, self.um, Av, d, lse_v, drop_p=self.p_drop, seed=self.seed, site=_site(self.bi, i, K_ATT_V),
-                   amax_o=am_Av)
+        H.attn_fwd(B, Hh, dh, S, vq["La"], vq["Lb"], vq["Qa"], vq["Qb"], vq["ldq"], vq["Ka"], vq["Va"], vq["ldka"], vq["Kb"], vq["Vb"],
+                   vq["ldkb"], self.vm, self.vm, self.um, Av, d, lse_v, drop_p=self.p_drop, seed=self.seed,
+                   site=_site(self.bi, i, K_ATT_V), amax_o=am_Av)
         X2v, am_X2v, sv_v = self._side_post(i, L, "vid", Xv, Av, Mv, (K_AO_V, K_MI_V, K_MO_V), am_Av)
         rec = dict(full=full, Xv=Xv, Xu=Xu, Yv=Yv, Yu=Yu, lse_v=lse_v, v=sv_v, am_Xv=am_Xv, am_Xu=am_Xu)
         X2u = am_X2u = None
         if full:
             Au, lse_u = _empty(Xv, Mu, d), _empty(Xv, 2, B, Hh, Lt)
             am_Au = am.new()
-            H.attn_fwd(B, Hh, dh, Lt, S, Lt, (Yu, 2 * d), (Yu, 3 * d), nu * d, (Yv, 4 * d), (Yv, 5 * d), nv * d,
-                       (Yu, 4 * d), (Yu, 5 * d), nu * d, self.um, self.vm, self.um, Au, d, lse_u, drop_p=self.p_drop,
+            H.attn_fwd(B, Hh, dh, Lt, uq["La"], uq["Lb"], uq["Qa"], uq["Qb"], uq["ldq"], uq["Ka"], uq["Va"], uq["ldka"], uq["Kb"],
+                       uq["Vb"], uq["ldkb"], self.um, self.vm, self.um, Au, d, lse_u, drop_p=self.p_drop,
                        seed=self.seed, site=_site(self.bi, i, K_ATT_U), amax_o=am_Au)
             X2u, am_X2u, sv_u = self._side_post(i, L, "usr", Xu, Au, Mu, (K_AO_U, K_MI_U, K_MO_U), am_Au)
             rec["lse_u"], rec["u"] = lse_u, sv_u
@@ -584,44 +709,51 @@ class BackboneRun:
         st, d, P = self.store, self.d, self.pre
         B, S, Lt, Mv, Mu, Hh, dh = self.B, self.S, self.Lt, self.Mv, self.Mu, self.H, self.dh
         full = rec["full"]
-        nv, nu = (6, 6) if full else (4, 2)
+        vidP, usrP = layer_plan(self.mode, full)
+        nv, nu = len(vidP), len(usrP)
         L = "%sencoder.layers.%d." % (P, i)
         ca = L + "cross_attn."
         Yv, Yu = rec["Yv"], rec["Yu"]
-        dYv, dYu = st.buf("dYv%d" % i, (Mv, nv * d)), st.buf("dYu%d" % i, (Mu, nu * d))
+        dYv = st.buf("dYv%d" % i, (Mv, nv * d))
+        dYu = st.buf("dYu%d" % i, (Mu, nu * d)) if nu else None
+        vq, uq = self._attn_views(full, Yv, Yu, nv, nu)
+        dvq, duq = self._attn_views(full, dYv, dYu, nv, nu)
         Dv = st.buf("attnD", (B * Hh * max(S, Lt),))
         am_dYv, am_dYu = self.amb.new(), self.amb.new()      # one per fused dY buffer: both attentions fold into them
         deferred = [] if st.defer_wgrad else None
         dR1v, dAv = self._side_post_bwd(i, L, "vid", rec["v"], dXv_out, Mv, (K_AO_V, K_MI_V, K_MO_V), gbuf, "v%d" % i, deferred)
         flush_deferred(st, deferred)          # the three weight-gradient GEMMs of this side run under the attention backward
-        H.attn_bwd(B, Hh, dh, S, S, Lt, (Yv, 0), (Yv, d), nv * d, (Yv, 2 * d), (Yv, 3 * d), nv * d, (Yu, 0), (Yu, d), nu * d,
-                   self.vm, self.vm, self.um, rec["lse_v"], rec["v"]["A"], d, dAv, d, Dv, (dYv, 0), (dYv, d), nv * d, (dYv, 2 * d), (dYv, 3 * d),
-                   nv * d, (dYu, 0), (dYu, d), nu * d, drop_p=self.p_drop, seed=self.seed, site=_site(self.bi, i, K_ATT_V),
-                   amax_q=am_dYv, amax_ka=am_dYv, amax_kb=am_dYu)
+        H.attn_bwd(B, Hh, dh, S, vq["La"], vq["Lb"], vq["Qa"], vq["Qb"], vq["ldq"], vq["Ka"], vq["Va"], vq["ldka"], vq["Kb"], vq["Vb"],
+                   vq["ldkb"], self.vm, self.vm, self.um, rec["lse_v"], rec["v"]["A"], d, dAv, d, Dv, dvq["Qa"], dvq["Qb"], dvq["ldq"],
+                   dvq["Ka"], dvq["Va"], dvq["ldka"], dvq["Kb"], dvq["Vb"], dvq["ldkb"], drop_p=self.p_drop, seed=self.seed,
+                   site=_site(self.bi, i, K_ATT_V), amax_q=am_dYv, amax_ka=am_dYv, amax_kb=am_dYu)
         dR1u = None
         if full:
             dR1u, dAu = self._side_post_bwd(i, L, "usr", rec["u"], dXu_out, Mu, (K_AO_U, K_MI_U, K_MO_U), gbuf, "u%d" % i, deferred)
             flush_deferred(st, deferred)
-            H.attn_bwd(B, Hh, dh, Lt, S, Lt, (Yu, 2 * d), (Yu, 3 * d), nu * d, (Yv, 4 * d), (Yv, 5 * d), nv * d,
-                       (Yu, 4 * d), (Yu, 5 * d), nu * d, self.um, self.vm, self.um, rec["lse_u"], rec["u"]["A"], d, dAu, d, Dv,
-                       (dYu, 2 * d), (dYu, 3 * d), nu * d, (dYv, 4 * d), (dYv, 5 * d), nv * d, (dYu, 4 * d), (dYu, 5 * d), nu * d,
+            H.attn_bwd(B, Hh, dh, Lt, uq["La"], uq["Lb"], uq["Qa"], uq["Qb"], uq["ldq"], uq["Ka"], uq["Va"], uq["ldka"], uq["Kb"],
+                       uq["Vb"], uq["ldkb"], self.um, self.vm, self.um, rec["lse_u"], rec["u"]["A"], d, dAu, d, Dv,
+                       duq["Qa"], duq["Qb"], duq["ldq"], duq["Ka"], duq["Va"], duq["ldka"], duq["Kb"], duq["Vb"], duq["ldkb"],
                        drop_p=self.p_drop, seed=self.seed, site=_site(self.bi, i, K_ATT_U),
                        amax_q=am_dYu, amax_ka=am_dYv, amax_kb=am_dYu)
         # fused projection weights / inputs
         with side_work(st):
-            _wgrad(st, dYv, nv * d, 0, rec["Xv"], d, 0, Mv, nv * d, d, _group_view(st, ca + "v2v_proj.0.weight", nv * d * d, gbuf),
+            _wgrad(st, dYv, nv * d, 0, rec["Xv"], d, 0, Mv, nv * d, d, _group_view(st, ca + vidP[0] + ".weight", nv * d * d, gbuf),
                    a_amax=am_dYv, b_amax=rec["am_Xv"])
-            _colsum(st, dYv, nv * d, Mv, nv * d, _group_view(st, ca + "v2v_proj.0.bias", nv * d, gbuf))
-            _wgrad(st, dYu, nu * d, 0, rec["Xu"], d, 0, Mu, nu * d, d, _group_view(st, ca + "t2v_proj.1.weight", nu * d * d, gbuf),
-                   a_amax=am_dYu, b_amax=rec["am_Xu"])
-            _colsum(st, dYu, nu * d, Mu, nu * d, _group_view(st, ca + "t2v_proj.1.bias", nu * d, gbuf))
+            _colsum(st, dYv, nv * d, Mv, nv * d, _group_view(st, ca + vidP[0] + ".bias", nv * d, gbuf))
+            if nu:
+                _wgrad(st, dYu, nu * d, 0, rec["Xu"], d, 0, Mu, nu * d, d, _group_view(st, ca + usrP[0] + ".weight", nu * d * d, gbuf),
+                       a_amax=am_dYu, b_amax=rec["am_Xu"])
+                _colsum(st, dYu, nu * d, Mu, nu * d, _group_view(st, ca + usrP[0] + ".bias", nu * d, gbuf))
         dXv_in = st.buf("dXv_in%d" % (i & 1), (Mv, d))
-        _lin_dgrad(st, Mv, d, nv * d, dYv, ca + "v2v_proj.0.weight", dXv_in, residual=dR1v, ldr=d, res_period=Mv, a_amax=am_dYv)
-        dXu_in = st.buf("dXu_in%d" % (i & 1), (Mu, d))
-        if full:
-            _lin_dgrad(st, Mu, d, nu * d, dYu, ca + "t2v_proj.1.weight", dXu_in, residual=dR1u, ldr=d, res_period=Mu, a_amax=am_dYu)
-        else:
-            _lin_dgrad(st, Mu, d, nu * d, dYu, ca + "t2v_proj.1.weight", dXu_in, a_amax=am_dYu)
+        _lin_dgrad(st, Mv, d, nv * d, dYv, ca + vidP[0] + ".weight", dXv_in, residual=dR1v, ldr=d, res_period=Mv, a_amax=am_dYv)
+        dXu_in = None
+        if nu:
+            dXu_in = st.buf("dXu_in%d" % (i & 1), (Mu, d))
+            if full:
+                _lin_dgrad(st, Mu, d, nu * d, dYu, ca + usrP[0] + ".weight", dXu_in, residual=dR1u, ldr=d, res_period=Mu, a_amax=am_dYu)
+            else:
+                _lin_dgrad(st, Mu, d, nu * d, dYu, ca + usrP[0] + ".weight", dXu_in, a_amax=am_dYu)
         return dXv_in, dXu_in
 
     def backward(self, d_vid_out: torch.Tensor, gbuf: Optional[torch.Tensor] = None, on_bucket=None):
@@ -629,17 +761,29 @@ class BackboneRun:
         ``on_bucket(name)`` is called as soon as a bucket's gradients are complete (DP overlap hook)."""
         st, bb, P, d, sv = self.store, self.bb, self.pre, self.d, self.sv
         B, S, Lt, Mv, Mu = self.B, self.S, self.Lt, self.Mv, self.Mu
-        dXv = d_vid_out.contiguous().view(Mv, d)
+        dXv = d_vid_out.contiguous().view(-1, d)
         dXu = None
         self.amb = AmaxArena(st, 4 + 8 * max(self.N - 1, 0))
-        for i in reversed(range(max(self.N - 1, 0))):
-            dXv, dXu = self._layer_bwd(i, sv["layers"][i], dXv, dXu, gbuf)
-            if on_bucket is not None:
+        if self.abl in MLP_VARIANTS:
+            if self.abl == "CrossMLP":
+                dZu, dZv = st.buf("pool_du", (Mu, d)), st.buf("pool_dv", (Mv, d))
+                H.pool_tokens_bwd(dXv, dZu, Lt, dZv, S, B, d, POOL_BINS)
+                dXu = self._mlp_bwd(dZu, sv["mlp_u"], Mu, 1, gbuf, False, "u")
+                dXv = self._mlp_bwd(dZv, sv["mlp_v"], Mv, 0, gbuf, True, "v")
+            elif self.abl == "SelfMLP":
+                dXv = self._mlp_bwd(dXv, sv["mlp_v"], Mv, 0, gbuf, False, "v")
+            if self.abl != "w/oAtt" and on_bucket is not None:
                 join_side(st)
-                on_bucket("%slayer%d" % (P, i))
+                on_bucket(P + "mlp")
+        else:
+            for i in reversed(range(max(self.N - 1, 0))):
+                dXv, dXu = self._layer_bwd(i, sv["layers"][i], dXv, dXu, gbuf)
+                if on_bucket is not None:
+                    join_side(st)
+                    on_bucket("%slayer%d" % (P, i))
         # ---- embedding backward.  User side first: its weight gradient (the larger one) queues on the side stream
         # behind the projection weight gradients still running there, the video side's runs on the main stream.
-        if self.N >= 2:
+        if dXu is not None:
             dpre_u = st.buf("dpre_u", (Mu, d))
             am_du = self.amb.new()
             _ln_bwd(st, dXu, sv["pre_u"], sv["meu"], sv["reu"], P + "usr_ln.weight", P + "usr_ln.bias", gbuf, dpre_u, None, Mu, d,
@@ -671,10 +815,14 @@ class BackboneRun:
             H.embed_id_bwd(dpre, L, d, 0, width, order, ids, gtab, B)
             if side == "vid":
                 dh_ = d // 2
-                pos = st.buf("arangeS", (L,))
-                pos.copy_(torch.arange(L, device=pos.device, dtype=torch.float32))
                 _colsum(st, gpe, d, L, dh_, st.g(P + "frameid_proj.bias", gbuf), x_off=dh_)
-                _colsum(st, gpe, d, L, dh_, st.g(P + "frameid_proj.weight", gbuf).view(-1), x_off=dh_, w=pos)
+                if sv.get("frame_pos") is not None:      # noPos: positions differ per row -> weighted sum over all tokens
+                    _colsum(st, dpre, d, M, dh_, st.g(P + "frameid_proj.weight", gbuf).view(-1), x_off=dh_,
+                            w=sv["frame_pos"].view(-1))
+                else:
+                    pos = st.buf("arangeS", (L,))
+                    pos.copy_(torch.arange(L, device=pos.device, dtype=torch.float32))
+                    _colsum(st, gpe, d, L, dh_, st.g(P + "frameid_proj.weight", gbuf).view(-1), x_off=dh_, w=pos)
         else:
             x = sv["%s_x" % side]
             Din = x.shape[-1]

@@ -15,7 +15,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SEGMM_LIB") or os.path.join(_HERE, "libsegmm_hip.so")      # SEGMM_LIB: A/B builds of the kernels
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _lib = None
 
@@ -47,7 +47,7 @@ SIGNATURES = {
     "segmm_vecsum": [_p, _i64, _p, _i, _p],
     "segmm_rowdot_pair": [_p, _i, _p, _i, _p, _i64, _i, _i, _p],
     "segmm_rowscale_mat": [_p, _p, _i, _p, _i, _i64, _i, _i, _p],
-    "segmm_embed_id_vid": [_p, _p, _i, _p, _p, _p, _p, _i, _i, _i64, _p],
+    "segmm_embed_id_vid": [_p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i64, _p],
     "segmm_embed_id_usr": [_p, _p, _i, _p, _p, _i, _i64, _p],
     "segmm_embed_id_bwd": [_p, _i, _i, _i, _i, _p, _p, _p, _i, _i64, _p],
     "segmm_pe_grad": [_p, _i, _i, _i, _i, _p, _i, _p],
@@ -60,6 +60,8 @@ SIGNATURES = {
     "segmm_survival": [_p, _i, _p, _p, _p, _i, _i, _p],
     "segmm_gather_l1": [_p, _i64, _i, _p, _i64, _i, _p, _p, _p],
     "segmm_segment_weighted_sum": [_p, _p, _p, _i64, _i, _p, _p],
+    "segmm_pool_tokens": [_p, _i, _p, _i, _p, _i, _i, _i, _p],
+    "segmm_pool_tokens_bwd": [_p, _p, _i, _p, _i, _i, _i, _i, _p],
 }
 
 
@@ -122,7 +124,7 @@ GEMM_ENGINE = {"f32": 0, "bf16x6": 1, "f16x3": 2}[os.environ.get("SEGMM_GEMM", "
 AMAX_SLOTS = 256          # partial maxima per tensor written by the fused producers (SEGMM_AMAX_SLOTS)
 AMAX_PARTS = 1024         # ... and by the stand-alone absmax() pass
 LAYOUT_NT, LAYOUT_NN, LAYOUT_TN = 0, 1, 2
-ACT_NONE, ACT_GELU, ACT_DGELU = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_DGELU, ACT_RELU, ACT_DRELU = 0, 1, 2, 3, 4
 
 
 def l1norm(x, out=None, inv_scale=None):
@@ -256,9 +258,10 @@ def colsum(X, ld, M, N, out, workspace, w=None, accumulate=False, x_off=0, out_o
 
 def attn_fwd(B, H, dh, Lq, La, Lb, Qa, Qb, ldq, Ka, Va, ldka, Kb, Vb, ldkb, mq, mka, mkb, O, ldo, lse,
              drop_p=0.0, seed=0, site=0, amax_o=None):
-    """Q*/K*/V* are (tensor, element_offset) pairs: column slices of the fused projection buffers."""
+    """Q*/K*/V* are (tensor, element_offset) pairs: column slices of the fused projection buffers.  A key block may be
+    empty (La == 0 or Lb == 0, its pairs None): the CrossAtt / SelfAtt ablations attend to one block only."""
     def P(x):
-        return x[0].data_ptr() + 4 * x[1]
+        return 0 if x is None else x[0].data_ptr() + 4 * x[1]
     prof = ATTN_PROFILE
     if prof is not None:
         e0 = torch.cuda.Event(enable_timing=True)
@@ -276,7 +279,7 @@ def attn_bwd(B, H, dh, Lq, La, Lb, Qa, Qb, ldq, Ka, Va, ldka, Kb, Vb, ldkb, mq, 
              dQa, dQb, lddq, dKa, dVa, lddka, dKb, dVb, lddkb, drop_p=0.0, seed=0, site=0, amax_q=None, amax_ka=None,
              amax_kb=None):
     def P(x):
-        return x[0].data_ptr() + 4 * x[1]
+        return 0 if x is None else x[0].data_ptr() + 4 * x[1]
     prof = ATTN_PROFILE
     if prof is not None:
         e0 = torch.cuda.Event(enable_timing=True)
@@ -315,9 +318,9 @@ def vecsum(v, n, out, accumulate=False):
     _check(lib().segmm_vecsum(_ptr(v), n, _ptr(out), int(bool(accumulate)), _stream()), "segmm_vecsum")
 
 
-def embed_id_vid(item_id, table, dhalf, frame_w, frame_b, pe, out, B, S):
+def embed_id_vid(item_id, table, dhalf, frame_w, frame_b, pe, out, B, S, frame_pos=None):
     _check(lib().segmm_embed_id_vid(_ptr(item_id), _ptr(table), dhalf, _ptr(frame_w), _ptr(frame_b), _ptr(pe),
-                                    _ptr(out), B, S, table.shape[0], _stream()), "segmm_embed_id_vid")
+                                    _ptr(frame_pos), _ptr(out), B, S, table.shape[0], _stream()), "segmm_embed_id_vid")
 
 
 def embed_id_usr(user_id, table, d, pe, out, B):
@@ -422,3 +425,14 @@ def segment_weighted_sum(pred, weight=None, duration=None):
                                             _ptr(None if duration is None else duration.contiguous()), rows, S, _ptr(out), _stream()),
            "segmm_segment_weighted_sum")
     return out
+
+
+def pool_tokens(U, Lu, V, Lv, out, B, d, bins):
+    """AdaptiveAvgPool1d(bins) over the tokens of cat(U[B,Lu,d], V[B,Lv,d]) (CrossMLP ablation)."""
+    _dev(U, V, out)
+    _check(lib().segmm_pool_tokens(_ptr(U), Lu, _ptr(V), Lv, _ptr(out), B, d, bins, _stream()), "segmm_pool_tokens")
+
+
+def pool_tokens_bwd(dOut, dU, Lu, dV, Lv, B, d, bins):
+    _dev(dOut, dU, dV)
+    _check(lib().segmm_pool_tokens_bwd(_ptr(dOut), _ptr(dU), Lu, _ptr(dV), Lv, B, d, bins, _stream()), "segmm_pool_tokens_bwd")

@@ -234,6 +234,13 @@ class Trainer:
                 self.comm.reduce_bucket(st.gflat, s, e)
                 return
 
+    def _n_users(self):
+        """reader.n_users as the reference's init_model sizes the user table (Embedding(n_users + 1, d)); None in image mode."""
+        for bb in (self.model.backbone1, getattr(self.model, "backbone2", None)):
+            if bb is not None and bb.id_usr:
+                return bb.usr_proj.num_embeddings - 1
+        return None
+
     def normalize(self, key, x):
         """a1: x / (sum|x| + 1e-6) over the feature dim, into a persistent buffer."""
         buf = self._norm.get(key)
@@ -265,7 +272,16 @@ class Trainer:
         model.train(self.dropout)
         self.opt.zero_grad()
         usr, um, vid, vm = self._features(batch)
-        out = model(usr_image=usr, usr_id=batch["user_identity_id"], usr_mask=um, vid_image=vid,
+        usr_id = batch["user_identity_id"]
+        if "noUser" in getattr(model.backbone1, "ablation_type", "ours"):
+            # 'noUser' / 'noUser_SelfAtt' (main...SegMM.py:275-280, main...KuaiRand.py:254-258): the TRAINING forward sees
+            # uniform-random user features and random user ids in [1, n_users); validation keeps the real ones
+            if usr is not None:
+                usr = torch.rand_like(usr)
+            n_users = self._n_users()
+            if n_users is not None:
+                usr_id = torch.randint(1, max(n_users, 2), usr_id.shape, device=usr_id.device)
+        out = model(usr_image=usr, usr_id=usr_id, usr_mask=um, vid_image=vid,
                     vid_id=batch["photo_identity_id"], vid_mask=vm, gt=batch["label"], mode="train")
         out["loss"].backward()
         if self.comm.world > 1:

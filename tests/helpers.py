@@ -31,7 +31,7 @@ def build_model(cfg, device=None):
     import argparse
     import segmminterest_amd as M
     S, N, d, h = cfg["S"], cfg["N"], cfg["d"], cfg["h"]
-    args = argparse.Namespace(debug=0, num_layers_enc=N, ablation_type="ours", d_model=d, nhead=h,
+    args = argparse.Namespace(debug=0, num_layers_enc=N, ablation_type=cfg.get("ablation_type", "ours"), d_model=d, nhead=h,
                               input_type={"user": cfg["user"], "photo": cfg["photo"]},
                               learnable_bias=cfg.get("learnable_bias", 0), exposure_prob=cfg["exposure_prob"],
                               fusion_heads=cfg.get("fusion_heads", 2), loss_type_list=cfg["loss_type_list"],
@@ -55,10 +55,15 @@ def build_model(cfg, device=None):
         model = M.MultiScaleTemporalDetrLeaveFocal(backbone(um1, vm1, ul1), None, None, torch.nn.Identity(), args)
     if device is not None:
         model = model.to(device)
+    model._test_fwd_seed = cfg.get("fwd_seed")      # 'noPos' fixtures: torch is reseeded before every forward
     return model
 
 
-def call_model(model, inp, mode="train", device=None):
+def call_model(model, inp, mode="train", device=None, fwd_seed=None):
+    """``fwd_seed``: the 'noPos' fixtures reseed torch before every forward (the model draws torch.randperm)."""
     kw = {k: (v.to(device) if device is not None else v) for k, v in inp.items()}
+    fwd_seed = getattr(model, "_test_fwd_seed", None) if fwd_seed is None else fwd_seed
+    if fwd_seed is not None:
+        torch.manual_seed(fwd_seed)
     return model(usr_image=kw["usr_image"], usr_id=kw["usr_id"], usr_mask=kw["usr_mask"], vid_image=kw["vid_image"],
                  vid_id=kw["vid_id"], vid_mask=kw["vid_mask"], gt=kw["gt"].clone(), mode=mode)

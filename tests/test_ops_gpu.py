@@ -579,3 +579,101 @@ def test_fused_amax_producers():
     assert aq.max().item() == max(outs[0].abs().max().item(), outs[1].abs().max().item())
     assert aka.max().item() == max(outs[2].abs().max().item(), outs[3].abs().max().item())
     assert akb.max().item() == max(outs[4].abs().max().item(), outs[5].abs().max().item())
+
+
+# ------------------------------------------------------------------ ablation variants (encoder.py:108-135,392-400,428-429,503-511)
+@pytest.mark.parametrize("B,H_,dh,Lq,La,Lb", [(3, 4, 8, 40, 0, 10), (2, 16, 48, 40, 0, 100), (2, 4, 8, 40, 40, 0), (2, 16, 48, 100, 40, 0),
+                                              (3, 4, 8, 1, 40, 0), (2, 2, 16, 40, 0, 1)])
+def test_attention_one_empty_key_block(B, H_, dh, Lq, La, Lb):
+    """CrossAtt / SelfAtt: the query attends to ONE key block; the other has length 0 and null pointers."""
+    H = _abi()
+    d = H_ * dh
+    g = torch.Generator().manual_seed(B * 1000 + Lq + La)
+    mk = lambda L: (torch.randn(B, L, d, generator=g) * 0.7).to(DEV)
+    L1 = La or Lb
+    Q, K, V = mk(Lq), mk(L1), mk(L1)
+    mq = (torch.rand(B, Lq, generator=g) < 0.8).to(DEV)
+    mk1 = (torch.rand(B, L1, generator=g) < 0.75).to(DEV)
+    mq[0, 0] = False
+    O = torch.empty(B * Lq, d, device=DEV)
+    lse = torch.empty(2, B, H_, Lq, device=DEV)
+    z = lambda t: (t, 0)
+    if La:
+        blocks = (z(Q), None, d, z(K), z(V), d, None, None, 0)
+        masks = (mq, mk1, None)
+    else:
+        blocks = (None, z(Q), d, None, None, 0, z(K), z(V), d)
+        masks = (mq, None, mk1)
+    H.attn_fwd(B, H_, dh, Lq, La, Lb, *blocks, *masks, O, d, lse)
+    Qd, Kd, Vd = [t.double().requires_grad_(True) for t in (Q, K, V)]
+    sp = lambda t: t.view(B, t.shape[1], H_, dh)
+    lg = torch.einsum("bqhd,bkhd->bhqk", sp(Qd), sp(Kd))
+    lg = torch.where((mq[:, :, None] & mk1[:, None, :])[:, None], lg, torch.full_like(lg, -10000.0)) / math.sqrt(dh)
+    ref = torch.einsum("bhqk,bkhd->bqhd", lg.softmax(-1), sp(Vd)).reshape(B, Lq, d)
+    assert (O.view(B, Lq, d).double() - ref).abs().max().item() < 2e-5
+    dO = torch.randn(B * Lq, d, generator=g).to(DEV)
+    ref.backward(dO.view(B, Lq, d).double())
+    Dv = torch.empty(B, H_, Lq, device=DEV)
+    dQ, dK, dV = [torch.full_like(t, float("nan")) for t in (Q, K, V)]
+    if La:
+        grads = (z(dQ), None, d, z(dK), z(dV), d, None, None, 0)
+    else:
+        grads = (None, z(dQ), d, None, None, 0, z(dK), z(dV), d)
+    H.attn_bwd(B, H_, dh, Lq, La, Lb, *blocks, *masks, lse, O, d, dO, d, Dv, *grads)
+    for name, got, leaf in (("dQ", dQ, Qd), ("dK", dK, Kd), ("dV", dV, Vd)):
+        err = (got.double() - leaf.grad).abs().max().item()
+        assert err < 2e-5 * max(1.0, leaf.grad.abs().max().item()), (name, err, leaf.grad.abs().max().item())
+    with pytest.raises(RuntimeError):          # both blocks empty
+        H.attn_fwd(B, H_, dh, Lq, 0, 0, *blocks, *masks, O, d, lse)
+
+
+def test_gemm_relu_epilogues():
+    H = _abi()
+    M, N, K = 360, 96, 64
+    A, W, b = _rand(M, K, seed=8), _rand(N, K, seed=9, scale=0.3), _rand(N, seed=10)
+    C = torch.empty(M, N, device=DEV)
+    H.gemm(H.LAYOUT_NT, M, N, K, A, K, W, K, C, N, bias=b, activation=H.ACT_RELU)
+    pre = A.double() @ W.double().t() + b.double()
+    assert (C.double() - pre.clamp_min(0)).abs().max().item() < 1e-5
+    # ReLU + dropout, then the backward epilogue reading the forward OUTPUT: zero where it is <= 0, same dropout mask
+    Hd = torch.empty(M, N, device=DEV)
+    H.gemm(H.LAYOUT_NT, M, N, K, A, K, W, K, Hd, N, bias=b, activation=H.ACT_RELU, drop_p=0.3, seed=77, site=5)
+    mult = torch.empty(M * N, device=DEV)
+    H.dropout_mult(mult, M * N, 0.3, 77, 5)
+    mult = mult.view(M, N)
+    assert (Hd.double() - pre.clamp_min(0) * mult.double()).abs().max().item() < 1e-5
+    G, W2 = _rand(M, K, seed=12), _rand(N, K, seed=13, scale=0.3)
+    dZ = torch.empty(M, N, device=DEV)
+    H.gemm(H.LAYOUT_NT, M, N, K, G, K, W2, K, dZ, N, activation=H.ACT_DRELU, aux=Hd, ldaux=N, drop_p=0.3, seed=77, site=5)
+    ref = (G.double() @ W2.double().t()) * (pre > 0).double() * mult.double()
+    assert (dZ.double() - ref).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("B,Lu,Lv,d,bins", [(3, 10, 40, 32, 40), (2, 100, 40, 768, 40), (2, 1, 40, 64, 40), (2, 7, 20, 32, 40)])
+def test_pool_tokens(B, Lu, Lv, d, bins):
+    H = _abi()
+    U, V = _rand(B, Lu, d, seed=1), _rand(B, Lv, d, seed=2)
+    out = torch.empty(B, bins, d, device=DEV)
+    H.pool_tokens(U, Lu, V, Lv, out, B, d, bins)
+    x = torch.cat((U, V), 1).double().requires_grad_(True)
+    ref = torch.nn.functional.adaptive_avg_pool1d(x.permute(0, 2, 1), bins).permute(0, 2, 1)
+    assert (out.double() - ref).abs().max().item() < 1e-6
+    dOut = _rand(B, bins, d, seed=3)
+    ref.backward(dOut.double())
+    dU, dV = torch.full_like(U, float("nan")), torch.full_like(V, float("nan"))
+    H.pool_tokens_bwd(dOut, dU, Lu, dV, Lv, B, d, bins)
+    assert (torch.cat((dU, dV), 1).double() - x.grad).abs().max().item() < 1e-5
+
+
+def test_embed_id_shuffled_positions():
+    """'noPos': frame_pos[b, s] replaces s in the frame-index Linear."""
+    H = _abi()
+    B, S, d, n_items = 5, 40, 32, 30
+    dh = d // 2
+    table, fw, fb, vpe = _rand(n_items + 1, dh, seed=50), _rand(dh, seed=52), _rand(dh, seed=53), _rand(S, d, seed=54)
+    ids = torch.tensor([3, 7, 3, 30, 1], device=DEV)
+    pos = torch.stack([torch.randperm(S) for _ in range(B)]).float().to(DEV)
+    out = torch.empty(B * S, d, device=DEV)
+    H.embed_id_vid(ids, table, dh, fw, fb, vpe, out, B, S, frame_pos=pos)
+    ref = torch.cat([table[ids][:, None, :].expand(B, S, dh), pos[:, :, None] * fw[None, None] + fb[None, None]], -1) + vpe[None]
+    assert torch.allclose(out.view(B, S, d), ref, atol=1e-6)
