@@ -136,6 +136,10 @@ class ParamStore:
         self.scratch: Dict[tuple, torch.Tensor] = {}
         self._params = None
         self.bucket_hook = None      # callable(bucket_name): set by the data-parallel trainer
+        # data-parallel id mode: callable(ids [B] int64, rows [B, w]) -> (ids of all ranks [G*B], rows of all ranks [G*B, w]);
+        # set by the trainer.  The table gradient is then built from the gathered per-row gradients on every rank and the
+        # table's range is left out of the dense gradient all-reduce (table_ranges()).
+        self.row_exchange = None
         self._side_stream = None
         self._on_side = False
         self.overlap = os.environ.get("SEGMM_OVERLAP", "1") != "0"
@@ -299,6 +303,18 @@ class ParamStore:
             merged[-2:] = [(a[0], b[0] + b[1] - a[0])]
         self._plane_ranges = [(o, min(n, n_live - o)) for o, n in merged]
         self._planes_key = None
+
+    def table_ranges(self) -> List[Tuple[int, int]]:
+        """[start, end) of the live id-embedding tables inside the flat gradient buffer (id mode: vid_proj / usr_proj
+        are nn.Embedding): the ranges a data-parallel step exchanges as rows instead of all-reducing densely."""
+        mods = dict(self.root.named_modules())
+        out = []
+        for name in self.live_names:
+            if name.endswith("vid_proj.weight") or name.endswith("usr_proj.weight"):
+                if isinstance(mods.get(name.rsplit(".", 1)[0]), torch.nn.Embedding):
+                    o, n = self.index[name]
+                    out.append((o, o + n))
+        return sorted(out)
 
     # -- access
     def p(self, name) -> torch.Tensor:
@@ -809,10 +825,24 @@ class BackboneRun:
         gtab = st.g(P + "%s_proj.weight" % side, gbuf)
         if is_id:
             ids = sv["%s_ids" % side]
-            order = torch.argsort(ids, stable=True).to(torch.int32)
-            gtab.zero_()
             width = d // 2 if side == "vid" else d
-            H.embed_id_bwd(dpre, L, d, 0, width, order, ids, gtab, B)
+            gtab.zero_()
+            if st.row_exchange is not None:
+                # Data parallel: a rank touches at most B rows of the table, so the ranks exchange
+                # their B compact row gradients [B, width] + ids (all-gather, ~1 MB) instead of all-reducing the dense
+                # [n_items, width] gradient (360 MB at config 3); every rank then runs the same deterministic sorted
+                # segment sum over the G*B gathered rows and ends with the bitwise-identical global table gradient.
+                rows = st.buf("idrows_" + side, (B, width))
+                ar = st.buf("idrows_ar", (B,), torch.int64)
+                ar.copy_(torch.arange(B, device=ar.device))
+                rows.zero_()                                                               # the kernel accumulates into its output
+                H.embed_id_bwd(dpre, L, d, 0, width, ar.to(torch.int32), ar, rows, B)      # rows[b] = sum_s dpre[b, s, :width]
+                ids_all, rows_all = st.row_exchange(ids, rows)
+                order = torch.argsort(ids_all, stable=True).to(torch.int32)
+                H.embed_id_bwd(rows_all, 1, width, 0, width, order, ids_all, gtab, ids_all.numel())
+            else:
+                order = torch.argsort(ids, stable=True).to(torch.int32)
+                H.embed_id_bwd(dpre, L, d, 0, width, order, ids, gtab, B)
             if side == "vid":
                 dh_ = d // 2
                 _colsum(st, gpe, d, L, dh_, st.g(P + "frameid_proj.bias", gbuf), x_off=dh_)

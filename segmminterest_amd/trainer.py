@@ -20,6 +20,8 @@ from __future__ import annotations
 import argparse
 from typing import Dict, List, Optional
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -176,6 +178,24 @@ class DPComm:
         self._all_reduce(norms_g)
         return gathered[:, 0].reshape(-1).contiguous(), gathered[:, 1].reshape(-1).contiguous(), norms_g
 
+    def gather_rows(self, ids, rows):
+        """(ids of all ranks [G*B], rows of all ranks [G*B, w]) in rank order: the sparse exchange of id-table gradients
+        (every rank holds the same B, like :meth:`global_label_stats`)."""
+        if self.world == 1:
+            return ids, rows
+        ids, rows = ids.contiguous(), rows.contiguous()
+        if self.host_staged and rows.is_cuda:
+            hi = torch.empty((self.world * ids.shape[0],), dtype=ids.dtype)
+            hr = torch.empty((self.world * rows.shape[0], rows.shape[1]), dtype=rows.dtype)
+            self.dist.all_gather_into_tensor(hi, ids.cpu(), group=self.group)
+            self.dist.all_gather_into_tensor(hr, rows.cpu(), group=self.group)
+            return hi.to(ids.device), hr.to(rows.device)
+        ids_all = torch.empty((self.world * ids.shape[0],), dtype=ids.dtype, device=ids.device)
+        rows_all = torch.empty((self.world * rows.shape[0], rows.shape[1]), dtype=rows.dtype, device=rows.device)
+        self.dist.all_gather_into_tensor(ids_all, ids, group=self.group)
+        self.dist.all_gather_into_tensor(rows_all, rows, group=self.group)
+        return ids_all, rows_all
+
     def reduce_bucket(self, flat_grad, start, end):
         """Asynchronous SUM all-reduce of one contiguous gradient bucket (gradients are already
         normalised by global counts, so SUM -- not mean -- reproduces the single-process gradient)."""
@@ -210,7 +230,7 @@ class Trainer:
     Gradient clipping is a no-op in the reference (exhausted generator at :298) and is therefore absent."""
 
     def __init__(self, model, lr=1e-3, weight_decay=1e-4, comm: Optional[DPComm] = None, overlap=True, dropout=True,
-                 feature_table=None):
+                 feature_table=None, sparse_tables=True):
         self.model = model
         # SURVEY.md §8(f)-1: with a device-resident feature table the batch carries INDEX lists ("photo_idx" [B, S],
         # "user_idx" [B, Lt], -1 = padding) instead of feature tensors; gather + pad + mask + L1 normalisation is one
@@ -223,6 +243,10 @@ class Trainer:
         st = model._store
         model._dp_hook = self.comm.global_label_stats if self.comm.world > 1 else None
         st.bucket_hook = self._on_bucket if self.comm.world > 1 else None
+        # id mode under DP: the embedding tables' gradients travel as B rows per rank (DPComm.gather_rows) and their flat
+        # ranges are cut out of the dense all-reduce; ``sparse_tables=False`` keeps the dense all-reduce (A/B, tests)
+        self.sparse_tables = bool(sparse_tables) and self.comm.world > 1 and os.environ.get("SEGMM_SPARSE_TABLES", "1") != "0"
+        st.row_exchange = self.comm.gather_rows if self.sparse_tables else None
         self._norm = {}
 
     def _on_bucket(self, name):
@@ -231,8 +255,18 @@ class Trainer:
             return
         for b, s, e in st.buckets:
             if b == name:
-                self.comm.reduce_bucket(st.gflat, s, e)
+                self._reduce_dense(s, e)
                 return
+
+    def _reduce_dense(self, s, e):
+        """All-reduce [s, e) of the flat gradient minus the row-exchanged table ranges."""
+        st = self.model._store
+        if self.sparse_tables:
+            for ts, te in st.table_ranges():
+                if ts < e and te > s:
+                    self.comm.reduce_bucket(st.gflat, s, max(s, ts))
+                    s = min(e, te)
+        self.comm.reduce_bucket(st.gflat, s, e)
 
     def _n_users(self):
         """reader.n_users as the reference's init_model sizes the user table (Embedding(n_users + 1, d)); None in image mode."""
@@ -286,7 +320,7 @@ class Trainer:
         out["loss"].backward()
         if self.comm.world > 1:
             if not self.overlap:
-                self.comm.reduce_bucket(st.gflat, 0, st.n_live)
+                self._reduce_dense(0, st.n_live)
             self.comm.finish()
         self.opt.step()
         return out

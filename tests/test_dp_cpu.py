@@ -51,6 +51,18 @@ def _worker(rank, world, port, q):
         comm.reduce_bucket(flat, half, flat.numel())
         comm.finish()
         loss = comm.sum_scalar(out["loss"].detach().clone())
+        # sparse exchange of id-table gradients: rows of all ranks in rank order; the table gradient built from them equals
+        # the sum over ranks of the dense per-rank table gradients
+        gen = torch.Generator().manual_seed(100 + rank)
+        ids = torch.randint(0, 6, (5,), generator=gen)
+        rows = torch.randn(5, 4, generator=gen)
+        ids_all, rows_all = comm.gather_rows(ids, rows)
+        assert ids_all.shape == (5 * world,) and rows_all.shape == (5 * world, 4)
+        assert torch.equal(ids_all[5 * rank:5 * rank + 5], ids) and torch.equal(rows_all[5 * rank:5 * rank + 5], rows)
+        dense = torch.zeros(6, 4).index_add_(0, ids, rows)
+        comm.reduce_bucket(dense.view(-1), 0, dense.numel())
+        comm.finish()
+        assert torch.allclose(torch.zeros(6, 4).index_add_(0, ids_all, rows_all), dense, atol=1e-6)
         if rank == 0:
             ref_out, ref_grads = O.forward_backward(g["sd"], cfg, inp)       # single process, whole batch
             ref_flat = torch.cat([ref_grads[k].reshape(-1) for k in names])

@@ -38,8 +38,11 @@ def _run(rank, world, port, name, q):
         s, e = shard_rows(16, world, rank)
         shard = {k: v[s:e].cuda() for k, v in full.items()}
         losses, gflat = [], None
+        has_id = "image" not in (cfg["user"], cfg["photo"]) or "both" in (cfg["user"], cfg["photo"])
         for i in range(2):
             out = tr.train_step(shard)
+            if world > 1 and has_id and os.environ.get("SEGMM_SPARSE_TABLES", "1") != "0":      # the id tables travel as rows, their ranges are cut out of the dense all-reduce
+                assert model._store.row_exchange is not None and len(model._store.table_ranges()) >= 1
             losses.append(float(tr.comm.sum_scalar(out["loss"].detach().clone())))
             if i == 0:
                 gflat = model._store.gflat.detach().cpu().numpy().copy()      # the all-reduced gradients of step 1
@@ -50,7 +53,7 @@ def _run(rank, world, port, name, q):
             dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name", ["img_d32_N3_alllosses", "both_fh2"])
+@pytest.mark.parametrize("name", ["img_d32_N3_alllosses", "both_fh2", "id_d32_N2"])      # id tables: sparse row exchange
 def test_two_ranks_equal_single_process(name):
     ctx = mp.get_context("spawn")
     results = {}
@@ -66,9 +69,11 @@ def test_two_ranks_equal_single_process(name):
             assert p.exitcode == 0
         results[world] = res
     (l1, g1, sd1), (l2, g2, sd2) = results[1], results[2]
-    for a, b in zip(l1, l2):
-        assert abs(a - b) <= 1e-5 * max(1.0, abs(a)), (l1, l2)
     g1, g2 = torch.from_numpy(g1), torch.from_numpy(g2)
     assert float((g1 - g2).abs().max()) <= 1e-4 * float(g1.abs().max()), "summed shard gradients != whole-batch gradients"
+    assert abs(l1[0] - l2[0]) <= 1e-5 * max(1.0, abs(l1[0])), (l1, l2)
+    # the loss after one AdamW step: elements whose gradient is rounding noise move by +-lr with a rounding-dependent sign
+    # (Adam normalises the gradient), so the second loss agrees to lr-sized effects only
+    assert abs(l1[1] - l2[1]) <= 3e-4 * max(1.0, abs(l1[1])), (l1, l2)
     for k in sd1:     # after 2 AdamW steps; lr-sized slack for elements whose gradient is rounding noise (Adam sign flips)
         assert torch.allclose(torch.from_numpy(sd1[k]), torch.from_numpy(sd2[k]), rtol=1e-4, atol=4.5e-3), k
