@@ -28,8 +28,9 @@ const char* segmm_last_error(void);
 int segmm_abi_version(void);
 
 /* a1 -- trainer L1 normalisation  x / (sum|x| + 1e-6)  (main_for_seq_leave_earlystop_SegMM.py:272-273).
- * y may be NULL: then only inv_scale[row] = 1/(sum|x|+1e-6) is produced, for the fused a1+a2 GEMM (row_scale). */
-int segmm_l1norm(const float* x, float* y, float* inv_scale, int64_t rows, int D, segmm_stream_t stream);
+ * y may be NULL: then only inv_scale[row] = 1/(sum|x|+1e-6) is produced, for the fused a1+a2 GEMM (row_scale).
+ * amax: optional zeroed [SEGMM_AMAX_SLOTS] array receiving the partial maxima of |y| (see segmm_gemm_h). */
+int segmm_l1norm(const float* x, float* y, float* inv_scale, int64_t rows, int D, float* amax, segmm_stream_t stream);
 
 /* K2/K3/K5/K6 -- every nn.Linear of the path and its gradients (encoder.py:95-104,163-167,183-184,438,445;
  * kn_util/nn_utils/layers/mlp.py:17-23), on the f32 MFMA.

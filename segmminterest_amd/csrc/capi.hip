@@ -149,15 +149,15 @@ __global__ void dropout_mult_kernel(float* out, long long n, DropCfg d) {
 extern "C" {
 
 const char* segmm_last_error(void) { return g_segmm_err; }
-int segmm_abi_version(void) { return 7; }
+int segmm_abi_version(void) { return 8; }
 
-int segmm_l1norm(const float* x, float* y, float* inv_scale, int64_t rows, int D, segmm_stream_t stream) {
+int segmm_l1norm(const float* x, float* y, float* inv_scale, int64_t rows, int D, float* amax, segmm_stream_t stream) {
     SEGMM_REQUIRE(x && (y || inv_scale), "l1norm: null pointer");
     SEGMM_REQUIRE(D > 0 && D % 4 == 0 && aligned16(x) && (!y || aligned16(y)), "l1norm: D %% 4 / alignment (D=%d)", D);
     if (rows <= 0) return 0;
     const int wpb = 4;
     hipLaunchKernelGGL(l1norm_kernel, dim3((unsigned)((rows + wpb - 1) / wpb)), dim3(64 * wpb), 0, (hipStream_t)stream,
-                       x, y, inv_scale, (long long)rows, D);
+                       x, y, inv_scale, (long long)rows, D, amax);
     LAUNCH_CHECK();
     return 0;
 }
@@ -665,5 +665,12 @@ int segmm_pool_tokens_bwd(const float* dOut, float* dU, int Lu, float* dV, int L
     LAUNCH_CHECK();
     return 0;
 }
+
+#ifdef SEGMM_GEMM_TRACE
+int segmm_debug_gemm_trace(unsigned long long* host, int n) {      // debug build only (-DSEGMM_GEMM_TRACE): phase timestamps
+    SEGMM_CHECK_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(segmm::g_gemm_trace), sizeof(unsigned long long) * (size_t)n));
+    return 0;
+}
+#endif
 
 }  // extern "C"

@@ -32,6 +32,14 @@
 
 namespace segmm {
 
+#ifdef SEGMM_GEMM_TRACE
+// debug build only (tools/gemm_trace.py): shader-clock timestamps of the main-loop phases of ONE wave
+__device__ unsigned long long g_gemm_trace[8 * 64];
+#define TRACE_MARK(it, ph) do { if (trace_on && (it) < 64) { g_gemm_trace[(it) * 8 + (ph)] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define TRACE_MARK(it, ph) do { } while (0)
+#endif
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -313,20 +321,45 @@ __global__ __launch_bounds__(256, 2) void gemm_split_mfma(const GemmArgs p, cons
                 }
         }
     };
+#ifdef SEGMM_GEMM_TRACE
+    const bool trace_on = blockIdx.x == gridDim.x / 2 + 3 && blockIdx.z == 0 && tid == 0;
+    int it = 0;
+#endif
     gload(R0, kbeg);
     lstore_at(R0, kbeg);
     __syncthreads();
     for (int k0 = kbeg; k0 < kend; k0 += GBK) {
-        // One tile in flight, three workgroups per CU (NPL 2: 166 registers, 40 KB LDS).  Measured alternatives:
-        // two tiles in flight at two workgroups per CU was 10 % slower -- occupancy hides the L2 latency better.
+        // One tile in flight, three workgroups per CU (NPL 2: 166 registers, 40 KB LDS).  Measured alternatives
+        // (profiles/README.md): two tiles in flight at two workgroups per CU -10 %; the split moved under the MFMAs of the
+        // current tile (packed registers, one or two LDS buffers) -3...-10 %; loads/VALU/LDS-refill removed one at a time
+        // (timing ablations) bound what any staging change can win at +16 % (B loads), +7 % (A loads), +19 % (split + refill).
+        TRACE_MARK(it, 0);
         gload(R0, k0 + GBK);                   // next tile L2/HBM -> registers, lands under the MFMAs
         __builtin_amdgcn_sched_barrier(0);     // (the scheduler would otherwise sink the loads below the MFMAs to save registers)
+        TRACE_MARK(it, 1);
         mma();
+#ifdef SEGMM_GEMM_TRACE
+        __builtin_amdgcn_sched_barrier(0);
+        TRACE_MARK(it, 2);
+#endif
         __syncthreads();
+        TRACE_MARK(it, 3);
         if (k0 + GBK < kend) {
+#ifdef SEGMM_GEMM_TRACE
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            TRACE_MARK(it, 4);
+#endif
             lstore_at(R0, k0 + GBK);
+#ifdef SEGMM_GEMM_TRACE
+            __builtin_amdgcn_sched_barrier(0);
+            TRACE_MARK(it, 5);
+#endif
             __syncthreads();
+            TRACE_MARK(it, 6);
         }
+#ifdef SEGMM_GEMM_TRACE
+        ++it;
+#endif
     }
 
     // ---- epilogue: identical to gemm_f32_mfma (the 32x32 C/D register map does not depend on the input type)

@@ -11,7 +11,8 @@ constexpr int ROW_MAXV = 8;      // float4 per lane kept in registers => d <= 20
 // ---------------------------------------------------------------- a1: x / (sum|x| + 1e-6)
 // trainer-side normalisation, main_for_seq_leave_earlystop_SegMM.py:272-273.  If y == null only the
 // reciprocal scale is written (consumed by the GEMM row_scale epilogue: the fused a1+a2 path).
-__global__ __launch_bounds__(256) void l1norm_kernel(const float* __restrict__ x, float* y, float* inv_scale, long long rows, int D) {
+__global__ __launch_bounds__(256) void l1norm_kernel(const float* __restrict__ x, float* y, float* inv_scale, long long rows, int D,
+                                                     float* amax) {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -26,11 +27,14 @@ __global__ __launch_bounds__(256) void l1norm_kernel(const float* __restrict__ x
     if (inv_scale && lane == 0) inv_scale[row] = inv;
     if (y) {
         const float den = s + 1e-6f;
+        float am = 0.f;
         for (int c = lane * 4; c < D; c += 256) {
             f32x4 v = *(const f32x4*)(xr + c);
             v.x /= den; v.y /= den; v.z /= den; v.w /= den;
             *(f32x4*)(y + row * D + c) = v;
+            am = absmax4(am, v);
         }
+        if (amax) amax_commit(amax, am, (unsigned)row);      // partial maxima of |y| for the fp16x3 GEMM that reads y
     }
 }
 

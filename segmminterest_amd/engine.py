@@ -140,6 +140,9 @@ class ParamStore:
         # set by the trainer.  The table gradient is then built from the gathered per-row gradients on every rank and the
         # table's range is left out of the dense gradient all-reduce (table_ranges()).
         self.row_exchange = None
+        # fp16x3 engine: partial maxima of EXTERNAL input tensors that their producer already has (Trainer.normalize folds
+        # them into the L1-normalisation kernel), keyed by the tensor's device address; absent -> one absmax pass
+        self.ext_amax: Dict[int, torch.Tensor] = {}
         self._side_stream = None
         self._on_side = False
         self.overlap = os.environ.get("SEGMM_OVERLAP", "1") != "0"
@@ -526,7 +529,8 @@ class BackboneRun:
             x = vid_feat.contiguous().float()
             sv["vid_x"] = x
             Din = x.shape[-1]
-            sv["am_vid_x"] = H.absmax(x, Mv, Din, Din) if st.engine_h else None      # external input: its own pass
+            sv["am_vid_x"] = (st.ext_amax.get(x.data_ptr()) if st.ext_amax.get(x.data_ptr()) is not None
+                              else H.absmax(x, Mv, Din, Din)) if st.engine_h else None      # external input
             _lin_fwd(st, Mv, d, Din, x, P + "vid_proj.weight", pre_v, d, a_amax=sv["am_vid_x"],
                      bias=st.p(P + "vid_proj.bias"), residual=st.p(P + "vid_pe.weight"), ldr=d, res_period=S)
         Ev, mev, rev = _empty(ref, Mv, d), _empty(ref, Mv), _empty(ref, Mv)
@@ -543,7 +547,8 @@ class BackboneRun:
             xu = usr_feat.contiguous().float()
             sv["usr_x"] = xu
             Din = xu.shape[-1]
-            sv["am_usr_x"] = H.absmax(xu, Mu, Din, Din) if st.engine_h else None
+            sv["am_usr_x"] = (st.ext_amax.get(xu.data_ptr()) if st.ext_amax.get(xu.data_ptr()) is not None
+                              else H.absmax(xu, Mu, Din, Din)) if st.engine_h else None
             _lin_fwd(st, Mu, d, Din, xu, P + "usr_proj.weight", pre_u, d, a_amax=sv["am_usr_x"],
                      bias=st.p(P + "usr_proj.bias"), residual=st.p(P + "usr_pe.weight"), ldr=d, res_period=Lt)
         Eu, meu, reu = _empty(ref, Mu, d), _empty(ref, Mu), _empty(ref, Mu)
@@ -896,12 +901,15 @@ class BackboneFn(torch.autograd.Function):
         ctx.store = store
         ctx.names = [n for n in store.live_names if n.startswith(prefix)] if prefix else list(store.live_names)
         ctx.mark_non_differentiable(usr)
+        ctx.set_materialize_grads(False)      # no [B, Lt, d] zero tensor for the non-differentiable user embedding output
         return vid, usr
 
     @staticmethod
     def backward(ctx, d_vid, d_usr):
         run, store = ctx.run, ctx.store
         gbuf = _pick_gbuf(store, ctx.names)
+        if d_vid is None:      # the video states took no part in the differentiated scalar
+            d_vid = torch.zeros((run.B, run.S if run.abl != "CrossMLP" else POOL_BINS, run.d), device=store.flat.device)
         run.backward(d_vid, gbuf, on_bucket=store.bucket_hook if gbuf is None else None)
         ctx.run = None
         grads = tuple(store.g(n, gbuf) for n in ctx.names)

@@ -15,7 +15,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SEGMM_LIB") or os.path.join(_HERE, "libsegmm_hip.so")      # SEGMM_LIB: A/B builds of the kernels
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _lib = None
 
@@ -23,7 +23,7 @@ _i, _i64, _f, _u64, _u32, _p = C.c_int, C.c_int64, C.c_float, C.c_uint64, C.c_ui
 
 # name -> argtypes; the single source of truth for the exported symbol set (tests check it against the header)
 SIGNATURES = {
-    "segmm_l1norm": [_p, _p, _p, _i64, _i, _p],
+    "segmm_l1norm": [_p, _p, _p, _i64, _i, _p, _p],
     "segmm_gemm": [_i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _p, _i, _f, _u64, _u32, _i, _p, _i, _i, _p],
     "segmm_gemm_x": [_i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _p, _i, _f, _u64, _u32, _i, _p, _i,
                      _p, _i64, _p, _i64, _i, _p],
@@ -127,11 +127,12 @@ LAYOUT_NT, LAYOUT_NN, LAYOUT_TN = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_DGELU, ACT_RELU, ACT_DRELU = 0, 1, 2, 3, 4
 
 
-def l1norm(x, out=None, inv_scale=None):
+def l1norm(x, out=None, inv_scale=None, amax=None):
+    """``amax``: optional zeroed [AMAX_SLOTS] vector that receives the partial maxima of |out| (fp16x3 GEMM operand)."""
     _dev(x)
     D = x.shape[-1]
     rows = x.numel() // D
-    _check(lib().segmm_l1norm(_ptr(x), _ptr(out), _ptr(inv_scale), rows, D, _stream()), "segmm_l1norm")
+    _check(lib().segmm_l1norm(_ptr(x), _ptr(out), _ptr(inv_scale), rows, D, _ptr(amax), _stream()), "segmm_l1norm")
 
 
 def gemm(layout, M, N, K, A, lda, B, ldb, Cout, ldc, bias=None, row_scale=None, residual=None, ldr=0, res_period=0,

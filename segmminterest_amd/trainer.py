@@ -248,6 +248,7 @@ class Trainer:
         self.sparse_tables = bool(sparse_tables) and self.comm.world > 1 and os.environ.get("SEGMM_SPARSE_TABLES", "1") != "0"
         st.row_exchange = self.comm.gather_rows if self.sparse_tables else None
         self._norm = {}
+        self._norm_amax = None
 
     def _on_bucket(self, name):
         st = self.model._store
@@ -280,7 +281,18 @@ class Trainer:
         buf = self._norm.get(key)
         if buf is None or buf.shape != x.shape or buf.device != x.device:
             buf = self._norm[key] = torch.empty_like(x)
-        H.l1norm(x, buf)
+        st = self.model._store
+        am = None
+        if H.GEMM_ENGINE == H.ENGINE_F16X3:
+            # the fp16x3 GEMM that reads ``buf`` needs max|buf|: folded into this kernel instead of a separate pass over
+            # the features (engine.BackboneRun looks it up by the buffer's address)
+            if self._norm_amax is None or self._norm_amax.device != x.device:
+                self._norm_amax = torch.empty((2, H.AMAX_SLOTS), dtype=torch.float32, device=x.device)
+            if key == "user" or "user" not in self._norm:
+                self._norm_amax.zero_()          # one fill per step: "user" is normalised first (see _features)
+            am = self._norm_amax[0 if key == "user" else 1]
+            st.ext_amax[buf.data_ptr()] = am
+        H.l1norm(x, buf, amax=am)
         return buf
 
     def _features(self, batch):
