@@ -203,19 +203,27 @@ static int gemm_impl(int layout, int M, int N, int K, const float* A, int lda, c
     g.aux = aux; g.ldaux = ldaux; g.epi = activation;
     g.drop = make_drop(drop_p, seed, site);
     g.amax_out = c_amax;
+    // workgroup tile width (fp16x3 engine): 128 x 256 for the weight-gradient form (TN: both operands fp32, k-strided,
+    // transposed in registers) once it has >= 36 wide tiles -- measured on one box, same run: TN 1536x768x51200 634 -> 562 us,
+    // TN 3072x768x20480 491 -> 470 us, but TN 768x768xK 139 -> 154 us and every NT shape (weights pre-split) 2-7 % slower
+    // at the two workgroups per CU the wide tile allows.  SEGMM_GEMM_BN=128 / 256 forces one of them (A/B knob).
+    static const int bn_env = getenv("SEGMM_GEMM_BN") ? atoi(getenv("SEGMM_GEMM_BN")) : 0;
+    const bool wide = engine == 2 && !a_planes && N > 128 && bn_env != 128 &&
+                      (bn_env == 256 || (layout == 2 && (long long)((M + 127) / 128) * ((N + 255) / 256) >= 36));
+    const int BN = wide ? 256 : GBN;
     {   // extents of the operand views (rows x ld, last row only as wide as it is read); the split engines address
         // them through 32-bit buffer offsets, tile overhang included
         const size_t a_rows = layout == 2 ? (size_t)K : (size_t)M, a_cols = layout == 2 ? (size_t)M : (size_t)K;
         const size_t b_rows = layout == 0 ? (size_t)N : (size_t)K, b_cols = layout == 0 ? (size_t)K : (size_t)N;
         const size_t a_ext = ((a_rows - 1) * lda + a_cols) * 4, b_ext = ((b_rows - 1) * ldb + b_cols) * 4;
         const size_t a_reach = (layout == 2 ? (size_t)K + GBK : (size_t)((M + GBM - 1) / GBM) * GBM) * lda * 4 + 4096;
-        const size_t b_reach = (layout == 0 ? (size_t)((N + GBN - 1) / GBN) * GBN : (size_t)K + GBK) * ldb * 4 + 4096;
+        const size_t b_reach = (layout == 0 ? (size_t)((N + BN - 1) / BN) * BN : (size_t)K + GBK) * ldb * 4 + 4096;
         if (engine != 0)
             SEGMM_REQUIRE(a_reach < (1ull << 32) && b_reach < (1ull << 32), "gemm: operand view above the 4 GiB buffer-addressing window of the split engines (%zu / %zu bytes)", a_reach, b_reach);
         g.a_bytes = (uint32_t)(a_ext < (1ull << 32) ? a_ext : 0xffffffffull);
         g.b_bytes = (uint32_t)(b_ext < (1ull << 32) ? b_ext : 0xffffffffull);
     }
-    g.nbm = (M + GBM - 1) / GBM; g.nbn = (N + GBN - 1) / GBN;
+    g.nbm = (M + GBM - 1) / GBM; g.nbn = (N + BN - 1) / BN;
     int ktiles = (K + GBK - 1) / GBK;
     if (splits > ktiles) splits = ktiles;
     if (splits > 1) {
@@ -246,7 +254,14 @@ static int gemm_impl(int layout, int M, int N, int K, const float* A, int lda, c
         q.a_amax = a_amax; q.a_namax = a_namax; q.b_amax = b_amax; q.b_namax = b_namax;
 #define X6(AK, BK, AP, BP, NP) hipLaunchKernelGGL((gemm_split_mfma<AK, BK, AP, BP, NP>), grid, block, 0, s, g, q)
 #define H3(AK, BK, AP, BP) hipLaunchKernelGGL((gemm_split_mfma<AK, BK, AP, BP, 2, true>), grid, block, 0, s, g, q)
-        if (engine == 2) {
+#define H3W(AK, BK, BP) hipLaunchKernelGGL((gemm_split_mfma<AK, BK, false, BP, 2, true, 4>), grid, block, 0, s, g, q)
+        if (engine == 2 && wide) {
+            if (layout == 0) {
+                if (b_planes) H3W(true, true, true);
+                else H3W(true, true, false);
+            } else if (layout == 1) H3W(true, false, false);
+            else H3W(false, false, false);
+        } else if (engine == 2) {
             if (layout == 0) {
                 if (a_planes && b_planes) H3(true, true, true, true);
                 else if (b_planes) H3(true, true, false, true);
@@ -270,6 +285,7 @@ static int gemm_impl(int layout, int M, int N, int K, const float* A, int lda, c
         }
 #undef X6
 #undef H3
+#undef H3W
     }
     LAUNCH_CHECK();
     if (splits > 1) {

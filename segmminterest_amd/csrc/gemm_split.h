@@ -91,27 +91,27 @@ __device__ __forceinline__ void split2_pair(float x0, float x1, uint32_t& ph, ui
     pm = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{r0, r1}, bf16x2));
 }
 // four consecutive-k floats of one row -> one 8-byte store per plane
-template <int NPL, bool F16>
+template <int NPL, bool F16, int PLANE = XPLANE>
 __device__ __forceinline__ void split_store4(__bf16* plane0, int off, f32x4 v, float s) {
     if (F16) {
         uint32_t h0, l0, h1, l1;
         splith_pair(v.x, v.y, s, h0, l0);
         splith_pair(v.z, v.w, s, h1, l1);
         *(uint2*)(plane0 + off) = make_uint2(h0, h1);
-        *(uint2*)(plane0 + XPLANE + off) = make_uint2(l0, l1);
+        *(uint2*)(plane0 + PLANE + off) = make_uint2(l0, l1);
     } else if (NPL == 3) {
         uint32_t h0, m0, l0, h1, m1, l1;
         split3_pair(v.x, v.y, h0, m0, l0);
         split3_pair(v.z, v.w, h1, m1, l1);
         *(uint2*)(plane0 + off) = make_uint2(h0, h1);
-        *(uint2*)(plane0 + XPLANE + off) = make_uint2(m0, m1);
-        *(uint2*)(plane0 + 2 * XPLANE + off) = make_uint2(l0, l1);
+        *(uint2*)(plane0 + PLANE + off) = make_uint2(m0, m1);
+        *(uint2*)(plane0 + 2 * PLANE + off) = make_uint2(l0, l1);
     } else {
         uint32_t h0, m0, h1, m1;
         split2_pair(v.x, v.y, h0, m0);
         split2_pair(v.z, v.w, h1, m1);
         *(uint2*)(plane0 + off) = make_uint2(h0, h1);
-        *(uint2*)(plane0 + XPLANE + off) = make_uint2(m0, m1);
+        *(uint2*)(plane0 + PLANE + off) = make_uint2(m0, m1);
     }
 }
 
@@ -121,28 +121,36 @@ __device__ __forceinline__ f32x16 mfma_x(f32x4 a, f32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-template <bool A_KC, bool B_KC, bool A_PRE, bool B_PRE, int NPL, bool F16 = false>
+// WNT = 32-column MFMA tiles per wave along n: 2 -> 128 x 128 workgroup tile (64 x 64 per wave, 3 workgroups per CU);
+// 4 -> 128 x 256 (64 x 128 per wave: 12 fragment reads per 24 MFMAs instead of 8 per 12, the A operand -- fp32, split on
+// the fly -- loaded, split and stored once per 256 instead of 128 output columns; 60 KB LDS, two workgroups per CU).
+template <bool A_KC, bool B_KC, bool A_PRE, bool B_PRE, int NPL, bool F16 = false, int WNT = 2>
 __global__ __launch_bounds__(256, 2) void gemm_split_mfma(const GemmArgs p, const GemmPlanes q) {
     static_assert(!A_PRE || A_KC, "pre-split operands are k-contiguous");
     static_assert(!B_PRE || B_KC, "pre-split operands are k-contiguous");
     static_assert(!F16 || NPL == 2, "the fp16 engine has two planes per operand");
+    constexpr int BN = 64 * WNT;                   // workgroup tile columns
+    constexpr int RB = 2 * WNT;                    // float4 (or 4 x 4 micro-block rows) per thread of a B k-tile
     constexpr int XOPER = NPL * XPLANE;
-    __shared__ __attribute__((aligned(16))) __bf16 smem[2 * NPL * XPLANE];    // 61 440 B (NPL 3) / 40 960 B (NPL 2); the epilogue needs 18 KB of it
+    constexpr int XPLANE_B = BN * XRS;             // B plane: BN rows
+    static_assert(WNT == 2 || WNT == 4, "128 or 256 columns");
+    static_assert(WNT == 2 || NPL == 2, "the wide tile is built for two-term engines");
+    __shared__ __attribute__((aligned(16))) __bf16 smem[NPL * (XPLANE + XPLANE_B)];    // 128 cols: 61 440 B (NPL 3) / 40 960 B (NPL 2); 256 cols: 61 440 B; the epilogue needs 18 KB of it
     __bf16* As = smem;
     __bf16* Bs = smem + XOPER;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
     const int lb = xcd_remap(blockIdx.x, p.nbm * p.nbn);
-    const int m0 = (lb / p.nbn) * GBM, n0 = (lb % p.nbn) * GBN;
+    const int m0 = (lb / p.nbn) * GBM, n0 = (lb % p.nbn) * BN;
     const int kbeg = blockIdx.z * p.k_per_split;
     const int kend = min(p.K, kbeg + p.k_per_split);
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][WNT];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < WNT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -171,13 +179,13 @@ __global__ __launch_bounds__(256, 2) void gemm_split_mfma(const GemmArgs p, cons
     //  pre-split planes : per plane 128 rows x 4 chunks of 8 halves; f = tid + 256 r (r < 2) -> (row f>>2, chunk f&3)
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     struct Stage {                           // one k-tile in flight between global memory and LDS
-        f32x4 ra[4], rb[4];                  // fp32 operand registers
-        f32x4 qa[A_PRE ? 2 * NPL : 1], qb[B_PRE ? 2 * NPL : 1];     // pre-split operand registers (16 B = 8 x 16 bit each)
+        f32x4 ra[4], rb[RB];                 // fp32 operand registers
+        f32x4 qa[A_PRE ? 2 * NPL : 1], qb[B_PRE ? WNT * NPL : 1];   // pre-split operand registers (16 B = 8 x 16 bit each)
     };
     Stage R0;
     __amdgpu_buffer_rsrc_t rsA[A_PRE ? NPL : 1], rsB[B_PRE ? NPL : 1];
-    uint32_t voa[4], vob[4];                 // byte offsets of this thread's loads at k = 0
-    int ka[4], kb[4];
+    uint32_t voa[4], vob[RB];                // byte offsets of this thread's loads at k = 0
+    int ka[4], kb[RB];
     if (A_PRE) {
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl) rsA[pl] = make_rsrc(q.Ap + (size_t)pl * q.a_pstride, p.a_bytes >> 1);
@@ -203,6 +211,10 @@ __global__ __launch_bounds__(256, 2) void gemm_split_mfma(const GemmArgs p, cons
             ka[r] = ((tid >> 5) << 2) + r;
             voa[r] = ((uint32_t)ka[r] * (uint32_t)p.lda + m0 + ((tid & 31) << 2)) * 4u;
         }
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {          // B: BN rows (k-contiguous forms) or BN/128 micro-blocks of 128 columns (k-strided)
+        const int f = tid + 256 * r;
         if (B_PRE) {
             kb[r] = (f & 3) << 3;
             vob[r] = ((uint32_t)(n0 + (f >> 2)) * (uint32_t)p.ldb + kb[r]) * 2u;
@@ -210,8 +222,8 @@ __global__ __launch_bounds__(256, 2) void gemm_split_mfma(const GemmArgs p, cons
             kb[r] = (f & 7) << 2;
             vob[r] = ((uint32_t)(n0 + (f >> 3)) * (uint32_t)p.ldb + kb[r]) * 4u;
         } else {
-            kb[r] = ((tid >> 5) << 2) + r;
-            vob[r] = ((uint32_t)kb[r] * (uint32_t)p.ldb + n0 + ((tid & 31) << 2)) * 4u;
+            kb[r] = ((tid >> 5) << 2) + (r & 3);
+            vob[r] = ((uint32_t)kb[r] * (uint32_t)p.ldb + n0 + 128 * (r >> 2) + ((tid & 31) << 2)) * 4u;
         }
     }
     auto gload = [&](Stage& R, int k0) {
@@ -228,12 +240,12 @@ __global__ __launch_bounds__(256, 2) void gemm_split_mfma(const GemmArgs p, cons
         }
         if (B_PRE) {
 #pragma unroll
-            for (int r = 0; r < 2; ++r)
+            for (int r = 0; r < WNT; ++r)
 #pragma unroll
                 for (int pl = 0; pl < NPL; ++pl) R.qb[r * NPL + pl] = buf_load4(rsB[pl], vob[r], sb_off);
         } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) R.rb[r] = buf_load4(rsB[0], vob[r], sb_off);
+            for (int r = 0; r < RB; ++r) R.rb[r] = buf_load4(rsB[0], vob[r], sb_off);
         }
     };
     // registers -> 16-bit planes in LDS (rows = m or n).  TAIL: the tile crosses kend (last tile, K % 32 != 0)
@@ -262,24 +274,27 @@ __global__ __launch_bounds__(256, 2) void gemm_split_mfma(const GemmArgs p, cons
         }
         if (B_PRE) {
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
+            for (int r = 0; r < WNT; ++r) {
                 const int f = tid + 256 * r;
                 const bool ok = !TAIL || k0 + kb[r] < kend;
 #pragma unroll
                 for (int pl = 0; pl < NPL; ++pl)
-                    *(f32x4*)(Bs + pl * XPLANE + (f >> 2) * XRS + ((f & 3) << 3)) = ok ? R.qb[r * NPL + pl] : zero4;
+                    *(f32x4*)(Bs + pl * XPLANE_B + (f >> 2) * XRS + ((f & 3) << 3)) = ok ? R.qb[r * NPL + pl] : zero4;
             }
         } else if (B_KC) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int r = 0; r < RB; ++r) {
                 const int f = tid + 256 * r;
-                split_store4<NPL, F16>(Bs, (f >> 3) * XRS + ((f & 7) << 2), (!TAIL || k0 + kb[r] < kend) ? R.rb[r] : zero4, sb);
+                split_store4<NPL, F16, XPLANE_B>(Bs, (f >> 3) * XRS + ((f & 7) << 2), (!TAIL || k0 + kb[r] < kend) ? R.rb[r] : zero4, sb);
             }
         } else {
             const int nrow = (tid & 31) << 2, kcol = (tid >> 5) << 2;
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                split_store4<NPL, F16>(Bs, (nrow + j) * XRS + kcol, f32x4{R.rb[0][j], R.rb[1][j], R.rb[2][j], R.rb[3][j]}, sb);
+            for (int b = 0; b < WNT / 2; ++b)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    split_store4<NPL, F16, XPLANE_B>(Bs, (128 * b + nrow + j) * XRS + kcol,
+                                                     f32x4{R.rb[4 * b][j], R.rb[4 * b + 1][j], R.rb[4 * b + 2][j], R.rb[4 * b + 3][j]}, sb);
         }
     };
     auto lstore_at = [&](const Stage& R, int k0) {
@@ -290,18 +305,21 @@ __global__ __launch_bounds__(256, 2) void gemm_split_mfma(const GemmArgs p, cons
     auto mma = [&]() {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {          // two K=16 steps per tile
-            f32x4 fa[2][NPL], fb[2][NPL];     // 8 sixteen-bit k values per lane
+            f32x4 fa[2][NPL], fb[WNT][NPL];   // 8 sixteen-bit k values per lane
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int pl = 0; pl < NPL; ++pl) {
+                for (int pl = 0; pl < NPL; ++pl)
                     fa[t][pl] = *(const f32x4*)(As + pl * XPLANE + (wm * 64 + t * 32 + li) * XRS + s * 16 + lh * 8);
-                    fb[t][pl] = *(const f32x4*)(Bs + pl * XPLANE + (wn * 64 + t * 32 + li) * XRS + s * 16 + lh * 8);
-                }
+#pragma unroll
+            for (int t = 0; t < WNT; ++t)
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl)
+                    fb[t][pl] = *(const f32x4*)(Bs + pl * XPLANE_B + (wn * 32 * WNT + t * 32 + li) * XRS + s * 16 + lh * 8);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < WNT; ++j) {
                     f32x16 c = acc[i][j];
                     if (F16) {
                         c = mfma_x<true>(fa[i][1], fb[j][0], c);                // lo.hi
@@ -371,7 +389,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_mfma(const GemmArgs p, cons
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < WNT; ++j) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) Cs[((r & 3) + 8 * (r >> 2) + 4 * lh) * 36 + li] = acc[i][j][r];
             __syncthreads();
@@ -379,7 +397,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_mfma(const GemmArgs p, cons
             for (int r4 = 0; r4 < 4; ++r4) {
                 const int idx = lane + 64 * r4;
                 const int row = idx >> 3, c4 = (idx & 7) << 2;
-                const int gm = m0 + wm * 64 + i * 32 + row, gn = n0 + wn * 64 + j * 32 + c4;
+                const int gm = m0 + wm * 64 + i * 32 + row, gn = n0 + wn * 32 * WNT + j * 32 + c4;
                 if (gm < p.M && gn < p.N) {
                     f32x4 v = *(const f32x4*)(Cs + row * 36 + c4);
                     if (F16) v = (v * inv_a) * inv_b;

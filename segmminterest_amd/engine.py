@@ -148,6 +148,7 @@ class ParamStore:
         self.overlap = os.environ.get("SEGMM_OVERLAP", "1") != "0"
         self.defer_wgrad = os.environ.get("SEGMM_DEFER_WGRAD", "0") != "0"
         self.tail_balance = os.environ.get("SEGMM_TAIL_BALANCE", "1") != "0"
+        self.fwd_side = os.environ.get("SEGMM_FWD_SIDE", "0") != "0"      # forward: user-token chain on the side stream (measured: -0.3 %, off)
         self.ln_side = os.environ.get("SEGMM_LN_SIDE", "0") != "0"      # measured: -2 % (kept as a knob)     # measured: no gain (kept as a knob)
         # pre-split bf16 planes of the weights for the bf16x6 GEMM engine: W planes (forward) and W^T planes (dgrad
         # in the NT form), refreshed when the parameters change (one split pass per optimizer step)
@@ -344,8 +345,15 @@ def _empty(ref, *shape, dtype=torch.float32):
 _SPLIT_TARGET = int(os.environ.get("SEGMM_SPLIT_TARGET", "1024"))     # workgroups a split-K weight gradient aims for
 
 
+_BN_ENV = os.environ.get("SEGMM_GEMM_BN", "")
+
+
 def _splits_for(M, N, K):
-    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    """Split-K factor of a weight-gradient GEMM (TN); mirrors the tile-width choice of segmm_gemm_h (capi.hip)."""
+    wide = (H.GEMM_ENGINE == H.ENGINE_F16X3 and N > 128 and _BN_ENV != "128"
+            and (_BN_ENV == "256" or ((M + 127) // 128) * ((N + 255) // 256) >= 36))
+    bn = 256 if wide else 128
+    tiles = ((M + 127) // 128) * ((N + bn - 1) // bn)
     ktiles = (K + 31) // 32
     return max(1, min(32, ktiles, (_SPLIT_TARGET + tiles - 1) // tiles))
 
@@ -513,7 +521,46 @@ class BackboneRun:
         sv = self.sv
         ref = vm
         am = self.am = AmaxArena(st, 6 + 12 * max(self.N - 1, 0))
-        # ---- embedding (encoder.py:425-473)
+        # ---- embedding (encoder.py:425-473).  The user-token chain (input Linear -> LayerNorm -> the first layer's fused
+        # user-token projection: 740 us at config 2) and the video-token chain (497 us) are independent until the first
+        # attention: with SEGMM_FWD_SIDE=1 the user chain is enqueued on the side stream, so that its HBM-bound LayerNorm runs
+        # under the other chain's GEMMs.  Measured on one box, alternating runs: 83.8 k -> 83.6 k interactions/s -- the GEMMs
+        # of both chains share the same power-limited matrix pipes, so the knob is OFF by default.
+        # Every buffer is allocated HERE, on the main stream (the caching allocator must never hand a side-stream block to
+        # the next step while main-stream kernels of this step still read it).
+        pre_u = _empty(ref, Mu, d)
+        Eu, meu, reu = _empty(ref, Mu, d), _empty(ref, Mu), _empty(ref, Mu)
+        am_u = am.new()
+        Yu0 = None
+        layered = self.abl not in MLP_VARIANTS and self.N >= 2
+        fwd_side = st.overlap and st.fwd_side and not bb.id_usr and layered and self.mode != "self"
+        if bb.id_usr:
+            uids = usr_feat.contiguous().to(torch.int64)
+            sv["usr_ids"] = uids
+            H.embed_id_usr(uids, st.p(P + "usr_proj.weight"), d, st.p(P + "usr_pe.weight"), pre_u, B)
+            H.layernorm_fwd(pre_u, st.p(P + "usr_ln.weight"), st.p(P + "usr_ln.bias"), Eu, meu, reu, drop_p=p_drop, seed=seed,
+                            site=_site(self.bi, 0, K_EMB_U), amax=am_u)
+        else:
+            xu = usr_feat.contiguous().float()
+            sv["usr_x"] = xu
+            Din_u = xu.shape[-1]
+            sv["am_usr_x"] = (st.ext_amax.get(xu.data_ptr()) if st.ext_amax.get(xu.data_ptr()) is not None
+                              else H.absmax(xu, Mu, Din_u, Din_u)) if st.engine_h else None
+
+            def usr_chain():
+                _lin_fwd(st, Mu, d, Din_u, xu, P + "usr_proj.weight", pre_u, d, a_amax=sv["am_usr_x"],
+                         bias=st.p(P + "usr_proj.bias"), residual=st.p(P + "usr_pe.weight"), ldr=d, res_period=Lt)
+                H.layernorm_fwd(pre_u, st.p(P + "usr_ln.weight"), st.p(P + "usr_ln.bias"), Eu, meu, reu, drop_p=p_drop, seed=seed,
+                                site=_site(self.bi, 0, K_EMB_U), amax=am_u)
+                if Yu0 is not None:
+                    self._usr_proj_fwd(0, Eu, am_u, Yu0)
+            if fwd_side:
+                Yu0 = _empty(ref, Mu, len(layer_plan(self.mode, 0 < self.N - 2)[1]) * d)
+                with side_work(st):
+                    usr_chain()
+            else:
+                usr_chain()
+        sv["pre_u"], sv["meu"], sv["reu"] = pre_u, meu, reu
         pre_v = _empty(ref, Mv, d)
         if bb.id_vid:
             ids = vid_feat.contiguous().to(torch.int64)
@@ -538,30 +585,12 @@ class BackboneRun:
         H.layernorm_fwd(pre_v, st.p(P + "vid_ln.weight"), st.p(P + "vid_ln.bias"), Ev, mev, rev, drop_p=p_drop, seed=seed,
                         site=_site(self.bi, 0, K_EMB_V), amax=am_v)
         sv["pre_v"], sv["mev"], sv["rev"] = pre_v, mev, rev
-        pre_u = _empty(ref, Mu, d)
-        if bb.id_usr:
-            uids = usr_feat.contiguous().to(torch.int64)
-            sv["usr_ids"] = uids
-            H.embed_id_usr(uids, st.p(P + "usr_proj.weight"), d, st.p(P + "usr_pe.weight"), pre_u, B)
-        else:
-            xu = usr_feat.contiguous().float()
-            sv["usr_x"] = xu
-            Din = xu.shape[-1]
-            sv["am_usr_x"] = (st.ext_amax.get(xu.data_ptr()) if st.ext_amax.get(xu.data_ptr()) is not None
-                              else H.absmax(xu, Mu, Din, Din)) if st.engine_h else None
-            _lin_fwd(st, Mu, d, Din, xu, P + "usr_proj.weight", pre_u, d, a_amax=sv["am_usr_x"],
-                     bias=st.p(P + "usr_proj.bias"), residual=st.p(P + "usr_pe.weight"), ldr=d, res_period=Lt)
-        Eu, meu, reu = _empty(ref, Mu, d), _empty(ref, Mu), _empty(ref, Mu)
-        am_u = am.new()
-        H.layernorm_fwd(pre_u, st.p(P + "usr_ln.weight"), st.p(P + "usr_ln.bias"), Eu, meu, reu, drop_p=p_drop, seed=seed,
-                        site=_site(self.bi, 0, K_EMB_U), amax=am_u)
-        sv["pre_u"], sv["meu"], sv["reu"] = pre_u, meu, reu
         Xv, Xu = Ev, Eu
         sv["layers"] = []
         if self.abl in MLP_VARIANTS:
             return self._mlp_variant_fwd(Ev, Eu, am_v, am_u).view(B, -1, d), Eu.view(B, Lt, d)
         for i in range(max(self.N - 1, 0)):
-            Xv, Xu, am_v, am_u = self._layer_fwd(i, Xv, Xu, am_v, am_u)
+            Xv, Xu, am_v, am_u = self._layer_fwd(i, Xv, Xu, am_v, am_u, Yu_ready=Yu0 if i == 0 else None)
         return Xv.view(B, S, d), Eu.view(B, Lt, d)
 
     # ---------------------------------------------------------------- MLP ablations (encoder.py:392-400,503-511)
@@ -654,7 +683,16 @@ class BackboneRun:
                       Kb=g(cu, "t2t_proj.1"), Vb=g(cu, "t2t_proj.2"), ldkb=ldu, La=S, Lb=0 if mode == "cross" else Lt)
         return vq, uq
 
-    def _layer_fwd(self, i, Xv, Xu, am_Xv, am_Xu):
+    def _usr_proj_fwd(self, i, Xu, am_Xu, Yu):
+        """Yu = Xu . [fused user-token projections of layer i]^T + b."""
+        st, d = self.store, self.d
+        full = i < self.N - 2 and self.mode != "self"
+        usrP = layer_plan(self.mode, full)[1]
+        ca = "%sencoder.layers.%d.cross_attn." % (self.pre, i)
+        nu = len(usrP)
+        _lin_fwd(st, self.Mu, nu * d, d, Xu, ca + usrP[0] + ".weight", Yu, nu * d, bias=st.p(ca + usrP[0] + ".bias"), a_amax=am_Xu)
+
+    def _layer_fwd(self, i, Xv, Xu, am_Xv, am_Xu, Yu_ready=None):
         st, d, P, am = self.store, self.d, self.pre, self.am
         B, S, Lt, Mv, Mu, Hh, dh = self.B, self.S, self.Lt, self.Mv, self.Mu, self.H, self.dh
         full = i < self.N - 2 and self.mode != "self"
@@ -665,9 +703,12 @@ class BackboneRun:
         Yv = _empty(Xv, Mv, nv * d)
         _lin_fwd(st, Mv, nv * d, d, Xv, ca + vidP[0] + ".weight", Yv, nv * d, bias=st.p(ca + vidP[0] + ".bias"), a_amax=am_Xv)
         Yu = None
-        if nu:
+        if Yu_ready is not None:      # computed on the side stream together with the user embedding (forward())
+            Yu = Yu_ready
+            join_side(st)
+        elif nu:
             Yu = _empty(Xv, Mu, nu * d)
-            _lin_fwd(st, Mu, nu * d, d, Xu, ca + usrP[0] + ".weight", Yu, nu * d, bias=st.p(ca + usrP[0] + ".bias"), a_amax=am_Xu)
+            self._usr_proj_fwd(i, Xu, am_Xu, Yu)
         vq, uq = self._attn_views(full, Yv, Yu, nv, nu)
         Av, lse_v = _empty(Xv, Mv, d), _empty(Xv, 2, B, Hh, S)
         am_Av = am.new()

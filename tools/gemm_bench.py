@@ -26,7 +26,10 @@ for lay, M, N, K in shapes:
     if os.environ.get("ZERO") == "1":       # data-dependent power: all-zero operands toggle no datapath bits
         A.zero_(); B.zero_()
     C = torch.empty(M, N, device=dev)
-    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    env_bn = os.environ.get("SEGMM_GEMM_BN", "")
+    bn = 256 if (os.environ.get("SEGMM_GEMM", "f32") == "f16x3" and N > 128 and env_bn != "128" and
+                 (env_bn == "256" or (lay == "TN" and ((M + 127) // 128) * ((N + 255) // 256) >= 36))) else 128
+    tiles = ((M + 127) // 128) * ((N + bn - 1) // bn)
     splits = max(1, min(32, (K + 31) // 32, (1024 + tiles - 1) // tiles)) if lay == "TN" else 1
     ws = torch.empty(splits * M * N, device=dev) if splits > 1 else None
     eng = {"f32": 0, "bf16x6": 1, "f16x3": 2}[os.environ.get("SEGMM_GEMM", "f32")]
