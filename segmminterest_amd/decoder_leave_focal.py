@@ -91,13 +91,8 @@ class HeadLossFn(torch.autograd.Function):
             return logits.new_zeros(()), logits.new_zeros(12), logits
         spec = model._loss_spec
         gt = gt.contiguous().to(torch.int64)
-        v = torch.empty(B, device=raw.device)
-        v2s = torch.empty(B, device=raw.device)
-        norms = torch.empty(3, device=raw.device)
-        H.label_stats(gt, B, S, int(spec.has_focal), v, v2s, norms)
-        v_all, v2_all = v, v2s
-        if model._dp_hook is not None:           # data-parallel: global normalisers
-            v_all, v2_all, norms = model._dp_hook(v, v2s, norms)
+        v_all, v2_all, norms = model._label_stats(gt, B, S) if model._stats is None else model._stats
+        model._stats = None
         expo = model._exposure_tensor(S, raw.device)
         logits = torch.empty(B, S, device=raw.device)
         dlogits = torch.empty(B, S, device=raw.device)
@@ -108,7 +103,9 @@ class HeadLossFn(torch.autograd.Function):
                        v_all, v2_all, v_all.numel(), logits, dlogits, parts)
         losses = torch.empty(12, device=raw.device)
         E._colsum(st, parts, 12, B, 12, losses)
-        total = (losses[:9] * model._coef_tensor(raw.device)).sum()
+        total = torch.empty(1, device=raw.device)
+        H.rowdot(losses, 12, model._coef_tensor(raw.device), None, total, 1, 12)      # sum_i coef_i * loss_i in one launch
+        total = total.view(())
         ctx.dlogits = dlogits
         ctx.mark_non_differentiable(losses, logits)
         return total, losses, logits
@@ -182,6 +179,7 @@ class MultiScaleTemporalDetrLeaveFocal(nn.Module):
         self._store = E.ParamStore(self)
         self._loss_spec = LossSpec(model_cfg) if getattr(model_cfg, "loss_type_list", None) else None
         self._dp_hook = None
+        self._stats = None
         self._consts = {}
         backbone1._store, backbone1._prefix = self._store, "backbone1."
         if backbone2 is not None:
@@ -208,6 +206,16 @@ class MultiScaleTemporalDetrLeaveFocal(nn.Module):
         buckets += E.backbone_layout("backbone1.", self.backbone1)
         return buckets
 
+    def _label_stats(self, gt, B, S):
+        """(view lengths of all rows, second length vector, 3 normalisers) -- global under data parallelism."""
+        v = torch.empty(B, device=gt.device)
+        v2s = torch.empty(B, device=gt.device)
+        norms = torch.empty(3, device=gt.device)
+        H.label_stats(gt, B, S, int(self._loss_spec.has_focal), v, v2s, norms)
+        if self._dp_hook is not None:
+            return self._dp_hook(v, v2s, norms)
+        return v, v2s, norms
+
     def _exposure_tensor(self, S, dev):
         k = ("expo", S, str(dev))
         t = self._consts.get(k)
@@ -222,7 +230,8 @@ class MultiScaleTemporalDetrLeaveFocal(nn.Module):
         k = ("coef", str(dev))
         t = self._consts.get(k)
         if t is None:
-            t = self._consts[k] = torch.tensor(self._loss_spec.coef, dtype=torch.float32, device=dev)
+            c = list(self._loss_spec.coef)[:9]
+            t = self._consts[k] = torch.tensor(c + [0.0] * (12 - len(c)), dtype=torch.float32, device=dev)      # padded to the 12 loss slots
         return t
 
     # ------------------------------------------------------------------ head kernels
@@ -323,6 +332,14 @@ class MultiScaleTemporalDetrLeaveFocal(nn.Module):
             v = pick(it["photo"], vid_image, vid_id, which)
             return E.BackboneFn.apply(st, bb, prefix, idx, u, usr_mask, v, vid_mask, training, seed + idx, *params)[0]
 
+        self._stats = None
+        if mode in ("train", "test"):
+            # label statistics depend on gt only: computed (and, data-parallel, all-gathered) BEFORE the backbones, so that the
+            # collective and its rank skew hide under the forward instead of stalling every rank between forward and loss
+            if self._loss_spec is None:
+                self._loss_spec = LossSpec(self.model_cfg)
+            gtc = gt.contiguous().to(torch.int64)
+            self._stats = self._label_stats(gtc, gtc.shape[0], gtc.shape[1])
         v1 = run(self.backbone1, "backbone1.", 0, 1)
         v2 = run(self.backbone2, "backbone2.", 1, 2) if self.backbone2 is not None else None
         hp = [st._params[n] for n in self._head_param_names()]

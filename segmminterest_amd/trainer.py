@@ -165,18 +165,20 @@ class DPComm:
         """(v_all, v2_all, norms_global): all-gather the per-row view lengths, sum the 3 normalisers."""
         if self.world == 1:
             return v, v2, norms
-        both = torch.stack([v, v2])                               # [2, B_local]; every rank holds the same B_local
-        if self.host_staged and both.is_cuda:
-            hg = torch.empty((self.world * 2, both.shape[1]), dtype=both.dtype)
-            self.dist.all_gather_into_tensor(hg, both.cpu(), group=self.group)
-            gathered = hg.to(both.device)
+        # ONE collective: [v | v2 | norms] of every rank (every rank holds the same B_local); the three normalisers are
+        # summed locally from the gathered copies, in rank order on every rank (identical results everywhere)
+        B = v.shape[0]
+        mine = torch.cat([v, v2, norms.to(v.dtype)])
+        if self.host_staged and mine.is_cuda:
+            hg = torch.empty((self.world * mine.shape[0],), dtype=mine.dtype)
+            self.dist.all_gather_into_tensor(hg, mine.cpu(), group=self.group)
+            gathered = hg.to(mine.device)
         else:
-            gathered = torch.empty((self.world * 2, both.shape[1]), dtype=both.dtype, device=both.device)
-            self.dist.all_gather_into_tensor(gathered, both, group=self.group)
-        gathered = gathered.view(self.world, 2, both.shape[1])
-        norms_g = norms.clone()
-        self._all_reduce(norms_g)
-        return gathered[:, 0].reshape(-1).contiguous(), gathered[:, 1].reshape(-1).contiguous(), norms_g
+            gathered = torch.empty((self.world * mine.shape[0],), dtype=mine.dtype, device=mine.device)
+            self.dist.all_gather_into_tensor(gathered, mine, group=self.group)
+        gathered = gathered.view(self.world, mine.shape[0])
+        norms_g = gathered[:, 2 * B:].sum(0).to(norms.dtype)      # counts: exact in fp32 below 2^24
+        return gathered[:, :B].reshape(-1).contiguous(), gathered[:, B:2 * B].reshape(-1).contiguous(), norms_g
 
     def gather_rows(self, ids, rows):
         """(ids of all ranks [G*B], rows of all ranks [G*B, w]) in rank order: the sparse exchange of id-table gradients
