@@ -204,6 +204,11 @@ int segmm_gather_l1(const float* table, int64_t n_lines, int D, const int64_t* i
 int segmm_segment_weighted_sum(const float* pred, const float* weight, const int64_t* duration, int64_t rows, int S, float* out,
                                segmm_stream_t stream);
 
+/* up to three column sums out_i[n] = sum_m X_i[m, n] of same-shaped matrices in one launch pair (X1/X2 may be null);
+ * workspace: 3 * segmm_colsum_chunks(M) * N floats.  Used for the partial buffers of segmm_layernorm_bwd. */
+int segmm_colsum3(const float* X0, const float* X1, const float* X2, int ld, int64_t M, int N, float* out0, float* out1,
+                  float* out2, float* workspace, segmm_stream_t stream);
+
 /* CrossMLP ablation (encoder.py:392-396,503-506): nn.AdaptiveAvgPool1d(bins) over the token axis of cat(U[B,Lu,d], V[B,Lv,d]):
  * out[b,i,:] = mean of tokens [floor(i T/bins), ceil((i+1) T/bins)), T = Lu+Lv; and its backward (dU, dV overwritten). */
 int segmm_pool_tokens(const float* U, int Lu, const float* V, int Lv, float* out, int B, int d, int bins, segmm_stream_t stream);

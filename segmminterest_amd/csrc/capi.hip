@@ -418,6 +418,26 @@ int segmm_colsum_chunks(int64_t M) {
     return (int)c;
 }
 
+int segmm_colsum3(const float* X0, const float* X1, const float* X2, int ld, int64_t M, int N, float* out0, float* out1,
+                  float* out2, float* workspace, segmm_stream_t stream) {
+    SEGMM_REQUIRE(X0 && out0 && workspace && (!X1 == !out1) && (!X2 == !out2) && (X1 || !X2), "colsum3: pointers");
+    SEGMM_REQUIRE(N % 4 == 0 && ld % 4 == 0 && aligned16(X0) && aligned16(out0) && (!X1 || (aligned16(X1) && aligned16(out1))) &&
+                  (!X2 || (aligned16(X2) && aligned16(out2))) && aligned16(workspace), "colsum3: N/ld %% 4 and alignment");
+    if (M <= 0) return 0;
+    const int nmat = X2 ? 3 : (X1 ? 2 : 1);
+    const int chunks = segmm_colsum_chunks(M);
+    const int rpc = (int)((M + chunks - 1) / chunks);
+    Colsum3 a;
+    a.X[0] = X0; a.X[1] = X1; a.X[2] = X2; a.out[0] = out0; a.out[1] = out1; a.out[2] = out2;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(colsum_partial3_kernel, dim3((N + 255) / 256, chunks, nmat), dim3(256), 0, s, a, ld, (long long)M, N, workspace,
+                       rpc > 0 ? rpc : 1);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_final3_kernel, dim3((N + 255) / 256, 1, nmat), dim3(256), 0, s, (const float*)workspace, chunks, N, a);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 int segmm_colsum(const float* X, int ld, const float* w, int64_t M, int N, float* out, int accumulate,
                  float* workspace, segmm_stream_t stream) {
     SEGMM_REQUIRE(X && out && workspace, "colsum: null pointer");

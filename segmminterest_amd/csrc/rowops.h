@@ -209,6 +209,39 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
     }
 }
 
+// up to three column sums of same-shaped matrices in ONE launch pair (blockIdx.z selects the matrix): the per-workgroup
+// partials that a LayerNorm backward leaves behind (d gamma, d beta, column sums of the forwarded gradient) were six tiny
+// dependent launches per LayerNorm; this makes them two
+struct Colsum3 { const float* X[3]; float* out[3]; };
+__global__ __launch_bounds__(256) void colsum_partial3_kernel(Colsum3 a, int ld, long long M, int N, float* __restrict__ partial,
+                                                              int rows_per_chunk) {
+    __shared__ f32x4 red[4][64];
+    const float* X = a.X[blockIdx.z];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int n = (blockIdx.x * 64 + tx) * 4;
+    const long long r0 = (long long)blockIdx.y * rows_per_chunk;
+    const long long r1 = min(M, r0 + rows_per_chunk);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (n < N)
+        for (long long r = r0 + ty; r < r1; r += 4) acc += *(const f32x4*)(X + r * ld + n);
+    red[ty][tx] = acc;
+    __syncthreads();
+    if (ty == 0 && n < N)
+        *(f32x4*)(partial + ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * N + n) = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
+}
+__global__ __launch_bounds__(256) void colsum_final3_kernel(const float* __restrict__ partial, int P, int N, Colsum3 a) {
+    __shared__ f32x4 red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int n = (blockIdx.x * 64 + tx) * 4;
+    const float* part = partial + (size_t)blockIdx.z * P * N;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (n < N)
+        for (int p = ty; p < P; p += 4) acc += *(const f32x4*)(part + (size_t)p * N + n);
+    red[ty][tx] = acc;
+    __syncthreads();
+    if (ty == 0 && n < N) *(f32x4*)(a.out[blockIdx.z] + n) = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+}
+
 // ---------------------------------------------------------------- interest head: Linear(d,1)  (decoder_leave_focal.py:451,596)
 // out[m] (+)= x[m,:].w (+ bias)
 __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ x, int ld, const float* __restrict__ w,

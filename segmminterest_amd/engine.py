@@ -470,10 +470,12 @@ def _ln_bwd(store, dy, x, mean, rstd, gname, bname, gbuf, dx, dx_drop, rows, d, 
     H.layernorm_bwd(dy, x, mean, rstd, store.p(gname), dx, dx_drop, pg, pb, drop_y_p=drop_y[0], drop_y_site=drop_y[1],
                     drop_b_p=drop_b[0], drop_b_site=drop_b[1], seed=seed, amax=amax, part_dsum=ps)
     with (side_work(store) if store.ln_side else contextlib.nullcontext()):
-        _colsum(store, pg, d, parts, d, store.g(gname, gbuf))
-        _colsum(store, pb, d, parts, d, store.g(bname, gbuf))
+        ws = store.buf("colsum3_ws_side" if store._on_side else "colsum3_ws", (3 * H.colsum_chunks(parts) * d,))
+        Xs, outs = [pg, pb], [store.g(gname, gbuf), store.g(bname, gbuf)]
         if ps is not None:
-            _colsum(store, ps, d, parts, d, dsum_to)
+            Xs.append(ps)
+            outs.append(dsum_to)
+        H.colsum3(Xs, d, parts, d, outs, ws)          # one launch pair instead of three
 
 
 def _mask_u8(m: torch.Tensor) -> torch.Tensor:

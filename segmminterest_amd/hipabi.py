@@ -60,6 +60,7 @@ SIGNATURES = {
     "segmm_survival": [_p, _i, _p, _p, _p, _i, _i, _p],
     "segmm_gather_l1": [_p, _i64, _i, _p, _i64, _i, _p, _p, _p],
     "segmm_segment_weighted_sum": [_p, _p, _p, _i64, _i, _p, _p],
+    "segmm_colsum3": [_p, _p, _p, _i, _i64, _i, _p, _p, _p, _p, _p],
     "segmm_pool_tokens": [_p, _i, _p, _i, _p, _i, _i, _i, _p],
     "segmm_pool_tokens_bwd": [_p, _p, _i, _p, _i, _i, _i, _i, _p],
 }
@@ -437,3 +438,11 @@ def pool_tokens(U, Lu, V, Lv, out, B, d, bins):
 def pool_tokens_bwd(dOut, dU, Lu, dV, Lv, B, d, bins):
     _dev(dOut, dU, dV)
     _check(lib().segmm_pool_tokens_bwd(_ptr(dOut), _ptr(dU), Lu, _ptr(dV), Lv, B, d, bins, _stream()), "segmm_pool_tokens_bwd")
+
+
+def colsum3(Xs, ld, M, N, outs, ws):
+    """Column sums of up to three same-shaped [M, N] matrices in one launch pair; ws: 3 * colsum_chunks(M) * N floats."""
+    X = list(Xs) + [None] * (3 - len(Xs))
+    O = list(outs) + [None] * (3 - len(outs))
+    _check(lib().segmm_colsum3(_ptr(X[0]), _ptr(X[1]), _ptr(X[2]), ld, M, N, _ptr(O[0]), _ptr(O[1]), _ptr(O[2]), _ptr(ws), _stream()),
+           "segmm_colsum3")

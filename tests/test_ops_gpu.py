@@ -677,3 +677,14 @@ def test_embed_id_shuffled_positions():
     H.embed_id_vid(ids, table, dh, fw, fb, vpe, out, B, S, frame_pos=pos)
     ref = torch.cat([table[ids][:, None, :].expand(B, S, dh), pos[:, :, None] * fw[None, None] + fb[None, None]], -1) + vpe[None]
     assert torch.allclose(out.view(B, S, d), ref, atol=1e-6)
+
+
+@pytest.mark.parametrize("M,N,nmat", [(2048, 768, 3), (37, 40, 2), (512, 128, 1), (2048, 1024, 3)])
+def test_colsum3(M, N, nmat):
+    H = _abi()
+    Xs = [_rand(M, N, seed=60 + i) for i in range(nmat)]
+    outs = [torch.full((N,), float("nan"), device=DEV) for _ in range(nmat)]
+    ws = torch.empty(3 * H.colsum_chunks(M) * N, device=DEV)
+    H.colsum3(Xs, N, M, N, outs, ws)
+    for X, o in zip(Xs, outs):
+        assert (o.double() - X.double().sum(0)).abs().max().item() < 1e-4 * max(1.0, X.abs().sum(0).max().item())
