@@ -91,7 +91,10 @@ class HeadLossFn(torch.autograd.Function):
             return logits.new_zeros(()), logits.new_zeros(12), logits
         spec = model._loss_spec
         gt = gt.contiguous().to(torch.int64)
-        v_all, v2_all, norms = model._label_stats(gt, B, S) if model._stats is None else model._stats
+        stats = model._label_stats(gt, B, S) if model._stats is None else model._stats
+        if callable(stats):          # data-parallel: the all-gather was issued before the backbones; wait for it here
+            stats = stats()
+        v_all, v2_all, norms = stats
         model._stats = None
         expo = model._exposure_tensor(S, raw.device)
         logits = torch.empty(B, S, device=raw.device)

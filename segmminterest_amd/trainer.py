@@ -162,23 +162,32 @@ class DPComm:
         return self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group, async_op=async_op)
 
     def global_label_stats(self, v, v2, norms):
-        """(v_all, v2_all, norms_global): all-gather the per-row view lengths, sum the 3 normalisers."""
+        """(v_all, v2_all, norms_global): all-gather the per-row view lengths, sum the 3 normalisers.  Returns the triple
+        (single process) or a closure that waits for the asynchronous collective and returns it."""
         if self.world == 1:
             return v, v2, norms
         # ONE collective: [v | v2 | norms] of every rank (every rank holds the same B_local); the three normalisers are
         # summed locally from the gathered copies, in rank order on every rank (identical results everywhere)
+        # The collective is ASYNCHRONOUS: the caller gets a closure and calls it right before the loss kernel, so the
+        # all-gather (and the rank skew it absorbs) runs under the backbone forward instead of in front of it.
         B = v.shape[0]
         mine = torch.cat([v, v2, norms.to(v.dtype)])
+        work = None
         if self.host_staged and mine.is_cuda:
             hg = torch.empty((self.world * mine.shape[0],), dtype=mine.dtype)
             self.dist.all_gather_into_tensor(hg, mine.cpu(), group=self.group)
             gathered = hg.to(mine.device)
         else:
             gathered = torch.empty((self.world * mine.shape[0],), dtype=mine.dtype, device=mine.device)
-            self.dist.all_gather_into_tensor(gathered, mine, group=self.group)
-        gathered = gathered.view(self.world, mine.shape[0])
-        norms_g = gathered[:, 2 * B:].sum(0).to(norms.dtype)      # counts: exact in fp32 below 2^24
-        return gathered[:, :B].reshape(-1).contiguous(), gathered[:, B:2 * B].reshape(-1).contiguous(), norms_g
+            work = self.dist.all_gather_into_tensor(gathered, mine, group=self.group, async_op=True)
+
+        def finish():
+            if work is not None:
+                work.wait()          # stream-level wait on the communication stream, no host sync
+            g = gathered.view(self.world, mine.shape[0])
+            norms_g = g[:, 2 * B:].sum(0).to(norms.dtype)      # counts: exact in fp32 below 2^24
+            return g[:, :B].reshape(-1).contiguous(), g[:, B:2 * B].reshape(-1).contiguous(), norms_g
+        return finish
 
     def gather_rows(self, ids, rows):
         """(ids of all ranks [G*B], rows of all ranks [G*B, w]) in rank order: the sparse exchange of id-table gradients

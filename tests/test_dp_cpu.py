@@ -35,7 +35,9 @@ def _worker(rank, world, port, q):
         v = (gt[s:e] == 1).sum(1).float()
         v2 = (gt[s:e] >= 0).sum(1).float()
         norms = torch.tensor([float((v < cfg["S"]).sum()), float(e - s), float((gt[s:e] != -2).sum())])
-        v_all, v2_all, norms_g = comm.global_label_stats(v, v2, norms)
+        stats = comm.global_label_stats(v, v2, norms)        # asynchronous all-gather: a closure that waits and slices
+        assert callable(stats)
+        v_all, v2_all, norms_g = stats()
         assert torch.equal(v_all, (gt == 1).sum(1).float())
         assert torch.equal(v2_all, (gt >= 0).sum(1).float())
         assert norms_g.tolist() == [float(((gt == 1).sum(1) < cfg["S"]).sum()), float(B), float((gt != -2).sum())]
