@@ -158,8 +158,20 @@ def main():
     hipabi.ATTN_PROFILE = None
     # the segment attention (QK^T / AV) on its own: algorithmic FLOPs (unpadded: 4 dh Lq T forward, 14 dh Lq T backward
     # per (b, head)) over the HIP-event time of its launches, against the fp32 MFMA peak its v_mfma_f32_16x16x4_f32 has
-    att_ms = sum(e0.elapsed_time(e1) for (*_, e0, e1) in aprof)
-    att_flops = sum((4.0 if k == "fwd" else 14.0) * dh_ * Lq_ * (La_ + Lb_) * B_ * H_ for (k, B_, H_, dh_, Lq_, La_, Lb_, _, _) in aprof)
+    # (the backward may run as three launches -- D, dQ, dK/dV -- with dQ and dK/dV concurrent on two streams: time = union
+    # of the launch intervals, like the GEMM's)
+    att_w = {"fwd": 4.0, "bwd": 14.0, "bwd1": 0.0, "bwd2": 6.0, "bwd3": 8.0}
+    att_flops = sum(att_w[k] * dh_ * Lq_ * (La_ + Lb_) * B_ * H_ for (k, B_, H_, dh_, Lq_, La_, Lb_, _, _) in aprof)
+    abase = aprof[0][7]
+    aiv = sorted((abase.elapsed_time(e0), abase.elapsed_time(e1)) for (*_, e0, e1) in aprof)
+    att_ms, cs, ce = 0.0, aiv[0][0], aiv[0][1]
+    for s_, e_ in aiv[1:]:
+        if s_ > ce:
+            att_ms += ce - cs
+            cs, ce = s_, e_
+        else:
+            ce = max(ce, e_)
+    att_ms += ce - cs
     att_tf = att_flops / (att_ms * 1e-3) / 1e12 if att_ms > 0 else 0.0
 
     # Dominant kernel = the GEMM.  Weight-gradient GEMMs run on a second stream concurrently with the
@@ -221,7 +233,7 @@ def main():
                          "note": "achieved = algorithmic 2MNK of every GEMM launch of the instrumented pass (same steps, run right after the timed region) / union of their HIP-event intervals; "
                                  "peak = dense MFMA peak of the instruction used" + {"bf16x6": " / 6 partial products", "f16x3": " / 3 partial products", "f32": ""}[engine] + traffic_note},
         }
-        rec["roofline_attention"] = {"bound": "mfma", "kernel": "attn_fwd + attn_bwd_dq + attn_bwd_dkv (v_mfma_f32_16x16x4_f32, exact fp32)",
+        rec["roofline_attention"] = {"bound": "mfma", "kernel": "attn_fwd + attn_D + attn_bwd_dq || attn_bwd_dkv (v_mfma_f32_16x16x4_f32, exact fp32; dQ and dK/dV concurrent on two streams)",
                                      "achieved": round(att_tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                      "frac": round(att_tf / PEAK_F32_MFMA_TFLOPS, 4), "ms_per_step": round(att_ms / psteps, 4),
                                      "note": "unpadded algorithmic FLOPs; the kernels pad 40 queries to 48 and 140 keys to 160, rocprof "

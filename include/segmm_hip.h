@@ -115,7 +115,11 @@ int segmm_colsum(const float* X, int ld, const float* w, int64_t M, int N, float
 /* K4 -- joint self+cross attention of one side (encoder.py:44-73,138-161).  Queries Qa/Qb (two projections of the
  * same Lq tokens) against key blocks a (La tokens) and b (Lb tokens); all tensors are [B*L, ld] with head h at
  * columns [h*dh, (h+1)*dh).  Masks are uint8 (torch.bool).  lse: [2, B, H, Lq] floats
- * (plane 0 = softmax row max, plane 1 = 1/row sum, written by the forward); Dvec: [B, H, Lq] floats. */
+ * (plane 0 = softmax row max, plane 1 = 1/row sum, written by the forward); Dvec: [B, H, Lq] floats.
+ * One key block may be empty (La == 0 or Lb == 0, its pointers null): the CrossAtt / SelfAtt ablations.
+ * segmm_attn_bwd phase: 0 = whole backward on `stream` (dQ kernel, which also writes Dvec, then dK/dV kernel);
+ * 1 = Dvec = rowsum(dO * O) only; 2 = dQa/dQb only (Dvec not written); 3 = dKa/dVa/dKb/dVb only (reads Dvec) -- phases 2
+ * and 3 are independent once phase 1 is complete and may run concurrently on two streams. */
 int segmm_attn_fwd(int B, int H, int dh, int Lq, int La, int Lb, const float* Qa, const float* Qb, int ldq,
                    const float* Ka, const float* Va, int ldka, const float* Kb, const float* Vb, int ldkb,
                    const uint8_t* mq, const uint8_t* mka, const uint8_t* mkb, float* O, int ldo, float* lse,
@@ -125,7 +129,7 @@ int segmm_attn_bwd(int B, int H, int dh, int Lq, int La, int Lb, const float* Qa
                    const uint8_t* mq, const uint8_t* mka, const uint8_t* mkb, const float* lse, const float* O, int ldo,
                    const float* dO, int lddo, float* Dvec, float* dQa, float* dQb, int lddq, float* dKa, float* dVa, int lddka,
                    float* dKb, float* dVb, int lddkb, float drop_p, uint64_t seed, uint32_t site,
-                   float* amax_q, float* amax_ka, float* amax_kb, segmm_stream_t stream);
+                   float* amax_q, float* amax_ka, float* amax_kb, int phase, segmm_stream_t stream);
 
 /* K7 -- interest head Linear(d,1) (decoder_leave_focal.py:451,596): out[m] (+)= x[m,:].w (+ bias[0]) and
  * dx[m,:] (+)= g[m]*w.  segmm_vecsum: deterministic out[0] (+)= sum v. */

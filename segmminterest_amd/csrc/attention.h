@@ -58,6 +58,7 @@ struct AttnArgs {
     float *dQa, *dQb; int lddq;
     float *dKa, *dVa; int lddka;
     float *dKb, *dVb; int lddkb;
+    int write_D;                        // dQ kernel: store Dvec (0 when a separate attn_D_kernel launch has produced it)
     int hpb;                            // adjacent heads per workgroup (divides H); waves per workgroup = hpb * row tiles
     uint32_t ka_bytes, kb_bytes, q_bytes, do_bytes;   // extents of the K/V (block a, b), Q and dO views (buffer range check)
     // optional partial maxima (AMAX_SLOTS each, common.h) of what the kernels write, for the fp16x3 GEMM engine:
@@ -382,7 +383,7 @@ __global__ __launch_bounds__(ATT_BWD_THREADS) void attn_bwd_dq_kernel(const Attn
         for (int c = 0; c < C::KS; ++c) Dq += dof[c] * of[c];
         Dq += __shfl_xor(Dq, 16, 64);
         Dq += __shfl_xor(Dq, 32, 64);
-        if (g == 0 && q_in) p.Dvec[(size_t)bh * p.Lq + qi] = Dq;
+        if (p.write_D && g == 0 && q_in) p.Dvec[(size_t)bh * p.Lq + qi] = Dq;
     }
     const float fac = p.drop.scale * p.scale;        // d(logit)/d(raw) of a live, kept element
 
@@ -466,6 +467,27 @@ __global__ __launch_bounds__(ATT_BWD_THREADS) void attn_bwd_dq_kernel(const Attn
         if (p.dQb) am = col_store<DH>(p.dQb + qrow * p.lddq + col0, db, g, am);
     }
     if (p.amax_q) amax_commit(p.amax_q, am, (blockIdx.x * gridDim.y + blockIdx.y) * wpb + wave);
+}
+
+// D[b, h, q] = sum_c dO[b, q, h*DH + c] * O[b, q, h*DH + c] on its own: lets the dQ and the dK/dV kernels of one backward
+// run CONCURRENTLY on two streams (both are latency-bound; dK/dV needs D of every query before it starts).
+// One thread per (b, q, h); adjacent threads read adjacent 4*DH-byte head slices of the same token row.
+template <int DH>
+__global__ __launch_bounds__(256) void attn_D_kernel(const AttnArgs p) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)p.B * p.Lq * p.H) return;
+    const int h = (int)(i % p.H);
+    const long long row = i / p.H;              // b * Lq + q
+    const int b = (int)(row / p.Lq), q = (int)(row % p.Lq);
+    const float* dO = p.dO + row * p.lddo + h * DH;
+    const float* O = p.O + row * p.ldo + h * DH;
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < DH; c += 4) {
+        const f32x4 a = *(const f32x4*)(dO + c), o = *(const f32x4*)(O + c);
+        s += a.x * o.x + a.y * o.y + a.z * o.z + a.w * o.w;
+    }
+    p.Dvec[((size_t)b * p.H + h) * p.Lq + q] = s;
 }
 
 // ------------------------------------------------------------------------------------------ backward: dK, dV

@@ -95,9 +95,16 @@ static int attn_launch_fwd(AttnArgs& a, hipStream_t s) {
 }
 
 template <int DH>
-static int attn_launch_bwd(AttnArgs& a, hipStream_t s) {
+static int attn_launch_bwd(AttnArgs& a, int phase, hipStream_t s) {
     const int Tp = ((a.La + 15) & ~15) + ((a.Lb + 15) & ~15);
-    {
+    if (phase == 1) {          // D only
+        const long long n = (long long)a.B * a.Lq * a.H;
+        hipLaunchKernelGGL((attn_D_kernel<DH>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+        LAUNCH_CHECK();
+        return 0;
+    }
+    a.write_D = phase == 0;
+    if (phase == 0 || phase == 2) {
         const int nqt = (a.Lq + 15) / 16;
         int wq, hpb;
         attn_shape(nqt, a.H, 12, 1, "SEGMM_ATT_HPB_DQ", wq, hpb);
@@ -108,7 +115,7 @@ static int attn_launch_bwd(AttnArgs& a, hipStream_t s) {
         else hipLaunchKernelGGL((attn_bwd_dq_kernel<DH, 12>), grid, block, Tp, s, a);
         LAUNCH_CHECK();
     }
-    {
+    if (phase == 0 || phase == 3) {
         const int nt = Tp / 16;
         int wq, hpb;
         attn_shape(nt, a.H, 12, 1, "SEGMM_ATT_HPB_DKV", wq, hpb);
@@ -149,7 +156,7 @@ __global__ void dropout_mult_kernel(float* out, long long n, DropCfg d) {
 extern "C" {
 
 const char* segmm_last_error(void) { return g_segmm_err; }
-int segmm_abi_version(void) { return 8; }
+int segmm_abi_version(void) { return 9; }
 
 int segmm_l1norm(const float* x, float* y, float* inv_scale, int64_t rows, int D, float* amax, segmm_stream_t stream) {
     SEGMM_REQUIRE(x && (y || inv_scale), "l1norm: null pointer");
@@ -472,7 +479,8 @@ int segmm_attn_bwd(int B, int H, int dh, int Lq, int La, int Lb, const float* Qa
                    const uint8_t* mq, const uint8_t* mka, const uint8_t* mkb, const float* lse, const float* O, int ldo,
                    const float* dO, int lddo, float* Dvec, float* dQa, float* dQb, int lddq, float* dKa, float* dVa, int lddka,
                    float* dKb, float* dVb, int lddkb, float drop_p, uint64_t seed, uint32_t site,
-                   float* amax_q, float* amax_ka, float* amax_kb, segmm_stream_t stream) {
+                   float* amax_q, float* amax_ka, float* amax_kb, int phase, segmm_stream_t stream) {
+    SEGMM_REQUIRE(phase >= 0 && phase <= 3, "attn_bwd: phase %d (0 all, 1 D, 2 dQ, 3 dK/dV)", phase);
     AttnArgs a;
     memset(&a, 0, sizeof(a));
     int rc = attn_fill(a, B, H, dh, Lq, La, Lb, Qa, Qb, ldq, Ka, Va, ldka, Kb, Vb, ldkb, mq, mka, mkb, drop_p, seed, site);
@@ -488,7 +496,7 @@ int segmm_attn_bwd(int B, int H, int dh, int Lq, int La, int Lb, const float* Qa
     a.do_bytes = (uint32_t)((((size_t)B * Lq - 1) * lddo + (size_t)H * dh) * 4);
     a.dQa = dQa; a.dQb = dQb; a.lddq = lddq; a.dKa = dKa; a.dVa = dVa; a.lddka = lddka; a.dKb = dKb; a.dVb = dVb; a.lddkb = lddkb;
     a.amax_q = amax_q; a.amax_ka = amax_ka; a.amax_kb = amax_kb;
-    ATTN_DISPATCH(attn_launch_bwd, dh, a, (hipStream_t)stream);
+    ATTN_DISPATCH(attn_launch_bwd, dh, a, phase, (hipStream_t)stream);
 }
 
 int segmm_rowdot(const float* x, int ld, const float* w, const float* bias, float* out, int64_t rows, int d,

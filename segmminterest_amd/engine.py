@@ -148,6 +148,11 @@ class ParamStore:
         self.overlap = os.environ.get("SEGMM_OVERLAP", "1") != "0"
         self.defer_wgrad = os.environ.get("SEGMM_DEFER_WGRAD", "0") != "0"
         self.tail_balance = os.environ.get("SEGMM_TAIL_BALANCE", "1") != "0"
+        # attention backward as D-kernel, then dQ (third stream) next to dK/dV (main stream).  Measured (same box, alternating
+        # runs): 80.3 k -> 79.6 k interactions/s, the union of the attention intervals unchanged at 1.10-1.14 ms/step -- the two
+        # kernels share the same vector-memory pipeline and simply slow each other down.  OFF by default.
+        self.attn_split = os.environ.get("SEGMM_ATTN_SPLIT", "0") != "0"
+        self._attn_stream = None
         self.fwd_side = os.environ.get("SEGMM_FWD_SIDE", "0") != "0"      # forward: user-token chain on the side stream (measured: -0.3 %, off)
         self.ln_side = os.environ.get("SEGMM_LN_SIDE", "0") != "0"      # measured: -2 % (kept as a knob)     # measured: no gain (kept as a knob)
         # pre-split bf16 planes of the weights for the bf16x6 GEMM engine: W planes (forward) and W^T planes (dgrad
@@ -171,6 +176,11 @@ class ParamStore:
             # stream's kernels (a 49 us LayerNorm backward was seen taking 470 us next to a same-priority GEMM)
             self._side_stream = torch.cuda.Stream(device=self.flat.device, priority=int(os.environ.get("SEGMM_SIDE_PRIORITY", "1")))
         return self._side_stream
+
+    def attn_stream(self):
+        if self._attn_stream is None or self._attn_stream.device != self.flat.device:
+            self._attn_stream = torch.cuda.Stream(device=self.flat.device)
+        return self._attn_stream
 
     # -- layout
     def _layout(self):
@@ -476,6 +486,24 @@ def _ln_bwd(store, dy, x, mean, rstd, gname, bname, gbuf, dx, dx_drop, rows, d, 
             Xs.append(ps)
             outs.append(dsum_to)
         H.colsum3(Xs, d, parts, d, outs, ws)          # one launch pair instead of three
+
+
+def _attn_bwd(store, *args, **kw):
+    """Attention backward.  SEGMM_ATTN_SPLIT=1: Dvec = rowsum(dO * O) first (one small kernel), then the dQ kernel on a third
+    stream CONCURRENTLY with the dK/dV kernel on the main stream (no gain measured, see ParamStore.attn_split).  The
+    partial-maxima slots they share are integer atomic maxima (order-independent), the outputs are disjoint column blocks."""
+    if not (store.overlap and store.attn_split):
+        H.attn_bwd(*args, **kw)
+        return
+    H.attn_bwd(*args, phase=1, **kw)
+    main, att = torch.cuda.current_stream(), store.attn_stream()
+    ev = torch.cuda.Event()
+    ev.record(main)
+    att.wait_event(ev)
+    with torch.cuda.stream(att):
+        H.attn_bwd(*args, phase=2, **kw)
+    H.attn_bwd(*args, phase=3, **kw)
+    main.wait_stream(att)
 
 
 def _mask_u8(m: torch.Tensor) -> torch.Tensor:
@@ -787,7 +815,7 @@ class BackboneRun:
         deferred = [] if st.defer_wgrad else None
         dR1v, dAv = self._side_post_bwd(i, L, "vid", rec["v"], dXv_out, Mv, (K_AO_V, K_MI_V, K_MO_V), gbuf, "v%d" % i, deferred)
         flush_deferred(st, deferred)          # the three weight-gradient GEMMs of this side run under the attention backward
-        H.attn_bwd(B, Hh, dh, S, vq["La"], vq["Lb"], vq["Qa"], vq["Qb"], vq["ldq"], vq["Ka"], vq["Va"], vq["ldka"], vq["Kb"], vq["Vb"],
+        _attn_bwd(st, B, Hh, dh, S, vq["La"], vq["Lb"], vq["Qa"], vq["Qb"], vq["ldq"], vq["Ka"], vq["Va"], vq["ldka"], vq["Kb"], vq["Vb"],
                    vq["ldkb"], self.vm, self.vm, self.um, rec["lse_v"], rec["v"]["A"], d, dAv, d, Dv, dvq["Qa"], dvq["Qb"], dvq["ldq"],
                    dvq["Ka"], dvq["Va"], dvq["ldka"], dvq["Kb"], dvq["Vb"], dvq["ldkb"], drop_p=self.p_drop, seed=self.seed,
                    site=_site(self.bi, i, K_ATT_V), amax_q=am_dYv, amax_ka=am_dYv, amax_kb=am_dYu)
@@ -795,7 +823,7 @@ class BackboneRun:
         if full:
             dR1u, dAu = self._side_post_bwd(i, L, "usr", rec["u"], dXu_out, Mu, (K_AO_U, K_MI_U, K_MO_U), gbuf, "u%d" % i, deferred)
             flush_deferred(st, deferred)
-            H.attn_bwd(B, Hh, dh, Lt, uq["La"], uq["Lb"], uq["Qa"], uq["Qb"], uq["ldq"], uq["Ka"], uq["Va"], uq["ldka"], uq["Kb"],
+            _attn_bwd(st, B, Hh, dh, Lt, uq["La"], uq["Lb"], uq["Qa"], uq["Qb"], uq["ldq"], uq["Ka"], uq["Va"], uq["ldka"], uq["Kb"],
                        uq["Vb"], uq["ldkb"], self.um, self.vm, self.um, rec["lse_u"], rec["u"]["A"], d, dAu, d, Dv,
                        duq["Qa"], duq["Qb"], duq["ldq"], duq["Ka"], duq["Va"], duq["ldka"], duq["Kb"], duq["Vb"], duq["ldkb"],
                        drop_p=self.p_drop, seed=self.seed, site=_site(self.bi, i, K_ATT_U),

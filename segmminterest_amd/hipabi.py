@@ -15,7 +15,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SEGMM_LIB") or os.path.join(_HERE, "libsegmm_hip.so")      # SEGMM_LIB: A/B builds of the kernels
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _lib = None
 
@@ -41,7 +41,7 @@ SIGNATURES = {
     "segmm_colsum": [_p, _i, _p, _i64, _i, _p, _i, _p, _p],
     "segmm_attn_fwd": [_i] * 6 + [_p, _p, _i, _p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _i, _p, _f, _u64, _u32, _p, _p],
     "segmm_attn_bwd": [_i] * 6 + [_p, _p, _i, _p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _i, _p, _i, _p, _p, _p, _i, _p, _p, _i,
-                                  _p, _p, _i, _f, _u64, _u32, _p, _p, _p, _p],
+                                  _p, _p, _i, _f, _u64, _u32, _p, _p, _p, _i, _p],
     "segmm_rowdot": [_p, _i, _p, _p, _p, _i64, _i, _i, _p],
     "segmm_rowscale_bcast": [_p, _p, _p, _i, _i64, _i, _i, _p],
     "segmm_vecsum": [_p, _i64, _p, _i, _p],
@@ -279,7 +279,8 @@ def attn_fwd(B, H, dh, Lq, La, Lb, Qa, Qb, ldq, Ka, Va, ldka, Kb, Vb, ldkb, mq, 
 
 def attn_bwd(B, H, dh, Lq, La, Lb, Qa, Qb, ldq, Ka, Va, ldka, Kb, Vb, ldkb, mq, mka, mkb, lse, O, ldo, dO, lddo, Dvec,
              dQa, dQb, lddq, dKa, dVa, lddka, dKb, dVb, lddkb, drop_p=0.0, seed=0, site=0, amax_q=None, amax_ka=None,
-             amax_kb=None):
+             amax_kb=None, phase=0):
+    """``phase``: 0 whole backward; 1 Dvec only; 2 dQ only; 3 dK/dV only (2 and 3 may run concurrently after 1)."""
     def P(x):
         return 0 if x is None else x[0].data_ptr() + 4 * x[1]
     prof = ATTN_PROFILE
@@ -289,11 +290,11 @@ def attn_bwd(B, H, dh, Lq, La, Lb, Qa, Qb, ldq, Ka, Va, ldka, Kb, Vb, ldkb, mq, 
     _check(lib().segmm_attn_bwd(B, H, dh, Lq, La, Lb, P(Qa), P(Qb), ldq, P(Ka), P(Va), ldka, P(Kb), P(Vb), ldkb,
                                 _ptr(mq), _ptr(mka), _ptr(mkb), _ptr(lse), _ptr(O), ldo, _ptr(dO), lddo, _ptr(Dvec), P(dQa),
                                 P(dQb), lddq, P(dKa), P(dVa), lddka, P(dKb), P(dVb), lddkb, float(drop_p), int(seed),
-                                int(site), _ptr(amax_q), _ptr(amax_ka), _ptr(amax_kb), _stream()), "segmm_attn_bwd")
+                                int(site), _ptr(amax_q), _ptr(amax_ka), _ptr(amax_kb), int(phase), _stream()), "segmm_attn_bwd")
     if prof is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        prof.append(("bwd", B, H, dh, Lq, La, Lb, e0, e1))
+        prof.append(("bwd" if phase == 0 else "bwd%d" % phase, B, H, dh, Lq, La, Lb, e0, e1))
 
 
 def rowdot(x, ld, w, bias, out, rows, d, accumulate=False, x_off=0, w_off=0):

@@ -688,3 +688,37 @@ def test_colsum3(M, N, nmat):
     H.colsum3(Xs, N, M, N, outs, ws)
     for X, o in zip(Xs, outs):
         assert (o.double() - X.double().sum(0)).abs().max().item() < 1e-4 * max(1.0, X.abs().sum(0).max().item())
+
+
+def test_attention_bwd_phases_equal_whole():
+    """phase 1 (D) + 2 (dQ) + 3 (dK/dV) reproduce the single-call backward bit for bit."""
+    H = _abi()
+    B, H_, dh, Lq, La, Lb = 2, 16, 48, 40, 40, 100
+    d = H_ * dh
+    g = torch.Generator().manual_seed(77)
+    mk = lambda L: (torch.randn(B, L, d, generator=g) * 0.7).to(DEV)
+    Qa, Qb, Ka, Va, Kb, Vb = mk(Lq), mk(Lq), mk(La), mk(La), mk(Lb), mk(Lb)
+    mq = (torch.rand(B, Lq, generator=g) < 0.8).to(DEV)
+    mka = (torch.rand(B, La, generator=g) < 0.8).to(DEV)
+    mkb = (torch.rand(B, Lb, generator=g) < 0.7).to(DEV)
+    O = torch.empty(B * Lq, d, device=DEV)
+    lse = torch.empty(2, B, H_, Lq, device=DEV)
+    z = lambda t: (t, 0)
+    H.attn_fwd(B, H_, dh, Lq, La, Lb, z(Qa), z(Qb), d, z(Ka), z(Va), d, z(Kb), z(Vb), d, mq, mka, mkb, O, d, lse, drop_p=0.1, seed=5, site=3)
+    dO = torch.randn(B * Lq, d, generator=g).to(DEV)
+
+    def run(phases):
+        Dv = torch.full((B, H_, Lq), float("nan"), device=DEV)
+        outs = [torch.full_like(t, float("nan")) for t in (Qa, Qb, Ka, Va, Kb, Vb)]
+        for ph in phases:
+            H.attn_bwd(B, H_, dh, Lq, La, Lb, z(Qa), z(Qb), d, z(Ka), z(Va), d, z(Kb), z(Vb), d, mq, mka, mkb, lse, O, d, dO, d, Dv,
+                       z(outs[0]), z(outs[1]), d, z(outs[2]), z(outs[3]), d, z(outs[4]), z(outs[5]), d, drop_p=0.1, seed=5, site=3,
+                       phase=ph)
+        return Dv, outs
+    D0, ref = run([0])
+    D1, got = run([1, 2, 3])
+    assert (D0 - D1).abs().max().item() < 1e-5 * max(1.0, D0.abs().max().item())      # different summation order of the 48 products
+    for a, b in zip(ref[:2], got[:2]):
+        assert torch.equal(a, b)                  # dQ: the kernel computes its own D either way
+    for a, b in zip(ref[2:], got[2:]):
+        assert (a - b).abs().max().item() < 2e-5 * max(1.0, a.abs().max().item())        # dK/dV read the D kernel's D
