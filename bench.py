@@ -160,7 +160,7 @@ def main():
     # per (b, head)) over the HIP-event time of its launches, against the fp32 MFMA peak its v_mfma_f32_16x16x4_f32 has
     # (the backward may run as three launches -- D, dQ, dK/dV -- with dQ and dK/dV concurrent on two streams: time = union
     # of the launch intervals, like the GEMM's)
-    att_w = {"fwd": 4.0, "bwd": 14.0, "bwd1": 0.0, "bwd2": 6.0, "bwd3": 8.0}
+    att_w = {"fwd": 4.0, "bwd": 14.0, "bwd1": 0.0, "bwd2": 6.0, "bwd3": 8.0, "bwd4": 10.0}      # fused: S and dP computed once
     att_flops = sum(att_w[k] * dh_ * Lq_ * (La_ + Lb_) * B_ * H_ for (k, B_, H_, dh_, Lq_, La_, Lb_, _, _) in aprof)
     abase = aprof[0][7]
     aiv = sorted((abase.elapsed_time(e0), abase.elapsed_time(e1)) for (*_, e0, e1) in aprof)
@@ -233,7 +233,7 @@ def main():
                          "note": "achieved = algorithmic 2MNK of every GEMM launch of the instrumented pass (same steps, run right after the timed region) / union of their HIP-event intervals; "
                                  "peak = dense MFMA peak of the instruction used" + {"bf16x6": " / 6 partial products", "f16x3": " / 3 partial products", "f32": ""}[engine] + traffic_note},
         }
-        rec["roofline_attention"] = {"bound": "mfma", "kernel": "attn_fwd + attn_D + attn_bwd_dq || attn_bwd_dkv (v_mfma_f32_16x16x4_f32, exact fp32; dQ and dK/dV concurrent on two streams)",
+        rec["roofline_attention"] = {"bound": "mfma", "kernel": "attn_fwd + attn_D + attn_bwd_fused (v_mfma_f32_16x16x4_f32, exact fp32; backward = dQ + dK + dV in one kernel, S and dP computed once: 10 dh Lq T FLOP instead of 14)",
                                      "achieved": round(att_tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                      "frac": round(att_tf / PEAK_F32_MFMA_TFLOPS, 4), "ms_per_step": round(att_ms / psteps, 4),
                                      "note": "unpadded algorithmic FLOPs; the kernels pad 40 queries to 48 and 140 keys to 160, rocprof "

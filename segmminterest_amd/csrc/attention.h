@@ -621,4 +621,229 @@ __global__ __launch_bounds__(ATT_BWD_THREADS) void attn_bwd_dkv_kernel(const Att
     if (slot) amax_commit(slot, am, (blockIdx.x * gridDim.y + blockIdx.y) * wpb + wave);
 }
 
+// ------------------------------------------------------------------------------------------ backward: fused dQ + dK + dV
+// ONE workgroup per (b, h); the query-side tensors every key tile needs (Qa, Qb, dO: Lq x DH each) are staged ONCE in LDS
+// in whole rows and read from there in both fragment forms, instead of being fetched from global memory in fragment shape
+// (16 rows x 64 B per instruction) by every key-tile wave in row AND column form -- 20 fetches of Q and dO per head in the
+// two-kernel version, which is bound by the vector-memory pipeline, not by HBM or the matrix cores.  S and dP are computed
+// once per (query tile, key tile) pair instead of once in each of two kernels.
+//   wave w owns up to two key tiles of ONE key block (block-a waves first): K / V row fragments and K column fragments of a
+//   tile come straight from global memory (each is needed by this wave only);
+//   per query tile: S = Q K^T, dP = dO V^T (operands from LDS) -> P, dS;  dV += P^T dO, dK += dS^T Q;
+//   dS is transposed through a 16 x 16 per-wave LDS scratch and dQ^T += K^T dS^T accumulates in registers over the wave's
+//   tiles; the waves then add their dQ partials into an LDS accumulator ONE WAVE AT A TIME in wave order (plain
+//   read-modify-write, no atomics: bitwise reproducible) and the workgroup stores dQa / dQb in whole rows.
+// Needs Dvec = rowsum(dO * O) from attn_D_kernel (phase 1).  LDS: 5 x [Lq_p][DH + 4] floats + statistics + scratch
+// (51 KB at Lq = 40, DH = 48: two workgroups per CU).
+constexpr int ATT_FUSED_MAXW = 12;
+// NW = waves per workgroup the launch bound is made for (blockDim.x <= 64 NW); 3 waves per SIMD: up to 6 waves two workgroups share a CU
+// (<= 168 registers), so that one head's staging / dQ reduction phases run under the other's MFMA phase.
+// TPW = key tiles per wave (1: one wave per key tile, best balance of the MFMA work over the 4 SIMDs; 2: half the waves).
+template <int DH, int NW, int TPW>
+__global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void attn_bwd_fused_kernel(const AttnArgs p) {
+    using C = AttnCfg<DH>;
+    constexpr int RS = DH + 4;                 // LDS row stride (floats): 16-byte aligned rows, conflict-free fragment reads
+    constexpr int TS = 20;                     // row stride of the 16 x 16 transpose scratch
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int bh = xcd_remap(blockIdx.x, gridDim.x), b = bh / p.H, h = bh % p.H;
+    const int La_p = round16(p.La), Lb_p = round16(p.Lb), Tp = La_p + Lb_p, nta = La_p >> 4, ntb = Lb_p >> 4;
+    const int Lq_p = round16(p.Lq), nqt = Lq_p >> 4;
+    const int col0 = h * DH;
+    float* sQa = smem_f;
+    float* sQb = sQa + Lq_p * RS;
+    float* sdO = sQb + Lq_p * RS;
+    float* sdQa = sdO + Lq_p * RS;
+    float* sdQb = sdQa + Lq_p * RS;
+    float* s_mx = sdQb + Lq_p * RS;
+    float* s_inv = s_mx + Lq_p;
+    float* s_D = s_inv + Lq_p;
+    float* s_tr = s_D + Lq_p + wave * (16 * TS);                            // this wave's transpose scratch
+    uint8_t* qm = (uint8_t*)(s_D + Lq_p + nw * (16 * TS));                  // [Lq_p] 1 valid query, 0 masked, 2 pad
+    uint8_t* km = qm + Lq_p;                                                // [Tp]
+    // ---- this wave's key tiles: all in one block.  The K / V fragments of the first one are requested BEFORE the staging
+    // below (they do not depend on it): their latency hides under the staging loads and the barrier.
+    const int wa = (nta + TPW - 1) / TPW;                  // waves of block a
+    const bool isa = wave < wa;
+    const int wt0 = isa ? TPW * wave : nta + TPW * (wave - wa);             // first padded key tile
+    const int wt1 = min(wt0 + TPW, isa ? nta : nta + ntb);                  // one past the last
+    KeyBlocks<DH> kbk;
+    kbk.init(p, b, col0, l15, g);
+    float kf[C::KS], vf[C::KS], kc[4][C::CT];
+    auto load_tile = [&](int jt) {
+        if (isa) {
+            const uint32_t so = (uint32_t)(16 * jt) * kbk.pitch_a;
+            frag_load<DH>(kf, kbk.ka, kbk.row_a, so);
+            frag_load<DH>(vf, kbk.va, kbk.row_a, so);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) col_load<DH>(kc[s4], kbk.ka, kbk.col_a, (uint32_t)(16 * jt + s4) * kbk.pitch_a, l15);
+        } else {
+            const uint32_t so = (uint32_t)(16 * (jt - nta)) * kbk.pitch_b;
+            frag_load<DH>(kf, kbk.kb, kbk.row_b, so);
+            frag_load<DH>(vf, kbk.vb, kbk.row_b, so);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) col_load<DH>(kc[s4], kbk.kb, kbk.col_b, (uint32_t)(16 * (jt - nta) + s4) * kbk.pitch_b, l15);
+        }
+    };
+    if (wt0 < wt1) load_tile(wt0);
+    // ---- stage the query side: whole rows, float4, rows >= Lq zero; zero the dQ accumulators
+    for (int i = threadIdx.x; i < Lq_p * (DH / 4); i += blockDim.x) {
+        const int q = i / (DH / 4), c = (i - q * (DH / 4)) * 4;
+        f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = va, vo = va;
+        if (q < p.Lq) {
+            const size_t row = (size_t)b * p.Lq + q;
+            va = *(const f32x4*)(p.Qa + row * p.ldq + col0 + c);
+            vb = *(const f32x4*)(p.Qb + row * p.ldq + col0 + c);
+            vo = *(const f32x4*)(p.dO + row * p.lddo + col0 + c);
+        }
+        *(f32x4*)(sQa + q * RS + c) = va;
+        *(f32x4*)(sQb + q * RS + c) = vb;
+        *(f32x4*)(sdO + q * RS + c) = vo;
+        *(f32x4*)(sdQa + q * RS + c) = f32x4{0.f, 0.f, 0.f, 0.f};
+        *(f32x4*)(sdQb + q * RS + c) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int q = threadIdx.x; q < Lq_p; q += blockDim.x) {
+        const bool in = q < p.Lq;
+        s_mx[q] = in ? p.lse[(size_t)bh * p.Lq + q] : 0.f;
+        s_inv[q] = in ? p.lse[(size_t)p.B * p.H * p.Lq + (size_t)bh * p.Lq + q] : 0.f;
+        s_D[q] = in ? p.Dvec[(size_t)bh * p.Lq + q] : 0.f;
+        qm[q] = in ? (p.mq[(size_t)b * p.Lq + q] ? 1 : 0) : 2;
+    }
+    stage_kmask(km, p.mka, p.mkb, b, p.La, p.Lb, La_p, Lb_p);
+    __syncthreads();
+
+    const float* sQ = isa ? sQa : sQb;
+    const float fscale = p.scale;
+    f32x4 dq[3][C::CT];                                    // dQ^T partial of this wave: up to 3 query tiles (Lq <= 48) ...
+    constexpr int MAXQT = 3;
+#pragma unroll
+    for (int qt = 0; qt < MAXQT; ++qt)
+#pragma unroll
+        for (int ct = 0; ct < C::CT; ++ct) dq[qt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int jt = wt0; jt < wt1; ++jt) {
+        const int jp = 16 * jt + l15;                      // this lane's key (padded index)
+        const uint8_t kflag = km[jp];
+        if (TPW > 1 && jt > wt0) load_tile(jt);
+        f32x4 dk[C::CT], dv[C::CT];
+#pragma unroll
+        for (int ct = 0; ct < C::CT; ++ct) { dk[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int qt = 0; qt < MAXQT; ++qt) {
+            if (qt < nqt) {
+                // row fragments (lane&15 = query): element k = 16 i + 4 g + e of the row, like frag_load
+                float qf[C::KS], dof[C::KS];
+                const float* qrow = sQ + (16 * qt + l15) * RS + C::row_off(g);
+                const float* drow = sdO + (16 * qt + l15) * RS + C::row_off(g);
+                frag_load_ptr<DH>(qf, qrow);
+                frag_load_ptr<DH>(dof, drow);
+                f32x4 sv = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < C::KS; ++c) {
+                    sv = MFMA16(qf[c], kf[c], sv);
+                    dp = MFMA16(dof[c], vf[c], dp);
+                }
+                const f32x4 mxq = *(const f32x4*)(s_mx + 16 * qt + 4 * g), invq = *(const f32x4*)(s_inv + 16 * qt + 4 * g);
+                const f32x4 Dq = *(const f32x4*)(s_D + 16 * qt + 4 * g);
+                const uint32_t qfl = *(const uint32_t*)(qm + 16 * qt + 4 * g);
+                f32x4 Pv, dSv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int qi = 16 * qt + 4 * g + r;
+                    const uint32_t qf_ = (qfl >> (8 * r)) & 0xff;
+                    const bool valid = (qf_ == 1) && (kflag == 1);
+                    float mult = 1.f;
+                    if (p.drop.p > 0.f && qf_ != 2) mult = drop_mult1(p.drop, ((uint64_t)bh * p.Lq + qi) * Tp + jp);
+                    const float v = logit_xform(sv[r], valid, mult, fscale);
+                    const float pr = (kflag == 2 || qf_ == 2) ? 0.f : fast_exp(v - mxq[r]) * invq[r];
+                    Pv[r] = pr;
+                    dSv[r] = valid ? pr * (dp[r] - Dq[r]) * mult * fscale : 0.f;
+                }
+                // column fragments from LDS: lane (c, g) takes rows 16 qt + 4 g + s4, head columns 16 ct + c
+                // (=> result register r of tile ct is head column 16 ct + 4 g + r: one float4 per tile)
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const float* qr = sQ + (16 * qt + 4 * g + s4) * RS;
+                    const float* dr = sdO + (16 * qt + 4 * g + s4) * RS;
+#pragma unroll
+                    for (int ct = 0; ct < C::CT; ++ct) {
+                        const int cc = 16 * ct + l15;
+                        const float qv = cc < DH ? qr[cc] : 0.f, dv_ = cc < DH ? dr[cc] : 0.f;
+                        dv[ct] = MFMA16(dv_, Pv[s4], dv[ct]);
+                        dk[ct] = MFMA16(qv, dSv[s4], dk[ct]);
+                    }
+                }
+                // dS[query 4g+r][key l15] -> dS^T fragments (lane&15 = query, registers = keys 4g..4g+3) through the scratch
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s_tr[(4 * g + r) * TS + l15] = dSv[r];
+                __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0): this wave's own LDS writes have landed
+                __builtin_amdgcn_wave_barrier();
+                const f32x4 dST = *(const f32x4*)(s_tr + l15 * TS + 4 * g);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                    for (int ct = 0; ct < C::CT; ++ct) dq[qt][ct] = MFMA16(kc[s4][ct], dST[s4], dq[qt][ct]);
+            }
+        }
+        // dK / dV rows of this tile: lane (key l15, g), tile ct register r = head column 16 ct + 4 g + r
+        const bool ka = jp < La_p;
+        const int jloc = ka ? jp : jp - La_p;
+        const bool real = ka ? (jloc < p.La) : (jloc < p.Lb);
+        float am = 0.f;
+        if (real) {
+            float* dKp = (ka ? p.dKa + (size_t)(b * p.La + jloc) * p.lddka : p.dKb + (size_t)(b * p.Lb + jloc) * p.lddkb) + col0;
+            float* dVp = (ka ? p.dVa + (size_t)(b * p.La + jloc) * p.lddka : p.dVb + (size_t)(b * p.Lb + jloc) * p.lddkb) + col0;
+#pragma unroll
+            for (int ct = 0; ct < C::CT; ++ct) {
+                if (16 * ct + 4 * g < DH) {
+                    *(f32x4*)(dKp + 16 * ct + 4 * g) = dk[ct];
+                    *(f32x4*)(dVp + 16 * ct + 4 * g) = dv[ct];
+                    am = absmax4(absmax4(am, dk[ct]), dv[ct]);
+                }
+            }
+        }
+        float* slot = isa ? p.amax_ka : p.amax_kb;
+        if (slot) amax_commit(slot, am, blockIdx.x * nw + wave);
+    }
+
+    // ---- dQ: the waves add their partials into LDS one at a time, in wave order (deterministic)
+    // lane (query l15, g) holds, per query tile and column tile ct, head columns CT*(4g + r) + ct (col_load mapping of kc)
+    // (block-a waves add into sdQa, block-b waves into sdQb: the two chains advance together, max(wa, wb) turns)
+    float* sdQ = isa ? sdQa : sdQb;
+    const int my_turn = isa ? wave : wave - wa;
+    const int nturn = max(wa, nw - wa);
+    for (int turn = 0; turn < nturn; ++turn) {
+        if (my_turn == turn && wt0 < wt1) {
+#pragma unroll
+            for (int qt = 0; qt < MAXQT; ++qt) {
+                if (qt < nqt && 4 * C::CT * g < DH) {
+                    float* row = sdQ + (16 * qt + l15) * RS + 4 * C::CT * g;
+                    float t[4 * C::CT];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int ct = 0; ct < C::CT; ++ct) t[C::CT * r + ct] = dq[qt][ct][r];
+#pragma unroll
+                    for (int i = 0; i < C::CT; ++i) {
+                        f32x4 a = *(f32x4*)(row + 4 * i);
+                        a += f32x4{t[4 * i], t[4 * i + 1], t[4 * i + 2], t[4 * i + 3]};
+                        *(f32x4*)(row + 4 * i) = a;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float am = 0.f;
+    for (int i = threadIdx.x; i < p.Lq * (DH / 4); i += blockDim.x) {
+        const int q = i / (DH / 4), c = (i - q * (DH / 4)) * 4;
+        const size_t row = (size_t)b * p.Lq + q;
+        if (p.dQa) { const f32x4 v = *(const f32x4*)(sdQa + q * RS + c); *(f32x4*)(p.dQa + row * p.lddq + col0 + c) = v; am = absmax4(am, v); }
+        if (p.dQb) { const f32x4 v = *(const f32x4*)(sdQb + q * RS + c); *(f32x4*)(p.dQb + row * p.lddq + col0 + c) = v; am = absmax4(am, v); }
+    }
+    if (p.amax_q) amax_commit(p.amax_q, am, blockIdx.x * nw + wave);
+}
+
 }  // namespace segmm

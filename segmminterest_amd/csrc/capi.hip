@@ -103,6 +103,19 @@ static int attn_launch_bwd(AttnArgs& a, int phase, hipStream_t s) {
         LAUNCH_CHECK();
         return 0;
     }
+    if (phase == 4) {          // fused dQ + dK + dV: one workgroup per (b, h); needs Dvec (phase 1)
+        const int nta = ((a.La + 15) & ~15) >> 4, ntb = ((a.Lb + 15) & ~15) >> 4;
+        static const int tpw_env = getenv("SEGMM_ATT_FUSED_TPW") ? atoi(getenv("SEGMM_ATT_FUSED_TPW")) : 1;
+        const int tpw = tpw_env == 2 ? 2 : 1;
+        const int nw = (nta + tpw - 1) / tpw + (ntb + tpw - 1) / tpw;
+        const int Lq_p = (a.Lq + 15) & ~15;
+        SEGMM_REQUIRE(Lq_p <= 48 && nw <= ATT_FUSED_MAXW, "attn_bwd phase 4: built for Lq <= 48 and <= 12 key tiles (Lq %d, %d waves)", a.Lq, nw);
+        const size_t lds = ((size_t)5 * Lq_p * (DH + 4) + 3 * Lq_p + (size_t)nw * 16 * 20) * 4 + Lq_p + Tp;
+        if (tpw == 2) hipLaunchKernelGGL((attn_bwd_fused_kernel<DH, 8, 2>), dim3(a.B * a.H), dim3(64 * nw), lds, s, a);
+        else hipLaunchKernelGGL((attn_bwd_fused_kernel<DH, 12, 1>), dim3(a.B * a.H), dim3(64 * nw), lds, s, a);
+        LAUNCH_CHECK();
+        return 0;
+    }
     a.write_D = phase == 0;
     if (phase == 0 || phase == 2) {
         const int nqt = (a.Lq + 15) / 16;
@@ -480,7 +493,7 @@ int segmm_attn_bwd(int B, int H, int dh, int Lq, int La, int Lb, const float* Qa
                    const float* dO, int lddo, float* Dvec, float* dQa, float* dQb, int lddq, float* dKa, float* dVa, int lddka,
                    float* dKb, float* dVb, int lddkb, float drop_p, uint64_t seed, uint32_t site,
                    float* amax_q, float* amax_ka, float* amax_kb, int phase, segmm_stream_t stream) {
-    SEGMM_REQUIRE(phase >= 0 && phase <= 3, "attn_bwd: phase %d (0 all, 1 D, 2 dQ, 3 dK/dV)", phase);
+    SEGMM_REQUIRE(phase >= 0 && phase <= 4, "attn_bwd: phase %d (0 all, 1 D, 2 dQ, 3 dK/dV, 4 fused dQ+dK+dV)", phase);
     AttnArgs a;
     memset(&a, 0, sizeof(a));
     int rc = attn_fill(a, B, H, dh, Lq, La, Lb, Qa, Qb, ldq, Ka, Va, ldka, Kb, Vb, ldkb, mq, mka, mkb, drop_p, seed, site);

@@ -716,6 +716,10 @@ def test_attention_bwd_phases_equal_whole():
                        phase=ph)
         return Dv, outs
     D0, ref = run([0])
+    _, fused = run([1, 4])                        # D kernel, then dQ + dK + dV in one kernel (LDS-staged query side)
+    for name, a, b in zip(("dQa", "dQb", "dKa", "dVa", "dKb", "dVb"), ref, fused):
+        err = (a - b).abs().max().item()
+        assert err < 2e-5 * max(1.0, a.abs().max().item()), (name, err)
     D1, got = run([1, 2, 3])
     assert (D0 - D1).abs().max().item() < 1e-5 * max(1.0, D0.abs().max().item())      # different summation order of the 48 products
     for a, b in zip(ref[:2], got[:2]):

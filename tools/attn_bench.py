@@ -21,11 +21,18 @@ dO = torch.randn(B * Lq, d, device=dev); Dv = torch.empty(B, Hh, Lq, device=dev)
 dYv = torch.empty_like(Yv); dYu = torch.empty_like(Yu); dQs = dYv if Lq == La else torch.empty_like(Qsrc)
 fwd = lambda: H.attn_fwd(B, Hh, dh, Lq, La, Lb, (Qsrc, 0), (Qsrc, d), 4 * d, (Yv, 2 * d), (Yv, 3 * d), 4 * d, (Yu, 0), (Yu, d), 2 * d,
                          qm, vm, um, O, d, lse, drop_p=p_drop, seed=1, site=3)
-bwd = lambda: H.attn_bwd(B, Hh, dh, Lq, La, Lb, (Qsrc, 0), (Qsrc, d), 4 * d, (Yv, 2 * d), (Yv, 3 * d), 4 * d, (Yu, 0), (Yu, d), 2 * d,
-                         qm, vm, um, lse, O, d, dO, d, Dv, (dQs, 0), (dQs, d), 4 * d, (dYv, 2 * d), (dYv, 3 * d), 4 * d, (dYu, 0), (dYu, d), 2 * d,
-                         drop_p=p_drop, seed=1, site=3)
+bwd_ph = lambda ph: H.attn_bwd(B, Hh, dh, Lq, La, Lb, (Qsrc, 0), (Qsrc, d), 4 * d, (Yv, 2 * d), (Yv, 3 * d), 4 * d, (Yu, 0), (Yu, d), 2 * d,
+                               qm, vm, um, lse, O, d, dO, d, Dv, (dQs, 0), (dQs, d), 4 * d, (dYv, 2 * d), (dYv, 3 * d), 4 * d, (dYu, 0), (dYu, d), 2 * d,
+                               drop_p=p_drop, seed=1, site=3, phase=ph)
+bwd = lambda: bwd_ph(0)
+def bwd_fused():
+    bwd_ph(1)
+    bwd_ph(4)
 T = La + Lb
-for name, fn, flops in (("fwd", fwd, 4.0 * dh * Lq * T), ("bwd(dq+dkv)", bwd, 14.0 * dh * Lq * T)):
+cases = [("fwd", fwd, 4.0 * dh * Lq * T), ("bwd(dq+dkv)", bwd, 14.0 * dh * Lq * T), ("bwd D only", lambda: bwd_ph(1), 0.0)]
+if Lq <= 48:
+    cases.append(("bwd(D+fused)", bwd_fused, 14.0 * dh * Lq * T))
+for name, fn, flops in cases:
     for _ in range(2):
         fn()
     torch.cuda.synchronize()
