@@ -636,6 +636,11 @@ __global__ __launch_bounds__(ATT_BWD_THREADS) void attn_bwd_dkv_kernel(const Att
 // Needs Dvec = rowsum(dO * O) from attn_D_kernel (phase 1).  LDS: 5 x [Lq_p][DH + 4] floats + statistics + scratch
 // (51 KB at Lq = 40, DH = 48: two workgroups per CU).
 constexpr int ATT_FUSED_MAXW = 12;
+// value of lane R of each aligned 4-lane group, in all four lanes of the group (DPP quad_perm broadcast)
+template <int R>
+__device__ __forceinline__ uint32_t quad_bcast(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, R * 0x55, 0xf, 0xf, true);
+}
 // NW = waves per workgroup the launch bound is made for (blockDim.x <= 64 NW); 3 waves per SIMD: up to 6 waves two workgroups share a CU
 // (<= 168 registers), so that one head's staging / dQ reduction phases run under the other's MFMA phase.
 // TPW = key tiles per wave (1: one wave per key tile, best balance of the MFMA work over the 4 SIMDs; 2: half the waves).
@@ -748,13 +753,27 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void attn_bwd_fused_kernel(c
                 const f32x4 Dq = *(const f32x4*)(s_D + 16 * qt + 4 * g);
                 const uint32_t qfl = *(const uint32_t*)(qm + 16 * qt + 4 * g);
                 f32x4 Pv, dSv;
+                // dropout multipliers of this lane's 4 (query, key) elements.  The random bits come in quads of 4 consecutive
+                // keys of one query (drop_rand_quad): the 4 lanes of an aligned group hold the 4 keys of such quads, so each
+                // lane hashes ONE query's quad (query 4g + (lane & 3)) and the group exchanges the words by DPP broadcasts --
+                // one hash per lane instead of four, bit-identical to drop_mult1.
+                uint32_t dw[4] = {0u, 0u, 0u, 0u};
+                if (p.drop.p > 0.f) {
+                    const int rr = l15 & 3;
+                    const uint2 hw = drop_rand_quad(p.drop, (((uint64_t)bh * p.Lq + (16 * qt + 4 * g + rr)) * Tp + jp) >> 2);
+                    const uint32_t a0 = quad_bcast<0>(hw.x), a1 = quad_bcast<1>(hw.x), a2 = quad_bcast<2>(hw.x), a3 = quad_bcast<3>(hw.x);
+                    const uint32_t b0 = quad_bcast<0>(hw.y), b1 = quad_bcast<1>(hw.y), b2 = quad_bcast<2>(hw.y), b3 = quad_bcast<3>(hw.y);
+                    const bool lo_word = rr < 2, hi_half = rr & 1;
+                    const uint32_t w0 = lo_word ? a0 : b0, w1 = lo_word ? a1 : b1, w2 = lo_word ? a2 : b2, w3 = lo_word ? a3 : b3;
+                    dw[0] = hi_half ? (w0 >> 16) : (w0 & 0xffffu); dw[1] = hi_half ? (w1 >> 16) : (w1 & 0xffffu);
+                    dw[2] = hi_half ? (w2 >> 16) : (w2 & 0xffffu); dw[3] = hi_half ? (w3 >> 16) : (w3 & 0xffffu);
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int qi = 16 * qt + 4 * g + r;
                     const uint32_t qf_ = (qfl >> (8 * r)) & 0xff;
                     const bool valid = (qf_ == 1) && (kflag == 1);
                     float mult = 1.f;
-                    if (p.drop.p > 0.f && qf_ != 2) mult = drop_mult1(p.drop, ((uint64_t)bh * p.Lq + qi) * Tp + jp);
+                    if (p.drop.p > 0.f && qf_ != 2) mult = (dw[r] >= p.drop.thresh) ? p.drop.scale : 0.f;
                     const float v = logit_xform(sv[r], valid, mult, fscale);
                     const float pr = (kflag == 2 || qf_ == 2) ? 0.f : fast_exp(v - mxq[r]) * invq[r];
                     Pv[r] = pr;
