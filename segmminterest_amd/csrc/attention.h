@@ -622,19 +622,29 @@ __global__ __launch_bounds__(ATT_BWD_THREADS) void attn_bwd_dkv_kernel(const Att
 }
 
 // ------------------------------------------------------------------------------------------ backward: fused dQ + dK + dV
-// ONE workgroup per (b, h); the query-side tensors every key tile needs (Qa, Qb, dO: Lq x DH each) are staged ONCE in LDS
+// ONE workgroup per (b, h, key block) -- dQa depends on the block-a keys only and dQb on the block-b keys only, so the two
+// blocks of a head are independent workgroups and several of them share a CU (one's staging loads run under another's MFMAs:
+// with one workgroup per head and CU the prologue, bound by the CU's ~10 B/clk share of HBM, was 28 % of the time).
+// The query-side tensors every key tile needs (Q of this block, dO: Lq x DH each) are staged ONCE in LDS
 // in whole rows and read from there in both fragment forms, instead of being fetched from global memory in fragment shape
 // (16 rows x 64 B per instruction) by every key-tile wave in row AND column form -- 20 fetches of Q and dO per head in the
 // two-kernel version, which is bound by the vector-memory pipeline, not by HBM or the matrix cores.  S and dP are computed
 // once per (query tile, key tile) pair instead of once in each of two kernels.
-//   wave w owns up to two key tiles of ONE key block (block-a waves first): K / V row fragments and K column fragments of a
-//   tile come straight from global memory (each is needed by this wave only);
+//   wave w owns key tile w of the block: its K / V row fragments and K column fragments come straight from global memory
+//   (each is needed by this wave only); waves beyond the block's tile count only help staging;
 //   per query tile: S = Q K^T, dP = dO V^T (operands from LDS) -> P, dS;  dV += P^T dO, dK += dS^T Q;
-//   dS is transposed through a 16 x 16 per-wave LDS scratch and dQ^T += K^T dS^T accumulates in registers over the wave's
-//   tiles; the waves then add their dQ partials into an LDS accumulator ONE WAVE AT A TIME in wave order (plain
-//   read-modify-write, no atomics: bitwise reproducible) and the workgroup stores dQa / dQb in whole rows.
-// Needs Dvec = rowsum(dO * O) from attn_D_kernel (phase 1).  LDS: 5 x [Lq_p][DH + 4] floats + statistics + scratch
-// (51 KB at Lq = 40, DH = 48: two workgroups per CU).
+//   dS is transposed through a 16 x 16 per-wave LDS scratch, dQ^T = K^T dS^T of the (query tile, key tile) pair is formed in
+//   registers and added into an LDS accumulator IN WAVE ORDER: a per-query-tile turn counter in LDS lets wave w add only
+//   after wave w-1 has (plain read-modify-write, no float atomics: bitwise reproducible; the waves run the same work in
+//   step, so the wait is short and no workgroup barrier is needed); the workgroup then stores dQ in whole rows.
+// Needs Dvec = rowsum(dO * O) from attn_D_kernel (phase 1).  LDS: 3 x [Lq_p][DH + 4] floats + statistics + scratch
+// (39 KB at Lq = 40, DH = 48, 7 waves).
+#ifdef SEGMM_ATT_TRACE
+__device__ unsigned long long g_att_trace[16 * 8];      // debug build (tools/attn_trace.py): phase stamps of every wave of one workgroup
+#define ATT_MARK(ph) do { if (att_trace_on && lane == 0) g_att_trace[wave * 8 + (ph)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define ATT_MARK(ph) do { } while (0)
+#endif
 constexpr int ATT_FUSED_MAXW = 12;
 // value of lane R of each aligned 4-lane group, in all four lanes of the group (DPP quad_perm broadcast)
 template <int R>
@@ -643,9 +653,8 @@ __device__ __forceinline__ uint32_t quad_bcast(uint32_t v) {
 }
 // NW = waves per workgroup the launch bound is made for (blockDim.x <= 64 NW); 3 waves per SIMD: up to 6 waves two workgroups share a CU
 // (<= 168 registers), so that one head's staging / dQ reduction phases run under the other's MFMA phase.
-// TPW = key tiles per wave (1: one wave per key tile, best balance of the MFMA work over the 4 SIMDs; 2: half the waves).
-template <int DH, int NW, int TPW>
-__global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void attn_bwd_fused_kernel(const AttnArgs p) {
+template <int DH, int NW>
+__global__ __launch_bounds__(64 * NW, 4) void attn_bwd_fused_kernel(const AttnArgs p) {
     using C = AttnCfg<DH>;
     constexpr int RS = DH + 4;                 // LDS row stride (floats): 16-byte aligned rows, conflict-free fragment reads
     constexpr int TS = 20;                     // row stride of the 16 x 16 transpose scratch
@@ -653,26 +662,30 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void attn_bwd_fused_kernel(c
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     const int bh = xcd_remap(blockIdx.x, gridDim.x), b = bh / p.H, h = bh % p.H;
+    const bool isa = p.hpb == 0;                           // this launch's key block (one launch per block: exact wave counts)
     const int La_p = round16(p.La), Lb_p = round16(p.Lb), Tp = La_p + Lb_p, nta = La_p >> 4, ntb = Lb_p >> 4;
+    const int ntk = isa ? nta : ntb;                       // key tiles (= working waves) of the block
+    if (ntk == 0) return;                                  // empty block (CrossAtt / SelfAtt ablations)
     const int Lq_p = round16(p.Lq), nqt = Lq_p >> 4;
     const int col0 = h * DH;
-    float* sQa = smem_f;
-    float* sQb = sQa + Lq_p * RS;
-    float* sdO = sQb + Lq_p * RS;
-    float* sdQa = sdO + Lq_p * RS;
-    float* sdQb = sdQa + Lq_p * RS;
-    float* s_mx = sdQb + Lq_p * RS;
+#ifdef SEGMM_ATT_TRACE
+    const bool att_trace_on = blockIdx.x == gridDim.x / 2 + 5;
+#endif
+    ATT_MARK(0);
+    float* sQ = smem_f;
+    float* sdO = sQ + Lq_p * RS;
+    float* sdQ = sdO + Lq_p * RS;
+    float* s_mx = sdQ + Lq_p * RS;
     float* s_inv = s_mx + Lq_p;
     float* s_D = s_inv + Lq_p;
     float* s_tr = s_D + Lq_p + wave * (16 * TS);                            // this wave's transpose scratch
-    uint8_t* qm = (uint8_t*)(s_D + Lq_p + nw * (16 * TS));                  // [Lq_p] 1 valid query, 0 masked, 2 pad
+    int* s_turn = (int*)(s_D + Lq_p + nw * (16 * TS));                      // [4] whose turn it is to add dQ of query tile qt
+    uint8_t* qm = (uint8_t*)(s_turn + 4);                                   // [Lq_p] 1 valid query, 0 masked, 2 pad
     uint8_t* km = qm + Lq_p;                                                // [Tp]
-    // ---- this wave's key tiles: all in one block.  The K / V fragments of the first one are requested BEFORE the staging
-    // below (they do not depend on it): their latency hides under the staging loads and the barrier.
-    const int wa = (nta + TPW - 1) / TPW;                  // waves of block a
-    const bool isa = wave < wa;
-    const int wt0 = isa ? TPW * wave : nta + TPW * (wave - wa);             // first padded key tile
-    const int wt1 = min(wt0 + TPW, isa ? nta : nta + ntb);                  // one past the last
+    // ---- this wave's key tile.  Its K / V fragments are requested BEFORE the staging below (they do not depend on it):
+    // their latency hides under the staging loads and the barrier.
+    const int wt0 = (isa ? 0 : nta) + wave;                                 // padded key tile of this wave ...
+    const int wt1 = wave < ntk ? wt0 + 1 : wt0;                             // ... if it has one
     KeyBlocks<DH> kbk;
     kbk.init(p, b, col0, l15, g);
     float kf[C::KS], vf[C::KS], kc[4][C::CT];
@@ -692,21 +705,19 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void attn_bwd_fused_kernel(c
         }
     };
     if (wt0 < wt1) load_tile(wt0);
-    // ---- stage the query side: whole rows, float4, rows >= Lq zero; zero the dQ accumulators
+    // ---- stage the query side: whole rows, float4, rows >= Lq zero; zero the dQ accumulator
+    const float* Qg = isa ? p.Qa : p.Qb;
     for (int i = threadIdx.x; i < Lq_p * (DH / 4); i += blockDim.x) {
         const int q = i / (DH / 4), c = (i - q * (DH / 4)) * 4;
-        f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = va, vo = va;
+        f32x4 va = {0.f, 0.f, 0.f, 0.f}, vo = va;
         if (q < p.Lq) {
             const size_t row = (size_t)b * p.Lq + q;
-            va = *(const f32x4*)(p.Qa + row * p.ldq + col0 + c);
-            vb = *(const f32x4*)(p.Qb + row * p.ldq + col0 + c);
+            va = *(const f32x4*)(Qg + row * p.ldq + col0 + c);
             vo = *(const f32x4*)(p.dO + row * p.lddo + col0 + c);
         }
-        *(f32x4*)(sQa + q * RS + c) = va;
-        *(f32x4*)(sQb + q * RS + c) = vb;
+        *(f32x4*)(sQ + q * RS + c) = va;
         *(f32x4*)(sdO + q * RS + c) = vo;
-        *(f32x4*)(sdQa + q * RS + c) = f32x4{0.f, 0.f, 0.f, 0.f};
-        *(f32x4*)(sdQb + q * RS + c) = f32x4{0.f, 0.f, 0.f, 0.f};
+        *(f32x4*)(sdQ + q * RS + c) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     for (int q = threadIdx.x; q < Lq_p; q += blockDim.x) {
         const bool in = q < p.Lq;
@@ -715,22 +726,18 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void attn_bwd_fused_kernel(c
         s_D[q] = in ? p.Dvec[(size_t)bh * p.Lq + q] : 0.f;
         qm[q] = in ? (p.mq[(size_t)b * p.Lq + q] ? 1 : 0) : 2;
     }
+    if (threadIdx.x < 4) s_turn[threadIdx.x] = 0;
     stage_kmask(km, p.mka, p.mkb, b, p.La, p.Lb, La_p, Lb_p);
+    ATT_MARK(1);
     __syncthreads();
+    ATT_MARK(2);
 
-    const float* sQ = isa ? sQa : sQb;
     const float fscale = p.scale;
-    f32x4 dq[3][C::CT];                                    // dQ^T partial of this wave: up to 3 query tiles (Lq <= 48) ...
-    constexpr int MAXQT = 3;
-#pragma unroll
-    for (int qt = 0; qt < MAXQT; ++qt)
-#pragma unroll
-        for (int ct = 0; ct < C::CT; ++ct) dq[qt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int MAXQT = 3;                               // Lq <= 48
 
     for (int jt = wt0; jt < wt1; ++jt) {
         const int jp = 16 * jt + l15;                      // this lane's key (padded index)
         const uint8_t kflag = km[jp];
-        if (TPW > 1 && jt > wt0) load_tile(jt);
         f32x4 dk[C::CT], dv[C::CT];
 #pragma unroll
         for (int ct = 0; ct < C::CT; ++ct) { dk[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -800,10 +807,34 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void attn_bwd_fused_kernel(c
                 __builtin_amdgcn_wave_barrier();
                 const f32x4 dST = *(const f32x4*)(s_tr + l15 * TS + 4 * g);
                 __builtin_amdgcn_wave_barrier();
+                f32x4 dqt[C::CT];
+#pragma unroll
+                for (int ct = 0; ct < C::CT; ++ct) dqt[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-                    for (int ct = 0; ct < C::CT; ++ct) dq[qt][ct] = MFMA16(kc[s4][ct], dST[s4], dq[qt][ct]);
+                    for (int ct = 0; ct < C::CT; ++ct) dqt[ct] = MFMA16(kc[s4][ct], dST[s4], dqt[ct]);
+                // ordered accumulation: lane (query l15, g) holds head columns CT*(4g + r) + ct (col_load mapping of kc),
+                // i.e. the 4*CT contiguous columns from 4*CT*g of row 16 qt + l15
+                if (wave > 0)
+                    while (__hip_atomic_load(s_turn + qt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != wave) __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                if (4 * C::CT * g < DH) {
+                    float* row = sdQ + (16 * qt + l15) * RS + 4 * C::CT * g;
+                    float t[4 * C::CT];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int ct = 0; ct < C::CT; ++ct) t[C::CT * r + ct] = dqt[ct][r];
+#pragma unroll
+                    for (int i = 0; i < C::CT; ++i) {
+                        f32x4 a = *(f32x4*)(row + 4 * i);
+                        a += f32x4{t[4 * i], t[4 * i + 1], t[4 * i + 2], t[4 * i + 3]};
+                        *(f32x4*)(row + 4 * i) = a;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) __hip_atomic_store(s_turn + qt, wave + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
         // dK / dV rows of this tile: lane (key l15, g), tile ct register r = head column 16 ct + 4 g + r
@@ -827,42 +858,19 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void attn_bwd_fused_kernel(c
         if (slot) amax_commit(slot, am, blockIdx.x * nw + wave);
     }
 
-    // ---- dQ: the waves add their partials into LDS one at a time, in wave order (deterministic)
-    // lane (query l15, g) holds, per query tile and column tile ct, head columns CT*(4g + r) + ct (col_load mapping of kc)
-    // (block-a waves add into sdQa, block-b waves into sdQb: the two chains advance together, max(wa, wb) turns)
-    float* sdQ = isa ? sdQa : sdQb;
-    const int my_turn = isa ? wave : wave - wa;
-    const int nturn = max(wa, nw - wa);
-    for (int turn = 0; turn < nturn; ++turn) {
-        if (my_turn == turn && wt0 < wt1) {
-#pragma unroll
-            for (int qt = 0; qt < MAXQT; ++qt) {
-                if (qt < nqt && 4 * C::CT * g < DH) {
-                    float* row = sdQ + (16 * qt + l15) * RS + 4 * C::CT * g;
-                    float t[4 * C::CT];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-#pragma unroll
-                        for (int ct = 0; ct < C::CT; ++ct) t[C::CT * r + ct] = dq[qt][ct][r];
-#pragma unroll
-                    for (int i = 0; i < C::CT; ++i) {
-                        f32x4 a = *(f32x4*)(row + 4 * i);
-                        a += f32x4{t[4 * i], t[4 * i + 1], t[4 * i + 2], t[4 * i + 3]};
-                        *(f32x4*)(row + 4 * i) = a;
-                    }
-                }
-            }
-        }
-        __syncthreads();
-    }
+    ATT_MARK(3);
+    __syncthreads();                                       // every wave has added its dQ partials
+    ATT_MARK(4);
     float am = 0.f;
     for (int i = threadIdx.x; i < p.Lq * (DH / 4); i += blockDim.x) {
         const int q = i / (DH / 4), c = (i - q * (DH / 4)) * 4;
         const size_t row = (size_t)b * p.Lq + q;
-        if (p.dQa) { const f32x4 v = *(const f32x4*)(sdQa + q * RS + c); *(f32x4*)(p.dQa + row * p.lddq + col0 + c) = v; am = absmax4(am, v); }
-        if (p.dQb) { const f32x4 v = *(const f32x4*)(sdQb + q * RS + c); *(f32x4*)(p.dQb + row * p.lddq + col0 + c) = v; am = absmax4(am, v); }
+        const f32x4 v = *(const f32x4*)(sdQ + q * RS + c);
+        *(f32x4*)((isa ? p.dQa : p.dQb) + row * p.lddq + col0 + c) = v;
+        am = absmax4(am, v);
     }
     if (p.amax_q) amax_commit(p.amax_q, am, blockIdx.x * nw + wave);
+    ATT_MARK(5);
 }
 
 }  // namespace segmm

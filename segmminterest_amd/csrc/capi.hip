@@ -103,16 +103,20 @@ static int attn_launch_bwd(AttnArgs& a, int phase, hipStream_t s) {
         LAUNCH_CHECK();
         return 0;
     }
-    if (phase == 4) {          // fused dQ + dK + dV: one workgroup per (b, h); needs Dvec (phase 1)
+    if (phase == 4) {          // fused dQ + dK + dV: one workgroup per (b, h, key block); needs Dvec (phase 1)
         const int nta = ((a.La + 15) & ~15) >> 4, ntb = ((a.Lb + 15) & ~15) >> 4;
-        static const int tpw_env = getenv("SEGMM_ATT_FUSED_TPW") ? atoi(getenv("SEGMM_ATT_FUSED_TPW")) : 1;
-        const int tpw = tpw_env == 2 ? 2 : 1;
-        const int nw = (nta + tpw - 1) / tpw + (ntb + tpw - 1) / tpw;
         const int Lq_p = (a.Lq + 15) & ~15;
-        SEGMM_REQUIRE(Lq_p <= 48 && nw <= ATT_FUSED_MAXW, "attn_bwd phase 4: built for Lq <= 48 and <= 12 key tiles (Lq %d, %d waves)", a.Lq, nw);
-        const size_t lds = ((size_t)5 * Lq_p * (DH + 4) + 3 * Lq_p + (size_t)nw * 16 * 20) * 4 + Lq_p + Tp;
-        if (tpw == 2) hipLaunchKernelGGL((attn_bwd_fused_kernel<DH, 8, 2>), dim3(a.B * a.H), dim3(64 * nw), lds, s, a);
-        else hipLaunchKernelGGL((attn_bwd_fused_kernel<DH, 12, 1>), dim3(a.B * a.H), dim3(64 * nw), lds, s, a);
+        SEGMM_REQUIRE(Lq_p <= 48 && nta <= ATT_FUSED_MAXW && ntb <= ATT_FUSED_MAXW, "attn_bwd phase 4: built for Lq <= 48 and <= 12 key tiles per block (Lq %d, %d + %d tiles)", a.Lq, nta, ntb);
+        for (int blk = 0; blk < 2; ++blk) {                // one launch per key block: one wave per key tile, no idle waves
+            const int nw = blk == 0 ? nta : ntb;
+            if (nw == 0) continue;
+            a.hpb = blk;
+            const size_t lds = ((size_t)3 * Lq_p * (DH + 4) + 3 * Lq_p + (size_t)nw * 16 * 20 + 4) * 4 + Lq_p + Tp;
+            const dim3 grid(a.B * a.H), block(64 * nw);
+            if (nw <= 4) hipLaunchKernelGGL((attn_bwd_fused_kernel<DH, 4>), grid, block, lds, s, a);
+            else if (nw <= 8) hipLaunchKernelGGL((attn_bwd_fused_kernel<DH, 8>), grid, block, lds, s, a);
+            else hipLaunchKernelGGL((attn_bwd_fused_kernel<DH, 12>), grid, block, lds, s, a);
+        }
         LAUNCH_CHECK();
         return 0;
     }
@@ -726,6 +730,13 @@ int segmm_pool_tokens_bwd(const float* dOut, float* dU, int Lu, float* dV, int L
 #ifdef SEGMM_GEMM_TRACE
 int segmm_debug_gemm_trace(unsigned long long* host, int n) {      // debug build only (-DSEGMM_GEMM_TRACE): phase timestamps
     SEGMM_CHECK_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(segmm::g_gemm_trace), sizeof(unsigned long long) * (size_t)n));
+    return 0;
+}
+#endif
+
+#ifdef SEGMM_ATT_TRACE
+int segmm_debug_attn_trace(unsigned long long* host, int n) {      // debug build only (-DSEGMM_ATT_TRACE)
+    SEGMM_CHECK_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(segmm::g_att_trace), sizeof(unsigned long long) * (size_t)n));
     return 0;
 }
 #endif
