@@ -661,11 +661,15 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_bwd_fused_kernel(const AttnAr
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int l15 = lane & 15, g = lane >> 4;
-    const int bh = xcd_remap(blockIdx.x, gridDim.x), b = bh / p.H, h = bh % p.H;
-    const bool isa = p.hpb == 0;                           // this launch's key block (one launch per block: exact wave counts)
+    // p.hpb: 0 / 1 = this launch handles key block a / b only (exact wave count per launch); 2 = both blocks in one launch,
+    // workgroup 2 bh + blk, sized for the larger block -- the surplus waves of the smaller block's workgroups END here, before
+    // any barrier (s_barrier waits for surviving waves only), so small and large workgroups mix on a CU
+    const int wg = xcd_remap(blockIdx.x, gridDim.x), bh = p.hpb == 2 ? wg >> 1 : wg, b = bh / p.H, h = bh % p.H;
+    const bool isa = p.hpb == 2 ? (wg & 1) == 0 : p.hpb == 0;
     const int La_p = round16(p.La), Lb_p = round16(p.Lb), Tp = La_p + Lb_p, nta = La_p >> 4, ntb = Lb_p >> 4;
     const int ntk = isa ? nta : ntb;                       // key tiles (= working waves) of the block
-    if (ntk == 0) return;                                  // empty block (CrossAtt / SelfAtt ablations)
+    if (wave >= ntk) return;                               // surplus wave, or empty block (CrossAtt / SelfAtt ablations)
+    const int nthr = 64 * ntk;                             // surviving threads
     const int Lq_p = round16(p.Lq), nqt = Lq_p >> 4;
     const int col0 = h * DH;
 #ifdef SEGMM_ATT_TRACE
@@ -684,8 +688,8 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_bwd_fused_kernel(const AttnAr
     uint8_t* km = qm + Lq_p;                                                // [Tp]
     // ---- this wave's key tile.  Its K / V fragments are requested BEFORE the staging below (they do not depend on it):
     // their latency hides under the staging loads and the barrier.
-    const int wt0 = (isa ? 0 : nta) + wave;                                 // padded key tile of this wave ...
-    const int wt1 = wave < ntk ? wt0 + 1 : wt0;                             // ... if it has one
+    const int wt0 = (isa ? 0 : nta) + wave;                                 // padded key tile of this wave
+    const int wt1 = wt0 + 1;
     KeyBlocks<DH> kbk;
     kbk.init(p, b, col0, l15, g);
     float kf[C::KS], vf[C::KS], kc[4][C::CT];
@@ -707,7 +711,7 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_bwd_fused_kernel(const AttnAr
     if (wt0 < wt1) load_tile(wt0);
     // ---- stage the query side: whole rows, float4, rows >= Lq zero; zero the dQ accumulator
     const float* Qg = isa ? p.Qa : p.Qb;
-    for (int i = threadIdx.x; i < Lq_p * (DH / 4); i += blockDim.x) {
+    for (int i = threadIdx.x; i < Lq_p * (DH / 4); i += nthr) {
         const int q = i / (DH / 4), c = (i - q * (DH / 4)) * 4;
         f32x4 va = {0.f, 0.f, 0.f, 0.f}, vo = va;
         if (q < p.Lq) {
@@ -719,7 +723,7 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_bwd_fused_kernel(const AttnAr
         *(f32x4*)(sdO + q * RS + c) = vo;
         *(f32x4*)(sdQ + q * RS + c) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    for (int q = threadIdx.x; q < Lq_p; q += blockDim.x) {
+    for (int q = threadIdx.x; q < Lq_p; q += nthr) {
         const bool in = q < p.Lq;
         s_mx[q] = in ? p.lse[(size_t)bh * p.Lq + q] : 0.f;
         s_inv[q] = in ? p.lse[(size_t)p.B * p.H * p.Lq + (size_t)bh * p.Lq + q] : 0.f;
@@ -727,7 +731,12 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_bwd_fused_kernel(const AttnAr
         qm[q] = in ? (p.mq[(size_t)b * p.Lq + q] ? 1 : 0) : 2;
     }
     if (threadIdx.x < 4) s_turn[threadIdx.x] = 0;
-    stage_kmask(km, p.mka, p.mkb, b, p.La, p.Lb, La_p, Lb_p);
+    for (int j = threadIdx.x; j < Tp; j += nthr) {         // stage_kmask with the surviving thread count
+        uint8_t v;
+        if (j < La_p) v = (j < p.La) ? (p.mka[(size_t)b * p.La + j] ? 1 : 0) : 2;
+        else { const int jb = j - La_p; v = (jb < p.Lb) ? (p.mkb[(size_t)b * p.Lb + jb] ? 1 : 0) : 2; }
+        km[j] = v;
+    }
     ATT_MARK(1);
     __syncthreads();
     ATT_MARK(2);
@@ -862,7 +871,7 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_bwd_fused_kernel(const AttnAr
     __syncthreads();                                       // every wave has added its dQ partials
     ATT_MARK(4);
     float am = 0.f;
-    for (int i = threadIdx.x; i < p.Lq * (DH / 4); i += blockDim.x) {
+    for (int i = threadIdx.x; i < p.Lq * (DH / 4); i += nthr) {
         const int q = i / (DH / 4), c = (i - q * (DH / 4)) * 4;
         const size_t row = (size_t)b * p.Lq + q;
         const f32x4 v = *(const f32x4*)(sdQ + q * RS + c);

@@ -107,12 +107,17 @@ static int attn_launch_bwd(AttnArgs& a, int phase, hipStream_t s) {
         const int nta = ((a.La + 15) & ~15) >> 4, ntb = ((a.Lb + 15) & ~15) >> 4;
         const int Lq_p = (a.Lq + 15) & ~15;
         SEGMM_REQUIRE(Lq_p <= 48 && nta <= ATT_FUSED_MAXW && ntb <= ATT_FUSED_MAXW, "attn_bwd phase 4: built for Lq <= 48 and <= 12 key tiles per block (Lq %d, %d + %d tiles)", a.Lq, nta, ntb);
-        for (int blk = 0; blk < 2; ++blk) {                // one launch per key block: one wave per key tile, no idle waves
-            const int nw = blk == 0 ? nta : ntb;
+        static const int fmode = getenv("SEGMM_ATT_FUSED_LAUNCH") ? atoi(getenv("SEGMM_ATT_FUSED_LAUNCH")) : 2;
+        const int nmax = nta > ntb ? nta : ntb;
+        for (int blk = 0; blk < 2; ++blk) {
+            // fmode 2 (default): one launch per key block with its exact wave count -- 539-549 us at config 2;
+            // fmode 1: ONE launch for both key blocks (workgroups of 64 * max(nta, ntb) threads, surplus waves end at once) -- 680 us
+            if (fmode == 1 && blk == 1) break;
+            const int nw = fmode == 1 ? nmax : (blk == 0 ? nta : ntb);
             if (nw == 0) continue;
-            a.hpb = blk;
+            a.hpb = fmode == 1 ? 2 : blk;
             const size_t lds = ((size_t)3 * Lq_p * (DH + 4) + 3 * Lq_p + (size_t)nw * 16 * 20 + 4) * 4 + Lq_p + Tp;
-            const dim3 grid(a.B * a.H), block(64 * nw);
+            const dim3 grid((fmode == 1 ? 2 : 1) * a.B * a.H), block(64 * nw);
             if (nw <= 4) hipLaunchKernelGGL((attn_bwd_fused_kernel<DH, 4>), grid, block, lds, s, a);
             else if (nw <= 8) hipLaunchKernelGGL((attn_bwd_fused_kernel<DH, 8>), grid, block, lds, s, a);
             else hipLaunchKernelGGL((attn_bwd_fused_kernel<DH, 12>), grid, block, lds, s, a);
