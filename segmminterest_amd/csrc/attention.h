@@ -637,8 +637,9 @@ __global__ __launch_bounds__(ATT_BWD_THREADS) void attn_bwd_dkv_kernel(const Att
 //   registers and added into an LDS accumulator IN WAVE ORDER: a per-query-tile turn counter in LDS lets wave w add only
 //   after wave w-1 has (plain read-modify-write, no float atomics: bitwise reproducible; the waves run the same work in
 //   step, so the wait is short and no workgroup barrier is needed); the workgroup then stores dQ in whole rows.
-// Needs Dvec = rowsum(dO * O) from attn_D_kernel (phase 1).  LDS: 3 x [Lq_p][DH + 4] floats + statistics + scratch
-// (39 KB at Lq = 40, DH = 48, 7 waves).
+// D = rowsum(dO * O) is formed during the staging (each staged dO chunk is multiplied with its O chunk, the DH/4 partial
+// products of a row are summed in a fixed order after the barrier): no separate D launch in front of the backward.
+// LDS: 3 x [Lq_p][DH + 4] floats + [Lq_p][DH/4] partials + statistics + scratch (41 KB at Lq = 40, DH = 48, 7 waves).
 #ifdef SEGMM_ATT_TRACE
 __device__ unsigned long long g_att_trace[16 * 8];      // debug build (tools/attn_trace.py): phase stamps of every wave of one workgroup
 #define ATT_MARK(ph) do { if (att_trace_on && lane == 0) g_att_trace[wave * 8 + (ph)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -684,7 +685,8 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_bwd_fused_kernel(const AttnAr
     float* s_D = s_inv + Lq_p;
     float* s_tr = s_D + Lq_p + wave * (16 * TS);                            // this wave's transpose scratch
     int* s_turn = (int*)(s_D + Lq_p + nw * (16 * TS));                      // [4] whose turn it is to add dQ of query tile qt
-    uint8_t* qm = (uint8_t*)(s_turn + 4);                                   // [Lq_p] 1 valid query, 0 masked, 2 pad
+    float* s_Dp = (float*)(s_turn + 4);                                     // [Lq_p][DH/4] partial products dO . O
+    uint8_t* qm = (uint8_t*)(s_Dp + Lq_p * (DH / 4));                       // [Lq_p] 1 valid query, 0 masked, 2 pad
     uint8_t* km = qm + Lq_p;                                                // [Tp]
     // ---- this wave's key tile.  Its K / V fragments are requested BEFORE the staging below (they do not depend on it):
     // their latency hides under the staging loads and the barrier.
@@ -713,21 +715,22 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_bwd_fused_kernel(const AttnAr
     const float* Qg = isa ? p.Qa : p.Qb;
     for (int i = threadIdx.x; i < Lq_p * (DH / 4); i += nthr) {
         const int q = i / (DH / 4), c = (i - q * (DH / 4)) * 4;
-        f32x4 va = {0.f, 0.f, 0.f, 0.f}, vo = va;
+        f32x4 va = {0.f, 0.f, 0.f, 0.f}, vo = va, oo = va;
         if (q < p.Lq) {
             const size_t row = (size_t)b * p.Lq + q;
             va = *(const f32x4*)(Qg + row * p.ldq + col0 + c);
             vo = *(const f32x4*)(p.dO + row * p.lddo + col0 + c);
+            oo = *(const f32x4*)(p.O + row * p.ldo + col0 + c);
         }
         *(f32x4*)(sQ + q * RS + c) = va;
         *(f32x4*)(sdO + q * RS + c) = vo;
         *(f32x4*)(sdQ + q * RS + c) = f32x4{0.f, 0.f, 0.f, 0.f};
+        s_Dp[i] = (vo.x * oo.x + vo.y * oo.y) + (vo.z * oo.z + vo.w * oo.w);
     }
     for (int q = threadIdx.x; q < Lq_p; q += nthr) {
         const bool in = q < p.Lq;
         s_mx[q] = in ? p.lse[(size_t)bh * p.Lq + q] : 0.f;
         s_inv[q] = in ? p.lse[(size_t)p.B * p.H * p.Lq + (size_t)bh * p.Lq + q] : 0.f;
-        s_D[q] = in ? p.Dvec[(size_t)bh * p.Lq + q] : 0.f;
         qm[q] = in ? (p.mq[(size_t)b * p.Lq + q] ? 1 : 0) : 2;
     }
     if (threadIdx.x < 4) s_turn[threadIdx.x] = 0;
@@ -738,6 +741,13 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_bwd_fused_kernel(const AttnAr
         km[j] = v;
     }
     ATT_MARK(1);
+    __syncthreads();
+    for (int q = threadIdx.x; q < Lq_p; q += nthr) {       // D[q]: the DH/4 partials of the row in index order (deterministic)
+        float d_ = 0.f;
+#pragma unroll
+        for (int j = 0; j < DH / 4; ++j) d_ += s_Dp[q * (DH / 4) + j];
+        s_D[q] = d_;
+    }
     __syncthreads();
     ATT_MARK(2);
 

@@ -103,7 +103,7 @@ static int attn_launch_bwd(AttnArgs& a, int phase, hipStream_t s) {
         LAUNCH_CHECK();
         return 0;
     }
-    if (phase == 4) {          // fused dQ + dK + dV: one workgroup per (b, h, key block); needs Dvec (phase 1)
+    if (phase == 4) {          // fused dQ + dK + dV: one workgroup per (b, h, key block); forms D = rowsum(dO * O) itself
         const int nta = ((a.La + 15) & ~15) >> 4, ntb = ((a.Lb + 15) & ~15) >> 4;
         const int Lq_p = (a.Lq + 15) & ~15;
         SEGMM_REQUIRE(Lq_p <= 48 && nta <= ATT_FUSED_MAXW && ntb <= ATT_FUSED_MAXW, "attn_bwd phase 4: built for Lq <= 48 and <= 12 key tiles per block (Lq %d, %d + %d tiles)", a.Lq, nta, ntb);
@@ -116,7 +116,7 @@ static int attn_launch_bwd(AttnArgs& a, int phase, hipStream_t s) {
             const int nw = fmode == 1 ? nmax : (blk == 0 ? nta : ntb);
             if (nw == 0) continue;
             a.hpb = fmode == 1 ? 2 : blk;
-            const size_t lds = ((size_t)3 * Lq_p * (DH + 4) + 3 * Lq_p + (size_t)nw * 16 * 20 + 4) * 4 + Lq_p + Tp;
+            const size_t lds = ((size_t)3 * Lq_p * (DH + 4) + 3 * Lq_p + (size_t)nw * 16 * 20 + 4 + (size_t)Lq_p * (DH / 4)) * 4 + Lq_p + Tp;
             const dim3 grid((fmode == 1 ? 2 : 1) * a.B * a.H), block(64 * nw);
             if (nw <= 4) hipLaunchKernelGGL((attn_bwd_fused_kernel<DH, 4>), grid, block, lds, s, a);
             else if (nw <= 8) hipLaunchKernelGGL((attn_bwd_fused_kernel<DH, 8>), grid, block, lds, s, a);

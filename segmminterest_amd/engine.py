@@ -495,9 +495,8 @@ def _attn_bwd(store, *args, **kw):
     partial-maxima slots they share are integer atomic maxima (order-independent), the outputs are disjoint column blocks."""
     B_, H_, dh_, Lq_, La_, Lb_ = args[:6]
     if store.attn_fused and Lq_ <= 48 and (La_ + 15) // 16 + (Lb_ + 15) // 16 <= 12:
-        # D = rowsum(dO * O), then dQ + dK + dV in ONE kernel: one workgroup per (b, h) with the query side staged in LDS
-        # (attention.h: attn_bwd_fused_kernel); 848 -> 693 us at config 2 (video queries), see profiles/README.md
-        H.attn_bwd(*args, phase=1, **kw)
+        # dQ + dK + dV in ONE kernel per key block: one workgroup per (b, h, block) with the query side staged in LDS and
+        # D = rowsum(dO * O) formed during the staging (attention.h: attn_bwd_fused_kernel); 848 -> ~540 us at config 2
         H.attn_bwd(*args, phase=4, **kw)
         return
     if not (store.overlap and store.attn_split):

@@ -26,12 +26,11 @@ bwd_ph = lambda ph: H.attn_bwd(B, Hh, dh, Lq, La, Lb, (Qsrc, 0), (Qsrc, d), 4 * 
                                drop_p=p_drop, seed=1, site=3, phase=ph)
 bwd = lambda: bwd_ph(0)
 def bwd_fused():
-    bwd_ph(1)
     bwd_ph(4)
 T = La + Lb
 cases = [("fwd", fwd, 4.0 * dh * Lq * T), ("bwd(dq+dkv)", bwd, 14.0 * dh * Lq * T), ("bwd D only", lambda: bwd_ph(1), 0.0)]
 if Lq <= 48:
-    cases.append(("bwd(D+fused)", bwd_fused, 14.0 * dh * Lq * T))
+    cases.append(("bwd(fused)", bwd_fused, 14.0 * dh * Lq * T))
 for name, fn, flops in cases:
     for _ in range(2):
         fn()
