@@ -120,8 +120,8 @@ int segmm_colsum(const float* X, int ld, const float* w, int64_t M, int N, float
  * segmm_attn_bwd phase: 0 = whole backward on `stream` (dQ kernel, which also writes Dvec, then dK/dV kernel);
  * 1 = Dvec = rowsum(dO * O) only; 2 = dQa/dQb only (Dvec not written); 3 = dKa/dVa/dKb/dVb only (reads Dvec) -- phases 2
  * and 3 are independent once phase 1 is complete and may run concurrently on two streams; 4 = dQ, dK and dV in ONE kernel
- * (one workgroup per (b, h, key block), query side staged in LDS, D formed inside -- Dvec is not used; Lq <= 48 and
- * <= 12 key tiles per block). */
+ * (one workgroup per (b, h, key block), query side staged in LDS in chunks of 48 rows, D formed inside -- Dvec is not
+ * used; <= 12 key tiles per block). */
 int segmm_attn_fwd(int B, int H, int dh, int Lq, int La, int Lb, const float* Qa, const float* Qb, int ldq,
                    const float* Ka, const float* Va, int ldka, const float* Kb, const float* Vb, int ldkb,
                    const uint8_t* mq, const uint8_t* mka, const uint8_t* mkb, float* O, int ldo, float* lse,

@@ -639,7 +639,9 @@ __global__ __launch_bounds__(ATT_BWD_THREADS) void attn_bwd_dkv_kernel(const Att
 //   step, so the wait is short and no workgroup barrier is needed); the workgroup then stores dQ in whole rows.
 // D = rowsum(dO * O) is formed during the staging (each staged dO chunk is multiplied with its O chunk, the DH/4 partial
 // products of a row are summed in a fixed order after the barrier): no separate D launch in front of the backward.
-// LDS: 3 x [Lq_p][DH + 4] floats + [Lq_p][DH/4] partials + statistics + scratch (41 KB at Lq = 40, DH = 48, 7 waves).
+// The query side is processed in chunks of 48 rows (K / V fragments and the dK / dV accumulators stay in registers across the
+// chunks), so the LDS footprint does not depend on Lq: 3 x [48][DH + 4] floats + [48][DH/4] partials + statistics + scratch
+// (41 KB at DH = 48, 7 waves).
 #ifdef SEGMM_ATT_TRACE
 __device__ unsigned long long g_att_trace[16 * 8];      // debug build (tools/attn_trace.py): phase stamps of every wave of one workgroup
 #define ATT_MARK(ph) do { if (att_trace_on && lane == 0) g_att_trace[wave * 8 + (ph)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -647,6 +649,7 @@ __device__ unsigned long long g_att_trace[16 * 8];      // debug build (tools/at
 #define ATT_MARK(ph) do { } while (0)
 #endif
 constexpr int ATT_FUSED_MAXW = 12;
+constexpr int ATT_FUSED_QCHUNK = 48;              // queries staged at a time by attn_bwd_fused_kernel
 // value of lane R of each aligned 4-lane group, in all four lanes of the group (DPP quad_perm broadcast)
 template <int R>
 __device__ __forceinline__ uint32_t quad_bcast(uint32_t v) {
@@ -654,11 +657,14 @@ __device__ __forceinline__ uint32_t quad_bcast(uint32_t v) {
 }
 // NW = waves per workgroup the launch bound is made for (blockDim.x <= 64 NW); 3 waves per SIMD: up to 6 waves two workgroups share a CU
 // (<= 168 registers), so that one head's staging / dQ reduction phases run under the other's MFMA phase.
-template <int DH, int NW>
+// ONE: Lq <= 48, a single chunk known at compile time (the chunk loop disappears: 538 us instead of 597 at config 2).
+template <int DH, int NW, bool ONE>
 __global__ __launch_bounds__(64 * NW, 4) void attn_bwd_fused_kernel(const AttnArgs p) {
     using C = AttnCfg<DH>;
     constexpr int RS = DH + 4;                 // LDS row stride (floats): 16-byte aligned rows, conflict-free fragment reads
     constexpr int TS = 20;                     // row stride of the 16 x 16 transpose scratch
+    constexpr int QC = ATT_FUSED_QCHUNK;       // queries staged at a time (3 query tiles)
+    constexpr int MAXQT = QC / 16;
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int l15 = lane & 15, g = lane >> 4;
@@ -671,104 +677,100 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_bwd_fused_kernel(const AttnAr
     const int ntk = isa ? nta : ntb;                       // key tiles (= working waves) of the block
     if (wave >= ntk) return;                               // surplus wave, or empty block (CrossAtt / SelfAtt ablations)
     const int nthr = 64 * ntk;                             // surviving threads
-    const int Lq_p = round16(p.Lq), nqt = Lq_p >> 4;
     const int col0 = h * DH;
 #ifdef SEGMM_ATT_TRACE
     const bool att_trace_on = blockIdx.x == gridDim.x / 2 + 5;
 #endif
     ATT_MARK(0);
-    float* sQ = smem_f;
-    float* sdO = sQ + Lq_p * RS;
-    float* sdQ = sdO + Lq_p * RS;
-    float* s_mx = sdQ + Lq_p * RS;
-    float* s_inv = s_mx + Lq_p;
-    float* s_D = s_inv + Lq_p;
-    float* s_tr = s_D + Lq_p + wave * (16 * TS);                            // this wave's transpose scratch
-    int* s_turn = (int*)(s_D + Lq_p + nw * (16 * TS));                      // [4] whose turn it is to add dQ of query tile qt
-    float* s_Dp = (float*)(s_turn + 4);                                     // [Lq_p][DH/4] partial products dO . O
-    uint8_t* qm = (uint8_t*)(s_Dp + Lq_p * (DH / 4));                       // [Lq_p] 1 valid query, 0 masked, 2 pad
-    uint8_t* km = qm + Lq_p;                                                // [Tp]
+    float* sQ = smem_f;                                    // [QC][RS] query rows of the current chunk
+    float* sdO = sQ + QC * RS;
+    float* sdQ = sdO + QC * RS;
+    float* s_mx = sdQ + QC * RS;
+    float* s_inv = s_mx + QC;
+    float* s_D = s_inv + QC;
+    float* s_tr = s_D + QC + wave * (16 * TS);                              // this wave's transpose scratch
+    int* s_turn = (int*)(s_D + QC + nw * (16 * TS));                        // [4] whose turn it is to add dQ of query tile qt
+    float* s_Dp = (float*)(s_turn + 4);                                     // [QC][DH/4] partial products dO . O
+    uint8_t* qm = (uint8_t*)(s_Dp + QC * (DH / 4));                         // [QC] 1 valid query, 0 masked, 2 pad
+    uint8_t* km = qm + QC;                                                  // [Tp]
     // ---- this wave's key tile.  Its K / V fragments are requested BEFORE the staging below (they do not depend on it):
     // their latency hides under the staging loads and the barrier.
-    const int wt0 = (isa ? 0 : nta) + wave;                                 // padded key tile of this wave
-    const int wt1 = wt0 + 1;
+    const int jt = (isa ? 0 : nta) + wave;                                  // padded key tile of this wave
     KeyBlocks<DH> kbk;
     kbk.init(p, b, col0, l15, g);
     float kf[C::KS], vf[C::KS], kc[4][C::CT];
-    auto load_tile = [&](int jt) {
-        if (isa) {
-            const uint32_t so = (uint32_t)(16 * jt) * kbk.pitch_a;
-            frag_load<DH>(kf, kbk.ka, kbk.row_a, so);
-            frag_load<DH>(vf, kbk.va, kbk.row_a, so);
+    if (isa) {
+        const uint32_t so = (uint32_t)(16 * jt) * kbk.pitch_a;
+        frag_load<DH>(kf, kbk.ka, kbk.row_a, so);
+        frag_load<DH>(vf, kbk.va, kbk.row_a, so);
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) col_load<DH>(kc[s4], kbk.ka, kbk.col_a, (uint32_t)(16 * jt + s4) * kbk.pitch_a, l15);
-        } else {
-            const uint32_t so = (uint32_t)(16 * (jt - nta)) * kbk.pitch_b;
-            frag_load<DH>(kf, kbk.kb, kbk.row_b, so);
-            frag_load<DH>(vf, kbk.vb, kbk.row_b, so);
+        for (int s4 = 0; s4 < 4; ++s4) col_load<DH>(kc[s4], kbk.ka, kbk.col_a, (uint32_t)(16 * jt + s4) * kbk.pitch_a, l15);
+    } else {
+        const uint32_t so = (uint32_t)(16 * (jt - nta)) * kbk.pitch_b;
+        frag_load<DH>(kf, kbk.kb, kbk.row_b, so);
+        frag_load<DH>(vf, kbk.vb, kbk.row_b, so);
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) col_load<DH>(kc[s4], kbk.kb, kbk.col_b, (uint32_t)(16 * (jt - nta) + s4) * kbk.pitch_b, l15);
-        }
-    };
-    if (wt0 < wt1) load_tile(wt0);
-    // ---- stage the query side: whole rows, float4, rows >= Lq zero; zero the dQ accumulator
-    const float* Qg = isa ? p.Qa : p.Qb;
-    for (int i = threadIdx.x; i < Lq_p * (DH / 4); i += nthr) {
-        const int q = i / (DH / 4), c = (i - q * (DH / 4)) * 4;
-        f32x4 va = {0.f, 0.f, 0.f, 0.f}, vo = va, oo = va;
-        if (q < p.Lq) {
-            const size_t row = (size_t)b * p.Lq + q;
-            va = *(const f32x4*)(Qg + row * p.ldq + col0 + c);
-            vo = *(const f32x4*)(p.dO + row * p.lddo + col0 + c);
-            oo = *(const f32x4*)(p.O + row * p.ldo + col0 + c);
-        }
-        *(f32x4*)(sQ + q * RS + c) = va;
-        *(f32x4*)(sdO + q * RS + c) = vo;
-        *(f32x4*)(sdQ + q * RS + c) = f32x4{0.f, 0.f, 0.f, 0.f};
-        s_Dp[i] = (vo.x * oo.x + vo.y * oo.y) + (vo.z * oo.z + vo.w * oo.w);
+        for (int s4 = 0; s4 < 4; ++s4) col_load<DH>(kc[s4], kbk.kb, kbk.col_b, (uint32_t)(16 * (jt - nta) + s4) * kbk.pitch_b, l15);
     }
-    for (int q = threadIdx.x; q < Lq_p; q += nthr) {
-        const bool in = q < p.Lq;
-        s_mx[q] = in ? p.lse[(size_t)bh * p.Lq + q] : 0.f;
-        s_inv[q] = in ? p.lse[(size_t)p.B * p.H * p.Lq + (size_t)bh * p.Lq + q] : 0.f;
-        qm[q] = in ? (p.mq[(size_t)b * p.Lq + q] ? 1 : 0) : 2;
-    }
-    if (threadIdx.x < 4) s_turn[threadIdx.x] = 0;
-    for (int j = threadIdx.x; j < Tp; j += nthr) {         // stage_kmask with the surviving thread count
+    for (int j = threadIdx.x; j < Tp; j += nthr) {         // key flags (stage_kmask with the surviving thread count)
         uint8_t v;
         if (j < La_p) v = (j < p.La) ? (p.mka[(size_t)b * p.La + j] ? 1 : 0) : 2;
         else { const int jb = j - La_p; v = (jb < p.Lb) ? (p.mkb[(size_t)b * p.Lb + jb] ? 1 : 0) : 2; }
         km[j] = v;
     }
-    ATT_MARK(1);
-    __syncthreads();
-    for (int q = threadIdx.x; q < Lq_p; q += nthr) {       // D[q]: the DH/4 partials of the row in index order (deterministic)
-        float d_ = 0.f;
-#pragma unroll
-        for (int j = 0; j < DH / 4; ++j) d_ += s_Dp[q * (DH / 4) + j];
-        s_D[q] = d_;
-    }
-    __syncthreads();
-    ATT_MARK(2);
-
+    const float* Qg = isa ? p.Qa : p.Qb;
+    float* dQg = isa ? p.dQa : p.dQb;
     const float fscale = p.scale;
-    constexpr int MAXQT = 3;                               // Lq <= 48
-
-    for (int jt = wt0; jt < wt1; ++jt) {
-        const int jp = 16 * jt + l15;                      // this lane's key (padded index)
-        const uint8_t kflag = km[jp];
-        f32x4 dk[C::CT], dv[C::CT];
+    const int jp = 16 * jt + l15;                          // this lane's key (padded index)
+    f32x4 dk[C::CT], dv[C::CT];
 #pragma unroll
-        for (int ct = 0; ct < C::CT; ++ct) { dk[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int ct = 0; ct < C::CT; ++ct) { dk[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    float am_q = 0.f;
+
+    // ---- the query side in chunks of QC rows: 41 KB of LDS whatever Lq is (user queries: Lq = 100 -> 3 chunks)
+    for (int q0 = 0; ONE ? q0 < 1 : q0 < p.Lq; q0 += QC) {
+        const int nq = min(QC, p.Lq - q0);                 // real queries of the chunk
+        const int nqt = (nq + 15) >> 4;
+        // stage whole rows (float4), rows >= nq zero; zero the dQ accumulator; partial products of D = rowsum(dO * O)
+        for (int i = threadIdx.x; i < QC * (DH / 4); i += nthr) {
+            const int q = i / (DH / 4), c = (i - q * (DH / 4)) * 4;
+            f32x4 va = {0.f, 0.f, 0.f, 0.f}, vo = va, oo = va;
+            if (q < nq) {
+                const size_t row = (size_t)b * p.Lq + q0 + q;
+                va = *(const f32x4*)(Qg + row * p.ldq + col0 + c);
+                vo = *(const f32x4*)(p.dO + row * p.lddo + col0 + c);
+                oo = *(const f32x4*)(p.O + row * p.ldo + col0 + c);
+            }
+            *(f32x4*)(sQ + q * RS + c) = va;
+            *(f32x4*)(sdO + q * RS + c) = vo;
+            *(f32x4*)(sdQ + q * RS + c) = f32x4{0.f, 0.f, 0.f, 0.f};
+            s_Dp[i] = (vo.x * oo.x + vo.y * oo.y) + (vo.z * oo.z + vo.w * oo.w);
+        }
+        for (int q = threadIdx.x; q < QC; q += nthr) {
+            const bool in = q < nq;
+            s_mx[q] = in ? p.lse[(size_t)bh * p.Lq + q0 + q] : 0.f;
+            s_inv[q] = in ? p.lse[(size_t)p.B * p.H * p.Lq + (size_t)bh * p.Lq + q0 + q] : 0.f;
+            qm[q] = in ? (p.mq[(size_t)b * p.Lq + q0 + q] ? 1 : 0) : 2;
+        }
+        if (threadIdx.x < 4) s_turn[threadIdx.x] = 0;
+        ATT_MARK(1);
+        __syncthreads();
+        for (int q = threadIdx.x; q < QC; q += nthr) {     // D[q]: the DH/4 partials of the row in index order (deterministic)
+            float d_ = 0.f;
+#pragma unroll
+            for (int j = 0; j < DH / 4; ++j) d_ += s_Dp[q * (DH / 4) + j];
+            s_D[q] = d_;
+        }
+        __syncthreads();
+        ATT_MARK(2);
+        const uint8_t kflag = km[jp];
 #pragma unroll
         for (int qt = 0; qt < MAXQT; ++qt) {
             if (qt < nqt) {
                 // row fragments (lane&15 = query): element k = 16 i + 4 g + e of the row, like frag_load
                 float qf[C::KS], dof[C::KS];
-                const float* qrow = sQ + (16 * qt + l15) * RS + C::row_off(g);
-                const float* drow = sdO + (16 * qt + l15) * RS + C::row_off(g);
-                frag_load_ptr<DH>(qf, qrow);
-                frag_load_ptr<DH>(dof, drow);
+                frag_load_ptr<DH>(qf, sQ + (16 * qt + l15) * RS + C::row_off(g));
+                frag_load_ptr<DH>(dof, sdO + (16 * qt + l15) * RS + C::row_off(g));
                 f32x4 sv = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int c = 0; c < C::KS; ++c) {
@@ -786,7 +788,7 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_bwd_fused_kernel(const AttnAr
                 uint32_t dw[4] = {0u, 0u, 0u, 0u};
                 if (p.drop.p > 0.f) {
                     const int rr = l15 & 3;
-                    const uint2 hw = drop_rand_quad(p.drop, (((uint64_t)bh * p.Lq + (16 * qt + 4 * g + rr)) * Tp + jp) >> 2);
+                    const uint2 hw = drop_rand_quad(p.drop, (((uint64_t)bh * p.Lq + (q0 + 16 * qt + 4 * g + rr)) * Tp + jp) >> 2);
                     const uint32_t a0 = quad_bcast<0>(hw.x), a1 = quad_bcast<1>(hw.x), a2 = quad_bcast<2>(hw.x), a3 = quad_bcast<3>(hw.x);
                     const uint32_t b0 = quad_bcast<0>(hw.y), b1 = quad_bcast<1>(hw.y), b2 = quad_bcast<2>(hw.y), b3 = quad_bcast<3>(hw.y);
                     const bool lo_word = rr < 2, hi_half = rr & 1;
@@ -856,7 +858,20 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_bwd_fused_kernel(const AttnAr
                 if (lane == 0) __hip_atomic_store(s_turn + qt, wave + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
-        // dK / dV rows of this tile: lane (key l15, g), tile ct register r = head column 16 ct + 4 g + r
+        ATT_MARK(3);
+        __syncthreads();                                   // every wave has added its dQ partials of this chunk
+        ATT_MARK(4);
+        for (int i = threadIdx.x; i < nq * (DH / 4); i += nthr) {
+            const int q = i / (DH / 4), c = (i - q * (DH / 4)) * 4;
+            const size_t row = (size_t)b * p.Lq + q0 + q;
+            const f32x4 v = *(const f32x4*)(sdQ + q * RS + c);
+            *(f32x4*)(dQg + row * p.lddq + col0 + c) = v;
+            am_q = absmax4(am_q, v);
+        }
+        if (!ONE && q0 + QC < p.Lq) __syncthreads();       // the next chunk's staging overwrites what was just read
+    }
+    // dK / dV rows of this tile: lane (key l15, g), tile ct register r = head column 16 ct + 4 g + r
+    {
         const bool ka = jp < La_p;
         const int jloc = ka ? jp : jp - La_p;
         const bool real = ka ? (jloc < p.La) : (jloc < p.Lb);
@@ -876,19 +891,7 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_bwd_fused_kernel(const AttnAr
         float* slot = isa ? p.amax_ka : p.amax_kb;
         if (slot) amax_commit(slot, am, blockIdx.x * nw + wave);
     }
-
-    ATT_MARK(3);
-    __syncthreads();                                       // every wave has added its dQ partials
-    ATT_MARK(4);
-    float am = 0.f;
-    for (int i = threadIdx.x; i < p.Lq * (DH / 4); i += nthr) {
-        const int q = i / (DH / 4), c = (i - q * (DH / 4)) * 4;
-        const size_t row = (size_t)b * p.Lq + q;
-        const f32x4 v = *(const f32x4*)(sdQ + q * RS + c);
-        *(f32x4*)((isa ? p.dQa : p.dQb) + row * p.lddq + col0 + c) = v;
-        am = absmax4(am, v);
-    }
-    if (p.amax_q) amax_commit(p.amax_q, am, blockIdx.x * nw + wave);
+    if (p.amax_q) amax_commit(p.amax_q, am_q, blockIdx.x * nw + wave);
     ATT_MARK(5);
 }
 

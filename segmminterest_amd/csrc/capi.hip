@@ -105,8 +105,8 @@ static int attn_launch_bwd(AttnArgs& a, int phase, hipStream_t s) {
     }
     if (phase == 4) {          // fused dQ + dK + dV: one workgroup per (b, h, key block); forms D = rowsum(dO * O) itself
         const int nta = ((a.La + 15) & ~15) >> 4, ntb = ((a.Lb + 15) & ~15) >> 4;
-        const int Lq_p = (a.Lq + 15) & ~15;
-        SEGMM_REQUIRE(Lq_p <= 48 && nta <= ATT_FUSED_MAXW && ntb <= ATT_FUSED_MAXW, "attn_bwd phase 4: built for Lq <= 48 and <= 12 key tiles per block (Lq %d, %d + %d tiles)", a.Lq, nta, ntb);
+        const int Lq_p = ATT_FUSED_QCHUNK;                 // LDS is sized for one chunk of the query side
+        SEGMM_REQUIRE(nta <= ATT_FUSED_MAXW && ntb <= ATT_FUSED_MAXW, "attn_bwd phase 4: built for <= 12 key tiles per block (%d + %d tiles)", nta, ntb);
         static const int fmode = getenv("SEGMM_ATT_FUSED_LAUNCH") ? atoi(getenv("SEGMM_ATT_FUSED_LAUNCH")) : 2;
         const int nmax = nta > ntb ? nta : ntb;
         for (int blk = 0; blk < 2; ++blk) {
@@ -118,9 +118,13 @@ static int attn_launch_bwd(AttnArgs& a, int phase, hipStream_t s) {
             a.hpb = fmode == 1 ? 2 : blk;
             const size_t lds = ((size_t)3 * Lq_p * (DH + 4) + 3 * Lq_p + (size_t)nw * 16 * 20 + 4 + (size_t)Lq_p * (DH / 4)) * 4 + Lq_p + Tp;
             const dim3 grid((fmode == 1 ? 2 : 1) * a.B * a.H), block(64 * nw);
-            if (nw <= 4) hipLaunchKernelGGL((attn_bwd_fused_kernel<DH, 4>), grid, block, lds, s, a);
-            else if (nw <= 8) hipLaunchKernelGGL((attn_bwd_fused_kernel<DH, 8>), grid, block, lds, s, a);
-            else hipLaunchKernelGGL((attn_bwd_fused_kernel<DH, 12>), grid, block, lds, s, a);
+            const bool one = a.Lq <= ATT_FUSED_QCHUNK;
+#define FUSED(NWV) do { if (one) hipLaunchKernelGGL((attn_bwd_fused_kernel<DH, NWV, true>), grid, block, lds, s, a); \
+                        else hipLaunchKernelGGL((attn_bwd_fused_kernel<DH, NWV, false>), grid, block, lds, s, a); } while (0)
+            if (nw <= 4) FUSED(4);
+            else if (nw <= 8) FUSED(8);
+            else FUSED(12);
+#undef FUSED
         }
         LAUNCH_CHECK();
         return 0;

@@ -152,7 +152,7 @@ class ParamStore:
         # runs): 80.3 k -> 79.6 k interactions/s, the union of the attention intervals unchanged at 1.10-1.14 ms/step -- the two
         # kernels share the same vector-memory pipeline and simply slow each other down.  OFF by default.
         self.attn_split = os.environ.get("SEGMM_ATTN_SPLIT", "0") != "0"
-        self.attn_fused = os.environ.get("SEGMM_ATTN_FUSED", "1") != "0"      # fused dQ+dK+dV kernel where it is built (Lq <= 48)
+        self.attn_fused = os.environ.get("SEGMM_ATTN_FUSED", "1") != "0"      # fused dQ+dK+dV kernel (<= 12 key tiles per block)
         self._attn_stream = None
         self.fwd_side = os.environ.get("SEGMM_FWD_SIDE", "0") != "0"      # forward: user-token chain on the side stream (measured: -0.3 %, off)
         self.ln_side = os.environ.get("SEGMM_LN_SIDE", "0") != "0"      # measured: -2 % (kept as a knob)     # measured: no gain (kept as a knob)
@@ -494,7 +494,7 @@ def _attn_bwd(store, *args, **kw):
     stream CONCURRENTLY with the dK/dV kernel on the main stream (no gain measured, see ParamStore.attn_split).  The
     partial-maxima slots they share are integer atomic maxima (order-independent), the outputs are disjoint column blocks."""
     B_, H_, dh_, Lq_, La_, Lb_ = args[:6]
-    if store.attn_fused and Lq_ <= 48 and (La_ + 15) // 16 + (Lb_ + 15) // 16 <= 12:
+    if store.attn_fused and max((La_ + 15) // 16, (Lb_ + 15) // 16) <= 12:
         # dQ + dK + dV in ONE kernel per key block: one workgroup per (b, h, block) with the query side staged in LDS and
         # D = rowsum(dO * O) formed during the staging (attention.h: attn_bwd_fused_kernel); 848 -> ~540 us at config 2
         H.attn_bwd(*args, phase=4, **kw)

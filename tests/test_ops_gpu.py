@@ -690,10 +690,12 @@ def test_colsum3(M, N, nmat):
         assert (o.double() - X.double().sum(0)).abs().max().item() < 1e-4 * max(1.0, X.abs().sum(0).max().item())
 
 
-def test_attention_bwd_phases_equal_whole():
-    """phase 1 (D) + 2 (dQ) + 3 (dK/dV) reproduce the single-call backward bit for bit."""
+@pytest.mark.parametrize("B,H_,dh,Lq,La,Lb", [(2, 16, 48, 40, 40, 100), (2, 16, 48, 100, 40, 100), (2, 4, 8, 7, 40, 7), (3, 4, 8, 1, 40, 1),
+                                              (2, 2, 32, 20, 20, 10), (2, 2, 64, 49, 40, 10), (2, 4, 16, 96, 40, 100)])
+def test_attention_bwd_phases_equal_whole(B, H_, dh, Lq, La, Lb):
+    """phase 1 (D) + 2 (dQ) + 3 (dK/dV), and phase 4 (fused, query side in chunks of 48 rows), reproduce the single-call
+    backward."""
     H = _abi()
-    B, H_, dh, Lq, La, Lb = 2, 16, 48, 40, 40, 100
     d = H_ * dh
     g = torch.Generator().manual_seed(77)
     mk = lambda L: (torch.randn(B, L, d, generator=g) * 0.7).to(DEV)

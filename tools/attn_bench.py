@@ -29,7 +29,7 @@ def bwd_fused():
     bwd_ph(4)
 T = La + Lb
 cases = [("fwd", fwd, 4.0 * dh * Lq * T), ("bwd(dq+dkv)", bwd, 14.0 * dh * Lq * T), ("bwd D only", lambda: bwd_ph(1), 0.0)]
-if Lq <= 48:
+if True:
     cases.append(("bwd(fused)", bwd_fused, 14.0 * dh * Lq * T))
 for name, fn, flops in cases:
     for _ in range(2):
