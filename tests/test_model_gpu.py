@@ -349,3 +349,62 @@ def test_full_size_batch_matches_oracle_on_a_row_subset():
     ref = O.model_forward(sd, cfg, sub, mode="inference")["logits"]
     assert (got[rows] - ref.detach()).abs().max().item() < 1e-4
     assert got.shape == (B, S) and torch.isfinite(got).all()
+
+
+def test_config1_sample_file_labels_vs_oracle():
+    """BASELINE config 1: the label rows of the reference's sample interaction file (tests/golden/cfg1_labels.npz, made by
+    oracle/gen_cfg1_labels.py: truncated / padded to S = 20), d = 128, h = 16, N = 2, Lt = 100, synthetic features:
+    logits, loss, gradients and the leave-rank metrics of the HIP path against the CPU oracle."""
+    import argparse
+    import numpy as np
+    import segmm_oracle as O
+    import segmminterest_amd as M
+    from helpers import GOLDEN
+    from segmminterest_amd.synth import make_batch, l1_normalize
+    z = np.load(os.path.join(GOLDEN, "cfg1_labels.npz"))
+    B, S, Lt, D, N, h = 96, 20, 100, 128, 2, 16
+    label = torch.from_numpy(z["label"][:B].astype(np.int64))
+    assert label.shape == (B, S) and int((label == -2).sum()) > 0 and int(((label == 0).sum(1) == 0).sum()) > 0
+    torch.manual_seed(1)
+    args = argparse.Namespace(debug=0, num_layers_enc=N, ablation_type="ours", d_model=D, nhead=h,
+                              input_type={"user": "image", "photo": "image"}, learnable_bias=0, exposure_prob=[1.0] * S,
+                              fusion_heads=2, loss_type_list=["interestBPR", "surviveCE"],
+                              loss_weight={"interestBPR": 1.0, "surviveCE": 0.5, "mse": 1.0}, mask_loss=0)
+    bb = M.SegFormerX(d_model_in=D, d_model_lvls=[D] * N, num_head_lvls=[h] * N, ff_dim_lvls=[D] * N, input_vid_dim=D,
+                      input_usr_dim=D, max_vid_len=S, max_usr_len=Lt, sr_ratio_lvls=[1] * N, use_patch_merge=[False] * N,
+                      output_layers=[-1], model_cfg=args)
+    model = M.MultiScaleTemporalDetrLeaveFocal(bb, None, None, torch.nn.Identity(), args)
+    with torch.no_grad():
+        for n_, p in model.named_parameters():
+            if p.dim() == 2 and "proj" in n_ and "backbone1.vid_proj" not in n_ and "backbone1.usr_proj" not in n_:
+                p.mul_(4.0)
+            if n_.endswith("vid_proj.weight") or n_.endswith("usr_proj.weight"):
+                p.mul_(60.0)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    b = make_batch(B, S, Lt, D, seed=11)
+    pm = label != -2                                       # the file's durations decide the padding
+    inp = dict(usr_image=l1_normalize(b["user"]), usr_id=b["user_identity_id"], usr_mask=b["user_mask"],
+               vid_image=l1_normalize(b["photo"] * pm[:, :, None]), vid_id=b["photo_identity_id"], vid_mask=pm, gt=label)
+    cfg = dict(N=N, h=h, S=S, user="image", photo="image", loss_type_list=["interestBPR", "surviveCE"],
+               loss_weight={"interestBPR": 1.0, "surviveCE": 0.5, "mse": 1.0}, exposure_prob=[1.0] * S)
+    ref, rgrads = O.forward_backward(sd, cfg, inp)
+    model = model.cuda().eval()
+    out = call_model(model, inp, "train", DEV)
+    assert (out["logits"].cpu() - ref["logits"].detach()).abs().max().item() < 1e-4
+    for k in ("loss", "interestBPR", "surviveCE"):
+        assert abs(float(out[k]) - float(ref[k])) < 1e-4 * max(1.0, abs(float(ref[k]))), k
+    out["loss"].backward()
+    for k, p in model.named_parameters():
+        if rgrads[k] is None:
+            assert p.grad is None, k
+        else:
+            err = (p.grad.cpu() - rgrads[k]).abs().max().item()
+            assert err <= 3e-4 * max(rgrads[k].abs().max().item(), 1e-6), (k, err)
+    # leave-rank metrics (integer ranks): device path == numpy oracle on the SAME interests
+    from segmminterest_amd.my_evaluation import TOP_K_leave_device
+    interests = torch.sigmoid(out["logits"].detach())
+    dev_m = TOP_K_leave_device(interests, label.to(DEV), permutation=0)
+    view = (label == 1).sum(1, keepdim=True).numpy()
+    ref_m = O.top_k_leave(interests.cpu().numpy(), view, pm.numpy(), permutation=0, S=S)
+    for k in ("HR@1", "HR@3", "HR@5", "HR@10", "NDCG@1", "NDCG@3", "NDCG@5", "NDCG@10"):
+        assert float(dev_m[k]) == float(ref_m[k]), (k, dev_m[k], ref_m[k])
