@@ -693,25 +693,30 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_bwd_fused_kernel(const AttnAr
     float* s_Dp = (float*)(s_turn + 4);                                     // [QC][DH/4] partial products dO . O
     uint8_t* qm = (uint8_t*)(s_Dp + QC * (DH / 4));                         // [QC] 1 valid query, 0 masked, 2 pad
     uint8_t* km = qm + QC;                                                  // [Tp]
-    // ---- this wave's key tile.  Its K / V fragments are requested BEFORE the staging below (they do not depend on it):
-    // their latency hides under the staging loads and the barrier.
+    // ---- this wave's key tile
     const int jt = (isa ? 0 : nta) + wave;                                  // padded key tile of this wave
     KeyBlocks<DH> kbk;
     kbk.init(p, b, col0, l15, g);
     float kf[C::KS], vf[C::KS], kc[4][C::CT];
-    if (isa) {
-        const uint32_t so = (uint32_t)(16 * jt) * kbk.pitch_a;
-        frag_load<DH>(kf, kbk.ka, kbk.row_a, so);
-        frag_load<DH>(vf, kbk.va, kbk.row_a, so);
+    auto load_frags = [&]() {     // K / V row fragments and K column fragments of this wave's tile (global, fragment form)
+        if (isa) {
+            const uint32_t so = (uint32_t)(16 * jt) * kbk.pitch_a;
+            frag_load<DH>(kf, kbk.ka, kbk.row_a, so);
+            frag_load<DH>(vf, kbk.va, kbk.row_a, so);
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) col_load<DH>(kc[s4], kbk.ka, kbk.col_a, (uint32_t)(16 * jt + s4) * kbk.pitch_a, l15);
-    } else {
-        const uint32_t so = (uint32_t)(16 * (jt - nta)) * kbk.pitch_b;
-        frag_load<DH>(kf, kbk.kb, kbk.row_b, so);
-        frag_load<DH>(vf, kbk.vb, kbk.row_b, so);
+            for (int s4 = 0; s4 < 4; ++s4) col_load<DH>(kc[s4], kbk.ka, kbk.col_a, (uint32_t)(16 * jt + s4) * kbk.pitch_a, l15);
+        } else {
+            const uint32_t so = (uint32_t)(16 * (jt - nta)) * kbk.pitch_b;
+            frag_load<DH>(kf, kbk.kb, kbk.row_b, so);
+            frag_load<DH>(vf, kbk.vb, kbk.row_b, so);
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) col_load<DH>(kc[s4], kbk.kb, kbk.col_b, (uint32_t)(16 * (jt - nta) + s4) * kbk.pitch_b, l15);
-    }
+            for (int s4 = 0; s4 < 4; ++s4) col_load<DH>(kc[s4], kbk.kb, kbk.col_b, (uint32_t)(16 * (jt - nta) + s4) * kbk.pitch_b, l15);
+        }
+    };
+    // single chunk (Lq <= 48): requested AFTER the staging loads (loads return in order: the first barrier then waits for the
+    // staging data only; 542 -> 518 us); several chunks: requested first, their latency hides under the first chunk's staging
+    // (the other order costs 18 % at Lq = 100)
+    if (!ONE) load_frags();
     for (int j = threadIdx.x; j < Tp; j += nthr) {         // key flags (stage_kmask with the surviving thread count)
         uint8_t v;
         if (j < La_p) v = (j < p.La) ? (p.mka[(size_t)b * p.La + j] ? 1 : 0) : 2;
@@ -753,6 +758,7 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_bwd_fused_kernel(const AttnAr
             qm[q] = in ? (p.mq[(size_t)b * p.Lq + q0 + q] ? 1 : 0) : 2;
         }
         if (threadIdx.x < 4) s_turn[threadIdx.x] = 0;
+        if (ONE) load_frags();
         ATT_MARK(1);
         __syncthreads();
         for (int q = threadIdx.x; q < QC; q += nthr) {     // D[q]: the DH/4 partials of the row in index order (deterministic)
