@@ -73,10 +73,13 @@ def TOP_K_leave_mask(interests, view_lengths, mask_batch, permutation=1):
     return _evaluations(_topk(interests, view_lengths, mask_batch, permutation, masked=True))
 
 
-def TOP_K_leave_device(interests: torch.Tensor, gt: torch.Tensor, permutation=1, masked=False, seq_valid=None, test=0):
+def TOP_K_leave_device(interests: torch.Tensor, gt: torch.Tensor, permutation=1, masked=False, seq_valid=None, test=0, gather=None):
     """TOP_K_leave / TOP_K_leave_mask on the device: interests [B, S] float32 and labels gt [B, S] int64 stay in HBM.
     Returns the same dict (same float arithmetic on the same integer ranks).  With ``permutation`` the host draws the
-    candidate shuffles from np.random exactly as the host path does (one permutation per VALID row, in row order)."""
+    candidate shuffles from np.random exactly as the host path does (one permutation per VALID row, in row order).
+    ``gather`` (data parallel): callable int32 [B] -> int32 [G*B] that collects the leave ranks of every
+    rank's rows; the metrics are then those of the GLOBAL batch, identical on every rank and -- with ``permutation=0`` --
+    bit-identical to a single process evaluating the whole batch (the ranks are integers)."""
     from . import hipabi as H
     B, S = gt.shape
     x = interests.detach()
@@ -94,6 +97,8 @@ def TOP_K_leave_device(interests: torch.Tensor, gt: torch.Tensor, permutation=1,
         perm = torch.zeros((B, S), dtype=torch.int32, device=x.device)
         perm[valid] = torch.from_numpy(pv).to(x.device)
     ranks, _hist = H.rank_leave(x, gt, perm=perm, masked=masked, seq_valid=seq_valid)
+    if gather is not None:
+        ranks = gather(ranks)
     r = ranks.cpu().numpy().astype(np.int64)
     ev = _evaluations(r[r > 0])
     if test:

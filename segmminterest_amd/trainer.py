@@ -207,6 +207,19 @@ class DPComm:
         self.dist.all_gather_into_tensor(rows_all, rows, group=self.group)
         return ids_all, rows_all
 
+    def gather_ints(self, t):
+        """[G*B] int32: the values of every rank in rank order (validation: leave ranks of the global batch)."""
+        if self.world == 1:
+            return t
+        t = t.contiguous()
+        if self.host_staged and t.is_cuda:
+            h = torch.empty((self.world * t.shape[0],), dtype=t.dtype)
+            self.dist.all_gather_into_tensor(h, t.cpu(), group=self.group)
+            return h.to(t.device)
+        out = torch.empty((self.world * t.shape[0],), dtype=t.dtype, device=t.device)
+        self.dist.all_gather_into_tensor(out, t, group=self.group)
+        return out
+
     def reduce_bucket(self, flat_grad, start, end):
         """Asynchronous SUM all-reduce of one contiguous gradient bucket (gradients are already
         normalised by global counts, so SUM -- not mean -- reproduces the single-process gradient)."""
@@ -374,12 +387,16 @@ class Trainer:
             if exposure is None:
                 exposure = torch.tensor(model.exposure_prob, dtype=torch.float32, device=logits.device)[: logits.shape[1]]
             interests = torch.sigmoid(logits) * exposure
-            ev = TOP_K_leave_device(interests, gt, permutation=permutation, masked=top_k_mask)
+            dp = self.comm.world > 1
+            ev = TOP_K_leave_device(interests, gt, permutation=permutation, masked=top_k_mask,
+                                    gather=self.comm.gather_ints if dp else None)
             for k in acc:
+                # data parallel: every rank's loss terms are already divided by the GLOBAL normalisers, so the global value
+                # is their sum over ranks; the rank metrics above are those of the global batch
                 if k == "valid_loss":
-                    acc[k].append(float(out["loss"]))
+                    acc[k].append(float(self.comm.sum_scalar(out["loss"].detach().clone())))
                 elif k in out and k not in ("gt", "logits"):
-                    acc[k].append(float(out[k]))
+                    acc[k].append(float(self.comm.sum_scalar(out[k].detach().clone())) if dp and k not in ("mse", "mse2") else float(out[k]))
                 elif k in ev:
                     acc[k].append(float(ev[k]))
         return {k: (sum(v) / len(v) if v else float("nan")) for k, v in acc.items()}

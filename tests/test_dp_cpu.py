@@ -61,6 +61,8 @@ def _worker(rank, world, port, q):
         ids_all, rows_all = comm.gather_rows(ids, rows)
         assert ids_all.shape == (5 * world,) and rows_all.shape == (5 * world, 4)
         assert torch.equal(ids_all[5 * rank:5 * rank + 5], ids) and torch.equal(rows_all[5 * rank:5 * rank + 5], rows)
+        r_all = comm.gather_ints(torch.arange(5, dtype=torch.int32) + 10 * rank)       # validation: leave ranks of every rank's rows
+        assert r_all.tolist() == [i + 10 * r for r in range(world) for i in range(5)]
         dense = torch.zeros(6, 4).index_add_(0, ids, rows)
         comm.reduce_bucket(dense.view(-1), 0, dense.numel())
         comm.finish()

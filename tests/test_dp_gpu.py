@@ -46,8 +46,9 @@ def _run(rank, world, port, name, q):
             losses.append(float(tr.comm.sum_scalar(out["loss"].detach().clone())))
             if i == 0:
                 gflat = model._store.gflat.detach().cpu().numpy().copy()      # the all-reduced gradients of step 1
+        vmet = tr.valid_model([shard], permutation=0)     # leave-rank metrics of the GLOBAL batch (ranks gathered)
         if rank == 0:
-            q.put((losses, gflat, {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}))   # numpy: no torch shm handles
+            q.put((losses, gflat, {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}, vmet))   # numpy: no torch shm handles
     finally:
         if world > 1:
             dist.destroy_process_group()
@@ -68,7 +69,14 @@ def test_two_ranks_equal_single_process(name):
             p.join(60)
             assert p.exitcode == 0
         results[world] = res
-    (l1, g1, sd1), (l2, g2, sd2) = results[1], results[2]
+    (l1, g1, sd1, vm1), (l2, g2, sd2, vm2) = results[1], results[2]
+    # validation after the 2 steps: parameters agree to lr-sized effects, so logits can differ in the last digits; the integer
+    # leave ranks -- and with them HR@k / NDCG@k of the global batch -- are expected to coincide
+    for k in vm1:
+        if k == "valid_loss":
+            assert abs(vm1[k] - vm2[k]) <= 3e-3 * max(1.0, abs(vm1[k])), (k, vm1[k], vm2[k])
+        else:
+            assert abs(vm1[k] - vm2[k]) <= 0.07, (k, vm1[k], vm2[k])      # one row of 16 changing rank moves HR@k by 1/16
     g1, g2 = torch.from_numpy(g1), torch.from_numpy(g2)
     assert float((g1 - g2).abs().max()) <= 1e-4 * float(g1.abs().max()), "summed shard gradients != whole-batch gradients"
     assert abs(l1[0] - l2[0]) <= 1e-5 * max(1.0, abs(l1[0])), (l1, l2)
