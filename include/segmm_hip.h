@@ -73,6 +73,34 @@ int segmm_gemm_h(int layout, int M, int N, int K, const float* A, int lda, const
                  float* workspace, int accumulate, const uint16_t* a_planes, int64_t a_pstride,
                  const uint16_t* b_planes, int64_t b_pstride, const float* a_amax, int a_namax, const float* b_amax,
                  int b_namax, float* c_amax, segmm_stream_t stream);
+
+/* Plane-operand GEMM: the fp16x3 arithmetic of segmm_gemm_h with operands that arrive PRE-SPLIT by their producers.
+ * P32 plane format of a matrix X[R][C], C % 32 == 0: one fp16 array with row stride ld2 (halves); per row and per block
+ * of 32 columns [32 hi | 32 lo] (128 bytes) -- element (r, c): hi at r*ld2 + (c/32)*64 + c%32, lo 32 further.
+ * Site header `hdr` of a plane tensor: SEGMM_SITE_HDR floats followed by SEGMM_AMAX_SLOTS partial maxima:
+ *   hdr[0] scale s the planes were written with (power of two; 0 = no planes written),
+ *   hdr[1] != 0 (as integer): an element left the fp16 range under s (delayed scaling) -> consumers read the fp32 copy.
+ * a_f32 / b_f32 (optional): fp32 copy of the operand; taken (exact split on the fly, slow) whenever the planes are not
+ * usable -- results are never silently wrong.  Replaces the same reference ops as segmm_gemm (encoder.py:95-104,
+ * 163-167,183-184,438,445; kn_util/nn_utils/layers/mlp.py:17-23).
+ *   layout 0 (NT): C[M,N] = A[M,K] . B[N,K]^T  A planes [M][2K], B planes [N][2K]          (forward; dgrad on W^T planes)
+ *   layout 2 (TN): C[M,N] = A[K,M]^T . B[K,N]  A planes [K][2M], B planes [K][2N], split-K  (weight gradients)
+ * Output: fp32 C (unless write_c == 0) and/or P32 planes c_planes with the scale found in c_hdr[0]; the partial maxima
+ * of |C| and the overflow flag are folded into c_hdr (caller zeroes slots and flag, sets the scale).  Epilogue as
+ * segmm_gemm.  K % 32 == 0. */
+#define SEGMM_SITE_HDR 8
+int segmm_gemm_p(int layout, int M, int N, int K, const uint16_t* a_planes, int lda2, const float* a_hdr, const float* a_f32, int ldaf,
+                 const uint16_t* b_planes, int ldb2, const float* b_hdr, const float* b_f32, int ldbf, float* C, int ldc,
+                 uint16_t* c_planes, int ldc2, float* c_hdr, int write_c, const float* bias, const float* row_scale,
+                 const float* residual, int ldr, int res_period, int activation, float* aux, int ldaux, float drop_p,
+                 uint64_t seed, uint32_t site, int splits, float* workspace, int accumulate, segmm_stream_t stream);
+/* fp32 [rows, cols] (row stride ld) -> P32 planes.  mode 0: exact scale from the header's partial maxima (complete when
+ * this runs), written to hdr[0], flag cleared.  mode 1: scale = hdr[0] as given; maxima and flag folded into hdr. */
+int segmm_split_p32(const float* x, int64_t rows, int cols, int ld, uint16_t* planes, int ld2, float* hdr, int mode,
+                    segmm_stream_t stream);
+/* P32 planes of the transpose of x[R, C]: plane row c holds x[:, c] (R % 32 == 0), scale hdr[0]. */
+int segmm_split_p32_transpose(const float* x, int R, int C, int ld, uint16_t* planes, int ld2, const float* hdr,
+                              segmm_stream_t stream);
 /* Producer side of those partial maxima.  segmm_gemm_h (c_amax), segmm_layernorm_fwd/bwd (amax), segmm_attn_fwd
  * (amax_o) and segmm_attn_bwd (amax_q / amax_ka / amax_kb) take OPTIONAL arrays of SEGMM_AMAX_SLOTS floats that
  * the CALLER HAS ZEROED; each wave folds the maximum of what it stored into one slot with an integer atomic max on

@@ -11,6 +11,7 @@
 #include "evalops.h"
 #include "gemm.h"
 #include "gemm_split.h"
+#include "gemm_planes.h"
 #include "loss.h"
 #include "rowops.h"
 
@@ -182,7 +183,7 @@ __global__ void dropout_mult_kernel(float* out, long long n, DropCfg d) {
 extern "C" {
 
 const char* segmm_last_error(void) { return g_segmm_err; }
-int segmm_abi_version(void) { return 9; }
+int segmm_abi_version(void) { return 10; }
 
 int segmm_l1norm(const float* x, float* y, float* inv_scale, int64_t rows, int D, float* amax, segmm_stream_t stream) {
     SEGMM_REQUIRE(x && (y || inv_scale), "l1norm: null pointer");
@@ -359,6 +360,86 @@ int segmm_gemm_h(int layout, int M, int N, int K, const float* A, int lda, const
     return gemm_impl(layout, M, N, K, A, lda, B, ldb, C, ldc, bias, row_scale, residual, ldr, res_period, activation, aux, ldaux,
                      drop_p, seed, site, splits, workspace, accumulate, 2, a_planes, a_pstride, b_planes, b_pstride, 2,
                      a_amax, a_namax, b_amax, b_namax, c_amax, stream);
+}
+
+/* ---- plane-operand GEMM (gemm_planes.h) */
+int segmm_gemm_p(int layout, int M, int N, int K, const uint16_t* a_planes, int lda2, const float* a_hdr, const float* a_f32, int ldaf,
+                 const uint16_t* b_planes, int ldb2, const float* b_hdr, const float* b_f32, int ldbf, float* C, int ldc,
+                 uint16_t* c_planes, int ldc2, float* c_hdr, int write_c, const float* bias, const float* row_scale,
+                 const float* residual, int ldr, int res_period, int activation, float* aux, int ldaux, float drop_p,
+                 uint64_t seed, uint32_t site, int splits, float* workspace, int accumulate, segmm_stream_t stream) {
+    SEGMM_REQUIRE(layout == 0 || layout == 2, "gemm_p: layout %d (0 = NT, 2 = TN)", layout);
+    SEGMM_REQUIRE(a_planes && b_planes && a_hdr && b_hdr, "gemm_p: null plane operand / header");
+    SEGMM_REQUIRE(C || (c_planes && !write_c), "gemm_p: no output");
+    if (M <= 0 || N <= 0) return 0;
+    SEGMM_REQUIRE(K > 0 && K % 32 == 0, "gemm_p: K %% 32 != 0 (K=%d)", K);
+    SEGMM_REQUIRE(N % 4 == 0 && (!C || (ldc % 4 == 0 && aligned16(C))), "gemm_p: N/ldc %% 4, alignment");
+    SEGMM_REQUIRE(lda2 % 64 == 0 && ldb2 % 64 == 0 && aligned16(a_planes) && aligned16(b_planes), "gemm_p: plane strides %% 64 halves / alignment");
+    SEGMM_REQUIRE(!c_planes || (c_hdr && ldc2 % 64 == 0 && N % 32 == 0 && aligned16(c_planes)), "gemm_p: plane output needs a header, N %% 32, ldc2 %% 64");
+    SEGMM_REQUIRE(!a_f32 || (aligned16(a_f32) && ldaf % 4 == 0), "gemm_p: fp32 copy of A alignment");
+    SEGMM_REQUIRE(!b_f32 || (aligned16(b_f32) && ldbf % 4 == 0), "gemm_p: fp32 copy of B alignment");
+    SEGMM_REQUIRE(!bias || aligned16(bias), "gemm_p: bias alignment");
+    SEGMM_REQUIRE(!residual || (aligned16(residual) && ldr % 4 == 0 && res_period > 0), "gemm_p: residual alignment/period");
+    SEGMM_REQUIRE(activation >= 0 && activation <= 4, "gemm_p: activation %d", activation);
+    SEGMM_REQUIRE(activation == 0 || activation == EPI_RELU || (aux && aligned16(aux) && ldaux % 4 == 0), "gemm_p: activation needs aux");
+    SEGMM_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "gemm_p: dropout p=%f", drop_p);
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.M = M; g.N = N; g.K = K;
+    g.bias = bias; g.row_scale = row_scale;
+    g.residual = residual; g.ldr = ldr; g.res_period = res_period > 0 ? res_period : 1;
+    g.aux = aux; g.ldaux = ldaux; g.epi = activation;
+    g.drop = make_drop(drop_p, seed, site);
+    g.amax_out = nullptr;
+    g.C = C; g.ldc = ldc;
+    PGemmX q;
+    memset(&q, 0, sizeof(q));
+    q.A.p = (const _Float16*)a_planes; q.A.ld2 = lda2; q.A.hdr = a_hdr; q.A.f32 = a_f32; q.A.ldf = ldaf;
+    q.B.p = (const _Float16*)b_planes; q.B.ld2 = ldb2; q.B.hdr = b_hdr; q.B.f32 = b_f32; q.B.ldf = ldbf;
+    q.Cp = (_Float16*)c_planes; q.ldc2 = ldc2; q.c_hdr = c_hdr; q.write_c = C ? (write_c != 0) : 0;
+    static const int pl_flags = getenv("SEGMM_PL_FLAGS") ? atoi(getenv("SEGMM_PL_FLAGS")) : 0;
+    q.dbg = pl_flags;
+    hipStream_t s = (hipStream_t)stream;
+    if (splits < 1) splits = 1;
+    if (layout == 0) {
+        SEGMM_REQUIRE(splits == 1, "gemm_p: the NT form has no split-K");
+        const size_t a_ext = ((size_t)(M - 1) * lda2 + 2 * (size_t)K) * 2, b_ext = ((size_t)(N - 1) * ldb2 + 2 * (size_t)K) * 2;
+        SEGMM_REQUIRE(a_ext < (1ull << 32) && b_ext < (1ull << 32), "gemm_p: operand view above the 4 GiB buffer window");
+        q.A.bytes = (uint32_t)a_ext; q.B.bytes = (uint32_t)b_ext;
+        if (accumulate) {
+            SEGMM_REQUIRE(!residual && C, "gemm_p: accumulate and residual are exclusive");
+            g.residual = C; g.ldr = ldc; g.res_period = M;
+        }
+        g.nbm = (M + PBM - 1) / PBM; g.nbn = (N + PBN - 1) / PBN;
+        static const int pl_var = getenv("SEGMM_PL_VAR") ? atoi(getenv("SEGMM_PL_VAR")) : 1;
+        if (pl_var == 0) hipLaunchKernelGGL(gemm_pl_nt<0>, dim3(g.nbm * g.nbn), dim3(512), 0, s, g, q);
+        else hipLaunchKernelGGL(gemm_pl_nt<1>, dim3(g.nbm * g.nbn), dim3(512), 0, s, g, q);
+        LAUNCH_CHECK();
+        return 0;
+    }
+    return segmm_fail(-1, "gemm_p: TN form not built yet");
+}
+
+int segmm_split_p32(const float* x, int64_t rows, int cols, int ld, uint16_t* planes, int ld2, float* hdr, int mode, segmm_stream_t stream) {
+    SEGMM_REQUIRE(x && planes && hdr && rows >= 0 && cols > 0 && cols % 32 == 0 && ld % 4 == 0 && ld >= cols && ld2 % 64 == 0 && ld2 >= 2 * cols
+                  && aligned16(x) && aligned16(planes), "split_p32: cols %% 32, ld %% 4, ld2 %% 64, alignment");
+    SEGMM_REQUIRE(mode == 0 || mode == 1, "split_p32: mode %d", mode);
+    if (rows == 0) return 0;
+    const long long n4 = rows * (cols / 4);
+    int blocks = (int)((n4 + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(split_p32_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (long long)rows, cols, ld, (_Float16*)planes, ld2, hdr, mode);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int segmm_split_p32_transpose(const float* x, int R, int Cc, int ld, uint16_t* planes, int ld2, const float* hdr, segmm_stream_t stream) {
+    SEGMM_REQUIRE(x && planes && hdr && R > 0 && Cc > 0 && R % 32 == 0 && ld >= Cc && ld2 % 64 == 0 && ld2 >= 2 * R && aligned16(planes),
+                  "split_p32_transpose: R %% 32, ld2 %% 64, alignment");
+    hipLaunchKernelGGL(split_p32_transpose_kernel, dim3((Cc + 31) / 32, (R + 31) / 32), dim3(256), 0, (hipStream_t)stream, x, R, Cc, ld,
+                       (_Float16*)planes, ld2, hdr);
+    LAUNCH_CHECK();
+    return 0;
 }
 
 int segmm_absmax(const float* x, int64_t rows, int cols, int ld, float* out, int nparts, segmm_stream_t stream) {

@@ -111,6 +111,18 @@ __device__ __forceinline__ void amax_commit(float* slots, float m, unsigned key)
     m = wave_max(m);
     if ((threadIdx.x & 63) == 0) atomicMax((unsigned int*)slots + (key & (AMAX_SLOTS - 1)), __float_as_uint(m));
 }
+// ---- "site header" of a plane tensor (gemm_planes.h): SITE_HDR floats followed by the AMAX_SLOTS partial maxima.
+// hdr[0] = power-of-two scale the fp16 (hi, lo) planes were written with (0: no planes written), hdr[1] (as an
+// integer) != 0: some element left the fp16 range under that scale -> consumers take the fp32 copy instead.
+constexpr int SITE_HDR = 8;
+constexpr int SITE_FLOATS = SITE_HDR + AMAX_SLOTS;
+__device__ __forceinline__ void site_commit(float* hdr, float m, unsigned key, float s_used) {
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax((unsigned int*)hdr + SITE_HDR + (key & (AMAX_SLOTS - 1)), __float_as_uint(m));
+        if (s_used > 0.f && !(m * s_used < 65504.f)) ((volatile unsigned int*)hdr)[1] = 1u;      // NaN raises it too
+    }
+}
 // inclusive prefix sum across the 64 lanes
 __device__ __forceinline__ float wave_scan_incl(float v, int lane) {
 #pragma unroll

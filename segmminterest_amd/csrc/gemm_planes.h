@@ -1,0 +1,385 @@
+// fp32-accurate GEMM on the fp16 matrix cores with operands that arrive PRE-SPLIT ("plane" operands).
+//
+// Same arithmetic as the fp16x3 engine of gemm_split.h -- x * s = hi + lo in two fp16 terms, s a per-tensor power of
+// two, three exact partial products hh + hl + lh on v_mfma_f32_32x32x16_f16 accumulated in fp32, result scaled back
+// by the exact 1/(sa sb) -- but the split is NOT done in the main loop any more: every producer of a GEMM operand
+// (LayerNorm, GEMM epilogue, attention, the L1 normalisation, the per-step weight split) writes the two fp16 terms
+// itself, and this kernel moves them global -> LDS with LDS-DMA (buffer_load ... lds, no VGPR round trip, no VALU).
+//
+// P32 plane format of a matrix X[R][C] (C % 32 == 0): one fp16 array, per row and per block of 32 columns
+// [32 hi | 32 lo] = 128 contiguous bytes -- element (r, c): hi at r * ld2 + (c >> 5) * 64 + (c & 31), lo 32 further.
+// A k-tile of 32 of one row is therefore ONE 128-byte line holding both terms (the NT form), and a row of 256 features
+// one contiguous KB (the TN form).  Column slices of fused buffers stay contiguous slices (offsets are multiples of 32).
+//
+// Site header (hdr, SITE_HDR floats followed by AMAX_SLOTS partial maxima; common.h): hdr[0] = the scale s the planes
+// were written with, hdr[1] != 0 = some element left the fp16 range under that scale (delayed scaling: s comes from an
+// earlier step) -- or hdr[0] == 0: no planes were written at all (first use of a tensor site).  In both cases the
+// kernel takes the operand from its fp32 copy instead and splits it on the fly with the exact scale of the partial
+// maxima (slow path, staged through registers; results identical in accuracy, never silently wrong).
+//
+// NT kernel: 256 x 256 x 32 tile, 512 threads = 8 waves as 2 (m) x 4 (n), 128 x 64 per wave = 4 x 2 MFMA tiles x 3
+// products, 128 accumulator registers; two 64 KB LDS stages (A 256 rows x 128 B, B 256 rows x 128 B); one barrier per
+// k-tile.  LDS rows are 128 B = 8 chunks of 16 B; chunk c of row r sits at physical chunk c ^ ((r >> 1) & 7) -- the
+// ds_read_b128 fragment reads (16 distinct rows per lane group, same logical chunk) are conflict-free; because LDS-DMA
+// writes lane-linear, the permutation is applied to each lane's SOURCE address.
+#pragma once
+#include "gemm_split.h"
+
+namespace segmm {
+
+struct PlaneOperand {
+    const _Float16* p; int ld2;        // P32 planes, row stride in fp16 elements
+    uint32_t bytes;                    // extent of the plane view (buffer range check)
+    const float* hdr;                  // site header (scale, overflow flag, partial maxima)
+    const float* f32; int ldf;         // fp32 copy for the slow path (may be null: the planes are then trusted)
+};
+struct PGemmX {
+    PlaneOperand A, B;
+    _Float16* Cp; int ldc2; float* c_hdr;      // optional plane output (scale = c_hdr[0]) ; amax / flag folded into c_hdr
+    int write_c;                               // 0: the fp32 C is not stored (planes only)
+    int dbg;                                   // timing ablations (SEGMM_PL_FLAGS; results are wrong when set): 1 no C stores, 2 no epilogue
+};
+
+constexpr int PBM = 256, PBN = 256, PBK = 32;
+constexpr int PSTAGE = (PBM + PBN) * 128;      // bytes per stage
+
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t r, void* lds_wave_base, uint32_t voff, uint32_t soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, (int)soff, 0, 0);
+}
+__device__ __forceinline__ void dma_wait_barrier() {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+// exact scale of a site from its partial maxima (slow path only): every thread of the block gets the same value
+__device__ __forceinline__ float site_exact_scale(const float* hdr, float* red, int tid, int nthreads) {
+    float m = 0.f;
+    for (int i = tid; i < AMAX_SLOTS; i += nthreads) m = fmaxf(m, hdr[SITE_HDR + i]);
+    m = wave_max(m);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    float r = 0.f;
+    for (int i = 0; i < (nthreads >> 6); ++i) r = fmaxf(r, red[i]);
+    __syncthreads();
+    return f16_scale_of(r);
+}
+
+// ---- shared epilogue.  A wave owns a [32 i] x [32 j] grid of accumulator tiles; it moves one 32-row strip of NJ tiles
+// (32 x 32 NJ floats) at a time through its own LDS patch [32][32 NJ] (256-byte rows for NJ = 2: the ds_write_b32 of the
+// accumulator layout and the ds_read_b128 of the row layout are both conflict-free) and then walks the strip in a ROLLED
+// loop: the element-wise epilogue is emitted once, not once per tile (the unrolled form was 24 k instructions and spent
+// 24 us per 256 x 256 tile missing the instruction cache).
+template <int NJ>
+__device__ __forceinline__ void epi_strip_write(const f32x16 (&c)[NJ], float* Cs, int lane) {
+    const int li = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Cs[((r & 3) + 8 * (r >> 2) + 4 * lh) * (32 * NJ) + j * 32 + li] = c[j][r];
+}
+template <bool SPLITK, int NJ>
+__device__ __forceinline__ void epi_strip_emit(const GemmArgs& p, const PGemmX& q, const float* Cs, int lane, int gm0, int gn0,
+                                               float inv_ab, float c_scale, float* Cout, float& am) {
+    constexpr int LPR = 8 * NJ;                    // lanes per row (float4 each)
+    constexpr int RPI = 64 / LPR;                  // rows per iteration
+    const int c4 = (lane % LPR) << 2, r0 = lane / LPR;
+    const int gn = gn0 + c4;
+    const bool col_ok = gn < p.N;
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (!SPLITK && p.bias && col_ok) bias4 = *(const f32x4*)(p.bias + gn);
+#pragma unroll 2
+    for (int it = 0; it < 32 / RPI; ++it) {
+        const int row = it * RPI + r0;
+        const int gm = gm0 + row;
+        if (gm < p.M && col_ok) {
+            f32x4 v = *(const f32x4*)(Cs + row * (32 * NJ) + c4);
+            v = v * inv_ab;
+            if (!SPLITK) {
+                if (p.row_scale) v *= p.row_scale[gm];
+                v += bias4;
+                if (p.epi == EPI_GELU) {
+                    *(f32x4*)(p.aux + (size_t)gm * p.ldaux + gn) = v;
+                    v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
+                } else if (p.epi == EPI_DGELU) {
+                    const f32x4 g = *(const f32x4*)(p.aux + (size_t)gm * p.ldaux + gn);
+                    v.x *= gelu_erf_grad(g.x); v.y *= gelu_erf_grad(g.y);
+                    v.z *= gelu_erf_grad(g.z); v.w *= gelu_erf_grad(g.w);
+                } else if (p.epi == EPI_RELU) {
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                } else if (p.epi == EPI_DRELU) {
+                    const f32x4 g = *(const f32x4*)(p.aux + (size_t)gm * p.ldaux + gn);
+                    v.x = g.x > 0.f ? v.x : 0.f; v.y = g.y > 0.f ? v.y : 0.f;
+                    v.z = g.z > 0.f ? v.z : 0.f; v.w = g.w > 0.f ? v.w : 0.f;
+                }
+                if (p.drop.p > 0.f) v = drop_apply4(p.drop, ((uint64_t)gm * (uint64_t)p.N + gn) >> 2, v);
+                if (p.residual) {
+                    const int rr = p.res_period >= p.M ? gm : gm % p.res_period;
+                    v += *(const f32x4*)(p.residual + (size_t)rr * p.ldr + gn);
+                }
+            }
+            if ((SPLITK || q.write_c) && !(q.dbg & 1)) *(f32x4*)(Cout + (size_t)gm * p.ldc + gn) = v;
+            if (!SPLITK) {
+                am = absmax4(am, v);
+                if (q.Cp) {
+                    uint32_t h0, l0, h1, l1;
+                    splith_pair(v.x, v.y, c_scale, h0, l0);
+                    splith_pair(v.z, v.w, c_scale, h1, l1);
+                    _Float16* o = q.Cp + (size_t)gm * q.ldc2 + ((gn >> 5) << 6) + (gn & 31);
+                    *(uint2*)o = make_uint2(h0, h1);
+                    *(uint2*)(o + 32) = make_uint2(l0, l1);
+                }
+            }
+        }
+    }
+}
+
+// =============================================================================== NT: C[M,N] = A[M,K] . B[N,K]^T
+// VAR 0: the next k-tile's LDS-DMA is issued in front of the MFMA block; VAR 1: one DMA piece between every six MFMAs
+template <int VAR>
+__global__ __launch_bounds__(512, 2) void gemm_pl_nt(const GemmArgs p, const PGemmX q) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * PSTAGE];      // 128 KB: two stages x (A 32 KB | B 32 KB)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int li = lane & 31, lh = lane >> 5;
+    const int lb = xcd_remap(blockIdx.x, p.nbm * p.nbn);
+    const int m0 = (lb / p.nbn) * PBM, n0 = (lb % p.nbn) * PBN;
+    const int nkt = p.K >> 5;
+
+    // ---- operand state: planes usable?  (block-uniform)
+    const float sa_hdr = q.A.hdr[0], sb = q.B.hdr[0];
+    const bool slowA = q.A.f32 != nullptr && (!(sa_hdr > 0.f) || __float_as_uint(q.A.hdr[1]) != 0u);
+    float sa = sa_hdr;
+    if (slowA) sa = site_exact_scale(q.A.hdr, (float*)smem, tid, 512);
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- LDS-DMA addressing: a wave-instruction moves 8 rows x 128 B; wave w, piece i covers tile rows (4 w + i) * 8 .. + 7
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(q.A.p, q.A.bytes), rsB = make_rsrc(q.B.p, q.B.bytes);
+    uint32_t voa[4], vob[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);                    // logical chunk that lands in this lane's physical slot
+        voa[i] = (uint32_t)min(m0 + row, p.M - 1) * (uint32_t)q.A.ld2 * 2u + (uint32_t)c * 16u;
+        vob[i] = (uint32_t)min(n0 + row, p.N - 1) * (uint32_t)q.B.ld2 * 2u + (uint32_t)c * 16u;
+    }
+    auto dmaB = [&](int kt, char* st) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) lds_dma16(rsB, st + PBM * 128 + (wave * 4 + i) * 1024, vob[i], (uint32_t)kt * 128u);
+    };
+    auto dmaA = [&](int kt, char* st) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) lds_dma16(rsA, st + (wave * 4 + i) * 1024, voa[i], (uint32_t)kt * 128u);
+    };
+    // slow path for A: fp32 copy -> exact split -> the same LDS image (thread: 2 jobs of 8 consecutive k)
+    auto slow_stage_A = [&](int kt, char* st) {
+#pragma unroll 1
+        for (int jj = 0; jj < 2; ++jj) {
+            const int j = tid + 512 * jj;
+            const int row = j >> 2, kc = j & 3;
+            const float* src = q.A.f32 + (size_t)min(m0 + row, p.M - 1) * q.A.ldf + kt * 32 + kc * 8;
+            const f32x4 x0 = *(const f32x4*)src, x1 = *(const f32x4*)(src + 4);
+            uint32_t h0, l0, h1, l1, h2, l2, h3, l3;
+            splith_pair(x0.x, x0.y, sa, h0, l0); splith_pair(x0.z, x0.w, sa, h1, l1);
+            splith_pair(x1.x, x1.y, sa, h2, l2); splith_pair(x1.z, x1.w, sa, h3, l3);
+            const int sw = (row >> 1) & 7;
+            *(uint4*)(st + row * 128 + ((kc ^ sw) << 4)) = make_uint4(h0, h1, h2, h3);
+            *(uint4*)(st + row * 128 + (((4 + kc) ^ sw) << 4)) = make_uint4(l0, l1, l2, l3);
+        }
+    };
+    auto stage = [&](int kt, char* st) {
+        if (slowA) slow_stage_A(kt, st); else dmaA(kt, st);
+        dmaB(kt, st);
+    };
+
+    // ---- fragment read addressing: lane (li, lh); logical chunk 4 p + 2 s + lh; physical = logical ^ ((li >> 1) & 7)
+    const int swz = (li >> 1) & 7;
+    uint32_t fa[2][2], fb[2][2];          // [plane][k16 step] byte offsets inside a stage (row block 0)
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int ch = ((4 * pl + 2 * s + lh) ^ swz) << 4;
+            fa[pl][s] = (uint32_t)((wm * 128 + li) * 128 + ch);
+            fb[pl][s] = (uint32_t)(PBM * 128 + (wn * 64 + li) * 128 + ch);
+        }
+
+    auto compute = [&](const char* st) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            f32x4 bh[2], bl[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                bh[j] = *(const f32x4*)(st + fb[0][s] + j * 4096);
+                bl[j] = *(const f32x4*)(st + fb[1][s] + j * 4096);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 ah = *(const f32x4*)(st + fa[0][s] + i * 4096);
+                const f32x4 al = *(const f32x4*)(st + fa[1][s] + i * 4096);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    f32x16 c = acc[i][j];
+                    c = mfma_x<true>(al, bh[j], c);
+                    c = mfma_x<true>(ah, bl[j], c);
+                    c = mfma_x<true>(ah, bh[j], c);
+                    acc[i][j] = c;
+                }
+            }
+        }
+    };
+
+    // compute with the DMA of k-tile kt_next woven in: piece g (4 of A, 4 of B) goes out after the fragment reads of MFMA group g
+    auto compute_dma = [&](const char* st, char* nx, int kt_next) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            f32x4 bh[2], bl[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                bh[j] = *(const f32x4*)(st + fb[0][s] + j * 4096);
+                bl[j] = *(const f32x4*)(st + fb[1][s] + j * 4096);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 ah = *(const f32x4*)(st + fa[0][s] + i * 4096);
+                const f32x4 al = *(const f32x4*)(st + fa[1][s] + i * 4096);
+                if (!(q.dbg & 4)) {
+                    if (s == 0) lds_dma16(rsA, nx + (wave * 4 + i) * 1024, voa[i], (uint32_t)kt_next * 128u);
+                    else lds_dma16(rsB, nx + PBM * 128 + (wave * 4 + i) * 1024, vob[i], (uint32_t)kt_next * 128u);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    f32x16 c = acc[i][j];
+                    c = mfma_x<true>(al, bh[j], c);
+                    c = mfma_x<true>(ah, bl[j], c);
+                    c = mfma_x<true>(ah, bh[j], c);
+                    acc[i][j] = c;
+                }
+            }
+        }
+    };
+
+    stage(0, smem);
+    dma_wait_barrier();
+    if (VAR == 1 && !slowA) {
+        for (int kt = 0; kt < nkt - 1; ++kt) {
+            char* cur = smem + (kt & 1) * PSTAGE;
+            char* nxt = smem + ((kt + 1) & 1) * PSTAGE;
+            compute_dma(cur, nxt, kt + 1);
+            dma_wait_barrier();
+        }
+        compute(smem + ((nkt - 1) & 1) * PSTAGE);
+        dma_wait_barrier();
+    } else {
+        for (int kt = 0; kt < nkt; ++kt) {
+            char* cur = smem + (kt & 1) * PSTAGE;
+            char* nxt = smem + ((kt + 1) & 1) * PSTAGE;
+            if (kt + 1 < nkt) stage(kt + 1, nxt);
+#if SEGMM_GEMM_SETPRIO
+            __builtin_amdgcn_s_setprio(SEGMM_GEMM_SETPRIO);
+#endif
+            compute(cur);
+#if SEGMM_GEMM_SETPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
+            dma_wait_barrier();
+        }
+    }
+
+    // ---- epilogue (all stages are free: the loop ended with a barrier)
+    float* Cs = (float*)smem + wave * (32 * 64);          // 8 KB per wave
+    const float inv_ab = (1.f / sa) * (1.f / sb);          // exact powers of two
+    const float c_scale = q.Cp ? q.c_hdr[0] : 1.f;
+    float am = 0.f;
+    if (q.dbg & 2) {
+        float t = 0.f;          // keeps every accumulator alive (no dead-code elimination of MFMAs)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+        if (t == 1.2345f) p.C[0] = 1.f;
+        return;
+    }
+#pragma unroll 1
+    for (int i = 0; i < 4; ++i) {
+        f32x16 c[2];
+        switch (i) {
+            case 0: c[0] = acc[0][0]; c[1] = acc[0][1]; break;
+            case 1: c[0] = acc[1][0]; c[1] = acc[1][1]; break;
+            case 2: c[0] = acc[2][0]; c[1] = acc[2][1]; break;
+            default: c[0] = acc[3][0]; c[1] = acc[3][1]; break;
+        }
+        epi_strip_write<2>(c, Cs, lane);
+        epi_strip_emit<false, 2>(p, q, Cs, lane, m0 + wm * 128 + i * 32, n0 + wn * 64, inv_ab, c_scale, p.C, am);
+    }
+    if (q.c_hdr) site_commit(q.c_hdr, am, blockIdx.x * 8 + wave, q.Cp ? c_scale : 0.f);
+    else if (p.amax_out) amax_commit(p.amax_out, am, blockIdx.x * 8 + wave);
+}
+
+// =============================================================================== fp32 -> P32 planes (stand-alone pass)
+// mode 0: the site's partial maxima are complete (producer or segmm_absmax): s = exact scale, written to hdr[0], flag cleared.
+// mode 1: s = hdr[0] as it stands (delayed scale); partial maxima and the overflow flag are folded into hdr.
+__global__ __launch_bounds__(256) void split_p32_kernel(const float* __restrict__ x, long long rows, int cols, int ld,
+                                                        _Float16* __restrict__ planes, int ld2, float* hdr, int mode) {
+    __shared__ float red[8];
+    float s;
+    if (mode == 0) s = site_exact_scale(hdr, red, threadIdx.x, 256);
+    else s = hdr[0];
+    const int c4n = cols >> 2;
+    const long long n4 = rows * c4n;
+    float am = 0.f;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / c4n;
+        const int c = (int)(i - r * c4n) << 2;
+        const f32x4 v = *(const f32x4*)(x + r * ld + c);
+        uint32_t h0, l0, h1, l1;
+        splith_pair(v.x, v.y, s, h0, l0);
+        splith_pair(v.z, v.w, s, h1, l1);
+        _Float16* o = planes + r * ld2 + ((c >> 5) << 6) + (c & 31);
+        *(uint2*)o = make_uint2(h0, h1);
+        *(uint2*)(o + 32) = make_uint2(l0, l1);
+        am = absmax4(am, v);
+    }
+    if (mode == 0) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) { hdr[0] = s; hdr[1] = 0.f; }
+    } else {
+        site_commit(hdr, am, blockIdx.x * 4 + (threadIdx.x >> 6), s);
+    }
+}
+// planes of the TRANSPOSE: out row c (of Cc), column r (of R) = x[r * ld + c]; P32 over the R axis (R % 32 == 0)
+__global__ __launch_bounds__(256) void split_p32_transpose_kernel(const float* __restrict__ x, int R, int Cc, int ld,
+                                                                  _Float16* __restrict__ planes, int ld2, const float* hdr) {
+    __shared__ float tile[32][33];
+    const float s = hdr[0];
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + ty + 8 * k, c = c0 + tx;
+        tile[ty + 8 * k][tx] = (r < R && c < Cc) ? x[(size_t)r * ld + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + ty + 8 * k, r = r0 + tx;
+        if (c < Cc && r < R) {
+            const float v = tile[tx][ty + 8 * k];
+            const _Float16 h = (_Float16)(v * s);
+            const _Float16 l = (_Float16)__builtin_fmaf(v, s, -(float)h);
+            _Float16* o = planes + (size_t)c * ld2 + ((r >> 5) << 6) + (r & 31);
+            o[0] = h; o[32] = l;
+        }
+    }
+}
+
+}  // namespace segmm

@@ -15,7 +15,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SEGMM_LIB") or os.path.join(_HERE, "libsegmm_hip.so")      # SEGMM_LIB: A/B builds of the kernels
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _lib = None
 
@@ -29,6 +29,10 @@ SIGNATURES = {
                      _p, _i64, _p, _i64, _i, _p],
     "segmm_gemm_h": [_i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _p, _i, _f, _u64, _u32, _i, _p, _i,
                      _p, _i64, _p, _i64, _p, _i, _p, _i, _p, _p],
+    "segmm_gemm_p": [_i, _i, _i, _i, _p, _i, _p, _p, _i, _p, _i, _p, _p, _i, _p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _p, _i, _f, _u64,
+                     _u32, _i, _p, _i, _p],
+    "segmm_split_p32": [_p, _i64, _i, _i, _p, _i, _p, _i, _p],
+    "segmm_split_p32_transpose": [_p, _i, _i, _i, _p, _i, _p, _p],
     "segmm_absmax": [_p, _i64, _i, _i, _p, _i, _p],
     "segmm_split2h": [_p, _p, _i64, _i64, _p, _i, _p],
     "segmm_split2h_transpose": [_p, _i, _i, _i, _p, _i64, _p, _i, _p],
@@ -189,6 +193,79 @@ def gemm(layout, M, N, K, A, lda, B, ldb, Cout, ldc, bias=None, row_scale=None, 
                                   res_period, activation, _ptr(aux), ldaux, float(drop_p), int(seed), int(site),
                                   int(splits), _ptr(workspace), int(bool(accumulate)), ap, aps, bp, bps, int(nplanes),
                                   _stream()), "segmm_gemm_x")
+    if prof is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        prof.append((layout, M, N, K, e0, e1))
+
+
+SITE_HDR = 8                                  # floats in front of the partial maxima of a plane tensor's site header
+SITE_FLOATS = SITE_HDR + AMAX_SLOTS
+
+
+class PT:
+    """A GEMM operand as its producer leaves it: P32 fp16 planes (``planes`` [rows, 2 * cols] halves, or a wider buffer
+    with ``p_off`` / ``ld2`` selecting a column slice), the site header ``hdr`` ([SITE_FLOATS] floats: scale, overflow flag,
+    partial maxima) and -- optionally -- the fp32 copy ``f32`` (``f_off`` / ``ldf``) that consumers fall back to."""
+    __slots__ = ("planes", "p_off", "ld2", "hdr", "f32", "f_off", "ldf", "rows", "cols")
+
+    def __init__(self, planes, hdr, rows, cols, ld2=None, p_off=0, f32=None, ldf=None, f_off=0):
+        self.planes, self.hdr, self.rows, self.cols = planes, hdr, rows, cols
+        self.ld2 = 2 * cols if ld2 is None else ld2
+        self.p_off = p_off
+        self.f32, self.ldf, self.f_off = f32, (cols if ldf is None else ldf), f_off
+
+    def cols_slice(self, c0, ncols):
+        """Columns [c0, c0 + ncols) of the same rows (c0, ncols multiples of 32)."""
+        return PT(self.planes, self.hdr, self.rows, ncols, self.ld2, self.p_off + 2 * c0, self.f32, self.ldf, self.f_off + c0)
+
+    def pptr(self):
+        return self.planes.data_ptr() + 2 * self.p_off
+
+    def fptr(self):
+        return None if self.f32 is None else self.f32.data_ptr() + 4 * self.f_off
+
+
+def new_site(device, n=1):
+    """Zeroed site headers [n, SITE_FLOATS]."""
+    return torch.zeros((n, SITE_FLOATS), dtype=torch.float32, device=device)
+
+
+def split_p32(x, rows, cols, ld, planes, ld2, hdr, mode=0, x_off=0, p_off=0):
+    """fp32 view -> P32 planes; mode 0: exact scale from the header's (complete) partial maxima; 1: scale hdr[0] as given."""
+    _check(lib().segmm_split_p32(x.data_ptr() + 4 * x_off, rows, cols, ld, planes.data_ptr() + 2 * p_off, ld2, hdr.data_ptr(), int(mode),
+                                 _stream()), "segmm_split_p32")
+
+
+def split_p32_transpose(x, R, Cc, ld, planes, ld2, hdr, x_off=0, p_off=0):
+    _check(lib().segmm_split_p32_transpose(x.data_ptr() + 4 * x_off, R, Cc, ld, planes.data_ptr() + 2 * p_off, ld2, hdr.data_ptr(),
+                                           _stream()), "segmm_split_p32_transpose")
+
+
+def to_planes(x, rows, cols, ld=None, x_off=0, keep_f32=True):
+    """Stand-alone adapter: absmax pass + exact split pass -> PT (tests, external inputs, first use of a site)."""
+    ld = cols if ld is None else ld
+    hdr = new_site(x.device)[0]
+    absmax(x, rows, cols, ld, off=x_off, out=hdr[SITE_HDR:])
+    planes = torch.empty((rows, 2 * cols), dtype=torch.float16, device=x.device)
+    split_p32(x, rows, cols, ld, planes, 2 * cols, hdr, mode=0, x_off=x_off)
+    return PT(planes, hdr, rows, cols, f32=x if keep_f32 else None, ldf=ld, f_off=x_off)
+
+
+def gemm_p(layout, M, N, K, A: "PT", B: "PT", Cout, ldc, c_pt: "PT" = None, write_c=True, bias=None, row_scale=None, residual=None,
+           ldr=0, res_period=0, activation=0, aux=None, ldaux=0, drop_p=0.0, seed=0, site=0, splits=1, workspace=None,
+           accumulate=False, c_off=0):
+    """Plane-operand GEMM (segmm_gemm_p).  ``c_pt``: optional plane output (its hdr[0] holds the scale to write with)."""
+    prof = GEMM_PROFILE
+    if prof is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _check(lib().segmm_gemm_p(layout, M, N, K, A.pptr(), A.ld2, A.hdr.data_ptr(), A.fptr(), A.ldf, B.pptr(), B.ld2, B.hdr.data_ptr(),
+                              B.fptr(), B.ldf, None if Cout is None else Cout.data_ptr() + 4 * c_off, ldc,
+                              None if c_pt is None else c_pt.pptr(), 0 if c_pt is None else c_pt.ld2,
+                              None if c_pt is None else c_pt.hdr.data_ptr(), int(bool(write_c)), _ptr(bias), _ptr(row_scale), _ptr(residual),
+                              ldr, res_period, activation, _ptr(aux), ldaux, float(drop_p), int(seed), int(site), int(splits),
+                              _ptr(workspace), int(bool(accumulate)), _stream()), "segmm_gemm_p")
     if prof is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
