@@ -417,7 +417,42 @@ int segmm_gemm_p(int layout, int M, int N, int K, const uint16_t* a_planes, int 
         LAUNCH_CHECK();
         return 0;
     }
-    return segmm_fail(-1, "gemm_p: TN form not built yet");
+    // TN: A planes [K][2M], B planes [K][2N]; split-K over blockIdx.z
+    SEGMM_REQUIRE(M % 32 == 0 && N % 32 == 0, "gemm_p TN: M, N %% 32 (M=%d N=%d)", M, N);
+    SEGMM_REQUIRE(!c_planes && !bias && !row_scale && activation == 0 && drop_p == 0.f, "gemm_p TN: no epilogue besides residual/accumulate");
+    {
+        const size_t a_ext = ((size_t)(K - 1) * lda2 + 2 * (size_t)M) * 2, b_ext = ((size_t)(K - 1) * ldb2 + 2 * (size_t)N) * 2;
+        SEGMM_REQUIRE(a_ext + 4096 < (1ull << 32) && b_ext + 4096 < (1ull << 32), "gemm_p: operand view above the 4 GiB buffer window");
+        q.A.bytes = (uint32_t)a_ext; q.B.bytes = (uint32_t)b_ext;
+    }
+    g.nbm = (M + PBM - 1) / PBM; g.nbn = (N + PBN - 1) / PBN;
+    const int ktiles = (K + 31) / 32;
+    if (splits > ktiles) splits = ktiles;
+    if (splits > 1) {
+        SEGMM_REQUIRE(workspace && aligned16(workspace), "gemm_p: split-K needs a workspace");
+        SEGMM_REQUIRE(!residual, "gemm_p: split-K supports no residual");
+        const int tps = (ktiles + splits - 1) / splits;
+        splits = (ktiles + tps - 1) / tps;
+        g.k_per_split = tps * 32;
+        g.C = workspace; g.ldc = N; g.slab_stride = (long long)M * N;
+    } else {
+        g.k_per_split = ktiles * 32;
+        g.slab_stride = 0;
+        if (accumulate) {
+            SEGMM_REQUIRE(!residual, "gemm_p: accumulate and residual are exclusive");
+            g.residual = C; g.ldr = ldc; g.res_period = M;
+        }
+    }
+    hipLaunchKernelGGL(gemm_pl_tn<0>, dim3(g.nbm * g.nbn, 1, splits), dim3(512), 0, s, g, q);
+    LAUNCH_CHECK();
+    if (splits > 1) {
+        const long long n4 = (long long)M * (N / 4);
+        int blocks = (int)((n4 + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_reduce, dim3(blocks), dim3(256), 0, s, (const float*)workspace, splits, (long long)M * N, C, ldc, M, N, accumulate);
+        LAUNCH_CHECK();
+    }
+    return 0;
 }
 
 int segmm_split_p32(const float* x, int64_t rows, int cols, int ld, uint16_t* planes, int ld2, float* hdr, int mode, segmm_stream_t stream) {

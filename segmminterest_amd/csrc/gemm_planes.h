@@ -326,6 +326,167 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_nt(const GemmArgs p, const PGe
     else if (p.amax_out) amax_commit(p.amax_out, am, blockIdx.x * 8 + wave);
 }
 
+// =============================================================================== TN: C[M,N] = A[K,M]^T . B[K,N]
+// Weight gradients: dW[n_out, n_in] = dY[tokens, n_out]^T . X[tokens, n_in]; the contraction runs over the token axis, the
+// SLOW axis of both operands.  A k-tile = 32 tokens x 256 features per operand; a token's 256 features are one contiguous
+// KB of P32 planes (8 blocks of [32 hi | 32 lo]) = one LDS-DMA wave-instruction.  MFMA fragments (8 consecutive tokens of
+// one feature per lane) come out of LDS through ds_read_b64_tr_b16 (hardware transpose: per 16-lane group a 4 token x 16
+// feature block, lane i receives feature i).  LDS row = 16 pieces of 64 B (piece = 2 * feature block + plane); piece c of
+// token t sits at physical piece c ^ (t & 3), so the four token rows of a transposed read fall into four different
+// 64-byte bank windows (conflict-free per 32-lane half); the permutation is applied to the DMA source address.
+// Split-K over blockIdx.z (partial slabs + splitk_reduce), 256 x 256 tile, 8 waves as 2 (m) x 4 (n).
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 lds_tr8(const char* a) {          // 8 tokens (two 4-token blocks, 4 KB apart) of this lane's feature
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a + 4096));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(f32x4, v);
+}
+
+template <int VAR>
+__global__ __launch_bounds__(512, 2) void gemm_pl_tn(const GemmArgs p, const PGemmX q) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * PSTAGE];      // two stages x (A: 32 tokens x 1 KB | B: 32 tokens x 1 KB)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int lb = xcd_remap(blockIdx.x, p.nbm * p.nbn);
+    const int m0 = (lb / p.nbn) * PBM, n0 = (lb % p.nbn) * PBN;
+    const int kbeg = blockIdx.z * p.k_per_split;
+    const int kend = min(p.K, kbeg + p.k_per_split);
+    const int nkt = (kend - kbeg + 31) >> 5;
+
+    const float sa_hdr = q.A.hdr[0], sb_hdr = q.B.hdr[0];
+    const bool slowA = q.A.f32 != nullptr && (!(sa_hdr > 0.f) || __float_as_uint(q.A.hdr[1]) != 0u);
+    const bool slowB = q.B.f32 != nullptr && (!(sb_hdr > 0.f) || __float_as_uint(q.B.hdr[1]) != 0u);
+    float sa = sa_hdr, sb = sb_hdr;
+    if (slowA) sa = site_exact_scale(q.A.hdr, (float*)smem, tid, 512);
+    if (slowB) sb = site_exact_scale(q.B.hdr, (float*)smem, tid, 512);
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- LDS-DMA: wave w, piece i = token row 4 w + i of the k-tile (1 KB); lane = physical 16-byte chunk of the row
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(q.A.p, q.A.bytes), rsB = make_rsrc(q.B.p, q.B.bytes);
+    uint32_t voa[4], vob[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int t = wave * 4 + i;
+        const uint32_t inrow = (uint32_t)((((lane >> 2) ^ (t & 3)) << 6) + ((lane & 3) << 4));
+        voa[i] = (uint32_t)t * (uint32_t)q.A.ld2 * 2u + (uint32_t)m0 * 4u + inrow;
+        vob[i] = (uint32_t)t * (uint32_t)q.B.ld2 * 2u + (uint32_t)n0 * 4u + inrow;
+    }
+    // slow path: fp32 [token][feature] -> exact split -> the same LDS image; a thread converts 8 consecutive features of one token
+    auto slow_stage = [&](const PlaneOperand& op, float sc, int k0, char* dst, int f0, int nfeat) {
+#pragma unroll 1
+        for (int jj = 0; jj < 2; ++jj) {
+            const int j = tid + 512 * jj;
+            const int t = j >> 5, f8 = j & 31;
+            const int gk = k0 + t, gf = f0 + f8 * 8;
+            f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = x0;
+            if (gk < kend && gf < nfeat) {
+                const float* src = op.f32 + (size_t)gk * op.ldf + gf;
+                x0 = *(const f32x4*)src;
+                x1 = *(const f32x4*)(src + 4);
+            }
+            uint32_t h0, l0, h1, l1, h2, l2, h3, l3;
+            splith_pair(x0.x, x0.y, sc, h0, l0); splith_pair(x0.z, x0.w, sc, h1, l1);
+            splith_pair(x1.x, x1.y, sc, h2, l2); splith_pair(x1.z, x1.w, sc, h3, l3);
+            const int b = f8 >> 2, cp = f8 & 3, sw = t & 3;
+            *(uint4*)(dst + t * 1024 + (((2 * b) ^ sw) << 6) + (cp << 4)) = make_uint4(h0, h1, h2, h3);
+            *(uint4*)(dst + t * 1024 + (((2 * b + 1) ^ sw) << 6) + (cp << 4)) = make_uint4(l0, l1, l2, l3);
+        }
+    };
+    auto stage = [&](int kt, char* st) {
+        const int k0 = kbeg + kt * 32;
+        if (slowA) slow_stage(q.A, sa, k0, st, m0, p.M);
+        else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) lds_dma16(rsA, st + (wave * 4 + i) * 1024, voa[i], (uint32_t)k0 * (uint32_t)q.A.ld2 * 2u);
+        }
+        if (slowB) slow_stage(q.B, sb, k0, st + 32768, n0, p.N);
+        else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) lds_dma16(rsB, st + 32768 + (wave * 4 + i) * 1024, vob[i], (uint32_t)k0 * (uint32_t)q.B.ld2 * 2u);
+        }
+    };
+
+    // ---- transposed fragment reads: lane = (g = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3) supplies token row qq of its
+    // group's 4 x 16 block, features 4 pp ..; group g covers features 16 (g & 1) .. and tokens 8 (g >> 1) ..
+    const int g = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
+    const uint32_t lane_base = (uint32_t)((8 * (g >> 1) + qq) * 1024 + (16 * (g & 1) + 4 * pp) * 2);
+    uint32_t fa[4], fb[4];          // [x = 2 (block & 1) + plane]
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        fa[x] = lane_base + (uint32_t)(8 * wm * 64) + (uint32_t)((x ^ qq) << 6);
+        fb[x] = lane_base + 32768u + (uint32_t)(4 * wn * 64) + (uint32_t)((x ^ qq) << 6);
+    }
+    auto compute = [&](const char* st) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            f32x4 bh[2], bl[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                bh[j] = lds_tr8(st + fb[2 * j] + s * 16384);
+                bl[j] = lds_tr8(st + fb[2 * j + 1] + s * 16384);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 ah = lds_tr8(st + fa[2 * (i & 1)] + (i >> 1) * 256 + s * 16384);
+                const f32x4 al = lds_tr8(st + fa[2 * (i & 1) + 1] + (i >> 1) * 256 + s * 16384);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    f32x16 c = acc[i][j];
+                    c = mfma_x<true>(al, bh[j], c);
+                    c = mfma_x<true>(ah, bl[j], c);
+                    c = mfma_x<true>(ah, bh[j], c);
+                    acc[i][j] = c;
+                }
+            }
+        }
+    };
+
+    stage(0, smem);
+    dma_wait_barrier();
+    for (int kt = 0; kt < nkt; ++kt) {
+        char* cur = smem + (kt & 1) * PSTAGE;
+        char* nxt = smem + ((kt + 1) & 1) * PSTAGE;
+        if (kt + 1 < nkt) stage(kt + 1, nxt);
+#if SEGMM_GEMM_SETPRIO
+        __builtin_amdgcn_s_setprio(SEGMM_GEMM_SETPRIO);
+#endif
+        compute(cur);
+#if SEGMM_GEMM_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+        dma_wait_barrier();
+    }
+
+    float* Cs = (float*)smem + wave * (32 * 64);
+    const float inv_ab = (1.f / sa) * (1.f / sb);
+    const bool split = gridDim.z > 1;
+    float* Cout = split ? p.C + (size_t)blockIdx.z * (size_t)p.slab_stride : p.C;
+    float am = 0.f;
+#pragma unroll 1
+    for (int i = 0; i < 4; ++i) {
+        f32x16 c[2];
+        switch (i) {
+            case 0: c[0] = acc[0][0]; c[1] = acc[0][1]; break;
+            case 1: c[0] = acc[1][0]; c[1] = acc[1][1]; break;
+            case 2: c[0] = acc[2][0]; c[1] = acc[2][1]; break;
+            default: c[0] = acc[3][0]; c[1] = acc[3][1]; break;
+        }
+        epi_strip_write<2>(c, Cs, lane);
+        if (split) epi_strip_emit<true, 2>(p, q, Cs, lane, m0 + wm * 128 + i * 32, n0 + wn * 64, inv_ab, 1.f, Cout, am);
+        else epi_strip_emit<false, 2>(p, q, Cs, lane, m0 + wm * 128 + i * 32, n0 + wn * 64, inv_ab, 1.f, Cout, am);
+    }
+}
+
 // =============================================================================== fp32 -> P32 planes (stand-alone pass)
 // mode 0: the site's partial maxima are complete (producer or segmm_absmax): s = exact scale, written to hdr[0], flag cleared.
 // mode 1: s = hdr[0] as it stands (delayed scale); partial maxima and the overflow flag are folded into hdr.

@@ -369,6 +369,13 @@ def _splits_for(M, N, K):
     return max(1, min(32, ktiles, (_SPLIT_TARGET + tiles - 1) // tiles))
 
 
+def _splits_for_p(M, N, K):
+    """Split-K factor of a plane-operand weight-gradient GEMM (256 x 256 tiles, one workgroup per CU): fill the 256 CUs once."""
+    tiles = ((M + 255) // 256) * ((N + 255) // 256)
+    ktiles = (K + 31) // 32
+    return max(1, min(64, ktiles, 256 // tiles if tiles <= 256 else 1))
+
+
 @contextlib.contextmanager
 def side_work(store):
     """Weight- and bias-gradient launches of a Linear are independent of its input-gradient GEMM.  They are
