@@ -372,7 +372,7 @@ int segmm_gemm_p(int layout, int M, int N, int K, const uint16_t* a_planes, int 
     SEGMM_REQUIRE(a_planes && b_planes && a_hdr && b_hdr, "gemm_p: null plane operand / header");
     SEGMM_REQUIRE(C || (c_planes && !write_c), "gemm_p: no output");
     if (M <= 0 || N <= 0) return 0;
-    SEGMM_REQUIRE(K > 0 && K % 32 == 0, "gemm_p: K %% 32 != 0 (K=%d)", K);
+    SEGMM_REQUIRE(K > 0 && (layout == 2 || K % 32 == 0), "gemm_p: K %% 32 != 0 (K=%d)", K);      // TN: token tails are zero-filled by the buffer range check
     SEGMM_REQUIRE(N % 4 == 0 && (!C || (ldc % 4 == 0 && aligned16(C))), "gemm_p: N/ldc %% 4, alignment");
     SEGMM_REQUIRE(lda2 % 64 == 0 && ldb2 % 64 == 0 && aligned16(a_planes) && aligned16(b_planes), "gemm_p: plane strides %% 64 halves / alignment");
     SEGMM_REQUIRE(!c_planes || (c_hdr && ldc2 % 64 == 0 && N % 32 == 0 && aligned16(c_planes)), "gemm_p: plane output needs a header, N %% 32, ldc2 %% 64");

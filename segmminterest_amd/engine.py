@@ -140,9 +140,6 @@ class ParamStore:
         # set by the trainer.  The table gradient is then built from the gathered per-row gradients on every rank and the
         # table's range is left out of the dense gradient all-reduce (table_ranges()).
         self.row_exchange = None
-        # fp16x3 engine: partial maxima of EXTERNAL input tensors that their producer already has (Trainer.normalize folds
-        # them into the L1-normalisation kernel), keyed by the tensor's device address; absent -> one absmax pass
-        self.ext_amax: Dict[int, torch.Tensor] = {}
         self._side_stream = None
         self._on_side = False
         self.overlap = os.environ.get("SEGMM_OVERLAP", "1") != "0"
@@ -160,9 +157,17 @@ class ParamStore:
         # in the NT form), refreshed when the parameters change (one split pass per optimizer step)
         # (fp16x3 engine: two fp16 planes scaled by one power of two derived from ``wamax``, the partial maxima of
         # |parameters|, which the GEMMs also need for weights they read as fp32)
-        self.engine_h = H.GEMM_ENGINE == H.ENGINE_F16X3
+        self.engine_p = H.GEMM_ENGINE == H.ENGINE_F16X3P      # plane-operand GEMMs (gemm_planes.h); implies the fp16x3 arithmetic
+        self.engine_h = H.GEMM_ENGINE in (H.ENGINE_F16X3, H.ENGINE_F16X3P)
         self.use_planes = H.GEMM_ENGINE in (H.ENGINE_BF16X6, H.ENGINE_F16X3) and os.environ.get("SEGMM_PLANES", "1") != "0"
         self.wamax = None
+        # engine_p: P32 planes of every weight matrix a GEMM reads (W: forward operand; W^T: the input-gradient GEMM in NT form),
+        # one site header per matrix (own scale: LayerNorm gammas and biases are not part of any of them)
+        self.wpt: Dict[str, "H.PT"] = {}
+        self.wTpt: Dict[str, "H.PT"] = {}
+        self._wmats: List[Tuple[str, int, int, int, bool]] = []      # (first parameter name, flat offset, rows, cols, needs W^T)
+        self.whdr = None
+        self.wpl = self.wTpl = None
         self.wgrad_planes = 2 if os.environ.get("SEGMM_WGRAD", "x6") == "x3" else 3      # x3 = opt-in, see DESIGN.md
         self.wplanes = self.wTplanes = None
         self.fused_version = 0
@@ -215,9 +220,11 @@ class ParamStore:
         if key == self._planes_key:
             return
         dev = self.flat.device
+        if self.engine_p:
+            self._refresh_p32(dev)
         # only parameters that ARE GEMM operands are scanned / split (an id-mode item table of 90 M floats is neither)
         ranges = self._plane_ranges
-        if self.engine_h:
+        if self.engine_h and not (self.engine_p and self._all_p32):
             if self.wamax is None or self.wamax.device != dev:
                 self.wamax = torch.zeros((H.AMAX_PARTS,), dtype=torch.float32, device=dev)
             per = H.AMAX_PARTS // max(len(ranges), 1)
@@ -240,6 +247,27 @@ class ParamStore:
                     H.split3_transpose(self.flat, R, Cc, Cc, self.wTplanes, x_off=off, p_off=off)
         self._planes_key = key
 
+    def _refresh_p32(self, dev):
+        """Per optimizer step: absmax + exact split of every GEMM weight matrix into P32 planes (and of its transpose)."""
+        mats = self._wmats
+        if self.whdr is None or self.whdr.device != dev or self.whdr.shape[0] != max(len(mats), 1):
+            self.whdr = torch.zeros((max(len(mats), 1), H.SITE_FLOATS), dtype=torch.float32, device=dev)
+            self.wpl = torch.empty((2 * self.n_live,), dtype=torch.float16, device=dev)
+            self.wTpl = torch.empty((2 * self.n_live,), dtype=torch.float16, device=dev)
+            self.wpt, self.wTpt = {}, {}
+            for i, (name, off, R, Cc, tr) in enumerate(mats):
+                self.wpt[name] = H.PT(self.wpl, self.whdr[i], R, Cc, ld2=2 * Cc, p_off=2 * off)
+                if tr:
+                    self.wTpt[name] = H.PT(self.wTpl, self.whdr[i], Cc, R, ld2=2 * R, p_off=2 * off)
+        else:
+            self.whdr.zero_()
+        for i, (name, off, R, Cc, tr) in enumerate(mats):
+            hdr = self.whdr[i]
+            H.absmax(self.flat, R, Cc, Cc, off=off, out=hdr[H.SITE_HDR:])
+            H.split_p32(self.flat, R, Cc, Cc, self.wpl, 2 * Cc, hdr, mode=0, x_off=off, p_off=2 * off)
+            if tr:
+                H.split_p32_transpose(self.flat, R, Cc, Cc, self.wTpl, 2 * R, hdr, x_off=off, p_off=2 * off)
+
     def _build(self, params):
         first = next(iter(params.values()))
         dev = first.device
@@ -253,7 +281,7 @@ class ParamStore:
         for bname, groups in self._layout():
             start = off
             for grp in groups:
-                off = (off + 7) & ~7          # 8 floats: 32-byte fp32 alignment = 16-byte alignment of the bf16 planes
+                off = (off + 31) & ~31        # 32 floats: the P32 plane blocks (and 16-byte alignment of every plane format)
                 for name in grp:
                     if name not in params:
                         raise KeyError("layout names unknown parameter %s" % name)
@@ -318,6 +346,27 @@ class ParamStore:
             merged[-2:] = [(a[0], b[0] + b[1] - a[0])]
         self._plane_ranges = [(o, min(n, n_live - o)) for o, n in merged]
         self._planes_key = None
+        # engine_p: the weight matrices as GEMMs read them -- fused projection groups as ONE [sum rows, cols] matrix
+        self._wmats, self._all_p32 = [], True
+        tr_offs = {o for o, _, _ in self._transposes}
+        mods = dict(self.root.named_modules())
+        for bname, groups in self._layout():
+            for grp in groups:
+                n0 = grp[0]
+                if not n0.endswith(".weight") or params[n0].dim() != 2 or "ln_" in n0 or "_pe." in n0 or bname == "head":
+                    continue
+                in_layer = ".encoder.layers." in "." + n0 or ".encoder_mlp.mlp." in "." + n0
+                is_lin = isinstance(mods.get(n0.rsplit(".", 1)[0]), torch.nn.Linear)
+                if not (in_layer or (is_lin and (n0.endswith("vid_proj.weight") or n0.endswith("usr_proj.weight")))):
+                    continue
+                R, Cc = sum(params[n].shape[0] for n in grp), params[n0].shape[1]
+                o = self.index[n0][0]
+                tr = o in tr_offs
+                if Cc % 32 == 0 and (not tr or R % 32 == 0):
+                    self._wmats.append((n0, o, R, Cc, tr))
+                else:
+                    self._all_p32 = False
+        self.whdr = None
 
     def table_ranges(self) -> List[Tuple[int, int]]:
         """[start, end) of the live id-embedding tables inside the flat gradient buffer (id mode: vid_proj / usr_proj
@@ -423,14 +472,32 @@ def join_side(store):
         torch.cuda.current_stream().wait_stream(store._side_stream)
 
 
+class Act:
+    """A tensor that some GEMM reads: the fp32 values ``t`` ([rows, cols] row-major), its site header ``hdr`` (scale, overflow
+    flag, partial maxima -- None on the f32 / bf16x6 engines) and, on the plane engine, the P32 fp16 planes ``planes``
+    ([rows, 2 cols]; None when cols is not a multiple of 32: such operands go through the on-the-fly kernel)."""
+    __slots__ = ("t", "hdr", "rows", "cols", "planes", "filled")
+
+    def __init__(self, t, hdr, rows, cols, planes=None):
+        self.t, self.hdr, self.rows, self.cols, self.planes, self.filled = t, hdr, rows, cols, planes, False
+
+    @property
+    def slots(self):
+        return None if self.hdr is None else self.hdr[H.SITE_HDR:]
+
+    def pt(self, c0=0, ncols=None):
+        ncols = self.cols - c0 if ncols is None else ncols
+        return H.PT(self.planes, self.hdr, self.rows, ncols, ld2=2 * self.cols, p_off=2 * c0, f32=self.t, ldf=self.cols, f_off=c0)
+
+
 class AmaxArena:
-    """fp16x3 engine: zeroed [AMAX_SLOTS] rows, one per tensor that a GEMM will read; its producer kernel folds
-    max|x| into the row (hipabi / common.h), the consuming GEMMs derive the tensor's power-of-two scale from it.
-    One allocation + one fill per forward and per backward; ``new()`` returns None on the other engines, which
-    turns every amax argument into a no-op."""
+    """fp16x3 engines: zeroed site headers ([SITE_FLOATS] rows: scale, flag, AMAX_SLOTS partial maxima), one per tensor that
+    a GEMM will read; its producer kernel folds max|x| into the slots (hipabi / common.h), the consuming GEMMs derive the
+    tensor's power-of-two scale from them.  One allocation + one fill per forward and per backward; ``new()`` returns None
+    on the other engines, which turns every amax argument into a no-op."""
 
     def __init__(self, store, n):
-        self.t = torch.zeros((n, H.AMAX_SLOTS), dtype=torch.float32, device=store.flat.device) if store.engine_h else None
+        self.t = torch.zeros((n, H.SITE_FLOATS), dtype=torch.float32, device=store.flat.device) if store.engine_h else None
         self.i = 0
 
     def new(self):
@@ -443,30 +510,70 @@ class AmaxArena:
         return r
 
 
-def _wgrad(store, dY, ldy, y_off, X, ldx, x_off, Mrows, n_out, n_in, gW, accumulate=False, a_amax=None, b_amax=None):
-    """gW[n_out, n_in] (+)= dY[:, y_off:y_off+n_out]^T . X[:, x_off:x_off+n_in]  (split-K over tokens)."""
+def new_act(store, arena, rows, cols, t=None, key=None, planes=True):
+    """An Act with a fresh site header; ``t`` given or allocated (``key``: persistent scratch name instead of a new tensor).
+    ``planes=False``: no GEMM reads it on the plane engine (only its fp32 values / maxima are wanted)."""
+    dev = store.flat.device
+    if t is None:
+        t = store.buf(key, (rows, cols)) if key is not None else torch.empty((rows, cols), dtype=torch.float32, device=dev)
+    want = planes
+    planes = None
+    if want and store.engine_p and cols % 32 == 0:
+        planes = store.buf(key + ":pl", (rows, 2 * cols), torch.float16) if key is not None else \
+            torch.empty((rows, 2 * cols), dtype=torch.float16, device=dev)
+    return Act(t, arena.new(), rows, cols, planes)
+
+
+def finish_act(store, act):
+    """Called when the producer(s) of ``act`` have been enqueued: makes the planes unless the producer wrote them itself."""
+    if act.planes is not None and not act.filled:
+        H.split_p32(act.t, act.rows, act.cols, act.cols, act.planes, 2 * act.cols, act.hdr, mode=0)
+        act.filled = True
+    return act
+
+
+def _wgrad(store, dY, y_off, X, x_off, Mrows, n_out, n_in, gW, accumulate=False):
+    """gW[n_out, n_in] (+)= dY[:, y_off:y_off+n_out]^T . X[:, x_off:x_off+n_in]  (split-K over tokens); dY, X: Act."""
+    if store.engine_p and dY.planes is not None and X.planes is not None and n_out % 32 == 0 and n_in % 32 == 0:
+        splits = _splits_for_p(n_out, n_in, Mrows)
+        ws = store.buf("splitk_ws_side" if store._on_side else "splitk_ws", (max(splits, 1) * n_out * n_in,)) if splits > 1 else None
+        H.gemm_p(H.LAYOUT_TN, n_out, n_in, Mrows, dY.pt(y_off, n_out), X.pt(x_off, n_in), gW, n_in, splits=splits, workspace=ws,
+                 accumulate=accumulate)
+        return
     splits = _splits_for(n_out, n_in, Mrows)
     ws = store.buf("splitk_ws_side" if store._on_side else "splitk_ws", (max(splits, 1) * n_out * n_in,)) if splits > 1 else None
-    H.gemm(H.LAYOUT_TN, n_out, n_in, Mrows, dY, ldy, X, ldx, gW, n_in, splits=splits, workspace=ws,
+    H.gemm(H.LAYOUT_TN, n_out, n_in, Mrows, dY.t, dY.cols, X.t, X.cols, gW, n_in, splits=splits, workspace=ws,
            accumulate=accumulate, a_off=y_off, b_off=x_off, nplanes=store.wgrad_planes if H.GEMM_ENGINE == H.ENGINE_BF16X6 else 3,
-           a_amax=a_amax, b_amax=b_amax)
+           a_amax=dY.slots, b_amax=X.slots)
 
 
-def _lin_fwd(store, M, N, K, X, wname, out, ldo, **kw):
-    """out[M,N] = X[M,K] . W[N,K]^T (+ epilogue); W = the parameter (or fused group starting at) ``wname``."""
+def _lin_fwd(store, M, N, K, X, wname, out, ldo, c_act=None, **kw):
+    """out[M,N] = X[M,K] . W[N,K]^T (+ epilogue); X: Act; W = the parameter (or fused group starting at) ``wname``;
+    ``c_act``: the Act that ``out`` belongs to (receives the partial maxima of |out|)."""
+    w = store.wpt.get(wname) if store.engine_p else None
+    if w is not None and X.planes is not None:
+        H.gemm_p(H.LAYOUT_NT, M, N, K, X.pt(), w, out, ldo, c_hdr=None if c_act is None else c_act.hdr, **kw)
+        return
     if store.use_planes and K % 8 == 0:
         kw["b_planes"] = (store.wplanes, store.index[wname][0])
-    H.gemm(H.LAYOUT_NT, M, N, K, X, K, store.p(wname), K, out, ldo, b_amax=store.wamax, **kw)
+    H.gemm(H.LAYOUT_NT, M, N, K, X.t, K, store.p(wname), K, out, ldo, a_amax=X.slots, b_amax=store.wamax,
+           c_amax=None if c_act is None else c_act.slots, **kw)
 
 
-def _lin_dgrad(store, M, n_in, n_out, dY, wname, out, **kw):
-    """out[M,n_in] = dY[M,n_out] . W[n_out,n_in] (+ epilogue).  With W^T planes this is the NT form (both operands
+def _lin_dgrad(store, M, n_in, n_out, dY, wname, out, c_act=None, **kw):
+    """out[M,n_in] = dY[M,n_out] . W[n_out,n_in] (+ epilogue); dY: Act.  With W^T planes this is the NT form (both operands
     k-contiguous), otherwise the NN layout on the fp32 weights."""
+    wT = store.wTpt.get(wname) if store.engine_p else None
+    if wT is not None and dY.planes is not None:
+        H.gemm_p(H.LAYOUT_NT, M, n_in, n_out, dY.pt(), wT, out, n_in, c_hdr=None if c_act is None else c_act.hdr, **kw)
+        return
+    ca = None if c_act is None else c_act.slots
     if store.use_planes and n_out % 8 == 0:
-        H.gemm(H.LAYOUT_NT, M, n_in, n_out, dY, n_out, None, n_out, out, n_in, b_planes=(store.wTplanes, store.index[wname][0]),
-               b_amax=store.wamax, **kw)
+        H.gemm(H.LAYOUT_NT, M, n_in, n_out, dY.t, n_out, None, n_out, out, n_in, b_planes=(store.wTplanes, store.index[wname][0]),
+               a_amax=dY.slots, b_amax=store.wamax, c_amax=ca, **kw)
     else:
-        H.gemm(H.LAYOUT_NN, M, n_in, n_out, dY, n_out, store.p(wname), n_in, out, n_in, b_amax=store.wamax, **kw)
+        H.gemm(H.LAYOUT_NN, M, n_in, n_out, dY.t, n_out, store.p(wname), n_in, out, n_in, a_amax=dY.slots, b_amax=store.wamax,
+               c_amax=ca, **kw)
 
 
 def _colsum(store, X, ld, M, N, out, x_off=0, w=None, accumulate=False):
@@ -536,6 +643,29 @@ class BackboneRun:
         self.sv = {}
         self.abl = getattr(bb, "ablation_type", "ours")
         self.mode = attn_mode(bb)
+        self.n_mlp = len(mlp_linears(bb)) if self.abl in MLP_VARIANTS else 0
+
+    def _input_act(self, x, rows, cols):
+        """External fp32 input (feature tensor) as a GEMM operand.  Its partial maxima come with the tensor when its producer
+        has them (Trainer.normalize / FeatureTable.gather attach the site header as ``_segmm_hdr``: they travel WITH the tensor
+        object, never keyed by address), otherwise from one absmax pass."""
+        st = self.store
+        hdr = None
+        if st.engine_h:
+            hdr = getattr(x, "_segmm_hdr", None)
+            if hdr is None or hdr.device != x.device:
+                hdr = self.am.new()
+                H.absmax(x, rows, cols, cols, out=hdr[H.SITE_HDR:])
+        planes = torch.empty((rows, 2 * cols), dtype=torch.float16, device=x.device) if st.engine_p and cols % 32 == 0 else None
+        return finish_act(st, Act(x, hdr, rows, cols, planes))
+
+    def _as_act(self, arena, t, rows, cols):
+        """A plain fp32 tensor (no producer-side maxima) as a GEMM operand: absmax pass (+ split pass)."""
+        st = self.store
+        a = new_act(st, arena, rows, cols, t=t)
+        if a.hdr is not None:
+            H.absmax(t, rows, cols, cols, out=a.slots)
+        return finish_act(st, a)
 
     # ---------------------------------------------------------------- forward
     def forward(self, usr_feat, usr_mask, vid_feat, vid_mask, train: bool, seed: int):
@@ -564,40 +694,40 @@ class BackboneRun:
         self.vm, self.um = vm, um
         sv = self.sv
         ref = vm
-        am = self.am = AmaxArena(st, 6 + 12 * max(self.N - 1, 0))
+        am = self.am = AmaxArena(st, 8 + 12 * max(self.N - 1, 0) + 2 * (self.n_mlp + 1))
+        layered = self.abl not in MLP_VARIANTS and self.N >= 2
+        usr_is_operand = (layered and self.mode != "self") or self.abl == "CrossMLP"      # does any GEMM read the user embedding?
         # ---- embedding (encoder.py:425-473).  The user-token chain (input Linear -> LayerNorm -> the first layer's fused
-        # user-token projection: 740 us at config 2) and the video-token chain (497 us) are independent until the first
-        # attention: with SEGMM_FWD_SIDE=1 the user chain is enqueued on the side stream, so that its HBM-bound LayerNorm runs
-        # under the other chain's GEMMs.  Measured on one box, alternating runs: 83.8 k -> 83.6 k interactions/s -- the GEMMs
-        # of both chains share the same power-limited matrix pipes, so the knob is OFF by default.
+        # user-token projection) and the video-token chain are independent until the first attention: with SEGMM_FWD_SIDE=1
+        # the user chain is enqueued on the side stream.  Measured on one box, alternating runs: 83.8 k -> 83.6 k
+        # interactions/s -- the GEMMs of both chains share the same power-limited matrix pipes, so the knob is OFF by default.
         # Every buffer is allocated HERE, on the main stream (the caching allocator must never hand a side-stream block to
         # the next step while main-stream kernels of this step still read it).
         pre_u = _empty(ref, Mu, d)
-        Eu, meu, reu = _empty(ref, Mu, d), _empty(ref, Mu), _empty(ref, Mu)
-        am_u = am.new()
+        meu, reu = _empty(ref, Mu), _empty(ref, Mu)
+        Eu = new_act(st, am, Mu, d, planes=usr_is_operand)
         Yu0 = None
-        layered = self.abl not in MLP_VARIANTS and self.N >= 2
-        fwd_side = st.overlap and st.fwd_side and not bb.id_usr and layered and self.mode != "self"
+        fwd_side = st.overlap and st.fwd_side and not bb.id_usr and layered and self.mode != "self" and not st.engine_p
         if bb.id_usr:
             uids = usr_feat.contiguous().to(torch.int64)
             sv["usr_ids"] = uids
             H.embed_id_usr(uids, st.p(P + "usr_proj.weight"), d, st.p(P + "usr_pe.weight"), pre_u, B)
-            H.layernorm_fwd(pre_u, st.p(P + "usr_ln.weight"), st.p(P + "usr_ln.bias"), Eu, meu, reu, drop_p=p_drop, seed=seed,
-                            site=_site(self.bi, 0, K_EMB_U), amax=am_u)
+            H.layernorm_fwd(pre_u, st.p(P + "usr_ln.weight"), st.p(P + "usr_ln.bias"), Eu.t, meu, reu, drop_p=p_drop, seed=seed,
+                            site=_site(self.bi, 0, K_EMB_U), amax=Eu.slots)
+            finish_act(st, Eu)
         else:
             xu = usr_feat.contiguous().float()
-            sv["usr_x"] = xu
             Din_u = xu.shape[-1]
-            sv["am_usr_x"] = (st.ext_amax.get(xu.data_ptr()) if st.ext_amax.get(xu.data_ptr()) is not None
-                              else H.absmax(xu, Mu, Din_u, Din_u)) if st.engine_h else None
+            sv["usr_x"] = self._input_act(xu, Mu, Din_u)
 
             def usr_chain():
-                _lin_fwd(st, Mu, d, Din_u, xu, P + "usr_proj.weight", pre_u, d, a_amax=sv["am_usr_x"],
+                _lin_fwd(st, Mu, d, Din_u, sv["usr_x"], P + "usr_proj.weight", pre_u, d,
                          bias=st.p(P + "usr_proj.bias"), residual=st.p(P + "usr_pe.weight"), ldr=d, res_period=Lt)
-                H.layernorm_fwd(pre_u, st.p(P + "usr_ln.weight"), st.p(P + "usr_ln.bias"), Eu, meu, reu, drop_p=p_drop, seed=seed,
-                                site=_site(self.bi, 0, K_EMB_U), amax=am_u)
+                H.layernorm_fwd(pre_u, st.p(P + "usr_ln.weight"), st.p(P + "usr_ln.bias"), Eu.t, meu, reu, drop_p=p_drop, seed=seed,
+                                site=_site(self.bi, 0, K_EMB_U), amax=Eu.slots)
+                finish_act(st, Eu)
                 if Yu0 is not None:
-                    self._usr_proj_fwd(0, Eu, am_u, Yu0)
+                    self._usr_proj_fwd(0, Eu, Yu0)
             if fwd_side:
                 Yu0 = _empty(ref, Mu, len(layer_plan(self.mode, 0 < self.N - 2)[1]) * d)
                 with side_work(st):
@@ -618,41 +748,40 @@ class BackboneRun:
                            st.p(P + "frameid_proj.bias"), st.p(P + "vid_pe.weight"), pre_v, B, S, frame_pos=fpos)
         else:
             x = vid_feat.contiguous().float()
-            sv["vid_x"] = x
             Din = x.shape[-1]
-            sv["am_vid_x"] = (st.ext_amax.get(x.data_ptr()) if st.ext_amax.get(x.data_ptr()) is not None
-                              else H.absmax(x, Mv, Din, Din)) if st.engine_h else None      # external input
-            _lin_fwd(st, Mv, d, Din, x, P + "vid_proj.weight", pre_v, d, a_amax=sv["am_vid_x"],
+            sv["vid_x"] = self._input_act(x, Mv, Din)
+            _lin_fwd(st, Mv, d, Din, sv["vid_x"], P + "vid_proj.weight", pre_v, d,
                      bias=st.p(P + "vid_proj.bias"), residual=st.p(P + "vid_pe.weight"), ldr=d, res_period=S)
-        Ev, mev, rev = _empty(ref, Mv, d), _empty(ref, Mv), _empty(ref, Mv)
-        am_v = am.new()
-        H.layernorm_fwd(pre_v, st.p(P + "vid_ln.weight"), st.p(P + "vid_ln.bias"), Ev, mev, rev, drop_p=p_drop, seed=seed,
-                        site=_site(self.bi, 0, K_EMB_V), amax=am_v)
+        mev, rev = _empty(ref, Mv), _empty(ref, Mv)
+        Ev = new_act(st, am, Mv, d, planes=layered or self.abl in ("SelfMLP", "CrossMLP"))
+        H.layernorm_fwd(pre_v, st.p(P + "vid_ln.weight"), st.p(P + "vid_ln.bias"), Ev.t, mev, rev, drop_p=p_drop, seed=seed,
+                        site=_site(self.bi, 0, K_EMB_V), amax=Ev.slots)
+        finish_act(st, Ev)
         sv["pre_v"], sv["mev"], sv["rev"] = pre_v, mev, rev
         Xv, Xu = Ev, Eu
         sv["layers"] = []
         if self.abl in MLP_VARIANTS:
-            return self._mlp_variant_fwd(Ev, Eu, am_v, am_u).view(B, -1, d), Eu.view(B, Lt, d)
+            return self._mlp_variant_fwd(Ev, Eu).view(B, -1, d), Eu.t.view(B, Lt, d)
         for i in range(max(self.N - 1, 0)):
-            Xv, Xu, am_v, am_u = self._layer_fwd(i, Xv, Xu, am_v, am_u, Yu_ready=Yu0 if i == 0 else None)
-        return Xv.view(B, S, d), Eu.view(B, Lt, d)
+            Xv, Xu = self._layer_fwd(i, Xv, Xu, Yu_ready=Yu0 if i == 0 else None)
+        return Xv.t.view(B, S, d), Eu.t.view(B, Lt, d)
 
     # ---------------------------------------------------------------- MLP ablations (encoder.py:392-400,503-511)
-    def _mlp_fwd(self, X, M, am_X, tok):
+    def _mlp_fwd(self, X, M, tok):
         """encoder_mlp on M tokens: [Linear -> ReLU -> Dropout] x n_hidden, Linear.  ``tok`` (0 video, 1 user) separates the
-        dropout streams of the two token sets of CrossMLP.  Returns (Z, saved hidden activations)."""
+        dropout streams of the two token sets of CrossMLP.  Returns (Z, saved hidden activations as Acts)."""
         st, d, P = self.store, self.d, self.pre
         lins = mlp_linears(self.bb)
         if len(lins) - 1 > 20:
             raise RuntimeError("encoder_mlp with %d hidden layers: dropout-site space holds 20" % (len(lins) - 1))
-        hs, am = [(X, am_X)], am_X
+        hs = [X]
         for k, n in enumerate(lins[:-1]):
-            Hk, am_k = _empty(X, M, d), self.am.new()
-            _lin_fwd(st, M, d, d, hs[-1][0], P + n + ".weight", Hk, d, bias=st.p(P + n + ".bias"), a_amax=hs[-1][1], c_amax=am_k,
+            Hk = new_act(st, self.am, M, d)
+            _lin_fwd(st, M, d, d, hs[-1], P + n + ".weight", Hk.t, d, bias=st.p(P + n + ".bias"), c_act=Hk,
                      activation=H.ACT_RELU, drop_p=self.p_drop, seed=self.seed, site=_site(self.bi, tok, K_MLP0 + k))
-            hs.append((Hk, am_k))
-        Z = _empty(X, M, d)
-        _lin_fwd(st, M, d, d, hs[-1][0], P + lins[-1] + ".weight", Z, d, bias=st.p(P + lins[-1] + ".bias"), a_amax=hs[-1][1])
+            hs.append(finish_act(st, Hk))
+        Z = _empty(X.t, M, d)
+        _lin_fwd(st, M, d, d, hs[-1], P + lins[-1] + ".weight", Z, d, bias=st.p(P + lins[-1] + ".bias"))
         return Z, hs
 
     def _mlp_bwd(self, dZ, hs, M, tok, gbuf, accumulate, tag):
@@ -660,55 +789,60 @@ class BackboneRun:
         Returns the gradient wrt the MLP input."""
         st, d, P = self.store, self.d, self.pre
         lins = mlp_linears(self.bb)
-        g = dZ
+        g = self._as_act(self.amb, dZ, M, d)
         for k in reversed(range(len(lins))):
             n = lins[k]
-            Xin = hs[k][0]
-            _wgrad(st, g, d, 0, Xin, d, 0, M, d, d, st.g(P + n + ".weight", gbuf), accumulate=accumulate)
-            _colsum(st, g, d, M, d, st.g(P + n + ".bias", gbuf), accumulate=accumulate)
-            gin = st.buf("mlp_g%d%s" % (k & 1, tag), (M, d))
+            _wgrad(st, g, 0, hs[k], 0, M, d, d, st.g(P + n + ".weight", gbuf), accumulate=accumulate)
+            _colsum(st, g.t, d, M, d, st.g(P + n + ".bias", gbuf), accumulate=accumulate)
+            gin = new_act(st, self.amb, M, d, key="mlp_g%d%s" % (k & 1, tag))
             if k > 0:       # through Dropout and ReLU of hidden layer k-1: aux = its saved output (> 0 iff live and kept)
-                _lin_dgrad(st, M, d, d, g, P + n + ".weight", gin, activation=H.ACT_DRELU, aux=hs[k][0], ldaux=d,
+                _lin_dgrad(st, M, d, d, g, P + n + ".weight", gin.t, c_act=gin, activation=H.ACT_DRELU, aux=hs[k].t, ldaux=d,
                            drop_p=self.p_drop, seed=self.seed, site=_site(self.bi, tok, K_MLP0 + k - 1))
+                finish_act(st, gin)
             else:
-                _lin_dgrad(st, M, d, d, g, P + n + ".weight", gin)
+                _lin_dgrad(st, M, d, d, g, P + n + ".weight", gin.t)
             g = gin
-        return g
+        return g.t
 
-    def _mlp_variant_fwd(self, Ev, Eu, am_v, am_u):
+    def _mlp_variant_fwd(self, Ev, Eu):
         sv, B, S, Lt, d = self.sv, self.B, self.S, self.Lt, self.d
         if self.abl == "w/oAtt":
-            return Ev
-        Zv, sv["mlp_v"] = self._mlp_fwd(Ev, self.Mv, am_v, 0)
+            return Ev.t
+        Zv, sv["mlp_v"] = self._mlp_fwd(Ev, self.Mv, 0)
         if self.abl == "SelfMLP":
             return Zv
-        Zu, sv["mlp_u"] = self._mlp_fwd(Eu, self.Mu, am_u, 1)
-        out = _empty(Ev, B * POOL_BINS, d)
+        Zu, sv["mlp_u"] = self._mlp_fwd(Eu, self.Mu, 1)
+        out = _empty(Ev.t, B * POOL_BINS, d)
         H.pool_tokens(Zu, Lt, Zv, S, out, B, d, POOL_BINS)       # AdaptiveAvgPool1d(40) over cat(user, video) tokens
         return out
 
-    def _side_post(self, i, L, side, X, A, M, kinds, am_A):
-        """R1 = X + drop(A.Wff^T+b); X1 = LN(R1); H = drop(gelu(X1.W0^T+b0)); R2 = X1 + drop(H.W1^T+b1); X2 = LN(R2)."""
+    def _side_post(self, i, L, side, X, A, M, kinds, out_is_operand):
+        """R1 = X + drop(A.Wff^T+b); X1 = LN(R1); H = drop(gelu(X1.W0^T+b0)); R2 = X1 + drop(H.W1^T+b1); X2 = LN(R2).
+        X, A: Acts; returns (X2 Act, saved)."""
         st, d, seed, am = self.store, self.d, self.seed, self.am
         k_ao, k_mi, k_mo = kinds
         ca = L + "cross_attn."
-        R1 = _empty(X, M, d)
-        _lin_fwd(st, M, d, d, A, ca + "ff_%s.weight" % side, R1, d, bias=st.p(ca + "ff_%s.bias" % side), a_amax=am_A,
-               residual=X, ldr=d, res_period=M, drop_p=self.p_drop, seed=seed, site=_site(self.bi, i, k_ao))
-        X1, m1, r1 = _empty(X, M, d), _empty(X, M), _empty(X, M)
-        am_X1, am_Hh, am_X2 = am.new(), am.new(), am.new()
-        H.layernorm_fwd(R1, st.p(ca + "ln_%s.weight" % side), st.p(ca + "ln_%s.bias" % side), X1, m1, r1, amax=am_X1)
-        G, Hh = _empty(X, M, d), _empty(X, M, d)
+        R1 = _empty(X.t, M, d)
+        _lin_fwd(st, M, d, d, A, ca + "ff_%s.weight" % side, R1, d, bias=st.p(ca + "ff_%s.bias" % side),
+                 residual=X.t, ldr=d, res_period=M, drop_p=self.p_drop, seed=seed, site=_site(self.bi, i, k_ao))
+        m1, r1 = _empty(X.t, M), _empty(X.t, M)
+        X1 = new_act(st, am, M, d)
+        H.layernorm_fwd(R1, st.p(ca + "ln_%s.weight" % side), st.p(ca + "ln_%s.bias" % side), X1.t, m1, r1, amax=X1.slots)
+        finish_act(st, X1)
+        G = _empty(X.t, M, d)
+        Hh = new_act(st, am, M, d)
         ff = L + "ff_%s.layers." % side
-        _lin_fwd(st, M, d, d, X1, ff + "0.weight", Hh, d, bias=st.p(ff + "0.bias"), a_amax=am_X1, c_amax=am_Hh,
-               activation=H.ACT_GELU, aux=G, ldaux=d, drop_p=self.p_inner, seed=seed, site=_site(self.bi, i, k_mi))
-        R2 = _empty(X, M, d)
-        _lin_fwd(st, M, d, d, Hh, ff + "1.weight", R2, d, bias=st.p(ff + "1.bias"), a_amax=am_Hh,
-               residual=X1, ldr=d, res_period=M, drop_p=self.p_drop, seed=seed, site=_site(self.bi, i, k_mo))
-        X2, m2, r2 = _empty(X, M, d), _empty(X, M), _empty(X, M)
-        H.layernorm_fwd(R2, st.p(L + "ln_%s.weight" % side), st.p(L + "ln_%s.bias" % side), X2, m2, r2, amax=am_X2)
-        return X2, am_X2, dict(A=A, R1=R1, X1=X1, m1=m1, r1=r1, G=G, Hh=Hh, R2=R2, m2=m2, r2=r2, am_A=am_A, am_X1=am_X1,
-                               am_Hh=am_Hh)
+        _lin_fwd(st, M, d, d, X1, ff + "0.weight", Hh.t, d, bias=st.p(ff + "0.bias"), c_act=Hh,
+                 activation=H.ACT_GELU, aux=G, ldaux=d, drop_p=self.p_inner, seed=seed, site=_site(self.bi, i, k_mi))
+        finish_act(st, Hh)
+        R2 = _empty(X.t, M, d)
+        _lin_fwd(st, M, d, d, Hh, ff + "1.weight", R2, d, bias=st.p(ff + "1.bias"),
+                 residual=X1.t, ldr=d, res_period=M, drop_p=self.p_drop, seed=seed, site=_site(self.bi, i, k_mo))
+        m2, r2 = _empty(X.t, M), _empty(X.t, M)
+        X2 = new_act(st, am, M, d, planes=out_is_operand)
+        H.layernorm_fwd(R2, st.p(L + "ln_%s.weight" % side), st.p(L + "ln_%s.bias" % side), X2.t, m2, r2, amax=X2.slots)
+        finish_act(st, X2)
+        return X2, dict(A=A, R1=R1, X1=X1, m1=m1, r1=r1, G=G, Hh=Hh, R2=R2, m2=m2, r2=r2)
 
     def _attn_views(self, full, Yv, Yu, nv, nu):
         """Column slices of the fused projection buffers (or of their gradients) as the attention kernels take them:
@@ -727,16 +861,16 @@ class BackboneRun:
                       Kb=g(cu, "t2t_proj.1"), Vb=g(cu, "t2t_proj.2"), ldkb=ldu, La=S, Lb=0 if mode == "cross" else Lt)
         return vq, uq
 
-    def _usr_proj_fwd(self, i, Xu, am_Xu, Yu):
+    def _usr_proj_fwd(self, i, Xu, Yu):
         """Yu = Xu . [fused user-token projections of layer i]^T + b."""
         st, d = self.store, self.d
         full = i < self.N - 2 and self.mode != "self"
         usrP = layer_plan(self.mode, full)[1]
         ca = "%sencoder.layers.%d.cross_attn." % (self.pre, i)
         nu = len(usrP)
-        _lin_fwd(st, self.Mu, nu * d, d, Xu, ca + usrP[0] + ".weight", Yu, nu * d, bias=st.p(ca + usrP[0] + ".bias"), a_amax=am_Xu)
+        _lin_fwd(st, self.Mu, nu * d, d, Xu, ca + usrP[0] + ".weight", Yu, nu * d, bias=st.p(ca + usrP[0] + ".bias"))
 
-    def _layer_fwd(self, i, Xv, Xu, am_Xv, am_Xu, Yu_ready=None):
+    def _layer_fwd(self, i, Xv, Xu, Yu_ready=None):
         st, d, P, am = self.store, self.d, self.pre, self.am
         B, S, Lt, Mv, Mu, Hh, dh = self.B, self.S, self.Lt, self.Mv, self.Mu, self.H, self.dh
         full = i < self.N - 2 and self.mode != "self"
@@ -744,71 +878,75 @@ class BackboneRun:
         nv, nu = len(vidP), len(usrP)
         L = "%sencoder.layers.%d." % (P, i)
         ca = L + "cross_attn."
-        Yv = _empty(Xv, Mv, nv * d)
-        _lin_fwd(st, Mv, nv * d, d, Xv, ca + vidP[0] + ".weight", Yv, nv * d, bias=st.p(ca + vidP[0] + ".bias"), a_amax=am_Xv)
+        Yv = _empty(Xv.t, Mv, nv * d)
+        _lin_fwd(st, Mv, nv * d, d, Xv, ca + vidP[0] + ".weight", Yv, nv * d, bias=st.p(ca + vidP[0] + ".bias"))
         Yu = None
         if Yu_ready is not None:      # computed on the side stream together with the user embedding (forward())
             Yu = Yu_ready
             join_side(st)
         elif nu:
-            Yu = _empty(Xv, Mu, nu * d)
-            self._usr_proj_fwd(i, Xu, am_Xu, Yu)
+            Yu = _empty(Xv.t, Mu, nu * d)
+            self._usr_proj_fwd(i, Xu, Yu)
         vq, uq = self._attn_views(full, Yv, Yu, nv, nu)
-        Av, lse_v = _empty(Xv, Mv, d), _empty(Xv, 2, B, Hh, S)
-        am_Av = am.new()
+        lse_v = _empty(Xv.t, 2, B, Hh, S)
+        Av = new_act(st, am, Mv, d)
         H.attn_fwd(B, Hh, dh, S, vq["La"], vq["Lb"], vq["Qa"], vq["Qb"], vq["ldq"], vq["Ka"], vq["Va"], vq["ldka"], vq["Kb"], vq["Vb"],
-                   vq["ldkb"], self.vm, self.vm, self.um, Av, d, lse_v, drop_p=self.p_drop, seed=self.seed,
-                   site=_site(self.bi, i, K_ATT_V), amax_o=am_Av)
-        X2v, am_X2v, sv_v = self._side_post(i, L, "vid", Xv, Av, Mv, (K_AO_V, K_MI_V, K_MO_V), am_Av)
-        rec = dict(full=full, Xv=Xv, Xu=Xu, Yv=Yv, Yu=Yu, lse_v=lse_v, v=sv_v, am_Xv=am_Xv, am_Xu=am_Xu)
-        X2u = am_X2u = None
+                   vq["ldkb"], self.vm, self.vm, self.um, Av.t, d, lse_v, drop_p=self.p_drop, seed=self.seed,
+                   site=_site(self.bi, i, K_ATT_V), amax_o=Av.slots)
+        finish_act(st, Av)
+        X2v, sv_v = self._side_post(i, L, "vid", Xv, Av, Mv, (K_AO_V, K_MI_V, K_MO_V), out_is_operand=i < self.N - 2)
+        rec = dict(full=full, Xv=Xv, Xu=Xu, Yv=Yv, Yu=Yu, lse_v=lse_v, v=sv_v)
+        X2u = None
         if full:
-            Au, lse_u = _empty(Xv, Mu, d), _empty(Xv, 2, B, Hh, Lt)
-            am_Au = am.new()
+            lse_u = _empty(Xv.t, 2, B, Hh, Lt)
+            Au = new_act(st, am, Mu, d)
             H.attn_fwd(B, Hh, dh, Lt, uq["La"], uq["Lb"], uq["Qa"], uq["Qb"], uq["ldq"], uq["Ka"], uq["Va"], uq["ldka"], uq["Kb"],
-                       uq["Vb"], uq["ldkb"], self.um, self.vm, self.um, Au, d, lse_u, drop_p=self.p_drop,
-                       seed=self.seed, site=_site(self.bi, i, K_ATT_U), amax_o=am_Au)
-            X2u, am_X2u, sv_u = self._side_post(i, L, "usr", Xu, Au, Mu, (K_AO_U, K_MI_U, K_MO_U), am_Au)
+                       uq["Vb"], uq["ldkb"], self.um, self.vm, self.um, Au.t, d, lse_u, drop_p=self.p_drop,
+                       seed=self.seed, site=_site(self.bi, i, K_ATT_U), amax_o=Au.slots)
+            finish_act(st, Au)
+            X2u, sv_u = self._side_post(i, L, "usr", Xu, Au, Mu, (K_AO_U, K_MI_U, K_MO_U), out_is_operand=True)
             rec["lse_u"], rec["u"] = lse_u, sv_u
         self.sv["layers"].append(rec)
-        return X2v, (X2u if full else Xu), am_X2v, (am_X2u if full else am_Xu)
+        return X2v, (X2u if full else Xu)
 
     # ---------------------------------------------------------------- backward
+    def _ln_bwd_act(self, key, dy, x, mean, rstd, gname, bname, gbuf, dx, M, drop_b, dsum_to):
+        """LayerNorm backward whose FORWARDED gradient (through the residual-branch dropout when p > 0) is a GEMM operand:
+        returns it as an Act.  ``dx`` receives the plain input gradient (residual path); without dropout the two coincide."""
+        st, d = self.store, self.d
+        has_drop = drop_b[0] > 0
+        a = new_act(st, self.amb, M, d, t=None if has_drop else dx, key=key)
+        _ln_bwd(st, dy, x, mean, rstd, gname, bname, gbuf, dx, a.t if has_drop else None, M, d, drop_b=drop_b, seed=self.seed,
+                amax=a.slots, dsum_to=dsum_to)
+        return finish_act(st, a)
+
     def _side_post_bwd(self, i, L, side, sv, dX2, M, kinds, gbuf, tag, deferred=None):
         """Reverse of _side_post.  Returns (dR1, dA): gradient wrt the residual input X and wrt the attention output."""
         st, d, seed, am = self.store, self.d, self.seed, self.amb
         k_ao, k_mi, k_mo = kinds
         ca = L + "cross_attn."
         ff = L + "ff_%s.layers." % side
-        am_dM, am_dG, am_dZ = am.new(), am.new(), am.new()
         dR2 = st.buf("dR2" + tag, (M, d))
-        dM = st.buf("dM" + tag, (M, d)) if self.p_drop > 0 else None
-        _ln_bwd(st, dX2, sv["R2"], sv["m2"], sv["r2"], L + "ln_%s.weight" % side, L + "ln_%s.bias" % side, gbuf, dR2, dM, M, d,
-                drop_b=(self.p_drop, _site(self.bi, i, k_mo)), seed=seed, amax=am_dM, dsum_to=st.g(ff + "1.bias", gbuf))
-        if dM is None:
-            dM = dR2
-        side_or_defer(st, lambda: _wgrad(st, dM, d, 0, sv["Hh"], d, 0, M, d, d, st.g(ff + "1.weight", gbuf), a_amax=am_dM,
-                                         b_amax=sv["am_Hh"]), deferred)
-        dG = st.buf("dG" + tag, (M, d))
-        _lin_dgrad(st, M, d, d, dM, ff + "1.weight", dG, activation=H.ACT_DGELU, aux=sv["G"], ldaux=d, a_amax=am_dM, c_amax=am_dG,
-               drop_p=self.p_inner, seed=seed, site=_site(self.bi, i, k_mi))
+        dM = self._ln_bwd_act("dM" + tag, dX2, sv["R2"], sv["m2"], sv["r2"], L + "ln_%s.weight" % side, L + "ln_%s.bias" % side, gbuf,
+                              dR2, M, (self.p_drop, _site(self.bi, i, k_mo)), st.g(ff + "1.bias", gbuf))
+        side_or_defer(st, lambda: _wgrad(st, dM, 0, sv["Hh"], 0, M, d, d, st.g(ff + "1.weight", gbuf)), deferred)
+        dG = new_act(st, am, M, d, key="dG" + tag)
+        _lin_dgrad(st, M, d, d, dM, ff + "1.weight", dG.t, c_act=dG, activation=H.ACT_DGELU, aux=sv["G"], ldaux=d,
+                   drop_p=self.p_inner, seed=seed, site=_site(self.bi, i, k_mi))
+        finish_act(st, dG)
+
         def _w0():
-            _wgrad(st, dG, d, 0, sv["X1"], d, 0, M, d, d, st.g(ff + "0.weight", gbuf), a_amax=am_dG, b_amax=sv["am_X1"])
-            _colsum(st, dG, d, M, d, st.g(ff + "0.bias", gbuf))
+            _wgrad(st, dG, 0, sv["X1"], 0, M, d, d, st.g(ff + "0.weight", gbuf))
+            _colsum(st, dG.t, d, M, d, st.g(ff + "0.bias", gbuf))
         side_or_defer(st, _w0, deferred)
         dX1 = st.buf("dX1" + tag, (M, d))
-        _lin_dgrad(st, M, d, d, dG, ff + "0.weight", dX1, residual=dR2, ldr=d, res_period=M, a_amax=am_dG)
+        _lin_dgrad(st, M, d, d, dG, ff + "0.weight", dX1, residual=dR2, ldr=d, res_period=M)
         dR1 = st.buf("dR1" + tag, (M, d))
-        dZ = st.buf("dZ" + tag, (M, d)) if self.p_drop > 0 else None
-        _ln_bwd(st, dX1, sv["R1"], sv["m1"], sv["r1"], ca + "ln_%s.weight" % side, ca + "ln_%s.bias" % side, gbuf, dR1, dZ, M, d,
-                drop_b=(self.p_drop, _site(self.bi, i, k_ao)), seed=seed, amax=am_dZ,
-                dsum_to=st.g(ca + "ff_%s.bias" % side, gbuf))
-        if dZ is None:
-            dZ = dR1
-        side_or_defer(st, lambda: _wgrad(st, dZ, d, 0, sv["A"], d, 0, M, d, d, st.g(ca + "ff_%s.weight" % side, gbuf),
-                                         a_amax=am_dZ, b_amax=sv["am_A"]), deferred)
+        dZ = self._ln_bwd_act("dZ" + tag, dX1, sv["R1"], sv["m1"], sv["r1"], ca + "ln_%s.weight" % side, ca + "ln_%s.bias" % side, gbuf,
+                              dR1, M, (self.p_drop, _site(self.bi, i, k_ao)), st.g(ca + "ff_%s.bias" % side, gbuf))
+        side_or_defer(st, lambda: _wgrad(st, dZ, 0, sv["A"], 0, M, d, d, st.g(ca + "ff_%s.weight" % side, gbuf)), deferred)
         dA = st.buf("dA" + tag, (M, d))
-        _lin_dgrad(st, M, d, d, dZ, ca + "ff_%s.weight" % side, dA, a_amax=am_dZ)
+        _lin_dgrad(st, M, d, d, dZ, ca + "ff_%s.weight" % side, dA)
         return dR1, dA
 
     def _layer_bwd(self, i, rec, dXv_out, dXu_out, gbuf):
@@ -820,46 +958,47 @@ class BackboneRun:
         L = "%sencoder.layers.%d." % (P, i)
         ca = L + "cross_attn."
         Yv, Yu = rec["Yv"], rec["Yu"]
-        dYv = st.buf("dYv%d" % i, (Mv, nv * d))
-        dYu = st.buf("dYu%d" % i, (Mu, nu * d)) if nu else None
+        dYv = new_act(st, self.amb, Mv, nv * d, key="dYv%d" % i)      # one site per fused dY buffer: both attentions fold into it
+        dYu = new_act(st, self.amb, Mu, nu * d, key="dYu%d" % i) if nu else None
         vq, uq = self._attn_views(full, Yv, Yu, nv, nu)
-        dvq, duq = self._attn_views(full, dYv, dYu, nv, nu)
+        dvq, duq = self._attn_views(full, dYv.t, dYu.t if nu else None, nv, nu)
         Dv = st.buf("attnD", (B * Hh * max(S, Lt),))
-        am_dYv, am_dYu = self.amb.new(), self.amb.new()      # one per fused dY buffer: both attentions fold into them
+        sl_v, sl_u = dYv.slots, (dYu.slots if nu else None)
         deferred = [] if st.defer_wgrad else None
         dR1v, dAv = self._side_post_bwd(i, L, "vid", rec["v"], dXv_out, Mv, (K_AO_V, K_MI_V, K_MO_V), gbuf, "v%d" % i, deferred)
         flush_deferred(st, deferred)          # the three weight-gradient GEMMs of this side run under the attention backward
         _attn_bwd(st, B, Hh, dh, S, vq["La"], vq["Lb"], vq["Qa"], vq["Qb"], vq["ldq"], vq["Ka"], vq["Va"], vq["ldka"], vq["Kb"], vq["Vb"],
-                   vq["ldkb"], self.vm, self.vm, self.um, rec["lse_v"], rec["v"]["A"], d, dAv, d, Dv, dvq["Qa"], dvq["Qb"], dvq["ldq"],
+                   vq["ldkb"], self.vm, self.vm, self.um, rec["lse_v"], rec["v"]["A"].t, d, dAv, d, Dv, dvq["Qa"], dvq["Qb"], dvq["ldq"],
                    dvq["Ka"], dvq["Va"], dvq["ldka"], dvq["Kb"], dvq["Vb"], dvq["ldkb"], drop_p=self.p_drop, seed=self.seed,
-                   site=_site(self.bi, i, K_ATT_V), amax_q=am_dYv, amax_ka=am_dYv, amax_kb=am_dYu)
+                   site=_site(self.bi, i, K_ATT_V), amax_q=sl_v, amax_ka=sl_v, amax_kb=sl_u)
         dR1u = None
         if full:
             dR1u, dAu = self._side_post_bwd(i, L, "usr", rec["u"], dXu_out, Mu, (K_AO_U, K_MI_U, K_MO_U), gbuf, "u%d" % i, deferred)
             flush_deferred(st, deferred)
             _attn_bwd(st, B, Hh, dh, Lt, uq["La"], uq["Lb"], uq["Qa"], uq["Qb"], uq["ldq"], uq["Ka"], uq["Va"], uq["ldka"], uq["Kb"],
-                       uq["Vb"], uq["ldkb"], self.um, self.vm, self.um, rec["lse_u"], rec["u"]["A"], d, dAu, d, Dv,
+                       uq["Vb"], uq["ldkb"], self.um, self.vm, self.um, rec["lse_u"], rec["u"]["A"].t, d, dAu, d, Dv,
                        duq["Qa"], duq["Qb"], duq["ldq"], duq["Ka"], duq["Va"], duq["ldka"], duq["Kb"], duq["Vb"], duq["ldkb"],
                        drop_p=self.p_drop, seed=self.seed, site=_site(self.bi, i, K_ATT_U),
-                       amax_q=am_dYu, amax_ka=am_dYv, amax_kb=am_dYu)
+                       amax_q=sl_u, amax_ka=sl_v, amax_kb=sl_u)
+        finish_act(st, dYv)
+        if nu:
+            finish_act(st, dYu)
         # fused projection weights / inputs
         with side_work(st):
-            _wgrad(st, dYv, nv * d, 0, rec["Xv"], d, 0, Mv, nv * d, d, _group_view(st, ca + vidP[0] + ".weight", nv * d * d, gbuf),
-                   a_amax=am_dYv, b_amax=rec["am_Xv"])
-            _colsum(st, dYv, nv * d, Mv, nv * d, _group_view(st, ca + vidP[0] + ".bias", nv * d, gbuf))
+            _wgrad(st, dYv, 0, rec["Xv"], 0, Mv, nv * d, d, _group_view(st, ca + vidP[0] + ".weight", nv * d * d, gbuf))
+            _colsum(st, dYv.t, nv * d, Mv, nv * d, _group_view(st, ca + vidP[0] + ".bias", nv * d, gbuf))
             if nu:
-                _wgrad(st, dYu, nu * d, 0, rec["Xu"], d, 0, Mu, nu * d, d, _group_view(st, ca + usrP[0] + ".weight", nu * d * d, gbuf),
-                       a_amax=am_dYu, b_amax=rec["am_Xu"])
-                _colsum(st, dYu, nu * d, Mu, nu * d, _group_view(st, ca + usrP[0] + ".bias", nu * d, gbuf))
+                _wgrad(st, dYu, 0, rec["Xu"], 0, Mu, nu * d, d, _group_view(st, ca + usrP[0] + ".weight", nu * d * d, gbuf))
+                _colsum(st, dYu.t, nu * d, Mu, nu * d, _group_view(st, ca + usrP[0] + ".bias", nu * d, gbuf))
         dXv_in = st.buf("dXv_in%d" % (i & 1), (Mv, d))
-        _lin_dgrad(st, Mv, d, nv * d, dYv, ca + vidP[0] + ".weight", dXv_in, residual=dR1v, ldr=d, res_period=Mv, a_amax=am_dYv)
+        _lin_dgrad(st, Mv, d, nv * d, dYv, ca + vidP[0] + ".weight", dXv_in, residual=dR1v, ldr=d, res_period=Mv)
         dXu_in = None
         if nu:
             dXu_in = st.buf("dXu_in%d" % (i & 1), (Mu, d))
             if full:
-                _lin_dgrad(st, Mu, d, nu * d, dYu, ca + usrP[0] + ".weight", dXu_in, residual=dR1u, ldr=d, res_period=Mu, a_amax=am_dYu)
+                _lin_dgrad(st, Mu, d, nu * d, dYu, ca + usrP[0] + ".weight", dXu_in, residual=dR1u, ldr=d, res_period=Mu)
             else:
-                _lin_dgrad(st, Mu, d, nu * d, dYu, ca + usrP[0] + ".weight", dXu_in, a_amax=am_dYu)
+                _lin_dgrad(st, Mu, d, nu * d, dYu, ca + usrP[0] + ".weight", dXu_in)
         return dXv_in, dXu_in
 
     def backward(self, d_vid_out: torch.Tensor, gbuf: Optional[torch.Tensor] = None, on_bucket=None):
@@ -869,7 +1008,7 @@ class BackboneRun:
         B, S, Lt, Mv, Mu = self.B, self.S, self.Lt, self.Mv, self.Mu
         dXv = d_vid_out.contiguous().view(-1, d)
         dXu = None
-        self.amb = AmaxArena(st, 4 + 8 * max(self.N - 1, 0))
+        self.amb = AmaxArena(st, 4 + 8 * max(self.N - 1, 0) + 2 * (self.n_mlp + 2))
         if self.abl in MLP_VARIANTS:
             if self.abl == "CrossMLP":
                 dZu, dZv = st.buf("pool_du", (Mu, d)), st.buf("pool_dv", (Mv, d))
@@ -890,22 +1029,23 @@ class BackboneRun:
         # ---- embedding backward.  User side first: its weight gradient (the larger one) queues on the side stream
         # behind the projection weight gradients still running there, the video side's runs on the main stream.
         if dXu is not None:
-            dpre_u = st.buf("dpre_u", (Mu, d))
-            am_du = self.amb.new()
-            _ln_bwd(st, dXu, sv["pre_u"], sv["meu"], sv["reu"], P + "usr_ln.weight", P + "usr_ln.bias", gbuf, dpre_u, None, Mu, d,
-                    drop_y=(self.p_drop, _site(self.bi, 0, K_EMB_U)), seed=self.seed, amax=am_du)
-            self._embed_bwd("usr", dpre_u, B, Lt, gbuf, am_du)
-        dpre_v = st.buf("dpre_v", (Mv, d))
-        am_dv = self.amb.new()
-        _ln_bwd(st, dXv, sv["pre_v"], sv["mev"], sv["rev"], P + "vid_ln.weight", P + "vid_ln.bias", gbuf, dpre_v, None, Mv, d,
-                drop_y=(self.p_drop, _site(self.bi, 0, K_EMB_V)), seed=self.seed, amax=am_dv)
-        self._embed_bwd("vid", dpre_v, B, S, gbuf, am_dv)
+            dpre_u = new_act(st, self.amb, Mu, d, key="dpre_u", planes=not bb.id_usr)
+            _ln_bwd(st, dXu, sv["pre_u"], sv["meu"], sv["reu"], P + "usr_ln.weight", P + "usr_ln.bias", gbuf, dpre_u.t, None, Mu, d,
+                    drop_y=(self.p_drop, _site(self.bi, 0, K_EMB_U)), seed=self.seed, amax=dpre_u.slots)
+            finish_act(st, dpre_u)
+            self._embed_bwd("usr", dpre_u, B, Lt, gbuf)
+        dpre_v = new_act(st, self.amb, Mv, d, key="dpre_v", planes=not bb.id_vid)
+        _ln_bwd(st, dXv, sv["pre_v"], sv["mev"], sv["rev"], P + "vid_ln.weight", P + "vid_ln.bias", gbuf, dpre_v.t, None, Mv, d,
+                drop_y=(self.p_drop, _site(self.bi, 0, K_EMB_V)), seed=self.seed, amax=dpre_v.slots)
+        finish_act(st, dpre_v)
+        self._embed_bwd("vid", dpre_v, B, S, gbuf)
         join_side(st)
         if on_bucket is not None:
             on_bucket(P + "embed")
 
-    def _embed_bwd(self, side, dpre, B, L, gbuf, am_dpre=None):
+    def _embed_bwd(self, side, dpre_act, B, L, gbuf):
         st, bb, P, d, sv = self.store, self.bb, self.pre, self.d, self.sv
+        dpre = dpre_act.t
         M = B * L
         is_id = bb.id_vid if side == "vid" else bb.id_usr
         gpe = st.g(P + "%s_pe.weight" % side, gbuf)
@@ -945,13 +1085,13 @@ class BackboneRun:
                     _colsum(st, gpe, d, L, dh_, st.g(P + "frameid_proj.weight", gbuf).view(-1), x_off=dh_, w=pos)
         else:
             x = sv["%s_x" % side]
-            Din = x.shape[-1]
+            Din = x.cols
             # The backward ends with the side stream still working through the big projection weight gradients while the
             # main stream runs dry: the video-side embedding weight gradient (the main stream's last GEMM-sized job
             # before the user side) therefore runs on the MAIN stream, the user-side one on the side stream.
             ctx = contextlib.nullcontext() if (side == "vid" and st.tail_balance) else side_work(st)
             with ctx:
-                _wgrad(st, dpre, d, 0, x, Din, 0, M, d, Din, gtab, a_amax=am_dpre, b_amax=sv["am_%s_x" % side])
+                _wgrad(st, dpre_act, 0, x, 0, M, d, Din, gtab)
                 # bias gradient = sum over all tokens of dpre = sum over positions of the positional-embedding
                 # gradient just computed ([L, d] instead of a second pass over [B*L, d])
                 _colsum(st, gpe, d, L, d, st.g(P + "%s_proj.bias" % side, gbuf))

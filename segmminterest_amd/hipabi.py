@@ -120,12 +120,14 @@ def _f32c(t, name="tensor"):
 
 GEMM_PROFILE = None       # bench.py sets this to a list to time every GEMM launch with HIP events
 ATTN_PROFILE = None       # ... and every attention launch: (kind, B, H, dh, Lq, La, Lb, event0, event1)
-ENGINE_F32, ENGINE_BF16X6, ENGINE_F16X3 = 0, 1, 2
+ENGINE_F32, ENGINE_BF16X6, ENGINE_F16X3, ENGINE_F16X3P = 0, 1, 2, 3
 # default engine of gemm(): the scaled two-term fp16 split on the fp16 matrix cores (22-bit operands, three exact
 # partial products, fp32 accumulation: measured error vs fp64 at or below the f32-MFMA kernel's on every layout).
 # SEGMM_GEMM=bf16x6 selects the exact 3-way bf16 split (six products), SEGMM_GEMM=f32 the f32-input MFMA kernel
 # (A/B and parity cross-checks)
-GEMM_ENGINE = {"f32": 0, "bf16x6": 1, "f16x3": 2}[os.environ.get("SEGMM_GEMM", "f16x3")]
+# "f16x3p" (default): the same fp16x3 arithmetic with operands PRE-SPLIT into fp16 planes by their producers and staged by
+# LDS-DMA (gemm_p / csrc/gemm_planes.h); raw gemm() calls under it run the on-the-fly fp16x3 kernel.
+GEMM_ENGINE = {"f32": 0, "bf16x6": 1, "f16x3": 2, "f16x3p": 3}[os.environ.get("SEGMM_GEMM", "f16x3p")]
 AMAX_SLOTS = 256          # partial maxima per tensor written by the fused producers (SEGMM_AMAX_SLOTS)
 AMAX_PARTS = 1024         # ... and by the stand-alone absmax() pass
 LAYOUT_NT, LAYOUT_NN, LAYOUT_TN = 0, 1, 2
@@ -155,6 +157,8 @@ def gemm(layout, M, N, K, A, lda, B, ldb, Cout, ldc, bias=None, row_scale=None, 
         e0 = torch.cuda.Event(enable_timing=True)
         e0.record()
     eng = GEMM_ENGINE if engine is None else int(engine)
+    if eng == ENGINE_F16X3P:
+        eng = ENGINE_F16X3
     if eng == ENGINE_F16X3:
         if a_amax is None:
             if a_planes is not None:
@@ -254,8 +258,9 @@ def to_planes(x, rows, cols, ld=None, x_off=0, keep_f32=True):
 
 def gemm_p(layout, M, N, K, A: "PT", B: "PT", Cout, ldc, c_pt: "PT" = None, write_c=True, bias=None, row_scale=None, residual=None,
            ldr=0, res_period=0, activation=0, aux=None, ldaux=0, drop_p=0.0, seed=0, site=0, splits=1, workspace=None,
-           accumulate=False, c_off=0):
-    """Plane-operand GEMM (segmm_gemm_p).  ``c_pt``: optional plane output (its hdr[0] holds the scale to write with)."""
+           accumulate=False, c_off=0, c_hdr=None):
+    """Plane-operand GEMM (segmm_gemm_p).  ``c_pt``: optional plane output (its hdr[0] holds the scale to write with);
+    ``c_hdr``: site header that only receives the partial maxima of |C| (no plane output)."""
     prof = GEMM_PROFILE
     if prof is not None:
         e0 = torch.cuda.Event(enable_timing=True)
@@ -263,7 +268,8 @@ def gemm_p(layout, M, N, K, A: "PT", B: "PT", Cout, ldc, c_pt: "PT" = None, writ
     _check(lib().segmm_gemm_p(layout, M, N, K, A.pptr(), A.ld2, A.hdr.data_ptr(), A.fptr(), A.ldf, B.pptr(), B.ld2, B.hdr.data_ptr(),
                               B.fptr(), B.ldf, None if Cout is None else Cout.data_ptr() + 4 * c_off, ldc,
                               None if c_pt is None else c_pt.pptr(), 0 if c_pt is None else c_pt.ld2,
-                              None if c_pt is None else c_pt.hdr.data_ptr(), int(bool(write_c)), _ptr(bias), _ptr(row_scale), _ptr(residual),
+                              (None if c_hdr is None else c_hdr.data_ptr()) if c_pt is None else c_pt.hdr.data_ptr(), int(bool(write_c)),
+                              _ptr(bias), _ptr(row_scale), _ptr(residual),
                               ldr, res_period, activation, _ptr(aux), ldaux, float(drop_p), int(seed), int(site), int(splits),
                               _ptr(workspace), int(bool(accumulate)), _stream()), "segmm_gemm_p")
     if prof is not None:

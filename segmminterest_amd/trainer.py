@@ -305,17 +305,19 @@ class Trainer:
         buf = self._norm.get(key)
         if buf is None or buf.shape != x.shape or buf.device != x.device:
             buf = self._norm[key] = torch.empty_like(x)
-        st = self.model._store
-        am = None
-        if H.GEMM_ENGINE == H.ENGINE_F16X3:
-            # the fp16x3 GEMM that reads ``buf`` needs max|buf|: folded into this kernel instead of a separate pass over
-            # the features (engine.BackboneRun looks it up by the buffer's address)
+        hdr = None
+        if H.GEMM_ENGINE in (H.ENGINE_F16X3, H.ENGINE_F16X3P):
+            # the fp16x3 GEMM that reads ``buf`` needs max|buf|: folded into this kernel instead of a separate pass over the
+            # features.  The site header travels WITH the tensor object (attribute), never keyed by its device address: a
+            # tensor the trainer did not produce in this step (rand_like for 'noUser', features handed straight to model())
+            # has no header and gets an absmax pass in engine.BackboneRun._input_act.
             if self._norm_amax is None or self._norm_amax.device != x.device:
-                self._norm_amax = torch.empty((2, H.AMAX_SLOTS), dtype=torch.float32, device=x.device)
+                self._norm_amax = torch.empty((2, H.SITE_FLOATS), dtype=torch.float32, device=x.device)
             if key == "user" or "user" not in self._norm:
                 self._norm_amax.zero_()          # one fill per step: "user" is normalised first (see _features)
-            am = self._norm_amax[0 if key == "user" else 1]
-            st.ext_amax[buf.data_ptr()] = am
+            hdr = self._norm_amax[0 if key == "user" else 1]
+            buf._segmm_hdr = hdr
+        am = None if hdr is None else hdr[H.SITE_HDR:]
         H.l1norm(x, buf, amax=am)
         return buf
 

@@ -97,7 +97,7 @@ def main():
             print("NT epilogue act=%d: maxdiff vs on-the-fly %.1e, plane output reconstruction %.1e, amax exact %s %s" % (act, d, dr, amax_ok, "ok" if good else "FAIL"))
     if "tn" in args.layouts:
         for (M, N, K) in tn_shapes:
-            if K % 32 or M % 32 or N % 32:
+            if M % 32 or N % 32:
                 continue
             dY = torch.randn(K, M, device=dev) * 0.01
             X = torch.randn(K, N, device=dev)
