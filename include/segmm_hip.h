@@ -30,7 +30,15 @@ int segmm_abi_version(void);
 /* a1 -- trainer L1 normalisation  x / (sum|x| + 1e-6)  (main_for_seq_leave_earlystop_SegMM.py:272-273).
  * y may be NULL: then only inv_scale[row] = 1/(sum|x|+1e-6) is produced, for the fused a1+a2 GEMM (row_scale).
  * amax: optional zeroed [SEGMM_AMAX_SLOTS] array receiving the partial maxima of |y| (see segmm_gemm_h). */
-int segmm_l1norm(const float* x, float* y, float* inv_scale, int64_t rows, int D, float* amax, segmm_stream_t stream);
+int segmm_l1norm(const float* x, float* y, float* inv_scale, int64_t rows, int D, float* amax, uint16_t* planes, int ld2, float* hdr,
+                 const float* scale_in, segmm_stream_t stream);
+/* PLANE OUTPUTS of producers (the four trailing arguments `planes, ld2, hdr, scale_in` of segmm_l1norm, segmm_gather_l1,
+ * segmm_layernorm_fwd / _bwd; segmm_attn_planes_t; c_planes / c_hdr / c_scale_in of segmm_gemm_p): a kernel that writes a
+ * tensor some GEMM reads can also write that tensor's P32 fp16 planes (format: segmm_gemm_p) with the DELAYED scale
+ * *scale_in -- a device scalar, the power of two that segmm_scales_update derived from the maxima the tensor site had on
+ * earlier passes.  The kernel stores the scale it used in hdr[0], folds the partial maxima of what it wrote into the header's
+ * slots and raises hdr[1] if an element left the fp16 range (consumers then read the fp32 copy).  planes == NULL, scale_in ==
+ * NULL or *scale_in == 0: no planes are written (the caller runs segmm_split_p32 with the exact scale instead). */
 
 /* K2/K3/K5/K6 -- every nn.Linear of the path and its gradients (encoder.py:95-104,163-167,183-184,438,445;
  * kn_util/nn_utils/layers/mlp.py:17-23), on the f32 MFMA.
@@ -85,13 +93,13 @@ int segmm_gemm_h(int layout, int M, int N, int K, const float* A, int lda, const
  * 163-167,183-184,438,445; kn_util/nn_utils/layers/mlp.py:17-23).
  *   layout 0 (NT): C[M,N] = A[M,K] . B[N,K]^T  A planes [M][2K], B planes [N][2K]          (forward; dgrad on W^T planes)
  *   layout 2 (TN): C[M,N] = A[K,M]^T . B[K,N]  A planes [K][2M], B planes [K][2N], split-K  (weight gradients)
- * Output: fp32 C (unless write_c == 0) and/or P32 planes c_planes with the scale found in c_hdr[0]; the partial maxima
- * of |C| and the overflow flag are folded into c_hdr (caller zeroes slots and flag, sets the scale).  Epilogue as
- * segmm_gemm.  K % 32 == 0. */
+ * Output: fp32 C (unless write_c == 0) and/or P32 planes c_planes written with the scale *c_scale_in; the partial maxima
+ * of |C|, the overflow flag and the scale used are folded into c_hdr (caller zeroes the header).  Epilogue as
+ * segmm_gemm.  NT: K % 32 == 0; TN: M, N % 32 == 0 (token tails are zero-filled). */
 #define SEGMM_SITE_HDR 8
 int segmm_gemm_p(int layout, int M, int N, int K, const uint16_t* a_planes, int lda2, const float* a_hdr, const float* a_f32, int ldaf,
                  const uint16_t* b_planes, int ldb2, const float* b_hdr, const float* b_f32, int ldbf, float* C, int ldc,
-                 uint16_t* c_planes, int ldc2, float* c_hdr, int write_c, const float* bias, const float* row_scale,
+                 uint16_t* c_planes, int ldc2, float* c_hdr, const float* c_scale_in, int write_c, const float* bias, const float* row_scale,
                  const float* residual, int ldr, int res_period, int activation, float* aux, int ldaux, float drop_p,
                  uint64_t seed, uint32_t site, int splits, float* workspace, int accumulate, segmm_stream_t stream);
 /* fp32 [rows, cols] (row stride ld) -> P32 planes.  mode 0: exact scale from the header's partial maxima (complete when
@@ -127,12 +135,12 @@ int segmm_split3_transpose(const float* x, int R, int C, int ld, uint16_t* plane
  * the bias gradient of the Linear whose output entered the LayerNorm through the residual branch. */
 int segmm_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                         int64_t rows, int d, float eps, float drop_p, uint64_t seed, uint32_t site, float* amax,
-                        segmm_stream_t stream);
+                        uint16_t* planes, int ld2, float* hdr, const float* scale_in, segmm_stream_t stream);
 int segmm_layernorm_bwd_parts(int64_t rows);
 int segmm_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                         float* dx, float* dx_drop, float* part_dgamma, float* part_dbeta, float* part_dsum, int64_t rows,
                         int d, float drop_y_p, uint32_t drop_y_site, float drop_b_p, uint32_t drop_b_site, uint64_t seed,
-                        float* amax, segmm_stream_t stream);
+                        float* amax, uint16_t* planes, int ld2, float* hdr, const float* scale_in, segmm_stream_t stream);
 
 /* out[n] (+)= sum_m w[m] * X[m,n]  (bias gradients, LayerNorm partial combine, head weight gradient).
  * workspace: segmm_colsum_chunks(M) * N floats. */
@@ -150,16 +158,29 @@ int segmm_colsum(const float* X, int ld, const float* w, int64_t M, int N, float
  * and 3 are independent once phase 1 is complete and may run concurrently on two streams; 4 = dQ, dK and dV in ONE kernel
  * (one workgroup per (b, h, key block), query side staged in LDS in chunks of 48 rows, D formed inside -- Dvec is not
  * used; <= 12 key tiles per block). */
+/* optional plane outputs of the attention kernels (see "PLANE OUTPUTS of producers"): the forward's O; in the fused backward
+ * (phase 4) the query-side gradients dQa / dQb (one site: they are columns of the same buffer) and the key-side gradients
+ * of block a (dKa, dVa) and block b (dKb, dVb).  Each plane pointer addresses the same column slice as its fp32 twin. */
+typedef struct {
+    uint16_t* o; int ldo2; float* hdr_o; const float* sin_o;
+    uint16_t *dqa, *dqb; int lddq2;
+    uint16_t *dka, *dva; int lddka2;
+    uint16_t *dkb, *dvb; int lddkb2;
+    float *hdr_q, *hdr_ka, *hdr_kb;
+    const float *sin_q, *sin_ka, *sin_kb;
+} segmm_attn_planes_t;
 int segmm_attn_fwd(int B, int H, int dh, int Lq, int La, int Lb, const float* Qa, const float* Qb, int ldq,
                    const float* Ka, const float* Va, int ldka, const float* Kb, const float* Vb, int ldkb,
                    const uint8_t* mq, const uint8_t* mka, const uint8_t* mkb, float* O, int ldo, float* lse,
-                   float drop_p, uint64_t seed, uint32_t site, float* amax_o, segmm_stream_t stream);
+                   float drop_p, uint64_t seed, uint32_t site, float* amax_o, const segmm_attn_planes_t* planes,
+                   segmm_stream_t stream);
 int segmm_attn_bwd(int B, int H, int dh, int Lq, int La, int Lb, const float* Qa, const float* Qb, int ldq,
                    const float* Ka, const float* Va, int ldka, const float* Kb, const float* Vb, int ldkb,
                    const uint8_t* mq, const uint8_t* mka, const uint8_t* mkb, const float* lse, const float* O, int ldo,
                    const float* dO, int lddo, float* Dvec, float* dQa, float* dQb, int lddq, float* dKa, float* dVa, int lddka,
                    float* dKb, float* dVb, int lddkb, float drop_p, uint64_t seed, uint32_t site,
-                   float* amax_q, float* amax_ka, float* amax_kb, int phase, segmm_stream_t stream);
+                   float* amax_q, float* amax_ka, float* amax_kb, int phase, const segmm_attn_planes_t* planes,
+                   segmm_stream_t stream);
 
 /* K7 -- interest head Linear(d,1) (decoder_leave_focal.py:451,596): out[m] (+)= x[m,:].w (+ bias[0]) and
  * dx[m,:] (+)= g[m]*w.  segmm_vecsum: deterministic out[0] (+)= sum v. */
@@ -232,7 +253,12 @@ int segmm_survival(const float* interest, int ld, const int64_t* gt, float* surv
 /* (f)-1 resident-table feature gather (dataloader_SegMM.py:271-362 + the trainer's L1 normalisation): out[r, :] =
  * table[idx[r], :] (/ (sum|.| + 1e-6) if normalize), mask[r] = 1, for idx[r] in [0, n_lines); zeros / 0 otherwise. */
 int segmm_gather_l1(const float* table, int64_t n_lines, int D, const int64_t* idx, int64_t rows, int normalize, float* out,
-                    uint8_t* mask, segmm_stream_t stream);
+                    uint8_t* mask, float* amax, uint16_t* planes, int ld2, float* hdr, const float* scale_in, segmm_stream_t stream);
+/* Delayed scaling, end of a pass: arena = the pass's n_rows site headers, site_idx[r] = index of row r's tensor site in
+ * site_scale (< 0: none).  site_scale[idx] = the power of two s with max|x| * s in [2^(target-1), 2^target) for every row
+ * that was produced; stats[0] += number of rows whose overflow flag is up. */
+int segmm_scales_update(const float* arena, const int32_t* site_idx, int n_rows, float* site_scale, float* stats, int target,
+                        segmm_stream_t stream);
 /* (f)-3 SegRec weighted head (ClipRec.forward, SegRec/models/context/ClipRec.py:163-181): out[r] = sum_seg pred[r, seg] *
  * weight[r, seg] * (seg < duration[r]); weight == null: ones, duration == null: no duration mask. */
 int segmm_segment_weighted_sum(const float* pred, const float* weight, const int64_t* duration, int64_t rows, int S, float* out,

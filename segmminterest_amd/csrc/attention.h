@@ -64,6 +64,15 @@ struct AttnArgs {
     // optional partial maxima (AMAX_SLOTS each, common.h) of what the kernels write, for the fp16x3 GEMM engine:
     float* amax_o;                      // forward: |O|
     float *amax_q, *amax_ka, *amax_kb;  // backward: |dQa|,|dQb| ; |dKa|,|dVa| ; |dKb|,|dVb|
+    // optional P32 plane outputs (common.h PlaneOut protocol): the forward's O, and -- fused backward only -- the three
+    // gradient buffers (query side: dQa/dQb columns; key block a: dKa/dVa; key block b: dKb/dVb).  The plane pointers
+    // address the same column slices as their fp32 twins (slice starts are multiples of 32 columns).
+    PlaneOut po_o;
+    _Float16 *dQap, *dQbp; int lddq2;
+    _Float16 *dKap, *dVap; int lddka2;
+    _Float16 *dKbp, *dVbp; int lddkb2;
+    float *hdr_q, *hdr_ka, *hdr_kb;
+    const float *sin_q, *sin_ka, *sin_kb;
 };
 
 #ifndef ATT_PF
@@ -160,6 +169,28 @@ __device__ __forceinline__ float col_store(float* rowp, const f32x4 (&o)[(DH + 1
         for (int i = 0; i < CT; ++i) {
             const f32x4 v = {t[4 * i], t[4 * i + 1], t[4 * i + 2], t[4 * i + 3]};
             *(f32x4*)(rowp + 4 * CT * g + 4 * i) = v;
+            am = absmax4(am, v);
+        }
+    }
+    return am;
+}
+
+// the same store plus the P32 planes of the values (row = absolute row of the output tensor, col0 = first column of the head)
+template <int DH>
+__device__ __forceinline__ float col_store_p(float* rowp, _Float16* planes, int ld2, long long row, int col0, float ps,
+                                             const f32x4 (&o)[(DH + 15) / 16], int g, float am) {
+    constexpr int CT = (DH + 15) / 16;
+    if (4 * CT * g < DH) {
+        float t[4 * CT];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) t[CT * r + ct] = o[ct][r];
+#pragma unroll
+        for (int i = 0; i < CT; ++i) {
+            const f32x4 v = {t[4 * i], t[4 * i + 1], t[4 * i + 2], t[4 * i + 3]};
+            *(f32x4*)(rowp + 4 * CT * g + 4 * i) = v;
+            plane_store4(planes, ld2, row, col0 + 4 * CT * g + 4 * i, v, ps);
             am = absmax4(am, v);
         }
     }
@@ -340,8 +371,13 @@ __global__ __launch_bounds__(ATT_MAX_THREADS) void attn_fwd_kernel(const AttnArg
         }
     }
     float am = 0.f;
-    if (q_in) am = col_store<DH>(p.O + qrow * p.ldo + col0, o, g, am);
-    if (p.amax_o) amax_commit(p.amax_o, am, (blockIdx.x * gridDim.y + blockIdx.y) * wpb + wave);
+    const float ps = plane_scale(p.po_o);
+    if (q_in) {
+        if (ps > 0.f) am = col_store_p<DH>(p.O + qrow * p.ldo + col0, p.po_o.p, p.po_o.ld2, (long long)qrow, col0, ps, o, g, am);
+        else am = col_store<DH>(p.O + qrow * p.ldo + col0, o, g, am);
+    }
+    plane_finish(p.po_o, p.amax_o, am, (blockIdx.x * gridDim.y + blockIdx.y) * wpb + wave, ps,
+                 blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0);
 }
 
 // ------------------------------------------------------------------------------------------ backward: dQ (+ D)
@@ -725,6 +761,10 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_bwd_fused_kernel(const AttnAr
     }
     const float* Qg = isa ? p.Qa : p.Qb;
     float* dQg = isa ? p.dQa : p.dQb;
+    _Float16* dQgp = isa ? p.dQap : p.dQbp;
+    const float s_q = (dQgp && p.sin_q) ? *p.sin_q : 0.f;
+    const float* sin_k = isa ? p.sin_ka : p.sin_kb;
+    const float s_k = ((isa ? p.dKap : p.dKbp) && sin_k) ? *sin_k : 0.f;
     const float fscale = p.scale;
     const int jp = 16 * jt + l15;                          // this lane's key (padded index)
     f32x4 dk[C::CT], dv[C::CT];
@@ -872,6 +912,7 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_bwd_fused_kernel(const AttnAr
             const size_t row = (size_t)b * p.Lq + q0 + q;
             const f32x4 v = *(const f32x4*)(sdQ + q * RS + c);
             *(f32x4*)(dQg + row * p.lddq + col0 + c) = v;
+            if (s_q > 0.f) plane_store4(dQgp, p.lddq2, (long long)row, col0 + c, v, s_q);
             am_q = absmax4(am_q, v);
         }
         if (!ONE && q0 + QC < p.Lq) __syncthreads();       // the next chunk's staging overwrites what was just read
@@ -885,19 +926,30 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_bwd_fused_kernel(const AttnAr
         if (real) {
             float* dKp = (ka ? p.dKa + (size_t)(b * p.La + jloc) * p.lddka : p.dKb + (size_t)(b * p.Lb + jloc) * p.lddkb) + col0;
             float* dVp = (ka ? p.dVa + (size_t)(b * p.La + jloc) * p.lddka : p.dVb + (size_t)(b * p.Lb + jloc) * p.lddkb) + col0;
+            const long long krow = ka ? (long long)b * p.La + jloc : (long long)b * p.Lb + jloc;
+            _Float16* dKpp = ka ? p.dKap : p.dKbp;
+            _Float16* dVpp = ka ? p.dVap : p.dVbp;
+            const int ldk2 = ka ? p.lddka2 : p.lddkb2;
 #pragma unroll
             for (int ct = 0; ct < C::CT; ++ct) {
                 if (16 * ct + 4 * g < DH) {
                     *(f32x4*)(dKp + 16 * ct + 4 * g) = dk[ct];
                     *(f32x4*)(dVp + 16 * ct + 4 * g) = dv[ct];
+                    if (s_k > 0.f) {
+                        plane_store4(dKpp, ldk2, krow, col0 + 16 * ct + 4 * g, dk[ct], s_k);
+                        plane_store4(dVpp, ldk2, krow, col0 + 16 * ct + 4 * g, dv[ct], s_k);
+                    }
                     am = absmax4(absmax4(am, dk[ct]), dv[ct]);
                 }
             }
         }
+        float* hk = isa ? p.hdr_ka : p.hdr_kb;
         float* slot = isa ? p.amax_ka : p.amax_kb;
-        if (slot) amax_commit(slot, am, blockIdx.x * nw + wave);
+        if (s_k > 0.f) { site_commit(hk, am, blockIdx.x * nw + wave, s_k); if (lane == 0) hk[0] = s_k; }
+        else if (slot) amax_commit(slot, am, blockIdx.x * nw + wave);
+        if (s_q > 0.f) { site_commit(p.hdr_q, am_q, blockIdx.x * nw + wave, s_q); if (lane == 0) p.hdr_q[0] = s_q; }
+        else if (p.amax_q) amax_commit(p.amax_q, am_q, blockIdx.x * nw + wave);
     }
-    if (p.amax_q) amax_commit(p.amax_q, am_q, blockIdx.x * nw + wave);
     ATT_MARK(5);
 }
 

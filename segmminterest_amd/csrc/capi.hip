@@ -183,15 +183,26 @@ __global__ void dropout_mult_kernel(float* out, long long n, DropCfg d) {
 extern "C" {
 
 const char* segmm_last_error(void) { return g_segmm_err; }
-int segmm_abi_version(void) { return 10; }
+int segmm_abi_version(void) { return 11; }
 
-int segmm_l1norm(const float* x, float* y, float* inv_scale, int64_t rows, int D, float* amax, segmm_stream_t stream) {
+static PlaneOut plane_out(uint16_t* planes, int ld2, float* hdr, const float* scale_in) {
+    PlaneOut po;
+    po.p = (_Float16*)planes; po.ld2 = ld2; po.hdr = hdr; po.scale_in = scale_in;
+    return po;
+}
+#define PLANE_OUT_CHECK(what, cols)                                                                                          \
+    SEGMM_REQUIRE(!planes || (hdr && (cols) % 32 == 0 && ld2 % 64 == 0 && ld2 >= 2 * (cols) && aligned16(planes)),             \
+                  what ": plane output needs a header, cols %% 32, ld2 %% 64, 16-byte alignment")
+
+int segmm_l1norm(const float* x, float* y, float* inv_scale, int64_t rows, int D, float* amax, uint16_t* planes, int ld2, float* hdr,
+                 const float* scale_in, segmm_stream_t stream) {
+    PLANE_OUT_CHECK("l1norm", D);
     SEGMM_REQUIRE(x && (y || inv_scale), "l1norm: null pointer");
     SEGMM_REQUIRE(D > 0 && D % 4 == 0 && aligned16(x) && (!y || aligned16(y)), "l1norm: D %% 4 / alignment (D=%d)", D);
     if (rows <= 0) return 0;
     const int wpb = 4;
     hipLaunchKernelGGL(l1norm_kernel, dim3((unsigned)((rows + wpb - 1) / wpb)), dim3(64 * wpb), 0, (hipStream_t)stream,
-                       x, y, inv_scale, (long long)rows, D, amax);
+                       x, y, inv_scale, (long long)rows, D, amax, plane_out(planes, ld2, hdr, scale_in));
     LAUNCH_CHECK();
     return 0;
 }
@@ -365,7 +376,7 @@ int segmm_gemm_h(int layout, int M, int N, int K, const float* A, int lda, const
 /* ---- plane-operand GEMM (gemm_planes.h) */
 int segmm_gemm_p(int layout, int M, int N, int K, const uint16_t* a_planes, int lda2, const float* a_hdr, const float* a_f32, int ldaf,
                  const uint16_t* b_planes, int ldb2, const float* b_hdr, const float* b_f32, int ldbf, float* C, int ldc,
-                 uint16_t* c_planes, int ldc2, float* c_hdr, int write_c, const float* bias, const float* row_scale,
+                 uint16_t* c_planes, int ldc2, float* c_hdr, const float* c_scale_in, int write_c, const float* bias, const float* row_scale,
                  const float* residual, int ldr, int res_period, int activation, float* aux, int ldaux, float drop_p,
                  uint64_t seed, uint32_t site, int splits, float* workspace, int accumulate, segmm_stream_t stream) {
     SEGMM_REQUIRE(layout == 0 || layout == 2, "gemm_p: layout %d (0 = NT, 2 = TN)", layout);
@@ -396,7 +407,7 @@ int segmm_gemm_p(int layout, int M, int N, int K, const uint16_t* a_planes, int 
     memset(&q, 0, sizeof(q));
     q.A.p = (const _Float16*)a_planes; q.A.ld2 = lda2; q.A.hdr = a_hdr; q.A.f32 = a_f32; q.A.ldf = ldaf;
     q.B.p = (const _Float16*)b_planes; q.B.ld2 = ldb2; q.B.hdr = b_hdr; q.B.f32 = b_f32; q.B.ldf = ldbf;
-    q.Cp = (_Float16*)c_planes; q.ldc2 = ldc2; q.c_hdr = c_hdr; q.write_c = C ? (write_c != 0) : 0;
+    q.Cp = (_Float16*)c_planes; q.ldc2 = ldc2; q.c_hdr = c_hdr; q.c_scale_in = c_scale_in; q.write_c = C ? (write_c != 0) : 0;
     static const int pl_flags = getenv("SEGMM_PL_FLAGS") ? atoi(getenv("SEGMM_PL_FLAGS")) : 0;
     q.dbg = pl_flags;
     hipStream_t s = (hipStream_t)stream;
@@ -523,14 +534,15 @@ int segmm_split3_transpose(const float* x, int R, int Cc, int ld, uint16_t* plan
 
 int segmm_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                         int64_t rows, int d, float eps, float drop_p, uint64_t seed, uint32_t site, float* amax,
-                        segmm_stream_t stream) {
+                        uint16_t* planes, int ld2, float* hdr, const float* scale_in, segmm_stream_t stream) {
     SEGMM_REQUIRE(x && gamma && beta && y && mean && rstd, "layernorm_fwd: null pointer");
+    PLANE_OUT_CHECK("layernorm_fwd", d);
     SEGMM_REQUIRE(d > 0 && d % 4 == 0 && d <= 256 * ROW_MAXV, "layernorm_fwd: d=%d unsupported", d);
     SEGMM_REQUIRE(aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta), "layernorm_fwd: alignment");
     if (rows <= 0) return 0;
     const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
     const DropCfg dc = make_drop(drop_p, seed, site);
-#define LNF(V) hipLaunchKernelGGL((layernorm_fwd_kernel<V>), grid, block, 0, (hipStream_t)stream, x, gamma, beta, y, mean, rstd, (long long)rows, d, eps, dc, amax)
+#define LNF(V) hipLaunchKernelGGL((layernorm_fwd_kernel<V>), grid, block, 0, (hipStream_t)stream, x, gamma, beta, y, mean, rstd, (long long)rows, d, eps, dc, amax, plane_out(planes, ld2, hdr, scale_in))
     if (d <= 256) LNF(1); else if (d <= 512) LNF(2); else if (d <= 768) LNF(3); else if (d <= 1024) LNF(4); else LNF(8);
 #undef LNF
     LAUNCH_CHECK();
@@ -547,13 +559,14 @@ int segmm_layernorm_bwd_parts(int64_t rows) {
 int segmm_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                         float* dx, float* dx_drop, float* part_dgamma, float* part_dbeta, float* part_dsum, int64_t rows,
                         int d, float drop_y_p, uint32_t drop_y_site, float drop_b_p, uint32_t drop_b_site, uint64_t seed,
-                        float* amax, segmm_stream_t stream) {
+                        float* amax, uint16_t* planes, int ld2, float* hdr, const float* scale_in, segmm_stream_t stream) {
     SEGMM_REQUIRE(dy && x && mean && rstd && gamma && dx && part_dgamma && part_dbeta, "layernorm_bwd: null pointer");
+    PLANE_OUT_CHECK("layernorm_bwd", d);
     SEGMM_REQUIRE(d > 0 && d % 4 == 0 && d <= 256 * ROW_MAXV, "layernorm_bwd: d=%d unsupported", d);
     SEGMM_REQUIRE(aligned16(dy) && aligned16(x) && aligned16(dx) && aligned16(gamma) && (!dx_drop || aligned16(dx_drop)), "layernorm_bwd: alignment");
     const int parts = segmm_layernorm_bwd_parts(rows);
     const DropCfg dy_ = make_drop(drop_y_p, seed, drop_y_site), db_ = make_drop(drop_b_p, seed, drop_b_site);
-#define LNB(V) hipLaunchKernelGGL((layernorm_bwd_kernel<V>), dim3(parts), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma, dx, dx_drop, part_dgamma, part_dbeta, part_dsum, (long long)rows, d, dy_, db_, amax)
+#define LNB(V) hipLaunchKernelGGL((layernorm_bwd_kernel<V>), dim3(parts), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma, dx, dx_drop, part_dgamma, part_dbeta, part_dsum, (long long)rows, d, dy_, db_, amax, plane_out(planes, ld2, hdr, scale_in))
     if (d <= 256) LNB(1); else if (d <= 512) LNB(2); else if (d <= 768) LNB(3); else if (d <= 1024) LNB(4); else LNB(8);
 #undef LNB
     LAUNCH_CHECK();
@@ -606,13 +619,17 @@ int segmm_colsum(const float* X, int ld, const float* w, int64_t M, int N, float
 int segmm_attn_fwd(int B, int H, int dh, int Lq, int La, int Lb, const float* Qa, const float* Qb, int ldq,
                    const float* Ka, const float* Va, int ldka, const float* Kb, const float* Vb, int ldkb,
                    const uint8_t* mq, const uint8_t* mka, const uint8_t* mkb, float* O, int ldo, float* lse,
-                   float drop_p, uint64_t seed, uint32_t site, float* amax_o, segmm_stream_t stream) {
+                   float drop_p, uint64_t seed, uint32_t site, float* amax_o, const segmm_attn_planes_t* pl, segmm_stream_t stream) {
     AttnArgs a;
     memset(&a, 0, sizeof(a));
     int rc = attn_fill(a, B, H, dh, Lq, La, Lb, Qa, Qb, ldq, Ka, Va, ldka, Kb, Vb, ldkb, mq, mka, mkb, drop_p, seed, site);
     if (rc) return rc;
     SEGMM_REQUIRE(O && lse && aligned16(O) && ldo % 4 == 0, "attn_fwd: output pointer/alignment");
     a.O = O; a.ldo = ldo; a.lse = lse; a.amax_o = amax_o;
+    if (pl && pl->o) {
+        SEGMM_REQUIRE(pl->hdr_o && pl->ldo2 % 64 == 0 && aligned16(pl->o) && (H * dh) % 32 == 0, "attn_fwd: plane output needs a header, ld2 %% 64, width %% 32");
+        a.po_o = plane_out(pl->o, pl->ldo2, pl->hdr_o, pl->sin_o);
+    }
     ATTN_DISPATCH(attn_launch_fwd, dh, a, (hipStream_t)stream);
 }
 
@@ -621,7 +638,7 @@ int segmm_attn_bwd(int B, int H, int dh, int Lq, int La, int Lb, const float* Qa
                    const uint8_t* mq, const uint8_t* mka, const uint8_t* mkb, const float* lse, const float* O, int ldo,
                    const float* dO, int lddo, float* Dvec, float* dQa, float* dQb, int lddq, float* dKa, float* dVa, int lddka,
                    float* dKb, float* dVb, int lddkb, float drop_p, uint64_t seed, uint32_t site,
-                   float* amax_q, float* amax_ka, float* amax_kb, int phase, segmm_stream_t stream) {
+                   float* amax_q, float* amax_ka, float* amax_kb, int phase, const segmm_attn_planes_t* pl, segmm_stream_t stream) {
     SEGMM_REQUIRE(phase >= 0 && phase <= 4, "attn_bwd: phase %d (0 all, 1 D, 2 dQ, 3 dK/dV, 4 fused dQ+dK+dV)", phase);
     AttnArgs a;
     memset(&a, 0, sizeof(a));
@@ -638,6 +655,18 @@ int segmm_attn_bwd(int B, int H, int dh, int Lq, int La, int Lb, const float* Qa
     a.do_bytes = (uint32_t)((((size_t)B * Lq - 1) * lddo + (size_t)H * dh) * 4);
     a.dQa = dQa; a.dQb = dQb; a.lddq = lddq; a.dKa = dKa; a.dVa = dVa; a.lddka = lddka; a.dKb = dKb; a.dVb = dVb; a.lddkb = lddkb;
     a.amax_q = amax_q; a.amax_ka = amax_ka; a.amax_kb = amax_kb;
+    if (pl && phase == 4 && (pl->dqa || pl->dqb || pl->dka || pl->dkb)) {          // plane outputs: fused backward only
+        SEGMM_REQUIRE(pl->lddq2 % 64 == 0 && pl->lddka2 % 64 == 0 && pl->lddkb2 % 64 == 0, "attn_bwd: plane strides %% 64");
+        SEGMM_REQUIRE((!(pl->dqa || pl->dqb) || pl->hdr_q) && (!pl->dka || (pl->dva && pl->hdr_ka)) && (!pl->dkb || (pl->dvb && pl->hdr_kb)),
+                      "attn_bwd: plane outputs need their headers (and dK and dV planes come in pairs)");
+        a.dQap = (_Float16*)pl->dqa; a.dQbp = (_Float16*)pl->dqb; a.lddq2 = pl->lddq2;
+        a.dKap = (_Float16*)pl->dka; a.dVap = (_Float16*)pl->dva; a.lddka2 = pl->lddka2;
+        a.dKbp = (_Float16*)pl->dkb; a.dVbp = (_Float16*)pl->dvb; a.lddkb2 = pl->lddkb2;
+        a.hdr_q = pl->hdr_q; a.hdr_ka = pl->hdr_ka; a.hdr_kb = pl->hdr_kb;
+        a.sin_q = pl->sin_q; a.sin_ka = pl->sin_ka; a.sin_kb = pl->sin_kb;
+        if (La == 0) { a.dQap = nullptr; a.dKap = a.dKbp; a.dVap = a.dVbp; a.lddka2 = a.lddkb2; a.hdr_ka = a.hdr_kb; a.sin_ka = a.sin_kb; }
+        if (Lb == 0) { a.dQbp = nullptr; a.dKbp = a.dKap; a.dVbp = a.dVap; a.lddkb2 = a.lddka2; a.hdr_kb = a.hdr_ka; a.sin_kb = a.sin_ka; }
+    }
     ATTN_DISPATCH(attn_launch_bwd, dh, a, phase, (hipStream_t)stream);
 }
 
@@ -813,12 +842,23 @@ int segmm_survival(const float* interest, int ld, const int64_t* gt, float* surv
     return 0;
 }
 
+int segmm_scales_update(const float* arena, const int32_t* site_idx, int n_rows, float* site_scale, float* stats, int target,
+                        segmm_stream_t stream) {
+    SEGMM_REQUIRE(arena && site_idx && site_scale && stats && n_rows >= 0 && target >= 2 && target <= 15, "scales_update: arguments");
+    if (n_rows == 0) return 0;
+    hipLaunchKernelGGL(scales_update_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, arena, (const int*)site_idx, n_rows,
+                       site_scale, stats, target);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 int segmm_gather_l1(const float* table, int64_t n_lines, int D, const int64_t* idx, int64_t rows, int normalize, float* out,
-                    uint8_t* mask, segmm_stream_t stream) {
+                    uint8_t* mask, float* amax, uint16_t* planes, int ld2, float* hdr, const float* scale_in, segmm_stream_t stream) {
+    PLANE_OUT_CHECK("gather_l1", D);
     SEGMM_REQUIRE(table && idx && out && n_lines > 0 && D > 0 && D % 4 == 0 && aligned16(table) && aligned16(out), "gather_l1: pointer / D %% 4 / alignment");
     if (rows <= 0) return 0;
     hipLaunchKernelGGL(gather_l1_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, table, (long long)n_lines, D,
-                       (const long long*)idx, (long long)rows, normalize, out, mask);
+                       (const long long*)idx, (long long)rows, normalize, out, mask, amax, plane_out(planes, ld2, hdr, scale_in));
     LAUNCH_CHECK();
     return 0;
 }

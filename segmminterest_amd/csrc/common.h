@@ -123,6 +123,60 @@ __device__ __forceinline__ void site_commit(float* hdr, float m, unsigned key, f
         if (s_used > 0.f && !(m * s_used < 65504.f)) ((volatile unsigned int*)hdr)[1] = 1u;      // NaN raises it too
     }
 }
+// power of two s with amax * s in [2^14, 2^15); exponent clamped to +-60 so that 1/(sa sb) stays finite
+__device__ __forceinline__ float f16_scale_of(float amax) {
+    const uint32_t u = __float_as_uint(amax);
+    if (!(amax > 0.f) || (u >> 23) == 0xff) return 1.f;
+    int se = 14 - ((int)(u >> 23) - 127);
+    se = max(-60, min(60, se));
+    return __uint_as_float((uint32_t)(se + 127) << 23);
+}
+// (x0, x1) * s -> packed fp16 (hi0, hi1), (lo0, lo1); hi + lo = x s up to 2^-22 |x s|.
+// Four VALU instructions per pair: v_fma_mix{lo,hi}_f16 multiply in fp32, round ONCE to fp16 and write one half
+// of the destination, and take the fp16 hi term straight back as the addend of the lo term
+// (lo = rn16(x s - hi), the fma is exact before that rounding).
+__device__ __forceinline__ void splith_pair(float x0, float x1, float s, uint32_t& ph, uint32_t& pl) {
+    uint32_t h, l;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(x0), "v"(s));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(x1), "v"(s));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(x0), "v"(s), "v"(h));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(x1), "v"(s), "v"(h));
+    ph = h;
+    pl = l;
+}
+
+// ---- producer side of a plane tensor.  A kernel that writes a GEMM operand also writes its P32 fp16 planes (gemm_planes.h:
+// per row and per 32 columns [32 hi | 32 lo]) with the DELAYED scale *scale_in (a power of two derived from the maxima this
+// tensor site had on earlier steps; null or 0: no planes yet -> the host runs an exact split pass instead), records that
+// scale in hdr[0] and folds the partial maxima / the overflow flag into the header.  Consumers fall back to the fp32 copy
+// when the flag is up, so a scale that has become too large costs time, never correctness.
+struct PlaneOut {
+    _Float16* p; int ld2;         // plane view (null: no plane output)
+    float* hdr;                   // site header of the tensor
+    const float* scale_in;        // device scalar: the scale to write with
+};
+__device__ __forceinline__ float plane_scale(const PlaneOut& po) {
+    return (po.p && po.scale_in) ? *po.scale_in : 0.f;
+}
+// 4 consecutive columns c .. c+3 (c % 4 == 0) of row `row`
+__device__ __forceinline__ void plane_store4(_Float16* p, int ld2, long long row, int c, f32x4 v, float s) {
+    uint32_t h0, l0, h1, l1;
+    splith_pair(v.x, v.y, s, h0, l0);
+    splith_pair(v.z, v.w, s, h1, l1);
+    _Float16* o = p + row * ld2 + ((c >> 5) << 6) + (c & 31);
+    *(uint2*)o = make_uint2(h0, h1);
+    *(uint2*)(o + 32) = make_uint2(l0, l1);
+}
+// end of a producer wave: partial maxima (+ flag) and the scale used (every wave stores the same value: no "first thread"
+// that might have left the kernel early).
+__device__ __forceinline__ void plane_finish(const PlaneOut& po, float* amax_slots, float am, unsigned key, float s, bool) {
+    if (s > 0.f) {
+        site_commit(po.hdr, am, key, s);
+        if ((threadIdx.x & 63) == 0) po.hdr[0] = s;
+    } else if (amax_slots) {
+        amax_commit(amax_slots, am, key);
+    }
+}
 // inclusive prefix sum across the 64 lanes
 __device__ __forceinline__ float wave_scan_incl(float v, int lane) {
 #pragma unroll

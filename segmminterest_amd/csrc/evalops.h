@@ -142,7 +142,8 @@ __global__ __launch_bounds__(256) void survival_kernel(const float* __restrict__
 // (negative index = padding slot of the collator, dataloader_SegMM.py:345-350).  One wave per output row.
 __global__ __launch_bounds__(256) void gather_l1_kernel(const float* __restrict__ table, long long n_lines, int D,
                                                         const long long* __restrict__ idx, long long rows, int normalize,
-                                                        float* __restrict__ out, unsigned char* __restrict__ mask) {
+                                                        float* __restrict__ out, unsigned char* __restrict__ mask, float* amax,
+                                                        PlaneOut po) {
     const int lane = threadIdx.x & 63;
     const long long r = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (r >= rows) return;
@@ -150,8 +151,13 @@ __global__ __launch_bounds__(256) void gather_l1_kernel(const float* __restrict_
     const bool ok = i >= 0 && i < n_lines;
     if (mask && lane == 0) mask[r] = ok ? 1 : 0;
     float* o = out + r * D;
+    const float ps = plane_scale(po);
     if (!ok) {
-        for (int c = lane * 4; c < D; c += 256) *(f32x4*)(o + c) = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int c = lane * 4; c < D; c += 256) {
+            *(f32x4*)(o + c) = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (ps > 0.f) plane_store4(po.p, po.ld2, r, c, f32x4{0.f, 0.f, 0.f, 0.f}, ps);
+        }
+        plane_finish(po, amax, 0.f, (unsigned)r, ps, r == 0 && lane == 0);
         return;
     }
     const float* t = table + i * D;
@@ -163,10 +169,42 @@ __global__ __launch_bounds__(256) void gather_l1_kernel(const float* __restrict_
         }
         s = wave_sum(s) + 1e-6f;
     }
+    float am = 0.f;
     for (int c = lane * 4; c < D; c += 256) {
         f32x4 v = *(const f32x4*)(t + c);
         if (normalize) { v.x /= s; v.y /= s; v.z /= s; v.w /= s; }
         *(f32x4*)(o + c) = v;
+        if (ps > 0.f) plane_store4(po.p, po.ld2, r, c, v, ps);
+        am = absmax4(am, v);
+    }
+    plane_finish(po, amax, am, (unsigned)r, ps, r == 0 && lane == 0);
+}
+
+// ---------------------------------------------------------------- delayed scaling: end-of-pass update of the site scales
+// arena: n_rows site headers of the pass that just ended; site_idx[r] = index of row r's tensor site in site_scale (< 0:
+// none).  For every row that was produced (max > 0): site_scale[idx] = the power of two s with max * s in
+// [2^(target-1), 2^target) -- the scale the NEXT pass writes this site's planes with (fp16 tops out at 2^16: target 12
+// leaves a factor 16 of head-room for step-to-step growth; an overflow beyond that is flagged by the producer and
+// handled by the consumers' fp32 path).  stats[0] += rows whose overflow flag was raised (diagnostics / tests).
+__global__ __launch_bounds__(256) void scales_update_kernel(const float* __restrict__ arena, const int* __restrict__ site_idx, int n_rows,
+                                                            float* site_scale, float* stats, int target) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= n_rows) return;
+    const int idx = site_idx[r];
+    if (idx < 0) return;
+    const float* hdr = arena + (size_t)r * SITE_FLOATS;
+    float m = 0.f;
+    for (int i = lane; i < AMAX_SLOTS; i += 64) m = fmaxf(m, hdr[SITE_HDR + i]);
+    m = wave_max(m);
+    if (lane == 0) {
+        const uint32_t u = __float_as_uint(m);
+        if (m > 0.f && (u >> 23) != 0xff) {
+            int se = (target - 1) - ((int)(u >> 23) - 127);
+            se = max(-60, min(60, se));
+            site_scale[idx] = __uint_as_float((uint32_t)(se + 127) << 23);
+        }
+        if (__float_as_uint(hdr[1]) != 0u) atomicAdd(stats, 1.0f);
     }
 }
 

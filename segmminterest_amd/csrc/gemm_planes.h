@@ -35,7 +35,8 @@ struct PlaneOperand {
 };
 struct PGemmX {
     PlaneOperand A, B;
-    _Float16* Cp; int ldc2; float* c_hdr;      // optional plane output (scale = c_hdr[0]) ; amax / flag folded into c_hdr
+    _Float16* Cp; int ldc2; float* c_hdr;      // optional plane output; amax / flag / the scale used are folded into c_hdr
+    const float* c_scale_in;                   // device scalar: scale to write the output planes with (null / 0: none)
     int write_c;                               // 0: the fp32 C is not stored (planes only)
     int dbg;                                   // timing ablations (SEGMM_PL_FLAGS; results are wrong when set): 1 no C stores, 2 no epilogue
 };
@@ -121,14 +122,7 @@ __device__ __forceinline__ void epi_strip_emit(const GemmArgs& p, const PGemmX& 
             if ((SPLITK || q.write_c) && !(q.dbg & 1)) *(f32x4*)(Cout + (size_t)gm * p.ldc + gn) = v;
             if (!SPLITK) {
                 am = absmax4(am, v);
-                if (q.Cp) {
-                    uint32_t h0, l0, h1, l1;
-                    splith_pair(v.x, v.y, c_scale, h0, l0);
-                    splith_pair(v.z, v.w, c_scale, h1, l1);
-                    _Float16* o = q.Cp + (size_t)gm * q.ldc2 + ((gn >> 5) << 6) + (gn & 31);
-                    *(uint2*)o = make_uint2(h0, h1);
-                    *(uint2*)(o + 32) = make_uint2(l0, l1);
-                }
+                if (c_scale > 0.f && q.Cp) plane_store4(q.Cp, q.ldc2, gm, gn, v, c_scale);
             }
         }
     }
@@ -297,7 +291,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_nt(const GemmArgs p, const PGe
     // ---- epilogue (all stages are free: the loop ended with a barrier)
     float* Cs = (float*)smem + wave * (32 * 64);          // 8 KB per wave
     const float inv_ab = (1.f / sa) * (1.f / sb);          // exact powers of two
-    const float c_scale = q.Cp ? q.c_hdr[0] : 1.f;
+    const float c_scale = (q.Cp && q.c_scale_in) ? *q.c_scale_in : 0.f;
     float am = 0.f;
     if (q.dbg & 2) {
         float t = 0.f;          // keeps every accumulator alive (no dead-code elimination of MFMAs)
@@ -322,8 +316,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_nt(const GemmArgs p, const PGe
         epi_strip_write<2>(c, Cs, lane);
         epi_strip_emit<false, 2>(p, q, Cs, lane, m0 + wm * 128 + i * 32, n0 + wn * 64, inv_ab, c_scale, p.C, am);
     }
-    if (q.c_hdr) site_commit(q.c_hdr, am, blockIdx.x * 8 + wave, q.Cp ? c_scale : 0.f);
-    else if (p.amax_out) amax_commit(p.amax_out, am, blockIdx.x * 8 + wave);
+    if (q.c_hdr) {
+        site_commit(q.c_hdr, am, blockIdx.x * 8 + wave, c_scale);
+        if (c_scale > 0.f && lane == 0) q.c_hdr[0] = c_scale;
+    } else if (p.amax_out) amax_commit(p.amax_out, am, blockIdx.x * 8 + wave);
 }
 
 // =============================================================================== TN: C[M,N] = A[K,M]^T . B[K,N]
@@ -482,8 +478,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_tn(const GemmArgs p, const PGe
             default: c[0] = acc[3][0]; c[1] = acc[3][1]; break;
         }
         epi_strip_write<2>(c, Cs, lane);
-        if (split) epi_strip_emit<true, 2>(p, q, Cs, lane, m0 + wm * 128 + i * 32, n0 + wn * 64, inv_ab, 1.f, Cout, am);
-        else epi_strip_emit<false, 2>(p, q, Cs, lane, m0 + wm * 128 + i * 32, n0 + wn * 64, inv_ab, 1.f, Cout, am);
+        if (split) epi_strip_emit<true, 2>(p, q, Cs, lane, m0 + wm * 128 + i * 32, n0 + wn * 64, inv_ab, 0.f, Cout, am);
+        else epi_strip_emit<false, 2>(p, q, Cs, lane, m0 + wm * 128 + i * 32, n0 + wn * 64, inv_ab, 0.f, Cout, am);
     }
 }
 

@@ -64,27 +64,6 @@ struct GemmPlanes {                              // optional pre-split operands 
     const float* b_amax; int b_namax;
 };
 
-// power of two s with amax * s in [2^14, 2^15); exponent clamped to +-60 so that 1/(sa sb) stays finite
-__device__ __forceinline__ float f16_scale_of(float amax) {
-    const uint32_t u = __float_as_uint(amax);
-    if (!(amax > 0.f) || (u >> 23) == 0xff) return 1.f;
-    int se = 14 - ((int)(u >> 23) - 127);
-    se = max(-60, min(60, se));
-    return __uint_as_float((uint32_t)(se + 127) << 23);
-}
-// (x0, x1) * s -> packed fp16 (hi0, hi1), (lo0, lo1); hi + lo = x s up to 2^-22 |x s|.
-// Four VALU instructions per pair: v_fma_mix{lo,hi}_f16 multiply in fp32, round ONCE to fp16 and write one half
-// of the destination, and take the fp16 hi term straight back as the addend of the lo term
-// (lo = rn16(x s - hi), the fma is exact before that rounding).
-__device__ __forceinline__ void splith_pair(float x0, float x1, float s, uint32_t& ph, uint32_t& pl) {
-    uint32_t h, l;
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(x0), "v"(s));
-    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(x1), "v"(s));
-    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(x0), "v"(s), "v"(h));
-    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(x1), "v"(s), "v"(h));
-    ph = h;
-    pl = l;
-}
 // exact 3-way split of two floats -> packed (hi0,hi1), (mid0,mid1), (lo0,lo1)
 __device__ __forceinline__ void split3_pair(float x0, float x1, uint32_t& ph, uint32_t& pm, uint32_t& pl) {
     ph = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{x0, x1}, bf16x2));

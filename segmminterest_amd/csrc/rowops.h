@@ -12,7 +12,7 @@ constexpr int ROW_MAXV = 8;      // float4 per lane kept in registers => d <= 20
 // trainer-side normalisation, main_for_seq_leave_earlystop_SegMM.py:272-273.  If y == null only the
 // reciprocal scale is written (consumed by the GEMM row_scale epilogue: the fused a1+a2 path).
 __global__ __launch_bounds__(256) void l1norm_kernel(const float* __restrict__ x, float* y, float* inv_scale, long long rows, int D,
-                                                     float* amax) {
+                                                     float* amax, PlaneOut po) {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -27,14 +27,16 @@ __global__ __launch_bounds__(256) void l1norm_kernel(const float* __restrict__ x
     if (inv_scale && lane == 0) inv_scale[row] = inv;
     if (y) {
         const float den = s + 1e-6f;
+        const float ps = plane_scale(po);
         float am = 0.f;
         for (int c = lane * 4; c < D; c += 256) {
             f32x4 v = *(const f32x4*)(xr + c);
             v.x /= den; v.y /= den; v.z /= den; v.w /= den;
             *(f32x4*)(y + row * D + c) = v;
+            if (ps > 0.f) plane_store4(po.p, po.ld2, row, c, v, ps);
             am = absmax4(am, v);
         }
-        if (amax) amax_commit(amax, am, (unsigned)row);      // partial maxima of |y| for the fp16x3 GEMM that reads y
+        plane_finish(po, amax, am, (unsigned)row, ps, row == 0 && lane == 0);      // partial maxima of |y| for the GEMM that reads y
     }
 }
 
@@ -45,11 +47,12 @@ __global__ __launch_bounds__(256) void l1norm_kernel(const float* __restrict__ x
 template <int V>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                      const float* __restrict__ beta, float* __restrict__ y, float* mean_out,
-                                     float* rstd_out, long long rows, int d, float eps, DropCfg drop, float* amax) {
+                                     float* rstd_out, long long rows, int d, float eps, DropCfg drop, float* amax, PlaneOut po) {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float* xr = x + row * d;
+    const float ps = plane_scale(po);
     f32x4 v[V];
     float s = 0.f;
 #pragma unroll
@@ -78,10 +81,11 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
             f32x4 o = (v[i] - mean) * rstd * *(const f32x4*)(gamma + c) + *(const f32x4*)(beta + c);
             if (drop.p > 0.f) o = drop_apply4(drop, ((uint64_t)row * d + c) >> 2, o);
             *(f32x4*)(y + row * d + c) = o;
+            if (ps > 0.f) plane_store4(po.p, po.ld2, row, c, o, ps);
             am = absmax4(am, o);
         }
     }
-    if (amax) amax_commit(amax, am, (unsigned)row);
+    plane_finish(po, amax, am, (unsigned)row, ps, row == 0 && lane == 0);
 }
 
 // ---------------------------------------------------------------- LayerNorm backward
@@ -96,8 +100,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                      const float* __restrict__ gamma, float* __restrict__ dx,
                                      float* __restrict__ dx_drop, float* __restrict__ part_dgamma,
                                      float* __restrict__ part_dbeta, float* __restrict__ part_dsum, long long rows, int d,
-                                     DropCfg drop_y, DropCfg drop_branch, float* amax) {
+                                     DropCfg drop_y, DropCfg drop_branch, float* amax, PlaneOut po) {
     __shared__ f32x4 red[4][64];
+    const float ps = plane_scale(po);
     float am = 0.f;          // max |dx_drop| (or |dx| when there is no dropped copy): the tensor the GEMMs consume
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     f32x4 ag[V], ab[V], as[V], gm[V];
@@ -140,12 +145,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                     if (drop_branch.p > 0.f) od = drop_apply4(drop_branch, ((uint64_t)row * d + c) >> 2, o);
                     *(f32x4*)(dx_drop + row * d + c) = od;
                 }
+                if (ps > 0.f) plane_store4(po.p, po.ld2, row, c, od, ps);
                 as[i] += od;
                 am = absmax4(am, od);
             }
         }
     }
-    if (amax) amax_commit(amax, am, blockIdx.x * nw + wave);
+    plane_finish(po, amax, am, blockIdx.x * nw + wave, ps, blockIdx.x == 0 && threadIdx.x == 0);
     // cross-wave reduce of the partials, one partial row per workgroup.  One 256-column chunk at a time through a 4 KB
     // buffer: the kernel usually runs NEXT TO a GEMM that holds 120 of the CU's 160 KB of LDS, and a 12 KB buffer
     // would cap it at three workgroups per CU there.

@@ -166,6 +166,15 @@ class ParamStore:
         self.wpt: Dict[str, "H.PT"] = {}
         self.wTpt: Dict[str, "H.PT"] = {}
         self._wmats: List[Tuple[str, int, int, int, bool]] = []      # (first parameter name, flat offset, rows, cols, needs W^T)
+        # delayed scaling of producer-written planes (common.h PlaneOut): one persistent scale per tensor SITE (a named
+        # activation / gradient of the model), refreshed at the end of every pass from the maxima that pass recorded
+        # (segmm_scales_update); a site is "calibrated" once it has been produced at least once
+        self.scaling = os.environ.get("SEGMM_SCALING", "delayed")      # delayed | exact (split pass after every producer) | always
+        self.scale_target = int(os.environ.get("SEGMM_SCALE_TARGET", "12"))
+        self.site_index: Dict[str, int] = {}
+        self.site_scale = None          # [MAX_SITES + 8] floats: scales, then [MAX_SITES] = count of overflowed tensors
+        self.calibrated = set()
+        self._site_idx_cache: Dict[tuple, torch.Tensor] = {}
         self.whdr = None
         self.wpl = self.wTpl = None
         self.wgrad_planes = 2 if os.environ.get("SEGMM_WGRAD", "x6") == "x3" else 3      # x3 = opt-in, see DESIGN.md
@@ -174,6 +183,46 @@ class ParamStore:
         self._planes_key = None
         self._transposes: List[Tuple[int, int, int]] = []
         self._plane_ranges: List[Tuple[int, int]] = []
+
+    MAX_SITES = 1024
+
+    def site(self, name: str) -> int:
+        i = self.site_index.get(name)
+        if i is None:
+            i = self.site_index[name] = len(self.site_index)
+            if i >= self.MAX_SITES:
+                raise RuntimeError("more than %d tensor sites" % self.MAX_SITES)
+        return i
+
+    def scales(self) -> torch.Tensor:
+        if self.site_scale is None or self.site_scale.device != self.flat.device:
+            self.site_scale = torch.zeros((self.MAX_SITES + 8,), dtype=torch.float32, device=self.flat.device)
+            self.calibrated = set()
+        return self.site_scale
+
+    def scale_ptr(self, name: str, delayed: bool):
+        """Device address of the delayed scale of site ``name`` -- or None when its planes must come from an exact split pass
+        (exact mode, or the site has never been produced: its scale is unknown)."""
+        if not (delayed and self.engine_p) or name not in self.calibrated:
+            return None
+        return self.scales().data_ptr() + 4 * self.site(name)
+
+    def update_scales(self, arena_t, site_names, n_rows):
+        """End of a pass: fold the pass's partial maxima into the site scales (one tiny launch)."""
+        if n_rows == 0 or not self.engine_p:
+            return
+        key = tuple(site_names[:n_rows])
+        idx = self._site_idx_cache.get(key)
+        if idx is None or idx.device != arena_t.device:
+            idx = self._site_idx_cache[key] = torch.tensor([-1 if n is None else self.site(n) for n in key], dtype=torch.int32,
+                                                           device=arena_t.device)
+        sc = self.scales()
+        H.scales_update(arena_t, idx, n_rows, sc, sc[self.MAX_SITES:], self.scale_target)
+        self.calibrated.update(n for n in key if n is not None)
+
+    def overflow_count(self) -> int:
+        """Number of plane tensors whose delayed scale overflowed so far (host sync; diagnostics and tests)."""
+        return int(self.scales()[self.MAX_SITES].item())
 
     # -- second HIP stream for weight/bias gradients (see class SideWork)
     def side_stream(self):
@@ -476,10 +525,12 @@ class Act:
     """A tensor that some GEMM reads: the fp32 values ``t`` ([rows, cols] row-major), its site header ``hdr`` (scale, overflow
     flag, partial maxima -- None on the f32 / bf16x6 engines) and, on the plane engine, the P32 fp16 planes ``planes``
     ([rows, 2 cols]; None when cols is not a multiple of 32: such operands go through the on-the-fly kernel)."""
-    __slots__ = ("t", "hdr", "rows", "cols", "planes", "filled")
+    __slots__ = ("t", "hdr", "rows", "cols", "planes", "filled", "po", "scale_ptr")
 
     def __init__(self, t, hdr, rows, cols, planes=None):
         self.t, self.hdr, self.rows, self.cols, self.planes, self.filled = t, hdr, rows, cols, planes, False
+        self.po = None              # hipabi.PO when the producer writes the planes itself (delayed scale)
+        self.scale_ptr = None
 
     @property
     def slots(self):
@@ -499,20 +550,29 @@ class AmaxArena:
     def __init__(self, store, n):
         self.t = torch.zeros((n, H.SITE_FLOATS), dtype=torch.float32, device=store.flat.device) if store.engine_h else None
         self.i = 0
+        self.sites: List[Optional[str]] = []
 
-    def new(self):
+    def new(self, site=None):
         if self.t is None:
             return None
         if self.i >= self.t.shape[0]:
             raise RuntimeError("AmaxArena exhausted (%d rows)" % self.t.shape[0])
         r = self.t[self.i]
         self.i += 1
+        self.sites.append(site)
         return r
 
+    def close(self, store):
+        """End of the pass: the site scales of the next pass."""
+        if self.t is not None:
+            store.update_scales(self.t, self.sites, self.i)
 
-def new_act(store, arena, rows, cols, t=None, key=None, planes=True):
+
+def new_act(store, arena, rows, cols, t=None, key=None, planes=True, site=None, delayed=False):
     """An Act with a fresh site header; ``t`` given or allocated (``key``: persistent scratch name instead of a new tensor).
-    ``planes=False``: no GEMM reads it on the plane engine (only its fp32 values / maxima are wanted)."""
+    ``planes=False``: no GEMM reads it on the plane engine (only its fp32 values / maxima are wanted).
+    ``site`` names the tensor for delayed scaling; with ``delayed`` and a calibrated site the Act carries a plane output
+    (``po``) for its producer kernel, otherwise ``finish_act`` makes the planes with an exact split pass."""
     dev = store.flat.device
     if t is None:
         t = store.buf(key, (rows, cols)) if key is not None else torch.empty((rows, cols), dtype=torch.float32, device=dev)
@@ -521,7 +581,19 @@ def new_act(store, arena, rows, cols, t=None, key=None, planes=True):
     if want and store.engine_p and cols % 32 == 0:
         planes = store.buf(key + ":pl", (rows, 2 * cols), torch.float16) if key is not None else \
             torch.empty((rows, 2 * cols), dtype=torch.float16, device=dev)
-    return Act(t, arena.new(), rows, cols, planes)
+    a = Act(t, arena.new(site), rows, cols, planes)
+    if planes is not None and site is not None:
+        a.scale_ptr = store.scale_ptr(site, delayed)
+        if a.scale_ptr is not None:
+            a.po = H.PO(planes, 2 * cols, a.hdr, a.scale_ptr)
+    return a
+
+
+def produced(act):
+    """The producer kernel of ``act`` was given its plane output (``po``): nothing left for finish_act to do."""
+    if act.po is not None:
+        act.filled = True
+    return act
 
 
 def finish_act(store, act):
@@ -552,7 +624,11 @@ def _lin_fwd(store, M, N, K, X, wname, out, ldo, c_act=None, **kw):
     ``c_act``: the Act that ``out`` belongs to (receives the partial maxima of |out|)."""
     w = store.wpt.get(wname) if store.engine_p else None
     if w is not None and X.planes is not None:
-        H.gemm_p(H.LAYOUT_NT, M, N, K, X.pt(), w, out, ldo, c_hdr=None if c_act is None else c_act.hdr, **kw)
+        if c_act is not None and c_act.po is not None:
+            H.gemm_p(H.LAYOUT_NT, M, N, K, X.pt(), w, out, ldo, c_pt=c_act.pt(), c_scale_ptr=c_act.scale_ptr, **kw)
+            c_act.filled = True
+        else:
+            H.gemm_p(H.LAYOUT_NT, M, N, K, X.pt(), w, out, ldo, c_hdr=None if c_act is None else c_act.hdr, **kw)
         return
     if store.use_planes and K % 8 == 0:
         kw["b_planes"] = (store.wplanes, store.index[wname][0])
@@ -565,7 +641,11 @@ def _lin_dgrad(store, M, n_in, n_out, dY, wname, out, c_act=None, **kw):
     k-contiguous), otherwise the NN layout on the fp32 weights."""
     wT = store.wTpt.get(wname) if store.engine_p else None
     if wT is not None and dY.planes is not None:
-        H.gemm_p(H.LAYOUT_NT, M, n_in, n_out, dY.pt(), wT, out, n_in, c_hdr=None if c_act is None else c_act.hdr, **kw)
+        if c_act is not None and c_act.po is not None:
+            H.gemm_p(H.LAYOUT_NT, M, n_in, n_out, dY.pt(), wT, out, n_in, c_pt=c_act.pt(), c_scale_ptr=c_act.scale_ptr, **kw)
+            c_act.filled = True
+        else:
+            H.gemm_p(H.LAYOUT_NT, M, n_in, n_out, dY.pt(), wT, out, n_in, c_hdr=None if c_act is None else c_act.hdr, **kw)
         return
     ca = None if c_act is None else c_act.slots
     if store.use_planes and n_out % 8 == 0:
@@ -582,7 +662,7 @@ def _colsum(store, X, ld, M, N, out, x_off=0, w=None, accumulate=False):
 
 
 def _ln_bwd(store, dy, x, mean, rstd, gname, bname, gbuf, dx, dx_drop, rows, d, drop_y=(0.0, 0), drop_b=(0.0, 0), seed=0,
-            amax=None, dsum_to=None):
+            amax=None, dsum_to=None, po=None):
     """LayerNorm backward + its affine gradients.  ``dsum_to``: gradient tensor that receives the column sums of the
     forwarded gradient (dx_drop, or dx): the bias gradient of the Linear feeding this LayerNorm's residual branch,
     accumulated inside the same kernel instead of by a second pass over [rows, d]."""
@@ -593,7 +673,7 @@ def _ln_bwd(store, dy, x, mean, rstd, gname, bname, gbuf, dx, dx_drop, rows, d, 
     pb = store.buf("ln_pb:" + gname, (parts, d))
     ps = store.buf("ln_ps:" + gname, (parts, d)) if dsum_to is not None else None
     H.layernorm_bwd(dy, x, mean, rstd, store.p(gname), dx, dx_drop, pg, pb, drop_y_p=drop_y[0], drop_y_site=drop_y[1],
-                    drop_b_p=drop_b[0], drop_b_site=drop_b[1], seed=seed, amax=amax, part_dsum=ps)
+                    drop_b_p=drop_b[0], drop_b_site=drop_b[1], seed=seed, amax=amax, part_dsum=ps, po=po)
     with (side_work(store) if store.ln_side else contextlib.nullcontext()):
         ws = store.buf("colsum3_ws_side" if store._on_side else "colsum3_ws", (3 * H.colsum_chunks(parts) * d,))
         Xs, outs = [pg, pb], [store.g(gname, gbuf), store.g(bname, gbuf)]
@@ -627,6 +707,10 @@ def _attn_bwd(store, *args, **kw):
     main.wait_stream(att)
 
 
+def vq_tiles(L):
+    return (L + 15) // 16
+
+
 def _mask_u8(m: torch.Tensor) -> torch.Tensor:
     m = m.to(torch.bool).contiguous()
     return m.view(torch.uint8)
@@ -647,15 +731,16 @@ class BackboneRun:
 
     def _input_act(self, x, rows, cols):
         """External fp32 input (feature tensor) as a GEMM operand.  Its partial maxima come with the tensor when its producer
-        has them (Trainer.normalize / FeatureTable.gather attach the site header as ``_segmm_hdr``: they travel WITH the tensor
-        object, never keyed by address), otherwise from one absmax pass."""
+        has them (Trainer attaches the whole Act -- header, planes -- as ``_segmm_act``: it travels WITH the tensor object, never
+        keyed by address), otherwise from one absmax pass."""
         st = self.store
+        a = getattr(x, "_segmm_act", None)
+        if a is not None and a.t is x and a.hdr.device == x.device:
+            return finish_act(st, a)
         hdr = None
         if st.engine_h:
-            hdr = getattr(x, "_segmm_hdr", None)
-            if hdr is None or hdr.device != x.device:
-                hdr = self.am.new()
-                H.absmax(x, rows, cols, cols, out=hdr[H.SITE_HDR:])
+            hdr = self.am.new()
+            H.absmax(x, rows, cols, cols, out=hdr[H.SITE_HDR:])
         planes = torch.empty((rows, 2 * cols), dtype=torch.float16, device=x.device) if st.engine_p and cols % 32 == 0 else None
         return finish_act(st, Act(x, hdr, rows, cols, planes))
 
@@ -673,6 +758,9 @@ class BackboneRun:
         p_drop = float(bb.dropout_p) if train else 0.0
         p_inner = MLP_INNER_DROPOUT if train else 0.0
         self.p_drop, self.p_inner, self.seed = p_drop, p_inner, seed
+        # producer-written planes with delayed scales in training passes; exact split passes otherwise (evaluation stays
+        # bitwise reproducible and independent of what ran before)
+        self.delayed = st.engine_p and ((train and st.scaling != "exact") or st.scaling == "always")
         vm = _mask_u8(vid_mask)
         B, S = vm.shape
         if S > bb.max_vid_len:
@@ -705,7 +793,7 @@ class BackboneRun:
         # the next step while main-stream kernels of this step still read it).
         pre_u = _empty(ref, Mu, d)
         meu, reu = _empty(ref, Mu), _empty(ref, Mu)
-        Eu = new_act(st, am, Mu, d, planes=usr_is_operand)
+        Eu = new_act(st, am, Mu, d, planes=usr_is_operand, site=P + "Eu", delayed=self.delayed)
         Yu0 = None
         fwd_side = st.overlap and st.fwd_side and not bb.id_usr and layered and self.mode != "self" and not st.engine_p
         if bb.id_usr:
@@ -713,8 +801,8 @@ class BackboneRun:
             sv["usr_ids"] = uids
             H.embed_id_usr(uids, st.p(P + "usr_proj.weight"), d, st.p(P + "usr_pe.weight"), pre_u, B)
             H.layernorm_fwd(pre_u, st.p(P + "usr_ln.weight"), st.p(P + "usr_ln.bias"), Eu.t, meu, reu, drop_p=p_drop, seed=seed,
-                            site=_site(self.bi, 0, K_EMB_U), amax=Eu.slots)
-            finish_act(st, Eu)
+                            site=_site(self.bi, 0, K_EMB_U), amax=Eu.slots, po=Eu.po)
+            finish_act(st, produced(Eu))
         else:
             xu = usr_feat.contiguous().float()
             Din_u = xu.shape[-1]
@@ -724,8 +812,8 @@ class BackboneRun:
                 _lin_fwd(st, Mu, d, Din_u, sv["usr_x"], P + "usr_proj.weight", pre_u, d,
                          bias=st.p(P + "usr_proj.bias"), residual=st.p(P + "usr_pe.weight"), ldr=d, res_period=Lt)
                 H.layernorm_fwd(pre_u, st.p(P + "usr_ln.weight"), st.p(P + "usr_ln.bias"), Eu.t, meu, reu, drop_p=p_drop, seed=seed,
-                                site=_site(self.bi, 0, K_EMB_U), amax=Eu.slots)
-                finish_act(st, Eu)
+                                site=_site(self.bi, 0, K_EMB_U), amax=Eu.slots, po=Eu.po)
+                finish_act(st, produced(Eu))
                 if Yu0 is not None:
                     self._usr_proj_fwd(0, Eu, Yu0)
             if fwd_side:
@@ -753,17 +841,20 @@ class BackboneRun:
             _lin_fwd(st, Mv, d, Din, sv["vid_x"], P + "vid_proj.weight", pre_v, d,
                      bias=st.p(P + "vid_proj.bias"), residual=st.p(P + "vid_pe.weight"), ldr=d, res_period=S)
         mev, rev = _empty(ref, Mv), _empty(ref, Mv)
-        Ev = new_act(st, am, Mv, d, planes=layered or self.abl in ("SelfMLP", "CrossMLP"))
+        Ev = new_act(st, am, Mv, d, planes=layered or self.abl in ("SelfMLP", "CrossMLP"), site=P + "Ev", delayed=self.delayed)
         H.layernorm_fwd(pre_v, st.p(P + "vid_ln.weight"), st.p(P + "vid_ln.bias"), Ev.t, mev, rev, drop_p=p_drop, seed=seed,
-                        site=_site(self.bi, 0, K_EMB_V), amax=Ev.slots)
-        finish_act(st, Ev)
+                        site=_site(self.bi, 0, K_EMB_V), amax=Ev.slots, po=Ev.po)
+        finish_act(st, produced(Ev))
         sv["pre_v"], sv["mev"], sv["rev"] = pre_v, mev, rev
         Xv, Xu = Ev, Eu
         sv["layers"] = []
         if self.abl in MLP_VARIANTS:
-            return self._mlp_variant_fwd(Ev, Eu).view(B, -1, d), Eu.t.view(B, Lt, d)
+            out = self._mlp_variant_fwd(Ev, Eu)
+            am.close(st)
+            return out.view(B, -1, d), Eu.t.view(B, Lt, d)
         for i in range(max(self.N - 1, 0)):
             Xv, Xu = self._layer_fwd(i, Xv, Xu, Yu_ready=Yu0 if i == 0 else None)
+        am.close(st)
         return Xv.t.view(B, S, d), Eu.t.view(B, Lt, d)
 
     # ---------------------------------------------------------------- MLP ablations (encoder.py:392-400,503-511)
@@ -776,7 +867,7 @@ class BackboneRun:
             raise RuntimeError("encoder_mlp with %d hidden layers: dropout-site space holds 20" % (len(lins) - 1))
         hs = [X]
         for k, n in enumerate(lins[:-1]):
-            Hk = new_act(st, self.am, M, d)
+            Hk = new_act(st, self.am, M, d, site="%smlp%d.%d.H" % (P, tok, k), delayed=self.delayed)
             _lin_fwd(st, M, d, d, hs[-1], P + n + ".weight", Hk.t, d, bias=st.p(P + n + ".bias"), c_act=Hk,
                      activation=H.ACT_RELU, drop_p=self.p_drop, seed=self.seed, site=_site(self.bi, tok, K_MLP0 + k))
             hs.append(finish_act(st, Hk))
@@ -794,7 +885,8 @@ class BackboneRun:
             n = lins[k]
             _wgrad(st, g, 0, hs[k], 0, M, d, d, st.g(P + n + ".weight", gbuf), accumulate=accumulate)
             _colsum(st, g.t, d, M, d, st.g(P + n + ".bias", gbuf), accumulate=accumulate)
-            gin = new_act(st, self.amb, M, d, key="mlp_g%d%s" % (k & 1, tag))
+            gin = new_act(st, self.amb, M, d, key="mlp_g%d%s" % (k & 1, tag), planes=k > 0, site="%smlp%d.%d.dH" % (P, tok, k),
+                          delayed=self.delayed)
             if k > 0:       # through Dropout and ReLU of hidden layer k-1: aux = its saved output (> 0 iff live and kept)
                 _lin_dgrad(st, M, d, d, g, P + n + ".weight", gin.t, c_act=gin, activation=H.ACT_DRELU, aux=hs[k].t, ldaux=d,
                            drop_p=self.p_drop, seed=self.seed, site=_site(self.bi, tok, K_MLP0 + k - 1))
@@ -826,11 +918,12 @@ class BackboneRun:
         _lin_fwd(st, M, d, d, A, ca + "ff_%s.weight" % side, R1, d, bias=st.p(ca + "ff_%s.bias" % side),
                  residual=X.t, ldr=d, res_period=M, drop_p=self.p_drop, seed=seed, site=_site(self.bi, i, k_ao))
         m1, r1 = _empty(X.t, M), _empty(X.t, M)
-        X1 = new_act(st, am, M, d)
-        H.layernorm_fwd(R1, st.p(ca + "ln_%s.weight" % side), st.p(ca + "ln_%s.bias" % side), X1.t, m1, r1, amax=X1.slots)
-        finish_act(st, X1)
+        sn = "%sL%d.%s." % (self.pre, i, side)
+        X1 = new_act(st, am, M, d, site=sn + "X1", delayed=self.delayed)
+        H.layernorm_fwd(R1, st.p(ca + "ln_%s.weight" % side), st.p(ca + "ln_%s.bias" % side), X1.t, m1, r1, amax=X1.slots, po=X1.po)
+        finish_act(st, produced(X1))
         G = _empty(X.t, M, d)
-        Hh = new_act(st, am, M, d)
+        Hh = new_act(st, am, M, d, site=sn + "H", delayed=self.delayed)
         ff = L + "ff_%s.layers." % side
         _lin_fwd(st, M, d, d, X1, ff + "0.weight", Hh.t, d, bias=st.p(ff + "0.bias"), c_act=Hh,
                  activation=H.ACT_GELU, aux=G, ldaux=d, drop_p=self.p_inner, seed=seed, site=_site(self.bi, i, k_mi))
@@ -839,9 +932,9 @@ class BackboneRun:
         _lin_fwd(st, M, d, d, Hh, ff + "1.weight", R2, d, bias=st.p(ff + "1.bias"),
                  residual=X1.t, ldr=d, res_period=M, drop_p=self.p_drop, seed=seed, site=_site(self.bi, i, k_mo))
         m2, r2 = _empty(X.t, M), _empty(X.t, M)
-        X2 = new_act(st, am, M, d, planes=out_is_operand)
-        H.layernorm_fwd(R2, st.p(L + "ln_%s.weight" % side), st.p(L + "ln_%s.bias" % side), X2.t, m2, r2, amax=X2.slots)
-        finish_act(st, X2)
+        X2 = new_act(st, am, M, d, planes=out_is_operand, site=sn + "X2", delayed=self.delayed)
+        H.layernorm_fwd(R2, st.p(L + "ln_%s.weight" % side), st.p(L + "ln_%s.bias" % side), X2.t, m2, r2, amax=X2.slots, po=X2.po)
+        finish_act(st, produced(X2))
         return X2, dict(A=A, R1=R1, X1=X1, m1=m1, r1=r1, G=G, Hh=Hh, R2=R2, m2=m2, r2=r2)
 
     def _attn_views(self, full, Yv, Yu, nv, nu):
@@ -889,21 +982,21 @@ class BackboneRun:
             self._usr_proj_fwd(i, Xu, Yu)
         vq, uq = self._attn_views(full, Yv, Yu, nv, nu)
         lse_v = _empty(Xv.t, 2, B, Hh, S)
-        Av = new_act(st, am, Mv, d)
+        Av = new_act(st, am, Mv, d, site="%sL%d.vid.A" % (P, i), delayed=self.delayed)
         H.attn_fwd(B, Hh, dh, S, vq["La"], vq["Lb"], vq["Qa"], vq["Qb"], vq["ldq"], vq["Ka"], vq["Va"], vq["ldka"], vq["Kb"], vq["Vb"],
                    vq["ldkb"], self.vm, self.vm, self.um, Av.t, d, lse_v, drop_p=self.p_drop, seed=self.seed,
-                   site=_site(self.bi, i, K_ATT_V), amax_o=Av.slots)
-        finish_act(st, Av)
+                   site=_site(self.bi, i, K_ATT_V), amax_o=Av.slots, po=Av.po)
+        finish_act(st, produced(Av))
         X2v, sv_v = self._side_post(i, L, "vid", Xv, Av, Mv, (K_AO_V, K_MI_V, K_MO_V), out_is_operand=i < self.N - 2)
         rec = dict(full=full, Xv=Xv, Xu=Xu, Yv=Yv, Yu=Yu, lse_v=lse_v, v=sv_v)
         X2u = None
         if full:
             lse_u = _empty(Xv.t, 2, B, Hh, Lt)
-            Au = new_act(st, am, Mu, d)
+            Au = new_act(st, am, Mu, d, site="%sL%d.usr.A" % (P, i), delayed=self.delayed)
             H.attn_fwd(B, Hh, dh, Lt, uq["La"], uq["Lb"], uq["Qa"], uq["Qb"], uq["ldq"], uq["Ka"], uq["Va"], uq["ldka"], uq["Kb"],
                        uq["Vb"], uq["ldkb"], self.um, self.vm, self.um, Au.t, d, lse_u, drop_p=self.p_drop,
-                       seed=self.seed, site=_site(self.bi, i, K_ATT_U), amax_o=Au.slots)
-            finish_act(st, Au)
+                       seed=self.seed, site=_site(self.bi, i, K_ATT_U), amax_o=Au.slots, po=Au.po)
+            finish_act(st, produced(Au))
             X2u, sv_u = self._side_post(i, L, "usr", Xu, Au, Mu, (K_AO_U, K_MI_U, K_MO_U), out_is_operand=True)
             rec["lse_u"], rec["u"] = lse_u, sv_u
         self.sv["layers"].append(rec)
@@ -915,10 +1008,10 @@ class BackboneRun:
         returns it as an Act.  ``dx`` receives the plain input gradient (residual path); without dropout the two coincide."""
         st, d = self.store, self.d
         has_drop = drop_b[0] > 0
-        a = new_act(st, self.amb, M, d, t=None if has_drop else dx, key=key)
+        a = new_act(st, self.amb, M, d, t=None if has_drop else dx, key=key, site=self.pre + key, delayed=self.delayed)
         _ln_bwd(st, dy, x, mean, rstd, gname, bname, gbuf, dx, a.t if has_drop else None, M, d, drop_b=drop_b, seed=self.seed,
-                amax=a.slots, dsum_to=dsum_to)
-        return finish_act(st, a)
+                amax=a.slots, dsum_to=dsum_to, po=a.po)
+        return finish_act(st, produced(a))
 
     def _side_post_bwd(self, i, L, side, sv, dX2, M, kinds, gbuf, tag, deferred=None):
         """Reverse of _side_post.  Returns (dR1, dA): gradient wrt the residual input X and wrt the attention output."""
@@ -930,7 +1023,7 @@ class BackboneRun:
         dM = self._ln_bwd_act("dM" + tag, dX2, sv["R2"], sv["m2"], sv["r2"], L + "ln_%s.weight" % side, L + "ln_%s.bias" % side, gbuf,
                               dR2, M, (self.p_drop, _site(self.bi, i, k_mo)), st.g(ff + "1.bias", gbuf))
         side_or_defer(st, lambda: _wgrad(st, dM, 0, sv["Hh"], 0, M, d, d, st.g(ff + "1.weight", gbuf)), deferred)
-        dG = new_act(st, am, M, d, key="dG" + tag)
+        dG = new_act(st, am, M, d, key="dG" + tag, site=self.pre + "dG" + tag, delayed=self.delayed)
         _lin_dgrad(st, M, d, d, dM, ff + "1.weight", dG.t, c_act=dG, activation=H.ACT_DGELU, aux=sv["G"], ldaux=d,
                    drop_p=self.p_inner, seed=seed, site=_site(self.bi, i, k_mi))
         finish_act(st, dG)
@@ -958,19 +1051,40 @@ class BackboneRun:
         L = "%sencoder.layers.%d." % (P, i)
         ca = L + "cross_attn."
         Yv, Yu = rec["Yv"], rec["Yu"]
-        dYv = new_act(st, self.amb, Mv, nv * d, key="dYv%d" % i)      # one site per fused dY buffer: both attentions fold into it
-        dYu = new_act(st, self.amb, Mu, nu * d, key="dYu%d" % i) if nu else None
+        # one site per fused dY buffer: both attentions fold into it.  Only the fused backward kernel writes planes itself.
+        fused = st.attn_fused and max((vq_tiles(S), vq_tiles(Lt))) <= 12
+        dly = self.delayed and fused
+        dYv = new_act(st, self.amb, Mv, nv * d, key="dYv%d" % i, site="%sdYv%d" % (P, i), delayed=dly)
+        dYu = new_act(st, self.amb, Mu, nu * d, key="dYu%d" % i, site="%sdYu%d" % (P, i), delayed=dly) if nu else None
         vq, uq = self._attn_views(full, Yv, Yu, nv, nu)
         dvq, duq = self._attn_views(full, dYv.t, dYu.t if nu else None, nv, nu)
         Dv = st.buf("attnD", (B * Hh * max(S, Lt),))
         sl_v, sl_u = dYv.slots, (dYu.slots if nu else None)
+
+        def planes_of(dq, dka_, dkb_, views):
+            """segmm_attn_planes_t for one fused-backward call: query-side buffer dq, key-block buffers dka_ / dkb_ (Acts)."""
+            if not dly or dq.po is None:
+                return None
+            pl = H.AttnPlanes()
+
+            def pp(act, view):          # plane address of the column slice ``view`` = (fp32 tensor, column offset)
+                return None if (act is None or act.po is None or view is None) else act.planes.data_ptr() + 4 * view[1]
+            pl.dqa, pl.dqb, pl.lddq2 = pp(dq, views["Qa"]), pp(dq, views["Qb"]), 2 * dq.cols
+            pl.hdr_q, pl.sin_q = dq.hdr.data_ptr(), dq.scale_ptr
+            if dka_ is not None and dka_.po is not None and views["Ka"] is not None:
+                pl.dka, pl.dva, pl.lddka2 = pp(dka_, views["Ka"]), pp(dka_, views["Va"]), 2 * dka_.cols
+                pl.hdr_ka, pl.sin_ka = dka_.hdr.data_ptr(), dka_.scale_ptr
+            if dkb_ is not None and dkb_.po is not None and views["Kb"] is not None:
+                pl.dkb, pl.dvb, pl.lddkb2 = pp(dkb_, views["Kb"]), pp(dkb_, views["Vb"]), 2 * dkb_.cols
+                pl.hdr_kb, pl.sin_kb = dkb_.hdr.data_ptr(), dkb_.scale_ptr
+            return pl
         deferred = [] if st.defer_wgrad else None
         dR1v, dAv = self._side_post_bwd(i, L, "vid", rec["v"], dXv_out, Mv, (K_AO_V, K_MI_V, K_MO_V), gbuf, "v%d" % i, deferred)
         flush_deferred(st, deferred)          # the three weight-gradient GEMMs of this side run under the attention backward
         _attn_bwd(st, B, Hh, dh, S, vq["La"], vq["Lb"], vq["Qa"], vq["Qb"], vq["ldq"], vq["Ka"], vq["Va"], vq["ldka"], vq["Kb"], vq["Vb"],
                    vq["ldkb"], self.vm, self.vm, self.um, rec["lse_v"], rec["v"]["A"].t, d, dAv, d, Dv, dvq["Qa"], dvq["Qb"], dvq["ldq"],
                    dvq["Ka"], dvq["Va"], dvq["ldka"], dvq["Kb"], dvq["Vb"], dvq["ldkb"], drop_p=self.p_drop, seed=self.seed,
-                   site=_site(self.bi, i, K_ATT_V), amax_q=sl_v, amax_ka=sl_v, amax_kb=sl_u)
+                   site=_site(self.bi, i, K_ATT_V), amax_q=sl_v, amax_ka=sl_v, amax_kb=sl_u, planes=planes_of(dYv, dYv, dYu, dvq))
         dR1u = None
         if full:
             dR1u, dAu = self._side_post_bwd(i, L, "usr", rec["u"], dXu_out, Mu, (K_AO_U, K_MI_U, K_MO_U), gbuf, "u%d" % i, deferred)
@@ -979,7 +1093,11 @@ class BackboneRun:
                        uq["Vb"], uq["ldkb"], self.um, self.vm, self.um, rec["lse_u"], rec["u"]["A"].t, d, dAu, d, Dv,
                        duq["Qa"], duq["Qb"], duq["ldq"], duq["Ka"], duq["Va"], duq["ldka"], duq["Kb"], duq["Vb"], duq["ldkb"],
                        drop_p=self.p_drop, seed=self.seed, site=_site(self.bi, i, K_ATT_U),
-                       amax_q=sl_u, amax_ka=sl_v, amax_kb=sl_u)
+                       amax_q=sl_u, amax_ka=sl_v, amax_kb=sl_u, planes=planes_of(dYu, dYv, dYu, duq))
+        if dly:          # every column block of a dY buffer must have been written WITH planes, else fall back to the split pass
+            produced(dYv)
+            if nu:
+                produced(dYu)
         finish_act(st, dYv)
         if nu:
             finish_act(st, dYu)
@@ -1029,17 +1147,18 @@ class BackboneRun:
         # ---- embedding backward.  User side first: its weight gradient (the larger one) queues on the side stream
         # behind the projection weight gradients still running there, the video side's runs on the main stream.
         if dXu is not None:
-            dpre_u = new_act(st, self.amb, Mu, d, key="dpre_u", planes=not bb.id_usr)
+            dpre_u = new_act(st, self.amb, Mu, d, key="dpre_u", planes=not bb.id_usr, site=P + "dpre_u", delayed=self.delayed)
             _ln_bwd(st, dXu, sv["pre_u"], sv["meu"], sv["reu"], P + "usr_ln.weight", P + "usr_ln.bias", gbuf, dpre_u.t, None, Mu, d,
-                    drop_y=(self.p_drop, _site(self.bi, 0, K_EMB_U)), seed=self.seed, amax=dpre_u.slots)
-            finish_act(st, dpre_u)
+                    drop_y=(self.p_drop, _site(self.bi, 0, K_EMB_U)), seed=self.seed, amax=dpre_u.slots, po=dpre_u.po)
+            finish_act(st, produced(dpre_u))
             self._embed_bwd("usr", dpre_u, B, Lt, gbuf)
-        dpre_v = new_act(st, self.amb, Mv, d, key="dpre_v", planes=not bb.id_vid)
+        dpre_v = new_act(st, self.amb, Mv, d, key="dpre_v", planes=not bb.id_vid, site=P + "dpre_v", delayed=self.delayed)
         _ln_bwd(st, dXv, sv["pre_v"], sv["mev"], sv["rev"], P + "vid_ln.weight", P + "vid_ln.bias", gbuf, dpre_v.t, None, Mv, d,
-                drop_y=(self.p_drop, _site(self.bi, 0, K_EMB_V)), seed=self.seed, amax=dpre_v.slots)
-        finish_act(st, dpre_v)
+                drop_y=(self.p_drop, _site(self.bi, 0, K_EMB_V)), seed=self.seed, amax=dpre_v.slots, po=dpre_v.po)
+        finish_act(st, produced(dpre_v))
         self._embed_bwd("vid", dpre_v, B, S, gbuf)
         join_side(st)
+        self.amb.close(st)
         if on_bucket is not None:
             on_bucket(P + "embed")
 

@@ -38,12 +38,18 @@ class ResidentFeatureTable:
         self.normalize = normalize
         self._out: Dict[tuple, tuple] = {}
 
-    def gather(self, which: str, idx: torch.Tensor):
-        """idx int64 [B, L] (-1 = padding) -> (features float32 [B, L, D] L1-normalised, mask bool [B, L])."""
+    def buffers(self, which: str, idx: torch.Tensor):
+        """The persistent (features float32 [B, L, D], mask uint8 [B, L]) output buffers of :meth:`gather` for this index shape."""
         t = self.tables[which]
         key = (which, tuple(idx.shape))
         bufs = self._out.get(key)
         if bufs is None:
             bufs = self._out[key] = (torch.empty(tuple(idx.shape) + (t.shape[1],), dtype=torch.float32, device=t.device),
                                      torch.empty(tuple(idx.shape), dtype=torch.uint8, device=t.device))
-        return H.gather_l1(t, idx, normalize=self.normalize, out=bufs[0], mask=bufs[1])
+        return bufs
+
+    def gather(self, which: str, idx: torch.Tensor, amax=None, po=None):
+        """idx int64 [B, L] (-1 = padding) -> (features float32 [B, L, D] L1-normalised, mask bool [B, L]).
+        ``amax`` / ``po``: optional partial-maxima slots and plane output of the features (hipabi.gather_l1)."""
+        bufs = self.buffers(which, idx)
+        return H.gather_l1(self.tables[which], idx, normalize=self.normalize, out=bufs[0], mask=bufs[1], amax=amax, po=po)

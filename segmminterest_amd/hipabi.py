@@ -15,7 +15,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SEGMM_LIB") or os.path.join(_HERE, "libsegmm_hip.so")      # SEGMM_LIB: A/B builds of the kernels
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _lib = None
 
@@ -23,14 +23,15 @@ _i, _i64, _f, _u64, _u32, _p = C.c_int, C.c_int64, C.c_float, C.c_uint64, C.c_ui
 
 # name -> argtypes; the single source of truth for the exported symbol set (tests check it against the header)
 SIGNATURES = {
-    "segmm_l1norm": [_p, _p, _p, _i64, _i, _p, _p],
+    "segmm_l1norm": [_p, _p, _p, _i64, _i, _p, _p, _i, _p, _p, _p],
     "segmm_gemm": [_i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _p, _i, _f, _u64, _u32, _i, _p, _i, _i, _p],
     "segmm_gemm_x": [_i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _p, _i, _f, _u64, _u32, _i, _p, _i,
                      _p, _i64, _p, _i64, _i, _p],
     "segmm_gemm_h": [_i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _p, _i, _f, _u64, _u32, _i, _p, _i,
                      _p, _i64, _p, _i64, _p, _i, _p, _i, _p, _p],
-    "segmm_gemm_p": [_i, _i, _i, _i, _p, _i, _p, _p, _i, _p, _i, _p, _p, _i, _p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _p, _i, _f, _u64,
+    "segmm_gemm_p": [_i, _i, _i, _i, _p, _i, _p, _p, _i, _p, _i, _p, _p, _i, _p, _i, _p, _i, _p, _p, _i, _p, _p, _p, _i, _i, _i, _p, _i, _f, _u64,
                      _u32, _i, _p, _i, _p],
+    "segmm_scales_update": [_p, _p, _i, _p, _p, _i, _p],
     "segmm_split_p32": [_p, _i64, _i, _i, _p, _i, _p, _i, _p],
     "segmm_split_p32_transpose": [_p, _i, _i, _i, _p, _i, _p, _p],
     "segmm_absmax": [_p, _i64, _i, _i, _p, _i, _p],
@@ -38,14 +39,14 @@ SIGNATURES = {
     "segmm_split2h_transpose": [_p, _i, _i, _i, _p, _i64, _p, _i, _p],
     "segmm_split3": [_p, _p, _i64, _i64, _p],
     "segmm_split3_transpose": [_p, _i, _i, _i, _p, _i64, _p],
-    "segmm_layernorm_fwd": [_p, _p, _p, _p, _p, _p, _i64, _i, _f, _f, _u64, _u32, _p, _p],
+    "segmm_layernorm_fwd": [_p, _p, _p, _p, _p, _p, _i64, _i, _f, _f, _u64, _u32, _p, _p, _i, _p, _p, _p],
     "segmm_layernorm_bwd_parts": [_i64],
-    "segmm_layernorm_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _f, _u32, _f, _u32, _u64, _p, _p],
+    "segmm_layernorm_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _f, _u32, _f, _u32, _u64, _p, _p, _i, _p, _p, _p],
     "segmm_colsum_chunks": [_i64],
     "segmm_colsum": [_p, _i, _p, _i64, _i, _p, _i, _p, _p],
-    "segmm_attn_fwd": [_i] * 6 + [_p, _p, _i, _p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _i, _p, _f, _u64, _u32, _p, _p],
+    "segmm_attn_fwd": [_i] * 6 + [_p, _p, _i, _p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _i, _p, _f, _u64, _u32, _p, _p, _p],
     "segmm_attn_bwd": [_i] * 6 + [_p, _p, _i, _p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _i, _p, _i, _p, _p, _p, _i, _p, _p, _i,
-                                  _p, _p, _i, _f, _u64, _u32, _p, _p, _p, _i, _p],
+                                  _p, _p, _i, _f, _u64, _u32, _p, _p, _p, _i, _p, _p],
     "segmm_rowdot": [_p, _i, _p, _p, _p, _i64, _i, _i, _p],
     "segmm_rowscale_bcast": [_p, _p, _p, _i, _i64, _i, _i, _p],
     "segmm_vecsum": [_p, _i64, _p, _i, _p],
@@ -62,7 +63,7 @@ SIGNATURES = {
     "segmm_rank_leave": [_p, _i, _p, _p, _i, _i, _i, _i, _p, _p, _p],
     "segmm_auc_counts": [_p, _p, _p, _i, _p, _p],
     "segmm_survival": [_p, _i, _p, _p, _p, _i, _i, _p],
-    "segmm_gather_l1": [_p, _i64, _i, _p, _i64, _i, _p, _p, _p],
+    "segmm_gather_l1": [_p, _i64, _i, _p, _i64, _i, _p, _p, _p, _p, _i, _p, _p, _p],
     "segmm_segment_weighted_sum": [_p, _p, _p, _i64, _i, _p, _p],
     "segmm_colsum3": [_p, _p, _p, _i, _i64, _i, _p, _p, _p, _p, _p],
     "segmm_pool_tokens": [_p, _i, _p, _i, _p, _i, _i, _i, _p],
@@ -120,6 +121,36 @@ def _f32c(t, name="tensor"):
 
 GEMM_PROFILE = None       # bench.py sets this to a list to time every GEMM launch with HIP events
 ATTN_PROFILE = None       # ... and every attention launch: (kind, B, H, dh, Lq, La, Lb, event0, event1)
+KERNEL_PROFILE = None     # ... and selected HBM-bound launches: (name, algorithmic bytes, event0, event1)
+
+
+class _kprof:
+    """``with _kprof(name, nbytes):`` -- HIP events around a launch when bench.py asked for them (KERNEL_PROFILE is a list)."""
+
+    def __init__(self, name, nbytes):
+        self.name, self.nbytes = name, nbytes
+
+    def __enter__(self):
+        self.on = KERNEL_PROFILE is not None
+        if self.on:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *exc):
+        if self.on:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            KERNEL_PROFILE.append((self.name, self.nbytes, self.e0, e1))
+
+
+def attn_peak_tflops():
+    """Dense MFMA peak of the instruction the attention kernels use (roofline denominator of bench.py)."""
+    return 157.3          # v_mfma_f32_16x16x4_f32 (exact fp32 products)
+
+
+def attn_kernel_name():
+    return ("attn_fwd + attn_bwd_fused (v_mfma_f32_16x16x4_f32, exact fp32; backward = dQ + dK + dV in one kernel per key block, "
+            "S and dP computed once: 10 dh Lq T FLOP instead of 14)")
 ENGINE_F32, ENGINE_BF16X6, ENGINE_F16X3, ENGINE_F16X3P = 0, 1, 2, 3
 # default engine of gemm(): the scaled two-term fp16 split on the fp16 matrix cores (22-bit operands, three exact
 # partial products, fp32 accumulation: measured error vs fp64 at or below the f32-MFMA kernel's on every layout).
@@ -134,12 +165,31 @@ LAYOUT_NT, LAYOUT_NN, LAYOUT_TN = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_DGELU, ACT_RELU, ACT_DRELU = 0, 1, 2, 3, 4
 
 
-def l1norm(x, out=None, inv_scale=None, amax=None):
-    """``amax``: optional zeroed [AMAX_SLOTS] vector that receives the partial maxima of |out| (fp16x3 GEMM operand)."""
+class PO:
+    """Plane output of a producer kernel: (planes tensor, element offset, ld2, site header, device address of the delayed scale)."""
+    __slots__ = ("planes", "p_off", "ld2", "hdr", "scale_ptr")
+
+    def __init__(self, planes, ld2, hdr, scale_ptr, p_off=0):
+        self.planes, self.ld2, self.hdr, self.scale_ptr, self.p_off = planes, ld2, hdr, scale_ptr, p_off
+
+    def args(self):
+        return (self.planes.data_ptr() + 2 * self.p_off, self.ld2, self.hdr.data_ptr(), self.scale_ptr)
+
+
+_NO_PO = (None, 0, None, None)
+
+
+def _po(po):
+    return _NO_PO if po is None else po.args()
+
+
+def l1norm(x, out=None, inv_scale=None, amax=None, po=None):
+    """``amax``: optional zeroed [AMAX_SLOTS] vector that receives the partial maxima of |out| (fp16x3 GEMM operand);
+    ``po``: optional plane output (PO)."""
     _dev(x)
     D = x.shape[-1]
     rows = x.numel() // D
-    _check(lib().segmm_l1norm(_ptr(x), _ptr(out), _ptr(inv_scale), rows, D, _ptr(amax), _stream()), "segmm_l1norm")
+    _check(lib().segmm_l1norm(_ptr(x), _ptr(out), _ptr(inv_scale), rows, D, _ptr(amax), *_po(po), _stream()), "segmm_l1norm")
 
 
 def gemm(layout, M, N, K, A, lda, B, ldb, Cout, ldc, bias=None, row_scale=None, residual=None, ldr=0, res_period=0,
@@ -258,7 +308,7 @@ def to_planes(x, rows, cols, ld=None, x_off=0, keep_f32=True):
 
 def gemm_p(layout, M, N, K, A: "PT", B: "PT", Cout, ldc, c_pt: "PT" = None, write_c=True, bias=None, row_scale=None, residual=None,
            ldr=0, res_period=0, activation=0, aux=None, ldaux=0, drop_p=0.0, seed=0, site=0, splits=1, workspace=None,
-           accumulate=False, c_off=0, c_hdr=None):
+           accumulate=False, c_off=0, c_hdr=None, c_scale_ptr=None):
     """Plane-operand GEMM (segmm_gemm_p).  ``c_pt``: optional plane output (its hdr[0] holds the scale to write with);
     ``c_hdr``: site header that only receives the partial maxima of |C| (no plane output)."""
     prof = GEMM_PROFILE
@@ -268,7 +318,8 @@ def gemm_p(layout, M, N, K, A: "PT", B: "PT", Cout, ldc, c_pt: "PT" = None, writ
     _check(lib().segmm_gemm_p(layout, M, N, K, A.pptr(), A.ld2, A.hdr.data_ptr(), A.fptr(), A.ldf, B.pptr(), B.ld2, B.hdr.data_ptr(),
                               B.fptr(), B.ldf, None if Cout is None else Cout.data_ptr() + 4 * c_off, ldc,
                               None if c_pt is None else c_pt.pptr(), 0 if c_pt is None else c_pt.ld2,
-                              (None if c_hdr is None else c_hdr.data_ptr()) if c_pt is None else c_pt.hdr.data_ptr(), int(bool(write_c)),
+                              (None if c_hdr is None else c_hdr.data_ptr()) if c_pt is None else c_pt.hdr.data_ptr(), c_scale_ptr,
+                              int(bool(write_c)),
                               _ptr(bias), _ptr(row_scale), _ptr(residual),
                               ldr, res_period, activation, _ptr(aux), ldaux, float(drop_p), int(seed), int(site), int(splits),
                               _ptr(workspace), int(bool(accumulate)), _stream()), "segmm_gemm_p")
@@ -276,6 +327,11 @@ def gemm_p(layout, M, N, K, A: "PT", B: "PT", Cout, ldc, c_pt: "PT" = None, writ
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
         prof.append((layout, M, N, K, e0, e1))
+
+
+def scales_update(arena, site_idx, n_rows, site_scale, stats, target=12):
+    _check(lib().segmm_scales_update(arena.data_ptr(), site_idx.data_ptr(), int(n_rows), site_scale.data_ptr(), stats.data_ptr(), int(target),
+                                     _stream()), "segmm_scales_update")
 
 
 def absmax(x, rows, cols, ld, off=0, out=None):
@@ -309,11 +365,11 @@ def split3_transpose(x, R, Cc, ld, planes, x_off=0, p_off=0):
                                         _stream()), "segmm_split3_transpose")
 
 
-def layernorm_fwd(x, gamma, beta, y, mean, rstd, eps=1e-12, drop_p=0.0, seed=0, site=0, amax=None):
+def layernorm_fwd(x, gamma, beta, y, mean, rstd, eps=1e-12, drop_p=0.0, seed=0, site=0, amax=None, po=None):
     _dev(x, y)
     d = x.shape[-1]
     _check(lib().segmm_layernorm_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd),
-                                     x.numel() // d, d, eps, float(drop_p), int(seed), int(site), _ptr(amax), _stream()),
+                                     x.numel() // d, d, eps, float(drop_p), int(seed), int(site), _ptr(amax), *_po(po), _stream()),
            "segmm_layernorm_fwd")
 
 
@@ -322,12 +378,12 @@ def layernorm_bwd_parts(rows):
 
 
 def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dx_drop, part_dgamma, part_dbeta, drop_y_p=0.0, drop_y_site=0,
-                  drop_b_p=0.0, drop_b_site=0, seed=0, amax=None, part_dsum=None):
+                  drop_b_p=0.0, drop_b_site=0, seed=0, amax=None, part_dsum=None, po=None):
     _dev(dy, x, dx)
     d = x.shape[-1]
     _check(lib().segmm_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(dx), _ptr(dx_drop),
                                      _ptr(part_dgamma), _ptr(part_dbeta), _ptr(part_dsum), x.numel() // d, d, float(drop_y_p),
-                                     int(drop_y_site), float(drop_b_p), int(drop_b_site), int(seed), _ptr(amax), _stream()),
+                                     int(drop_y_site), float(drop_b_p), int(drop_b_site), int(seed), _ptr(amax), *_po(po), _stream()),
            "segmm_layernorm_bwd")
 
 
@@ -341,8 +397,16 @@ def colsum(X, ld, M, N, out, workspace, w=None, accumulate=False, x_off=0, out_o
                               int(bool(accumulate)), _ptr(workspace), _stream()), "segmm_colsum")
 
 
+class AttnPlanes(C.Structure):
+    """segmm_attn_planes_t"""
+    _fields_ = [("o", _p), ("ldo2", _i), ("hdr_o", _p), ("sin_o", _p),
+                ("dqa", _p), ("dqb", _p), ("lddq2", _i), ("dka", _p), ("dva", _p), ("lddka2", _i),
+                ("dkb", _p), ("dvb", _p), ("lddkb2", _i), ("hdr_q", _p), ("hdr_ka", _p), ("hdr_kb", _p),
+                ("sin_q", _p), ("sin_ka", _p), ("sin_kb", _p)]
+
+
 def attn_fwd(B, H, dh, Lq, La, Lb, Qa, Qb, ldq, Ka, Va, ldka, Kb, Vb, ldkb, mq, mka, mkb, O, ldo, lse,
-             drop_p=0.0, seed=0, site=0, amax_o=None):
+             drop_p=0.0, seed=0, site=0, amax_o=None, po=None):
     """Q*/K*/V* are (tensor, element_offset) pairs: column slices of the fused projection buffers.  A key block may be
     empty (La == 0 or Lb == 0, its pairs None): the CrossAtt / SelfAtt ablations attend to one block only."""
     def P(x):
@@ -351,9 +415,13 @@ def attn_fwd(B, H, dh, Lq, La, Lb, Qa, Qb, ldq, Ka, Va, ldka, Kb, Vb, ldkb, mq, 
     if prof is not None:
         e0 = torch.cuda.Event(enable_timing=True)
         e0.record()
+    pl = None
+    if po is not None:
+        a = po.args()
+        pl = C.byref(AttnPlanes(o=a[0], ldo2=a[1], hdr_o=a[2], sin_o=a[3]))
     _check(lib().segmm_attn_fwd(B, H, dh, Lq, La, Lb, P(Qa), P(Qb), ldq, P(Ka), P(Va), ldka, P(Kb), P(Vb), ldkb,
                                 _ptr(mq), _ptr(mka), _ptr(mkb), _ptr(O), ldo, _ptr(lse), float(drop_p), int(seed),
-                                int(site), _ptr(amax_o), _stream()), "segmm_attn_fwd")
+                                int(site), _ptr(amax_o), pl, _stream()), "segmm_attn_fwd")
     if prof is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
@@ -362,7 +430,7 @@ def attn_fwd(B, H, dh, Lq, La, Lb, Qa, Qb, ldq, Ka, Va, ldka, Kb, Vb, ldkb, mq, 
 
 def attn_bwd(B, H, dh, Lq, La, Lb, Qa, Qb, ldq, Ka, Va, ldka, Kb, Vb, ldkb, mq, mka, mkb, lse, O, ldo, dO, lddo, Dvec,
              dQa, dQb, lddq, dKa, dVa, lddka, dKb, dVb, lddkb, drop_p=0.0, seed=0, site=0, amax_q=None, amax_ka=None,
-             amax_kb=None, phase=0):
+             amax_kb=None, phase=0, planes=None):
     """``phase``: 0 whole backward; 1 Dvec only; 2 dQ only; 3 dK/dV only (2 and 3 may run concurrently after 1)."""
     def P(x):
         return 0 if x is None else x[0].data_ptr() + 4 * x[1]
@@ -373,7 +441,8 @@ def attn_bwd(B, H, dh, Lq, La, Lb, Qa, Qb, ldq, Ka, Va, ldka, Kb, Vb, ldkb, mq, 
     _check(lib().segmm_attn_bwd(B, H, dh, Lq, La, Lb, P(Qa), P(Qb), ldq, P(Ka), P(Va), ldka, P(Kb), P(Vb), ldkb,
                                 _ptr(mq), _ptr(mka), _ptr(mkb), _ptr(lse), _ptr(O), ldo, _ptr(dO), lddo, _ptr(Dvec), P(dQa),
                                 P(dQb), lddq, P(dKa), P(dVa), lddka, P(dKb), P(dVb), lddkb, float(drop_p), int(seed),
-                                int(site), _ptr(amax_q), _ptr(amax_ka), _ptr(amax_kb), int(phase), _stream()), "segmm_attn_bwd")
+                                int(site), _ptr(amax_q), _ptr(amax_ka), _ptr(amax_kb), int(phase),
+                                None if planes is None else C.byref(planes), _stream()), "segmm_attn_bwd")
     if prof is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
@@ -439,6 +508,11 @@ def loss_fwd_bwd(B, S, logits, gt, bias_w, bias_b, exposure, coef, enabled, rew_
 
 
 def adamw(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, p_off=0):
+    with _kprof("adamw", 28 * int(n)):
+        _adamw(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, p_off)
+
+
+def _adamw(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, p_off=0):
     _check(lib().segmm_adamw(p.data_ptr() + 4 * p_off, g.data_ptr() + 4 * p_off, m.data_ptr() + 4 * p_off,
                              v.data_ptr() + 4 * p_off, n, lr, beta1, beta2, eps, weight_decay, step, _stream()),
            "segmm_adamw")
@@ -487,7 +561,7 @@ def survival(interest, gt):
     return surv, label
 
 
-def gather_l1(table, idx, normalize=True, out=None, mask=None):
+def gather_l1(table, idx, normalize=True, out=None, mask=None, amax=None, po=None):
     """out[..., :] = (L1-normalised) table[idx[...]], mask[...] = idx in range; idx int64 of any shape."""
     _dev(table, idx)
     D = table.shape[1]
@@ -496,8 +570,9 @@ def gather_l1(table, idx, normalize=True, out=None, mask=None):
         out = torch.empty(tuple(idx.shape) + (D,), dtype=torch.float32, device=table.device)
     if mask is None:
         mask = torch.empty(tuple(idx.shape), dtype=torch.uint8, device=table.device)
-    _check(lib().segmm_gather_l1(_ptr(_f32c(table, "table")), table.shape[0], D, _ptr(idx.contiguous()), rows, int(bool(normalize)),
-                                 _ptr(out), _ptr(mask), _stream()), "segmm_gather_l1")
+    with _kprof("gather_l1", rows * (8 * D + 9)):
+        _check(lib().segmm_gather_l1(_ptr(_f32c(table, "table")), table.shape[0], D, _ptr(idx.contiguous()), rows, int(bool(normalize)),
+                                     _ptr(out), _ptr(mask), _ptr(amax), *_po(po), _stream()), "segmm_gather_l1")
     return out, mask.view(torch.bool)
 
 

@@ -25,6 +25,7 @@ import os
 import torch
 import torch.nn as nn
 
+from . import engine as E
 from . import hipabi as H
 from .decoder_leave_focal import MultiScaleTemporalDetrLeaveFocal
 from .encoder import SegFormerX
@@ -273,6 +274,8 @@ class Trainer:
         st.row_exchange = self.comm.gather_rows if self.sparse_tables else None
         self._norm = {}
         self._norm_amax = None
+        self._norm_planes = {}
+        self._norm_fresh = False
 
     def _on_bucket(self, name):
         st = self.model._store
@@ -300,43 +303,78 @@ class Trainer:
                 return bb.usr_proj.num_embeddings - 1
         return None
 
+    def _input_act(self, key, buf):
+        """Site header (+ planes, + plane output for the producer kernel) of an input feature tensor the trainer itself
+        produces this step (L1 normalisation or table gather).  The Act travels WITH the tensor object (attribute
+        ``_segmm_act``), never keyed by its device address: a tensor the trainer did not produce in this step (rand_like for
+        'noUser', features handed straight to model()) has none and gets an absmax pass in engine.BackboneRun._input_act."""
+        st = self.model._store
+        if not st.engine_h:
+            return None
+        dev = buf.device
+        if self._norm_amax is None or self._norm_amax.device != dev:
+            self._norm_amax = torch.zeros((2, H.SITE_FLOATS), dtype=torch.float32, device=dev)
+            self._norm_fresh = True
+        if not self._norm_fresh:
+            self._norm_amax.zero_()          # one fill per step, before the first input of the step is produced
+            self._norm_fresh = True
+        cols = buf.shape[-1]
+        rows = buf.numel() // cols
+        planes = None
+        if st.engine_p and cols % 32 == 0:
+            planes = self._norm_planes.get(key)
+            if planes is None or planes.shape != (rows, 2 * cols) or planes.device != dev:
+                planes = self._norm_planes[key] = torch.empty((rows, 2 * cols), dtype=torch.float16, device=dev)
+        act = E.Act(buf, self._norm_amax[0 if key == "user" else 1], rows, cols, planes)
+        if planes is not None:
+            delayed = (self.model.training and st.scaling != "exact") or st.scaling == "always"
+            act.scale_ptr = st.scale_ptr("in." + key, delayed)
+            if act.scale_ptr is not None:
+                act.po = H.PO(planes, 2 * cols, act.hdr, act.scale_ptr)
+        buf._segmm_act = act
+        return act
+
     def normalize(self, key, x):
         """a1: x / (sum|x| + 1e-6) over the feature dim, into a persistent buffer."""
         buf = self._norm.get(key)
         if buf is None or buf.shape != x.shape or buf.device != x.device:
             buf = self._norm[key] = torch.empty_like(x)
-        hdr = None
-        if H.GEMM_ENGINE in (H.ENGINE_F16X3, H.ENGINE_F16X3P):
-            # the fp16x3 GEMM that reads ``buf`` needs max|buf|: folded into this kernel instead of a separate pass over the
-            # features.  The site header travels WITH the tensor object (attribute), never keyed by its device address: a
-            # tensor the trainer did not produce in this step (rand_like for 'noUser', features handed straight to model())
-            # has no header and gets an absmax pass in engine.BackboneRun._input_act.
-            if self._norm_amax is None or self._norm_amax.device != x.device:
-                self._norm_amax = torch.empty((2, H.SITE_FLOATS), dtype=torch.float32, device=x.device)
-            if key == "user" or "user" not in self._norm:
-                self._norm_amax.zero_()          # one fill per step: "user" is normalised first (see _features)
-            hdr = self._norm_amax[0 if key == "user" else 1]
-            buf._segmm_hdr = hdr
-        am = None if hdr is None else hdr[H.SITE_HDR:]
-        H.l1norm(x, buf, amax=am)
+        act = self._input_act(key, buf)
+        # the GEMM that reads ``buf`` needs max|buf| (and, on the plane engine, its fp16 planes): both are folded into this
+        # kernel instead of separate passes over the features
+        H.l1norm(x, buf, amax=None if act is None else act.slots, po=None if act is None else act.po)
+        if act is not None:
+            E.produced(act)
         return buf
 
     def _features(self, batch):
         """(usr, usr_mask, vid, vid_mask): L1-normalised feature tensors of a batch, from the tensors it carries or --
         index batches -- gathered from the resident table."""
         it = self.model.input_type
+        self.model._store.ensure()
         usr = vid = None
         um, vm = batch.get("user_mask"), batch.get("photo_mask")
-        if it["user"] != "id":
-            if "user_idx" in batch:
-                usr, um = self.feature_table.gather("user", batch["user_idx"])
+        self._norm_fresh = False
+        for key, kind in (("user", it["user"]), ("photo", it["photo"])):
+            if kind == "id":
+                continue
+            if key + "_idx" in batch:
+                out, mask = self.feature_table.buffers(key, batch[key + "_idx"])
+                act = self._input_act(key, out)
+                self.feature_table.gather(key, batch[key + "_idx"], amax=None if act is None else act.slots,
+                                          po=None if act is None else act.po)
+                if act is not None:
+                    E.produced(act)
+                x, m = out, mask.view(torch.bool)
             else:
-                usr = self.normalize("user", batch["user"])
-        if it["photo"] != "id":
-            if "photo_idx" in batch:
-                vid, vm = self.feature_table.gather("photo", batch["photo_idx"])
+                x, m = self.normalize(key, batch[key]), (um if key == "user" else vm)
+            if key == "user":
+                usr, um = x, m
             else:
-                vid = self.normalize("photo", batch["photo"])
+                vid, vm = x, m
+        st = self.model._store
+        if st.engine_p and self._norm_amax is not None and self._norm_fresh:
+            st.update_scales(self._norm_amax, ["in.user", "in.photo"], 2)          # the input sites' scales of the next step
         return usr, um, vid, vm
 
     def train_step(self, batch: Dict[str, torch.Tensor]):

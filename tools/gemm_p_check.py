@@ -80,11 +80,11 @@ def main():
             Cp, Cl = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev)
             auxp, auxl = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev)
             hdr = H.new_site(dev)[0]
-            hdr[0] = 2.0 ** 10
+            sc = torch.tensor([2.0 ** 10], device=dev)
             cpl = torch.empty(M, 2 * N, dtype=torch.float16, device=dev)
             cpt = H.PT(cpl, hdr, M, N, f32=Cp)
             kw = dict(bias=bias, residual=res, ldr=N, res_period=M, activation=act, drop_p=0.1, seed=1234, site=7, ldaux=N)
-            H.gemm_p(H.LAYOUT_NT, M, N, K, pa, pw, Cp, N, c_pt=cpt, aux=auxp if act else None, **kw)
+            H.gemm_p(H.LAYOUT_NT, M, N, K, pa, pw, Cp, N, c_pt=cpt, c_scale_ptr=sc.data_ptr(), aux=auxp if act else None, **kw)
             H.gemm(H.LAYOUT_NT, M, N, K, A, K, W, K, Cl, N, engine=H.ENGINE_F16X3, aux=auxl if act else None, **kw)
             torch.cuda.synchronize()
             d = float((Cp - Cl).abs().max() / Cl.abs().max())
@@ -92,7 +92,7 @@ def main():
             recon = ((v[:, :, 0] + v[:, :, 1]) / hdr[0]).reshape(M, N)
             dr = float((recon - Cp).abs().max() / Cp.abs().max())
             amax_ok = abs(float(hdr[H.SITE_HDR:].max()) - float(Cp.abs().max())) == 0.0
-            good = d < 1e-5 and dr < 1e-6 and amax_ok and float(hdr[1]) == 0.0
+            good = d < 1e-5 and dr < 1e-6 and amax_ok and float(hdr[1]) == 0.0 and float(hdr[0]) == 2.0 ** 10
             ok &= good
             print("NT epilogue act=%d: maxdiff vs on-the-fly %.1e, plane output reconstruction %.1e, amax exact %s %s" % (act, d, dr, amax_ok, "ok" if good else "FAIL"))
     if "tn" in args.layouts:
