@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void gather_l1_kernel(const float* __restrict_
     if (!ok) {
         for (int c = lane * 4; c < D; c += 256) {
             *(f32x4*)(o + c) = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (ps > 0.f) plane_store4(po.p, po.ld2, r, c, f32x4{0.f, 0.f, 0.f, 0.f}, ps);
+            if (ps > 0.f) plane_store4_pair(po.p, po.ld2, r, c, f32x4{0.f, 0.f, 0.f, 0.f}, ps);
         }
         plane_finish(po, amax, 0.f, (unsigned)r, ps, r == 0 && lane == 0);
         return;
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void gather_l1_kernel(const float* __restrict_
         f32x4 v = *(const f32x4*)(t + c);
         if (normalize) { v.x /= s; v.y /= s; v.z /= s; v.w /= s; }
         *(f32x4*)(o + c) = v;
-        if (ps > 0.f) plane_store4(po.p, po.ld2, r, c, v, ps);
+        if (ps > 0.f) plane_store4_pair(po.p, po.ld2, r, c, v, ps);
         am = absmax4(am, v);
     }
     plane_finish(po, amax, am, (unsigned)r, ps, r == 0 && lane == 0);

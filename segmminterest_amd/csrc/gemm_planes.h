@@ -122,7 +122,7 @@ __device__ __forceinline__ void epi_strip_emit(const GemmArgs& p, const PGemmX& 
             if ((SPLITK || q.write_c) && !(q.dbg & 1)) *(f32x4*)(Cout + (size_t)gm * p.ldc + gn) = v;
             if (!SPLITK) {
                 am = absmax4(am, v);
-                if (c_scale > 0.f && q.Cp) plane_store4(q.Cp, q.ldc2, gm, gn, v, c_scale);
+                if (c_scale > 0.f && q.Cp) plane_store4_pair(q.Cp, q.ldc2, gm, gn, v, c_scale);
             }
         }
     }
@@ -499,12 +499,7 @@ __global__ __launch_bounds__(256) void split_p32_kernel(const float* __restrict_
         const long long r = i / c4n;
         const int c = (int)(i - r * c4n) << 2;
         const f32x4 v = *(const f32x4*)(x + r * ld + c);
-        uint32_t h0, l0, h1, l1;
-        splith_pair(v.x, v.y, s, h0, l0);
-        splith_pair(v.z, v.w, s, h1, l1);
-        _Float16* o = planes + r * ld2 + ((c >> 5) << 6) + (c & 31);
-        *(uint2*)o = make_uint2(h0, h1);
-        *(uint2*)(o + 32) = make_uint2(l0, l1);
+        plane_store4_pair(planes, ld2, r, c, v, s);      // i even <-> c % 8 == 0: lane pairs share a row (cols % 8 == 0)
         am = absmax4(am, v);
     }
     if (mode == 0) {

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void l1norm_kernel(const float* __restrict__ x
             f32x4 v = *(const f32x4*)(xr + c);
             v.x /= den; v.y /= den; v.z /= den; v.w /= den;
             *(f32x4*)(y + row * D + c) = v;
-            if (ps > 0.f) plane_store4(po.p, po.ld2, row, c, v, ps);
+            if (ps > 0.f) plane_store4_pair(po.p, po.ld2, row, c, v, ps);
             am = absmax4(am, v);
         }
         plane_finish(po, amax, am, (unsigned)row, ps, row == 0 && lane == 0);      // partial maxima of |y| for the GEMM that reads y
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
             f32x4 o = (v[i] - mean) * rstd * *(const f32x4*)(gamma + c) + *(const f32x4*)(beta + c);
             if (drop.p > 0.f) o = drop_apply4(drop, ((uint64_t)row * d + c) >> 2, o);
             *(f32x4*)(y + row * d + c) = o;
-            if (ps > 0.f) plane_store4(po.p, po.ld2, row, c, o, ps);
+            if (ps > 0.f) plane_store4_pair(po.p, po.ld2, row, c, o, ps);
             am = absmax4(am, o);
         }
     }
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                     if (drop_branch.p > 0.f) od = drop_apply4(drop_branch, ((uint64_t)row * d + c) >> 2, o);
                     *(f32x4*)(dx_drop + row * d + c) = od;
                 }
-                if (ps > 0.f) plane_store4(po.p, po.ld2, row, c, od, ps);
+                if (ps > 0.f) plane_store4_pair(po.p, po.ld2, row, c, od, ps);
                 as[i] += od;
                 am = absmax4(am, od);
             }

@@ -1,0 +1,363 @@
+"""The plane-operand GEMM path on the MI355X (csrc/gemm_planes.h, common.h PlaneOut): GEMM kernels against fp64 and the
+on-the-fly fp16x3 kernel, producer-written planes against the stand-alone split pass (bit for bit), the overflow fall-back,
+the delayed-scale update, and whole-model agreement of delayed scaling with exact scaling.  Run with ``pytest -m gpu``."""
+import math
+import os
+import sys
+
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from helpers import MODEL_CASES, build_model, call_model, load_case      # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _abi():
+    from segmminterest_amd import hipabi
+    hipabi.lib()
+    return hipabi
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+def _planes_to_f32(planes, rows, cols, scale):
+    v = planes.view(rows, cols // 32, 2, 32).float()
+    return ((v[:, :, 0] + v[:, :, 1]) / scale).reshape(rows, cols)
+
+
+def _ref_planes(H, x, rows, cols, scale):
+    """planes of x made by the stand-alone pass with a GIVEN scale (mode 1) -- the reference for every fused producer"""
+    hdr = H.new_site(x.device)[0]
+    hdr[0] = scale
+    pl = torch.empty((rows, 2 * cols), dtype=torch.float16, device=x.device)
+    H.split_p32(x, rows, cols, cols, pl, 2 * cols, hdr, mode=1)
+    return pl, hdr
+
+
+def _po(H, rows, cols, scale):
+    hdr = H.new_site(DEV)[0]
+    sc = torch.tensor([scale], dtype=torch.float32, device=DEV)
+    pl = torch.zeros((rows, 2 * cols), dtype=torch.float16, device=DEV)
+    return pl, hdr, sc, H.PO(pl, 2 * cols, hdr, sc.data_ptr())
+
+
+# ------------------------------------------------------------------ GEMM kernels
+@pytest.mark.parametrize("M,N,K", [(256, 256, 32), (1024, 768, 768), (300, 96, 64), (20480, 768, 768), (37, 32, 160)])
+def test_gemm_p_nt_matches_fp64_and_on_the_fly(M, N, K):
+    H = _abi()
+    A, W = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=0.02)
+    A[::7] *= 3.0
+    pa, pw = H.to_planes(A, M, K), H.to_planes(W, N, K, keep_f32=False)
+    Cp, Cl = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+    H.gemm_p(H.LAYOUT_NT, M, N, K, pa, pw, Cp, N)
+    H.gemm(H.LAYOUT_NT, M, N, K, A, K, W, K, Cl, N, engine=H.ENGINE_F16X3)
+    ref = A[:512].double() @ W.double().t()
+    e_p = (Cp[:512].double() - ref).abs().mean() / ref.abs().mean()
+    e_l = (Cl[:512].double() - ref).abs().mean() / ref.abs().mean()
+    assert e_p <= 1.5 * e_l + 1e-7, (float(e_p), float(e_l))
+    assert float((Cp - Cl).abs().max() / Cl.abs().max()) < 2e-6
+
+
+def test_gemm_p_asymmetric_identity():
+    """A = I with an asymmetric B catches a transposed C/D map or a wrong LDS permutation (guide §3)."""
+    H = _abi()
+    n = 256
+    A = torch.eye(n, device=DEV)
+    Bm = (torch.arange(n * n, device=DEV, dtype=torch.float32).view(n, n) % 97) + torch.arange(n, device=DEV)[:, None] * 0.5
+    C = torch.empty(n, n, device=DEV)
+    H.gemm_p(H.LAYOUT_NT, n, n, n, H.to_planes(A, n, n), H.to_planes(Bm, n, n), C, n)
+    assert torch.equal(C, Bm.t())
+    H.gemm_p(H.LAYOUT_TN, n, n, n, H.to_planes(Bm, n, n), H.to_planes(A, n, n), C, n)      # C = Bm^T . I
+    assert torch.equal(C, Bm.t())
+
+
+@pytest.mark.parametrize("M,N,K,splits", [(768, 768, 2048, 7), (96, 64, 300, 1), (96, 64, 300, 3), (64, 32, 8, 1), (3072, 768, 4096, 4)])
+def test_gemm_p_tn_splitk(M, N, K, splits):
+    H = _abi()
+    dY, X = _rand(K, M, seed=3, scale=0.01), _rand(K, N, seed=4)
+    C = torch.empty(M, N, device=DEV)
+    ws = torch.empty(splits * M * N, device=DEV)
+    H.gemm_p(H.LAYOUT_TN, M, N, K, H.to_planes(dY, K, M), H.to_planes(X, K, N), C, N, splits=splits, workspace=ws)
+    ref = dY.double().t() @ X.double()
+    assert float((C.double() - ref).abs().max() / ref.abs().max()) < 3e-6
+    # accumulate
+    C0 = C.clone()
+    H.gemm_p(H.LAYOUT_TN, M, N, K, H.to_planes(dY, K, M), H.to_planes(X, K, N), C, N, splits=splits, workspace=ws, accumulate=True)
+    assert float((C - 2 * C0).abs().max() / C0.abs().max()) < 1e-6
+
+
+def test_gemm_p_column_slices_of_fused_buffers():
+    """Operands as column slices (multiples of 32) of wider plane buffers: the fused dY / projection layouts."""
+    H = _abi()
+    T, d = 640, 64
+    dY, X = _rand(T, 3 * d, seed=5), _rand(T, d, seed=6)
+    pdy, px = H.to_planes(dY, T, 3 * d), H.to_planes(X, T, d)
+    C = torch.empty(d, d, device=DEV)
+    H.gemm_p(H.LAYOUT_TN, d, d, T, pdy.cols_slice(d, d), px, C, d)
+    ref = dY[:, d:2 * d].double().t() @ X.double()
+    assert float((C.double() - ref).abs().max() / ref.abs().max()) < 3e-6
+    W = _rand(d, 3 * d, seed=7, scale=0.05)          # dgrad: [T, 3d] . W^T planes [d, 3d]
+    Cd = torch.empty(T, d, device=DEV)
+    H.gemm_p(H.LAYOUT_NT, T, d, 3 * d, pdy, H.to_planes(W, d, 3 * d), Cd, d)
+    refd = dY.double() @ W.double().t()
+    assert float((Cd.double() - refd).abs().max() / refd.abs().max()) < 3e-6
+
+
+@pytest.mark.parametrize("act", [0, 1, 2, 3])
+def test_gemm_p_epilogue_matches_on_the_fly(act):
+    H = _abi()
+    M, N, K = 512, 128, 64
+    A, W = _rand(M, K, seed=8), _rand(N, K, seed=9, scale=0.1)
+    bias, res = _rand(N, seed=10), _rand(40, N, seed=11)
+    aux0 = _rand(M, N, seed=12)
+    Cp, Cl = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+    auxp, auxl = aux0.clone(), aux0.clone()
+    kw = dict(bias=bias, residual=res, ldr=N, res_period=40, activation=act, drop_p=0.25, seed=77, site=5, ldaux=N)
+    pl, hdr, sc, po = _po(H, M, N, 2.0 ** 9)
+    H.gemm_p(H.LAYOUT_NT, M, N, K, H.to_planes(A, M, K), H.to_planes(W, N, K), Cp, N, c_pt=H.PT(pl, hdr, M, N, f32=Cp),
+             c_scale_ptr=sc.data_ptr(), aux=auxp if act in (1, 2) else None, **kw)
+    H.gemm(H.LAYOUT_NT, M, N, K, A, K, W, K, Cl, N, engine=H.ENGINE_F16X3, aux=auxl if act in (1, 2) else None, **kw)
+    assert float((Cp - Cl).abs().max()) <= 1e-6 * float(Cl.abs().max())
+    if act == 1:
+        assert float((auxp - auxl).abs().max()) <= 1e-6 * float(auxl.abs().max())
+    ref_pl, _ = _ref_planes(H, Cp, M, N, 2.0 ** 9)
+    assert torch.equal(pl, ref_pl)
+    assert float(hdr[0]) == 2.0 ** 9 and float(hdr[1]) == 0.0
+    assert float(hdr[H.SITE_HDR:].max()) == float(Cp.abs().max())
+
+
+def test_gemm_p_overflow_flag_takes_fp32_path():
+    """A delayed scale that has become too large: the producer raises the flag, the consumer reads the fp32 copy instead of
+    the (infinite) planes -- same result as with exact planes."""
+    H = _abi()
+    M, N, K = 384, 96, 128
+    A, W = _rand(M, K, seed=13), _rand(N, K, seed=14, scale=0.05)
+    A[5, 7] = 300.0
+    good = H.to_planes(A, M, K)
+    pw = H.to_planes(W, N, K)
+    C0, C1, C2 = (torch.empty(M, N, device=DEV) for _ in range(3))
+    H.gemm_p(H.LAYOUT_NT, M, N, K, good, pw, C0, N)
+    # planes written with a scale 2^10 too large for the outlier: 300 * 2^10 > 65504
+    pl, hdr = _ref_planes(H, A, M, K, 2.0 ** 10)
+    assert float(hdr[1]) != 0.0 and not torch.isfinite(pl.float()).all()
+    bad = H.PT(pl, hdr, M, K, f32=A)
+    H.gemm_p(H.LAYOUT_NT, M, N, K, bad, pw, C1, N)
+    assert torch.isfinite(C1).all() and float((C1 - C0).abs().max()) <= 2e-6 * float(C0.abs().max())
+    # TN: both operands flagged
+    dY, X = _rand(K, M, seed=15), _rand(K, N, seed=16)
+    dY[3, 3] = 500.0
+    pdy, h1 = _ref_planes(H, dY, K, M, 2.0 ** 9)
+    px, h2 = _ref_planes(H, X, K, N, 2.0 ** 14)
+    assert float(h1[1]) != 0.0 and float(h2[1]) != 0.0
+    H.gemm_p(H.LAYOUT_TN, M, N, K, H.PT(pdy, h1, K, M, f32=dY), H.PT(px, h2, K, N, f32=X), C2, N)
+    ref = dY.double().t() @ X.double()
+    assert float((C2.double() - ref).abs().max() / ref.abs().max()) < 3e-6
+    # never-written planes (scale 0) take the same path
+    hz = H.new_site(DEV)[0]
+    H.absmax(A, M, K, K, out=hz[H.SITE_HDR:])
+    H.gemm_p(H.LAYOUT_NT, M, N, K, H.PT(torch.zeros_like(pl), hz, M, K, f32=A), pw, C1, N)
+    assert float((C1 - C0).abs().max()) <= 2e-6 * float(C0.abs().max())
+
+
+def test_low_scale_keeps_fp32_level_accuracy():
+    """Delayed scales sit 2^3 below the exact ones (head-room for growth): the GEMM error vs fp64 must stay at fp32 level."""
+    H = _abi()
+    M, N, K = 2048, 768, 768
+    A, W = _rand(M, K, seed=17), _rand(N, K, seed=18, scale=0.02)
+    A[:, ::5] *= 1e-3                                    # wide dynamic range inside rows
+    ref = A[:256].double() @ W.double().t()
+    pw = H.to_planes(W, N, K)
+    errs = []
+    for shift in (0, 3, 6):
+        exact = H.to_planes(A, M, K)
+        s = float(exact.hdr[0]) / 2.0 ** shift
+        pl, hdr = _ref_planes(H, A, M, K, s)
+        C = torch.empty(M, N, device=DEV)
+        H.gemm_p(H.LAYOUT_NT, M, N, K, H.PT(pl, hdr, M, K, f32=A), pw, C, N)
+        errs.append(float((C[:256].double() - ref).abs().mean() / ref.abs().mean()))
+    Cf = torch.empty(M, N, device=DEV)
+    H.gemm(H.LAYOUT_NT, M, N, K, A, K, W, K, Cf, N, engine=H.ENGINE_F32)
+    e32 = float((Cf[:256].double() - ref).abs().mean() / ref.abs().mean())
+    assert errs[1] <= 1.5 * e32 + 1e-8 and errs[2] <= 2.0 * e32 + 1e-8, (errs, e32)
+
+
+# ------------------------------------------------------------------ producers: fused planes == split pass of their fp32 output
+def test_rowop_producers_write_the_split_pass_planes():
+    H = _abi()
+    rows, d = 300, 96
+    x = _rand(rows, d, seed=20).abs() + 0.01
+    # L1 normalisation
+    y = torch.empty_like(x)
+    pl, hdr, sc, po = _po(H, rows, d, 2.0 ** 13)
+    H.l1norm(x, y, po=po)
+    ref_pl, _ = _ref_planes(H, y, rows, d, 2.0 ** 13)
+    assert torch.equal(pl, ref_pl) and float(hdr[0]) == 2.0 ** 13 and float(hdr[1]) == 0.0
+    assert float(hdr[H.SITE_HDR:].max()) == float(y.abs().max())
+    # LayerNorm forward (+ dropout)
+    g, b = _rand(d, seed=21), _rand(d, seed=22)
+    out, mean, rstd = torch.empty_like(x), torch.empty(rows, device=DEV), torch.empty(rows, device=DEV)
+    pl, hdr, sc, po = _po(H, rows, d, 2.0 ** 10)
+    H.layernorm_fwd(x, g, b, out, mean, rstd, drop_p=0.1, seed=5, site=3, po=po)
+    ref_pl, _ = _ref_planes(H, out, rows, d, 2.0 ** 10)
+    assert torch.equal(pl, ref_pl) and float(hdr[0]) == 2.0 ** 10
+    out2 = torch.empty_like(x)
+    H.layernorm_fwd(x, g, b, out2, mean, rstd, drop_p=0.1, seed=5, site=3)
+    assert torch.equal(out, out2)                       # the fp32 output does not depend on the plane output
+    # LayerNorm backward: planes of the forwarded (dropped) gradient
+    dy = _rand(rows, d, seed=23)
+    parts = H.layernorm_bwd_parts(rows)
+    dx, dxd = torch.empty_like(x), torch.empty_like(x)
+    pg, pb = torch.empty(parts, d, device=DEV), torch.empty(parts, d, device=DEV)
+    pl, hdr, sc, po = _po(H, rows, d, 2.0 ** 11)
+    H.layernorm_bwd(dy, x, mean, rstd, g, dx, dxd, pg, pb, drop_b_p=0.1, drop_b_site=9, seed=5, po=po)
+    ref_pl, _ = _ref_planes(H, dxd, rows, d, 2.0 ** 11)
+    assert torch.equal(pl, ref_pl)
+    assert float(hdr[H.SITE_HDR:].max()) == float(dxd.abs().max())
+    # no scale yet (first use of a site): no planes, only the maxima
+    pl, hdr, sc, po = _po(H, rows, d, 0.0)
+    am = hdr[H.SITE_HDR:]
+    H.layernorm_fwd(x, g, b, out2, mean, rstd, amax=am, po=po)
+    assert float(hdr[0]) == 0.0 and float(pl.float().abs().max()) == 0.0 and float(am.max()) == float(out2.abs().max())
+
+
+def test_gather_writes_planes_and_maxima():
+    H = _abi()
+    table = _rand(50, 64, seed=24).abs()
+    idx = torch.tensor([[3, 7, -1, 49], [0, 0, 12, -1]], device=DEV)
+    out = torch.empty(2, 4, 64, device=DEV)
+    mask = torch.empty(2, 4, dtype=torch.uint8, device=DEV)
+    pl, hdr, sc, po = _po(H, 8, 64, 2.0 ** 14)
+    H.gather_l1(table, idx, out=out, mask=mask, po=po)
+    ref_pl, _ = _ref_planes(H, out.view(8, 64), 8, 64, 2.0 ** 14)
+    assert torch.equal(pl, ref_pl) and float(hdr[H.SITE_HDR:].max()) == float(out.abs().max())
+
+
+def test_attention_producers_write_the_split_pass_planes():
+    H = _abi()
+    B, Hh, dh, S, Lt = 3, 4, 16, 40, 23
+    d = Hh * dh
+    Yv, Yu = _rand(B * S, 4 * d, seed=30), _rand(B * Lt, 2 * d, seed=31)
+    vm = (torch.rand(B, S, generator=torch.Generator().manual_seed(1)) > 0.2).to(torch.uint8).to(DEV)
+    um = (torch.rand(B, Lt, generator=torch.Generator().manual_seed(2)) > 0.2).to(torch.uint8).to(DEV)
+    O, lse = torch.empty(B * S, d, device=DEV), torch.empty(2, B, Hh, S, device=DEV)
+    args = (B, Hh, dh, S, S, Lt, (Yv, 0), (Yv, d), 4 * d, (Yv, 2 * d), (Yv, 3 * d), 4 * d, (Yu, 0), (Yu, d), 2 * d, vm, vm, um)
+    pl, hdr, sc, po = _po(H, B * S, d, 2.0 ** 12)
+    H.attn_fwd(*args, O, d, lse, drop_p=0.1, seed=3, site=2, po=po)
+    ref_pl, _ = _ref_planes(H, O, B * S, d, 2.0 ** 12)
+    assert torch.equal(pl, ref_pl) and float(hdr[0]) == 2.0 ** 12
+    assert float(hdr[H.SITE_HDR:].max()) == float(O.abs().max())
+    # fused backward: planes of dYv (Qa, Qb, Ka, Va column blocks) and dYu (Kb, Vb)
+    dO = _rand(B * S, d, seed=32)
+    dYv, dYu = torch.zeros_like(Yv), torch.zeros_like(Yu)
+    Dv = torch.empty(B * Hh * S, device=DEV)
+    plv, hv, scv, _ = _po(H, B * S, 4 * d, 2.0 ** 9)
+    plu, hu, scu, _ = _po(H, B * Lt, 2 * d, 2.0 ** 8)
+    pln = H.AttnPlanes()
+    base_v, base_u = plv.data_ptr(), plu.data_ptr()
+    pln.dqa, pln.dqb, pln.lddq2 = base_v, base_v + 4 * d, 8 * d
+    pln.dka, pln.dva, pln.lddka2 = base_v + 8 * d, base_v + 12 * d, 8 * d
+    pln.dkb, pln.dvb, pln.lddkb2 = base_u, base_u + 4 * d, 4 * d
+    pln.hdr_q = pln.hdr_ka = hv.data_ptr()
+    pln.hdr_kb = hu.data_ptr()
+    pln.sin_q = pln.sin_ka = scv.data_ptr()
+    pln.sin_kb = scu.data_ptr()
+    H.attn_bwd(*args, lse, O, d, dO, d, Dv, (dYv, 0), (dYv, d), 4 * d, (dYv, 2 * d), (dYv, 3 * d), 4 * d, (dYu, 0), (dYu, d), 2 * d,
+               drop_p=0.1, seed=3, site=2, phase=4, planes=pln)
+    rv, _ = _ref_planes(H, dYv, B * S, 4 * d, 2.0 ** 9)
+    ru, _ = _ref_planes(H, dYu, B * Lt, 2 * d, 2.0 ** 8)
+    assert torch.equal(plv, rv) and torch.equal(plu, ru)
+    assert float(hv[0]) == 2.0 ** 9 and float(hu[0]) == 2.0 ** 8 and float(hv[1]) == 0.0 and float(hu[1]) == 0.0
+    assert float(hv[H.SITE_HDR:].max()) == float(dYv.abs().max()) and float(hu[H.SITE_HDR:].max()) == float(dYu.abs().max())
+
+
+def test_scales_update():
+    H = _abi()
+    arena = H.new_site(DEV, 4)
+    arena[0, H.SITE_HDR + 3] = 5.0            # max 5 -> 2^2 <= 5 < 2^3: scale 2^(11-2) = 512 (5 * 512 = 2560 in [2048, 4096))
+    arena[1, H.SITE_HDR + 200] = 0.002        # 2^-9 <= .002 < 2^-8 -> 2^20
+    arena[2, H.SITE_HDR] = float("inf")       # non-finite: scale kept
+    arena[2, 1] = 1.0                         # flagged
+    idx = torch.tensor([0, 1, 2, -1], dtype=torch.int32, device=DEV)
+    sc = torch.full((8,), 7.0, device=DEV)
+    stats = torch.zeros(8, device=DEV)
+    H.scales_update(arena, idx, 4, sc, stats, 12)
+    assert sc[:4].tolist() == [512.0, 2.0 ** 20, 7.0, 7.0] and float(stats[0]) == 1.0
+
+
+# ------------------------------------------------------------------ whole model: delayed scaling == exact scaling
+@pytest.mark.parametrize("name", ["img_d32_N3_alllosses", "img_d64_h16_N3_Lt100", "both_fh2", "abl_crossmlp_N2", "abl_selfatt_N3"])
+def test_delayed_scaling_matches_exact(name):
+    """Second pass of the same eval-mode forward/backward with producer-written planes under DELAYED scales (the first pass
+    calibrates them) against the exact-split pass: same logits and gradients to fp32 rounding, and still within the
+    reference tolerance of the golden fixture."""
+    from segmminterest_amd import hipabi as H
+    if H.GEMM_ENGINE != H.ENGINE_F16X3P:
+        pytest.skip("plane engine only")
+    cfg, g, nograd, _ = load_case(name)
+    model = build_model(cfg)
+    model.load_state_dict(g["sd"])
+    model = model.cuda().eval()
+    st = model._store
+
+    def run():
+        model.zero_grad(set_to_none=True)
+        out = call_model(model, g["in"], "train", DEV)
+        out["loss"].backward()
+        return out["logits"].detach().clone(), {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+
+    st.scaling = "exact"
+    lg0, gr0 = run()
+    st.scaling = "always"
+    run()                                   # calibration pass (sites unknown -> exact split passes), scales recorded
+    assert len(st.calibrated) > 0
+    lg1, gr1 = run()                        # delayed scales, producer-written planes
+    assert st.overflow_count() == 0
+    assert float((lg1 - lg0).abs().max()) < 2e-6 * max(1.0, float(lg0.abs().max()))
+    for k in gr0:
+        sc = max(float(gr0[k].abs().max()), 1e-6)
+        assert float((gr1[k] - gr0[k]).abs().max()) <= 2e-5 * sc + 1e-7, k
+    assert float((lg1.cpu() - g["out"]["logits"]).abs().max()) < 1e-4
+    for k, ref in g["grad"].items():
+        sc = max(float(ref.abs().max()), 1e-6)
+        assert float((gr1[k].cpu() - ref).abs().max()) <= 3e-4 * sc + 2e-6, k
+
+
+def test_delayed_scaling_survives_a_magnitude_jump():
+    """Inputs 4096x larger than the calibration pass: delayed scales overflow, the flags route the GEMMs to the fp32 copies,
+    results stay correct (and the next pass runs on fresh scales again)."""
+    from segmminterest_amd import hipabi as H
+    if H.GEMM_ENGINE != H.ENGINE_F16X3P:
+        pytest.skip("plane engine only")
+    cfg, g, _, _ = load_case("img_d32_N2")
+    model = build_model(cfg)
+    model.load_state_dict(g["sd"])
+    model = model.cuda().eval()
+    st = model._store
+    inp = {k: v.clone() for k, v in g["in"].items()}
+    big = dict(model.backbone1.named_parameters())
+
+    def fwd():
+        with torch.no_grad():
+            return call_model(model, inp, "inference", DEV)["logits"].clone()
+
+    st.scaling = "always"
+    fwd()
+    fwd()
+    assert st.overflow_count() == 0
+    with torch.no_grad():
+        big["encoder.layers.0.cross_attn.ln_vid.weight"].mul_(4096.0)      # X1 of layer 0 (a GEMM operand) grows 4096x
+    got = fwd()                                # stale scales: 16x head-room is not enough
+    assert st.overflow_count() >= 1
+    n = st.overflow_count()
+    got2 = fwd()                               # rescaled by the end-of-pass update: no new overflow
+    assert st.overflow_count() == n
+    st.scaling = "exact"
+    ref = fwd()
+    tol = 1e-5 * max(1.0, float(ref.abs().max()))
+    assert torch.isfinite(got).all() and float((got - ref).abs().max()) <= tol and float((got2 - ref).abs().max()) <= tol
