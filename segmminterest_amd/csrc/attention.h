@@ -945,9 +945,9 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_bwd_fused_kernel(const AttnAr
         }
         float* hk = isa ? p.hdr_ka : p.hdr_kb;
         float* slot = isa ? p.amax_ka : p.amax_kb;
-        if (s_k > 0.f) { site_commit(hk, am, blockIdx.x * nw + wave, s_k); if (lane == 0) hk[0] = s_k; }
+        if (s_k > 0.f) { site_commit(hk, am, blockIdx.x * nw + wave, s_k); if (scale_writer(blockIdx.x * nw + wave)) hk[0] = s_k; }
         else if (slot) amax_commit(slot, am, blockIdx.x * nw + wave);
-        if (s_q > 0.f) { site_commit(p.hdr_q, am_q, blockIdx.x * nw + wave, s_q); if (lane == 0) p.hdr_q[0] = s_q; }
+        if (s_q > 0.f) { site_commit(p.hdr_q, am_q, blockIdx.x * nw + wave, s_q); if (scale_writer(blockIdx.x * nw + wave)) p.hdr_q[0] = s_q; }
         else if (p.amax_q) amax_commit(p.amax_q, am_q, blockIdx.x * nw + wave);
     }
     ATT_MARK(5);

@@ -185,12 +185,14 @@ __device__ __forceinline__ void plane_store4_pair(_Float16* p, int ld2, long lon
     _Float16* o = p + row * ld2 + ((cb >> 5) << 6) + (cb & 31) + (odd ? 32 : 0);
     *(uint4*)o = odd ? make_uint4(r0, r1, l0, l1) : make_uint4(h0, h1, r0, r1);
 }
-// end of a producer wave: partial maxima (+ flag) and the scale used (every wave stores the same value: no "first thread"
-// that might have left the kernel early).
+// end of a producer wave: partial maxima (+ flag) and the scale used.  The scale is stored by the waves whose key is a
+// multiple of 1024 (key 0 always exists and always gets here; EVERY wave storing to that one word serialised the stores of
+// a 51 200-row kernel at the memory side and more than doubled its run time).
+__device__ __forceinline__ bool scale_writer(unsigned key) { return (threadIdx.x & 63) == 0 && (key & 1023u) == 0u; }
 __device__ __forceinline__ void plane_finish(const PlaneOut& po, float* amax_slots, float am, unsigned key, float s, bool) {
     if (s > 0.f) {
         site_commit(po.hdr, am, key, s);
-        if ((threadIdx.x & 63) == 0) po.hdr[0] = s;
+        if (scale_writer(key)) po.hdr[0] = s;
     } else if (amax_slots) {
         amax_commit(amax_slots, am, key);
     }

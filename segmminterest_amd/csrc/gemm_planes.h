@@ -318,7 +318,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_nt(const GemmArgs p, const PGe
     }
     if (q.c_hdr) {
         site_commit(q.c_hdr, am, blockIdx.x * 8 + wave, c_scale);
-        if (c_scale > 0.f && lane == 0) q.c_hdr[0] = c_scale;
+        if (c_scale > 0.f && scale_writer(blockIdx.x * 8 + wave)) q.c_hdr[0] = c_scale;
     } else if (p.amax_out) amax_commit(p.amax_out, am, blockIdx.x * 8 + wave);
 }
 
