@@ -48,9 +48,11 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t r, void* lds_wa
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, (int)soff, 0, 0);
 }
 __device__ __forceinline__ void dma_wait_barrier() {
+    __builtin_amdgcn_sched_barrier(0);          // MFMAs are register-only: without this the scheduler sinks them below the barrier
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
 }
 // exact scale of a site from its partial maxima (slow path only): every thread of the block gets the same value
 __device__ __forceinline__ float site_exact_scale(const float* hdr, float* red, int tid, int nthreads) {
@@ -261,9 +263,64 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_nt(const GemmArgs p, const PGe
         }
     };
 
+    // VAR 2: software-pipelined across the barrier.  The fragments of the SECOND k16 step of a tile are read before the
+    // end-of-tile barrier and multiplied after it: every wave leaves the barrier with 24 MFMAs ready to issue while the
+    // first fragments of the new tile come out of LDS, and the stage it has just finished reading is free for the DMA of the
+    // tile after next straight away.
+    struct Frags { f32x4 bh[2], bl[2], ah[4], al[4]; };
+    auto load_frags = [&](const char* st, int s, Frags& F) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            F.bh[j] = *(const f32x4*)(st + fb[0][s] + j * 4096);
+            F.bl[j] = *(const f32x4*)(st + fb[1][s] + j * 4096);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            F.ah[i] = *(const f32x4*)(st + fa[0][s] + i * 4096);
+            F.al[i] = *(const f32x4*)(st + fa[1][s] + i * 4096);
+        }
+    };
+    auto mma = [&](const Frags& F) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f32x16 c = acc[i][j];
+                c = mfma_x<true>(F.al[i], F.bh[j], c);
+                c = mfma_x<true>(F.ah[i], F.bl[j], c);
+                c = mfma_x<true>(F.ah[i], F.bh[j], c);
+                acc[i][j] = c;
+            }
+    };
+
     stage(0, smem);
     dma_wait_barrier();
-    if (VAR == 1 && !slowA) {
+    if (VAR == 2 && !slowA) {
+        Frags FA, FB;
+        load_frags(smem, 0, FB);
+        if (nkt > 1) { dmaA(1, smem + PSTAGE); dmaB(1, smem + PSTAGE); }
+        load_frags(smem, 1, FA);
+        mma(FB);
+        dma_wait_barrier();
+        for (int kt = 1; kt < nkt; ++kt) {
+            char* cur = smem + (kt & 1) * PSTAGE;
+            char* nxt = smem + ((kt + 1) & 1) * PSTAGE;
+            load_frags(cur, 0, FB);
+            if (kt + 1 < nkt) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    lds_dma16(rsA, nxt + (wave * 4 + i) * 1024, voa[i], (uint32_t)(kt + 1) * 128u);
+                    lds_dma16(rsB, nxt + PBM * 128 + (wave * 4 + i) * 1024, vob[i], (uint32_t)(kt + 1) * 128u);
+                }
+            }
+            mma(FA);                    // second half of the PREVIOUS tile, operands already in registers
+            load_frags(cur, 1, FA);
+            mma(FB);
+            dma_wait_barrier();
+        }
+        mma(FA);
+        dma_wait_barrier();
+    } else if (VAR == 1 && !slowA) {
         for (int kt = 0; kt < nkt - 1; ++kt) {
             char* cur = smem + (kt & 1) * PSTAGE;
             char* nxt = smem + ((kt + 1) & 1) * PSTAGE;
