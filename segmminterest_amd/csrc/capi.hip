@@ -183,7 +183,7 @@ __global__ void dropout_mult_kernel(float* out, long long n, DropCfg d) {
 extern "C" {
 
 const char* segmm_last_error(void) { return g_segmm_err; }
-int segmm_abi_version(void) { return 11; }
+int segmm_abi_version(void) { return 12; }
 
 static PlaneOut plane_out(uint16_t* planes, int ld2, float* hdr, const float* scale_in) {
     PlaneOut po;
@@ -378,8 +378,9 @@ int segmm_gemm_p(int layout, int M, int N, int K, const uint16_t* a_planes, int 
                  const uint16_t* b_planes, int ldb2, const float* b_hdr, const float* b_f32, int ldbf, float* C, int ldc,
                  uint16_t* c_planes, int ldc2, float* c_hdr, const float* c_scale_in, int write_c, const float* bias, const float* row_scale,
                  const float* residual, int ldr, int res_period, int activation, float* aux, int ldaux, float drop_p,
-                 uint64_t seed, uint32_t site, int splits, float* workspace, int accumulate, segmm_stream_t stream) {
+                 uint64_t seed, uint32_t site, int splits, float* workspace, int accumulate, float* colsum_out, segmm_stream_t stream) {
     SEGMM_REQUIRE(layout == 0 || layout == 2, "gemm_p: layout %d (0 = NT, 2 = TN)", layout);
+    SEGMM_REQUIRE(!colsum_out || layout == 2, "gemm_p: colsum_out is an output of the TN form");
     SEGMM_REQUIRE(a_planes && b_planes && a_hdr && b_hdr, "gemm_p: null plane operand / header");
     SEGMM_REQUIRE(C || (c_planes && !write_c), "gemm_p: no output");
     if (M <= 0 || N <= 0) return 0;
@@ -447,6 +448,7 @@ int segmm_gemm_p(int layout, int M, int N, int K, const uint16_t* a_planes, int 
         splits = (ktiles + tps - 1) / tps;
         g.k_per_split = tps * 32;
         g.C = workspace; g.ldc = N; g.slab_stride = (long long)M * N;
+        q.colsum_ws = workspace + (size_t)splits * M * N;          // the caller sizes the workspace splits * (M * N + M) with colsum_out
     } else {
         g.k_per_split = ktiles * 32;
         g.slab_stride = 0;
@@ -455,8 +457,13 @@ int segmm_gemm_p(int layout, int M, int N, int K, const uint16_t* a_planes, int 
             g.residual = C; g.ldr = ldc; g.res_period = M;
         }
     }
+    q.colsum_out = colsum_out;
     hipLaunchKernelGGL(gemm_pl_tn<0>, dim3(g.nbm * g.nbn, 1, splits), dim3(512), 0, s, g, q);
     LAUNCH_CHECK();
+    if (splits > 1 && colsum_out) {
+        hipLaunchKernelGGL(colsum_reduce_kernel, dim3((M + 255) / 256), dim3(256), 0, s, (const float*)q.colsum_ws, splits, M, colsum_out, accumulate);
+        LAUNCH_CHECK();
+    }
     if (splits > 1) {
         const long long n4 = (long long)M * (N / 4);
         int blocks = (int)((n4 + 255) / 256);

@@ -38,6 +38,7 @@ struct PGemmX {
     _Float16* Cp; int ldc2; float* c_hdr;      // optional plane output; amax / flag / the scale used are folded into c_hdr
     const float* c_scale_in;                   // device scalar: scale to write the output planes with (null / 0: none)
     int write_c;                               // 0: the fp32 C is not stored (planes only)
+    float* colsum_out; float* colsum_ws;       // TN only: optional [M] column sums of A over k (= bias gradient), split-K partials [splits][M]
     int dbg;                                   // timing ablations (SEGMM_PL_FLAGS; results are wrong when set): 1 no C stores, 2 no epilogue
 };
 
@@ -409,6 +410,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_tn(const GemmArgs p, const PGe
     const int kend = min(p.K, kbeg + p.k_per_split);
     const int nkt = (kend - kbeg + 31) >> 5;
 
+    // bias gradient folded in: the workgroups of the first column tile also form sum_k A[k, m] -- one more MFMA pair per
+    // k16 step and wave against an all-ones B fragment (wave (wm, wn) takes A block i = wn of its 128 rows), instead of a
+    // separate column-sum pass over the whole fp32 dY tensor
+    const bool do_colsum = q.colsum_out != nullptr && (lb % p.nbn) == 0;
     const float sa_hdr = q.A.hdr[0], sb_hdr = q.B.hdr[0];
     const bool slowA = q.A.f32 != nullptr && (!(sa_hdr > 0.f) || __float_as_uint(q.A.hdr[1]) != 0u);
     const bool slowB = q.B.f32 != nullptr && (!(sb_hdr > 0.f) || __float_as_uint(q.B.hdr[1]) != 0u);
@@ -423,6 +428,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_tn(const GemmArgs p, const PGe
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x16 accb;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accb[r] = 0.f;
+    const f32x4 ones = __builtin_bit_cast(f32x4, make_uint4(0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u));      // 8 x fp16 1.0
 
     // ---- LDS-DMA: wave w, piece i = token row 4 w + i of the k-tile (1 KB); lane = physical 16-byte chunk of the row
     const __amdgpu_buffer_rsrc_t rsA = make_rsrc(q.A.p, q.A.bytes), rsB = make_rsrc(q.B.p, q.B.bytes);
@@ -492,6 +502,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_tn(const GemmArgs p, const PGe
             for (int i = 0; i < 4; ++i) {
                 const f32x4 ah = lds_tr8(st + fa[2 * (i & 1)] + (i >> 1) * 256 + s * 16384);
                 const f32x4 al = lds_tr8(st + fa[2 * (i & 1) + 1] + (i >> 1) * 256 + s * 16384);
+                if (do_colsum && i == wn) {
+                    accb = mfma_x<true>(al, ones, accb);
+                    accb = mfma_x<true>(ah, ones, accb);
+                }
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     f32x16 c = acc[i][j];
@@ -520,9 +534,18 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_tn(const GemmArgs p, const PGe
         dma_wait_barrier();
     }
 
+    const bool split = gridDim.z > 1;
+    if (do_colsum && (lane & 31) == 0) {          // every column of accb holds the row sums: lanes 0 and 32 own 16 rows each
+        float* dst = split ? q.colsum_ws + (size_t)blockIdx.z * p.M : q.colsum_out;
+        const float inv_a = 1.f / sa;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 128 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (m < p.M) dst[m] = (!split && p.residual) ? dst[m] + accb[r] * inv_a : accb[r] * inv_a;      // residual set = accumulate
+        }
+    }
     float* Cs = (float*)smem + wave * (32 * 64);
     const float inv_ab = (1.f / sa) * (1.f / sb);
-    const bool split = gridDim.z > 1;
     float* Cout = split ? p.C + (size_t)blockIdx.z * (size_t)p.slab_stride : p.C;
     float am = 0.f;
 #pragma unroll 1
@@ -538,6 +561,15 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_tn(const GemmArgs p, const PGe
         if (split) epi_strip_emit<true, 2>(p, q, Cs, lane, m0 + wm * 128 + i * 32, n0 + wn * 64, inv_ab, 0.f, Cout, am);
         else epi_strip_emit<false, 2>(p, q, Cs, lane, m0 + wm * 128 + i * 32, n0 + wn * 64, inv_ab, 0.f, Cout, am);
     }
+}
+
+// out[m] (+)= sum_z ws[z][m]   (split-K combine of the folded column sums)
+__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ ws, int splits, int M, float* out, int accumulate) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += ws[(size_t)z * M + m];
+    out[m] = accumulate ? out[m] + s : s;
 }
 
 // =============================================================================== fp32 -> P32 planes (stand-alone pass)

@@ -604,14 +604,18 @@ def finish_act(store, act):
     return act
 
 
-def _wgrad(store, dY, y_off, X, x_off, Mrows, n_out, n_in, gW, accumulate=False):
-    """gW[n_out, n_in] (+)= dY[:, y_off:y_off+n_out]^T . X[:, x_off:x_off+n_in]  (split-K over tokens); dY, X: Act."""
+def _wgrad(store, dY, y_off, X, x_off, Mrows, n_out, n_in, gW, accumulate=False, gb=None):
+    """gW[n_out, n_in] (+)= dY[:, y_off:y_off+n_out]^T . X[:, x_off:x_off+n_in]  (split-K over tokens); dY, X: Act.
+    ``gb``: the bias gradient [n_out] = column sums of the same dY columns -- formed inside the weight-gradient kernel on the
+    plane engine (one more MFMA pair per k-step in a third of the workgroups), by a column-sum pass otherwise."""
     if store.engine_p and dY.planes is not None and X.planes is not None and n_out % 32 == 0 and n_in % 32 == 0:
         splits = _splits_for_p(n_out, n_in, Mrows)
-        ws = store.buf("splitk_ws_side" if store._on_side else "splitk_ws", (max(splits, 1) * n_out * n_in,)) if splits > 1 else None
+        ws = store.buf("splitk_ws_side" if store._on_side else "splitk_ws", (max(splits, 1) * (n_out * n_in + n_out),)) if splits > 1 else None
         H.gemm_p(H.LAYOUT_TN, n_out, n_in, Mrows, dY.pt(y_off, n_out), X.pt(x_off, n_in), gW, n_in, splits=splits, workspace=ws,
-                 accumulate=accumulate)
+                 accumulate=accumulate, colsum_out=gb)
         return
+    if gb is not None:
+        _colsum(store, dY.t, dY.cols, Mrows, n_out, gb, x_off=y_off, accumulate=accumulate)
     splits = _splits_for(n_out, n_in, Mrows)
     ws = store.buf("splitk_ws_side" if store._on_side else "splitk_ws", (max(splits, 1) * n_out * n_in,)) if splits > 1 else None
     H.gemm(H.LAYOUT_TN, n_out, n_in, Mrows, dY.t, dY.cols, X.t, X.cols, gW, n_in, splits=splits, workspace=ws,
@@ -883,8 +887,7 @@ class BackboneRun:
         g = self._as_act(self.amb, dZ, M, d)
         for k in reversed(range(len(lins))):
             n = lins[k]
-            _wgrad(st, g, 0, hs[k], 0, M, d, d, st.g(P + n + ".weight", gbuf), accumulate=accumulate)
-            _colsum(st, g.t, d, M, d, st.g(P + n + ".bias", gbuf), accumulate=accumulate)
+            _wgrad(st, g, 0, hs[k], 0, M, d, d, st.g(P + n + ".weight", gbuf), accumulate=accumulate, gb=st.g(P + n + ".bias", gbuf))
             gin = new_act(st, self.amb, M, d, key="mlp_g%d%s" % (k & 1, tag), planes=k > 0, site="%smlp%d.%d.dH" % (P, tok, k),
                           delayed=self.delayed)
             if k > 0:       # through Dropout and ReLU of hidden layer k-1: aux = its saved output (> 0 iff live and kept)
@@ -1029,8 +1032,7 @@ class BackboneRun:
         finish_act(st, dG)
 
         def _w0():
-            _wgrad(st, dG, 0, sv["X1"], 0, M, d, d, st.g(ff + "0.weight", gbuf))
-            _colsum(st, dG.t, d, M, d, st.g(ff + "0.bias", gbuf))
+            _wgrad(st, dG, 0, sv["X1"], 0, M, d, d, st.g(ff + "0.weight", gbuf), gb=st.g(ff + "0.bias", gbuf))
         side_or_defer(st, _w0, deferred)
         dX1 = st.buf("dX1" + tag, (M, d))
         _lin_dgrad(st, M, d, d, dG, ff + "0.weight", dX1, residual=dR2, ldr=d, res_period=M)
@@ -1103,11 +1105,11 @@ class BackboneRun:
             finish_act(st, dYu)
         # fused projection weights / inputs
         with side_work(st):
-            _wgrad(st, dYv, 0, rec["Xv"], 0, Mv, nv * d, d, _group_view(st, ca + vidP[0] + ".weight", nv * d * d, gbuf))
-            _colsum(st, dYv.t, nv * d, Mv, nv * d, _group_view(st, ca + vidP[0] + ".bias", nv * d, gbuf))
+            _wgrad(st, dYv, 0, rec["Xv"], 0, Mv, nv * d, d, _group_view(st, ca + vidP[0] + ".weight", nv * d * d, gbuf),
+                   gb=_group_view(st, ca + vidP[0] + ".bias", nv * d, gbuf))
             if nu:
-                _wgrad(st, dYu, 0, rec["Xu"], 0, Mu, nu * d, d, _group_view(st, ca + usrP[0] + ".weight", nu * d * d, gbuf))
-                _colsum(st, dYu.t, nu * d, Mu, nu * d, _group_view(st, ca + usrP[0] + ".bias", nu * d, gbuf))
+                _wgrad(st, dYu, 0, rec["Xu"], 0, Mu, nu * d, d, _group_view(st, ca + usrP[0] + ".weight", nu * d * d, gbuf),
+                       gb=_group_view(st, ca + usrP[0] + ".bias", nu * d, gbuf))
         dXv_in = st.buf("dXv_in%d" % (i & 1), (Mv, d))
         _lin_dgrad(st, Mv, d, nv * d, dYv, ca + vidP[0] + ".weight", dXv_in, residual=dR1v, ldr=d, res_period=Mv)
         dXu_in = None

@@ -92,6 +92,24 @@ def test_gemm_p_tn_splitk(M, N, K, splits):
     assert float((C - 2 * C0).abs().max() / C0.abs().max()) < 1e-6
 
 
+@pytest.mark.parametrize("M,N,K,splits", [(768, 768, 2048, 7), (96, 64, 300, 1), (512, 256, 1000, 3), (3072, 768, 4096, 4)])
+def test_gemm_p_tn_folded_column_sums(M, N, K, splits):
+    """colsum_out = sum_k A[k, :]: the bias gradient formed inside the weight-gradient kernel."""
+    H = _abi()
+    dY, X = _rand(K, M, seed=40), _rand(K, N, seed=41)
+    C, cs = torch.empty(M, N, device=DEV), torch.full((M,), 7.0, device=DEV)
+    ws = torch.empty(splits * (M * N + M), device=DEV)
+    pdy, px = H.to_planes(dY, K, M), H.to_planes(X, K, N)
+    H.gemm_p(H.LAYOUT_TN, M, N, K, pdy, px, C, N, splits=splits, workspace=ws, colsum_out=cs)
+    ref = dY.double().sum(0)
+    tol = 3e-6 * float(dY.double().abs().sum(0).max())
+    assert float((cs.double() - ref).abs().max()) <= tol
+    refC = dY.double().t() @ X.double()
+    assert float((C.double() - refC).abs().max() / refC.abs().max()) < 3e-6
+    H.gemm_p(H.LAYOUT_TN, M, N, K, pdy, px, C, N, splits=splits, workspace=ws, colsum_out=cs, accumulate=True)
+    assert float((cs.double() - 2 * ref).abs().max()) <= 2 * tol
+
+
 def test_gemm_p_column_slices_of_fused_buffers():
     """Operands as column slices (multiples of 32) of wider plane buffers: the fused dY / projection layouts."""
     H = _abi()
