@@ -109,6 +109,13 @@ int segmm_gemm_p(int layout, int M, int N, int K, const uint16_t* a_planes, int 
  * this runs), written to hdr[0], flag cleared.  mode 1: scale = hdr[0] as given; maxima and flag folded into hdr. */
 int segmm_split_p32(const float* x, int64_t rows, int cols, int ld, uint16_t* planes, int ld2, float* hdr, int mode,
                     segmm_stream_t stream);
+/* All GEMM weight matrices of a model in two launches per optimizer step (absmax; exact split + transposed split).
+ * desc: device array of n_mats records {int64 flat offset (floats); int32 R, C, needs_transpose, first_tile, tile_cols}
+ * (32 x 32 tiles, n_tiles in total, matrices in ascending first_tile order); hdr: [n_mats][SEGMM_SITE_HDR +
+ * SEGMM_AMAX_SLOTS] zeroed site headers (receive maxima and scale); W planes at wpl + 2 * offset (ld2 = 2 C), W^T planes
+ * at wTpl + 2 * offset (ld2 = 2 R).  C % 32 == 0 (and R % 32 == 0 for transposed matrices). */
+int segmm_wsplit_p32(const float* flat, const void* desc, int n_mats, int n_tiles, float* hdr, uint16_t* wpl, uint16_t* wTpl,
+                     segmm_stream_t stream);
 /* P32 planes of the transpose of x[R, C]: plane row c holds x[:, c] (R % 32 == 0), scale hdr[0]. */
 int segmm_split_p32_transpose(const float* x, int R, int C, int ld, uint16_t* planes, int ld2, const float* hdr,
                               segmm_stream_t stream);

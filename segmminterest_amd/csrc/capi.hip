@@ -487,6 +487,17 @@ int segmm_split_p32(const float* x, int64_t rows, int cols, int ld, uint16_t* pl
     return 0;
 }
 
+int segmm_wsplit_p32(const float* flat, const void* desc, int n_mats, int n_tiles, float* hdr, uint16_t* wpl, uint16_t* wTpl,
+                     segmm_stream_t stream) {
+    SEGMM_REQUIRE(flat && desc && hdr && wpl && n_mats > 0 && n_tiles > 0 && aligned16(flat) && aligned16(wpl), "wsplit_p32: arguments");
+    hipLaunchKernelGGL(wabsmax_kernel, dim3(64, n_mats), dim3(256), 0, (hipStream_t)stream, flat, (const WMat*)desc, hdr);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(wsplit_kernel, dim3(n_tiles), dim3(256), 0, (hipStream_t)stream, flat, (const WMat*)desc, n_mats, hdr,
+                       (_Float16*)wpl, (_Float16*)wTpl);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 int segmm_split_p32_transpose(const float* x, int R, int Cc, int ld, uint16_t* planes, int ld2, const float* hdr, segmm_stream_t stream) {
     SEGMM_REQUIRE(x && planes && hdr && R > 0 && Cc > 0 && R % 32 == 0 && ld >= Cc && ld2 % 64 == 0 && ld2 >= 2 * R && aligned16(planes),
                   "split_p32_transpose: R %% 32, ld2 %% 64, alignment");

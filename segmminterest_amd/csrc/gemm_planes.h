@@ -623,4 +623,60 @@ __global__ __launch_bounds__(256) void split_p32_transpose_kernel(const float* _
     }
 }
 
+// ---------------------------------------------------------------- all weight matrices of a model in TWO launches per step
+// desc[i] = {flat offset of matrix i (floats), rows R, cols C, needs transpose, first 32 x 32 tile index, tile columns}
+// (tiles cover [ceil(R/32)][C/32]); hdr = [n][SITE_FLOATS] site headers (zeroed by the caller).
+struct WMat { long long off; int R, Cc, tr, tile0, tcols; };
+__global__ __launch_bounds__(256) void wabsmax_kernel(const float* __restrict__ flat, const WMat* __restrict__ desc, float* hdr) {
+    const WMat m = desc[blockIdx.y];
+    const float* x = flat + m.off;
+    const long long n4 = (long long)m.R * m.Cc / 4;
+    float am = 0.f;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x)
+        am = absmax4(am, *(const f32x4*)(x + 4 * i));
+    amax_commit(hdr + (size_t)blockIdx.y * SITE_FLOATS + SITE_HDR, am, blockIdx.x * 4 + (threadIdx.x >> 6));
+}
+// one 32 x 32 tile per workgroup: P32 planes of W (wpl, at element offset 2 * off, ld2 = 2 C) and -- if asked -- of W^T
+// (wTpl, same offset, ld2 = 2 R), both with the exact scale of the matrix' own maxima, which is also stored in its header
+__global__ __launch_bounds__(256) void wsplit_kernel(const float* __restrict__ flat, const WMat* __restrict__ desc, int n_mats, float* hdr,
+                                                     _Float16* __restrict__ wpl, _Float16* __restrict__ wTpl) {
+    __shared__ float tile[32][33];
+    __shared__ float red[8];
+    int mi = 0;
+    while (mi + 1 < n_mats && (int)blockIdx.x >= desc[mi + 1].tile0) ++mi;
+    const WMat m = desc[mi];
+    float* h = hdr + (size_t)mi * SITE_FLOATS;
+    const float s = site_exact_scale(h, red, threadIdx.x, 256);
+    const int t = blockIdx.x - m.tile0;
+    const int r0 = (t / m.tcols) * 32, c0 = (t % m.tcols) * 32;
+    if (t == 0 && threadIdx.x == 0) { h[0] = s; h[1] = 0.f; }
+    const float* x = flat + m.off;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + ty + 8 * k, c = c0 + tx;
+        const float v = (r < m.R && c < m.Cc) ? x[(size_t)r * m.Cc + c] : 0.f;
+        tile[ty + 8 * k][tx] = v;
+        if (r < m.R && c < m.Cc) {
+            const _Float16 hi = (_Float16)(v * s);
+            const _Float16 lo = (_Float16)__builtin_fmaf(v, s, -(float)hi);
+            _Float16* o = wpl + 2 * m.off + (size_t)r * (2 * m.Cc) + ((c >> 5) << 6) + (c & 31);
+            o[0] = hi; o[32] = lo;
+        }
+    }
+    if (!m.tr) return;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + ty + 8 * k, r = r0 + tx;          // plane row c of the transpose, column r
+        if (c < m.Cc && r < m.R) {
+            const float v = tile[tx][ty + 8 * k];
+            const _Float16 hi = (_Float16)(v * s);
+            const _Float16 lo = (_Float16)__builtin_fmaf(v, s, -(float)hi);
+            _Float16* o = wTpl + 2 * m.off + (size_t)c * (2 * m.R) + ((r >> 5) << 6) + (r & 31);
+            o[0] = hi; o[32] = lo;
+        }
+    }
+}
+
 }  // namespace segmm

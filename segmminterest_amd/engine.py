@@ -151,7 +151,10 @@ class ParamStore:
         self.attn_split = os.environ.get("SEGMM_ATTN_SPLIT", "0") != "0"
         self.attn_fused = os.environ.get("SEGMM_ATTN_FUSED", "1") != "0"      # fused dQ+dK+dV kernel (<= 12 key tiles per block)
         self._attn_stream = None
-        self.fwd_side = os.environ.get("SEGMM_FWD_SIDE", "0") != "0"      # forward: user-token chain on the side stream (measured: -0.3 %, off)
+        # forward: user-token chain (input Linear -> LayerNorm -> fused user projection) on the side stream next to the
+        # video-token chain.  On-the-fly engines: -0.3 % (off); plane engine (one workgroup per CU: the tail of one kernel and the
+        # HBM-bound LayerNorms fill under the other chain's GEMMs): +1.2 %, same-box alternating runs (on)
+        self.fwd_side = os.environ.get("SEGMM_FWD_SIDE", "1" if H.GEMM_ENGINE == H.ENGINE_F16X3P else "0") != "0"
         self.ln_side = os.environ.get("SEGMM_LN_SIDE", "0") != "0"      # measured: -2 % (kept as a knob)     # measured: no gain (kept as a knob)
         # pre-split bf16 planes of the weights for the bf16x6 GEMM engine: W planes (forward) and W^T planes (dgrad
         # in the NT form), refreshed when the parameters change (one split pass per optimizer step)
@@ -308,14 +311,19 @@ class ParamStore:
                 self.wpt[name] = H.PT(self.wpl, self.whdr[i], R, Cc, ld2=2 * Cc, p_off=2 * off)
                 if tr:
                     self.wTpt[name] = H.PT(self.wTpl, self.whdr[i], Cc, R, ld2=2 * R, p_off=2 * off)
+            # descriptor table of segmm_wsplit_p32: {int64 offset; int32 R, C, transpose, first tile, tile columns}
+            import struct
+            recs, tile0 = b"", 0
+            for (name, off, R, Cc, tr) in mats:
+                tcols = Cc // 32
+                recs += struct.pack("<qiiiii", off, R, Cc, int(tr), tile0, tcols) + b"\0" * 4          # 32-byte records
+                tile0 += ((R + 31) // 32) * tcols
+            self._wdesc = torch.frombuffer(bytearray(recs), dtype=torch.uint8).to(dev) if mats else None
+            self._wtiles = tile0
         else:
             self.whdr.zero_()
-        for i, (name, off, R, Cc, tr) in enumerate(mats):
-            hdr = self.whdr[i]
-            H.absmax(self.flat, R, Cc, Cc, off=off, out=hdr[H.SITE_HDR:])
-            H.split_p32(self.flat, R, Cc, Cc, self.wpl, 2 * Cc, hdr, mode=0, x_off=off, p_off=2 * off)
-            if tr:
-                H.split_p32_transpose(self.flat, R, Cc, Cc, self.wTpl, 2 * R, hdr, x_off=off, p_off=2 * off)
+        if mats:
+            H.wsplit_p32(self.flat, self._wdesc, len(mats), self._wtiles, self.whdr, self.wpl, self.wTpl)
 
     def _build(self, params):
         first = next(iter(params.values()))
@@ -799,7 +807,7 @@ class BackboneRun:
         meu, reu = _empty(ref, Mu), _empty(ref, Mu)
         Eu = new_act(st, am, Mu, d, planes=usr_is_operand, site=P + "Eu", delayed=self.delayed)
         Yu0 = None
-        fwd_side = st.overlap and st.fwd_side and not bb.id_usr and layered and self.mode != "self" and not st.engine_p
+        fwd_side = st.overlap and st.fwd_side and not bb.id_usr and layered and self.mode != "self"
         if bb.id_usr:
             uids = usr_feat.contiguous().to(torch.int64)
             sv["usr_ids"] = uids

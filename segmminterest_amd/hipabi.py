@@ -34,6 +34,7 @@ SIGNATURES = {
     "segmm_scales_update": [_p, _p, _i, _p, _p, _i, _p],
     "segmm_split_p32": [_p, _i64, _i, _i, _p, _i, _p, _i, _p],
     "segmm_split_p32_transpose": [_p, _i, _i, _i, _p, _i, _p, _p],
+    "segmm_wsplit_p32": [_p, _p, _i, _i, _p, _p, _p, _p],
     "segmm_absmax": [_p, _i64, _i, _i, _p, _i, _p],
     "segmm_split2h": [_p, _p, _i64, _i64, _p, _i, _p],
     "segmm_split2h_transpose": [_p, _i, _i, _i, _p, _i64, _p, _i, _p],
@@ -294,6 +295,12 @@ def split_p32(x, rows, cols, ld, planes, ld2, hdr, mode=0, x_off=0, p_off=0):
 def split_p32_transpose(x, R, Cc, ld, planes, ld2, hdr, x_off=0, p_off=0):
     _check(lib().segmm_split_p32_transpose(x.data_ptr() + 4 * x_off, R, Cc, ld, planes.data_ptr() + 2 * p_off, ld2, hdr.data_ptr(),
                                            _stream()), "segmm_split_p32_transpose")
+
+
+def wsplit_p32(flat, desc, n_mats, n_tiles, hdr, wpl, wTpl):
+    """Absmax + exact P32 split (+ transposed split) of every weight matrix described in ``desc`` (see segmm_wsplit_p32)."""
+    _check(lib().segmm_wsplit_p32(flat.data_ptr(), desc.data_ptr(), int(n_mats), int(n_tiles), hdr.data_ptr(), wpl.data_ptr(),
+                                  wTpl.data_ptr(), _stream()), "segmm_wsplit_p32")
 
 
 def to_planes(x, rows, cols, ld=None, x_off=0, keep_f32=True):
