@@ -2,8 +2,9 @@
 
 ``inference/save_logits_for_all_leave_SegMM.py:105-150`` runs the interest model over every split and writes
 ``{"<user_id>-<photo_id>-<time_ms>": [S logits]}`` as JSON (and a torch pickle); SegRec reads that file as
-``clip_weight`` and feeds ``feed_dict['c_interest_weight']`` ([batch, item_num, 40], missing keys -> ones,
-SegRec/models/BaseModel.py:262-408), which ``ClipRec.forward`` multiplies into the per-segment predictions
+``clip_weight`` and feeds ``feed_dict['c_interest_weight']`` ([batch, item_num, 40]: the TARGET item's slice for every item of
+the row, ones when the target's key is missing, own slices for the negatives when a negatives file is given --
+SegRec/models/BaseModel.py:228-288), which ``ClipRec.forward`` multiplies into the per-segment predictions
 (``sum_seg pred * weight * (seg < duration)``, ClipRec.py:163-181).
 
 ``LogitStore`` keeps the same mapping as three int64 key columns + one float32 [n, S] matrix, writes the reference's
@@ -82,28 +83,55 @@ class LogitStore:
             last[:-1] = (ks[1:] != ks[:-1]).any(1)
         self._index = (ks[last], order[last])
 
-    def weights(self, user_id, item_ids, time_ms, device=None):
-        """``c_interest_weight`` for one batch: user_id [B], item_ids [B, I], time_ms [B] -> float32 [B, I, S]; keys not in
-        the store get ones (BaseModel.py:259-260,283-288)."""
+    def _lookup(self, q):
+        """rows of the value matrix for the [n, 3] keys ``q`` (-1 where absent)"""
         if self._index is None:
             self._build_index()
         ks, rows = self._index
-        _, v = self._cat()
-        u = np.asarray(user_id, np.int64).reshape(-1, 1)
-        it = np.asarray(item_ids, np.int64)
-        t = np.asarray(time_ms, np.int64).reshape(-1, 1)
-        q = np.stack([np.broadcast_to(u, it.shape), it, np.broadcast_to(t, it.shape)], -1).reshape(-1, 3)
-        out = np.ones((q.shape[0], self.S), np.float32)
+        out = np.full((q.shape[0],), -1, dtype=np.int64)
         if len(ks):
-            # lexicographic search on (user, item, time) via a structured view
-            dt = np.dtype([("a", np.int64), ("b", np.int64), ("c", np.int64)])
+            dt = np.dtype([("a", np.int64), ("b", np.int64), ("c", np.int64)])          # lexicographic (user, item, time)
             kv = np.ascontiguousarray(ks).view(dt).reshape(-1)
             qv = np.ascontiguousarray(q).view(dt).reshape(-1)
             pos = np.searchsorted(kv, qv)
             pos_c = np.minimum(pos, len(kv) - 1)
             hit = (pos < len(kv)) & (kv[pos_c] == qv)
-            out[hit] = v[rows[pos_c[hit]]]
-        w = torch.from_numpy(out.reshape(it.shape + (self.S,)))
+            out[hit] = rows[pos_c[hit]]
+        return out
+
+    def weights(self, user_id, item_ids, time_ms, neg: "Optional[LogitStore]" = None, id2user=None, id2item=None, device=None):
+        """``feed_dict['c_interest_weight']`` of a batch exactly as ``GeneralModel.Dataset._get_feed_dict`` builds it
+        (SegRec/models/BaseModel.py:228-288): user_id [B], item_ids [B, I] (column 0 = the target item), time_ms [B] ->
+        float32 [B, I, S].  Per row, with key = "<user>-<item 0>-<time>":
+          * key absent                      -> ones (the reference appends ONE row of ones, which broadcasts over the items);
+          * key present, no negatives file  -> EVERY item of the row gets the TARGET's slice;
+          * key present, negatives file ``neg`` and I > 2 -> item 0 the target's slice, item j its own slice from ``neg``
+            (KeyError if absent, like the reference).
+        ``id2user`` / ``id2item`` (dicts keyed by str): the id mapping the non-KuaiRand branch applies first (:268,275)."""
+        u = np.asarray(user_id, np.int64).reshape(-1)
+        it = np.asarray(item_ids, np.int64)
+        t = np.asarray(time_ms, np.int64).reshape(-1)
+        if id2user is not None:
+            u = np.asarray([int(id2user[str(int(x))]) for x in u], np.int64)
+        if id2item is not None:
+            it = np.asarray([[int(id2item[str(int(x))]) for x in r] for r in it], np.int64)
+        B, I = it.shape
+        _, v = self._cat()
+        first = self._lookup(np.stack([u, it[:, 0], t], 1))
+        out = np.ones((B, I, self.S), np.float32)
+        hit = first >= 0
+        if hit.any():
+            out[hit] = v[first[hit]][:, None, :]
+            if neg is not None and I > 2:
+                _, nv = neg._cat()
+                q = np.stack([np.broadcast_to(u[:, None], (B, I - 1)), it[:, 1:], np.broadcast_to(t[:, None], (B, I - 1))], -1)
+                rows = neg._lookup(q.reshape(-1, 3)).reshape(B, I - 1)
+                bad = hit[:, None] & (rows < 0)
+                if bad.any():
+                    b_, j_ = np.argwhere(bad)[0]
+                    raise KeyError("Inference, Key %d-%d-%d not found in clip_weight" % (u[b_], it[b_, j_ + 1], t[b_]))
+                out[hit, 1:] = nv[rows[hit]]
+        w = torch.from_numpy(out)
         return w.to(device) if device is not None else w
 
 

@@ -8,7 +8,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
-NOT_MODEL_CASES = ("metrics_kat.npz", "cfg1_labels.npz")      # metric known answers; config-1 labels of the reference's sample file
+# metric known answers; config-1 labels of the reference's sample file; data-format fixtures (oracle/gen_golden_io.py)
+NOT_MODEL_CASES = ("metrics_kat.npz", "cfg1_labels.npz", "io_dataloader.npz", "io_cliprec.npz")
 MODEL_CASES = sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and f not in NOT_MODEL_CASES)
 
 

@@ -52,7 +52,8 @@ def test_binary_roundtrip_and_lookup(tmp_path):
     assert st2.as_dict() == ref
     st3 = LogitStore.load(_write_json(tmp_path, ref))
     assert st3.as_dict() == ref
-    # reader rule: key present -> its slice, absent -> [1]*40
+    # reader rule (BaseModel.py:228-288, pinned by tests/test_feature_store_cpu.py::test_reader_rule_matches_segrec):
+    # target key present -> EVERY item of the row gets the target's slice; absent -> ones
     uid = np.array([int(k.split("-")[0]) for k in list(ref)[:5]] + [9999])
     tms = np.array([int(k.split("-")[2]) for k in list(ref)[:5]] + [1])
     items = np.array([[int(k.split("-")[1]), 12345] for k in list(ref)[:5]] + [[1, 2]])
@@ -60,8 +61,7 @@ def test_binary_roundtrip_and_lookup(tmp_path):
     assert w.shape == (6, 2, 40)
     for i, k in enumerate(list(ref)[:5]):
         assert torch.equal(w[i, 0], torch.tensor(ref[k], dtype=torch.float32))
-        other = "%d-%d-%d" % (uid[i], 12345, tms[i])
-        assert torch.equal(w[i, 1], torch.tensor(ref[other], dtype=torch.float32) if other in ref else torch.ones(40))
+        assert torch.equal(w[i, 1], w[i, 0])
     assert torch.equal(w[5], torch.ones(2, 40))
 
 

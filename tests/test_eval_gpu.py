@@ -204,3 +204,42 @@ def test_valid_model_matches_host_metrics():
         acc.setdefault("valid_loss", []).append(float(out["loss"]))
     for k, v in acc.items():
         assert got[k] == sum(v) / len(v), k
+
+
+# ------------------------------------------------------------------ (f)-1 / (f)-3 against fixtures made by the reference's own code
+def test_index_batch_gather_matches_reference_dataset_rows():
+    """oracle/gen_golden_io.py ran FrameDatasetSeq_SegMM._getitem (dataloader_SegMM.py:271-362) on a synthetic corpus; the
+    index rows built by IndexBatchBuilder, gathered + L1-normalised on the device, equal the reference's feature rows after
+    the trainer's normalisation (main...SegMM.py:272-273), masks included."""
+    import json
+    import random
+    import numpy as np
+    from segmminterest_amd.feature_store import IndexBatchBuilder, KeyIndex, ResidentFeatureTable
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "io_dataloader.npz"))
+    rows = json.loads(str(z["rows"]))
+    b = IndexBatchBuilder(KeyIndex([str(k) for k in z["keys"]]), json.loads(str(z["user_input_dict"])),
+                          json.loads(str(z["user2id"])), json.loads(str(z["item2id"])))
+    random.seed(int(z["seed"]))
+    np.random.seed(int(z["seed"]))
+    batch = b.batch([b.row(r["user_id"], r["video_id"], r["time_ms"], r["duration_ms"], r["playing_time_x"], r["label_1D"],
+                           r["history_items"], r["history_playing"], r["history_lengths"]) for r in rows], device=DEV)
+    ft = ResidentFeatureTable(torch.from_numpy(z["table"]).to(DEV))
+    for key in ("photo", "user"):
+        got, mask = ft.gather(key, batch[key + "_idx"])
+        ref = torch.from_numpy(z["exp_" + key]).to(DEV)
+        ref = ref / (ref.abs().sum(-1, keepdim=True) + 1e-6)
+        assert torch.equal(mask.cpu(), torch.from_numpy(z["exp_" + key + "_mask"]))
+        assert float((got - ref).abs().max()) <= 1e-7
+
+
+def test_weighted_head_matches_cliprec_forward():
+    """ClipRecBase.forward (SegRec/models/context/ClipRec.py:134-198) run by oracle/gen_golden_io.py: the device kernel
+    reproduces its weighted, duration-masked prediction from the per-clip predictions."""
+    import numpy as np
+    from segmminterest_amd.bridge import weighted_head
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "io_cliprec.npz"))
+    cp, w = torch.from_numpy(z["clip_pred"]).to(DEV), torch.from_numpy(z["weight"]).to(DEV)
+    dur = torch.from_numpy(z["duration"]).to(DEV)
+    for got, ref in ((weighted_head(cp, w, dur), z["pred_weighted_masked"]), (weighted_head(cp, None, dur), z["pred_ones_masked"]),
+                     (weighted_head(cp, w, None), z["pred_weighted_nomask"])):
+        assert float((got.cpu() - torch.from_numpy(ref)).abs().max()) <= 2e-5
