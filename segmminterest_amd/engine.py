@@ -103,17 +103,20 @@ def backbone_layout(prefix: str, bb) -> Tuple[List[Tuple[str, List[List[str]]]],
             for s in singles:
                 groups += [[s + ".weight"], [s + ".bias"]]
             buckets.append(("%slayer%d" % (prefix, i), groups))
+    # the user side of the embedding completes first in the backward (its weight gradient queues on the side stream while the
+    # video side is still being differentiated): its own bucket, so its all-reduce starts before the last weight gradient
+    if usr_live:
+        emb_u = [[prefix + "usr_proj.weight"]]
+        if not bb.id_usr:
+            emb_u += [[prefix + "usr_proj.bias"]]
+        emb_u += [[prefix + "usr_pe.weight"], [prefix + "usr_ln.weight"], [prefix + "usr_ln.bias"]]
+        buckets.append((prefix + "embed_u", emb_u))
     emb = [[prefix + "vid_proj.weight"]]
     if bb.id_vid:
         emb += [[prefix + "frameid_proj.weight"], [prefix + "frameid_proj.bias"]]
     else:
         emb += [[prefix + "vid_proj.bias"]]
     emb += [[prefix + "vid_pe.weight"], [prefix + "vid_ln.weight"], [prefix + "vid_ln.bias"]]
-    if usr_live:
-        emb += [[prefix + "usr_proj.weight"]]
-        if not bb.id_usr:
-            emb += [[prefix + "usr_proj.bias"]]
-        emb += [[prefix + "usr_pe.weight"], [prefix + "usr_ln.weight"], [prefix + "usr_ln.bias"]]
     buckets.append((prefix + "embed", emb))
     return buckets
 
@@ -383,7 +386,8 @@ class ParamStore:
                     self._transposes.append((self.index[n0][0], sum(params[n].shape[0] for n in grp), params[n0].shape[1]))
         # flat ranges read by GEMMs as the weight operand: the encoder-layer buckets and the input
         # projections when they are Linears (image mode); Embedding tables, positional tables and the head are not
-        ranges = [(s0, e0 - s0) for bname, s0, e0 in buckets if not bname.endswith("embed") and bname != "head" and e0 > s0]
+        ranges = [(s0, e0 - s0) for bname, s0, e0 in buckets
+                  if not (bname.endswith("embed") or bname.endswith("embed_u")) and bname != "head" and e0 > s0]
         for name in live_names:
             if name.endswith("vid_proj.weight") or name.endswith("usr_proj.weight"):
                 mod = dict(self.root.named_modules()).get(name.rsplit(".", 1)[0])
@@ -1162,6 +1166,11 @@ class BackboneRun:
                     drop_y=(self.p_drop, _site(self.bi, 0, K_EMB_U)), seed=self.seed, amax=dpre_u.slots, po=dpre_u.po)
             finish_act(st, produced(dpre_u))
             self._embed_bwd("usr", dpre_u, B, Lt, gbuf)
+            if on_bucket is not None:
+                # the user-side embedding gradients: LayerNorm / positional parts were written on the main stream, the weight
+                # gradient is still in flight on the side stream -- the hook orders the all-reduce behind BOTH without making the
+                # main stream (which goes on with the video side) wait for the side stream
+                on_bucket(P + "embed_u", after_side=True)
         dpre_v = new_act(st, self.amb, Mv, d, key="dpre_v", planes=not bb.id_vid, site=P + "dpre_v", delayed=self.delayed)
         _ln_bwd(st, dXv, sv["pre_v"], sv["mev"], sv["rev"], P + "vid_ln.weight", P + "vid_ln.bias", gbuf, dpre_v.t, None, Mv, d,
                 drop_y=(self.p_drop, _site(self.bi, 0, K_EMB_V)), seed=self.seed, amax=dpre_v.slots, po=dpre_v.po)

@@ -97,11 +97,24 @@ class FusedAdamW:
             p.grad = None
 
     def step(self, gbuf=None):
-        st = self._state()
+        self.begin_step()
+        self.step_range(0, self._state().n_live, gbuf)
+        self.end_step()
+
+    # one optimizer step as several launches over disjoint ranges that together cover the live range: the data-parallel
+    # trainer steps each gradient bucket as soon as ITS all-reduce has completed (begin_step, step_range ..., end_step)
+    def begin_step(self):
+        self._state()
         self.step_count += 1
-        g = st.gflat if gbuf is None else gbuf
-        H.adamw(st.flat, g, self.m, self.v, st.n_live, self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.step_count)
-        st.fused_version += 1          # the pre-split weight planes of the bf16x6 GEMM engine are now stale
+
+    def step_range(self, start, end, gbuf=None):
+        st = self._state()
+        if end > start:
+            H.adamw(st.flat, st.gflat if gbuf is None else gbuf, self.m, self.v, end - start, self.lr, self.betas[0], self.betas[1],
+                    self.eps, self.wd, self.step_count, p_off=start)
+
+    def end_step(self):
+        self.model._store.fused_version += 1          # the pre-split weight planes of the GEMM engines are now stale
 
     def state_dict(self):
         """torch.optim.AdamW-format state (keyed by the index of the parameter in model.parameters()),
@@ -230,10 +243,15 @@ class DPComm:
         if w is not None:
             self.pending.append(w)
 
+    def take_pending(self):
+        """The outstanding asynchronous all-reduces (issue order); the caller waits for them (``work.wait()`` is a
+        stream-level wait on the communication stream, no host sync)."""
+        p, self.pending = self.pending, []
+        return p
+
     def finish(self):
-        for w in self.pending:
+        for w in self.take_pending():
             w.wait()
-        self.pending = []
 
     def sum_scalar(self, t):
         if self.world > 1:
@@ -272,18 +290,34 @@ class Trainer:
         # ranges are cut out of the dense all-reduce; ``sparse_tables=False`` keeps the dense all-reduce (A/B, tests)
         self.sparse_tables = bool(sparse_tables) and self.comm.world > 1 and os.environ.get("SEGMM_SPARSE_TABLES", "1") != "0"
         st.row_exchange = self.comm.gather_rows if self.sparse_tables else None
+        self.per_bucket_adamw = os.environ.get("SEGMM_BUCKET_ADAMW", "1") != "0"
+        self._bucket_works = []
         self._norm = {}
         self._norm_amax = None
         self._norm_planes = {}
         self._norm_fresh = False
 
-    def _on_bucket(self, name):
+    def _on_bucket(self, name, after_side=False):
+        """Called from inside the backward the moment the gradients of bucket ``name`` are written (``after_side``: part of
+        them by launches still in flight on the engine's side stream): issues the bucket's asynchronous all-reduce and
+        remembers its works, so that AdamW can step the bucket as soon as THEY are done (train_step)."""
         st = self.model._store
         if not self.overlap:
             return
         for b, s, e in st.buckets:
             if b == name:
-                self._reduce_dense(s, e)
+                if after_side and st.overlap and st._side_stream is not None:
+                    # order the collective behind main AND side stream without stalling the main stream: issue it from the side
+                    # stream's context after making the side stream wait for the main stream's work so far
+                    main, side = torch.cuda.current_stream(), st.side_stream()
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                    side.wait_event(ev)
+                    with torch.cuda.stream(side):
+                        self._reduce_dense(s, e)
+                else:
+                    self._reduce_dense(s, e)
+                self._bucket_works.append((s, e, self.comm.take_pending()))
                 return
 
     def _reduce_dense(self, s, e):
@@ -393,13 +427,42 @@ class Trainer:
                 usr_id = torch.randint(1, max(n_users, 2), usr_id.shape, device=usr_id.device)
         out = model(usr_image=usr, usr_id=usr_id, usr_mask=um, vid_image=vid,
                     vid_id=batch["photo_identity_id"], vid_mask=vm, gt=batch["label"], mode="train")
+        self._bucket_works = []
         out["loss"].backward()
+        if self.comm.world > 1 and self.overlap and self.per_bucket_adamw and self._covers_live(st):
+            # AdamW per bucket, in completion order: each launch waits (stream-level) only for its own bucket's all-reduce, so
+            # the optimizer of the early buckets runs under the collectives of the late ones and only the last, small bucket
+            # (the video-side embedding) is exposed
+            self.opt.begin_step()
+            for s, e, works in self._bucket_works:
+                for w in works:
+                    w.wait()
+                self.opt.step_range(s, e)
+            self.opt.end_step()
+            return out
         if self.comm.world > 1:
             if not self.overlap:
                 self._reduce_dense(0, st.n_live)
+            for _, _, works in self._bucket_works:
+                for w in works:
+                    w.wait()
             self.comm.finish()
         self.opt.step()
         return out
+
+    def _covers_live(self, st):
+        """The buckets whose hooks fired tile [0, n_live) exactly (always, for a backward over the whole model)."""
+        spans = sorted((s, e) for s, e, _ in self._bucket_works)
+        pos = 0
+        for s, e in spans:
+            if s != pos:
+                return False
+            pos = e
+        return pos == st.n_live
+
+    def fit(self, train_batches, valid_batches, epochs, **kw):
+        """The reference's train / validate / checkpoint / early-stop loop (module-level :func:`fit`)."""
+        return fit(self, train_batches, valid_batches, epochs, **kw)
 
     @torch.no_grad()
     def eval_step(self, batch, mode="inference"):
@@ -440,6 +503,72 @@ class Trainer:
                 elif k in ev:
                     acc[k].append(float(ev[k]))
         return {k: (sum(v) / len(v) if v else float("nan")) for k, v in acc.items()}
+
+
+def early_stop_reached(metric_history: List[float], early_stop: int) -> bool:
+    """The two early-stop tests of the reference loop on the monitored validation metric (higher is better),
+    main_for_seq_leave_earlystop_SegMM.py:336-352: (i) none of the last ``early_stop`` validations beat the first of that window,
+    (ii) the best validation lies more than ``early_stop`` validations back."""
+    m = list(metric_history)
+    if early_stop <= 0 or not m:
+        return False
+    if len(m) > early_stop:
+        lst = m[-early_stop:]
+        if all(lst[0] >= y for y in lst[1:]):
+            return True
+    return len(m) - m.index(max(m)) > early_stop
+
+
+def fit(trainer: "Trainer", train_batches, valid_batches, epochs: int, valid_step: int = 30, early_stop: int = 0,
+        main_metric: str = "NDCG@5", ckpt: Optional["CheckPointer"] = None, logging_step: int = 0, log=None,
+        permutation: int = 1, top_k_mask: bool = False, metrics=None):
+    """The train / validate / checkpoint / early-stop loop of the reference trainer around ``Trainer.train_step``
+    (main_for_seq_leave_earlystop_SegMM.py:247-354): one validation over ``valid_batches`` BEFORE training, then per epoch every
+    ``valid_step`` local steps a validation whose ``main_metric`` (mean over the validation batches, :179-181) drives
+    ``ckpt.save_checkpoint(..., metric_vals={"main_metric": ...})`` (:333) and the early-stop tests (:336-352).
+    ``train_batches``: a list of batch dicts, or a callable ``epoch -> iterable of batch dicts`` (an epoch of the DataLoader).
+    The loss is read on the host only where the reference's bookkeeping needs a number (validation points, logging steps).
+    Returns the history dict the reference calls ``total_valid_loss_metrics`` (+ "stopped_epoch", "global_step")."""
+    metrics = list(metrics) if metrics is not None else ["valid_loss", "HR@1", "HR@3", "HR@5", "HR@10", "NDCG@1", "NDCG@3", "NDCG@5", "NDCG@10"]
+    hist: Dict[str, list] = {"train_loss": [0.0]}
+    for k in metrics:
+        hist[k] = []
+
+    def validate():
+        vm = trainer.valid_model(valid_batches, metrics=tuple(metrics), permutation=permutation, top_k_mask=top_k_mask)
+        for k in metrics:
+            hist[k].append(vm[k])
+        return vm
+
+    validate()                                           # "Evaluation Before Training" (:247-249)
+    global_step, stop, stopped_epoch = 0, False, None
+    for epoch in range(epochs):
+        if stop:
+            break
+        it = train_batches(epoch) if callable(train_batches) else train_batches
+        epoch_losses = []
+        for local_step, batch in enumerate(it):
+            out = trainer.train_step(batch)
+            epoch_losses.append(out["loss"].detach())
+            global_step += 1
+            if logging_step and (local_step + 1) % logging_step == 0 and log is not None:
+                log("Train_loss: %f, Global_step: %d" % (float(epoch_losses[-1]), global_step))
+            if (local_step + 1) % valid_step == 0:
+                hist["train_loss"].append(float(epoch_losses[-1]))
+                validate()
+                avg = hist[main_metric][-1]
+                if log is not None:
+                    log("Valid_loss: %s, %s: %s, Global_step: %d" % (hist["valid_loss"][-1] if "valid_loss" in hist else None, main_metric, avg, global_step))
+                if ckpt is not None and trainer.comm.rank == 0:
+                    ckpt.save_checkpoint(model=trainer.model, optimizer=trainer.opt, num_epochs=epoch, metric_vals={"main_metric": avg})
+                if early_stop_reached(hist[main_metric], early_stop):
+                    stop, stopped_epoch = True, epoch
+                    break
+        if log is not None and epoch_losses:
+            log("Epoch: %d, Epoch Loss: %f" % (epoch, float(torch.stack(epoch_losses).mean())))
+    hist["stopped_epoch"] = stopped_epoch
+    hist["global_step"] = global_step
+    return hist
 
 
 class CheckPointer:

@@ -85,3 +85,55 @@ def test_two_ranks_equal_single_process(name):
     assert abs(l1[1] - l2[1]) <= 3e-4 * max(1.0, abs(l1[1])), (l1, l2)
     for k in sd1:     # after 2 AdamW steps; lr-sized slack for elements whose gradient is rounding noise (Adam sign flips)
         assert torch.allclose(torch.from_numpy(sd1[k]), torch.from_numpy(sd2[k]), rtol=1e-4, atol=4.5e-3), k
+
+
+def _run_sched(rank, world, port, name, per_bucket, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      SEGMM_BUCKET_ADAMW="1" if per_bucket else "0")
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from segmminterest_amd.trainer import DPComm, Trainer, shard_rows
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        cfg, g, _, _ = load_case(name)
+        model = build_model(cfg)
+        model.load_state_dict(g["sd"])
+        model = model.cuda()
+        tr = Trainer(model, comm=DPComm(), overlap=True, dropout=False)
+        assert tr.per_bucket_adamw == per_bucket
+        full = _batch(cfg, 16)
+        s, e = shard_rows(16, world, rank)
+        shard = {k: v[s:e].cuda() for k, v in full.items()}
+        for _ in range(3):
+            tr.train_step(shard)
+        nb = len(tr._bucket_works)
+        if rank == 0:
+            q.put((nb, [b for b, _, _ in model._store.buckets], {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["img_d32_N3_alllosses", "id_d32_N2"])
+def test_per_bucket_adamw_equals_single_launch(name):
+    """AdamW stepped bucket by bucket as each all-reduce completes (user-side embedding in its own, earlier bucket) leaves
+    bitwise the same parameters as one launch over the live range after every collective has finished."""
+    ctx = mp.get_context("spawn")
+    res = {}
+    for per_bucket in (False, True):
+        q = ctx.Queue()
+        port = 29700 + (os.getpid() + int(per_bucket)) % 200
+        procs = [ctx.Process(target=_run_sched, args=(r, 2, port, name, per_bucket, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        res[per_bucket] = q.get(timeout=240)
+        for p in procs:
+            p.join(60)
+            assert p.exitcode == 0
+    (nb0, names0, sd0), (nb1, names1, sd1) = res[False], res[True]
+    assert nb1 == len(names1) and names1 == names0           # a hook fired for every bucket of the layout
+    if name.startswith("img"):
+        assert any(b.endswith("embed_u") for b in names1) and names1[-1].endswith("embed")
+    for k in sd0:
+        assert (sd0[k] == sd1[k]).all(), k

@@ -79,3 +79,23 @@ def test_product_package_never_imports_oracle():
         if fn.endswith(".py"):
             src = open(os.path.join(pkg, fn)).read()
             assert "oracle" not in src.replace("the oracle", "").replace("CPU oracle", "") or fn == "smoke.py", fn
+
+
+def test_early_stop_rule_matches_reference_loop():
+    """main_for_seq_leave_earlystop_SegMM.py:336-352 on hand-made metric histories."""
+    from segmminterest_amd.trainer import early_stop_reached
+
+    def reference(total_valid_metric, early_stop):      # the two tests of the reference, restated line by line
+        if early_stop > 0:
+            if len(total_valid_metric) > early_stop:
+                lst = total_valid_metric[-early_stop:]
+                if all(x >= y for x, y in zip([lst[0]] * (len(lst) - 1), lst[1:])):
+                    return True
+            if len(total_valid_metric) - total_valid_metric.index(max(total_valid_metric)) > early_stop:
+                return True
+        return False
+    import itertools
+    for n in range(1, 7):
+        for vals in itertools.product([0.1, 0.2, 0.3], repeat=n):
+            for es in (0, 1, 2, 3):
+                assert early_stop_reached(list(vals), es) == reference(list(vals), es), (vals, es)

@@ -408,3 +408,141 @@ def test_config1_sample_file_labels_vs_oracle():
     ref_m = O.top_k_leave(interests.cpu().numpy(), view, pm.numpy(), permutation=0, S=S)
     for k in ("HR@1", "HR@3", "HR@5", "HR@10", "NDCG@1", "NDCG@3", "NDCG@5", "NDCG@10"):
         assert float(dev_m[k]) == float(ref_m[k]), (k, dev_m[k], ref_m[k])
+
+
+def _cfg2_model(B, seed=1, scale_layers=2.0, scale_in=100.0):
+    import segmminterest_amd as M
+    from segmminterest_amd.synth import make_batch, l1_normalize
+    torch.manual_seed(seed)
+    S, Lt, D, N, h = 40, 100, 768, 2, 16
+    args = _ref_args(N, D, h, S, "image", "image")
+    bb = M.SegFormerX(d_model_in=D, d_model_lvls=[D] * N, num_head_lvls=[h] * N, ff_dim_lvls=[D] * N, input_vid_dim=D,
+                      input_usr_dim=D, max_vid_len=S, max_usr_len=Lt, sr_ratio_lvls=[1] * N, use_patch_merge=[False] * N,
+                      output_layers=[-1], model_cfg=args)
+    model = M.MultiScaleTemporalDetrLeaveFocal(bb, None, None, torch.nn.Identity(), args)
+    with torch.no_grad():
+        for n_, p in model.named_parameters():
+            if p.dim() == 2 and ".encoder.layers." in n_ and "ln_" not in n_:
+                p.mul_(scale_layers)
+            if n_.endswith("vid_proj.weight") or n_.endswith("usr_proj.weight"):
+                p.mul_(scale_in)
+    b = make_batch(B, S, Lt, D, seed=11)
+    inp = dict(usr_image=l1_normalize(b["user"]), usr_id=b["user_identity_id"], usr_mask=b["user_mask"],
+               vid_image=l1_normalize(b["photo"]), vid_id=b["photo_identity_id"], vid_mask=b["photo_mask"], gt=b["label"])
+    cfg = dict(N=N, h=h, S=S, user="image", photo="image", loss_type_list=["interestBPR"], loss_weight={"interestBPR": 1.0, "mse": 1.0},
+               exposure_prob=[1.0] * S)
+    return model, inp, cfg
+
+
+def _check_live_grads(model, rgrads):
+    """Every live gradient within 3e-4 of its tensor's maximum.  interestBPR is invariant to a per-row shift of the logits, so
+    the gradients that are SUMS of d loss / d logits over all tokens (head bias, the last LayerNorm's bias) are exactly zero in
+    exact arithmetic and pure cancellation noise in fp32 -- in the oracle as well: an absolute floor of 1e-6 of the largest
+    gradient in the model covers them."""
+    gmax = max(float(r.abs().max()) for r in rgrads.values() if r is not None)
+    errs, bad = {}, {}
+    for k, p in model.named_parameters():
+        if rgrads[k] is None:
+            assert p.grad is None, k
+            continue
+        scale = float(rgrads[k].abs().max())
+        e = float((p.grad.cpu() - rgrads[k]).abs().max())
+        errs[k] = e / max(scale, 1e-30)
+        if e > 3e-4 * scale + 1e-6 * gmax:
+            bad[k] = (e, scale, gmax)
+    assert not bad, bad
+    return errs
+
+
+def test_full_size_gradients_match_oracle():
+    """BASELINE config 2 at FULL size (B = 512, S = 40, Lt = 100, D = 768, N = 2): loss and EVERY live gradient of the
+    eval-mode training forward/backward against the CPU oracle on the whole batch (the loss normalisers couple the rows, so
+    no row subset will do; ~10 s of CPU)."""
+    import segmm_oracle as O
+    model, inp, cfg = _cfg2_model(512)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    ref, rgrads = O.forward_backward(sd, cfg, inp)
+    model = model.cuda().eval()
+    out = call_model(model, inp, "train", DEV)
+    assert (out["logits"].cpu() - ref["logits"].detach()).abs().max().item() < 1e-4
+    assert abs(float(out["loss"]) - float(ref["loss"])) < 1e-5 * max(1.0, abs(float(ref["loss"])))
+    out["loss"].backward()
+    errs = _check_live_grads(model, rgrads)
+    print("full-size worst gradient error / tensor max: %.2e" % max(v for k, v in errs.items() if "bias" not in k))
+
+
+def test_outlier_gamma_and_outlier_activation_row():
+    """Scale groups: every weight matrix has its OWN scale on the plane engine and LayerNorm gammas / biases are
+    part of none, so a x50 outlier gamma must not cost the GEMM weights any head-room; and one activation row 1000x larger than
+    the rest (an un-normalised input row passed straight to model()) must leave the other rows at fp32-level accuracy."""
+    import segmm_oracle as O
+    model, inp, cfg = _cfg2_model(24, seed=3)
+    with torch.no_grad():
+        model.backbone1.encoder.layers[0].cross_attn.ln_vid.weight[5] *= 50.0
+        model.backbone1.vid_ln.weight[100] *= 50.0
+    inp["vid_image"][3, 7] *= 1000.0
+    inp["usr_image"][5, 11] *= 1000.0
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    ref, rgrads = O.forward_backward(sd, cfg, inp)
+    model = model.cuda().eval()
+    out = call_model(model, inp, "train", DEV)
+    assert (out["logits"].cpu() - ref["logits"].detach()).abs().max().item() < 1e-4
+    out["loss"].backward()
+    _check_live_grads(model, rgrads)
+
+
+def test_loss_curve_under_dropout_tracks_the_oracle():
+    """Train mode has no bitwise oracle (different dropout streams): 40 AdamW steps on one batch with dropout 0.1 on the
+    device (3 seeds) against the CPU oracle's own train loop with torch dropout (3 seeds) -- the curves must agree within
+    the seed-to-seed spread of either side, at the start, in the middle and at the end."""
+    import segmm_oracle as O
+    import torch.nn.functional as F
+    from segmminterest_amd.trainer import Trainer
+    cfg, g, nograd, _ = load_case("img_d32_N2")
+    steps, marks = 40, (slice(0, 5), slice(15, 25), slice(30, 40))
+    ocfg = dict(cfg)
+    curves_o = []
+    for seed in (1, 2, 3):
+        torch.manual_seed(seed)
+        _, losses = O.train_steps(g["sd"], ocfg, g["in"], steps, skip_dead=True, drop=lambda t: F.dropout(t, 0.1))
+        curves_o.append(losses)
+    curves_h = []
+    for seed in (11, 12, 13):
+        model = build_model(cfg)
+        model.load_state_dict(g["sd"])
+        model = model.cuda()
+        tr = Trainer(model)
+        batch = dict(user=g["in"]["usr_image"].to(DEV), photo=g["in"]["vid_image"].to(DEV), user_mask=g["in"]["usr_mask"].to(DEV),
+                     photo_mask=g["in"]["vid_mask"].to(DEV), label=g["in"]["gt"].to(DEV), user_identity_id=g["in"]["usr_id"].to(DEV),
+                     photo_identity_id=g["in"]["vid_id"].to(DEV))
+        tr.normalize = lambda key, x: x                      # the fixture's features are already L1-normalised
+        torch.manual_seed(seed)
+        curves_h.append([float(tr.train_step(batch)["loss"]) for _ in range(steps)])
+    co, ch = torch.tensor(curves_o), torch.tensor(curves_h)
+    for m in marks:
+        mo, mh = co[:, m].mean(1), ch[:, m].mean(1)           # per-seed window means
+        spread = max(float(mo.std()), float(mh.std()), 0.01 * float(mo.mean().abs()))
+        assert abs(float(mo.mean()) - float(mh.mean())) <= 4.0 * spread, (m, mo.tolist(), mh.tolist())
+    assert float(ch[:, -5:].mean()) < float(ch[:, :5].mean())        # and it learns
+
+
+def test_fit_loop_validates_checkpoints_and_stops_early(tmp_path):
+    """Trainer.fit = the reference loop (main...SegMM.py:247-354): validation before training and every valid_step steps,
+    CheckPointer on the main metric, early stop."""
+    from segmminterest_amd.synth import make_batch
+    from segmminterest_amd.trainer import CheckPointer, Trainer
+    cfg, g, _, _, model = _loaded("img_d32_N2")
+    tr = Trainer(model, lr=1e-3)
+    mk = lambda s: {k: v.to(DEV) for k, v in make_batch(16, cfg["S"], cfg["Lt"], cfg["D_in"], seed=s).items()}
+    train, valid = [mk(s) for s in range(6)], [mk(100), mk(101)]
+    ck = CheckPointer("main_metric", str(tmp_path), mode="max")
+    logs = []
+    hist = tr.fit(train, valid, epochs=3, valid_step=2, early_stop=0, main_metric="NDCG@5", ckpt=ck, log=logs.append, permutation=0)
+    assert hist["global_step"] == 18 and len(hist["NDCG@5"]) == 1 + 9 and len(hist["train_loss"]) == 1 + 9
+    assert hist["train_loss"][0] == 0.0 and os.path.exists(ck.ckpt_latest) and ck.best_metric == max(hist["NDCG@5"][1:])
+    assert all(0.0 <= v <= 1.0 for v in hist["HR@1"]) and hist["stopped_epoch"] is None
+    # a learning rate of zero: the metric never improves -> the "best lies more than early_stop validations back" test fires
+    tr0 = Trainer(model, lr=0.0, weight_decay=0.0, dropout=False)
+    hist0 = tr0.fit(train, valid, epochs=5, valid_step=1, early_stop=2, main_metric="NDCG@5", permutation=0)
+    assert hist0["stopped_epoch"] == 0 and len(hist0["NDCG@5"]) == 3 and len(set(hist0["NDCG@5"])) == 1
