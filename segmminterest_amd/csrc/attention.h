@@ -175,11 +175,61 @@ __device__ __forceinline__ float col_store(float* rowp, const f32x4 (&o)[(DH + 1
     return am;
 }
 
+// ---- plane stores of the attention kernels: 16 bytes per lane (8 hi terms or 8 lo terms of 8 consecutive columns), like
+// plane_store4_pair (common.h), but the partner that holds the other 4 columns of an aligned group of 8 is either the SAME
+// lane (a lane owns 4 CT consecutive columns) or the lane 16 further (g ^ 1): exchange through ds_swizzle (xor 16).
+__device__ __forceinline__ uint32_t swz16(uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x401F); }
+struct HL { uint32_t h0, h1, l0, l1; };
+__device__ __forceinline__ HL split4(f32x4 v, float s) {
+    HL r;
+    splith_pair(v.x, v.y, s, r.h0, r.l0);
+    splith_pair(v.z, v.w, s, r.h1, r.l1);
+    return r;
+}
+__device__ __forceinline__ _Float16* p32_at(_Float16* p, int ld2, long long row, int c) { return p + row * ld2 + ((c >> 5) << 6) + (c & 31); }
+// columns c .. c+7 (c % 8 == 0) held by ONE lane as two split groups a (c..c+3), b (c+4..c+7)
+__device__ __forceinline__ void plane_store8(_Float16* p, int ld2, long long row, int c, const HL& a, const HL& b) {
+    _Float16* o = p32_at(p, ld2, row, c);
+    *(uint4*)o = make_uint4(a.h0, a.h1, b.h0, b.h1);
+    *(uint4*)(o + 32) = make_uint4(a.l0, a.l1, b.l0, b.l1);
+}
+// columns c .. c+3 of this lane, the other half of the aligned 8 in lane ^ 16 (which calls this in the same instruction)
+__device__ __forceinline__ void plane_store4_x16(_Float16* p, int ld2, long long row, int c, const HL& a) {
+    const bool odd = (c & 4) != 0;
+    const uint32_t r0 = swz16(odd ? a.h0 : a.l0), r1 = swz16(odd ? a.h1 : a.l1);
+    _Float16* o = p32_at(p, ld2, row, c & ~7) + (odd ? 32 : 0);
+    *(uint4*)o = odd ? make_uint4(r0, r1, a.l0, a.l1) : make_uint4(a.h0, a.h1, r0, r1);
+}
+// NG consecutive float4 groups of one row starting at column c0 (multiple of 4; c0 of the lane 16 further = c0 + 4 NG, same
+// row; every lane of the 16-lane exchange pairs takes part).  Groups are paired into aligned 8-column chunks in-lane where
+// possible, across lane ^ 16 at the seams.
+template <int NG>
+__device__ __forceinline__ void plane_store_groups(_Float16* p, int ld2, long long row, int c0, const f32x4 (&v)[NG], float s) {
+    HL g[NG];
+#pragma unroll
+    for (int i = 0; i < NG; ++i) g[i] = split4(v[i], s);
+    if (NG % 2 == 0) {                        // c0 % 8 == 0 for every lane (4 NG % 8 == 0): all pairs in-lane
+#pragma unroll
+        for (int i = 0; i < NG; i += 2) plane_store8(p, ld2, row, c0 + 4 * i, g[i], g[i + 1]);
+    } else {
+        const bool odd = (c0 & 4) != 0;        // odd lanes: group 0 completes the previous lane's last group
+        // seam: this lane's first (odd) or last (even) group with lane ^ 16
+        const HL sm = odd ? g[0] : g[NG - 1];
+        plane_store4_x16(p, ld2, row, odd ? c0 : c0 + 4 * (NG - 1), sm);
+#pragma unroll
+        for (int k = 0; k < NG / 2; ++k) {
+            const HL a = odd ? g[2 * k + 1] : g[2 * k], b = odd ? g[2 * k + 2] : g[2 * k + 1];
+            plane_store8(p, ld2, row, c0 + 4 * (2 * k) + (odd ? 4 : 0), a, b);
+        }
+    }
+}
+
 // the same store plus the P32 planes of the values (row = absolute row of the output tensor, col0 = first column of the head)
 template <int DH>
 __device__ __forceinline__ float col_store_p(float* rowp, _Float16* planes, int ld2, long long row, int col0, float ps,
                                              const f32x4 (&o)[(DH + 15) / 16], int g, float am) {
     constexpr int CT = (DH + 15) / 16;
+    f32x4 vv[CT];
     if (4 * CT * g < DH) {
         float t[4 * CT];
 #pragma unroll
@@ -188,12 +238,16 @@ __device__ __forceinline__ float col_store_p(float* rowp, _Float16* planes, int 
             for (int ct = 0; ct < CT; ++ct) t[CT * r + ct] = o[ct][r];
 #pragma unroll
         for (int i = 0; i < CT; ++i) {
-            const f32x4 v = {t[4 * i], t[4 * i + 1], t[4 * i + 2], t[4 * i + 3]};
-            *(f32x4*)(rowp + 4 * CT * g + 4 * i) = v;
-            plane_store4(planes, ld2, row, col0 + 4 * CT * g + 4 * i, v, ps);
-            am = absmax4(am, v);
+            vv[i] = f32x4{t[4 * i], t[4 * i + 1], t[4 * i + 2], t[4 * i + 3]};
+            *(f32x4*)(rowp + 4 * CT * g + 4 * i) = vv[i];
+            am = absmax4(am, vv[i]);
+        }
+        if (DH % 16 != 0 || (col0 & 7) != 0) {          // narrow heads (some g idle) or unaligned head start: 8-byte stores
+#pragma unroll
+            for (int i = 0; i < CT; ++i) plane_store4(planes, ld2, row, col0 + 4 * CT * g + 4 * i, vv[i], ps);
         }
     }
+    if (DH % 16 == 0 && (col0 & 7) == 0) plane_store_groups<CT>(planes, ld2, row, col0 + 4 * CT * g, vv, ps);
     return am;
 }
 
@@ -912,7 +966,10 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_bwd_fused_kernel(const AttnAr
             const size_t row = (size_t)b * p.Lq + q0 + q;
             const f32x4 v = *(const f32x4*)(sdQ + q * RS + c);
             *(f32x4*)(dQg + row * p.lddq + col0 + c) = v;
-            if (s_q > 0.f) plane_store4(dQgp, p.lddq2, (long long)row, col0 + c, v, s_q);
+            if (s_q > 0.f) {          // adjacent threads hold adjacent float4 groups of one row (DH / 4 even, col0 % 8 == 0)
+                if ((DH & 7) == 0 && (col0 & 7) == 0) plane_store4_pair(dQgp, p.lddq2, (long long)row, col0 + c, v, s_q);
+                else plane_store4(dQgp, p.lddq2, (long long)row, col0 + c, v, s_q);
+            }
             am_q = absmax4(am_q, v);
         }
         if (!ONE && q0 + QC < p.Lq) __syncthreads();       // the next chunk's staging overwrites what was just read
@@ -935,9 +992,14 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_bwd_fused_kernel(const AttnAr
                 if (16 * ct + 4 * g < DH) {
                     *(f32x4*)(dKp + 16 * ct + 4 * g) = dk[ct];
                     *(f32x4*)(dVp + 16 * ct + 4 * g) = dv[ct];
-                    if (s_k > 0.f) {
-                        plane_store4(dKpp, ldk2, krow, col0 + 16 * ct + 4 * g, dk[ct], s_k);
-                        plane_store4(dVpp, ldk2, krow, col0 + 16 * ct + 4 * g, dv[ct], s_k);
+                    if (s_k > 0.f) {          // lane (key, g) and lane (key, g ^ 1) hold the two halves of an aligned 8
+                        if (DH % 16 == 0 && (col0 & 7) == 0) {
+                            plane_store4_x16(dKpp, ldk2, krow, col0 + 16 * ct + 4 * g, split4(dk[ct], s_k));
+                            plane_store4_x16(dVpp, ldk2, krow, col0 + 16 * ct + 4 * g, split4(dv[ct], s_k));
+                        } else {
+                            plane_store4(dKpp, ldk2, krow, col0 + 16 * ct + 4 * g, dk[ct], s_k);
+                            plane_store4(dVpp, ldk2, krow, col0 + 16 * ct + 4 * g, dv[ct], s_k);
+                        }
                     }
                     am = absmax4(absmax4(am, dk[ct]), dv[ct]);
                 }

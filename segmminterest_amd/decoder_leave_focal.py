@@ -131,8 +131,8 @@ class HeadLossFn(torch.autograd.Function):
         if gbuf is None and st.bucket_hook is not None:
             st.bucket_hook("head")
         ctx.dlogits = ctx.T = None
-        grads = tuple(st.g(n, gbuf) for n in names)
-        return (None, None, dv1.view(B, S, d), dv2.view(B, S, d) if dv2 is not None else None, None) + grads
+        E.deliver_grads(st, names, gbuf)
+        return (None, None, dv1.view(B, S, d), dv2.view(B, S, d) if dv2 is not None else None, None) + (None,) * len(names)
 
 
 class MultiScaleTemporalDetrLeaveFocal(nn.Module):

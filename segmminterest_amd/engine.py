@@ -1275,19 +1275,34 @@ class BackboneFn(torch.autograd.Function):
             d_vid = torch.zeros((run.B, run.S if run.abl != "CrossMLP" else POOL_BINS, run.d), device=store.flat.device)
         run.backward(d_vid, gbuf, on_bucket=store.bucket_hook if gbuf is None else None)
         ctx.run = None
-        grads = tuple(store.g(n, gbuf) for n in ctx.names)
-        return (None,) * 10 + grads
+        deliver_grads(store, ctx.names, gbuf)
+        return (None,) * (10 + len(ctx.names))
 
 
 def _pick_gbuf(store, names):
-    """Use the store's flat gradient buffer unless a parameter still holds a .grad that aliases it
-    (gradient accumulation over several backward calls): then compute into a fresh buffer."""
-    base, end = store.gflat.data_ptr(), store.gflat.data_ptr() + 4 * store.gflat.numel()
-    for n in names[:1] + names[-1:]:
-        g = store._params[n].grad
-        if g is not None and base <= g.data_ptr() < end:
-            return torch.zeros_like(store.gflat)
+    """Use the store's flat gradient buffer unless a parameter still holds a .grad (gradient accumulation over several
+    backward calls without zero_grad): then compute into a fresh buffer, which ``deliver_grads`` adds to the held gradients."""
+    if any(store._params[n].grad is not None for n in names):
+        if store.bucket_hook is not None:
+            raise RuntimeError("gradient accumulation under data parallelism is not supported: call zero_grad() before every "
+                               "backward (the bucket all-reduces are issued from inside the backward)")
+        return torch.zeros_like(store.gflat)
     return None
+
+
+def deliver_grads(store, names, gbuf):
+    """Hand the gradients of ``names`` to their parameters' ``.grad`` directly: views of the flat gradient buffer, so that the
+    fused AdamW, the bucket all-reduces and any torch optimizer all see ONE buffer.  (Returned through autograd they would be
+    cloned tensor by tensor by AccumulateGrad -- it never steals a view: 21 device copies and 33 MB per step at config 2.)
+    A parameter that already holds a gradient (accumulation; ``gbuf`` is then a fresh buffer) gets the new one ADDED in place --
+    into the flat buffer when that is what its ``.grad`` aliases, which is what the fused AdamW reads."""
+    for n in names:
+        p = store._params[n]
+        g = store.g(n, gbuf)
+        if p.grad is None:
+            p.grad = g
+        else:
+            p.grad.add_(g)
 
 
 def backbone_apply(store, bb, prefix, usr_feat, usr_mask, vid_feat, vid_mask, training, bb_index=0, seed=None):

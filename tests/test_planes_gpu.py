@@ -256,9 +256,10 @@ def test_gather_writes_planes_and_maxima():
     assert torch.equal(pl, ref_pl) and float(hdr[H.SITE_HDR:].max()) == float(out.abs().max())
 
 
-def test_attention_producers_write_the_split_pass_planes():
+@pytest.mark.parametrize("Hh,dh", [(4, 16), (2, 32), (2, 48), (1, 64), (8, 8)])
+def test_attention_producers_write_the_split_pass_planes(Hh, dh):
     H = _abi()
-    B, Hh, dh, S, Lt = 3, 4, 16, 40, 23
+    B, S, Lt = 3, 40, 23
     d = Hh * dh
     Yv, Yu = _rand(B * S, 4 * d, seed=30), _rand(B * Lt, 2 * d, seed=31)
     vm = (torch.rand(B, S, generator=torch.Generator().manual_seed(1)) > 0.2).to(torch.uint8).to(DEV)
