@@ -635,10 +635,23 @@ def _wgrad(store, dY, y_off, X, x_off, Mrows, n_out, n_in, gW, accumulate=False,
            a_amax=dY.slots, b_amax=X.slots)
 
 
+_FEW_TILES = int(os.environ.get("SEGMM_FEW_TILES", "48"))
+
+
+def _few_tiles(M, N):
+    return ((M + 255) // 256) * ((N + 255) // 256) < _FEW_TILES
+
+
 def _lin_fwd(store, M, N, K, X, wname, out, ldo, c_act=None, **kw):
     """out[M,N] = X[M,K] . W[N,K]^T (+ epilogue); X: Act; W = the parameter (or fused group starting at) ``wname``;
     ``c_act``: the Act that ``out`` belongs to (receives the partial maxima of |out|)."""
     w = store.wpt.get(wname) if store.engine_p else None
+    if w is not None and X.planes is not None and _few_tiles(M, N):
+        # a handful of 256 x 256 tiles would leave most of the 256 CUs idle (config 3: 1024 user tokens): the 128 x 128
+        # on-the-fly kernel has 4x the workgroups; it takes the fp32 operands and the same partial maxima
+        H.gemm(H.LAYOUT_NT, M, N, K, X.t, K, store.p(wname), K, out, ldo, a_amax=X.slots, b_amax=w.hdr[H.SITE_HDR:],
+               c_amax=None if c_act is None else c_act.slots, **kw)
+        return
     if w is not None and X.planes is not None:
         if c_act is not None and c_act.po is not None:
             H.gemm_p(H.LAYOUT_NT, M, N, K, X.pt(), w, out, ldo, c_pt=c_act.pt(), c_scale_ptr=c_act.scale_ptr, **kw)
@@ -656,6 +669,10 @@ def _lin_dgrad(store, M, n_in, n_out, dY, wname, out, c_act=None, **kw):
     """out[M,n_in] = dY[M,n_out] . W[n_out,n_in] (+ epilogue); dY: Act.  With W^T planes this is the NT form (both operands
     k-contiguous), otherwise the NN layout on the fp32 weights."""
     wT = store.wTpt.get(wname) if store.engine_p else None
+    if wT is not None and dY.planes is not None and _few_tiles(M, n_in):
+        H.gemm(H.LAYOUT_NN, M, n_in, n_out, dY.t, n_out, store.p(wname), n_in, out, n_in, a_amax=dY.slots, b_amax=wT.hdr[H.SITE_HDR:],
+               c_amax=None if c_act is None else c_act.slots, **kw)
+        return
     if wT is not None and dY.planes is not None:
         if c_act is not None and c_act.po is not None:
             H.gemm_p(H.LAYOUT_NT, M, n_in, n_out, dY.pt(), wT, out, n_in, c_pt=c_act.pt(), c_scale_ptr=c_act.scale_ptr, **kw)
