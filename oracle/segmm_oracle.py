@@ -385,7 +385,7 @@ def forward_backward(sd, cfg, inp, dtype=torch.float32, skip_dead=True, drop=Non
     reference's eval mode; a callable (e.g. ``lambda t: F.dropout(t, 0.1)``) is its train mode."""
     params = {k: v.detach().clone().to(dtype if v.is_floating_point() else v.dtype).requires_grad_(v.is_floating_point())
               for k, v in sd.items()}
-    inp = {k: (v.to(dtype) if v.is_floating_point() else v.clone()) for k, v in inp.items()}
+    inp = {k: (v if v is None else v.to(dtype) if v.is_floating_point() else v.clone()) for k, v in inp.items()}
     out = model_forward(params, cfg, inp, "train", skip_dead, drop)
     out["loss"].backward()
     grads = {k: (p.grad if p.requires_grad else None) for k, p in params.items()}

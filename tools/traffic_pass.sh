@@ -9,12 +9,13 @@ OUT=$R/gpurun_out/traffic_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 400 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/$C.log 2>&1 || exit 1
+  timeout -k 10 400 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-f32-engine > $OUT/$C.log 2>&1 || exit 1
 done
 cd $R
-python3 - "$OUT" <<'PY'
-import collections, csv, glob, json, sys
-out = sys.argv[1]
+GIT=${GIT_SHA:-unknown}
+python3 - "$OUT" "$GIT" <<'PY'
+import collections, csv, glob, json, os, sys
+out, git = sys.argv[1], sys.argv[2]
 acc = collections.OrderedDict()
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for f in sorted(glob.glob("%s/%s/**/*counter_collection.csv" % (out, c), recursive=True)):
@@ -34,10 +35,11 @@ with open(out + "/summary.csv", "w") as o:
     o.write("kernel,dispatches_fetch_pass,dispatches_write_pass,read_bytes_per_dispatch(2x FETCH_SIZE KiB),write_bytes_per_dispatch(WRITE_SIZE KiB)\n")
     for r in rows:
         o.write("%s,%d,%d,%.0f,%.0f\n" % (r[0].replace(",", ";"), r[1], r[2], r[3], r[4]))
-g = [r for r in rows if "gemm_split_mfma" in r[0] or "gemm_f32_mfma" in r[0]]
+g = [r for r in rows if "gemm_split_mfma" in r[0] or "gemm_f32_mfma" in r[0] or "gemm_pl_" in r[0]]
+engine = os.environ.get("SEGMM_GEMM", "f16x3p")
 n = sum(r[1] for r in g)
 tot = sum((r[3] + r[4]) * r[1] for r in g)
-json.dump({"kernel": "gemm_split_mfma / gemm_f32_mfma (all template instances)", "launches": n,
+json.dump({"kernel": "every GEMM dispatch of the run (gemm_pl_nt / gemm_pl_tn / gemm_split_mfma / gemm_f32_mfma)", "engine": engine, "git": git, "launches": n,
            "hbm_bytes_per_launch": tot / max(n, 1), "read_bytes_per_launch": sum(r[3] * r[1] for r in g) / max(n, 1),
            "write_bytes_per_launch": sum(r[4] * r[1] for r in g) / max(n, 1),
            "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over bench.py --steps 3 --warmup 1; "
