@@ -23,6 +23,7 @@
 // ds_read_b128 fragment reads (16 distinct rows per lane group, same logical chunk) are conflict-free; because LDS-DMA
 // writes lane-linear, the permutation is applied to each lane's SOURCE address.
 #pragma once
+#include <type_traits>
 #include "gemm_split.h"
 
 namespace segmm {
@@ -50,8 +51,13 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t r, void* lds_wa
 }
 __device__ __forceinline__ void dma_wait_barrier() {
     __builtin_amdgcn_sched_barrier(0);          // MFMAs are register-only: without this the scheduler sinks them below the barrier
+#ifndef SEGMM_PROBE_BAR          // timing probes only (results are wrong): 1 no s_barrier, 2 no DMA wait, 3 neither
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+#else
+    if (SEGMM_PROBE_BAR & 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (!(SEGMM_PROBE_BAR & 1)) __builtin_amdgcn_s_barrier();
+#endif
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 }
@@ -247,11 +253,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_nt(const GemmArgs p, const PGe
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const f32x4 ah = *(const f32x4*)(st + fa[0][s] + i * 4096);
+#if defined(SEGMM_PROBE_BAR) && (SEGMM_PROBE_BAR & 4)          // timing probe: half the LDS fragment traffic
+                const f32x4 al = ah;
+#else
                 const f32x4 al = *(const f32x4*)(st + fa[1][s] + i * 4096);
-                if (!(q.dbg & 4)) {
-                    if (s == 0) lds_dma16(rsA, nx + (wave * 4 + i) * 1024, voa[i], (uint32_t)kt_next * 128u);
-                    else lds_dma16(rsB, nx + PBM * 128 + (wave * 4 + i) * 1024, vob[i], (uint32_t)kt_next * 128u);
-                }
+#endif
+                // (no run-time condition here: a branch would end the scheduling region after every 6 MFMAs)
+                if (s == 0) lds_dma16(rsA, nx + (wave * 4 + i) * 1024, voa[i], (uint32_t)kt_next * 128u);
+                else lds_dma16(rsB, nx + PBM * 128 + (wave * 4 + i) * 1024, vob[i], (uint32_t)kt_next * 128u);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     f32x16 c = acc[i][j];
@@ -493,7 +502,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_tn(const GemmArgs p, const PGe
         fa[x] = lane_base + (uint32_t)(8 * wm * 64) + (uint32_t)((x ^ qq) << 6);
         fb[x] = lane_base + 32768u + (uint32_t)(4 * wn * 64) + (uint32_t)((x ^ qq) << 6);
     }
-    auto compute = [&](const char* st) {
+    // the column-sum fragments (A block i = wn) are fetched by address, not by "if (i == wn)": a branch inside the MFMA
+    // block would cut it into eight scheduling regions, each opening with a full LDS wait
+    const uint32_t fcs_h = fa[2 * (wn & 1)] + (uint32_t)((wn >> 1) * 256), fcs_l = fa[2 * (wn & 1) + 1] + (uint32_t)((wn >> 1) * 256);
+    auto compute = [&](const char* st, auto cs_tag) {
+        constexpr bool CS = decltype(cs_tag)::value;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             f32x4 bh[2], bl[2];
@@ -502,14 +515,16 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_tn(const GemmArgs p, const PGe
                 bh[j] = lds_tr8(st + fb[2 * j] + s * 16384);
                 bl[j] = lds_tr8(st + fb[2 * j + 1] + s * 16384);
             }
+            if constexpr (CS) {
+                const f32x4 ch = lds_tr8(st + fcs_h + s * 16384);
+                const f32x4 cl = lds_tr8(st + fcs_l + s * 16384);
+                accb = mfma_x<true>(cl, ones, accb);
+                accb = mfma_x<true>(ch, ones, accb);
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const f32x4 ah = lds_tr8(st + fa[2 * (i & 1)] + (i >> 1) * 256 + s * 16384);
                 const f32x4 al = lds_tr8(st + fa[2 * (i & 1) + 1] + (i >> 1) * 256 + s * 16384);
-                if (do_colsum && i == wn) {
-                    accb = mfma_x<true>(al, ones, accb);
-                    accb = mfma_x<true>(ah, ones, accb);
-                }
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     f32x16 c = acc[i][j];
@@ -521,22 +536,26 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_tn(const GemmArgs p, const PGe
             }
         }
     };
+    auto k_loop = [&](auto cs_tag) {
+        for (int kt = 0; kt < nkt; ++kt) {
+            char* cur = smem + (kt & 1) * PSTAGE;
+            char* nxt = smem + ((kt + 1) & 1) * PSTAGE;
+            if (kt + 1 < nkt) stage(kt + 1, nxt);
+#if SEGMM_GEMM_SETPRIO
+            __builtin_amdgcn_s_setprio(SEGMM_GEMM_SETPRIO);
+#endif
+            compute(cur, cs_tag);
+#if SEGMM_GEMM_SETPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
+            dma_wait_barrier();
+        }
+    };
 
     stage(0, smem);
     dma_wait_barrier();
-    for (int kt = 0; kt < nkt; ++kt) {
-        char* cur = smem + (kt & 1) * PSTAGE;
-        char* nxt = smem + ((kt + 1) & 1) * PSTAGE;
-        if (kt + 1 < nkt) stage(kt + 1, nxt);
-#if SEGMM_GEMM_SETPRIO
-        __builtin_amdgcn_s_setprio(SEGMM_GEMM_SETPRIO);
-#endif
-        compute(cur);
-#if SEGMM_GEMM_SETPRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
-        dma_wait_barrier();
-    }
+    if (do_colsum) k_loop(std::true_type{});
+    else k_loop(std::false_type{});
 
     const bool split = gridDim.z > 1;
     if (do_colsum && (lane & 31) == 0) {          // every column of accb holds the row sums: lanes 0 and 32 own 16 rows each
