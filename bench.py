@@ -352,6 +352,13 @@ def main():
                                        "second stream); peak = dense MFMA peak of the instruction used"
                                        + {"bf16x6": " / 6 partial products", "f16x3": " / 3 partial products", "f16x3p": " / 3 partial products", "f32": ""}[engine]
                                        + traffic_note}
+            if engine in ("f16x3", "f16x3p"):
+                sus = hipabi.mfma_sustained_tflops()
+                rec["roofline"]["sustained_probe"] = {
+                    "fp16_mfma_tflops": round(sus, 1), "per_product_tflops": round(sus / 3.0, 1), "frac_of_sustained": round(achieved / (sus / 3.0), 4),
+                    "note": "segmm_probe_mfma_rate, run right after the timed region: v_mfma_f32_32x32x16_f16 on RANDOM operand bits, registers only, "
+                            "the GEMM's occupancy and accumulator order; the part's power management holds a random-data MFMA stream below the "
+                            "datasheet peak, so this -- not `peak` -- is the ceiling a real-data GEMM kernel can reach here"}
         if aprof:
             att_w = {"fwd": 4.0, "bwd": 14.0, "bwd1": 0.0, "bwd2": 6.0, "bwd3": 8.0, "bwd4": 10.0}      # fused: S and dP computed once
             att_flops = sum(att_w[k] * dh_ * Lq_ * (La_ + Lb_) * B_ * H_ for (k, B_, H_, dh_, Lq_, La_, Lb_, _, _) in aprof)
@@ -363,6 +370,23 @@ def main():
                                          "unit": "TFLOP/s", "frac": round(att_tf / apeak, 4), "ms_per_step": round(att_ms / psteps, 4),
                                          "note": "unpadded algorithmic FLOPs (4 dh Lq T forward + 10 dh Lq T backward per (b, head)) / union of the "
                                                  "attention launches' HIP-event intervals"}
+            # the same launches against HBM: a head is 69 KB of operands for 5 MFLOP, so the tensors' one-pass bytes bound the kernels too
+            pl = 2.0 if engine == "f16x3p" else 1.0          # outputs written as fp32 + P32 planes
+            att_bytes, ok = 0.0, True
+            for (k, B_, H_, dh_, Lq_, La_, Lb_, _, _) in aprof:
+                eq, ea, eb = 4.0 * B_ * Lq_ * H_ * dh_, 4.0 * B_ * La_ * H_ * dh_, 4.0 * B_ * Lb_ * H_ * dh_
+                if k == "fwd":
+                    att_bytes += 2 * eq + 2 * ea + 2 * eb + pl * eq                  # Qa Qb | Ka Va | Kb Vb -> O
+                elif k == "bwd4":
+                    att_bytes += (2 * eq + 2 * ea + 2 * eb + 2 * 2 * eq) + pl * (2 * eq + 2 * ea + 2 * eb)      # + O, dO per key block -> dQ dK dV
+                else:
+                    ok = False
+            if ok and att_ms > 0:
+                gbs = att_bytes / (att_ms * 1e-3) / 1e9
+                rec["roofline_attention"]["hbm"] = {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+                                                    "algorithmic_bytes_per_step": round(att_bytes / psteps),
+                                                    "note": "one pass over Q, K, V (O, dO per key block in the backward) and over every output "
+                                                            "(fp32 + planes); the tighter of the two bounds at these shapes"}
         gat = [(nb, e0.elapsed_time(e1)) for (name, nb, e0, e1) in kprof if name == "gather_l1"]
         if gat:
             gb = sum(nb for nb, _ in gat) / 1e9

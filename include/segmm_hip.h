@@ -269,6 +269,12 @@ int segmm_gather_l1(const float* table, int64_t n_lines, int D, const int64_t* i
  * that was produced; stats[0] += number of rows whose overflow flag is up. */
 int segmm_scales_update(const float* arena, const int32_t* site_idx, int n_rows, float* site_scale, float* stats, int target,
                         segmm_stream_t stream);
+/* DIAGNOSTIC, not part of the reference path: launches `workgroups` x 512 threads that issue `iters` x 48 v_mfma_f32_32x32x16_f16
+ * per wave on random operand bits (registers only, the plane GEMM's accumulator order and occupancy); *flops_out = the fp16 MFMA
+ * FLOPs of the launch.  bench.py times it to report the SUSTAINED matrix-core rate of the part beside the datasheet peak
+ * (power management clocks a random-data MFMA stream down; constant operands do not show it). */
+int segmm_probe_mfma_rate(int workgroups, int iters, float* scratch, double* flops_out, segmm_stream_t stream);
+
 /* (f)-3 SegRec weighted head (ClipRec.forward, SegRec/models/context/ClipRec.py:163-181): out[r] = sum_seg pred[r, seg] *
  * weight[r, seg] * (seg < duration[r]); weight == null: ones, duration == null: no duration mask. */
 int segmm_segment_weighted_sum(const float* pred, const float* weight, const int64_t* duration, int64_t rows, int S, float* out,

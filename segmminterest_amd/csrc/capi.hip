@@ -180,10 +180,54 @@ __global__ void dropout_mult_kernel(float* out, long long n, DropCfg d) {
     }
 }
 
+
+// Diagnostic (bench.py roofline context): the sustained issue rate of v_mfma_f32_32x32x16_f16 with the GEMM's accumulator
+// pattern, its occupancy (8 waves per CU) and RANDOM operand bits, registers only.  With constant operands the MI355X holds
+// ~2.47 PFLOP/s; with random bits the power management clocks it down (~1.78 PFLOP/s measured) -- the ceiling a real-data GEMM
+// can reach on this part, below the 2.5 PFLOP/s datasheet figure bench.py prices against.
+namespace segmm {
+__global__ __launch_bounds__(512, 2) void mfma_rate_kernel(float* out, int iters, uint32_t seed) {
+    f32x16 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    h8 a[4], b[2];
+    uint32_t h = (threadIdx.x + blockIdx.x * 977u) * 2654435761u + seed;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { h = h * 1664525u + 1013904223u; a[i][r] = (_Float16)(((int)(h >> 16) - 32768) * (1.f / 32768.f)); }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { h = h * 1664525u + 1013904223u; b[i][r] = (_Float16)(((int)(h >> 16) - 32768) * (1.f / 32768.f)); }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i * 2 + j], 0, 0, 0);
+        asm volatile("" ::: "memory");
+    }
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += acc[i][r];
+    if (t == 12345.678f) out[0] = t;          // never true: keeps the accumulators live
+}
+}  // namespace segmm
+
 extern "C" {
 
 const char* segmm_last_error(void) { return g_segmm_err; }
-int segmm_abi_version(void) { return 12; }
+int segmm_abi_version(void) { return 13; }
 
 static PlaneOut plane_out(uint16_t* planes, int ld2, float* hdr, const float* scale_in) {
     PlaneOut po;
@@ -924,5 +968,13 @@ int segmm_debug_attn_trace(unsigned long long* host, int n) {      // debug buil
     return 0;
 }
 #endif
+
+int segmm_probe_mfma_rate(int workgroups, int iters, float* scratch, double* flops_out, segmm_stream_t stream) {
+    SEGMM_REQUIRE(workgroups > 0 && iters > 0 && scratch, "probe_mfma_rate: workgroups/iters > 0 and a scratch float");
+    hipLaunchKernelGGL(mfma_rate_kernel, dim3(workgroups), dim3(512), 0, (hipStream_t)stream, scratch, iters, 12345u);
+    LAUNCH_CHECK();
+    if (flops_out) *flops_out = (double)workgroups * 8.0 * iters * 48.0 * 32768.0;
+    return 0;
+}
 
 }  // extern "C"

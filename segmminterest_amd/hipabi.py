@@ -15,7 +15,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SEGMM_LIB") or os.path.join(_HERE, "libsegmm_hip.so")      # SEGMM_LIB: A/B builds of the kernels
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 _lib = None
 
@@ -32,6 +32,7 @@ SIGNATURES = {
     "segmm_gemm_p": [_i, _i, _i, _i, _p, _i, _p, _p, _i, _p, _i, _p, _p, _i, _p, _i, _p, _i, _p, _p, _i, _p, _p, _p, _i, _i, _i, _p, _i, _f, _u64,
                      _u32, _i, _p, _i, _p, _p],
     "segmm_scales_update": [_p, _p, _i, _p, _p, _i, _p],
+    "segmm_probe_mfma_rate": [_i, _i, _p, _p, _p],
     "segmm_split_p32": [_p, _i64, _i, _i, _p, _i, _p, _i, _p],
     "segmm_split_p32_transpose": [_p, _i, _i, _i, _p, _i, _p, _p],
     "segmm_wsplit_p32": [_p, _p, _i, _i, _p, _p, _p, _p],
@@ -339,6 +340,30 @@ def gemm_p(layout, M, N, K, A: "PT", B: "PT", Cout, ldc, c_pt: "PT" = None, writ
 def scales_update(arena, site_idx, n_rows, site_scale, stats, target=12):
     _check(lib().segmm_scales_update(arena.data_ptr(), site_idx.data_ptr(), int(n_rows), site_scale.data_ptr(), stats.data_ptr(), int(target),
                                      _stream()), "segmm_scales_update")
+
+
+def mfma_sustained_tflops(ms_target=25.0):
+    """Diagnostic: sustained fp16 matrix-core rate (TFLOP/s) of this GPU on random operand bits, registers only
+    (``segmm_probe_mfma_rate``: 256 workgroups x 8 waves, the plane GEMM's accumulator order).  bench.py reports it beside
+    the datasheet peak: the power management clocks a random-data MFMA stream down, so no real-data GEMM can reach the
+    datasheet figure on this part."""
+    import ctypes
+    scratch = torch.zeros(1, dtype=torch.float32, device="cuda")
+    fl = ctypes.c_double(0.0)
+    iters = 4000
+
+    def run(n):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _check(lib().segmm_probe_mfma_rate(256, int(n), scratch.data_ptr(), ctypes.addressof(fl), _stream()), "segmm_probe_mfma_rate")
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1)
+
+    ms = run(iters)                                   # warm-up + calibration
+    iters = max(1000, int(iters * ms_target / max(ms, 1e-3)))
+    ms = run(iters)
+    return fl.value / (ms * 1e-3) * 1e-12
 
 
 def absmax(x, rows, cols, ld, off=0, out=None):
