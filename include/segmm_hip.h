@@ -222,6 +222,11 @@ int segmm_embed_id_bwd(const float* dpre, int tokens_per_row, int ld, int col0, 
                        const int64_t* ids, float* dtable, int B, int64_t n_rows, segmm_stream_t stream);
 int segmm_pe_grad(const float* dpre, int ld, int B, int S, int d, float* dpe, int accumulate, segmm_stream_t stream);
 
+/* The loss scalars of compute_loss (decoder_leave_focal.py:490-572) from the per-row terms segmm_loss_fwd_bwd wrote:
+ * losses[c] = sum_b parts[b][c] for the 12 loss slots and total[0] = sum_c coef[c] * losses[c] (the weighted sum of
+ * :560-571), one launch, fixed summation order. */
+int segmm_loss_finish(const float* parts, int B, const float* coef, float* losses, float* total, segmm_stream_t stream);
+
 /* K8 -- compute_loss forward + backward in one launch (decoder_leave_focal.py:490-572).
  * part order: 0 interestBPR 1 focal 2 surviveCE 3 interestCE 4 interestKL 5 huber 6 hazard 7 mse 8 mse2.
  * coef/enabled are host arrays of 9; parts: [B, 12] (row stride 12, columns 9..11 zero) per-row contributions already divided by the GLOBAL

@@ -227,7 +227,7 @@ __global__ __launch_bounds__(512, 2) void mfma_rate_kernel(float* out, int iters
 extern "C" {
 
 const char* segmm_last_error(void) { return g_segmm_err; }
-int segmm_abi_version(void) { return 13; }
+int segmm_abi_version(void) { return 14; }
 
 static PlaneOut plane_out(uint16_t* planes, int ld2, float* hdr, const float* scale_in) {
     PlaneOut po;
@@ -382,7 +382,7 @@ static int gemm_impl(int layout, int M, int N, int K, const float* A, int lda, c
         int blocks = (int)((n4 + 255) / 256);
         if (blocks > 2048) blocks = 2048;
         hipLaunchKernelGGL(splitk_reduce, dim3(blocks), dim3(256), 0, s, (const float*)workspace, splits,
-                           (long long)M * N, C, ldc, M, N, accumulate);
+                           (long long)M * N, C, ldc, M, N, accumulate, (const float*)nullptr, (float*)nullptr);
         LAUNCH_CHECK();
     }
     return 0;
@@ -504,15 +504,12 @@ int segmm_gemm_p(int layout, int M, int N, int K, const uint16_t* a_planes, int 
     q.colsum_out = colsum_out;
     hipLaunchKernelGGL(gemm_pl_tn<0>, dim3(g.nbm * g.nbn, 1, splits), dim3(512), 0, s, g, q);
     LAUNCH_CHECK();
-    if (splits > 1 && colsum_out) {
-        hipLaunchKernelGGL(colsum_reduce_kernel, dim3((M + 255) / 256), dim3(256), 0, s, (const float*)q.colsum_ws, splits, M, colsum_out, accumulate);
-        LAUNCH_CHECK();
-    }
-    if (splits > 1) {
+    if (splits > 1) {          // one combine launch for the slabs AND the folded column sums
         const long long n4 = (long long)M * (N / 4);
         int blocks = (int)((n4 + 255) / 256);
         if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(splitk_reduce, dim3(blocks), dim3(256), 0, s, (const float*)workspace, splits, (long long)M * N, C, ldc, M, N, accumulate);
+        hipLaunchKernelGGL(splitk_reduce, dim3(blocks), dim3(256), 0, s, (const float*)workspace, splits, (long long)M * N, C, ldc, M, N, accumulate,
+                           (const float*)q.colsum_ws, colsum_out);
         LAUNCH_CHECK();
     }
     return 0;
@@ -534,6 +531,7 @@ int segmm_split_p32(const float* x, int64_t rows, int cols, int ld, uint16_t* pl
 int segmm_wsplit_p32(const float* flat, const void* desc, int n_mats, int n_tiles, float* hdr, uint16_t* wpl, uint16_t* wTpl,
                      segmm_stream_t stream) {
     SEGMM_REQUIRE(flat && desc && hdr && wpl && n_mats > 0 && n_tiles > 0 && aligned16(flat) && aligned16(wpl), "wsplit_p32: arguments");
+    static_assert(AMAX_SLOTS == 64 * 4, "wabsmax: one wave per slot");
     hipLaunchKernelGGL(wabsmax_kernel, dim3(64, n_mats), dim3(256), 0, (hipStream_t)stream, flat, (const WMat*)desc, hdr);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(wsplit_kernel, dim3(n_tiles), dim3(256), 0, (hipStream_t)stream, flat, (const WMat*)desc, n_mats, hdr,
@@ -614,7 +612,7 @@ int segmm_layernorm_fwd(const float* x, const float* gamma, const float* beta, f
 
 int segmm_layernorm_bwd_parts(int64_t rows) {
     int64_t b = (rows + 3) / 4;
-    if (b > 2048) b = 2048;
+    if (b > 1024) b = 1024;          // ~3 workgroups per CU are resident (130 VGPR at d = 768): more parts only grow the partial buffers
     if (b < 1) b = 1;
     return (int)b;
 }
@@ -824,6 +822,13 @@ int segmm_label_stats(const int64_t* gt, int B, int S, int rewritten, float* v, 
                       segmm_stream_t stream) {
     SEGMM_REQUIRE(gt && v && v2 && norms && B > 0 && S > 0, "label_stats: bad args");
     hipLaunchKernelGGL(label_stats_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const long long*)gt, B, S, rewritten, v, v2, norms);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int segmm_loss_finish(const float* parts, int B, const float* coef, float* losses, float* total, segmm_stream_t stream) {
+    SEGMM_REQUIRE(parts && coef && losses && total && B > 0, "loss_finish: arguments");
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, parts, B, coef, losses, total);
     LAUNCH_CHECK();
     return 0;
 }

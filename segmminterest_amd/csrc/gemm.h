@@ -225,8 +225,16 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmArgs p) {
 }
 
 // C[m,n] (+)= sum_z slabs[z][m,n]   (deterministic split-K combine)
+// cs_out != null: also cs_out[m] (+)= sum_z cs_ws[z][m], the split-K combine of the column sums folded into the plane TN GEMM
 __global__ __launch_bounds__(256) void splitk_reduce(const float* __restrict__ slabs, int splits, long long slab_stride, float* C, int ldc,
-                              int M, int N, int accumulate) {
+                              int M, int N, int accumulate, const float* __restrict__ cs_ws, float* cs_out) {
+    if (cs_out) {
+        for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < M; m += gridDim.x * blockDim.x) {
+            float s = 0.f;
+            for (int z = 0; z < splits; ++z) s += cs_ws[(size_t)z * M + m];
+            cs_out[m] = accumulate ? cs_out[m] + s : s;
+        }
+    }
     const int n4 = N >> 2;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < (long long)M * n4;
          i += (long long)gridDim.x * blockDim.x) {

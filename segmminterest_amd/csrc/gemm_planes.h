@@ -586,15 +586,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_tn(const GemmArgs p, const PGe
     }
 }
 
-// out[m] (+)= sum_z ws[z][m]   (split-K combine of the folded column sums)
-__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ ws, int splits, int M, float* out, int accumulate) {
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= M) return;
-    float s = 0.f;
-    for (int z = 0; z < splits; ++z) s += ws[(size_t)z * M + m];
-    out[m] = accumulate ? out[m] + s : s;
-}
-
 // =============================================================================== fp32 -> P32 planes (stand-alone pass)
 // mode 0: the site's partial maxima are complete (producer or segmm_absmax): s = exact scale, written to hdr[0], flag cleared.
 // mode 1: s = hdr[0] as it stands (delayed scale); partial maxima and the overflow flag are folded into hdr.
@@ -648,7 +639,7 @@ __global__ __launch_bounds__(256) void split_p32_transpose_kernel(const float* _
 
 // ---------------------------------------------------------------- all weight matrices of a model in TWO launches per step
 // desc[i] = {flat offset of matrix i (floats), rows R, cols C, needs transpose, first 32 x 32 tile index, tile columns}
-// (tiles cover [ceil(R/32)][C/32]); hdr = [n][SITE_FLOATS] site headers (zeroed by the caller).
+// (tiles cover [ceil(R/32)][C/32]); hdr = [n][SITE_FLOATS] site headers (zeroed once at allocation; wabsmax rewrites all slots).
 struct WMat { long long off; int R, Cc, tr, tile0, tcols; };
 __global__ __launch_bounds__(256) void wabsmax_kernel(const float* __restrict__ flat, const WMat* __restrict__ desc, float* hdr) {
     const WMat m = desc[blockIdx.y];
@@ -657,7 +648,10 @@ __global__ __launch_bounds__(256) void wabsmax_kernel(const float* __restrict__ 
     float am = 0.f;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x)
         am = absmax4(am, *(const f32x4*)(x + 4 * i));
-    amax_commit(hdr + (size_t)blockIdx.y * SITE_FLOATS + SITE_HDR, am, blockIdx.x * 4 + (threadIdx.x >> 6));
+    // the launch is (64 workgroups x 4 waves) per matrix = exactly AMAX_SLOTS waves: every slot has ONE writer, so a plain
+    // store replaces the atomic max and the header needs no zero-fill between optimizer steps
+    am = wave_max(am);
+    if ((threadIdx.x & 63) == 0) hdr[(size_t)blockIdx.y * SITE_FLOATS + SITE_HDR + blockIdx.x * 4 + (threadIdx.x >> 6)] = am;
 }
 // one 32 x 32 tile per workgroup: P32 planes of W (wpl, at element offset 2 * off, ld2 = 2 C) and -- if asked -- of W^T
 // (wTpl, same offset, ld2 = 2 R), both with the exact scale of the matrix' own maxima, which is also stored in its header

@@ -225,4 +225,29 @@ __global__ __launch_bounds__(1024) void label_stats_kernel(const long long* __re
     }
 }
 
+// losses[c] = sum_b parts[b][c] (c < 12) and total[0] = sum_c coef[c] * losses[c], one workgroup, fixed summation order:
+// replaces a column-sum launch pair + a dot-product launch between the loss kernel and the backward.
+__global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restrict__ parts, int B, const float* __restrict__ coef,
+                                                          float* __restrict__ losses, float* __restrict__ total) {
+    __shared__ float red[16][16];
+    const int c = threadIdx.x & 15, r0 = threadIdx.x >> 4;
+    float a = 0.f;
+    if (c < 12)
+        for (int r = r0; r < B; r += 16) a += parts[(size_t)r * 12 + c];
+    red[r0][c] = a;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        float s = 0.f;
+        for (int r = 0; r < 16; ++r) s += red[r][threadIdx.x];
+        red[0][threadIdx.x] = threadIdx.x < 12 ? s : 0.f;
+        if (threadIdx.x < 12) losses[threadIdx.x] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int i = 0; i < 12; ++i) t += coef[i] * red[0][i];
+        total[0] = t;
+    }
+}
+
 }  // namespace segmm

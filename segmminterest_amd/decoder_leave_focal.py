@@ -81,6 +81,7 @@ class HeadLossFn(torch.autograd.Function):
         T = model._head_fwd(v1c, v2c, raw, M, d)
         ctx.model, ctx.dims, ctx.T = model, (B, S, d), T
         ctx.has_v2 = v2 is not None
+        ctx.set_materialize_grads(False)          # no zero tensors for the two non-differentiable outputs (two fill launches)
         ctx.save_for_backward(v1c, v2c if v2c is not None else v1c)
         if not want_loss:
             logits = raw.view(B, S)
@@ -105,10 +106,8 @@ class HeadLossFn(torch.autograd.Function):
         H.loss_fwd_bwd(B, S, raw, gt, bw, bb, expo, spec.coef, spec.enabled, spec.rew_ce, spec.rew_kl, spec.use_mask, norms,
                        v_all, v2_all, v_all.numel(), logits, dlogits, parts)
         losses = torch.empty(12, device=raw.device)
-        E._colsum(st, parts, 12, B, 12, losses)
-        total = torch.empty(1, device=raw.device)
-        H.rowdot(losses, 12, model._coef_tensor(raw.device), None, total, 1, 12)      # sum_i coef_i * loss_i in one launch
-        total = total.view(())
+        total = torch.empty((), device=raw.device)
+        H.loss_finish(parts, B, model._coef_tensor(raw.device), losses, total)      # sum_b parts and sum_i coef_i * loss_i, one launch
         ctx.dlogits = dlogits
         ctx.mark_non_differentiable(losses, logits)
         return total, losses, logits
@@ -123,8 +122,14 @@ class HeadLossFn(torch.autograd.Function):
         if not ctx.has_v2:
             v2 = None
         names = model._head_param_names()
+        if g_total is None:          # the loss took no part in the differentiated scalar
+            return (None,) * (5 + len(names))
         gbuf = E._pick_gbuf(st, names)
-        dl = (ctx.dlogits * g_total).view(M)
+        unit = getattr(model, "_unit_grad", None)
+        if unit is not None and g_total.data_ptr() == unit.data_ptr():
+            dl = ctx.dlogits.view(M)          # d loss / d loss == 1: the trainer's constant-one seed (Trainer.train_step)
+        else:
+            dl = (ctx.dlogits * g_total).view(M)
         dv1 = torch.empty(M, d, device=v1.device)
         dv2 = torch.empty(M, d, device=v1.device) if v2 is not None else None
         model._head_bwd(v1, v2, dl, dv1, dv2, ctx.T, M, d, B, S, gbuf)
@@ -227,6 +232,13 @@ class MultiScaleTemporalDetrLeaveFocal(nn.Module):
             if len(e) < S:
                 raise RuntimeError("exposure_prob has %d entries, S=%d" % (len(e), S))
             t = self._consts[k] = torch.tensor(e, dtype=torch.float32, device=dev)
+        return t
+
+    def unit_grad(self, dev):
+        """The constant 1.0 the trainer seeds ``backward`` with; never written after creation."""
+        t = getattr(self, "_unit_grad", None)
+        if t is None or t.device != torch.device(dev):
+            t = self._unit_grad = torch.ones((), dtype=torch.float32, device=dev)
         return t
 
     def _coef_tensor(self, dev):

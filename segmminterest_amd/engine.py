@@ -200,6 +200,29 @@ class ParamStore:
                 raise RuntimeError("more than %d tensor sites" % self.MAX_SITES)
         return i
 
+    # ---- site-header ring.  A header ([SITE_FLOATS]: scale, flag, AMAX_SLOTS partial maxima) must be ZERO when its producer
+    # starts folding maxima into it, and is read until the last GEMM that consumes the tensor has run (the backward reads the
+    # forward's).  Instead of one torch.zeros per pass (three fill launches per step), rows are handed out sequentially from a
+    # ring that is zeroed a quarter at a time, when the cursor enters the quarter: the rows cleared then were handed out
+    # >= 3/4 ring (dozens of steps) earlier.  One 2 MB fill every ~10-20 steps instead of 3-4 small ones per step.
+    HDR_RING_ROWS = 8192
+
+    def hdr_rows(self, n: int) -> torch.Tensor:
+        dev = self.flat.device
+        q = self.HDR_RING_ROWS // 4
+        if n > q:
+            return torch.zeros((n, H.SITE_FLOATS), dtype=torch.float32, device=dev)
+        ring = getattr(self, "_hdr_ring", None)
+        if ring is None or ring.device != dev:
+            ring = self._hdr_ring = torch.zeros((self.HDR_RING_ROWS, H.SITE_FLOATS), dtype=torch.float32, device=dev)
+            self._hdr_q, self._hdr_off = 0, 0
+        if self._hdr_off + n > q:          # the rest of this quarter is too small: enter the next one, clearing it first
+            self._hdr_q, self._hdr_off = (self._hdr_q + 1) % 4, 0
+            ring[self._hdr_q * q:(self._hdr_q + 1) * q].zero_()
+        r0 = self._hdr_q * q + self._hdr_off
+        self._hdr_off += n
+        return ring[r0:r0 + n]
+
     def scales(self) -> torch.Tensor:
         if self.site_scale is None or self.site_scale.device != self.flat.device:
             self.site_scale = torch.zeros((self.MAX_SITES + 8,), dtype=torch.float32, device=self.flat.device)
@@ -323,9 +346,7 @@ class ParamStore:
                 tile0 += ((R + 31) // 32) * tcols
             self._wdesc = torch.frombuffer(bytearray(recs), dtype=torch.uint8).to(dev) if mats else None
             self._wtiles = tile0
-        else:
-            self.whdr.zero_()
-        if mats:
+        if mats:          # (no zero-fill: wabsmax rewrites every slot of every header)
             H.wsplit_p32(self.flat, self._wdesc, len(mats), self._wtiles, self.whdr, self.wpl, self.wTpl)
 
     def _build(self, params):
@@ -560,7 +581,7 @@ class AmaxArena:
     on the other engines, which turns every amax argument into a no-op."""
 
     def __init__(self, store, n):
-        self.t = torch.zeros((n, H.SITE_FLOATS), dtype=torch.float32, device=store.flat.device) if store.engine_h else None
+        self.t = store.hdr_rows(n) if store.engine_h else None          # clean rows of the store's header ring
         self.i = 0
         self.sites: List[Optional[str]] = []
 

@@ -15,7 +15,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SEGMM_LIB") or os.path.join(_HERE, "libsegmm_hip.so")      # SEGMM_LIB: A/B builds of the kernels
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 _lib = None
 
@@ -33,6 +33,7 @@ SIGNATURES = {
                      _u32, _i, _p, _i, _p, _p],
     "segmm_scales_update": [_p, _p, _i, _p, _p, _i, _p],
     "segmm_probe_mfma_rate": [_i, _i, _p, _p, _p],
+    "segmm_loss_finish": [_p, _i, _p, _p, _p, _p],
     "segmm_split_p32": [_p, _i64, _i, _i, _p, _i, _p, _i, _p],
     "segmm_split_p32_transpose": [_p, _i, _i, _i, _p, _i, _p, _p],
     "segmm_wsplit_p32": [_p, _p, _i, _i, _p, _p, _p, _p],
@@ -479,6 +480,11 @@ def attn_bwd(B, H, dh, Lq, La, Lb, Qa, Qb, ldq, Ka, Va, ldka, Kb, Vb, ldkb, mq, 
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
         prof.append(("bwd" if phase == 0 else "bwd%d" % phase, B, H, dh, Lq, La, Lb, e0, e1))
+
+
+def loss_finish(parts, B, coef, losses, total):
+    """losses[12] = column sums of parts[B, 12]; total[0] = coef . losses (one launch)."""
+    _check(lib().segmm_loss_finish(_ptr(parts), int(B), _ptr(coef), _ptr(losses), _ptr(total), _stream()), "segmm_loss_finish")
 
 
 def rowdot(x, ld, w, bias, out, rows, d, accumulate=False, x_off=0, w_off=0):

@@ -346,11 +346,8 @@ class Trainer:
         if not st.engine_h:
             return None
         dev = buf.device
-        if self._norm_amax is None or self._norm_amax.device != dev:
-            self._norm_amax = torch.zeros((2, H.SITE_FLOATS), dtype=torch.float32, device=dev)
-            self._norm_fresh = True
         if not self._norm_fresh:
-            self._norm_amax.zero_()          # one fill per step, before the first input of the step is produced
+            self._norm_amax = st.hdr_rows(2)          # two clean site headers per step from the store's ring (no fill launch)
             self._norm_fresh = True
         cols = buf.shape[-1]
         rows = buf.numel() // cols
@@ -428,7 +425,9 @@ class Trainer:
         out = model(usr_image=usr, usr_id=usr_id, usr_mask=um, vid_image=vid,
                     vid_id=batch["photo_identity_id"], vid_mask=vm, gt=batch["label"], mode="train")
         self._bucket_works = []
-        out["loss"].backward()
+        # seed the backward with the model's own constant-one tensor: the head recognises it (same storage) and skips both the
+        # ones_like fill autograd would launch and the dlogits * 1 multiply
+        torch.autograd.backward(out["loss"], grad_tensors=[model.unit_grad(out["loss"].device)])
         if self.comm.world > 1 and self.overlap and self.per_bucket_adamw and self._covers_live(st):
             # AdamW per bucket, in completion order: each launch waits (stream-level) only for its own bucket's all-reduce, so
             # the optimizer of the early buckets runs under the collectives of the late ones and only the last, small bucket
