@@ -25,7 +25,12 @@ Prints ONE JSON line (rank 0) with the driver contract fields plus
                   instrumented pass of the same steps, vs the peak of the instruction used (MI355X_MICROARCH.md)
   cpu_baseline -- the CPU oracle's train step (what the reference executes, dead layers and dropout included) timed on this
                   box's host cores on a bounded sample of the same workload (3 warm-up + 10 timed steps, median).
+                  roofline.sustained_probe: the fp16 matrix-core rate this GPU sustains on random operand bits, registers only
+                  (segmm_probe_mfma_rate) -- the power-limited ceiling a real-data GEMM can reach, below the datasheet `peak`.
+                  roofline_attention carries both views of the attention kernels (fp32 MFMA and HBM).
   value_f32_engine / ms_per_step_f32_engine (N = 1) -- the same step on the exact-fp32 MFMA engine, same run.
+  host_fed (N = 1) -- the same step with the feature tensors copied from pinned host memory every step (what the reference's
+                  loop does); PCIe-inclusive, reported beside `value`, never as `value`.
 """
 import argparse
 import json
@@ -69,6 +74,8 @@ def parse_args():
     ap.add_argument("--n-users", type=int, default=1903)
     ap.add_argument("--batches", type=int, default=8, help="distinct synthetic batches rotated through the steps")
     ap.add_argument("--input", choices=("features", "index"), default="features")
+    ap.add_argument("--no-host-fed", action="store_true", help="skip the host-fed (PCIe-inclusive) leg")
+    ap.add_argument("--no-probe", action="store_true", help="skip the sustained-MFMA probe (roofline.sustained_probe)")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
                     help="gloo: CPU-staged collectives, lets several ranks share one GPU (CI rehearsal of the N > 1 path)")
     ap.add_argument("--no-overlap", action="store_true")
@@ -352,7 +359,7 @@ def main():
                                        "second stream); peak = dense MFMA peak of the instruction used"
                                        + {"bf16x6": " / 6 partial products", "f16x3": " / 3 partial products", "f16x3p": " / 3 partial products", "f32": ""}[engine]
                                        + traffic_note}
-            if engine in ("f16x3", "f16x3p"):
+            if engine in ("f16x3", "f16x3p") and not args.no_probe:
                 sus = hipabi.mfma_sustained_tflops()
                 rec["roofline"]["sustained_probe"] = {
                     "fp16_mfma_tflops": round(sus, 1), "per_product_tflops": round(sus / 3.0, 1), "frac_of_sustained": round(achieved / (sus / 3.0), 4),
@@ -395,6 +402,53 @@ def main():
                                       "achieved": round(gb / (gms * 1e-3), 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                       "frac": round(gb / (gms * 1e-3) / PEAK_HBM_GBS, 4), "ms_per_step": round(gms / psteps, 4),
                                       "note": "algorithmic bytes = 2 x 4 B per gathered feature element (read + write) + indices"}
+
+    # ---- the same steps fed from HOST memory (N = 1, feature input): what the reference's loop does every step
+    # (main...SegMM.py:271: batch[k].to(device)).  Pinned host batches, a copy stream one batch ahead, two device buffers.
+    # PCIe-inclusive, so it is reported beside `value`, never as `value`.
+    if world == 1 and not args.no_host_fed and not w["id_mode"] and args.input == "features":
+        fkeys = ("user", "photo")
+        host = [{k: batches[i][k].cpu().pin_memory() for k in fkeys} for i in range(min(len(batches), 4))]
+        dbuf = [{k: torch.empty_like(batches[0][k]) for k in fkeys} for _ in range(2)]
+        cstream = torch.cuda.Stream()
+        ready = [torch.cuda.Event(), torch.cuda.Event()]
+        consumed = [torch.cuda.Event(), torch.cuda.Event()]
+
+        def stage(i):
+            j = i & 1
+            with torch.cuda.stream(cstream):
+                cstream.wait_event(consumed[j])          # the step that read this buffer has been enqueued and finished
+                for k in fkeys:
+                    dbuf[j][k].copy_(host[i % len(host)][k], non_blocking=True)
+                ready[j].record(cstream)
+
+        def run_host(n):
+            for j in (0, 1):
+                consumed[j].record()
+            stage(0)
+            for i in range(n):
+                if i + 1 < n:
+                    stage(i + 1)
+                j = i & 1
+                torch.cuda.current_stream().wait_event(ready[j])
+                b = dict(batches[i % len(batches)])
+                b.update(dbuf[j])
+                trainer.train_step(b)
+                consumed[j].record()
+
+        hsteps = min(args.steps, 10)
+        run_host(2)
+        barrier()
+        th0 = time.perf_counter()
+        run_host(hsteps)
+        barrier()
+        th = time.perf_counter() - th0
+        nbytes = sum(host[0][k].numel() * 4 for k in fkeys)
+        if rec is not None:
+            rec["host_fed"] = {"value": round(B * hsteps / th, 2), "unit": "interactions/s", "ms_per_step": round(1e3 * th / hsteps, 4),
+                               "h2d_bytes_per_step": nbytes, "h2d_GBs": round(nbytes * hsteps / th / 1e9, 1),
+                               "note": "same step with the two feature tensors copied from pinned host memory every step (copy stream one "
+                                       "batch ahead); PCIe-inclusive, NOT `value` -- the product path keeps features resident (--input index)"}
 
     # ---- the same step on the exact-fp32 MFMA engine, same run (N = 1): the strict-fp32 number next to the headline
     if world == 1 and not args.no_f32_engine and not w["id_mode"] and engine != "f32":

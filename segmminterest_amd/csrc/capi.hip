@@ -635,7 +635,7 @@ int segmm_layernorm_bwd(const float* dy, const float* x, const float* mean, cons
 }
 
 int segmm_colsum_chunks(int64_t M) {
-    int64_t c = (M + 63) / 64;          // >= 64 rows per chunk; up to 256 chunks so that a 768-column sum still fills the chip
+    int64_t c = (M + 15) / 16;          // >= 16 rows per chunk; up to 256 chunks so that a 768-column sum still fills the chip
     if (c > 256) c = 256;
     if (c < 1) c = 1;
     return (int)c;

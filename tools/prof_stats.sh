@@ -4,13 +4,13 @@ TAG=${1:-r2}; shift
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-f32-engine "$@" > $R/gpurun_out/prof_bench_$TAG.log 2>&1
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-f32-engine --no-host-fed --no-probe "$@" > $R/gpurun_out/prof_bench_$TAG.log 2>&1
 cd $R
 F=$(find gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1)
 cp "$F" gpurun_out/prof_${TAG}_kernel_stats.csv
 python3 - "$F" <<'PY'
 import csv, sys
-rows = list(csv.DictReader(open(sys.argv[1])))
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "mfma_rate_kernel" not in r["Name"]]
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 print("%-110s %8s %10s %10s %6s" % ("kernel", "calls", "total_us", "avg_us", "%"))
 for r in rows[:45]:

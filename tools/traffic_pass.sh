@@ -9,7 +9,7 @@ OUT=$R/gpurun_out/traffic_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 400 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-f32-engine > $OUT/$C.log 2>&1 || exit 1
+  timeout -k 10 400 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-f32-engine --no-host-fed --no-probe > $OUT/$C.log 2>&1 || exit 1
 done
 cd $R
 GIT=${GIT_SHA:-unknown}
