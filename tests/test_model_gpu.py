@@ -454,6 +454,60 @@ def _check_live_grads(model, rgrads):
     return errs
 
 
+def test_config3_full_item_table_matches_oracle():
+    """BASELINE config 3 (main_for_seq_leave_earlystop_KuaiRand.py:259-261; encoder.py:426-435) with the FULL item table
+    (352 494 rows) and user table: id/id inputs, S = 20, d = 512, h = 16, N = 4, on a 256-row subset of the 1024-row batch
+    (the oracle's dense 352 k x 256 table gradient and four 512-wide layers stay at a few seconds of CPU).  Logits, loss,
+    every live gradient -- the item-table gradient compared on ALL rows: touched rows against the oracle's, untouched rows
+    exactly zero -- and the parameters after one fused AdamW step (the dense update that bounds the config: every row decays)."""
+    import segmm_oracle as O
+    from segmminterest_amd.synth import make_batch
+    from segmminterest_amd.trainer import FusedAdamW, default_args, init_model
+    S, d, N, h, B, n_users, n_items = 20, 512, 4, 16, 256, 30000, 352494
+    args = default_args(num_layers_enc=N, d_model=d, nhead=h, input_type={"user": "id", "photo": "id"}, exposure_prob=[1.0] * S)
+    torch.manual_seed(5)
+    model = init_model(args, n_users=n_users, n_items=n_items, input_dim=d, max_vid_len=S, max_usr_len=1)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    b = make_batch(B, S, 1, d, n_users=n_users, n_items=n_items, seed=77, features=False)
+    inp = dict(usr_image=None, usr_id=b["user_identity_id"], usr_mask=b["user_mask"], vid_image=None, vid_id=b["photo_identity_id"],
+               vid_mask=b["photo_mask"], gt=b["label"])
+    cfg = dict(N=N, h=h, S=S, user="id", photo="id", loss_type_list=["interestBPR"], loss_weight=args.loss_weight, exposure_prob=[1.0] * S)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    ref, rgrads = O.forward_backward(sd, cfg, inp)
+    model = model.cuda().eval()
+    kw = {k: (v.cuda() if v is not None else None) for k, v in inp.items()}
+    out = model(usr_image=None, usr_id=kw["usr_id"], usr_mask=kw["usr_mask"], vid_image=None, vid_id=kw["vid_id"], vid_mask=kw["vid_mask"],
+                gt=kw["gt"].clone(), mode="train")
+    assert (out["logits"].cpu() - ref["logits"].detach()).abs().max().item() < 1e-4
+    assert abs(float(out["loss"]) - float(ref["loss"])) < 1e-5 * max(1.0, abs(float(ref["loss"])))
+    opt = FusedAdamW(model, lr=1e-3, weight_decay=1e-4)
+    opt.zero_grad()
+    out["loss"].backward()
+    _check_live_grads(model, rgrads)
+    tabs = [k for k, p in model.named_parameters() if p.dim() == 2 and p.shape[0] == n_items + 1 and rgrads[k] is not None]
+    assert tabs, "no live item table"
+    for k in tabs:
+        g = dict(model.named_parameters())[k].grad.cpu()
+        touched = torch.zeros(n_items + 1, dtype=torch.bool)
+        touched[b["photo_identity_id"].reshape(-1)] = True
+        assert float(g[~touched].abs().max()) == 0.0 and float(rgrads[k][~touched].abs().max()) == 0.0, k
+        assert int(touched.sum()) > 100
+    # one dense AdamW step over the whole table == torch.optim.AdamW on the oracle's gradients
+    opt.step()
+    ref_p = {k: torch.nn.Parameter(v.clone()) for k, v in sd.items() if rgrads.get(k) is not None}
+    for k, p in ref_p.items():
+        p.grad = rgrads[k].clone()
+    torch.optim.AdamW(list(ref_p.values()), lr=1e-3, weight_decay=1e-4).step()
+    for k in tabs:
+        got = dict(model.named_parameters())[k].detach().cpu()
+        gabs = rgrads[k].abs()
+        solid = gabs > max(1e-5, 2e-3 * float(gabs.max()))
+        err = (got - ref_p[k].detach()).abs()
+        assert float(err[gabs == 0].max()) < 1e-9, "untouched rows: pure weight decay"
+        assert float(err[solid].max()) < 3e-5, float(err[solid].max())
+        assert float(err.max()) < 2.2e-3
+
+
 def test_full_size_gradients_match_oracle():
     """BASELINE config 2 at FULL size (B = 512, S = 40, Lt = 100, D = 768, N = 2): loss and EVERY live gradient of the
     eval-mode training forward/backward against the CPU oracle on the whole batch (the loss normalisers couple the rows, so
