@@ -140,6 +140,39 @@ def test_gemm_dropout_epilogue_matches_mask_hook():
     assert not torch.equal(mult, mult2)
 
 
+def test_dropout_hash_rate_and_independence():
+    """The stateless (seed, site, element) hash behind every dropout mask (common.h): keep rate within 4 sigma of the binomial
+    for several p, and no structure a counter hash could leak -- masks of neighbouring elements, of elements one row (768)
+    apart, of the same element under consecutive sites and under consecutive seeds are uncorrelated (|r| < 4 / sqrt(n)),
+    and the byte-level population count of packed masks matches the binomial variance (no clumping)."""
+    H = _abi()
+    n = 1 << 22
+    lim = 4.0 / n ** 0.5
+
+    def mask(p, seed, site):
+        m = torch.empty(n, device=DEV)
+        H.dropout_mult(m, n, p, seed, site)
+        return (m > 0).double()
+
+    def corr(a, b):
+        a, b = a - a.mean(), b - b.mean()
+        return float((a * b).mean() / (a.std() * b.std() + 1e-30))
+
+    for p in (0.1, 0.25, 0.5):
+        k = mask(p, 1234, 7)
+        sigma = (p * (1 - p) / n) ** 0.5
+        assert abs(float(k.mean()) - (1 - p)) < 4 * sigma + 1.0 / 65536, (p, float(k.mean()))      # p is quantised to 1/65536
+        assert abs(corr(k[:-1], k[1:])) < lim, ("neighbours", p)
+        assert abs(corr(k[:-4], k[4:])) < lim, ("next hash group", p)
+        assert abs(corr(k[:-768], k[768:])) < lim, ("row stride", p)
+        assert abs(corr(k, mask(p, 1234, 8))) < lim, ("consecutive sites", p)
+        assert abs(corr(k, mask(p, 1235, 7))) < lim, ("consecutive seeds", p)
+        # population count of 64-element blocks: variance of a binomial(64, 1-p), within 2 %
+        blocks = k.view(-1, 64).sum(1)
+        var, ref = float(blocks.var()), 64 * p * (1 - p)
+        assert abs(var - ref) < 0.02 * ref, (p, var, ref)
+
+
 def test_gemm_rejects_bad_shapes():
     H = _abi()
     A = torch.zeros(8, 6, device=DEV)

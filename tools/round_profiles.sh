@@ -5,13 +5,13 @@ O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
 python bench.py --steps 20 --warmup 5 > $O/bench_n1.json 2> $O/bench_n1.err
-SEGMM_GEMM=f16x3 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-f32-engine > $O/bench_n1_f16x3_onthefly.json 2>/dev/null
-SEGMM_SCALING=exact python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-f32-engine > $O/bench_n1_exact_scaling.json 2>/dev/null
+SEGMM_GEMM=f16x3 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-f32-engine --no-host-fed --no-probe > $O/bench_n1_f16x3_onthefly.json 2>/dev/null
+SEGMM_SCALING=exact python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-f32-engine --no-host-fed --no-probe > $O/bench_n1_exact_scaling.json 2>/dev/null
 python bench.py --config 3 --steps 20 --warmup 5 > $O/bench_cfg3.json 2>/dev/null
-python bench.py --config 5 --steps 20 --warmup 5 --no-cpu-baseline --no-f32-engine > $O/bench_cfg5.json 2>/dev/null
-python bench.py --config 4 --gpus 1 --global-batch 256 --steps 20 --warmup 5 --no-cpu-baseline --no-f32-engine > $O/bench_cfg4_256rows.json 2>/dev/null
-python bench.py --input index --steps 20 --warmup 5 --no-cpu-baseline --no-f32-engine > $O/bench_index_input.json 2>/dev/null
-python bench.py --gpus 2 --backend gloo --steps 6 --warmup 2 --no-cpu-baseline > $O/bench_gloo2_one_gpu.json 2>/dev/null
+python bench.py --config 5 --steps 20 --warmup 5 --no-cpu-baseline --no-f32-engine --no-host-fed --no-probe > $O/bench_cfg5.json 2>/dev/null
+python bench.py --config 4 --gpus 1 --global-batch 256 --steps 20 --warmup 5 --no-cpu-baseline --no-f32-engine --no-host-fed --no-probe > $O/bench_cfg4_256rows.json 2>/dev/null
+python bench.py --input index --steps 20 --warmup 5 --no-cpu-baseline --no-f32-engine --no-host-fed --no-probe > $O/bench_index_input.json 2>/dev/null
+python bench.py --gpus 2 --backend gloo --steps 6 --warmup 2 --no-cpu-baseline --no-probe > $O/bench_gloo2_one_gpu.json 2>/dev/null
 bash tools/prof_stats.sh ${TAG}_cfg2 > $O/prof_cfg2_summary.txt 2>&1
 cp gpurun_out/prof_${TAG}_cfg2_kernel_stats.csv $O/bench_cfg2_kernel_stats.csv
 python tools/timeline.py gpurun_out/prof_${TAG}_cfg2 --full > $O/step_timeline_cfg2.txt 2>&1
@@ -21,5 +21,7 @@ bash tools/traffic_pass.sh $TAG > $O/traffic.log 2>&1
 cp gpurun_out/traffic_$TAG/hbm_traffic.json $O/hbm_traffic.json; cp gpurun_out/traffic_$TAG/summary.csv $O/hbm_traffic_by_kernel.csv
 bash tools/pmc_run.sh ${TAG}_pmc_nt gemm_pl tools/gemm_p_one.py nt 20480 3072 768 > /dev/null 2>&1; cp gpurun_out/${TAG}_pmc_nt/summary.csv $O/gemm_pl_nt_20480x3072x768_pmc.csv
 bash tools/pmc_run.sh ${TAG}_pmc_tn gemm_pl tools/gemm_p_one.py tn 3072 768 20480 > /dev/null 2>&1; cp gpurun_out/${TAG}_pmc_tn/summary.csv $O/gemm_pl_tn_3072x768x20480_pmc.csv
+bash tools/pmc_run.sh ${TAG}_pmc_attn attn_ tools/attn_bench.py 3 > /dev/null 2>&1; grep -v "dq_kernel\|dkv_kernel\|D_kernel" gpurun_out/${TAG}_pmc_attn/summary.csv > $O/attention_pmc.csv
+./build/probe/mfma_rate > $O/mfma_rate_probe.txt 2>&1
 python tools/gemm_p_check.py > $O/gemm_p_standalone.txt 2>&1
 ls -la $O
