@@ -162,6 +162,10 @@ class DPComm:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        # every collective of the step is issued iff ``active``: more than one rank -- or SEGMM_DP_FORCE=1 with an initialised
+        # process group of ONE rank, which sends the single-GPU step through the real RCCL calls (tests/test_dp_gpu.py: the
+        # only way to execute the nccl code path on a one-GPU box; results must equal the plain step bit for bit)
+        self.active = self.world > 1 or (dist.is_initialized() and os.environ.get("SEGMM_DP_FORCE", "0") == "1")
         self.pending = []
         # gloo has no device collectives for every op: device tensors are staged through the host.
         # Only the test harness uses that (two ranks sharing one GPU); production is nccl = RCCL.
@@ -178,7 +182,7 @@ class DPComm:
     def global_label_stats(self, v, v2, norms):
         """(v_all, v2_all, norms_global): all-gather the per-row view lengths, sum the 3 normalisers.  Returns the triple
         (single process) or a closure that waits for the asynchronous collective and returns it."""
-        if self.world == 1:
+        if not self.active:
             return v, v2, norms
         # ONE collective: [v | v2 | norms] of every rank (every rank holds the same B_local); the three normalisers are
         # summed locally from the gathered copies, in rank order on every rank (identical results everywhere)
@@ -206,7 +210,7 @@ class DPComm:
     def gather_rows(self, ids, rows):
         """(ids of all ranks [G*B], rows of all ranks [G*B, w]) in rank order: the sparse exchange of id-table gradients
         (every rank holds the same B, like :meth:`global_label_stats`)."""
-        if self.world == 1:
+        if not self.active:
             return ids, rows
         ids, rows = ids.contiguous(), rows.contiguous()
         if self.host_staged and rows.is_cuda:
@@ -223,7 +227,7 @@ class DPComm:
 
     def gather_ints(self, t):
         """[G*B] int32: the values of every rank in rank order (validation: leave ranks of the global batch)."""
-        if self.world == 1:
+        if not self.active:
             return t
         t = t.contiguous()
         if self.host_staged and t.is_cuda:
@@ -237,7 +241,7 @@ class DPComm:
     def reduce_bucket(self, flat_grad, start, end):
         """Asynchronous SUM all-reduce of one contiguous gradient bucket (gradients are already
         normalised by global counts, so SUM -- not mean -- reproduces the single-process gradient)."""
-        if self.world == 1 or end <= start:
+        if not self.active or end <= start:
             return
         w = self._all_reduce(flat_grad[start:end], async_op=True)
         if w is not None:
@@ -254,7 +258,7 @@ class DPComm:
             w.wait()
 
     def sum_scalar(self, t):
-        if self.world > 1:
+        if self.active:
             self._all_reduce(t)
         return t
 
@@ -284,11 +288,11 @@ class Trainer:
         self.comm = comm if comm is not None else DPComm()
         self.overlap = overlap
         st = model._store
-        model._dp_hook = self.comm.global_label_stats if self.comm.world > 1 else None
-        st.bucket_hook = self._on_bucket if self.comm.world > 1 else None
+        model._dp_hook = self.comm.global_label_stats if self.comm.active else None
+        st.bucket_hook = self._on_bucket if self.comm.active else None
         # id mode under DP: the embedding tables' gradients travel as B rows per rank (DPComm.gather_rows) and their flat
         # ranges are cut out of the dense all-reduce; ``sparse_tables=False`` keeps the dense all-reduce (A/B, tests)
-        self.sparse_tables = bool(sparse_tables) and self.comm.world > 1 and os.environ.get("SEGMM_SPARSE_TABLES", "1") != "0"
+        self.sparse_tables = bool(sparse_tables) and self.comm.active and os.environ.get("SEGMM_SPARSE_TABLES", "1") != "0"
         st.row_exchange = self.comm.gather_rows if self.sparse_tables else None
         self.per_bucket_adamw = os.environ.get("SEGMM_BUCKET_ADAMW", "1") != "0"
         self._bucket_works = []
@@ -428,7 +432,7 @@ class Trainer:
         # seed the backward with the model's own constant-one tensor: the head recognises it (same storage) and skips both the
         # ones_like fill autograd would launch and the dlogits * 1 multiply
         torch.autograd.backward(out["loss"], grad_tensors=[model.unit_grad(out["loss"].device)])
-        if self.comm.world > 1 and self.overlap and self.per_bucket_adamw and self._covers_live(st):
+        if self.comm.active and self.overlap and self.per_bucket_adamw and self._covers_live(st):
             # AdamW per bucket, in completion order: each launch waits (stream-level) only for its own bucket's all-reduce, so
             # the optimizer of the early buckets runs under the collectives of the late ones and only the last, small bucket
             # (the video-side embedding) is exposed
@@ -439,7 +443,7 @@ class Trainer:
                 self.opt.step_range(s, e)
             self.opt.end_step()
             return out
-        if self.comm.world > 1:
+        if self.comm.active:
             if not self.overlap:
                 self._reduce_dense(0, st.n_live)
             for _, _, works in self._bucket_works:
@@ -489,7 +493,7 @@ class Trainer:
             if exposure is None:
                 exposure = torch.tensor(model.exposure_prob, dtype=torch.float32, device=logits.device)[: logits.shape[1]]
             interests = torch.sigmoid(logits) * exposure
-            dp = self.comm.world > 1
+            dp = self.comm.active
             ev = TOP_K_leave_device(interests, gt, permutation=permutation, masked=top_k_mask,
                                     gather=self.comm.gather_ints if dp else None)
             for k in acc:

@@ -137,3 +137,56 @@ def test_per_bucket_adamw_equals_single_launch(name):
         assert any(b.endswith("embed_u") for b in names1) and names1[-1].endswith("embed")
     for k in sd0:
         assert (sd0[k] == sd1[k]).all(), k
+
+
+def _run_rccl(port, name, force, q):
+    """One rank on cuda:0.  force=1: process group 'nccl' (= RCCL) of ONE rank + SEGMM_DP_FORCE=1, so every collective of the
+    data-parallel step (async all-gather of the label statistics, bucket all-reduces issued from inside the backward, per-bucket
+    AdamW waits, sparse row exchange of id tables, rank gather of the validation) really goes through RCCL on the device."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", SEGMM_DP_FORCE="1" if force else "0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from segmminterest_amd.trainer import DPComm, Trainer
+    torch.cuda.set_device(0)
+    if force:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        cfg, g, _, _ = load_case(name)
+        model = build_model(cfg)
+        model.load_state_dict(g["sd"])
+        model = model.cuda()
+        tr = Trainer(model, comm=DPComm(), overlap=True, dropout=False)
+        assert tr.comm.active == bool(force)
+        batch = {k: v.cuda() for k, v in _batch(cfg, 16).items()}
+        losses = []
+        for _ in range(3):
+            losses.append(float(tr.train_step(batch)["loss"].detach()))
+        vmet = tr.valid_model([batch], permutation=0)
+        torch.cuda.synchronize()
+        q.put((losses, {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}, vmet))
+    finally:
+        if force:
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["img_d32_N3_alllosses", "id_d32_N2"])
+def test_rccl_single_rank_step_equals_plain_step(name):
+    """The nccl (RCCL) code path, executed for real: a forced one-rank process group must reproduce the plain single-process
+    step exactly (SUM over one rank and a gather of one rank are identities)."""
+    ctx = mp.get_context("spawn")
+    res = {}
+    for force in (0, 1):
+        q = ctx.Queue()
+        p = ctx.Process(target=_run_rccl, args=(29650 + force + (7 if name.startswith("id") else 0), name, force, q))
+        p.start()
+        res[force] = q.get(timeout=300)
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (l0, sd0, v0), (l1, sd1, v1) = res[0], res[1]
+    assert l0 == l1, (l0, l1)
+    for k in sd0:
+        assert (sd0[k] == sd1[k]).all(), k
+    for k in v0:
+        assert v0[k] == v1[k], (k, v0[k], v1[k])
