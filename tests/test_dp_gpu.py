@@ -5,6 +5,7 @@ loss normalisers, the bucket hooks fired from inside the backward, the SUM all-r
 import os
 import sys
 
+import numpy as np
 import pytest
 import torch
 import torch.multiprocessing as mp
@@ -185,8 +186,15 @@ def test_rccl_single_rank_step_equals_plain_step(name):
         p.join(timeout=60)
         assert p.exitcode == 0
     (l0, sd0, v0), (l1, sd1, v1) = res[0], res[1]
-    assert l0 == l1, (l0, l1)
-    for k in sd0:
-        assert (sd0[k] == sd1[k]).all(), k
+    if name.startswith("id"):
+        # the id tables' gradients take the sparse row exchange under DP (compact rows + sorted segment sum): the same sums in
+        # another order, so parameters agree to rounding -- and to lr-sized steps where Adam normalises a rounding-noise gradient
+        assert all(abs(a - b) <= 1e-5 * max(1.0, abs(a)) for a, b in zip(l0, l1)), (l0, l1)
+        for k in sd0:
+            assert np.allclose(sd0[k], sd1[k], rtol=1e-4, atol=4.5e-3), k
+    else:
+        assert l0 == l1, (l0, l1)
+        for k in sd0:
+            assert (sd0[k] == sd1[k]).all(), k
     for k in v0:
         assert v0[k] == v1[k], (k, v0[k], v1[k])
