@@ -206,7 +206,10 @@ def main():
     dev = torch.device("cuda", local_rank % n_dev)
     torch.cuda.set_device(dev)
     dist = None
-    if world > 1:
+    # SEGMM_DP_FORCE=1 under a one-rank launcher: the single-GPU step through the REAL data-parallel machinery (RCCL group of
+    # one rank: bucket hooks, async all-reduces, per-bucket AdamW) -- the cost of that machinery on one GPU, next to the plain step
+    forced_dp = world == 1 and os.environ.get("SEGMM_DP_FORCE", "0") == "1" and "RANK" in os.environ
+    if world > 1 or forced_dp:
         import torch.distributed as dist
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -300,7 +303,8 @@ def main():
                                    "tokens, interestBPR, dropout 0.1, AdamW; %d distinct batches rotated; input=%s"
                                    % (w["name"], B, S, Din, D, h, N, kind, kind, Lt, len(batches), args.input),
                        "rows_per_gpu": B, "global_batch": B * world, "segments": S, "feat_dim": D, "in_dim": Din, "user_tokens": Lt, "layers": N,
-                       "parallelism": "dp%d" % world, "backend": args.backend if world > 1 else None,
+                       "parallelism": "dp%d" % world + (" (forced one-rank process group)" if forced_dp else ""),
+                       "backend": args.backend if (world > 1 or forced_dp) else None,
                        "grad_allreduce_overlap": not args.no_overlap, "final_loss": round(loss, 6),
                        "live_train_flops_per_interaction": ftrain, "gemm_engine": engine,
                        "step_frac_of_f32_mfma_peak": round(rows_per_s / world * ftrain / (PEAK_F32_MFMA_TFLOPS * 1e12), 4)},
