@@ -208,7 +208,12 @@ def main():
     dist = None
     # SEGMM_DP_FORCE=1 under a one-rank launcher: the single-GPU step through the REAL data-parallel machinery (RCCL group of
     # one rank: bucket hooks, async all-reduces, per-bucket AdamW) -- the cost of that machinery on one GPU, next to the plain step
-    forced_dp = world == 1 and os.environ.get("SEGMM_DP_FORCE", "0") == "1" and "RANK" in os.environ
+    forced_dp = world == 1 and os.environ.get("SEGMM_DP_FORCE", "0") == "1"
+    if forced_dp and "RANK" not in os.environ:          # no launcher: a one-rank rendezvous of our own (no child, no exec)
+        s_ = socket.socket()
+        s_.bind(("127.0.0.1", 0))
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(s_.getsockname()[1]), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+        s_.close()
     if world > 1 or forced_dp:
         import torch.distributed as dist
         if args.backend == "nccl":
