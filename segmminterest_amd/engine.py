@@ -1188,14 +1188,14 @@ class BackboneRun:
             elif self.abl == "SelfMLP":
                 dXv = self._mlp_bwd(dXv, sv["mlp_v"], Mv, 0, gbuf, False, "v")
             if self.abl != "w/oAtt" and on_bucket is not None:
-                join_side(st)
-                on_bucket(P + "mlp")
+                on_bucket(P + "mlp", after_side=True)
         else:
             for i in reversed(range(max(self.N - 1, 0))):
                 dXv, dXu = self._layer_bwd(i, sv["layers"][i], dXv, dXu, gbuf)
                 if on_bucket is not None:
-                    join_side(st)
-                    on_bucket("%slayer%d" % (P, i))
+                    # no join: the hook issues the bucket's all-reduce from the side stream's context (ordered behind both
+                    # streams), the main stream goes straight on with the next layer's input-gradient GEMMs
+                    on_bucket("%slayer%d" % (P, i), after_side=True)
         # ---- embedding backward.  User side first: its weight gradient (the larger one) queues on the side stream
         # behind the projection weight gradients still running there, the video side's runs on the main stream.
         if dXu is not None:

@@ -436,11 +436,25 @@ class Trainer:
             # AdamW per bucket, in completion order: each launch waits (stream-level) only for its own bucket's all-reduce, so
             # the optimizer of the early buckets runs under the collectives of the late ones and only the last, small bucket
             # (the video-side embedding) is exposed
+            # ... in TWO launches: every cross-stream wait costs ~15 us of queue time on the GPU, so the buckets that
+            # completed early (a contiguous prefix of the flat buffer: head | layers ...) are stepped together, then the last one
             self.opt.begin_step()
-            for s, e, works in self._bucket_works:
-                for w in works:
+            bw = sorted(self._bucket_works, key=lambda x: x[0])
+            last = self._bucket_works[-1]
+            early = [x for x in bw if x is not last]
+            if early and early[-1][1] <= last[0] and all(a[1] == b[0] for a, b in zip(early, early[1:])):
+                for _, _, works in early:
+                    for w in works:
+                        w.wait()
+                self.opt.step_range(early[0][0], early[-1][1])
+                for w in last[2]:
                     w.wait()
-                self.opt.step_range(s, e)
+                self.opt.step_range(last[0], last[1])
+            else:          # not a prefix + tail (two backbones interleave their buckets): one launch per bucket
+                for s, e, works in self._bucket_works:
+                    for w in works:
+                        w.wait()
+                    self.opt.step_range(s, e)
             self.opt.end_step()
             return out
         if self.comm.active:

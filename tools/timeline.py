@@ -3,9 +3,16 @@ usage: python tools/timeline.py <dir with *_kernel_trace.csv> [--full]"""
 import collections, csv, glob, sys
 f = sorted(glob.glob(sys.argv[1] + "/**/*_kernel_trace.csv", recursive=True))[-1]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "adamw" in r["Kernel_Name"]]
-a, b = idx[-3], idx[-2]
-step = rows[a + 1:b + 1]
+# a step starts with the weight split (wabsmax, plane engine) -- with per-bucket AdamW (data parallel) there are several adamw
+# launches per step, so adamw only delimits steps when no wabsmax is in the trace
+idx = [i for i, r in enumerate(rows) if "wabsmax" in r["Kernel_Name"]]
+if len(idx) >= 3:
+    a, b = idx[-3], idx[-2]
+    step = rows[a:b]
+else:
+    idx = [i for i, r in enumerate(rows) if "adamw" in r["Kernel_Name"]]
+    a, b = idx[-3], idx[-2]
+    step = rows[a + 1:b + 1]
 t0, t1 = int(step[0]["Start_Timestamp"]), int(step[-1]["End_Timestamp"])
 print("step wall %.3f ms, %d kernels" % ((t1 - t0) / 1e6, len(step)))
 qs = collections.defaultdict(list)
