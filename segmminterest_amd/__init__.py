@@ -4,6 +4,13 @@ Mirrors ``MMinterest/models/__init__.py:1-5``: the trainers do
 ``from model import MultiScaleTemporalDetrLeaveFocal, SegFormerX, QueryBasedDecoder, main_eval_batch,
 TOP_K_leave, TOP_K_leave_mask`` (main_for_seq_leave_earlystop_SegMM.py:5).
 """
+import os as _os
+
+# Data-parallel ranks use more streams (main, side, RCCL's) than HIP's default 4 hardware queues: sharing one lets an all-reduce
+# that waits for the side stream stall the main stream behind it (bench.py, DESIGN.md section 7).  Only effective if this import
+# happens before the HIP runtime initialises (import this package, or set the variable, before the first CUDA call).
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 from .encoder import (MLP, MLP_Block, SegFormerX, SegFormerXAttention, SegFormerXEncoder,  # noqa: F401
                       SegFormerXEncoderLayer, SegFormerXFPN, clones)
 from .decoder_leave_focal import InteractionAggregation, MultiScaleTemporalDetrLeaveFocal  # noqa: F401
