@@ -223,6 +223,15 @@ class ParamStore:
         self._hdr_off += n
         return ring[r0:r0 + n]
 
+    def const_arange(self, n: int, dtype) -> torch.Tensor:
+        """arange(n) on the device, made once (never written afterwards)."""
+        c = self.__dict__.setdefault("_consts", {})
+        key = (n, dtype, self.flat.device)
+        t = c.get(key)
+        if t is None:
+            t = c[key] = torch.arange(n, device=self.flat.device, dtype=dtype)
+        return t
+
     def scales(self) -> torch.Tensor:
         if self.site_scale is None or self.site_scale.device != self.flat.device:
             self.site_scale = torch.zeros((self.MAX_SITES + 8,), dtype=torch.float32, device=self.flat.device)
@@ -391,6 +400,7 @@ class ParamStore:
                 p.data = flat[o:o + n].view(p.shape)
         self.flat = flat
         self.gflat = torch.zeros((n_live,), dtype=torch.float32, device=dev)
+        self._tab_rows = {}          # id-table gradient: (gradient view address, rows scattered into it by the last backward)
         self.index = {name: (o, n) for name, o, n in order}
         self.buckets = buckets
         self.n_live = n_live
@@ -1232,23 +1242,34 @@ class BackboneRun:
         if is_id:
             ids = sv["%s_ids" % side]
             width = d // 2 if side == "vid" else d
-            gtab.zero_()
+            # the dense table gradient (360 MB at config 3) is zero except for the rows the PREVIOUS step scattered into it
+            # (AdamW reads it, nobody else writes it): clear those rows instead of filling the whole table again
+            prev = st._tab_rows.get(P + side)
+            if gbuf is None and prev is not None and prev[0] == gtab.data_ptr() and prev[1].device == gtab.device:
+                gtab.index_fill_(0, prev[1], 0.0)
+            else:
+                gtab.zero_()
+            st._tab_rows.pop(P + side, None)
             if st.row_exchange is not None:
                 # Data parallel: a rank touches at most B rows of the table, so the ranks exchange
                 # their B compact row gradients [B, width] + ids (all-gather, ~1 MB) instead of all-reducing the dense
                 # [n_items, width] gradient (360 MB at config 3); every rank then runs the same deterministic sorted
                 # segment sum over the G*B gathered rows and ends with the bitwise-identical global table gradient.
                 rows = st.buf("idrows_" + side, (B, width))
-                ar = st.buf("idrows_ar", (B,), torch.int64)
-                ar.copy_(torch.arange(B, device=ar.device))
+                ar, ar32 = st.const_arange(B, torch.int64), st.const_arange(B, torch.int32)
                 rows.zero_()                                                               # the kernel accumulates into its output
-                H.embed_id_bwd(dpre, L, d, 0, width, ar.to(torch.int32), ar, rows, B)      # rows[b] = sum_s dpre[b, s, :width]
+                H.embed_id_bwd(dpre, L, d, 0, width, ar32, ar, rows, B)                    # rows[b] = sum_s dpre[b, s, :width]
                 ids_all, rows_all = st.row_exchange(ids, rows)
                 order = torch.argsort(ids_all, stable=True).to(torch.int32)
                 H.embed_id_bwd(rows_all, 1, width, 0, width, order, ids_all, gtab, ids_all.numel())
+                touched = ids_all
             else:
                 order = torch.argsort(ids, stable=True).to(torch.int32)
                 H.embed_id_bwd(dpre, L, d, 0, width, order, ids, gtab, B)
+                touched = ids
+            # (a dense all-reduce of the table under data parallelism adds the OTHER ranks' rows: no row list then)
+            if gbuf is None and (st.bucket_hook is None or st.row_exchange is not None):
+                st._tab_rows[P + side] = (gtab.data_ptr(), touched.reshape(-1).clamp(0, gtab.shape[0] - 1))
             if side == "vid":
                 dh_ = d // 2
                 _colsum(st, gpe, d, L, dh_, st.g(P + "frameid_proj.bias", gbuf), x_off=dh_)
@@ -1256,8 +1277,7 @@ class BackboneRun:
                     _colsum(st, dpre, d, M, dh_, st.g(P + "frameid_proj.weight", gbuf).view(-1), x_off=dh_,
                             w=sv["frame_pos"].view(-1))
                 else:
-                    pos = st.buf("arangeS", (L,))
-                    pos.copy_(torch.arange(L, device=pos.device, dtype=torch.float32))
+                    pos = st.const_arange(L, torch.float32)
                     _colsum(st, gpe, d, L, dh_, st.g(P + "frameid_proj.weight", gbuf).view(-1), x_off=dh_, w=pos)
         else:
             x = sv["%s_x" % side]
