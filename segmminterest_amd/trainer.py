@@ -295,7 +295,9 @@ class Trainer:
         self.sparse_tables = bool(sparse_tables) and self.comm.active and os.environ.get("SEGMM_SPARSE_TABLES", "1") != "0"
         st.row_exchange = self.comm.gather_rows if self.sparse_tables else None
         self.per_bucket_adamw = os.environ.get("SEGMM_BUCKET_ADAMW", "1") != "0"
+        self.bucket_bytes = int(float(os.environ.get("SEGMM_DP_BUCKET_MB", "8")) * (1 << 20))      # merge threshold of _on_bucket
         self._bucket_works = []
+        self._pending_range = None
         self._norm = {}
         self._norm_amax = None
         self._norm_planes = {}
@@ -303,26 +305,42 @@ class Trainer:
 
     def _on_bucket(self, name, after_side=False):
         """Called from inside the backward the moment the gradients of bucket ``name`` are written (``after_side``: part of
-        them by launches still in flight on the engine's side stream): issues the bucket's asynchronous all-reduce and
-        remembers its works, so that AdamW can step the bucket as soon as THEY are done (train_step)."""
+        them by launches still in flight on the engine's side stream).  Adjacent buckets are MERGED until ``bucket_bytes`` of
+        gradients are pending (a collective call costs ~0.2 ms of host time, whatever its size), then one asynchronous
+        all-reduce is issued for the merged range; its works are remembered so that AdamW can step the range as soon as THEY
+        are done (train_step, which also flushes what is still pending when the backward returns)."""
         st = self.model._store
         if not self.overlap:
             return
         for b, s, e in st.buckets:
             if b == name:
-                if after_side and st.overlap and st._side_stream is not None:
-                    # order the collective behind main AND side stream without stalling the main stream: issue it from the side
-                    # stream's context after making the side stream wait for the main stream's work so far
-                    main, side = torch.cuda.current_stream(), st.side_stream()
-                    ev = torch.cuda.Event()
-                    ev.record(main)
-                    side.wait_event(ev)
-                    with torch.cuda.stream(side):
-                        self._reduce_dense(s, e)
-                else:
-                    self._reduce_dense(s, e)
-                self._bucket_works.append((s, e, self.comm.take_pending()))
+                p = self._pending_range
+                if p is not None and p[1] != s and p[0] != e:
+                    self._flush_bucket()          # not adjacent (two backbones interleave): send what is pending first
+                    p = None
+                self._pending_range = [s, e, after_side] if p is None else [min(p[0], s), max(p[1], e), p[2] or after_side]
+                if 4 * (self._pending_range[1] - self._pending_range[0]) >= self.bucket_bytes:
+                    self._flush_bucket()
                 return
+
+    def _flush_bucket(self):
+        p, self._pending_range = self._pending_range, None
+        if p is None:
+            return
+        st = self.model._store
+        s, e, after_side = p
+        if after_side and st.overlap and st._side_stream is not None:
+            # order the collective behind main AND side stream without stalling the main stream: issue it from the side
+            # stream's context after making the side stream wait for the main stream's work so far
+            main, side = torch.cuda.current_stream(), st.side_stream()
+            ev = torch.cuda.Event()
+            ev.record(main)
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                self._reduce_dense(s, e)
+        else:
+            self._reduce_dense(s, e)
+        self._bucket_works.append((s, e, self.comm.take_pending()))
 
     def _reduce_dense(self, s, e):
         """All-reduce [s, e) of the flat gradient minus the row-exchanged table ranges."""
@@ -429,9 +447,12 @@ class Trainer:
         out = model(usr_image=usr, usr_id=usr_id, usr_mask=um, vid_image=vid,
                     vid_id=batch["photo_identity_id"], vid_mask=vm, gt=batch["label"], mode="train")
         self._bucket_works = []
+        self._pending_range = None
         # seed the backward with the model's own constant-one tensor: the head recognises it (same storage) and skips both the
         # ones_like fill autograd would launch and the dlogits * 1 multiply
         torch.autograd.backward(out["loss"], grad_tensors=[model.unit_grad(out["loss"].device)])
+        if self.comm.active and self.overlap:
+            self._flush_bucket()          # the tail of the backward (embedding gradients) that stayed below the merge threshold
         if self.comm.active and self.overlap and self.per_bucket_adamw and self._covers_live(st):
             # AdamW per bucket, in completion order: each launch waits (stream-level) only for its own bucket's all-reduce, so
             # the optimizer of the early buckets runs under the collectives of the late ones and only the last, small bucket
