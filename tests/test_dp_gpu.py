@@ -90,7 +90,8 @@ def test_two_ranks_equal_single_process(name):
 
 def _run_sched(rank, world, port, name, per_bucket, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      SEGMM_BUCKET_ADAMW="1" if per_bucket else "0")
+                      SEGMM_BUCKET_ADAMW="1" if per_bucket else "0",
+                      SEGMM_DP_BUCKET_MB="0")          # no merging of adjacent buckets: one collective (and AdamW range) per bucket
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
