@@ -466,8 +466,14 @@ int segmm_gemm_p(int layout, int M, int N, int K, const uint16_t* a_planes, int 
             SEGMM_REQUIRE(!residual && C, "gemm_p: accumulate and residual are exclusive");
             g.residual = C; g.ldr = ldc; g.res_period = M;
         }
-        g.nbm = (M + PBM - 1) / PBM; g.nbn = (N + PBN - 1) / PBN;
         static const int pl_var = getenv("SEGMM_PL_VAR") ? atoi(getenv("SEGMM_PL_VAR")) : 1;
+        if (pl_var == 4) {          // four-wave form: 128 x 256 tiles, two workgroups per CU
+            g.nbm = (M + QBM - 1) / QBM; g.nbn = (N + QBN - 1) / QBN;
+            hipLaunchKernelGGL(gemm_pl_nt4, dim3(g.nbm * g.nbn), dim3(256), 0, s, g, q);
+            LAUNCH_CHECK();
+            return 0;
+        }
+        g.nbm = (M + PBM - 1) / PBM; g.nbn = (N + PBN - 1) / PBN;
         if (pl_var == 0) hipLaunchKernelGGL(gemm_pl_nt<0>, dim3(g.nbm * g.nbn), dim3(512), 0, s, g, q);
         else if (pl_var == 2) hipLaunchKernelGGL(gemm_pl_nt<2>, dim3(g.nbm * g.nbn), dim3(512), 0, s, g, q);
         else hipLaunchKernelGGL(gemm_pl_nt<1>, dim3(g.nbm * g.nbn), dim3(512), 0, s, g, q);
