@@ -12,6 +12,8 @@ python bench.py --config 5 --steps 20 --warmup 5 --no-cpu-baseline --no-f32-engi
 python bench.py --config 4 --gpus 1 --global-batch 256 --steps 20 --warmup 5 --no-cpu-baseline --no-f32-engine --no-host-fed --no-probe > $O/bench_cfg4_256rows.json 2>/dev/null
 python bench.py --input index --steps 20 --warmup 5 --no-cpu-baseline --no-f32-engine --no-host-fed --no-probe > $O/bench_index_input.json 2>/dev/null
 python bench.py --gpus 2 --backend gloo --steps 6 --warmup 2 --no-cpu-baseline --no-probe > $O/bench_gloo2_one_gpu.json 2>/dev/null
+SEGMM_DP_FORCE=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-f32-engine --no-host-fed --no-probe > $O/bench_dp_forced_one_rank.json 2>/dev/null
+bash tools/probe/zero_probe.sh > $O/zero_operand_probe.txt 2>&1
 bash tools/prof_stats.sh ${TAG}_cfg2 > $O/prof_cfg2_summary.txt 2>&1
 cp gpurun_out/prof_${TAG}_cfg2_kernel_stats.csv $O/bench_cfg2_kernel_stats.csv
 python tools/timeline.py gpurun_out/prof_${TAG}_cfg2 --full > $O/step_timeline_cfg2.txt 2>&1
