@@ -324,6 +324,7 @@ def main():
                        "parallelism": "dp%d" % world + (" (forced one-rank process group)" if forced_dp else ""),
                        "backend": args.backend if (world > 1 or forced_dp) else None,
                        "grad_allreduce_overlap": not args.no_overlap, "final_loss": round(loss, 6),
+                       "delayed_scale_overflows": (model._store.overflow_count() if model._store.engine_p else None),
                        "live_train_flops_per_interaction": ftrain, "gemm_engine": engine,
                        "step_frac_of_f32_mfma_peak": round(rows_per_s / world * ftrain / (PEAK_F32_MFMA_TFLOPS * 1e12), 4)},
         }

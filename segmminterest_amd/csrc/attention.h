@@ -302,7 +302,14 @@ struct KeyBlocks {
 
 // ------------------------------------------------------------------------------------------ forward
 template <int DH, int NT>
+#ifndef ATT_FWD_WAVES
+#define ATT_FWD_WAVES 0          // probe: minimum waves per SIMD the register allocator has to make room for (0 = compiler's choice)
+#endif
+#if ATT_FWD_WAVES
+__global__ __launch_bounds__(ATT_MAX_THREADS, ATT_FWD_WAVES) void attn_fwd_kernel(const AttnArgs p) {
+#else
 __global__ __launch_bounds__(ATT_MAX_THREADS) void attn_fwd_kernel(const AttnArgs p) {
+#endif
     using C = AttnCfg<DH>;
     extern __shared__ uint8_t km[];
     // A workgroup = p.hpb ADJACENT heads of one batch row x wq row tiles: the heads read interleaved 4*DH-byte slices of
