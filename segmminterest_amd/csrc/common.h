@@ -1,5 +1,8 @@
 // Shared device helpers for the gfx950 (CDNA4, wave64) kernels of the segment-interest path.
 #pragma once
+#ifndef SEGMM_NT_STORES
+#define SEGMM_NT_STORES 0          // 1: streaming (nontemporal) stores for the big write-once outputs
+#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -183,7 +186,13 @@ __device__ __forceinline__ void plane_store4_pair(_Float16* p, int ld2, long lon
     const uint32_t r0 = dpp_swap1(odd ? h0 : l0), r1 = dpp_swap1(odd ? h1 : l1);      // odd lanes give away hi, even lanes lo
     const int cb = c & ~7;
     _Float16* o = p + row * ld2 + ((cb >> 5) << 6) + (cb & 31) + (odd ? 32 : 0);
-    *(uint4*)o = odd ? make_uint4(r0, r1, l0, l1) : make_uint4(h0, h1, r0, r1);
+    const uint4 w = odd ? make_uint4(r0, r1, l0, l1) : make_uint4(h0, h1, r0, r1);
+#if SEGMM_NT_STORES
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    __builtin_nontemporal_store(u32x4{w.x, w.y, w.z, w.w}, (u32x4*)o);          // written once, read by a later kernel after GBs of other traffic
+#else
+    *(uint4*)o = w;
+#endif
 }
 // end of a producer wave: partial maxima (+ flag) and the scale used.  The scale is stored by the waves whose key is a
 // multiple of 1024 (key 0 always exists and always gets here; EVERY wave storing to that one word serialised the stores of

@@ -128,7 +128,13 @@ __device__ __forceinline__ void epi_strip_emit(const GemmArgs& p, const PGemmX& 
                     v += *(const f32x4*)(p.residual + (size_t)rr * p.ldr + gn);
                 }
             }
-            if ((SPLITK || q.write_c) && !(q.dbg & 1)) *(f32x4*)(Cout + (size_t)gm * p.ldc + gn) = v;
+            if ((SPLITK || q.write_c) && !(q.dbg & 1)) {
+#if SEGMM_NT_STORES
+                if (!SPLITK) __builtin_nontemporal_store(v, (f32x4*)(Cout + (size_t)gm * p.ldc + gn));
+                else
+#endif
+                *(f32x4*)(Cout + (size_t)gm * p.ldc + gn) = v;
+            }
             if (!SPLITK) {
                 am = absmax4(am, v);
                 if (c_scale > 0.f && q.Cp) plane_store4_pair(q.Cp, q.ldc2, gm, gn, v, c_scale);
