@@ -44,7 +44,7 @@ def run(device="cuda:0"):
     out["loss"].backward()
     err = float((out["logits"].cpu() - ref["logits"].detach()).abs().max())
     assert err < 1e-4, "logit mismatch vs oracle: %g" % err
-    assert abs(float(out["loss"]) - float(ref["loss"])) < 1e-4
+    assert abs(float(out["loss"].detach()) - float(ref["loss"].detach())) < 1e-4
     worst = 0.0
     for k, p in model.named_parameters():
         if rgrads[k] is None:

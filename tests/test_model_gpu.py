@@ -255,7 +255,7 @@ def test_full_width_config_vs_oracle(B, S, Lt, D, N):
     model = model.cuda().eval()
     out = call_model(model, inp, "train", DEV)
     assert (out["logits"].cpu() - ref["logits"].detach()).abs().max().item() < 1e-4
-    assert abs(float(out["loss"]) - float(ref["loss"])) < 1e-4
+    assert abs(float(out["loss"].detach()) - float(ref["loss"].detach())) < 1e-4
     out["loss"].backward()
     for k, p in model.named_parameters():
         if rgrads[k] is None:
@@ -307,7 +307,7 @@ def test_baseline_config_widths_vs_oracle(case):
     model = model.cuda().eval()
     out = call_model(model, inp, "train", DEV)
     assert (out["logits"].cpu() - ref["logits"].detach()).abs().max().item() < 1e-4
-    assert abs(float(out["loss"]) - float(ref["loss"])) < 1e-4
+    assert abs(float(out["loss"].detach()) - float(ref["loss"].detach())) < 1e-4
     out["loss"].backward()
     for k, p in model.named_parameters():
         if rgrads[k] is None:
@@ -479,7 +479,7 @@ def test_config3_full_item_table_matches_oracle():
     out = model(usr_image=None, usr_id=kw["usr_id"], usr_mask=kw["usr_mask"], vid_image=None, vid_id=kw["vid_id"], vid_mask=kw["vid_mask"],
                 gt=kw["gt"].clone(), mode="train")
     assert (out["logits"].cpu() - ref["logits"].detach()).abs().max().item() < 1e-4
-    assert abs(float(out["loss"]) - float(ref["loss"])) < 1e-5 * max(1.0, abs(float(ref["loss"])))
+    assert abs(float(out["loss"].detach()) - float(ref["loss"].detach())) < 1e-5 * max(1.0, abs(float(ref["loss"])))
     opt = FusedAdamW(model, lr=1e-3, weight_decay=1e-4)
     opt.zero_grad()
     out["loss"].backward()
@@ -520,7 +520,7 @@ def test_full_size_gradients_match_oracle():
     model = model.cuda().eval()
     out = call_model(model, inp, "train", DEV)
     assert (out["logits"].cpu() - ref["logits"].detach()).abs().max().item() < 1e-4
-    assert abs(float(out["loss"]) - float(ref["loss"])) < 1e-5 * max(1.0, abs(float(ref["loss"])))
+    assert abs(float(out["loss"].detach()) - float(ref["loss"].detach())) < 1e-5 * max(1.0, abs(float(ref["loss"])))
     out["loss"].backward()
     errs = _check_live_grads(model, rgrads)
     print("full-size worst gradient error / tensor max: %.2e" % max(v for k, v in errs.items() if "bias" not in k))
