@@ -282,6 +282,10 @@ class ParamStore:
         return self.root._param_buckets()
 
     def ensure(self):
+        # inside Trainer.train_step the layout and the weight planes were checked once at the start of the step and nothing
+        # outside the step can touch the parameters until it returns: the later calls of the same step are free
+        if self.__dict__.get("_trusted") and self.flat is not None:
+            return
         params = self._params
         if params is None:
             params = self._params = dict(self.root.named_parameters())

@@ -93,7 +93,10 @@ class FusedAdamW:
         return st
 
     def zero_grad(self, set_to_none=True):
-        for p in self.model.parameters():
+        plist = self.__dict__.get("_plist")
+        if plist is None:          # the Parameter objects of a model do not change; walking the module tree costs 0.3 ms per step
+            plist = self._plist = list(self.model.parameters())
+        for p in plist:
             p.grad = None
 
     def step(self, gbuf=None):
@@ -432,9 +435,19 @@ class Trainer:
 
     def train_step(self, batch: Dict[str, torch.Tensor]):
         model, st = self.model, self.model._store
-        model.train(self.dropout)
+        if model.training != bool(self.dropout):
+            model.train(self.dropout)          # (walks every sub-module: 0.35 ms of host time when done every step)
         self.opt.zero_grad()
-        usr, um, vid, vm = self._features(batch)
+        st._trusted = False
+        try:
+            usr, um, vid, vm = self._features(batch)          # first ParamStore.ensure() of the step: the full check
+            st._trusted = True
+            return self._train_step(batch, usr, um, vid, vm)
+        finally:
+            st._trusted = False
+
+    def _train_step(self, batch, usr, um, vid, vm):
+        model, st = self.model, self.model._store
         usr_id = batch["user_identity_id"]
         if "noUser" in getattr(model.backbone1, "ablation_type", "ours"):
             # 'noUser' / 'noUser_SelfAtt' (main...SegMM.py:275-280, main...KuaiRand.py:254-258): the TRAINING forward sees
