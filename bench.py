@@ -82,6 +82,8 @@ def parse_args():
     ap.add_argument("--batches", type=int, default=8, help="distinct synthetic batches rotated through the steps")
     ap.add_argument("--input", choices=("features", "index"), default="features")
     ap.add_argument("--no-host-fed", action="store_true", help="skip the host-fed (PCIe-inclusive) leg")
+    ap.add_argument("--no-prefetch", dest="prefetch", action="store_false",
+                    help="run the input stage (L1 normalisation / table gather) of a batch inside its own step instead of under the previous step")
     ap.add_argument("--no-probe", action="store_true", help="skip the sustained-MFMA probe (roofline.sustained_probe)")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
                     help="gloo: CPU-staged collectives, lets several ranks share one GPU (CI rehearsal of the N > 1 path)")
@@ -273,7 +275,8 @@ def main():
         out = None
         for i in range(n):
             h0 = time.perf_counter()
-            out = tr.train_step(batches[(start + i) % len(batches)])
+            nxt = batches[(start + i + 1) % len(batches)] if (args.prefetch and len(batches) > 1) else None
+            out = tr.train_step(batches[(start + i) % len(batches)], next_batch=nxt)
             host_s.append(time.perf_counter() - h0)
         return out
 
@@ -323,7 +326,8 @@ def main():
                        "rows_per_gpu": B, "global_batch": B * world, "segments": S, "feat_dim": D, "in_dim": Din, "user_tokens": Lt, "layers": N,
                        "parallelism": "dp%d" % world + (" (forced one-rank process group)" if forced_dp else ""),
                        "backend": args.backend if (world > 1 or forced_dp) else None,
-                       "grad_allreduce_overlap": not args.no_overlap, "final_loss": round(loss, 6),
+                       "grad_allreduce_overlap": not args.no_overlap, "input_prefetch": bool(args.prefetch and len(batches) > 1),
+                       "final_loss": round(loss, 6),
                        "delayed_scale_overflows": (model._store.overflow_count() if model._store.engine_p else None),
                        "live_train_flops_per_interaction": ftrain, "gemm_engine": engine,
                        "step_frac_of_f32_mfma_peak": round(rows_per_s / world * ftrain / (PEAK_F32_MFMA_TFLOPS * 1e12), 4)},

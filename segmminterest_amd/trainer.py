@@ -304,6 +304,9 @@ class Trainer:
         self._norm = {}
         self._norm_amax = None
         self._norm_planes = {}
+        self._slot = 0
+        self._pf = None
+        self._pf_stream = None
         self._norm_fresh = False
 
     def _on_bucket(self, name, after_side=False):
@@ -378,9 +381,10 @@ class Trainer:
         rows = buf.numel() // cols
         planes = None
         if st.engine_p and cols % 32 == 0:
-            planes = self._norm_planes.get(key)
+            pk = (key, self._slot)
+            planes = self._norm_planes.get(pk)
             if planes is None or planes.shape != (rows, 2 * cols) or planes.device != dev:
-                planes = self._norm_planes[key] = torch.empty((rows, 2 * cols), dtype=torch.float16, device=dev)
+                planes = self._norm_planes[pk] = torch.empty((rows, 2 * cols), dtype=torch.float16, device=dev)
         act = E.Act(buf, self._norm_amax[0 if key == "user" else 1], rows, cols, planes)
         if planes is not None:
             delayed = (self.model.training and st.scaling != "exact") or st.scaling == "always"
@@ -392,9 +396,10 @@ class Trainer:
 
     def normalize(self, key, x):
         """a1: x / (sum|x| + 1e-6) over the feature dim, into a persistent buffer."""
-        buf = self._norm.get(key)
+        bk = (key, self._slot)
+        buf = self._norm.get(bk)
         if buf is None or buf.shape != x.shape or buf.device != x.device:
-            buf = self._norm[key] = torch.empty_like(x)
+            buf = self._norm[bk] = torch.empty_like(x)
         act = self._input_act(key, buf)
         # the GEMM that reads ``buf`` needs max|buf| (and, on the plane engine, its fp16 planes): both are folded into this
         # kernel instead of separate passes over the features
@@ -405,20 +410,36 @@ class Trainer:
 
     def _features(self, batch):
         """(usr, usr_mask, vid, vid_mask): L1-normalised feature tensors of a batch, from the tensors it carries or --
-        index batches -- gathered from the resident table."""
+        index batches -- gathered from the resident table.  Taken from :meth:`prefetch` when that ran for this very batch."""
+        st = self.model._store
+        st.ensure()
+        pf, self._pf = self._pf, None
+        if pf is not None and pf["batch"] is batch:
+            torch.cuda.current_stream().wait_event(pf["done"])          # the main stream waits for the prefetch stream's kernels
+            usr, um, vid, vm = pf["out"]
+            self._norm_amax, self._norm_fresh = pf["amax"], pf["fresh"]
+        else:
+            usr, um, vid, vm = self._features_compute(batch)
+        if st.engine_p and self._norm_amax is not None and self._norm_fresh:
+            st.update_scales(self._norm_amax, ["in.user", "in.photo"], 2)          # the input sites' scales of the next step
+        return usr, um, vid, vm
+
+    def _features_compute(self, batch, hdr_rows=None):
         it = self.model.input_type
-        self.model._store.ensure()
         usr = vid = None
         um, vm = batch.get("user_mask"), batch.get("photo_mask")
+        self._slot ^= 1                      # two sets of output buffers, alternated: see prefetch()
         self._norm_fresh = False
+        if hdr_rows is not None:
+            self._norm_amax, self._norm_fresh = hdr_rows, True
         for key, kind in (("user", it["user"]), ("photo", it["photo"])):
             if kind == "id":
                 continue
             if key + "_idx" in batch:
-                out, mask = self.feature_table.buffers(key, batch[key + "_idx"])
+                out, mask = self.feature_table.buffers(key, batch[key + "_idx"], self._slot)
                 act = self._input_act(key, out)
                 self.feature_table.gather(key, batch[key + "_idx"], amax=None if act is None else act.slots,
-                                          po=None if act is None else act.po)
+                                          po=None if act is None else act.po, slot=self._slot)
                 if act is not None:
                     E.produced(act)
                 x, m = out, mask.view(torch.bool)
@@ -428,12 +449,34 @@ class Trainer:
                 usr, um = x, m
             else:
                 vid, vm = x, m
-        st = self.model._store
-        if st.engine_p and self._norm_amax is not None and self._norm_fresh:
-            st.update_scales(self._norm_amax, ["in.user", "in.photo"], 2)          # the input sites' scales of the next step
         return usr, um, vid, vm
 
-    def train_step(self, batch: Dict[str, torch.Tensor]):
+    def prefetch(self, batch):
+        """Enqueue the input stage of ``batch`` (a1: L1 normalisation, or the table gather of an index batch; with the fp16 planes
+        and maxima the first GEMM needs) on a low-priority stream of its own, NOW -- typically while the current step's backward
+        is running.  The next ``train_step(batch)`` with this very dict picks the results up instead of running the stage at the
+        head of its critical path (the reference overlaps the same work through its DataLoader workers).  Output buffers
+        alternate between two sets, so the step in flight keeps reading its own."""
+        st = self.model._store
+        it = self.model.input_type
+        if st.flat is None or (it["user"] == "id" and it["photo"] == "id"):
+            return
+        main = torch.cuda.current_stream()
+        if self._pf_stream is None:          # lowest priority, like the engine's side stream: it must not starve the step in flight
+            self._pf_stream = torch.cuda.Stream(device=st.flat.device, priority=int(os.environ.get("SEGMM_SIDE_PRIORITY", "1")))
+        rows = st.hdr_rows(2) if st.engine_h else None          # taken (and, at a ring quarter, cleared) in main-stream order
+        ev = torch.cuda.Event()
+        ev.record(main)                                            # behind this step's scales_update of the input sites
+        self._pf_stream.wait_event(ev)
+        with torch.cuda.stream(self._pf_stream):
+            out = self._features_compute(batch, hdr_rows=rows)
+            done = torch.cuda.Event()
+            done.record(self._pf_stream)
+        self._pf = dict(batch=batch, out=out, done=done, amax=self._norm_amax, fresh=self._norm_fresh)
+
+    def train_step(self, batch: Dict[str, torch.Tensor], next_batch: Optional[Dict[str, torch.Tensor]] = None):
+        """One optimisation step on ``batch``.  ``next_batch``: the batch of the FOLLOWING step, if known -- its input stage is
+        enqueued on a side stream right away (:meth:`prefetch`) and overlaps this step's backward."""
         model, st = self.model, self.model._store
         if model.training != bool(self.dropout):
             model.train(self.dropout)          # (walks every sub-module: 0.35 ms of host time when done every step)
@@ -442,6 +485,8 @@ class Trainer:
         try:
             usr, um, vid, vm = self._features(batch)          # first ParamStore.ensure() of the step: the full check
             st._trusted = True
+            if next_batch is not None:
+                self.prefetch(next_batch)
             return self._train_step(batch, usr, um, vid, vm)
         finally:
             st._trusted = False

@@ -163,6 +163,47 @@ def test_index_batches_train_like_feature_batches():
     assert torch.allclose(outs[0][2], outs[1][2], atol=1e-5)
 
 
+@pytest.mark.parametrize("index_input", [False, True])
+def test_input_prefetch_changes_nothing(index_input):
+    """Trainer.prefetch (the input stage of the NEXT batch on its own stream, alternating output buffers) leaves every step
+    bitwise unchanged: 6 steps over 3 rotating batches with and without it, feature batches and index batches -- incl. a
+    prefetched batch that is then NOT the one trained on (its results must be dropped)."""
+    _abi()
+    from segmminterest_amd.feature_store import ResidentFeatureTable
+    from segmminterest_amd.synth import make_batch
+    from segmminterest_amd.trainer import Trainer, default_args, init_model
+    B, S, Lt, D, N = 16, 40, 10, 64, 2
+    g = torch.Generator().manual_seed(9)
+    table = torch.rand(700, D, generator=g)
+    batches = []
+    for i in range(3):
+        b = make_batch(B, S, Lt, D, seed=100 + i)
+        if index_input:
+            iv = torch.randint(0, 700, (B, S), generator=g)
+            iv[~b["photo_mask"]] = -1
+            iu = torch.randint(0, 700, (B, Lt), generator=g)
+            iu[~b["user_mask"]] = -1
+            b = {k: v for k, v in b.items() if k not in ("photo", "user", "photo_mask", "user_mask")}
+            b["photo_idx"], b["user_idx"] = iv, iu
+        batches.append({k: v.to(DEV) for k, v in b.items()})
+    margs = default_args(num_layers_enc=N, d_model=D, nhead=4, input_type={"user": "image", "photo": "image"}, exposure_prob=[1.0] * S)
+    res = []
+    for prefetch in (False, True):
+        torch.manual_seed(1)
+        model = init_model(margs, n_users=1, n_items=1, input_dim=D, max_vid_len=S, max_usr_len=Lt).to(DEV)
+        tr = Trainer(model, dropout=False, feature_table=ResidentFeatureTable(table.to(DEV)) if index_input else None)
+        losses = []
+        for i in range(6):
+            nxt = None
+            if prefetch:
+                nxt = batches[(i + 1) % 3] if i != 3 else batches[0]          # step 3 announces the WRONG next batch
+            losses.append(float(tr.train_step(batches[i % 3], next_batch=nxt)["loss"].detach()))
+        torch.cuda.synchronize()
+        res.append((losses, model._store.flat.detach().cpu().clone()))
+    assert res[0][0] == res[1][0], (res[0][0], res[1][0])
+    assert torch.equal(res[0][1], res[1][1])
+
+
 def test_segment_weighted_sum_matches_cliprec():
     H = _abi()
     g = torch.Generator().manual_seed(8)
