@@ -82,8 +82,9 @@ def parse_args():
     ap.add_argument("--batches", type=int, default=8, help="distinct synthetic batches rotated through the steps")
     ap.add_argument("--input", choices=("features", "index"), default="features")
     ap.add_argument("--no-host-fed", action="store_true", help="skip the host-fed (PCIe-inclusive) leg")
-    ap.add_argument("--no-prefetch", dest="prefetch", action="store_false",
-                    help="run the input stage (L1 normalisation / table gather) of a batch inside its own step instead of under the previous step")
+    ap.add_argument("--prefetch", action="store_true",
+                    help="Trainer.train_step(batch, next_batch=...): the input stage (L1 normalisation / table gather) of the next batch runs on "
+                         "its own stream under the current step.  Off by default: measured +0.2 %% (the GPU is saturated, the overlap buys nothing)")
     ap.add_argument("--no-probe", action="store_true", help="skip the sustained-MFMA probe (roofline.sustained_probe)")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
                     help="gloo: CPU-staged collectives, lets several ranks share one GPU (CI rehearsal of the N > 1 path)")
