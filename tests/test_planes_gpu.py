@@ -380,3 +380,31 @@ def test_delayed_scaling_survives_a_magnitude_jump():
     ref = fwd()
     tol = 1e-5 * max(1.0, float(ref.abs().max()))
     assert torch.isfinite(got).all() and float((got - ref).abs().max()) <= tol and float((got2 - ref).abs().max()) <= tol
+
+
+def test_site_header_ring_wraps_cleanly():
+    """The ParamStore hands site headers out of a ring that is cleared a quarter at a time (engine.ParamStore.hdr_rows).  With
+    a ring so small that 30 training steps lap it several times, every step must still equal the run on the default ring
+    bitwise: a header row that came back dirty would carry stale maxima into a tensor's scale and change the fp16 split."""
+    from segmminterest_amd import engine as E
+    from segmminterest_amd.synth import make_batch
+    from segmminterest_amd.trainer import Trainer, default_args, init_model
+    B, S, Lt, D, N = 8, 20, 6, 64, 3
+    margs = default_args(num_layers_enc=N, d_model=D, nhead=4, input_type={"user": "image", "photo": "image"}, exposure_prob=[1.0] * S)
+    batches = [{k: v.cuda() for k, v in make_batch(B, S, Lt, D, seed=40 + i).items()} for i in range(3)]
+    res = []
+    saved = E.ParamStore.HDR_RING_ROWS
+    try:
+        for rows in (saved, 256):
+            E.ParamStore.HDR_RING_ROWS = rows
+            torch.manual_seed(3)
+            model = init_model(margs, n_users=1, n_items=1, input_dim=D, max_vid_len=S, max_usr_len=Lt).cuda()
+            tr = Trainer(model, dropout=False)
+            losses = [float(tr.train_step(batches[i % 3])["loss"].detach()) for i in range(30)]
+            torch.cuda.synchronize()
+            res.append((losses, model._store.flat.detach().cpu().clone(), model._store.overflow_count()))
+    finally:
+        E.ParamStore.HDR_RING_ROWS = saved
+    assert res[0][0] == res[1][0]
+    assert torch.equal(res[0][1], res[1][1])
+    assert res[0][2] == res[1][2] == 0
