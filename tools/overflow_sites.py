@@ -1,0 +1,48 @@
+"""Which tensor sites overflow their delayed scale, and by how much (debug: one host sync per pass).
+   python tools/overflow_sites.py [steps] [config 2|3]"""
+import collections, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from segmminterest_amd import engine as E, hipabi as H
+from segmminterest_amd.synth import make_batch
+from segmminterest_amd.trainer import DPComm, Trainer, default_args, init_model
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+cfg = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+dev = torch.device("cuda", 0)
+if cfg == 2:
+    B, S, D, N, Lt, h, kind, nu, ni = 512, 40, 768, 2, 100, 16, "image", 1, 1
+else:
+    B, S, D, N, Lt, h, kind, nu, ni = 1024, 20, 512, 4, 1, 16, "id", 30000, 352494
+args = default_args(num_layers_enc=N, d_model=D, nhead=h, input_type={"user": kind, "photo": kind}, exposure_prob=[1.0] * S)
+torch.manual_seed(1234)
+model = init_model(args, n_users=nu, n_items=ni, input_dim=D, max_vid_len=S, max_usr_len=Lt).to(dev)
+tr = Trainer(model, lr=1e-3, weight_decay=1e-4, comm=DPComm())
+batches = [{k: v.to(dev) for k, v in make_batch(B, S, Lt, D, n_users=nu, n_items=ni, seed=1234 + 1000 * i, features=kind == "image").items()} for i in range(8)]
+hits = collections.Counter()
+ratio = collections.defaultdict(float)
+orig = E.ParamStore.update_scales
+
+def spy(self, arena_t, site_names, n_rows):
+    if n_rows:
+        a = arena_t[:n_rows].detach().cpu()
+        for r in range(n_rows):
+            name = site_names[r]
+            if name is None:
+                continue
+            flag = a[r, 1].view(torch.int32).item()
+            s_used = float(a[r, 0])
+            amax = float(a[r, H.SITE_HDR:].max())
+            if flag:
+                hits[name] += 1
+                ratio[name] = max(ratio[name], amax * s_used / 65504.0)
+    return orig(self, arena_t, site_names, n_rows)
+
+E.ParamStore.update_scales = spy
+for i in range(steps):
+    tr.train_step(batches[i % 8])
+torch.cuda.synchronize()
+print("steps %d, overflow events per site (worst max*scale / 65504):" % steps)
+for k, v in hits.most_common():
+    print("  %-28s %4d   x%.2f" % (k, v, ratio[k]))
+print("total", sum(hits.values()), "counter", model._store.overflow_count())
