@@ -55,11 +55,12 @@ def _run(rank, world, port, name, q):
             dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name", ["img_d32_N3_alllosses", "both_fh2", "id_d32_N2"])      # id tables: sparse row exchange
-def test_two_ranks_equal_single_process(name):
+@pytest.mark.parametrize("name,ranks", [("img_d32_N3_alllosses", 2), ("both_fh2", 2), ("id_d32_N2", 2),      # id tables: sparse row exchange
+                                        ("img_d32_N3_alllosses", 4), ("id_d32_N2", 4)])                        # 4 ranks x 4 rows on the one GPU
+def test_two_ranks_equal_single_process(name, ranks):
     ctx = mp.get_context("spawn")
     results = {}
-    for world in (1, 2):
+    for world in (1, ranks):
         q = ctx.Queue()
         port = 29600 + (os.getpid() + world) % 300
         procs = [ctx.Process(target=_run, args=(r, world, port, name, q)) for r in range(world)]
@@ -70,7 +71,7 @@ def test_two_ranks_equal_single_process(name):
             p.join(60)
             assert p.exitcode == 0
         results[world] = res
-    (l1, g1, sd1, vm1), (l2, g2, sd2, vm2) = results[1], results[2]
+    (l1, g1, sd1, vm1), (l2, g2, sd2, vm2) = results[1], results[ranks]
     # validation after the 2 steps: parameters agree to lr-sized effects, so logits can differ in the last digits; the integer
     # leave ranks -- and with them HR@k / NDCG@k of the global batch -- are expected to coincide
     for k in vm1:
