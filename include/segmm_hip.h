@@ -220,6 +220,9 @@ int segmm_embed_id_usr(const int64_t* user_id, const float* table, int d, const 
                        int64_t n_rows, segmm_stream_t stream);
 int segmm_embed_id_bwd(const float* dpre, int tokens_per_row, int ld, int col0, int width, const int32_t* order,
                        const int64_t* ids, float* dtable, int B, int64_t n_rows, segmm_stream_t stream);
+/* order[k] = index of the k-th smallest id, equal ids in index order (torch.argsort(ids, stable=True), which
+ * segmm_embed_id_bwd needs as `order`); n <= 8192, one workgroup, no host sync. */
+int segmm_argsort_ids(const int64_t* ids, int n, int32_t* order, segmm_stream_t stream);
 int segmm_pe_grad(const float* dpre, int ld, int B, int S, int d, float* dpe, int accumulate, segmm_stream_t stream);
 
 /* The loss scalars of compute_loss (decoder_leave_focal.py:490-572) from the per-row terms segmm_loss_fwd_bwd wrote:

@@ -227,7 +227,7 @@ __global__ __launch_bounds__(512, 2) void mfma_rate_kernel(float* out, int iters
 extern "C" {
 
 const char* segmm_last_error(void) { return g_segmm_err; }
-int segmm_abi_version(void) { return 14; }
+int segmm_abi_version(void) { return 15; }
 
 static PlaneOut plane_out(uint16_t* planes, int ld2, float* hdr, const float* scale_in) {
     PlaneOut po;
@@ -812,6 +812,17 @@ int segmm_embed_id_bwd(const float* dpre, int tokens_per_row, int ld, int col0, 
     if (B <= 0) return 0;
     hipLaunchKernelGGL(embed_id_bwd_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, dpre, tokens_per_row, ld, col0, width,
                        (const int*)order, (const long long*)ids, dtable, B, (long long)n_rows);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int segmm_argsort_ids(const int64_t* ids, int n, int32_t* order, segmm_stream_t stream) {
+    SEGMM_REQUIRE(ids && order && n >= 0 && n <= ARGSORT_MAX, "argsort_ids: 0 <= n <= %d (n=%d)", ARGSORT_MAX, n);
+    if (n == 0) return 0;
+    int np2 = 2;
+    while (np2 < n) np2 <<= 1;
+    hipLaunchKernelGGL(argsort_ids_kernel, dim3(1), dim3(np2 >= 2048 ? 1024 : (np2 >= 128 ? np2 / 2 : 64)), (size_t)np2 * 8, (hipStream_t)stream,
+                       (const long long*)ids, n, np2, (int*)order);
     LAUNCH_CHECK();
     return 0;
 }

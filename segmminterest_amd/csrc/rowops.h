@@ -354,6 +354,34 @@ __global__ __launch_bounds__(256) void embed_id_usr_kernel(const long long* __re
     for (int c = threadIdx.x * 4; c < d; c += blockDim.x * 4)
         *(f32x4*)(out + (size_t)b * d + c) = (ok ? *(const f32x4*)(table + id * d + c) : f32x4{nan, nan, nan, nan}) + *(const f32x4*)(pe + c);
 }
+// order[k] = index of the k-th smallest id, ties in index order (a STABLE argsort, like torch.argsort(ids, stable=True)): one
+// workgroup, bitonic network over the 64-bit keys (id << 32 | index) in LDS, n <= 8192 (a data-parallel node of 8 ranks x 1024
+// rows).  Replaces the five ATen launches of torch.argsort on the id-mode step path.
+constexpr int ARGSORT_MAX = 8192;
+__global__ __launch_bounds__(1024) void argsort_ids_kernel(const long long* __restrict__ ids, int n, int npow2, int* __restrict__ order) {
+    extern __shared__ unsigned long long keys[];
+    for (int i = threadIdx.x; i < npow2; i += blockDim.x) {
+        // ids are row numbers of an embedding table (< 2^31); out-of-range ones sort by their low 31 bits + the sign bit, any
+        // fixed order is fine for them (the scatter kernel skips them).  Padding keys are larger than every real key.
+        const unsigned long long id = i < n ? ((unsigned long long)ids[i] & 0xFFFFFFFFull) ^ 0x80000000ull : 0xFFFFFFFFull;
+        keys[i] = i < n ? ((id << 32) | (unsigned)i) : 0xFFFFFFFFFFFFFFFFull;
+    }
+    __syncthreads();
+    for (int k = 2; k <= npow2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < (npow2 >> 1); t += blockDim.x) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));          // lower index of the pair (bit j clear)
+                const int l = i | j;
+                const bool up = (i & k) == 0;
+                const unsigned long long a = keys[i], b = keys[l];
+                if ((a > b) == up) { keys[i] = b; keys[l] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = threadIdx.x; i < n; i += blockDim.x) order[i] = (int)(keys[i] & 0xFFFFFFFFull);
+}
+
 // backward of the gathers: dense table gradients (torch.nn.Embedding semantics), deterministic and
 // sync-free: `order` = batch rows sorted by id (host-side torch.sort, no size-dependent output).
 // Workgroup k owns sorted position k; it is a segment head iff its id differs from position k-1,

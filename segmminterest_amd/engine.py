@@ -1268,11 +1268,11 @@ class BackboneRun:
                 rows.zero_()                                                               # the kernel accumulates into its output
                 H.embed_id_bwd(dpre, L, d, 0, width, ar32, ar, rows, B)                    # rows[b] = sum_s dpre[b, s, :width]
                 ids_all, rows_all = st.row_exchange(ids, rows)
-                order = torch.argsort(ids_all, stable=True).to(torch.int32)
+                order = _argsort_ids(ids_all)
                 H.embed_id_bwd(rows_all, 1, width, 0, width, order, ids_all, gtab, ids_all.numel())
                 touched = ids_all
             else:
-                order = torch.argsort(ids, stable=True).to(torch.int32)
+                order = _argsort_ids(ids)
                 H.embed_id_bwd(dpre, L, d, 0, width, order, ids, gtab, B)
                 touched = ids
             # (a dense all-reduce of the table under data parallelism adds the OTHER ranks' rows: no row list then)
@@ -1299,6 +1299,14 @@ class BackboneRun:
                 # bias gradient = sum over all tokens of dpre = sum over positions of the positional-embedding
                 # gradient just computed ([L, d] instead of a second pass over [B*L, d])
                 _colsum(st, gpe, d, L, d, st.g(P + "%s_proj.bias" % side, gbuf))
+
+
+def _argsort_ids(ids):
+    """Stable argsort of a batch's table ids as int32: the library's one-launch kernel up to 8192 ids, torch beyond."""
+    ids = ids.reshape(-1).contiguous()
+    if ids.numel() <= H.ARGSORT_MAX and ids.dtype == torch.int64:
+        return H.argsort_ids(ids)
+    return torch.argsort(ids, stable=True).to(torch.int32)
 
 
 def _group_view(store, first_name, numel, gbuf):

@@ -15,7 +15,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SEGMM_LIB") or os.path.join(_HERE, "libsegmm_hip.so")      # SEGMM_LIB: A/B builds of the kernels
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 _lib = None
 
@@ -59,6 +59,7 @@ SIGNATURES = {
     "segmm_embed_id_usr": [_p, _p, _i, _p, _p, _i, _i64, _p],
     "segmm_embed_id_bwd": [_p, _i, _i, _i, _i, _p, _p, _p, _i, _i64, _p],
     "segmm_pe_grad": [_p, _i, _i, _i, _i, _p, _i, _p],
+    "segmm_argsort_ids": [_p, _i, _p, _p],
     "segmm_label_stats": [_p, _i, _i, _i, _p, _p, _p, _p],
     "segmm_loss_fwd_bwd": [_i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p],
     "segmm_adamw": [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _i, _p],
@@ -486,6 +487,18 @@ def attn_bwd(B, H, dh, Lq, La, Lb, Qa, Qb, ldq, Ka, Va, ldka, Kb, Vb, ldkb, mq, 
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
         prof.append(("bwd" if phase == 0 else "bwd%d" % phase, B, H, dh, Lq, La, Lb, e0, e1))
+
+
+ARGSORT_MAX = 8192
+
+
+def argsort_ids(ids, out=None):
+    """Stable argsort of int64 ids (n <= ARGSORT_MAX) as int32, one launch (torch.argsort(ids, stable=True) is five)."""
+    n = ids.numel()
+    if out is None:
+        out = torch.empty((n,), dtype=torch.int32, device=ids.device)
+    _check(lib().segmm_argsort_ids(ids.data_ptr(), int(n), out.data_ptr(), _stream()), "segmm_argsort_ids")
+    return out
 
 
 def loss_finish(parts, B, coef, losses, total):

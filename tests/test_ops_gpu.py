@@ -173,6 +173,17 @@ def test_dropout_hash_rate_and_independence():
         assert abs(var - ref) < 0.02 * ref, (p, var, ref)
 
 
+@pytest.mark.parametrize("n", [1, 2, 7, 64, 1000, 1024, 4097, 8192])
+def test_argsort_ids_is_torch_stable_argsort(n):
+    H = _abi()
+    g = torch.Generator().manual_seed(n)
+    ids = torch.randint(0, max(2, n // 3), (n,), generator=g)          # many duplicates: stability matters
+    ids[::5] = torch.randint(0, 352495, (len(ids[::5]),), generator=g)
+    got = H.argsort_ids(ids.to(DEV))
+    ref = torch.argsort(ids, stable=True)
+    assert got.dtype == torch.int32 and torch.equal(got.cpu().long(), ref)
+
+
 def test_gemm_rejects_bad_shapes():
     H = _abi()
     A = torch.zeros(8, 6, device=DEV)
