@@ -223,6 +223,9 @@ int segmm_embed_id_bwd(const float* dpre, int tokens_per_row, int ld, int col0, 
 /* order[k] = index of the k-th smallest id, equal ids in index order (torch.argsort(ids, stable=True), which
  * segmm_embed_id_bwd needs as `order`); n <= 8192, one workgroup, no host sync. */
 int segmm_argsort_ids(const int64_t* ids, int n, int32_t* order, segmm_stream_t stream);
+/* table[ids[k], :] = 0 for k < n (ids outside [0, n_rows) are skipped): the rows a previous segmm_embed_id_bwd scattered into a
+ * dense [n_rows, width] table gradient, cleared without re-filling the table. */
+int segmm_zero_rows(float* table, int width, const int64_t* ids, int n, int64_t n_rows, segmm_stream_t stream);
 int segmm_pe_grad(const float* dpre, int ld, int B, int S, int d, float* dpe, int accumulate, segmm_stream_t stream);
 
 /* The loss scalars of compute_loss (decoder_leave_focal.py:490-572) from the per-row terms segmm_loss_fwd_bwd wrote:

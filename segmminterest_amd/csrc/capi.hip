@@ -827,6 +827,14 @@ int segmm_argsort_ids(const int64_t* ids, int n, int32_t* order, segmm_stream_t 
     return 0;
 }
 
+int segmm_zero_rows(float* table, int width, const int64_t* ids, int n, int64_t n_rows, segmm_stream_t stream) {
+    SEGMM_REQUIRE(table && ids && width > 0 && width % 4 == 0 && aligned16(table) && n_rows > 0, "zero_rows: arguments");
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(zero_rows_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, table, width, (const long long*)ids, (long long)n_rows);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 int segmm_pe_grad(const float* dpre, int ld, int B, int S, int d, float* dpe, int accumulate, segmm_stream_t stream) {
     SEGMM_REQUIRE(dpre && dpe && d % 4 == 0 && ld % 4 == 0 && aligned16(dpre) && aligned16(dpe), "pe_grad: pointer/alignment");
     if (S <= 0) return 0;

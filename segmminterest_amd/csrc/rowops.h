@@ -382,6 +382,14 @@ __global__ __launch_bounds__(1024) void argsort_ids_kernel(const long long* __re
     for (int i = threadIdx.x; i < n; i += blockDim.x) order[i] = (int)(keys[i] & 0xFFFFFFFFull);
 }
 
+// table[ids[k]][:] = 0 for every k (ids outside the table are skipped): clears the rows the previous step scattered into a
+// dense embedding-table gradient instead of re-filling the whole table
+__global__ __launch_bounds__(64) void zero_rows_kernel(float* __restrict__ table, int width, const long long* __restrict__ ids, long long n_rows) {
+    const long long id = ids[blockIdx.x];
+    if (id < 0 || id >= n_rows) return;
+    for (int c = threadIdx.x * 4; c < width; c += 256) *(f32x4*)(table + id * width + c) = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
 // backward of the gathers: dense table gradients (torch.nn.Embedding semantics), deterministic and
 // sync-free: `order` = batch rows sorted by id (host-side torch.sort, no size-dependent output).
 // Workgroup k owns sorted position k; it is a segment head iff its id differs from position k-1,

@@ -236,6 +236,14 @@ class ParamStore:
             t = c[key] = torch.arange(n, device=self.flat.device, dtype=dtype)
         return t
 
+    def const_ones(self, shape, dtype) -> torch.Tensor:
+        c = self.__dict__.setdefault("_consts", {})
+        key = ("ones", tuple(shape), dtype, self.flat.device)
+        t = c.get(key)
+        if t is None:
+            t = c[key] = torch.ones(tuple(shape), device=self.flat.device, dtype=dtype)
+        return t
+
     def scales(self) -> torch.Tensor:
         if self.site_scale is None or self.site_scale.device != self.flat.device:
             self.site_scale = torch.zeros((self.MAX_SITES + 8,), dtype=torch.float32, device=self.flat.device)
@@ -841,7 +849,7 @@ class BackboneRun:
             if usr_feat.dim() != 1:
                 raise RuntimeError("id-mode user input must be [B] ids (encoder.py:478-481)")
             Lt = 1
-            um = torch.ones((B, 1), dtype=torch.uint8, device=vm.device)          # encoder.py:481
+            um = self.store.const_ones((B, 1), torch.uint8)          # encoder.py:481 (made once: a constant)
         else:
             if usr_feat.dim() != 3:
                 raise RuntimeError("image-mode user input must be [B,Lt,D]")
@@ -1254,7 +1262,7 @@ class BackboneRun:
             # (AdamW reads it, nobody else writes it): clear those rows instead of filling the whole table again
             prev = st._tab_rows.get(P + side)
             if gbuf is None and prev is not None and prev[0] == gtab.data_ptr() and prev[1].device == gtab.device:
-                gtab.index_fill_(0, prev[1], 0.0)
+                H.zero_rows(gtab, prev[1])
             else:
                 gtab.zero_()
             st._tab_rows.pop(P + side, None)
@@ -1277,7 +1285,7 @@ class BackboneRun:
                 touched = ids
             # (a dense all-reduce of the table under data parallelism adds the OTHER ranks' rows: no row list then)
             if gbuf is None and (st.bucket_hook is None or st.row_exchange is not None):
-                st._tab_rows[P + side] = (gtab.data_ptr(), touched.reshape(-1).clamp(0, gtab.shape[0] - 1))
+                st._tab_rows[P + side] = (gtab.data_ptr(), touched.reshape(-1))          # (zero_rows skips ids outside the table)
             if side == "vid":
                 dh_ = d // 2
                 _colsum(st, gpe, d, L, dh_, st.g(P + "frameid_proj.bias", gbuf), x_off=dh_)

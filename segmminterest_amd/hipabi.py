@@ -60,6 +60,7 @@ SIGNATURES = {
     "segmm_embed_id_bwd": [_p, _i, _i, _i, _i, _p, _p, _p, _i, _i64, _p],
     "segmm_pe_grad": [_p, _i, _i, _i, _i, _p, _i, _p],
     "segmm_argsort_ids": [_p, _i, _p, _p],
+    "segmm_zero_rows": [_p, _i, _p, _i, _i64, _p],
     "segmm_label_stats": [_p, _i, _i, _i, _p, _p, _p, _p],
     "segmm_loss_fwd_bwd": [_i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p],
     "segmm_adamw": [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _i, _p],
@@ -499,6 +500,13 @@ def argsort_ids(ids, out=None):
         out = torch.empty((n,), dtype=torch.int32, device=ids.device)
     _check(lib().segmm_argsort_ids(ids.data_ptr(), int(n), out.data_ptr(), _stream()), "segmm_argsort_ids")
     return out
+
+
+def zero_rows(table, ids):
+    """table[ids, :] = 0 (2-D float32 table, int64 ids; ids outside the table are skipped), one launch."""
+    ids = ids.reshape(-1)
+    _check(lib().segmm_zero_rows(table.data_ptr(), int(table.shape[1]), ids.data_ptr(), int(ids.numel()), int(table.shape[0]), _stream()),
+           "segmm_zero_rows")
 
 
 def loss_finish(parts, B, coef, losses, total):
