@@ -11,7 +11,7 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 cfg = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 dev = torch.device("cuda", 0)
 if cfg == 2:
-    B, S, D, N, Lt, h, kind, nu, ni = 512, 40, 768, 2, 100, 16, "image", 1, 1
+    B, S, D, N, Lt, h, kind, nu, ni = int(os.environ.get("OVF_B", "512")), 40, 768, 2, 100, 16, "image", 1, 1
 else:
     B, S, D, N, Lt, h, kind, nu, ni = 1024, 20, 512, 4, 1, 16, "id", 30000, 352494
 args = default_args(num_layers_enc=N, d_model=D, nhead=h, input_type={"user": kind, "photo": kind}, exposure_prob=[1.0] * S)
