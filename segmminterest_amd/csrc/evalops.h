@@ -184,8 +184,8 @@ __global__ __launch_bounds__(256) void gather_l1_kernel(const float* __restrict_
 // arena: n_rows site headers of the pass that just ended; site_idx[r] = index of row r's tensor site in site_scale (< 0:
 // none).  For every row that was produced (max > 0): site_scale[idx] = the power of two s with max * s in
 // [2^(target-1), 2^target) -- the scale the NEXT pass writes this site's planes with (fp16 tops out at 2^16: target 12
-// leaves a factor 16 of head-room for step-to-step growth; an overflow beyond that is flagged by the producer and
-// handled by the consumers' fp32 path).  stats[0] += rows whose overflow flag was raised (diagnostics / tests).
+// leaves head-room for step-to-step growth AND shrinkage; a tensor that leaves the window is refused by the consumers, which
+// take their fp32 path).  stats[0] += rows whose planes were outside the window (diagnostics / tests).
 __global__ __launch_bounds__(256) void scales_update_kernel(const float* __restrict__ arena, const int* __restrict__ site_idx, int n_rows,
                                                             float* site_scale, float* stats, int target) {
     const int lane = threadIdx.x & 63;
@@ -204,7 +204,9 @@ __global__ __launch_bounds__(256) void scales_update_kernel(const float* __restr
             se = max(-60, min(60, se));
             site_scale[idx] = __uint_as_float((uint32_t)(se + 127) << 23);
         }
-        if (__float_as_uint(hdr[1]) != 0u) atomicAdd(stats, 1.0f);
+        // tensors whose planes the consumers had to refuse: overflow flag up, or the maximum below the window (site_planes_ok)
+        const float s_used = hdr[0];
+        if (__float_as_uint(hdr[1]) != 0u || (s_used > 0.f && m > 0.f && m * s_used < 0.25f)) atomicAdd(stats, 1.0f);
     }
 }
 

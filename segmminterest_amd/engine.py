@@ -176,11 +176,12 @@ class ParamStore:
         # activation / gradient of the model), refreshed at the end of every pass from the maxima that pass recorded
         # (segmm_scales_update); a site is "calibrated" once it has been produced at least once
         self.scaling = os.environ.get("SEGMM_SCALING", "delayed")      # delayed | exact (split pass after every producer) | always
-        # the scale puts the maxima of the LAST pass at 2^target.  8 = 128x headroom to the fp16 range: the attention-backward
-        # gradients of a nearly converged BPR model jump up to 45x from one batch to the next (tools/overflow_sites.py; with
-        # target 12 = 16x headroom a 400-step run took the in-kernel fallback 38 times).  Costs no accuracy: an element keeps
-        # max(2^-22 |x|, 2^-32 max) instead of max(2^-22 |x|, 2^-36 max)
-        self.scale_target = int(os.environ.get("SEGMM_SCALE_TARGET", "8"))
+        # the scale puts the maxima of the LAST pass at 2^target, in the middle of the window the consumers accept
+        # (gemm_planes.h site_planes_ok: 2^-2 <= max * s < 2^16): 7 = 256x of headroom before an element overflows fp16 and
+        # 512x before the lo terms of a SHRUNKEN tensor sink into the subnormals; outside the window the consuming GEMM takes
+        # its fp32 fallback.  The attention-backward gradients of a nearly converged BPR model jump up to 45x from one batch to
+        # the next (tools/overflow_sites.py; target 12 = 16x headroom took the fallback 38 times in 400 steps).
+        self.scale_target = int(os.environ.get("SEGMM_SCALE_TARGET", "7"))
         self.site_index: Dict[str, int] = {}
         self.site_scale = None          # [MAX_SITES + 8] floats: scales, then [MAX_SITES] = count of overflowed tensors
         self.calibrated = set()

@@ -408,3 +408,40 @@ def test_site_header_ring_wraps_cleanly():
     assert res[0][0] == res[1][0]
     assert torch.equal(res[0][1], res[1][1])
     assert res[0][2] == res[1][2] == 0
+
+
+def test_delayed_scaling_survives_a_magnitude_drop():
+    """The opposite of the jump: a GEMM operand 2^20 times SMALLER than in the calibration pass.  Its delayed scale would leave
+    the values deep in fp16's subnormals (12 bits instead of 22, silently); the consuming GEMMs see the complete maxima, refuse
+    the planes and take the fp32 copy, so the result still equals exact scaling."""
+    from segmminterest_amd import hipabi as H
+    if H.GEMM_ENGINE != H.ENGINE_F16X3P:
+        pytest.skip("plane engine only")
+    cfg, g, _, _ = load_case("img_d32_N2")
+    model = build_model(cfg)
+    model.load_state_dict(g["sd"])
+    model = model.cuda().eval()
+    st = model._store
+    inp = {k: v.clone() for k, v in g["in"].items()}
+    big = dict(model.backbone1.named_parameters())
+
+    def fwd():
+        with torch.no_grad():
+            return call_model(model, inp, "inference", DEV)["logits"].clone()
+
+    st.scaling = "always"
+    fwd()
+    fwd()
+    n0 = st.overflow_count()
+    with torch.no_grad():
+        big["encoder.layers.0.cross_attn.ln_vid.weight"].mul_(2.0 ** -20)      # X1 of layer 0 (a GEMM operand) shrinks 2^20 x
+        big["encoder.layers.0.cross_attn.ln_vid.bias"].mul_(2.0 ** -20)
+    got = fwd()                                # stale scale: the tensor sits 2^20 below where the scale expects it
+    assert st.overflow_count() > n0            # counted as refused planes
+    n = st.overflow_count()
+    got2 = fwd()                               # rescaled by the end-of-pass update
+    assert st.overflow_count() == n
+    st.scaling = "exact"
+    ref = fwd()
+    tol = 1e-5 * max(1.0, float(ref.abs().max()))
+    assert torch.isfinite(got).all() and float((got - ref).abs().max()) <= tol and float((got2 - ref).abs().max()) <= tol
