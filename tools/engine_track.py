@@ -19,6 +19,6 @@ for eng, name in ((H.ENGINE_F32, "f32"), (H.ENGINE_F16X3P, "f16x3p")):
     model = init_model(args, input_dim=D, max_vid_len=S, max_usr_len=Lt).to(dev)
     tr = Trainer(model, lr=1e-3, weight_decay=1e-4, comm=DPComm(), dropout=False)
     curves[name] = [float(tr.train_step(batches[i % 6])["loss"].detach()) for i in range(steps)]
-for i in (0, 1, 5, 10, 25, 50, 100, steps - 1):
+for i in sorted(set([0, 1, 5, 10, 25, 50] + list(range(100, steps, 6)) + [steps - 1])):
     a, b = curves["f32"][i], curves["f16x3p"][i]
     print("step %4d  f32 %.6f  f16x3p %.6f  rel diff %.2e" % (i, a, b, abs(a - b) / max(abs(a), 1e-9)))
