@@ -11,7 +11,7 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 cfg = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 dev = torch.device("cuda", 0)
 if cfg == 2:
-    B, S, D, N, Lt, h, kind, nu, ni = int(os.environ.get("OVF_B", "512")), 40, 768, 2, 100, 16, "image", 1, 1
+    B, S, D, N, Lt, h, kind, nu, ni = int(os.environ.get("OVF_B", "512")), 40, int(os.environ.get("OVF_D", "768")), int(os.environ.get("OVF_N", "2")), 100, 16, "image", 1, 1
 else:
     B, S, D, N, Lt, h, kind, nu, ni = 1024, 20, 512, 4, 1, 16, "id", 30000, 352494
 args = default_args(num_layers_enc=N, d_model=D, nhead=h, input_type={"user": kind, "photo": kind}, exposure_prob=[1.0] * S)
@@ -33,16 +33,18 @@ def spy(self, arena_t, site_names, n_rows):
             flag = a[r, 1].view(torch.int32).item()
             s_used = float(a[r, 0])
             amax = float(a[r, H.SITE_HDR:].max())
-            if flag:
-                hits[name] += 1
-                ratio[name] = max(ratio[name], amax * s_used / 65504.0)
+            under = s_used > 0 and amax > 0 and amax * s_used < 0.25
+            if flag or under:
+                hits[name + (" (under)" if under and not flag else "")] += 1
+                key = name + (" (under)" if under and not flag else "")
+                ratio[key] = max(ratio[key], amax * s_used / 65504.0) if not under or flag else max(ratio[key], 0.25 / (amax * s_used))
     return orig(self, arena_t, site_names, n_rows)
 
 E.ParamStore.update_scales = spy
 for i in range(steps):
     tr.train_step(batches[i % 8])
 torch.cuda.synchronize()
-print("steps %d, overflow events per site (worst max*scale / 65504):" % steps)
+print("steps %d, window exits per site (overflow: worst max*scale / 65504; under: worst 0.25 / (max*scale)):" % steps)
 for k, v in hits.most_common():
     print("  %-28s %4d   x%.2f" % (k, v, ratio[k]))
 print("total", sum(hits.values()), "counter", model._store.overflow_count())
