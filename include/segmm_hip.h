@@ -230,8 +230,11 @@ int segmm_pe_grad(const float* dpre, int ld, int B, int S, int d, float* dpe, in
 
 /* The loss scalars of compute_loss (decoder_leave_focal.py:490-572) from the per-row terms segmm_loss_fwd_bwd wrote:
  * losses[c] = sum_b parts[b][c] for the 12 loss slots and total[0] = sum_c coef[c] * losses[c] (the weighted sum of
- * :560-571), one launch, fixed summation order. */
-int segmm_loss_finish(const float* parts, int B, const float* coef, float* losses, float* total, segmm_stream_t stream);
+ * :560-571), one launch, fixed summation order.  dlogits != NULL (the n_dl values of d loss / d logits): also gmax[0] = their
+ * largest magnitude, and site_scale[i] for every i < n_sites with gain[i] > 0 becomes the power of two that puts gain[i] * gmax at
+ * 2^target -- the delayed scales of the BACKWARD tensors, which are linear in d loss / d logits (see segmm_scales_update). */
+int segmm_loss_finish(const float* parts, int B, const float* coef, float* losses, float* total, const float* dlogits, int64_t n_dl,
+                      float* site_scale, const float* gain, int n_sites, float* gmax, int target, segmm_stream_t stream);
 
 /* K8 -- compute_loss forward + backward in one launch (decoder_leave_focal.py:490-572).
  * part order: 0 interestBPR 1 focal 2 surviveCE 3 interestCE 4 interestKL 5 huber 6 hazard 7 mse 8 mse2.
@@ -277,9 +280,10 @@ int segmm_gather_l1(const float* table, int64_t n_lines, int D, const int64_t* i
                     uint8_t* mask, float* amax, uint16_t* planes, int ld2, float* hdr, const float* scale_in, segmm_stream_t stream);
 /* Delayed scaling, end of a pass: arena = the pass's n_rows site headers, site_idx[r] = index of row r's tensor site in
  * site_scale (< 0: none).  site_scale[idx] = the power of two s with max|x| * s in [2^(target-1), 2^target) for every row
- * that was produced; stats[0] += number of rows whose overflow flag is up. */
+ * that was produced; stats[0] += number of rows whose planes were outside the fp16 window.  gain / gmax non-NULL (backward pass):
+ * also gain[idx] = max|x| / gmax[0] (segmm_loss_finish turns it into the next step's scale). */
 int segmm_scales_update(const float* arena, const int32_t* site_idx, int n_rows, float* site_scale, float* stats, int target,
-                        segmm_stream_t stream);
+                        float* gain, const float* gmax, segmm_stream_t stream);
 /* DIAGNOSTIC, not part of the reference path: launches `workgroups` x 512 threads that issue `iters` x 48 v_mfma_f32_32x32x16_f16
  * per wave on random operand bits (registers only, the plane GEMM's accumulator order and occupancy); *flops_out = the fp16 MFMA
  * FLOPs of the launch.  bench.py times it to report the SUSTAINED matrix-core rate of the part beside the datasheet peak

@@ -227,7 +227,7 @@ __global__ __launch_bounds__(512, 2) void mfma_rate_kernel(float* out, int iters
 extern "C" {
 
 const char* segmm_last_error(void) { return g_segmm_err; }
-int segmm_abi_version(void) { return 15; }
+int segmm_abi_version(void) { return 16; }
 
 static PlaneOut plane_out(uint16_t* planes, int ld2, float* hdr, const float* scale_in) {
     PlaneOut po;
@@ -851,9 +851,12 @@ int segmm_label_stats(const int64_t* gt, int B, int S, int rewritten, float* v, 
     return 0;
 }
 
-int segmm_loss_finish(const float* parts, int B, const float* coef, float* losses, float* total, segmm_stream_t stream) {
+int segmm_loss_finish(const float* parts, int B, const float* coef, float* losses, float* total, const float* dlogits, int64_t n_dl,
+                      float* site_scale, const float* gain, int n_sites, float* gmax, int target, segmm_stream_t stream) {
     SEGMM_REQUIRE(parts && coef && losses && total && B > 0, "loss_finish: arguments");
-    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, parts, B, coef, losses, total);
+    SEGMM_REQUIRE(!dlogits || (site_scale && gain && gmax && n_sites >= 0 && n_dl >= 0 && target >= 2 && target <= 15), "loss_finish: scale arguments");
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, parts, B, coef, losses, total, dlogits, (long long)n_dl,
+                       site_scale, gain, n_sites, gmax, target);
     LAUNCH_CHECK();
     return 0;
 }
@@ -936,11 +939,11 @@ int segmm_survival(const float* interest, int ld, const int64_t* gt, float* surv
 }
 
 int segmm_scales_update(const float* arena, const int32_t* site_idx, int n_rows, float* site_scale, float* stats, int target,
-                        segmm_stream_t stream) {
-    SEGMM_REQUIRE(arena && site_idx && site_scale && stats && n_rows >= 0 && target >= 2 && target <= 15, "scales_update: arguments");
+                        float* gain, const float* gmax, segmm_stream_t stream) {
+    SEGMM_REQUIRE(arena && site_idx && site_scale && stats && n_rows >= 0 && target >= 2 && target <= 15 && (!gain == !gmax), "scales_update: arguments");
     if (n_rows == 0) return 0;
     hipLaunchKernelGGL(scales_update_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, arena, (const int*)site_idx, n_rows,
-                       site_scale, stats, target);
+                       site_scale, stats, target, gain, gmax);
     LAUNCH_CHECK();
     return 0;
 }

@@ -186,8 +186,11 @@ __global__ __launch_bounds__(256) void gather_l1_kernel(const float* __restrict_
 // [2^(target-1), 2^target) -- the scale the NEXT pass writes this site's planes with (fp16 tops out at 2^16: target 12
 // leaves head-room for step-to-step growth AND shrinkage; a tensor that leaves the window is refused by the consumers, which
 // take their fp32 path).  stats[0] += rows whose planes were outside the window (diagnostics / tests).
+// gain != null (the BACKWARD pass): also gain[idx] = max|x| / gmax[0], the site's size relative to the largest d loss / d logits
+// of the step it was measured in -- every backward tensor is linear in d loss / d logits, so the next step predicts its maximum
+// as gain * (that step's gmax) (loss_finish_kernel) instead of assuming it repeats.
 __global__ __launch_bounds__(256) void scales_update_kernel(const float* __restrict__ arena, const int* __restrict__ site_idx, int n_rows,
-                                                            float* site_scale, float* stats, int target) {
+                                                            float* site_scale, float* stats, int target, float* gain, const float* gmax) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (r >= n_rows) return;
@@ -203,6 +206,7 @@ __global__ __launch_bounds__(256) void scales_update_kernel(const float* __restr
             int se = (target - 1) - ((int)(u >> 23) - 127);
             se = max(-60, min(60, se));
             site_scale[idx] = __uint_as_float((uint32_t)(se + 127) << 23);
+            if (gain) gain[idx] = gmax[0] > 0.f ? m / gmax[0] : 0.f;
         }
         // tensors whose planes the consumers had to refuse: overflow flag up, or the maximum below the window (site_planes_ok)
         const float s_used = hdr[0];

@@ -227,9 +227,37 @@ __global__ __launch_bounds__(1024) void label_stats_kernel(const long long* __re
 
 // losses[c] = sum_b parts[b][c] (c < 12) and total[0] = sum_c coef[c] * losses[c], one workgroup, fixed summation order:
 // replaces a column-sum launch pair + a dot-product launch between the loss kernel and the backward.
+// dlogits != null (plane engine, training): also gmax[0] = max |d loss / d logits| of this step, and every site with a recorded
+// gain (scales_update_kernel) gets the delayed scale that puts gain * gmax at 2^target -- the backward tensors are linear in
+// d loss / d logits, so a batch whose loss has collapsed (or spiked) no longer throws them out of the fp16 window.
 __global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restrict__ parts, int B, const float* __restrict__ coef,
-                                                          float* __restrict__ losses, float* __restrict__ total) {
+                                                          float* __restrict__ losses, float* __restrict__ total,
+                                                          const float* __restrict__ dlogits, long long n_dl, float* site_scale,
+                                                          const float* __restrict__ gain, int n_sites, float* gmax, int target) {
     __shared__ float red[16][16];
+    if (dlogits) {
+        __shared__ float gred[4];
+        float g = 0.f;
+        for (long long i = threadIdx.x; i < n_dl; i += blockDim.x) g = fmaxf(g, fabsf(dlogits[i]));
+        g = wave_max(g);
+        if ((threadIdx.x & 63) == 0) gred[threadIdx.x >> 6] = g;
+        __syncthreads();
+        g = fmaxf(fmaxf(gred[0], gred[1]), fmaxf(gred[2], gred[3]));
+        if (threadIdx.x == 0) gmax[0] = g;
+        const uint32_t gu = __float_as_uint(g);
+        if (g > 0.f && (gu >> 23) != 0xff) {
+            for (int i = threadIdx.x; i < n_sites; i += blockDim.x) {
+                const float pred = gain[i] * g;
+                const uint32_t u = __float_as_uint(pred);
+                if (gain[i] > 0.f && pred > 0.f && (u >> 23) != 0xff && (u >> 23) != 0) {
+                    int se = (target - 1) - ((int)(u >> 23) - 127);
+                    se = max(-60, min(60, se));
+                    site_scale[i] = __uint_as_float((uint32_t)(se + 127) << 23);
+                }
+            }
+        }
+        __syncthreads();
+    }
     const int c = threadIdx.x & 15, r0 = threadIdx.x >> 4;
     float a = 0.f;
     if (c < 12)

@@ -107,7 +107,13 @@ class HeadLossFn(torch.autograd.Function):
                        v_all, v2_all, v_all.numel(), logits, dlogits, parts)
         losses = torch.empty(12, device=raw.device)
         total = torch.empty((), device=raw.device)
-        H.loss_finish(parts, B, model._coef_tensor(raw.device), losses, total)      # sum_b parts and sum_i coef_i * loss_i, one launch
+        # sum_b parts and sum_i coef_i * loss_i in one launch -- which, on the plane engine in training, also takes max|dlogits| and
+        # sets the delayed scales of the backward tensors relative to it (engine.ParamStore.update_scales(backward=True))
+        rel = st.engine_p and st.loss_relative and model.training and st.scaling != "exact"
+        st._gmax_fresh = bool(rel)
+        H.loss_finish(parts, B, model._coef_tensor(raw.device), losses, total, dlogits=dlogits if rel else None,
+                      site_scale=st.scales() if rel else None, gain=st.gains() if rel else None, n_sites=st.MAX_SITES if rel else 0,
+                      gmax=st.gmax() if rel else None, target=st.scale_target)
         ctx.dlogits = dlogits
         ctx.mark_non_differentiable(losses, logits)
         return total, losses, logits

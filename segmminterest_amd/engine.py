@@ -182,6 +182,8 @@ class ParamStore:
         # its fp32 fallback.  The attention-backward gradients of a nearly converged BPR model jump up to 45x from one batch to
         # the next (tools/overflow_sites.py; target 12 = 16x headroom took the fallback 38 times in 400 steps).
         self.scale_target = int(os.environ.get("SEGMM_SCALE_TARGET", "7"))
+        # backward sites: scale predicted from the site's recorded gain x THIS step's max |d loss / d logits| (they are linear in it)
+        self.loss_relative = os.environ.get("SEGMM_LOSS_RELATIVE", "1") != "0"
         self.site_index: Dict[str, int] = {}
         self.site_scale = None          # [MAX_SITES + 8] floats: scales, then [MAX_SITES] = count of overflowed tensors
         self.calibrated = set()
@@ -247,7 +249,8 @@ class ParamStore:
 
     def scales(self) -> torch.Tensor:
         if self.site_scale is None or self.site_scale.device != self.flat.device:
-            self.site_scale = torch.zeros((self.MAX_SITES + 8,), dtype=torch.float32, device=self.flat.device)
+            # [0, MAX): scales | [MAX, MAX + 8): counters | [MAX + 8, 2 MAX + 8): loss-relative gains of the backward sites | gmax
+            self.site_scale = torch.zeros((2 * self.MAX_SITES + 16,), dtype=torch.float32, device=self.flat.device)
             self.calibrated = set()
         return self.site_scale
 
@@ -258,8 +261,16 @@ class ParamStore:
             return None
         return self.scales().data_ptr() + 4 * self.site(name)
 
-    def update_scales(self, arena_t, site_names, n_rows):
-        """End of a pass: fold the pass's partial maxima into the site scales (one tiny launch)."""
+    def gains(self) -> torch.Tensor:
+        return self.scales()[self.MAX_SITES + 8:2 * self.MAX_SITES + 8]
+
+    def gmax(self) -> torch.Tensor:
+        return self.scales()[2 * self.MAX_SITES + 8:2 * self.MAX_SITES + 9]
+
+    def update_scales(self, arena_t, site_names, n_rows, backward=False):
+        """End of a pass: fold the pass's partial maxima into the site scales (one tiny launch).  ``backward``: also record every
+        site's size relative to this step's max |d loss / d logits| (the head's loss_finish launch predicts the next step's
+        scale from it)."""
         if n_rows == 0 or not self.engine_p:
             return
         key = tuple(site_names[:n_rows])
@@ -268,7 +279,11 @@ class ParamStore:
             idx = self._site_idx_cache[key] = torch.tensor([-1 if n is None else self.site(n) for n in key], dtype=torch.int32,
                                                            device=arena_t.device)
         sc = self.scales()
-        H.scales_update(arena_t, idx, n_rows, sc, sc[self.MAX_SITES:], self.scale_target)
+        rel = backward and self.loss_relative and self.__dict__.get("_gmax_fresh", False)      # the head measured gmax in THIS step
+        if backward:
+            self._gmax_fresh = False
+        H.scales_update(arena_t, idx, n_rows, sc, sc[self.MAX_SITES:], self.scale_target, gain=self.gains() if rel else None,
+                        gmax=self.gmax() if rel else None)
         self.calibrated.update(n for n in key if n is not None)
 
     def overflow_count(self) -> int:
@@ -622,10 +637,10 @@ class AmaxArena:
         self.sites.append(site)
         return r
 
-    def close(self, store):
+    def close(self, store, backward=False):
         """End of the pass: the site scales of the next pass."""
         if self.t is not None:
-            store.update_scales(self.t, self.sites, self.i)
+            store.update_scales(self.t, self.sites, self.i, backward=backward)
 
 
 def new_act(store, arena, rows, cols, t=None, key=None, planes=True, site=None, delayed=False):
@@ -1242,7 +1257,7 @@ class BackboneRun:
         finish_act(st, produced(dpre_v))
         self._embed_bwd("vid", dpre_v, B, S, gbuf)
         join_side(st)
-        self.amb.close(st)
+        self.amb.close(st, backward=True)
         if on_bucket is not None:
             on_bucket(P + "embed")
 

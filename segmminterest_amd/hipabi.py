@@ -15,7 +15,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SEGMM_LIB") or os.path.join(_HERE, "libsegmm_hip.so")      # SEGMM_LIB: A/B builds of the kernels
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 _lib = None
 
@@ -31,9 +31,9 @@ SIGNATURES = {
                      _p, _i64, _p, _i64, _p, _i, _p, _i, _p, _p],
     "segmm_gemm_p": [_i, _i, _i, _i, _p, _i, _p, _p, _i, _p, _i, _p, _p, _i, _p, _i, _p, _i, _p, _p, _i, _p, _p, _p, _i, _i, _i, _p, _i, _f, _u64,
                      _u32, _i, _p, _i, _p, _p],
-    "segmm_scales_update": [_p, _p, _i, _p, _p, _i, _p],
+    "segmm_scales_update": [_p, _p, _i, _p, _p, _i, _p, _p, _p],
     "segmm_probe_mfma_rate": [_i, _i, _p, _p, _p],
-    "segmm_loss_finish": [_p, _i, _p, _p, _p, _p],
+    "segmm_loss_finish": [_p, _i, _p, _p, _p, _p, _i64, _p, _p, _i, _p, _i, _p],
     "segmm_split_p32": [_p, _i64, _i, _i, _p, _i, _p, _i, _p],
     "segmm_split_p32_transpose": [_p, _i, _i, _i, _p, _i, _p, _p],
     "segmm_wsplit_p32": [_p, _p, _i, _i, _p, _p, _p, _p],
@@ -346,9 +346,9 @@ def gemm_p(layout, M, N, K, A: "PT", B: "PT", Cout, ldc, c_pt: "PT" = None, writ
         prof.append((layout, M, N, K, e0, e1))
 
 
-def scales_update(arena, site_idx, n_rows, site_scale, stats, target=12):
+def scales_update(arena, site_idx, n_rows, site_scale, stats, target=12, gain=None, gmax=None):
     _check(lib().segmm_scales_update(arena.data_ptr(), site_idx.data_ptr(), int(n_rows), site_scale.data_ptr(), stats.data_ptr(), int(target),
-                                     _stream()), "segmm_scales_update")
+                                     _ptr(gain), _ptr(gmax), _stream()), "segmm_scales_update")
 
 
 def mfma_sustained_tflops(ms_target=25.0):
@@ -509,9 +509,12 @@ def zero_rows(table, ids):
            "segmm_zero_rows")
 
 
-def loss_finish(parts, B, coef, losses, total):
-    """losses[12] = column sums of parts[B, 12]; total[0] = coef . losses (one launch)."""
-    _check(lib().segmm_loss_finish(_ptr(parts), int(B), _ptr(coef), _ptr(losses), _ptr(total), _stream()), "segmm_loss_finish")
+def loss_finish(parts, B, coef, losses, total, dlogits=None, site_scale=None, gain=None, n_sites=0, gmax=None, target=7):
+    """losses[12] = column sums of parts[B, 12]; total[0] = coef . losses (one launch).  With ``dlogits``: also the step's
+    max |d loss / d logits| and the loss-relative delayed scales of the backward sites (segmm_loss_finish)."""
+    _check(lib().segmm_loss_finish(_ptr(parts), int(B), _ptr(coef), _ptr(losses), _ptr(total), _ptr(dlogits),
+                                   0 if dlogits is None else int(dlogits.numel()), _ptr(site_scale), _ptr(gain), int(n_sites), _ptr(gmax),
+                                   int(target), _stream()), "segmm_loss_finish")
 
 
 def rowdot(x, ld, w, bias, out, rows, d, accumulate=False, x_off=0, w_off=0):
