@@ -23,7 +23,7 @@ hits = collections.Counter()
 ratio = collections.defaultdict(float)
 orig = E.ParamStore.update_scales
 
-def spy(self, arena_t, site_names, n_rows):
+def spy(self, arena_t, site_names, n_rows, backward=False):
     if n_rows:
         a = arena_t[:n_rows].detach().cpu()
         for r in range(n_rows):
@@ -38,7 +38,7 @@ def spy(self, arena_t, site_names, n_rows):
                 hits[name + (" (under)" if under and not flag else "")] += 1
                 key = name + (" (under)" if under and not flag else "")
                 ratio[key] = max(ratio[key], amax * s_used / 65504.0) if not under or flag else max(ratio[key], 0.25 / (amax * s_used))
-    return orig(self, arena_t, site_names, n_rows)
+    return orig(self, arena_t, site_names, n_rows, backward=backward)
 
 E.ParamStore.update_scales = spy
 for i in range(steps):
