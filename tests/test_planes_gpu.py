@@ -445,3 +445,33 @@ def test_delayed_scaling_survives_a_magnitude_drop():
     ref = fwd()
     tol = 1e-5 * max(1.0, float(ref.abs().max()))
     assert torch.isfinite(got).all() and float((got - ref).abs().max()) <= tol and float((got2 - ref).abs().max()) <= tol
+
+
+def test_backward_scales_follow_the_loss_gradient():
+    """A memorising run (tiny batches, large learning rate) whose BPR loss collapses on some batches: the gradients of
+    consecutive steps differ by many orders of magnitude.  With the backward sites' delayed scales tied to the step's
+    max |d loss / d logits| no tensor leaves the fp16 window; with repeat-the-last-maximum scales (SEGMM_LOSS_RELATIVE=0
+    semantics) they do, and the consumers' fallback keeps the results equal anyway."""
+    from segmminterest_amd import hipabi as H
+    if H.GEMM_ENGINE != H.ENGINE_F16X3P:
+        pytest.skip("plane engine only")
+    from segmminterest_amd.synth import make_batch
+    from segmminterest_amd.trainer import Trainer, default_args, init_model
+    B, S, Lt, D, N = 8, 20, 6, 64, 3
+    margs = default_args(num_layers_enc=N, d_model=D, nhead=4, input_type={"user": "image", "photo": "image"}, exposure_prob=[1.0] * S)
+    batches = [{k: v.cuda() for k, v in make_batch(B, S, Lt, D, seed=60 + i).items()} for i in range(3)]
+    res = {}
+    for rel in (True, False):
+        torch.manual_seed(3)
+        model = init_model(margs, n_users=1, n_items=1, input_dim=D, max_vid_len=S, max_usr_len=Lt).cuda()
+        tr = Trainer(model, lr=3e-3, dropout=False)
+        model._store.loss_relative = rel
+        losses = [float(tr.train_step(batches[i % 3])["loss"].detach()) for i in range(120)]
+        torch.cuda.synchronize()
+        res[rel] = (losses, model._store.overflow_count())
+    print("window exits: loss-relative %d, repeat-last-maximum %d; loss range %.3g .. %.3g" % (res[True][1], res[False][1], min(res[True][0]), max(res[True][0])))
+    assert res[True][1] == 0
+    assert res[False][1] >= res[True][1]
+    # both runs are fp32-accurate (planes or fallback): the early trajectory agrees to rounding
+    for a, b in zip(res[True][0][:30], res[False][0][:30]):
+        assert abs(a - b) <= 1e-4 * max(abs(a), 1e-3), (a, b)
