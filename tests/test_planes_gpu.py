@@ -448,10 +448,10 @@ def test_delayed_scaling_survives_a_magnitude_drop():
 
 
 def test_backward_scales_follow_the_loss_gradient():
-    """A memorising run (tiny batches, large learning rate) whose BPR loss collapses on some batches: the gradients of
-    consecutive steps differ by many orders of magnitude.  With the backward sites' delayed scales tied to the step's
-    max |d loss / d logits| no tensor leaves the fp16 window; with repeat-the-last-maximum scales (SEGMM_LOSS_RELATIVE=0
-    semantics) they do, and the consumers' fallback keeps the results equal anyway."""
+    """Every backward tensor is linear in d loss / d logits.  Scaling the loss by 1e-6 and back by 1e6 between steps (a stand-in for
+    a batch whose BPR loss has collapsed, then a normal one) moves every gradient by the same factor: with the backward sites'
+    delayed scales tied to the step's max |d loss / d logits| nothing leaves the fp16 window; with repeat-the-last-maximum scales
+    both steps do (under-range, then overflow) and run through the consumers' fallback.  The gradients agree either way."""
     from segmminterest_amd import hipabi as H
     if H.GEMM_ENGINE != H.ENGINE_F16X3P:
         pytest.skip("plane engine only")
@@ -459,19 +459,27 @@ def test_backward_scales_follow_the_loss_gradient():
     from segmminterest_amd.trainer import Trainer, default_args, init_model
     B, S, Lt, D, N = 8, 20, 6, 64, 3
     margs = default_args(num_layers_enc=N, d_model=D, nhead=4, input_type={"user": "image", "photo": "image"}, exposure_prob=[1.0] * S)
-    batches = [{k: v.cuda() for k, v in make_batch(B, S, Lt, D, seed=60 + i).items()} for i in range(3)]
+    batch = {k: v.cuda() for k, v in make_batch(B, S, Lt, D, seed=60).items()}
     res = {}
     for rel in (True, False):
         torch.manual_seed(3)
         model = init_model(margs, n_users=1, n_items=1, input_dim=D, max_vid_len=S, max_usr_len=Lt).cuda()
-        tr = Trainer(model, lr=3e-3, dropout=False)
-        model._store.loss_relative = rel
-        losses = [float(tr.train_step(batches[i % 3])["loss"].detach()) for i in range(120)]
-        torch.cuda.synchronize()
-        res[rel] = (losses, model._store.overflow_count())
-    print("window exits: loss-relative %d, repeat-last-maximum %d; loss range %.3g .. %.3g" % (res[True][1], res[False][1], min(res[True][0]), max(res[True][0])))
-    assert res[True][1] == 0
-    assert res[False][1] >= res[True][1]
-    # both runs are fp32-accurate (planes or fallback): the early trajectory agrees to rounding
-    for a, b in zip(res[True][0][:30], res[False][0][:30]):
-        assert abs(a - b) <= 1e-4 * max(abs(a), 1e-3), (a, b)
+        tr = Trainer(model, lr=0.0, weight_decay=0.0, dropout=False)          # lr 0: the parameters (and so the forward) never change
+        st = model._store
+        st.loss_relative = rel
+        coef0 = list(model._loss_spec.coef)
+        grads, exits = [], []
+        for factor in (1.0, 1.0, 1.0, 1e-6, 1e6 * 1e-6, 1.0):
+            model._loss_spec.coef = [c * factor for c in coef0]
+            model._consts.clear()
+            tr.train_step(batch)
+            grads.append(st.gflat.detach().clone())
+            exits.append(st.overflow_count())
+        res[rel] = (grads, exits)
+    (g_rel, e_rel), (g_plain, e_plain) = res[True], res[False]
+    assert e_rel[-1] == 0, e_rel
+    assert e_plain[3] > e_plain[2] and e_plain[4] > e_plain[3], e_plain          # the shrunken step AND the step after it
+    gmax = float(g_rel[2].abs().max())
+    for k, f in enumerate((1.0, 1.0, 1.0, 1e-6, 1.0, 1.0)):
+        assert float((g_rel[k] - g_plain[k]).abs().max()) <= 2e-6 * gmax * f, k          # planes and fallback: the same numbers
+        assert float((g_rel[k] / f - g_rel[2]).abs().max()) <= 2e-5 * gmax, k            # linear in the loss coefficient
