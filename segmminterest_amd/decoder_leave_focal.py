@@ -109,7 +109,7 @@ class HeadLossFn(torch.autograd.Function):
         total = torch.empty((), device=raw.device)
         # sum_b parts and sum_i coef_i * loss_i in one launch -- which, on the plane engine in training, also takes max|dlogits| and
         # sets the delayed scales of the backward tensors relative to it (engine.ParamStore.update_scales(backward=True))
-        rel = st.engine_p and st.loss_relative and model.training and st.scaling != "exact"
+        rel = st.engine_p and st.loss_relative and ((model.training and st.scaling != "exact") or st.scaling == "always")
         st._gmax_fresh = bool(rel)
         H.loss_finish(parts, B, model._coef_tensor(raw.device), losses, total, dlogits=dlogits if rel else None,
                       site_scale=st.scales() if rel else None, gain=st.gains() if rel else None, n_sites=st.MAX_SITES if rel else 0,

@@ -467,6 +467,7 @@ def test_backward_scales_follow_the_loss_gradient():
         tr = Trainer(model, lr=0.0, weight_decay=0.0, dropout=False)          # lr 0: the parameters (and so the forward) never change
         st = model._store
         st.loss_relative = rel
+        st.scaling = "always"          # delayed scales although dropout=False keeps the model in eval mode (identical steps)
         coef0 = list(model._loss_spec.coef)
         grads, exits = [], []
         for factor in (1.0, 1.0, 1.0, 1e-6, 1e6 * 1e-6, 1.0):
