@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void scales_update_kernel(const float* __restr
         }
         // tensors whose planes the consumers had to refuse: overflow flag up, or the maximum below the window (site_planes_ok)
         const float s_used = hdr[0];
-        if (__float_as_uint(hdr[1]) != 0u || (s_used > 0.f && m > 0.f && m * s_used < 0.25f)) atomicAdd(stats, 1.0f);
+        if (__float_as_uint(hdr[1]) != 0u || (s_used > 0.f && s_used < 0x1p60f && m > 0.f && m * s_used < 0.25f)) atomicAdd(stats, 1.0f);
     }
 }
 

@@ -75,7 +75,8 @@ __device__ __forceinline__ float site_amax(const float* hdr, int lane) {
 __device__ __forceinline__ bool site_planes_ok(const float* hdr, float s, int lane) {
     if (!(s > 0.f) || __float_as_uint(hdr[1]) != 0u) return false;
     const float m = site_amax(hdr, lane);
-    return !(m > 0.f) || (m * s >= 0.25f && m * s < 65504.f);
+    // (s at its upper clamp 2^60 -- f16_scale_of / scales_update keep 1/(sa sb) finite: the fallback would use the same scale)
+    return !(m > 0.f) || ((m * s >= 0.25f || s >= 0x1p60f) && m * s < 65504.f);
 }
 // exact scale of a site from its partial maxima (slow path only): every thread of the block gets the same value
 __device__ __forceinline__ float site_exact_scale(const float* hdr, float* red, int tid, int nthreads) {
