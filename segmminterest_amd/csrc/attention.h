@@ -1014,9 +1014,13 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_bwd_fused_kernel(const AttnAr
         }
         float* hk = isa ? p.hdr_ka : p.hdr_kb;
         float* slot = isa ? p.amax_ka : p.amax_kb;
-        if (s_k > 0.f) { site_commit(hk, am, blockIdx.x * nw + wave, s_k); if (scale_writer(blockIdx.x * nw + wave)) hk[0] = s_k; }
+        // the scale the planes were written with is recorded by ONE deterministic surviving wave per header: wave 0 of the
+        // workgroup(s) of (b, h) = (0, 0) -- the 'a' workgroup for hdr_ka, the 'b' workgroup for hdr_kb, both for hdr_q.  (A
+        // "key % 1024 == 0" rule left hdr_kb unwritten on small grids: consumers then saw s == 0 and took the fp32 path.)
+        const bool hdr_writer = bh == 0 && wave == 0 && lane == 0;
+        if (s_k > 0.f) { site_commit(hk, am, blockIdx.x * nw + wave, s_k); if (hdr_writer) hk[0] = s_k; }
         else if (slot) amax_commit(slot, am, blockIdx.x * nw + wave);
-        if (s_q > 0.f) { site_commit(p.hdr_q, am_q, blockIdx.x * nw + wave, s_q); if (scale_writer(blockIdx.x * nw + wave)) p.hdr_q[0] = s_q; }
+        if (s_q > 0.f) { site_commit(p.hdr_q, am_q, blockIdx.x * nw + wave, s_q); if (hdr_writer) p.hdr_q[0] = s_q; }
         else if (p.amax_q) amax_commit(p.amax_q, am_q, blockIdx.x * nw + wave);
     }
     ATT_MARK(5);

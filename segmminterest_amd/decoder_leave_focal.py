@@ -132,8 +132,11 @@ class HeadLossFn(torch.autograd.Function):
             return (None,) * (5 + len(names))
         gbuf = E._pick_gbuf(st, names)
         unit = getattr(model, "_unit_grad", None)
-        if unit is not None and g_total.data_ptr() == unit.data_ptr():
-            dl = ctx.dlogits.view(M)          # d loss / d loss == 1: the trainer's constant-one seed (Trainer.train_step)
+        # the trainer's constant-one seed (Trainer.train_step) also selects the direct gradient delivery for the whole backward
+        # (engine.grads_out); every other backward goes through autograd like a plain nn.Module
+        st.direct_grads = unit is not None and g_total.data_ptr() == unit.data_ptr()
+        if st.direct_grads:
+            dl = ctx.dlogits.view(M)          # d loss / d loss == 1
         else:
             dl = (ctx.dlogits * g_total).view(M)
         dv1 = torch.empty(M, d, device=v1.device)
@@ -142,8 +145,7 @@ class HeadLossFn(torch.autograd.Function):
         if gbuf is None and st.bucket_hook is not None:
             st.bucket_hook("head")
         ctx.dlogits = ctx.T = None
-        E.deliver_grads(st, names, gbuf)
-        return (None, None, dv1.view(B, S, d), dv2.view(B, S, d) if dv2 is not None else None, None) + (None,) * len(names)
+        return (None, None, dv1.view(B, S, d), dv2.view(B, S, d) if dv2 is not None else None, None) + E.grads_out(st, names, gbuf)
 
 
 class MultiScaleTemporalDetrLeaveFocal(nn.Module):

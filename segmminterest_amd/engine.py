@@ -279,9 +279,9 @@ class ParamStore:
             idx = self._site_idx_cache[key] = torch.tensor([-1 if n is None else self.site(n) for n in key], dtype=torch.int32,
                                                            device=arena_t.device)
         sc = self.scales()
-        rel = backward and self.loss_relative and self.__dict__.get("_gmax_fresh", False)      # the head measured gmax in THIS step
-        if backward:
-            self._gmax_fresh = False
+        # the head measured gmax in THIS step (HeadLossFn.forward sets the flag, the next BackboneFn.forward clears it: every
+        # backbone of a two-tower model records its gains, not only the first one whose backward arena closes)
+        rel = backward and self.loss_relative and self.__dict__.get("_gmax_fresh", False)
         H.scales_update(arena_t, idx, n_rows, sc, sc[self.MAX_SITES:], self.scale_target, gain=self.gains() if rel else None,
                         gmax=self.gmax() if rel else None)
         self.calibrated.update(n for n in key if n is not None)
@@ -1357,6 +1357,8 @@ class BackboneFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, store, bb, prefix, bb_index, usr_feat, usr_mask, vid_feat, vid_mask, train, seed, *params):
         run = BackboneRun(store, bb, prefix, bb_index)
+        store.direct_grads = False          # decided by the backward of THIS pass (HeadLossFn.backward, trainer-seeded or not)
+        store._gmax_fresh = False           # set by the head of THIS pass once it has measured max |d loss / d logits|
         vid, usr = run.forward(usr_feat, usr_mask, vid_feat, vid_mask, train, seed)
         ctx.run = run
         ctx.store = store
@@ -1373,8 +1375,7 @@ class BackboneFn(torch.autograd.Function):
             d_vid = torch.zeros((run.B, run.S if run.abl != "CrossMLP" else POOL_BINS, run.d), device=store.flat.device)
         run.backward(d_vid, gbuf, on_bucket=store.bucket_hook if gbuf is None else None)
         ctx.run = None
-        deliver_grads(store, ctx.names, gbuf)
-        return (None,) * (10 + len(ctx.names))
+        return (None,) * 10 + grads_out(store, ctx.names, gbuf)
 
 
 def _pick_gbuf(store, names):
@@ -1386,6 +1387,20 @@ def _pick_gbuf(store, names):
                                "backward (the bucket all-reduces are issued from inside the backward)")
         return torch.zeros_like(store.gflat)
     return None
+
+
+def grads_out(store, names, gbuf):
+    """The parameter gradients of one autograd.Function.backward, as the tuple it returns for its parameter inputs.
+
+    Trainer.train_step's backward (recognised by the head through the trainer's constant-one seed: ``store.direct_grads``)
+    takes the fast path: ``deliver_grads`` hands every parameter a VIEW of the flat gradient buffer and autograd gets None.
+    Any other backward -- ``loss.backward()``, ``torch.autograd.grad(loss, params)``, ``backward(inputs=...)`` -- returns the
+    views THROUGH autograd like a plain nn.Module: AccumulateGrad copies them into ``.grad``, tensor hooks and
+    post-accumulate-grad hooks on the parameters fire, ``autograd.grad`` receives them."""
+    if store.__dict__.get("direct_grads", False):
+        deliver_grads(store, names, gbuf)
+        return (None,) * len(names)
+    return tuple(store.g(n, gbuf) for n in names)
 
 
 def deliver_grads(store, names, gbuf):

@@ -107,8 +107,22 @@ class FusedAdamW:
     # one optimizer step as several launches over disjoint ranges that together cover the live range: the data-parallel
     # trainer steps each gradient bucket as soon as ITS all-reduce has completed (begin_step, step_range ..., end_step)
     def begin_step(self):
-        self._state()
+        st = self._state()
         self.step_count += 1
+        if not st.__dict__.get("direct_grads", False):
+            self._sync_grads(st)
+
+    def _sync_grads(self, st):
+        """The kernel reads the FLAT gradient buffer.  After Trainer.train_step the parameters' ``.grad`` ARE views of it
+        (engine.deliver_grads).  After any other backward (``loss.backward()``: gradients arrive through autograd, possibly
+        rewritten by hooks, clipped or accumulated over several backwards) they are tensors of their own: copy them in."""
+        base = st.gflat.data_ptr()
+        for n in st.live_names:
+            g = st._params[n].grad
+            if g is not None:
+                o, k = st.index[n]
+                if g.data_ptr() != base + 4 * o or not g.is_contiguous():
+                    st.gflat[o:o + k].view(g.shape).copy_(g)
 
     def step_range(self, start, end, gbuf=None):
         st = self._state()
@@ -508,7 +522,15 @@ class Trainer:
         self._pending_range = None
         # seed the backward with the model's own constant-one tensor: the head recognises it (same storage) and skips both the
         # ones_like fill autograd would launch and the dlogits * 1 multiply
-        torch.autograd.backward(out["loss"], grad_tensors=[model.unit_grad(out["loss"].device)])
+        if self._param_hooks():
+            # tensor / post-accumulate-grad hooks on parameters (gradient scaling, clipping, DDP-style wrappers) only fire when
+            # the gradients travel through autograd: take the plain path (engine.grads_out), FusedAdamW copies the results in
+            if self.comm.active:
+                raise RuntimeError("parameter hooks under data parallelism are not supported: the bucket all-reduces are "
+                                   "issued from inside the backward, before autograd would run the hooks")
+            out["loss"].backward()
+        else:
+            torch.autograd.backward(out["loss"], grad_tensors=[model.unit_grad(out["loss"].device)])
         if self.comm.active and self.overlap:
             self._flush_bucket()          # the tail of the backward (embedding gradients) that stayed below the merge threshold
         if self.comm.active and self.overlap and self.per_bucket_adamw and self._covers_live(st):
@@ -545,6 +567,15 @@ class Trainer:
             self.comm.finish()
         self.opt.step()
         return out
+
+    def _param_hooks(self) -> bool:
+        plist = self.__dict__.get("_hook_plist")
+        if plist is None:
+            plist = self._hook_plist = list(self.model.parameters())
+        for p in plist:
+            if p._backward_hooks or getattr(p, "_post_accumulate_grad_hooks", None):
+                return True
+        return False
 
     def _covers_live(self, st):
         """The buckets whose hooks fired tile [0, n_live) exactly (always, for a backward over the whole model)."""

@@ -159,6 +159,49 @@ def test_grad_accumulation_over_two_backwards():
             assert torch.allclose(p.grad, 2 * g1[k], rtol=1e-5, atol=1e-7), k
 
 
+def test_parameter_gradients_travel_through_autograd():
+    """Outside Trainer.train_step the model behaves like the reference's plain nn.Module: torch.autograd.grad returns the
+    parameter gradients (and leaves .grad alone), tensor hooks rewrite them, post-accumulate-grad hooks fire; inside the
+    trainer a hooked parameter switches the step to the same path and the fused AdamW consumes the hooked gradient."""
+    from segmminterest_amd.trainer import Trainer
+    cfg, g, nograd, _, model = _loaded("img_d32_N2")
+    named = dict(model.named_parameters())
+    live = [k for k in named if k not in nograd]
+    out = call_model(model, g["in"], "train", DEV)
+    grads = torch.autograd.grad(out["loss"], [named[k] for k in live])
+    assert all(p.grad is None for p in model.parameters())
+    for k, got in zip(live, grads):
+        ref = g["grad"][k]
+        assert float((got.cpu() - ref).abs().max()) <= 3e-4 * max(float(ref.abs().max()), 1e-6) + 2e-6, k
+    name = "backbone1.encoder.layers.0.ff_vid.layers.0.weight"
+    p, fired = named[name], []
+    h1 = p.register_hook(lambda gr: gr * 2.0)
+    h2 = p.register_post_accumulate_grad_hook(lambda q: fired.append(q is p))
+    call_model(model, g["in"], "train", DEV)["loss"].backward()
+    assert fired == [True]
+    ref = g["grad"][name]
+    assert float((p.grad.cpu() - 2.0 * ref).abs().max()) <= 6e-4 * float(ref.abs().max()) + 4e-6
+    h1.remove()
+    h2.remove()
+    # a hook that zeroes one parameter's gradient: the trainer's fused AdamW must see the zero (pure weight decay on it)
+    for q in model.parameters():
+        q.grad = None
+    tr = Trainer(model, lr=1e-2, weight_decay=0.5, dropout=False)
+    h3 = p.register_hook(lambda gr: torch.zeros_like(gr))
+    before = p.detach().clone()
+    other = named["backbone1.encoder.layers.0.ff_vid.layers.1.weight"]
+    other_before = other.detach().clone()
+    batch = dict(user=g["in"]["usr_image"].to(DEV), photo=g["in"]["vid_image"].to(DEV), user_mask=g["in"]["usr_mask"].to(DEV),
+                 photo_mask=g["in"]["vid_mask"].to(DEV), label=g["in"]["gt"].to(DEV), user_identity_id=g["in"]["usr_id"].to(DEV),
+                 photo_identity_id=g["in"]["vid_id"].to(DEV))
+    tr.train_step(batch)
+    h3.remove()
+    assert torch.allclose(p.detach(), before * (1.0 - 1e-2 * 0.5), rtol=1e-6, atol=1e-9)
+    assert float((other.detach() - other_before * (1.0 - 1e-2 * 0.5)).abs().max()) > 1e-3          # Adam moved the un-hooked one
+    tr.train_step(batch)          # hooks gone: back on the direct path, still stepping
+    assert model._store.direct_grads
+
+
 def test_standalone_backbone_forward():
     cfg, g, _, _, model = _loaded("img_d32_N3_alllosses")
     import segmm_oracle as O
@@ -524,6 +567,126 @@ def test_full_size_gradients_match_oracle():
     out["loss"].backward()
     errs = _check_live_grads(model, rgrads)
     print("full-size worst gradient error / tensor max: %.2e" % max(v for k, v in errs.items() if "bias" not in k))
+
+
+class _MaskFeed:
+    """The oracle's ``drop`` hook fed the DEVICE's dropout masks: the reference applies dropout at fixed places in a fixed
+    order (embedding after LN, encoder.py:461,471; raw attention logits before the scale, :144-146; after ff_vid, :166-167;
+    inside and after the MLP, mlp.py:17-23 / encoder.py:202-206); call k of the oracle multiplies by the multiplier tensor
+    (0 or 1/(1-p)) that ``segmm_dropout_mult(seed, site_k)`` exports for the site the engine uses at that place."""
+
+    def __init__(self, seed, plan):
+        self.seed, self.plan, self.i = seed, plan, 0
+
+    def __call__(self, t):
+        from segmminterest_amd import hipabi as H
+        site, p, kind = self.plan[self.i]
+        self.i += 1
+        if kind == "tokens":                      # [B, L, d]: element index = flat index
+            m = torch.empty(t.numel(), device=DEV)
+            H.dropout_mult(m, m.numel(), p, self.seed, site)
+            return t * m.view(t.shape).cpu()
+        B, h, Lq, T = t.shape                     # attention logits [B, h, Lq, La + Lb]: key blocks padded to 16 on the device
+        La, Lb = kind
+        assert La + Lb == T
+        La_p, Lb_p = (La + 15) // 16 * 16, (Lb + 15) // 16 * 16
+        m = torch.empty(B * h * Lq * (La_p + Lb_p), device=DEV)
+        H.dropout_mult(m, m.numel(), p, self.seed, site)
+        m = m.view(B, h, Lq, La_p + Lb_p)
+        return t * torch.cat([m[..., :La], m[..., La_p:La_p + Lb]], -1).cpu()
+
+
+def test_full_size_train_mode_gradients_with_exported_masks():
+    """The configuration bench.py times: BASELINE config 2 at FULL size (B = 512, S = 40, Lt = 100, d = 768, h = 16, N = 2),
+    TRAIN mode (dropout 0.1 at every site of the reference), DELAYED plane scales after one calibration step.  Logits, loss
+    and EVERY live gradient against the CPU oracle run on the same batch with the device's own dropout masks (exported per
+    site with segmm_dropout_mult and multiplied in by the oracle's ``drop`` hook in the reference's call order)."""
+    import segmm_oracle as O
+    from segmminterest_amd import engine as E
+    model, inp, cfg = _cfg2_model(512)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.cuda().train()
+    st = model._store
+    if st.engine_p:
+        assert st.scaling == "delayed"
+    # calibration step (first use of every site: exact split passes), then the measured step on delayed scales
+    torch.manual_seed(100)
+    call_model(model, inp, "train", DEV)["loss"].backward()
+    for p in model.parameters():
+        p.grad = None
+    torch.manual_seed(7)
+    seed = int(torch.randint(0, 2 ** 62, (1,)).item())          # what engine.next_seed() will draw
+    torch.manual_seed(7)
+    out = call_model(model, inp, "train", DEV)
+    out["loss"].backward()
+    if st.engine_p:
+        assert len(st.calibrated) > 10
+    assert st.overflow_count() == 0, "a delayed scale left its window (the fallback would have run)"
+    S, Lt, p = 40, 100, float(model.backbone1.dropout_p)
+    assert p == pytest.approx(0.1)
+    s = lambda kind: E._site(0, 0, kind)
+    plan = [(s(E.K_EMB_V), p, "tokens"), (s(E.K_EMB_U), p, "tokens"), (s(E.K_ATT_V), p, (S, Lt)), (s(E.K_AO_V), p, "tokens"),
+            (s(E.K_MI_V), E.MLP_INNER_DROPOUT, "tokens"), (s(E.K_MO_V), p, "tokens")]
+    feed = _MaskFeed(seed, plan)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    ref, rgrads = O.forward_backward(sd, cfg, inp, drop=feed)
+    assert feed.i == len(plan), "the oracle called dropout %d times, the plan lists %d sites" % (feed.i, len(plan))
+    # dropout must have done something, and the same thing on both sides
+    ref_eval = O.model_forward(sd, cfg, inp, "inference")["logits"]
+    assert (ref["logits"].detach() - ref_eval.detach()).abs().max().item() > 1e-2
+    assert (out["logits"].cpu() - ref["logits"].detach()).abs().max().item() < 1e-4
+    assert abs(float(out["loss"].detach()) - float(ref["loss"].detach())) < 1e-5 * max(1.0, abs(float(ref["loss"])))
+    errs = _check_live_grads(model, rgrads)
+    print("full-size train-mode worst gradient error / tensor max: %.2e" % max(v for k, v in errs.items() if "bias" not in k))
+
+
+def test_config4_global_batch_2048_vs_oracle():
+    """BASELINE config 4 (main...SegMM.py:265-300 at global B = 2048, S = 40, D = 768, N = 2; 256 rows per GPU under DP-8):
+    (1) the whole 2 048-row batch through the device in one pass, inference logits against the oracle on a row subset (rows
+    are independent); (2) one rank's 256-row shard as the data-parallel step sees it -- loss normalisers of the GLOBAL batch
+    (the model's DP hook) -- loss terms and every live gradient against the oracle run on the same shard with
+    the same global statistics; the shard losses of all 8 ranks must add up to the full-batch loss."""
+    import segmm_oracle as O
+    G, Bg = 8, 2048
+    model, inp, cfg = _cfg2_model(Bg, seed=4)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.cuda().eval()
+    got = call_model(model, inp, "inference", DEV)["logits"].cpu()
+    rows = torch.tensor([0, 1, 255, 256, 511, 777, 1023, 1024, 1500, 1791, 1792, 2047])
+    ref = O.model_forward(sd, cfg, {k: v[rows] for k, v in inp.items()}, mode="inference")["logits"]
+    assert got.shape == (Bg, 40) and torch.isfinite(got).all()
+    assert (got[rows] - ref.detach()).abs().max().item() < 1e-4
+    # global label statistics, exactly what DPComm.global_label_stats hands the loss kernel on every rank
+    gt = inp["gt"]
+    v_all, v2_all = (gt == 1).sum(1).float(), (gt >= 0).sum(1).float()
+    norms = torch.tensor([float((v_all < 40).sum()), float(Bg), float((gt != -2).sum())])
+    model._dp_hook = lambda v, v2, n: (v_all.to(DEV), v2_all.to(DEV), norms.to(DEV))
+    rank = 3
+    s, e = rank * Bg // G, (rank + 1) * Bg // G
+    shard = {k: v[s:e].clone() for k, v in inp.items()}
+    out = call_model(model, shard, "train", DEV)
+    out["loss"].backward()
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    params = {k: t.clone().requires_grad_(t.is_floating_point()) for k, t in sd.items()}
+    gs = dict(v_all=v_all, v2_all=v2_all, norms=norms)
+    rout = O.model_forward(params, cfg, {k: v.clone() for k, v in shard.items()}, "train", global_stats=gs)
+    rout["loss"].backward()
+    rgrads = {k: params[k].grad for k in params}
+    assert (out["logits"].cpu() - rout["logits"].detach()).abs().max().item() < 1e-4
+    assert abs(float(out["loss"].detach()) - float(rout["loss"].detach())) < 1e-5 * max(1.0, abs(float(rout["loss"])))
+    _check_live_grads(model, rgrads)
+    # the 8 shard losses (device) add up to the loss of the whole batch (oracle's logits are row-independent: use the device's)
+    for p in model.parameters():
+        p.grad = None
+    total = 0.0
+    with torch.no_grad():
+        for r in range(G):
+            sh = {k: v[r * Bg // G:(r + 1) * Bg // G].clone() for k, v in inp.items()}
+            total += float(call_model(model, sh, "train", DEV)["loss"])
+    model._dp_hook = None
+    with torch.no_grad():
+        full = float(call_model(model, inp, "train", DEV)["loss"])
+    assert abs(total - full) < 2e-5 * max(1.0, abs(full)), (total, full)
 
 
 def test_outlier_gamma_and_outlier_activation_row():

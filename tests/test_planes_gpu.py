@@ -256,10 +256,12 @@ def test_gather_writes_planes_and_maxima():
     assert torch.equal(pl, ref_pl) and float(hdr[H.SITE_HDR:].max()) == float(out.abs().max())
 
 
-@pytest.mark.parametrize("Hh,dh", [(4, 16), (2, 32), (2, 48), (1, 64), (8, 8)])
-def test_attention_producers_write_the_split_pass_planes(Hh, dh):
+@pytest.mark.parametrize("Hh,dh,B", [(4, 16, 3), (2, 32, 3), (2, 48, 3), (1, 64, 3), (8, 8, 3), (16, 8, 8)])
+def test_attention_producers_write_the_split_pass_planes(Hh, dh, B):
+    """(B = 8, H = 16: a grid on which no 'b' workgroup's wave key is a multiple of 1024 -- the user-key header's scale must
+    still be written, by the (b, h) = (0, 0) workgroup.)"""
     H = _abi()
-    B, S, Lt = 3, 40, 23
+    S, Lt = 40, 23
     d = Hh * dh
     Yv, Yu = _rand(B * S, 4 * d, seed=30), _rand(B * Lt, 2 * d, seed=31)
     vm = (torch.rand(B, S, generator=torch.Generator().manual_seed(1)) > 0.2).to(torch.uint8).to(DEV)
@@ -447,7 +449,8 @@ def test_delayed_scaling_survives_a_magnitude_drop():
     assert torch.isfinite(got).all() and float((got - ref).abs().max()) <= tol and float((got2 - ref).abs().max()) <= tol
 
 
-def test_backward_scales_follow_the_loss_gradient():
+@pytest.mark.parametrize("towers", [1, 2])
+def test_backward_scales_follow_the_loss_gradient(towers):
     """Every backward tensor is linear in d loss / d logits.  Scaling the loss by 1e-6 and back by 1e6 between steps (a stand-in for
     a batch whose BPR loss has collapsed, then a normal one) moves every gradient by the same factor: with the backward sites'
     delayed scales tied to the step's max |d loss / d logits| nothing leaves the fp16 window; with repeat-the-last-maximum scales
@@ -458,12 +461,15 @@ def test_backward_scales_follow_the_loss_gradient():
     from segmminterest_amd.synth import make_batch
     from segmminterest_amd.trainer import Trainer, default_args, init_model
     B, S, Lt, D, N = 8, 20, 6, 64, 3
-    margs = default_args(num_layers_enc=N, d_model=D, nhead=4, input_type={"user": "image", "photo": "image"}, exposure_prob=[1.0] * S)
-    batch = {k: v.cuda() for k, v in make_batch(B, S, Lt, D, seed=60).items()}
+    # towers == 2: image backbone + id backbone ("both" inputs) -- BOTH backbones' backward sites must get loss-relative scales
+    kind = "image" if towers == 1 else "both"
+    nu, ni = (1, 1) if towers == 1 else (50, 60)
+    margs = default_args(num_layers_enc=N, d_model=D, nhead=4, input_type={"user": kind, "photo": kind}, exposure_prob=[1.0] * S)
+    batch = {k: v.cuda() for k, v in make_batch(B, S, Lt, D, n_users=nu, n_items=ni, seed=60).items()}
     res = {}
     for rel in (True, False):
         torch.manual_seed(3)
-        model = init_model(margs, n_users=1, n_items=1, input_dim=D, max_vid_len=S, max_usr_len=Lt).cuda()
+        model = init_model(margs, n_users=nu, n_items=ni, input_dim=D, max_vid_len=S, max_usr_len=Lt).cuda()
         tr = Trainer(model, lr=0.0, weight_decay=0.0, dropout=False)          # lr 0: the parameters (and so the forward) never change
         st = model._store
         st.loss_relative = rel
