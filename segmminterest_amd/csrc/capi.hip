@@ -12,8 +12,25 @@
 #include "gemm.h"
 #include "gemm_split.h"
 #include "gemm_planes.h"
+#include "gemm_planes8.h"
 #include "loss.h"
 #include "rowops.h"
+
+// compute units of the current device (cached; persistent kernels launch one workgroup per CU)
+static int num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+#ifdef SEGMM_STAMPS
+static unsigned long long* g_segmm_stamps = nullptr;
+extern "C" int segmm_debug_set_stamps(void* p) { g_segmm_stamps = (unsigned long long*)p; return 0; }
+#endif
 
 thread_local char g_segmm_err[512] = {0};
 
@@ -466,7 +483,41 @@ int segmm_gemm_p(int layout, int M, int N, int K, const uint16_t* a_planes, int 
             SEGMM_REQUIRE(!residual && C, "gemm_p: accumulate and residual are exclusive");
             g.residual = C; g.ldr = ldc; g.res_period = M;
         }
-        static const int pl_var = getenv("SEGMM_PL_VAR") ? atoi(getenv("SEGMM_PL_VAR")) : 1;
+        static const int pl_var = getenv("SEGMM_PL_VAR") ? atoi(getenv("SEGMM_PL_VAR")) : 8;          // 8: gemm_pl_nt8 (round 3); 0-2, 4: round-2 forms (A/B)
+#ifdef SEGMM_STAMPS
+        q.stamps = g_segmm_stamps;
+#endif
+        if (pl_var == 8) {          // round-3 form: 16x16x32 MFMA, ping-pong wave groups, register epilogue (gemm_planes8.h)
+            // every epilogue access is a buffer operation with a 32-bit offset whose top bit masks out-of-range columns
+            const long long lim = 1ll << 31;
+            const bool fits = !row_scale && (long long)M * ldc * 4 < lim && (!aux || (long long)M * ldaux * 4 < lim) &&
+                              (!residual || (long long)(res_period < M ? res_period : M) * ldr * 4 < lim) &&
+                              (!c_planes || (long long)M * ldc2 * 2 < lim) &&
+                              !(residual && (activation == EPI_DGELU || activation == EPI_DRELU));      // one extra operand per element
+            if (fits) {
+                // tile width 64 NJ: the one that needs the fewest CU-rounds (a tile costs ~ 5 + 13.4 NJ us at K = 768); ties and
+                // near-ties go to the widest tile (least operand traffic per FLOP)
+                static const int nj_env = getenv("SEGMM_PL_NJ") ? atoi(getenv("SEGMM_PL_NJ")) : 0;
+                int best = 4;
+                if (nj_env >= 2 && nj_env <= 4) best = nj_env;
+                else {
+                    double best_cost = 0.0;
+                    const int ncu = num_cus(), bm = (M + PBM - 1) / PBM;
+                    for (int nj = 4; nj >= 2; --nj) {
+                        const long long tiles = (long long)bm * ((N + 64 * nj - 1) / (64 * nj));
+                        const double cost = (double)((tiles + ncu - 1) / ncu) * (5.0 + 13.4 * nj * (K / 768.0));
+                        if (nj == 4 || cost < 0.93 * best_cost) { best = nj; best_cost = cost; }
+                    }
+                }
+                g.nbm = (M + PBM - 1) / PBM; g.nbn = (N + 64 * best - 1) / (64 * best);
+                const dim3 grid(g.nbm * g.nbn);
+                if (best == 4) hipLaunchKernelGGL(gemm_pl_nt8<4>, grid, dim3(512), 0, s, g, q);
+                else if (best == 3) hipLaunchKernelGGL(gemm_pl_nt8<3>, grid, dim3(512), 0, s, g, q);
+                else hipLaunchKernelGGL(gemm_pl_nt8<2>, grid, dim3(512), 0, s, g, q);
+                LAUNCH_CHECK();
+                return 0;
+            }
+        }
         if (pl_var == 4) {          // four-wave form: 128 x 256 tiles, two workgroups per CU
             g.nbm = (M + QBM - 1) / QBM; g.nbn = (N + QBN - 1) / QBN;
             hipLaunchKernelGGL(gemm_pl_nt4, dim3(g.nbm * g.nbn), dim3(256), 0, s, g, q);

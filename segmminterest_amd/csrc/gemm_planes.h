@@ -41,6 +41,7 @@ struct PGemmX {
     int write_c;                               // 0: the fp32 C is not stored (planes only)
     float* colsum_out; float* colsum_ws;       // TN only: optional [M] column sums of A over k (= bias gradient), split-K partials [splits][M]
     int dbg;                                   // timing ablations (SEGMM_PL_FLAGS; results are wrong when set): 1 no C stores, 2 no epilogue
+    unsigned long long* stamps;                // SEGMM_STAMPS builds only (tools/probe/gemm_stamps.py): 8 x u64 per workgroup
 };
 
 constexpr int PBM = 256, PBN = 256, PBK = 32;

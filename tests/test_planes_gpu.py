@@ -150,6 +150,68 @@ def test_gemm_p_epilogue_matches_on_the_fly(act):
     assert float(hdr[H.SITE_HDR:].max()) == float(Cp.abs().max())
 
 
+@pytest.mark.parametrize("M,N,K", [(600, 448, 96), (16384, 768, 64), (16300, 1024, 64)])
+@pytest.mark.parametrize("case", ["plain", "bias_res_full", "res_periodic_drop", "accumulate", "gelu_planes_drop", "dgelu_drop_planes",
+                                  "relu", "drelu", "planes_only"])
+def test_gemm_p_nt_epilogue_variants(M, N, K, case):
+    """Every epilogue form of the NT plane GEMM against the on-the-fly fp16x3 kernel (same arithmetic, independent epilogue
+    code), on shapes that are ragged in M and N and that make the launcher pick each tile width (128 / 192 / 256 columns): the
+    residual / aux operand staged through LDS, periodic (positional-table) residuals, accumulate, activations with their aux
+    tensors, dropout, plane output with and without the fp32 copy."""
+    H = _abi()
+    A, W = _rand(M, K, seed=81), _rand(N, K, seed=82, scale=0.1)
+    pa, pw = H.to_planes(A, M, K), H.to_planes(W, N, K, keep_f32=False)
+    bias = _rand(N, seed=83)
+    Cp, Cl = torch.full((M, N), 7.0, device=DEV), torch.full((M, N), 7.0, device=DEV)
+    kw, kwp, aux_p, aux_l, want_planes = {}, {}, None, None, False
+    if case == "bias_res_full":
+        res = _rand(M, N, seed=84)
+        kw = dict(bias=bias, residual=res, ldr=N, res_period=M)
+    elif case == "res_periodic_drop":
+        res = _rand(100, N, seed=85)
+        kw = dict(bias=bias, residual=res, ldr=N, res_period=100, drop_p=0.1, seed=5, site=9)
+    elif case == "accumulate":
+        Cp.copy_(_rand(M, N, seed=86)); Cl.copy_(Cp)
+        kw = dict(accumulate=True)
+    elif case == "gelu_planes_drop":
+        aux_p, aux_l = torch.zeros(M, N, device=DEV), torch.zeros(M, N, device=DEV)
+        kw = dict(bias=bias, activation=1, drop_p=0.1, seed=6, site=3, ldaux=N)
+        want_planes = N % 32 == 0
+    elif case == "dgelu_drop_planes":
+        aux_p = _rand(M, N, seed=87); aux_l = aux_p.clone()
+        kw = dict(activation=2, drop_p=0.1, seed=6, site=3, ldaux=N)
+        want_planes = N % 32 == 0
+    elif case == "relu":
+        kw = dict(bias=bias, activation=3, drop_p=0.2, seed=7, site=4)
+    elif case == "drelu":
+        aux_p = _rand(M, N, seed=88); aux_l = aux_p.clone()
+        kw = dict(activation=4, ldaux=N)
+    elif case == "planes_only":
+        if N % 32:
+            pytest.skip("plane output needs N % 32 == 0")
+        want_planes = True
+        kwp = dict(write_c=False)
+    if want_planes:
+        pl, hdr, sc, po = _po(H, M, N, 2.0 ** 6)
+        kwp.update(c_pt=H.PT(pl, hdr, M, N, f32=Cp), c_scale_ptr=sc.data_ptr())
+    H.gemm_p(H.LAYOUT_NT, M, N, K, pa, pw, Cp, N, aux=aux_p, **kw, **kwp)
+    H.gemm(H.LAYOUT_NT, M, N, K, A, K, W, K, Cl, N, engine=H.ENGINE_F16X3, aux=aux_l, **kw)
+    tol = 2e-6 * float(Cl.abs().max())
+    if case == "planes_only":
+        assert float(Cp.min()) == 7.0 and float(Cp.max()) == 7.0          # the fp32 C was not written
+        # (the on-the-fly result differs at rounding level: compare the values the planes reconstruct)
+        assert float((_planes_to_f32(pl, M, N, 2.0 ** 6) - Cl).abs().max()) <= tol + 2e-7 * float(Cl.abs().max())
+    else:
+        assert float((Cp - Cl).abs().max()) <= tol, case
+        if case == "gelu_planes_drop":
+            assert float((aux_p - aux_l).abs().max()) <= 2e-6 * float(aux_l.abs().max())
+        if want_planes:
+            ref_pl, _ = _ref_planes(H, Cp, M, N, 2.0 ** 6)
+            assert torch.equal(pl, ref_pl)
+            assert float(hdr[0]) == 2.0 ** 6 and float(hdr[1]) == 0.0
+            assert float(hdr[H.SITE_HDR:].max()) == float(Cp.abs().max())
+
+
 def test_gemm_p_overflow_flag_takes_fp32_path():
     """A delayed scale that has become too large: the producer raises the flag, the consumer reads the fp32 copy instead of
     the (infinite) planes -- same result as with exact planes."""
