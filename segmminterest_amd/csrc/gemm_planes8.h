@@ -496,3 +496,223 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_nt8(const GemmArgs p, const PG
 }
 
 }  // namespace segmm
+
+namespace segmm {
+
+// =============================================================================== TN, round-3 form
+// Weight gradients gW[M, N] = A[K, M]^T . B[K, N] over the token axis K (the SLOW axis of both operands), split-K over
+// blockIdx.z -- the same ping-pong structure as gemm_pl_nt8 on v_mfma_f32_16x16x32_f16, with the operand handling of
+// gemm_pl_tn (gemm_planes.h): a k-tile is 32 token rows of 1 KB per operand (256 features x [hi | lo]), one LDS-DMA
+// wave-instruction per row, fragments by ds_read_b64_tr_b16 (hardware transpose: per 16-lane group 4 tokens x 16 features,
+// a lane ends up with 8 consecutive tokens of ITS feature -- the 16 x 16 x 32 operand form directly).
+//
+// LDS image of a token row (1 KB): 16 pieces of 64 B (piece = 2 * feature block + plane); piece c of token t sits at
+// physical piece c ^ (t & 3) -- the four token rows of a transposed read fall into four different 64-byte bank windows -- and
+// inside a piece the two 32-byte halves (16 features each) are swapped for tokens with bit 3 set: the two 16-lane groups of a
+// 32-lane half read the SAME 16 features of tokens 8 apart (16 x 16 x 32: lane group = token octet), which would otherwise hit
+// the same banks twice.  Both permutations are applied to the DMA source address.
+//
+// Schedule per k-tile t (stage t & 1; g0 = waves 0-3 = features 0-127 of A, g1 one segment behind):
+//     L(t,P0): tr-reads of B (all 64 columns of the wave) and A sub-tile 0; DMA of the group's 16 token rows of A(t+1)
+//     C(t,P0): 48 MFMAs                                   | vmcnt(4): B(t+1) has landed
+//     L(t,P1): tr-reads of A sub-tile 1; DMA of the group's 16 rows of B(t+2)   | vmcnt(4): A(t+1) has landed
+//     C(t,P1): 48 MFMAs
+// Every wave reads ALL 32 token rows of a stage (its own feature columns), so a row of A(t+1) may be requested only after both
+// groups' L(t-1,P1) (true from L(t,P0) on) and must have landed before g0's L(t+1,P0): the issuing wave waits for it at the
+// end of its own L(t,P1).  B(t+2) replaces B(t), last read in L(t,P0) of both groups.
+//
+// The bias gradient (column sums of A over k) rides along in the workgroups of the first column tile: wave (wm, wn) adds
+// one MFMA pair per phase against an all-ones fragment for its m-tile wn.  Output: split-K slabs (plain float4 stores from the
+// accumulators, C^T trick as in gemm_pl_nt8) combined by splitk_reduce, or C itself for a single split.
+__device__ __forceinline__ f32x4 lds_tr8b(const char* a) {          // 8 tokens (two 4-token blocks, 4 KB apart) of this lane's feature
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a + 4096));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(f32x4, v);
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_pl_tn8(const GemmArgs p, const PGemmX q) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * PSTAGE];      // two stages x (A: 32 tokens x 1 KB | B: 32 tokens x 1 KB)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wn = wave & 3;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int ntile = p.nbm * p.nbn;
+    const int lg = xcd_remap(blockIdx.x + ntile * blockIdx.z, ntile * gridDim.z);          // tiles of one token slab meet in one L2
+    const int kz = lg / ntile, lb = lg - kz * ntile;
+    const int m0 = (lb / p.nbn) * PBM, n0 = (lb % p.nbn) * PBN;
+    const int kbeg = kz * p.k_per_split;
+    const int kend = min(p.K, kbeg + p.k_per_split);
+    const int nkt = (kend - kbeg + 31) >> 5;
+    const bool do_colsum = q.colsum_out != nullptr && (lb % p.nbn) == 0;
+
+    // ---- LDS-DMA: piece = one token row (1 KB); group g fetches rows t = 16 g + 4 wn + i (i < 4) of both operands.  The row
+    // and the tile's feature offset are wave-uniform (scalar offset of the instruction); per lane only the position inside the row:
+    // physical 16-byte chunk `lane` of row t holds logical piece (lane >> 2) ^ (t & 3), chunk (lane & 3) ^ (2 * bit 3 of t) --
+    // t & 3 = i and bit 3 of t = wn >> 1 here, so the offset of piece i is inrow0 ^ (i << 6)
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(q.A.p, q.A.bytes), rsB = make_rsrc(q.B.p, q.B.bytes);
+    const int t0 = 16 * grp + 4 * wn;
+    const uint32_t inrow0 = (uint32_t)(((lane >> 2) << 6) + (((lane & 3) ^ ((wn >> 1) << 1)) << 4));
+    auto dmaA = [&](int kt) {
+        char* st = smem + (kt & 1) * PSTAGE + t0 * 1024;
+        const uint32_t so = (uint32_t)(kbeg + kt * 32 + t0) * (uint32_t)q.A.ld2 * 2u + (uint32_t)m0 * 4u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) lds_dma16(rsA, st + i * 1024, inrow0 ^ (uint32_t)(i << 6), so + (uint32_t)i * (uint32_t)q.A.ld2 * 2u);
+    };
+    auto dmaB = [&](int kt) {
+        char* st = smem + (kt & 1) * PSTAGE + 32768 + t0 * 1024;
+        const uint32_t so = (uint32_t)(kbeg + kt * 32 + t0) * (uint32_t)q.B.ld2 * 2u + (uint32_t)n0 * 4u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) lds_dma16(rsB, st + i * 1024, inrow0 ^ (uint32_t)(i << 6), so + (uint32_t)i * (uint32_t)q.B.ld2 * 2u);
+    };
+    dmaA(0);
+    dmaB(0);
+    if (nkt > 1) dmaB(1);
+
+    // ---- operand state (all header words requested at once)
+    auto uni = [](float x) { return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(x))); };
+    const float ha0 = q.A.hdr[0], ha1 = q.A.hdr[1], hb0 = q.B.hdr[0], hb1 = q.B.hdr[1];
+    const f32x4 ama = *(const f32x4*)(q.A.hdr + SITE_HDR + lane * 4), amb = *(const f32x4*)(q.B.hdr + SITE_HDR + lane * 4);
+    const float sa = uni(ha0), sb = uni(hb0);
+    auto planes_ok = [&](float s, float flag, f32x4 v) {
+        const float m = wave_max(fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+        if (!(s > 0.f) || __float_as_uint(flag) != 0u) return false;
+        return !(m > 0.f) || ((m * s >= 0.25f || s >= 0x1p60f) && m * s < 65504.f);
+    };
+    const bool slowA = q.A.f32 != nullptr && !planes_ok(sa, uni(ha1), ama);          // delayed scale outside its window: fp32 fallback
+    const bool slowB = q.B.f32 != nullptr && !planes_ok(sb, uni(hb1), amb);
+
+    // ---- transposed fragment reads: lane = (g = lq: token octet, qq = (lane >> 2) & 3: token inside a 4-block, pp = lane & 3)
+    const int qq = (lane >> 2) & 3, pp = lane & 3;
+    const uint32_t lane_base = (uint32_t)((8 * lq + qq) * 1024 + 4 * pp * 2);
+    const uint32_t hsw = (uint32_t)((lq & 1) << 5);          // tokens 8 .. 15 and 24 .. 31 (bit 3 set): the 32-byte halves of a piece are swapped
+    // A tile i (16 features) of phase mh, plane pl: lane part fr[i >> 1][pl] + (32 (i & 1)) ^ hsw, uniform part (2 wm + mh) * 256;
+    // B tile j: the same lane part, uniform part 32768 + 256 wn
+    uint32_t fr[2][2];
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) fr[hb][pl] = lane_base + (uint32_t)(((2 * hb + pl) ^ qq) << 6);
+    const uint32_t h0 = hsw, h1 = 32u ^ hsw;          // byte offset of the even / odd 16-feature half inside the piece
+    const int ua = grp * 2 * 256, ub = 32768 + wn * 256;          // wave-uniform parts
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 accb[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    f32x4 ah[4], al[4], bh[4], bl[4];
+    auto readA = [&](const char* st, int mh) {
+        const char* sa_ = st + ua + mh * 256;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ah[i] = lds_tr8b(sa_ + fr[i >> 1][0] + ((i & 1) ? h1 : h0));
+            al[i] = lds_tr8b(sa_ + fr[i >> 1][1] + ((i & 1) ? h1 : h0));
+        }
+    };
+    auto readB = [&](const char* st) {
+        const char* sb_ = st + ub;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bh[j] = lds_tr8b(sb_ + fr[j >> 1][0] + ((j & 1) ? h1 : h0));
+            bl[j] = lds_tr8b(sb_ + fr[j >> 1][1] + ((j & 1) ? h1 : h0));
+        }
+    };
+    auto mma = [&](auto mh_tag, auto cs_tag) {
+        constexpr int mh = decltype(mh_tag)::value;
+        constexpr bool CS = decltype(cs_tag)::value;
+        __builtin_amdgcn_s_setprio(1);
+        if (CS) {
+            const f32x4 ones = __builtin_bit_cast(f32x4, make_uint4(0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u));      // 8 x fp16 1.0
+            // the column sums of this wave's A tile i = wn of the phase (a wave-uniform choice among fragments it holds anyway)
+            f32x4 cb = accb[mh];
+            switch (wn) {
+                case 0: cb = mfma16(ones, al[0], cb); cb = mfma16(ones, ah[0], cb); break;
+                case 1: cb = mfma16(ones, al[1], cb); cb = mfma16(ones, ah[1], cb); break;
+                case 2: cb = mfma16(ones, al[2], cb); cb = mfma16(ones, ah[2], cb); break;
+                default: cb = mfma16(ones, al[3], cb); cb = mfma16(ones, ah[3], cb); break;
+            }
+            accb[mh] = cb;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 c = acc[mh * 4 + i][j];
+                c = mfma16(bh[j], al[i], c);
+                c = mfma16(bl[j], ah[i], c);
+                c = mfma16(bh[j], ah[i], c);
+                acc[mh * 4 + i][j] = c;
+            }
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto end_load_vm4 = [&](bool wait4, bool wait0) {          // close a load segment; A(t+1) must have landed when asked
+        __builtin_amdgcn_sched_barrier(0);
+        if (wait4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else if (wait0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto k_loop = [&](auto cs_tag) {
+        constexpr bool CS = decltype(cs_tag)::value;
+        if (nkt > 1) end_compute_segment<4>(); else end_compute_segment<0>();          // A(0), B(0) landed; B(1) may fly
+        if (grp == 1) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll 1
+        for (int t = 0; t < nkt; ++t) {
+            const char* st = smem + (t & 1) * PSTAGE;
+            readB(st);
+            readA(st, 0);
+            if (t + 1 < nkt) dmaA(t + 1);
+            end_load_segment();
+            mma(std::integral_constant<int, 0>{}, cs_tag);
+            if (t + 1 < nkt) end_compute_segment<4>(); else end_compute_segment<0>();          // B(t+1) landed (A(t+1) may fly)
+            readA(st, 1);
+            if (t + 2 < nkt) dmaB(t + 2);
+            end_load_vm4(t + 2 < nkt, t + 1 < nkt);                                             // A(t+1) landed (B(t+2) may fly)
+            mma(std::integral_constant<int, 1>{}, cs_tag);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (grp == 0) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+    };
+    // A delayed scale outside its window (rare): this kernel has no fp32 fallback of its own -- with the split code inline the
+    // register allocator spilled inside the k-loop (230 -> 256 VGPRs + scratch).  The workgroup leaves without writing anything;
+    // the host has queued gemm_pl_tn behind this launch with ``only_fallback`` set: it evaluates the same predicate on the same
+    // headers and does the whole job in that case, nothing otherwise.
+    if (slowA || slowB) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // no LDS-DMA may be in flight when the workgroup's LDS is released
+        return;
+    }
+    if (do_colsum) k_loop(std::true_type{}); else k_loop(std::false_type{});
+
+    // ---- outputs
+    const bool split = gridDim.z > 1;
+    const float inv_a = 1.f / sa;
+    const float nanv = 0.f;
+    if (do_colsum && lq == 0) {          // every row of accb holds the column sums: lanes of column group 0 own 16 features each
+        float* dst = split ? q.colsum_ws + (size_t)kz * p.M : q.colsum_out;
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh) {
+            const int m = m0 + grp * 128 + mh * 64 + 16 * wn + l15;
+            if (m < p.M) dst[m] = accb[mh].x * inv_a + nanv;
+        }
+    }
+    const float inv_ab = inv_a * (1.f / sb);
+    float* Cout = split ? p.C + (size_t)kz * (size_t)p.slab_stride : p.C;
+    const __amdgpu_buffer_rsrc_t rsC = make_rsrc(Cout, (uint32_t)((((long long)p.M - 1) * p.ldc + p.N) * 4));
+    const int gm0 = m0 + grp * 128 + l15, gn0 = n0 + wn * 64 + 4 * lq;
+    uint32_t oCj[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) oCj[j] = (((uint32_t)gm0 * (uint32_t)p.ldc + (uint32_t)gn0) * 4u + 64u * j) | (gn0 + 16 * j < p.N ? 0u : BUF_OOB);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) buf_store4(rsC, oCj[j], (uint32_t)i * 16u * (uint32_t)p.ldc * 4u, acc[i][j] * inv_ab + nanv);
+}
+
+}  // namespace segmm
