@@ -562,13 +562,8 @@ int segmm_gemm_p(int layout, int M, int N, int K, const uint16_t* a_planes, int 
     // round-3 form (gemm_planes8.h): whole 256 x 256 tiles, plain or split-K stores (no accumulate into C), 32-bit output offsets
     static const int tn_var = getenv("SEGMM_TN_VAR") ? atoi(getenv("SEGMM_TN_VAR")) : 8;
     const bool tn8 = tn_var == 8 && M % PBM == 0 && N % PBN == 0 && !g.residual && (long long)M * (splits > 1 ? N : ldc) * 4 < (1ll << 31);
-    if (tn8) {
-        hipLaunchKernelGGL(gemm_pl_tn8, dim3(g.nbm * g.nbn, 1, splits), dim3(512), 0, s, g, q);
-        if (a_f32 || b_f32) {          // an operand may need its fp32 copy (decided on the device, from the site headers): the round-2
-            q.only_fallback = 1;       // kernel follows and does the job in that case -- its workgroups return at once otherwise
-            hipLaunchKernelGGL(gemm_pl_tn<0>, dim3(g.nbm * g.nbn, 1, splits), dim3(512), 0, s, g, q);
-        }
-    } else hipLaunchKernelGGL(gemm_pl_tn<0>, dim3(g.nbm * g.nbn, 1, splits), dim3(512), 0, s, g, q);
+    if (tn8) hipLaunchKernelGGL(gemm_pl_tn8, dim3(g.nbm * g.nbn, 1, splits), dim3(512), 0, s, g, q);
+    else hipLaunchKernelGGL(gemm_pl_tn<0>, dim3(g.nbm * g.nbn, 1, splits), dim3(512), 0, s, g, q);
     LAUNCH_CHECK();
     if (splits > 1) {          // one combine launch for the slabs AND the folded column sums
         const long long n4 = (long long)M * (N / 4);

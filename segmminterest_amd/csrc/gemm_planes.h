@@ -42,7 +42,6 @@ struct PGemmX {
     float* colsum_out; float* colsum_ws;       // TN only: optional [M] column sums of A over k (= bias gradient), split-K partials [splits][M]
     int dbg;                                   // timing ablations (SEGMM_PL_FLAGS; results are wrong when set): 1 no C stores, 2 no epilogue
     unsigned long long* stamps;                // SEGMM_STAMPS builds only (tools/probe/gemm_stamps.py): 8 x u64 per workgroup
-    int only_fallback;                         // gemm_pl_tn queued behind gemm_pl_tn8: run only if an operand needs its fp32 copy
 };
 
 constexpr int PBM = 256, PBN = 256, PBK = 32;
@@ -611,7 +610,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_tn(const GemmArgs p, const PGe
     const bool slowA = q.A.f32 != nullptr && !site_planes_ok(q.A.hdr, sa_hdr, lane);
     const bool slowB = q.B.f32 != nullptr && !site_planes_ok(q.B.hdr, sb_hdr, lane);
     float sa = sa_hdr, sb = sb_hdr;
-    if (q.only_fallback && !(slowA || slowB)) return;          // gemm_pl_tn8 (launched just before) has done the work
     if (slowA) sa = site_exact_scale(q.A.hdr, (float*)smem, tid, 512);
     if (slowB) sb = site_exact_scale(q.B.hdr, (float*)smem, tid, 512);
 

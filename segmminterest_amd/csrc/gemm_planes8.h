@@ -554,34 +554,67 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_tn8(const GemmArgs p, const PG
     const __amdgpu_buffer_rsrc_t rsA = make_rsrc(q.A.p, q.A.bytes), rsB = make_rsrc(q.B.p, q.B.bytes);
     const int t0 = 16 * grp + 4 * wn;
     const uint32_t inrow0 = (uint32_t)(((lane >> 2) << 6) + (((lane & 3) ^ ((wn >> 1) << 1)) << 4));
-    auto dmaA = [&](int kt) {
+    auto dmaA_pl = [&](int kt) {
         char* st = smem + (kt & 1) * PSTAGE + t0 * 1024;
         const uint32_t so = (uint32_t)(kbeg + kt * 32 + t0) * (uint32_t)q.A.ld2 * 2u + (uint32_t)m0 * 4u;
 #pragma unroll
         for (int i = 0; i < 4; ++i) lds_dma16(rsA, st + i * 1024, inrow0 ^ (uint32_t)(i << 6), so + (uint32_t)i * (uint32_t)q.A.ld2 * 2u);
     };
-    auto dmaB = [&](int kt) {
+    auto dmaB_pl = [&](int kt) {
         char* st = smem + (kt & 1) * PSTAGE + 32768 + t0 * 1024;
         const uint32_t so = (uint32_t)(kbeg + kt * 32 + t0) * (uint32_t)q.B.ld2 * 2u + (uint32_t)n0 * 4u;
 #pragma unroll
         for (int i = 0; i < 4; ++i) lds_dma16(rsB, st + i * 1024, inrow0 ^ (uint32_t)(i << 6), so + (uint32_t)i * (uint32_t)q.B.ld2 * 2u);
     };
-    dmaA(0);
-    dmaB(0);
-    if (nkt > 1) dmaB(1);
+    dmaA_pl(0);
+    dmaB_pl(0);
+    if (nkt > 1) dmaB_pl(1);
 
     // ---- operand state (all header words requested at once)
     auto uni = [](float x) { return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(x))); };
     const float ha0 = q.A.hdr[0], ha1 = q.A.hdr[1], hb0 = q.B.hdr[0], hb1 = q.B.hdr[1];
     const f32x4 ama = *(const f32x4*)(q.A.hdr + SITE_HDR + lane * 4), amb = *(const f32x4*)(q.B.hdr + SITE_HDR + lane * 4);
-    const float sa = uni(ha0), sb = uni(hb0);
+    const float sa0 = uni(ha0), sb0 = uni(hb0);
     auto planes_ok = [&](float s, float flag, f32x4 v) {
         const float m = wave_max(fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
         if (!(s > 0.f) || __float_as_uint(flag) != 0u) return false;
         return !(m > 0.f) || ((m * s >= 0.25f || s >= 0x1p60f) && m * s < 65504.f);
     };
-    const bool slowA = q.A.f32 != nullptr && !planes_ok(sa, uni(ha1), ama);          // delayed scale outside its window: fp32 fallback
-    const bool slowB = q.B.f32 != nullptr && !planes_ok(sb, uni(hb1), amb);
+    const bool slowA = q.A.f32 != nullptr && !planes_ok(sa0, uni(ha1), ama);          // delayed scale outside its window: fp32 fallback
+    const bool slowB = q.B.f32 != nullptr && !planes_ok(sb0, uni(hb1), amb);
+    const bool slow = slowA || slowB;
+    // Fallback (rare): the SAME schedule, with the group's share of a stage written by ds_write from the operand's fp32 copy --
+    // split with the exact scale of its recorded maxima -- instead of by LDS-DMA; every counted vmcnt wait becomes vmcnt(0) then
+    // (the counts assume four pieces of the other operand behind them).  A wave converts its 4 token rows, 4 features per lane and row.
+    float sa = sa0, sb = sb0;
+    if (slow) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the early pieces have landed before anything is restaged
+        if (slowA) sa = site_exact_scale(q.A.hdr, (float*)(smem + 2 * PSTAGE - 64), tid, 512);
+        if (slowB) sb = site_exact_scale(q.B.hdr, (float*)(smem + 2 * PSTAGE - 64), tid, 512);
+    }
+    auto stage_f32 = [&](const PlaneOperand& op, float sc, int kt, int f0, int nfeat, char* dst) {
+#pragma unroll 1
+        for (int i = 0; i < 4; ++i) {
+            const int t = t0 + i, gk = kbeg + kt * 32 + t, gf = f0 + lane * 4;
+            f32x4 x = {0.f, 0.f, 0.f, 0.f};
+            if (gk < kend && gf < nfeat) x = *(const f32x4*)(op.f32 + (size_t)gk * op.ldf + gf);
+            uint32_t hh0, l0, hh1, l1;
+            splith_pair(x.x, x.y, sc, hh0, l0); splith_pair(x.z, x.w, sc, hh1, l1);
+            // 8-byte group g8 = lane & 7 of feature block b = lane >> 3: 16-byte chunk g8 >> 1 (halves swapped for tokens with bit 3 set)
+            const int b = lane >> 3, g8 = lane & 7, cp = (g8 >> 1) ^ (((t >> 3) & 1) << 1), sw = t & 3;
+            *(uint2*)(dst + t * 1024 + (((2 * b) ^ sw) << 6) + (cp << 4) + ((g8 & 1) << 3)) = make_uint2(hh0, hh1);
+            *(uint2*)(dst + t * 1024 + (((2 * b + 1) ^ sw) << 6) + (cp << 4) + ((g8 & 1) << 3)) = make_uint2(l0, l1);
+        }
+    };
+    auto dmaA = [&](int kt) { if (slowA) stage_f32(q.A, sa, kt, m0, p.M, smem + (kt & 1) * PSTAGE); else dmaA_pl(kt); };
+    auto dmaB = [&](int kt) { if (slowB) stage_f32(q.B, sb, kt, n0, p.N, smem + (kt & 1) * PSTAGE + 32768); else dmaB_pl(kt); };
+    if (slow) {          // restage what the early pieces brought
+        __syncthreads();
+        dmaA(0);
+        dmaB(0);
+        if (nkt > 1) dmaB(1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (the ds_writes of the fallback are retired before the first barrier)
+    }
 
     // ---- transposed fragment reads: lane = (g = lq: token octet, qq = (lane >> 2) & 3: token inside a 4-block, pp = lane & 3)
     const int qq = (lane >> 2) & 3, pp = lane & 3;
@@ -650,7 +683,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_tn8(const GemmArgs p, const PG
     };
     auto end_load_vm4 = [&](bool wait4, bool wait0) {          // close a load segment; A(t+1) must have landed when asked
         __builtin_amdgcn_sched_barrier(0);
-        if (wait4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        if (wait4 && !slow) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
         else if (wait0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -659,7 +692,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_tn8(const GemmArgs p, const PG
     };
     auto k_loop = [&](auto cs_tag) {
         constexpr bool CS = decltype(cs_tag)::value;
-        if (nkt > 1) end_compute_segment<4>(); else end_compute_segment<0>();          // A(0), B(0) landed; B(1) may fly
+        if (nkt > 1 && !slow) end_compute_segment<4>(); else end_compute_segment<0>();          // A(0), B(0) landed; B(1) may fly
         if (grp == 1) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll 1
         for (int t = 0; t < nkt; ++t) {
@@ -669,7 +702,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_tn8(const GemmArgs p, const PG
             if (t + 1 < nkt) dmaA(t + 1);
             end_load_segment();
             mma(std::integral_constant<int, 0>{}, cs_tag);
-            if (t + 1 < nkt) end_compute_segment<4>(); else end_compute_segment<0>();          // B(t+1) landed (A(t+1) may fly)
+            if (t + 1 < nkt && !slow) end_compute_segment<4>(); else end_compute_segment<0>();          // B(t+1) landed (A(t+1) may fly)
             readA(st, 1);
             if (t + 2 < nkt) dmaB(t + 2);
             end_load_vm4(t + 2 < nkt, t + 1 < nkt);                                             // A(t+1) landed (B(t+2) may fly)
@@ -680,14 +713,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_tn8(const GemmArgs p, const PG
         }
         if (grp == 0) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
     };
-    // A delayed scale outside its window (rare): this kernel has no fp32 fallback of its own -- with the split code inline the
-    // register allocator spilled inside the k-loop (230 -> 256 VGPRs + scratch).  The workgroup leaves without writing anything;
-    // the host has queued gemm_pl_tn behind this launch with ``only_fallback`` set: it evaluates the same predicate on the same
-    // headers and does the whole job in that case, nothing otherwise.
-    if (slowA || slowB) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // no LDS-DMA may be in flight when the workgroup's LDS is released
-        return;
-    }
     if (do_colsum) k_loop(std::true_type{}); else k_loop(std::false_type{});
 
     // ---- outputs
