@@ -495,8 +495,9 @@ int segmm_gemm_p(int layout, int M, int N, int K, const uint16_t* a_planes, int 
                               (!c_planes || (long long)M * ldc2 * 2 < lim) &&
                               !(residual && (activation == EPI_DGELU || activation == EPI_DRELU));      // one extra operand per element
             if (fits) {
-                // tile width 64 NJ: the one that needs the fewest CU-rounds (a tile costs ~ 5 + 13.4 NJ us at K = 768); ties and
-                // near-ties go to the widest tile (least operand traffic per FLOP)
+                // tile width 64 NJ: the one that needs the fewest CU-rounds.  Measured tile times at K = 768 (stand-alone, round 3):
+                // 60.7 / 49 / 38 us for NJ = 4 / 3 / 2 = 15 + 11.4 NJ us -- a narrower tile carries the same A traffic, prologue and
+                // barrier count for less work -- so it only wins when it saves a whole round or more; near-ties go to the widest tile
                 static const int nj_env = getenv("SEGMM_PL_NJ") ? atoi(getenv("SEGMM_PL_NJ")) : 0;
                 int best = 4;
                 if (nj_env >= 2 && nj_env <= 4) best = nj_env;
@@ -505,7 +506,7 @@ int segmm_gemm_p(int layout, int M, int N, int K, const uint16_t* a_planes, int 
                     const int ncu = num_cus(), bm = (M + PBM - 1) / PBM;
                     for (int nj = 4; nj >= 2; --nj) {
                         const long long tiles = (long long)bm * ((N + 64 * nj - 1) / (64 * nj));
-                        const double cost = (double)((tiles + ncu - 1) / ncu) * (5.0 + 13.4 * nj * (K / 768.0));
+                        const double cost = (double)((tiles + ncu - 1) / ncu) * (15.0 + 11.4 * nj * (K / 768.0));
                         if (nj == 4 || cost < 0.93 * best_cost) { best = nj; best_cost = cost; }
                     }
                 }
