@@ -198,45 +198,45 @@ __global__ void dropout_mult_kernel(float* out, long long n, DropCfg d) {
 }
 
 
-// Diagnostic (bench.py roofline context): the sustained issue rate of v_mfma_f32_32x32x16_f16 with the GEMM's accumulator
-// pattern, its occupancy (8 waves per CU) and RANDOM operand bits, registers only.  With constant operands the MI355X holds
-// ~2.47 PFLOP/s; with random bits the power management clocks it down (~1.78 PFLOP/s measured) -- the ceiling a real-data GEMM
-// can reach on this part, below the 2.5 PFLOP/s datasheet figure bench.py prices against.
+// Diagnostic (bench.py roofline context): the sustained issue rate of the plane GEMMs' MFMA instruction with their accumulator
+// pattern, their occupancy (8 waves per CU) and RANDOM operand bits, registers only.  With constant operands the MI355X holds
+// ~2.47 PFLOP/s; with random bits the power management clocks it down (32x32x16: 1.6-1.78 PFLOP/s, 16x16x32: ~1.85 PFLOP/s,
+// box to box) -- the ceiling a real-data GEMM can reach on this part, below the 2.5 PFLOP/s datasheet figure bench.py prices against.
 namespace segmm {
 __global__ __launch_bounds__(512, 2) void mfma_rate_kernel(float* out, int iters, uint32_t seed) {
-    f32x16 acc[8];
+    // the plane GEMMs' instruction (round 3: v_mfma_f32_16x16x32_f16 -- the chip holds a higher clock on it than on 32x32x16),
+    // tile grid (8 x 4 accumulators of 16 x 16 per wave) and accumulator order (three products per accumulator, back to back)
+    f32x4 acc[8][4];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-    h8 a[4], b[2];
+    h8 a[8], b[4];
     uint32_t h = (threadIdx.x + blockIdx.x * 977u) * 2654435761u + seed;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int r = 0; r < 8; ++r) { h = h * 1664525u + 1013904223u; a[i][r] = (_Float16)(((int)(h >> 16) - 32768) * (1.f / 32768.f)); }
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int r = 0; r < 8; ++r) { h = h * 1664525u + 1013904223u; b[i][r] = (_Float16)(((int)(h >> 16) - 32768) * (1.f / 32768.f)); }
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
+        for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int pr = 0; pr < 3; ++pr)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i * 2 + j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[j], a[i], acc[i][j], 0, 0, 0);
         asm volatile("" ::: "memory");
     }
     float t = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) t += acc[i][r];
+        for (int j = 0; j < 4; ++j) t += acc[i][j].x + acc[i][j].y + acc[i][j].z + acc[i][j].w;
     if (t == 12345.678f) out[0] = t;          // never true: keeps the accumulators live
 }
 }  // namespace segmm
@@ -1062,7 +1062,7 @@ int segmm_probe_mfma_rate(int workgroups, int iters, float* scratch, double* flo
     SEGMM_REQUIRE(workgroups > 0 && iters > 0 && scratch, "probe_mfma_rate: workgroups/iters > 0 and a scratch float");
     hipLaunchKernelGGL(mfma_rate_kernel, dim3(workgroups), dim3(512), 0, (hipStream_t)stream, scratch, iters, 12345u);
     LAUNCH_CHECK();
-    if (flops_out) *flops_out = (double)workgroups * 8.0 * iters * 48.0 * 32768.0;
+    if (flops_out) *flops_out = (double)workgroups * 8.0 * iters * 96.0 * 16384.0;          // 96 MFMAs of 16 x 16 x 32 per wave and iteration
     return 0;
 }
 
