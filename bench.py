@@ -309,6 +309,15 @@ def main():
     prof_elapsed = time.perf_counter() - tp0
     hipabi.GEMM_PROFILE = hipabi.ATTN_PROFILE = hipabi.KERNEL_PROFILE = None
 
+    # data parallel: the replicas must still hold the SAME parameters (fp64 checksums of the flat parameter buffer of every rank)
+    replicas_identical = None
+    if world > 1:
+        flat = model._store.flat.detach().double()
+        cs = [float(flat.sum().item()), float((flat * flat).sum().item())]
+        allcs = [None] * world
+        dist.all_gather_object(allcs, cs)
+        replicas_identical = all(c == allcs[0] for c in allcs)
+
     engine = {hipabi.ENGINE_F32: "f32", hipabi.ENGINE_BF16X6: "bf16x6", hipabi.ENGINE_F16X3: "f16x3", hipabi.ENGINE_F16X3P: "f16x3p"}[hipabi.GEMM_ENGINE]
     ftrain = f_train_flops(Din, D, S, Lt, N, w["id_mode"])
     rec = None
@@ -328,7 +337,7 @@ def main():
                        "parallelism": "dp%d" % world + (" (forced one-rank process group)" if forced_dp else ""),
                        "backend": args.backend if (world > 1 or forced_dp) else None,
                        "grad_allreduce_overlap": not args.no_overlap, "input_prefetch": bool(args.prefetch and len(batches) > 1),
-                       "final_loss": round(loss, 6),
+                       "final_loss": round(loss, 6), "replicas_identical": replicas_identical,
                        "delayed_scale_overflows": (model._store.overflow_count() if model._store.engine_p else None),
                        "live_train_flops_per_interaction": ftrain, "gemm_engine": engine,
                        "step_frac_of_f32_mfma_peak": round(rows_per_s / world * ftrain / (PEAK_F32_MFMA_TFLOPS * 1e12), 4)},

@@ -139,8 +139,8 @@ class ParamStore:
         self.scratch: Dict[tuple, torch.Tensor] = {}
         self._params = None
         self.bucket_hook = None      # callable(bucket_name): set by the data-parallel trainer
-        # data-parallel id mode: callable(ids [B] int64, rows [B, w]) -> (ids of all ranks [G*B], rows of all ranks [G*B, w]);
-        # set by the trainer.  The table gradient is then built from the gathered per-row gradients on every rank and the
+        # data-parallel id mode: callable(ids [B] int64, rows [B, w]) -> closure yielding (ids of all ranks [G*B], rows of all
+        # ranks [G*B, w]) -- the collective is asynchronous, the closure waits for it (DPComm.gather_rows); set by the trainer.  The table gradient is then built from the gathered per-row gradients on every rank and the
         # table's range is left out of the dense gradient all-reduce (table_ranges()).
         self.row_exchange = None
         self._side_stream = None
@@ -1291,7 +1291,20 @@ class BackboneRun:
                 ar, ar32 = st.const_arange(B, torch.int64), st.const_arange(B, torch.int32)
                 rows.zero_()                                                               # the kernel accumulates into its output
                 H.embed_id_bwd(dpre, L, d, 0, width, ar32, ar, rows, B)                    # rows[b] = sum_s dpre[b, s, :width]
-                ids_all, rows_all = st.row_exchange(ids, rows)
+                pending = st.row_exchange(ids, rows)          # asynchronous all-gather: waited for below, after the work that needs no rows
+            else:
+                pending = None
+            if side == "vid":
+                dh_ = d // 2
+                _colsum(st, gpe, d, L, dh_, st.g(P + "frameid_proj.bias", gbuf), x_off=dh_)
+                if sv.get("frame_pos") is not None:      # noPos: positions differ per row -> weighted sum over all tokens
+                    _colsum(st, dpre, d, M, dh_, st.g(P + "frameid_proj.weight", gbuf).view(-1), x_off=dh_,
+                            w=sv["frame_pos"].view(-1))
+                else:
+                    pos = st.const_arange(L, torch.float32)
+                    _colsum(st, gpe, d, L, dh_, st.g(P + "frameid_proj.weight", gbuf).view(-1), x_off=dh_, w=pos)
+            if pending is not None:
+                ids_all, rows_all = pending()
                 order = _argsort_ids(ids_all)
                 H.embed_id_bwd(rows_all, 1, width, 0, width, order, ids_all, gtab, ids_all.numel())
                 touched = ids_all
@@ -1302,15 +1315,6 @@ class BackboneRun:
             # (a dense all-reduce of the table under data parallelism adds the OTHER ranks' rows: no row list then)
             if gbuf is None and (st.bucket_hook is None or st.row_exchange is not None):
                 st._tab_rows[P + side] = (gtab.data_ptr(), touched.reshape(-1))          # (zero_rows skips ids outside the table)
-            if side == "vid":
-                dh_ = d // 2
-                _colsum(st, gpe, d, L, dh_, st.g(P + "frameid_proj.bias", gbuf), x_off=dh_)
-                if sv.get("frame_pos") is not None:      # noPos: positions differ per row -> weighted sum over all tokens
-                    _colsum(st, dpre, d, M, dh_, st.g(P + "frameid_proj.weight", gbuf).view(-1), x_off=dh_,
-                            w=sv["frame_pos"].view(-1))
-                else:
-                    pos = st.const_arange(L, torch.float32)
-                    _colsum(st, gpe, d, L, dh_, st.g(P + "frameid_proj.weight", gbuf).view(-1), x_off=dh_, w=pos)
         else:
             x = sv["%s_x" % side]
             Din = x.cols

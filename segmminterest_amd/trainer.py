@@ -225,22 +225,47 @@ class DPComm:
         return finish
 
     def gather_rows(self, ids, rows):
-        """(ids of all ranks [G*B], rows of all ranks [G*B, w]) in rank order: the sparse exchange of id-table gradients
-        (every rank holds the same B, like :meth:`global_label_stats`)."""
+        """Sparse exchange of id-table gradients: returns a CLOSURE that yields (ids of all ranks [G*B], rows of all ranks
+        [G*B, w]) in rank order (every rank holds the same B, like :meth:`global_label_stats`).
+
+        ONE asynchronous all-gather of ``[rows | id]`` per rank (the int64 id rides in two float lanes of its row) on a process
+        group OF ITS OWN: on the gradient group it would queue behind every bucket all-reduce still in flight on that group's
+        RCCL stream.  The caller issues it as soon as the compact rows exist and calls the closure right before the segment sum
+        (engine._embed_bwd), so the collective and the rank skew it absorbs run under the rest of the embedding backward."""
         if not self.active:
-            return ids, rows
+            return lambda: (ids, rows)
         ids, rows = ids.contiguous(), rows.contiguous()
+        B, w = rows.shape
+        packed = torch.empty((B, w + 2), dtype=torch.float32, device=rows.device)
+        packed[:, :w] = rows
+        packed[:, w:] = ids.to(torch.int64).view(B, 1).view(torch.float32)          # bit pattern of the id, not a conversion
         if self.host_staged and rows.is_cuda:
-            hi = torch.empty((self.world * ids.shape[0],), dtype=ids.dtype)
-            hr = torch.empty((self.world * rows.shape[0], rows.shape[1]), dtype=rows.dtype)
-            self.dist.all_gather_into_tensor(hi, ids.cpu(), group=self.group)
-            self.dist.all_gather_into_tensor(hr, rows.cpu(), group=self.group)
-            return hi.to(ids.device), hr.to(rows.device)
-        ids_all = torch.empty((self.world * ids.shape[0],), dtype=ids.dtype, device=ids.device)
-        rows_all = torch.empty((self.world * rows.shape[0], rows.shape[1]), dtype=rows.dtype, device=rows.device)
-        self.dist.all_gather_into_tensor(ids_all, ids, group=self.group)
-        self.dist.all_gather_into_tensor(rows_all, rows, group=self.group)
-        return ids_all, rows_all
+            hg = torch.empty((self.world * B, w + 2), dtype=torch.float32)
+            self.dist.all_gather_into_tensor(hg, packed.cpu(), group=self.group)
+            gathered, work = hg.to(rows.device), None
+        else:
+            gathered = torch.empty((self.world * B, w + 2), dtype=torch.float32, device=rows.device)
+            work = self.dist.all_gather_into_tensor(gathered, packed, group=self._row_group(), async_op=True)
+
+        def finish():
+            if work is not None:
+                work.wait()          # stream-level wait on the row group's communication stream, no host sync
+            ids_all = gathered[:, w:].contiguous().view(torch.int64).view(-1)
+            return ids_all.to(ids.dtype), gathered[:, :w].contiguous()
+        return finish
+
+    def _row_group(self):
+        """Process group of the row exchange (same ranks as the gradient group; created on first use, by every rank at the
+        same point of its first data-parallel backward).  A one-rank forced group (tests) shares the gradient group."""
+        g = self.__dict__.get("_rowg")
+        if g is None:
+            if self.world > 1:
+                ranks = self.dist.get_process_group_ranks(self.group) if self.group is not None else list(range(self.dist.get_world_size()))
+                g = self.dist.new_group(ranks=ranks, backend=self.dist.get_backend(self.group))
+            else:
+                g = self.group if self.group is not None else self.dist.group.WORLD
+            self._rowg = g
+        return g
 
     def gather_ints(self, t):
         """[G*B] int32: the values of every rank in rank order (validation: leave ranks of the global batch)."""

@@ -58,7 +58,10 @@ def _worker(rank, world, port, q):
         gen = torch.Generator().manual_seed(100 + rank)
         ids = torch.randint(0, 6, (5,), generator=gen)
         rows = torch.randn(5, 4, generator=gen)
-        ids_all, rows_all = comm.gather_rows(ids, rows)
+        pending = comm.gather_rows(ids, rows)          # asynchronous, on a process group of its own
+        assert callable(pending)
+        ids_all, rows_all = pending()
+        assert ids_all.dtype == ids.dtype
         assert ids_all.shape == (5 * world,) and rows_all.shape == (5 * world, 4)
         assert torch.equal(ids_all[5 * rank:5 * rank + 5], ids) and torch.equal(rows_all[5 * rank:5 * rank + 5], rows)
         r_all = comm.gather_ints(torch.arange(5, dtype=torch.int32) + 10 * rank)       # validation: leave ranks of every rank's rows

@@ -200,3 +200,26 @@ def test_rccl_single_rank_step_equals_plain_step(name):
             assert (sd0[k] == sd1[k]).all(), k
     for k in v0:
         assert v0[k] == v1[k], (k, v0[k], v1[k])
+
+
+def test_bench_launcher_four_ranks_on_one_gpu():
+    """bench.py --gpus N end to end, the way the driver starts it for N > 1 (a child torch.distributed.run, one rank per
+    process, rows sharded, global loss normalisers, bucketed all-reduce, per-bucket AdamW): config 4 at a toy width, FOUR
+    gloo ranks sharing this GPU (the GPU boxes admit at most 6 processes on the card, so 8 ranks cannot be rehearsed here).
+    One JSON line, n_gpus = 4, every rank ends with bit-identical parameters."""
+    import json
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--backend", "gloo", "--config", "4", "--global-batch", "64",
+           "--dim", "64", "--heads", "4", "--lt", "12", "--steps", "3", "--warmup", "1", "--batches", "2",
+           "--no-cpu-baseline", "--no-f32-engine", "--no-host-fed", "--no-probe"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None); env.pop("LOCAL_RANK", None)
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 4 and rec["scaling"] == "weak" and rec["value"] > 0
+    assert rec["config"]["global_batch"] == 64 and rec["config"]["rows_per_gpu"] == 16
+    assert rec["config"]["replicas_identical"] is True
+    assert rec["config"]["parallelism"].startswith("dp4")
