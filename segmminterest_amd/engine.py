@@ -542,11 +542,14 @@ def _splits_for(M, N, K):
     return max(1, min(32, ktiles, (_SPLIT_TARGET + tiles - 1) // tiles))
 
 
+_SPLIT_TARGET_P = int(os.environ.get("SEGMM_SPLIT_TARGET_P", "256"))     # workgroups a plane-operand weight gradient aims for
+
+
 def _splits_for_p(M, N, K):
     """Split-K factor of a plane-operand weight-gradient GEMM (256 x 256 tiles, one workgroup per CU): fill the 256 CUs once."""
     tiles = ((M + 255) // 256) * ((N + 255) // 256)
     ktiles = (K + 31) // 32
-    return max(1, min(64, ktiles, 256 // tiles if tiles <= 256 else 1))
+    return max(1, min(64, ktiles, _SPLIT_TARGET_P // tiles if tiles <= _SPLIT_TARGET_P else 1))
 
 
 @contextlib.contextmanager

@@ -733,7 +733,7 @@ def test_loss_curve_under_dropout_tracks_the_oracle():
         batch = dict(user=g["in"]["usr_image"].to(DEV), photo=g["in"]["vid_image"].to(DEV), user_mask=g["in"]["usr_mask"].to(DEV),
                      photo_mask=g["in"]["vid_mask"].to(DEV), label=g["in"]["gt"].to(DEV), user_identity_id=g["in"]["usr_id"].to(DEV),
                      photo_identity_id=g["in"]["vid_id"].to(DEV))
-        tr.normalize = lambda key, x: x                      # the fixture's features are already L1-normalised
+        tr.normalize = lambda key, x, *a, **k: x             # the fixture's features are already L1-normalised
         torch.manual_seed(seed)
         curves_h.append([float(tr.train_step(batch)["loss"]) for _ in range(steps)])
     co, ch = torch.tensor(curves_o), torch.tensor(curves_h)
