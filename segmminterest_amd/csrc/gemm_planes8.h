@@ -92,7 +92,8 @@ template <int NJ>
 __global__ __launch_bounds__(512, 2) void gemm_pl_nt8(const GemmArgs p, const PGemmX q) {
     static_assert(NJ >= 2 && NJ <= 4, "tile widths 128, 192, 256");
     constexpr int BNW = 64 * NJ;                                         // tile columns
-    __shared__ __attribute__((aligned(16))) char smem[2 * PSTAGE];      // 128 KB: two stages x (A 32 KB | B 16 NJ KB)
+    // 128 KB: two stages x (A 32 KB | B 16 NJ KB); + 32 KB: a 16-row x 256-byte transpose patch per wave for the epilogue's stores
+    __shared__ __attribute__((aligned(16))) char smem[2 * PSTAGE + 8 * 4096];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, wn = wave & 3;          // grp = wm: rows [128 grp, +128) of the tile; columns [16 NJ wn, +16 NJ)
@@ -325,24 +326,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_nt8(const GemmArgs p, const PG
             colmask[j] = gn < p.N ? 0u : BUF_OOB;
             bias4[j] = (p.bias && gn < p.N) ? *(const f32x4*)(p.bias + gn) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        // per-lane byte offsets of row block 0 (the row block enters as the SCALAR offset of the buffer instruction), one per
-        // column tile with the column mask folded in
-        uint32_t oCj[NJ], oAuxj[NJ];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            oCj[j] = (((uint32_t)gm0 * (uint32_t)p.ldc + (uint32_t)gn0) * 4u + 64u * j) | colmask[j];
-            oAuxj[j] = (((uint32_t)gm0 * (uint32_t)p.ldaux + (uint32_t)gn0) * 4u + 64u * j) | colmask[j];
-        }
         const bool full_tile = m0 + PBM <= p.M && n0 + BNW <= p.N;
-        // plane store: after the lane exchange a lane with an even column group holds the 8 hi terms, an odd one the 8 lo terms
-        // of the aligned 8 columns cb .. cb + 7
-        uint32_t oPlj[NJ];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int cb = n0 + wn * 16 * NJ + 8 * (lq >> 1) + 16 * j;
-            oPlj[j] = (((uint32_t)gm0 * (uint32_t)q.ldc2 + (uint32_t)(((cb >> 5) << 6) + (cb & 31) + ((lq & 1) ? 32 : 0))) * 2u) | colmask[j];
-        }
-
         // E quarter qq -> LDS half (qq & 1): slot s = 32 g + r (g = wave group, r = row inside the group's 32 rows of the quarter) at
         // byte s * 1024; 16-byte chunk c of the row at physical chunk c ^ (row & 15) (conflict-free ds_read_b128 of the accumulator
         // layout: 16 rows x 4 chunks per instruction); the permutation is applied to the DMA source address
@@ -359,17 +343,34 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_nt8(const GemmArgs p, const PG
                 lds_dma16(rsE, dst + slot * 1024, vo, ((uint32_t)er * (uint32_t)ldE + (uint32_t)n0) * 4u);
             }
         };
-        auto vmwait = [&](int kind) {          // kind 0: 8 newer ops; 1: S + 8; 2: S newer ops, S = 2 NJ ns stores of the last quarter
-            __builtin_amdgcn_sched_barrier(0);
+        auto vmwait = [&](int kind) {          // kind 0: 8 newer ops; 1: S + 8; 2: S newer ops, S = 8 ns store instructions of the last quarter
+            __builtin_amdgcn_sched_barrier(0);          // (2 row blocks x 4 row-segment stores per output tensor)
             if (kind == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else if (ns == 1) { if (kind == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NJ + 8) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NJ) : "memory"); }
-            else if (ns == 2) { if (kind == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * NJ + 8) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * NJ) : "memory"); }
-            else if (ns == 3) { if (kind == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(6 * NJ + 8) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(6 * NJ) : "memory"); }
+            else if (ns == 1) { if (kind == 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+            else if (ns == 2) { if (kind == 1) asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }
+            else if (ns == 3) { if (kind == 1) asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); }
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
         };
+        // ---- stores.  In the accumulator layout a lane owns 16 bytes of ITS row: the 16 lanes of a quarter-wave touch 16
+        // different cache lines, 64 sixteen-byte transactions per store instruction -- 18.8 k cycles to drain a 256 KB tile on an
+        // otherwise idle chip against 5.4 k for stores that cover 256 contiguous bytes per quarter-wave (tools/probe/store_rate.hip).
+        // Each 16-row x 16 NJ-column strip therefore takes a detour through a wave-private 4 KB LDS patch (chunk c of row r at
+        // physical chunk c ^ r: conflict-free both ways) and is stored as whole 64 NJ-byte row segments: lane (lq, l15) of pass t
+        // stores row 4 t + lq, columns 4 l15 .. 4 l15 + 3 of the strip.
+        char* trp = smem + 2 * PSTAGE + wave * 4096;
+        const uint32_t tr_w = (uint32_t)(l15 * 256);                                   // + ((lq + 4 j) ^ l15) << 4
+        const int gnT = n0 + wn * 16 * NJ + 4 * l15;
+        const uint32_t tmask = (l15 < 4 * NJ && gnT < p.N) ? 0u : BUF_OOB;
+        const uint32_t oCT = (((uint32_t)(m0 + grp * 128 + lq) * (uint32_t)p.ldc + (uint32_t)gnT) * 4u) | tmask;
+        const uint32_t oAuxT = (((uint32_t)(m0 + grp * 128 + lq) * (uint32_t)p.ldaux + (uint32_t)gnT) * 4u) | tmask;
+        auto tr_put = [&](int j, f32x4 v) { *(f32x4*)(trp + tr_w + (((lq + 4 * j) ^ l15) << 4)) = v; };
+        auto tr_get = [&](int t) { const int r = 4 * t + lq; return *(const f32x4*)(trp + r * 256 + (((l15 ^ r) & 15) << 4)); };
+        // planes of a transposed float4: adjacent lanes hold adjacent column groups of one row (plane_store4_pair's pattern)
+        const uint32_t oPlT = (((uint32_t)(m0 + grp * 128 + lq) * (uint32_t)q.ldc2 + (uint32_t)((((gnT & ~7) >> 5) << 6) + ((gnT & ~7) & 31) + ((l15 & 1) ? 32 : 0))) * 2u) | tmask;
+
         // The row-block loop exists in twelve copies -- activation class (none / ReLU-type / GELU-type) x dropout x plane output
         // fixed at compile time -- picked once per tile: with every option tested inside ONE body, the dozen taken branches per
         // float4 (each hopping over an inlined erf) and ~60 VALU instructions cost more than the stores (21 k cycles per tile,
@@ -409,7 +410,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_nt8(const GemmArgs p, const PG
                     f32x4 v = c[j] * inv_ab + bias4[j];
                     if (ACT == 2) {
                         if (epi == EPI_GELU) {
-                            buf_store4(rsAuxW, oAuxj[j], soAux, v);
+                            tr_put(j, v);          // the pre-activation leaves through the transpose patch below
                             v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
                         } else {
                             v.x *= gelu_erf_grad(e[j].x); v.y *= gelu_erf_grad(e[j].y); v.z *= gelu_erf_grad(e[j].z); v.w *= gelu_erf_grad(e[j].w);
@@ -424,7 +425,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_nt8(const GemmArgs p, const PG
                     if (DROP) v = drop_apply4(p.drop, ((uint64_t)gm * (uint64_t)p.N + (uint64_t)(gn0 + 16 * j)) >> 2, v);
                     if (ACT == 0) v += e[j];                    // e = 0 without a residual
                     else if (has_res) v += e[j];                // (e is the aux tensor of an activation gradient otherwise)
-                    buf_store4(rsC, oCj[j], soC, v);
+                    c[j] = v;
                     {          // running max |v| over the elements that exist (branch-free: rows / columns beyond the matrix are masked to 0)
                         const uint32_t mk = rowmask & ~((int32_t)colmask[j] >> 31);
                         const float mx = __uint_as_float(__float_as_uint(v.x) & mk), my = __uint_as_float(__float_as_uint(v.y) & mk);
@@ -432,15 +433,27 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_nt8(const GemmArgs p, const PG
                         asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(am) : "v"(mx), "v"(my));
                         asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(am) : "v"(mz), "v"(mw));
                     }
+                }
+                if (ACT == 2 && epi == EPI_GELU) {          // the pre-activations (put above), as whole row segments
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) buf_store4(rsAuxW, oAuxT, soAux + (uint32_t)(4 * t) * (uint32_t)p.ldaux * 4u, tr_get(t));
+                }
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) tr_put(j, c[j]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const f32x4 v = tr_get(t);
+                    buf_store4(rsC, oCT, soC + (uint32_t)(4 * t) * (uint32_t)p.ldc * 4u, v);
                     if (PLANES) {
-                        // P32 planes of 4 columns when the other half of the aligned 8 sits in the lane 16 further: one
-                        // v_permlane16_swap per dword -- even column groups end up with the 8 hi terms, odd groups with the 8 lo terms
+                        // adjacent lanes hold adjacent float4 column groups of one row: the pair trades half of its terms through
+                        // DPP -- the even lane stores the 8 hi terms, the odd lane the 8 lo terms of the aligned 8 columns
                         uint32_t h0, l0, h1, l1;
                         splith_pair(v.x, v.y, c_scale, h0, l0);
                         splith_pair(v.z, v.w, c_scale, h1, l1);
-                        const auto r0 = __builtin_amdgcn_permlane16_swap(h0, l0, false, false);
-                        const auto r1 = __builtin_amdgcn_permlane16_swap(h1, l1, false, false);
-                        buf_store4u(rsPl, oPlj[j], (uint32_t)i * 16u * (uint32_t)q.ldc2 * 2u, u32x4_t{r0[0], r1[0], r0[1], r1[1]});
+                        const bool oddl = (l15 & 1) != 0;
+                        const uint32_t r0 = dpp_swap1(oddl ? h0 : l0), r1 = dpp_swap1(oddl ? h1 : l1);
+                        const u32x4_t w = oddl ? u32x4_t{r0, r1, l0, l1} : u32x4_t{h0, h1, r0, r1};
+                        buf_store4u(rsPl, oPlT, (uint32_t)(16 * i + 4 * t) * (uint32_t)q.ldc2 * 2u, w);
                     }
                 }
                 if (has_e && (i & 1) == 1 && i < 5) {          // both row blocks of the quarter are read: refill its half with quarter + 2
@@ -463,10 +476,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_nt8(const GemmArgs p, const PG
                 for (int j = 0; j < NJ; ++j) {
                     f32x4 v = acc[i][j] * inv_ab + bias4[j];
                     if (HAS_E) v += *(const f32x4*)(ebuf + (((4 * NJ * wn + 4 * j + lq) ^ l15) << 4));
-                    buf_store4(rsC, oCj[j], soC, v);
                     asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(am) : "v"(v.x), "v"(v.y));
                     asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(am) : "v"(v.z), "v"(v.w));
+                    tr_put(j, v);
                 }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) buf_store4(rsC, oCT, soC + (uint32_t)(4 * t) * (uint32_t)p.ldc * 4u, tr_get(t));
                 if (HAS_E && (i & 1) == 1 && i < 5) {
                     end_load_segment();
                     dmaE((i >> 1) + 2);
@@ -533,7 +548,8 @@ __device__ __forceinline__ f32x4 lds_tr8b(const char* a) {          // 8 tokens 
 }
 
 __global__ __launch_bounds__(512, 2) void gemm_pl_tn8(const GemmArgs p, const PGemmX q) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * PSTAGE];      // two stages x (A: 32 tokens x 1 KB | B: 32 tokens x 1 KB)
+    // two stages x (A: 32 tokens x 1 KB | B: 32 tokens x 1 KB) + a 4 KB transpose patch per wave for the output stores
+    __shared__ __attribute__((aligned(16))) char smem[2 * PSTAGE + 8 * 4096];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, wn = wave & 3;
@@ -730,14 +746,20 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_tn8(const GemmArgs p, const PG
     const float inv_ab = inv_a * (1.f / sb);
     float* Cout = split ? p.C + (size_t)kz * (size_t)p.slab_stride : p.C;
     const __amdgpu_buffer_rsrc_t rsC = make_rsrc(Cout, (uint32_t)((((long long)p.M - 1) * p.ldc + p.N) * 4));
-    const int gm0 = m0 + grp * 128 + l15, gn0 = n0 + wn * 64 + 4 * lq;
-    uint32_t oCj[4];
+    // whole 256-byte row segments through the wave's transpose patch (see gemm_pl_nt8: 16-byte-per-row stores drain 3.5x slower)
+    char* trp = smem + 2 * PSTAGE + wave * 4096;
+    const int gnT = n0 + wn * 64 + 4 * l15;
+    const uint32_t oCT = (((uint32_t)(m0 + grp * 128 + lq) * (uint32_t)p.ldc + (uint32_t)gnT) * 4u) | (gnT < p.N ? 0u : BUF_OOB);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) oCj[j] = (((uint32_t)gm0 * (uint32_t)p.ldc + (uint32_t)gn0) * 4u + 64u * j) | (gn0 + 16 * j < p.N ? 0u : BUF_OOB);
+    for (int i = 0; i < 8; ++i) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+        for (int j = 0; j < 4; ++j) *(f32x4*)(trp + l15 * 256 + (((lq + 4 * j) ^ l15) << 4)) = acc[i][j] * inv_ab + nanv;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) buf_store4(rsC, oCj[j], (uint32_t)i * 16u * (uint32_t)p.ldc * 4u, acc[i][j] * inv_ab + nanv);
+        for (int t = 0; t < 4; ++t) {
+            const int r = 4 * t + lq;
+            buf_store4(rsC, oCT, (uint32_t)(16 * i + 4 * t) * (uint32_t)p.ldc * 4u, *(const f32x4*)(trp + r * 256 + (((l15 ^ r) & 15) << 4)));
+        }
+    }
 }
 
 }  // namespace segmm
