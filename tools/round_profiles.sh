@@ -1,5 +1,5 @@
 # Round checkpoint on the GPU box: every number the docs quote, in one call.   bash tools/round_profiles.sh <tag> <git sha>
-TAG=${1:-r2}; export GIT_SHA=${2:-unknown}
+TAG=${1:-r3}; export GIT_SHA=${2:-unknown}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
@@ -25,5 +25,8 @@ bash tools/pmc_run.sh ${TAG}_pmc_nt gemm_pl tools/gemm_p_one.py nt 20480 3072 76
 bash tools/pmc_run.sh ${TAG}_pmc_tn gemm_pl tools/gemm_p_one.py tn 3072 768 20480 > /dev/null 2>&1; cp gpurun_out/${TAG}_pmc_tn/summary.csv $O/gemm_pl_tn_3072x768x20480_pmc.csv
 bash tools/pmc_run.sh ${TAG}_pmc_attn attn_ tools/attn_bench.py 3 > /dev/null 2>&1; grep -v "dq_kernel\|dkv_kernel\|D_kernel" gpurun_out/${TAG}_pmc_attn/summary.csv > $O/attention_pmc.csv
 ./build/probe/mfma_rate > $O/mfma_rate_probe.txt 2>&1
+./build/probe/mfma_shape > $O/mfma_shape_probe.txt 2>&1
+./build/probe/store_rate > $O/store_rate_probe.txt 2>&1
+for s in "20480 3072 768" "20480 768 3072" "4096 1024 768"; do SEGMM_LIB=$R/build/probe/libsegmm_stamps.so python tools/probe/gemm_stamps.py $s; done > $O/gemm_tile_stamps.txt 2>&1
 python tools/gemm_p_check.py > $O/gemm_p_standalone.txt 2>&1
 ls -la $O
