@@ -387,7 +387,8 @@ def main():
             if os.path.exists(tpath):
                 with open(tpath) as f:
                     tj = json.load(f)
-                if tj.get("engine") == engine:          # only a pass over THIS engine's kernels counts
+                # only a pass over THIS engine's kernels on THIS workload's launch shapes counts (the committed pass is config 2)
+                if tj.get("engine") == engine and args.config == 2 and not (args.batch or args.dim or args.layers or args.segments or args.global_batch):
                     traffic = round(tj["hbm_bytes_per_launch"])
                     traffic_note = "; traffic = mean HBM-side bytes per GEMM launch from profiles/hbm_traffic.json (git %s; %s)" % (tj.get("git", "?"), tj["method"])
             rec["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",

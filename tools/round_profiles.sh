@@ -27,6 +27,6 @@ bash tools/pmc_run.sh ${TAG}_pmc_attn attn_ tools/attn_bench.py 3 > /dev/null 2>
 ./build/probe/mfma_rate > $O/mfma_rate_probe.txt 2>&1
 ./build/probe/mfma_shape > $O/mfma_shape_probe.txt 2>&1
 ./build/probe/store_rate > $O/store_rate_probe.txt 2>&1
-for s in "20480 3072 768" "20480 768 3072" "4096 1024 768"; do SEGMM_LIB=$R/build/probe/libsegmm_stamps.so python tools/probe/gemm_stamps.py $s; done > $O/gemm_tile_stamps.txt 2>&1
+for s in "20480 3072 768" "20480 768 3072" "20480 768 768 3" "4096 1024 768 2"; do SEGMM_LIB=$R/build/probe/libsegmm_stamps.so python tools/probe/gemm_stamps.py $s; done > $O/gemm_tile_stamps.txt 2>&1
 python tools/gemm_p_check.py > $O/gemm_p_standalone.txt 2>&1
 ls -la $O
