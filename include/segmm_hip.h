@@ -284,11 +284,17 @@ int segmm_gather_l1(const float* table, int64_t n_lines, int D, const int64_t* i
  * also gain[idx] = max|x| / gmax[0] (segmm_loss_finish turns it into the next step's scale). */
 int segmm_scales_update(const float* arena, const int32_t* site_idx, int n_rows, float* site_scale, float* stats, int target,
                         float* gain, const float* gmax, segmm_stream_t stream);
-/* DIAGNOSTIC, not part of the reference path: launches `workgroups` x 512 threads that issue `iters` x 48 v_mfma_f32_32x32x16_f16
+/* DIAGNOSTIC, not part of the reference path: launches `workgroups` x 512 threads that issue `iters` x 48 v_mfma_f32_16x16x32_f16
  * per wave on random operand bits (registers only, the plane GEMM's accumulator order and occupancy); *flops_out = the fp16 MFMA
  * FLOPs of the launch.  bench.py times it to report the SUSTAINED matrix-core rate of the part beside the datasheet peak
  * (power management clocks a random-data MFMA stream down; constant operands do not show it). */
 int segmm_probe_mfma_rate(int workgroups, int iters, float* scratch, double* flops_out, segmm_stream_t stream);
+
+/* Arithmetic of the attention kernels (models/encoder.py:44-73,138-161): 0 = exact-fp32 matrix-core products everywhere,
+ * 1 = fp16x3 products (22-bit operands, the GEMM engine's arithmetic) where that form is built and measured faster (default;
+ * env SEGMM_ATTN=f32|f16|f16all sets the initial value), 2 = fp16x3 wherever it is built.  Returns the previous mode; mode < 0
+ * only queries.  Results of the two forms agree to ~1e-6 relative; both are deterministic. */
+int segmm_attn_mode(int mode);
 
 /* (f)-3 SegRec weighted head (ClipRec.forward, SegRec/models/context/ClipRec.py:163-181): out[r] = sum_seg pred[r, seg] *
  * weight[r, seg] * (seg < duration[r]); weight == null: ones, duration == null: no duration mask. */

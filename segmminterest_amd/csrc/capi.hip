@@ -6,7 +6,7 @@
 #include <stdlib.h>
 
 #include "../../include/segmm_hip.h"
-#include "attention.h"
+#include "attention16.h"
 #include "common.h"
 #include "evalops.h"
 #include "gemm.h"
@@ -77,6 +77,14 @@ static int attn_fill(AttnArgs& a, int B, int H, int dh, int Lq, int La, int Lb, 
     return 0;
 }
 
+// SEGMM_ATTN=f32 keeps every attention kernel on the exact-fp32 matrix-core form (attention.h); default: the fp16x3 form
+// (attention16.h) where it is built (head dims 16, 32, 48) and measured faster
+static int g_attn_mode = -1;
+static int attn_f16() {          // 0: exact-fp32 kernels only; 1 (default): fp16x3 where it is faster; 2: fp16x3 wherever it is built
+    if (g_attn_mode < 0) g_attn_mode = !getenv("SEGMM_ATTN") ? 1 : !strcmp(getenv("SEGMM_ATTN"), "f32") ? 0 : !strcmp(getenv("SEGMM_ATTN"), "f16all") ? 2 : 1;
+    return g_attn_mode;
+}
+
 // workgroup shape for n row tiles per head: wq tiles x hpb adjacent heads, at most max_waves waves, every wave busy
 static void attn_shape(int n, int H, int max_waves, int want_default, const char* env, int& wq, int& hpb) {
     wq = n;
@@ -134,9 +142,23 @@ static int attn_launch_bwd(AttnArgs& a, int phase, hipStream_t s) {
             const int nw = fmode == 1 ? nmax : (blk == 0 ? nta : ntb);
             if (nw == 0) continue;
             a.hpb = fmode == 1 ? 2 : blk;
-            const size_t lds = ((size_t)3 * Lq_p * (DH + 4) + 3 * Lq_p + (size_t)nw * 16 * 20 + 4 + (size_t)Lq_p * (DH / 4)) * 4 + Lq_p + Tp;
+            const size_t lds = ((size_t)3 * Lq_p * (DH + 4) + 3 * Lq_p + (size_t)nw * 16 * 20 + 4 + 36 + (size_t)Lq_p * (DH / 4)) * 4 + Lq_p + Tp;
             const dim3 grid((fmode == 1 ? 2 : 1) * a.B * a.H), block(64 * nw);
             const bool one = a.Lq <= ATT_FUSED_QCHUNK;
+            if constexpr (DH % 16 == 0 && DH <= 48) {
+                // fp16x3 matrix-core form (attention16.h).  Single-chunk launches only by default: with several query chunks the
+                // kernel needs more than the 128 registers that keep two 7-wave workgroups on a CU and loses to the fp32 form
+                // (Lq = 100: 1 459 vs 1 199 us); SEGMM_ATTN=f16all forces it everywhere it is built (parity tests)
+                if (attn_f16() >= (one ? 1 : 2)) {
+#define FUSED16(NWV) do { if (one) hipLaunchKernelGGL((attn_bwd_fused16_kernel<DH, NWV, true>), grid, block, lds, s, a); \
+                          else hipLaunchKernelGGL((attn_bwd_fused16_kernel<DH, NWV, false>), grid, block, lds, s, a); } while (0)
+                    if (nw <= 4) FUSED16(4);
+                    else if (nw <= 8) FUSED16(8);
+                    else FUSED16(12);
+#undef FUSED16
+                    continue;
+                }
+            }
 #define FUSED(NWV) do { if (one) hipLaunchKernelGGL((attn_bwd_fused_kernel<DH, NWV, true>), grid, block, lds, s, a); \
                         else hipLaunchKernelGGL((attn_bwd_fused_kernel<DH, NWV, false>), grid, block, lds, s, a); } while (0)
             if (nw <= 4) FUSED(4);
@@ -244,7 +266,8 @@ __global__ __launch_bounds__(512, 2) void mfma_rate_kernel(float* out, int iters
 extern "C" {
 
 const char* segmm_last_error(void) { return g_segmm_err; }
-int segmm_abi_version(void) { return 16; }
+int segmm_abi_version(void) { return 17; }
+int segmm_attn_mode(int mode) { const int prev = attn_f16(); if (mode >= 0 && mode <= 2) g_attn_mode = mode; return prev; }
 
 static PlaneOut plane_out(uint16_t* planes, int ld2, float* hdr, const float* scale_in) {
     PlaneOut po;

@@ -15,7 +15,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SEGMM_LIB") or os.path.join(_HERE, "libsegmm_hip.so")      # SEGMM_LIB: A/B builds of the kernels
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 _lib = None
 
@@ -33,6 +33,7 @@ SIGNATURES = {
                      _u32, _i, _p, _i, _p, _p],
     "segmm_scales_update": [_p, _p, _i, _p, _p, _i, _p, _p, _p],
     "segmm_probe_mfma_rate": [_i, _i, _p, _p, _p],
+    "segmm_attn_mode": [_i],
     "segmm_loss_finish": [_p, _i, _p, _p, _p, _p, _i64, _p, _p, _i, _p, _i, _p],
     "segmm_split_p32": [_p, _i64, _i, _i, _p, _i, _p, _i, _p],
     "segmm_split_p32_transpose": [_p, _i, _i, _i, _p, _i, _p, _p],
@@ -349,6 +350,12 @@ def gemm_p(layout, M, N, K, A: "PT", B: "PT", Cout, ldc, c_pt: "PT" = None, writ
 def scales_update(arena, site_idx, n_rows, site_scale, stats, target=12, gain=None, gmax=None):
     _check(lib().segmm_scales_update(arena.data_ptr(), site_idx.data_ptr(), int(n_rows), site_scale.data_ptr(), stats.data_ptr(), int(target),
                                      _ptr(gain), _ptr(gmax), _stream()), "segmm_scales_update")
+
+
+def attn_mode(mode=-1):
+    """``segmm_attn_mode``: 0 exact-fp32 attention kernels, 1 fp16x3 where faster (default), 2 fp16x3 wherever built;
+    returns the previous mode, ``mode < 0`` only queries."""
+    return int(lib().segmm_attn_mode(int(mode)))
 
 
 def mfma_sustained_tflops(ms_target=25.0):

@@ -736,10 +736,20 @@ def test_colsum3(M, N, nmat):
 
 @pytest.mark.parametrize("B,H_,dh,Lq,La,Lb", [(2, 16, 48, 40, 40, 100), (2, 16, 48, 100, 40, 100), (2, 4, 8, 7, 40, 7), (3, 4, 8, 1, 40, 1),
                                               (2, 2, 32, 20, 20, 10), (2, 2, 64, 49, 40, 10), (2, 4, 16, 96, 40, 100)])
-def test_attention_bwd_phases_equal_whole(B, H_, dh, Lq, La, Lb):
+@pytest.mark.parametrize("mode", [1, 2, 0])
+def test_attention_bwd_phases_equal_whole(B, H_, dh, Lq, La, Lb, mode):
     """phase 1 (D) + 2 (dQ) + 3 (dK/dV), and phase 4 (fused, query side in chunks of 48 rows), reproduce the single-call
-    backward."""
+    backward.  ``mode`` = segmm_attn_mode: the fused kernel in its default mix (fp16x3 products for single-chunk launches), with
+    fp16x3 products wherever that form is built (several chunks too), and all exact-fp32."""
     H = _abi()
+    prev = H.attn_mode(mode)
+    try:
+        _attention_bwd_phases(H, B, H_, dh, Lq, La, Lb)
+    finally:
+        H.attn_mode(prev)
+
+
+def _attention_bwd_phases(H, B, H_, dh, Lq, La, Lb):
     d = H_ * dh
     g = torch.Generator().manual_seed(77)
     mk = lambda L: (torch.randn(B, L, d, generator=g) * 0.7).to(DEV)
