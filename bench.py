@@ -368,6 +368,17 @@ def main():
                                                     "launches_per_step": v[2] / psteps} for k, v in by.items()}
         if prof and "roofline" not in rec:
             flops = sum(2.0 * M * Nn * K for (_, M, Nn, K, _, _) in prof)
+            if os.environ.get("SEGMM_DUMP_GEMMS"):          # per-shape table of the instrumented pass (diagnostic)
+                agg = {}
+                for (lay, M, Nn, K, e0, e1) in prof:
+                    a = agg.setdefault((lay, M, Nn, K), [0, 0.0])
+                    a[0] += 1
+                    a[1] += e0.elapsed_time(e1)
+                with open(os.environ["SEGMM_DUMP_GEMMS"], "w") as f:
+                    f.write("kernel layout M N K launches_per_step avg_us TFLOPs ms_per_step\n")
+                    for (lay, M, Nn, K), (n, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                        f.write("%s %s %d %d %d %.1f %.1f %.1f %.4f\n" % ("planes" if lay >= 10 else "on-the-fly", ("NT", "NN", "TN")[lay % 10], M, Nn, K,
+                                                                       n / psteps, 1e3 * ms / n, 2e-9 * M * Nn * K / (ms / n), ms / psteps))
             base = prof[0][4]
             gemm_ms = union_ms((base.elapsed_time(e0), base.elapsed_time(e1)) for (_, _, _, _, e0, e1) in prof)
             achieved = flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
@@ -409,6 +420,16 @@ def main():
                     "note": "segmm_probe_mfma_rate, run right after the timed region: v_mfma_f32_16x16x32_f16 on RANDOM operand bits, registers only, "
                             "the GEMM's occupancy and accumulator order; the part's power management holds a random-data MFMA stream below the "
                             "datasheet peak, so this -- not `peak` -- is the ceiling a real-data GEMM kernel can reach here"}
+        if aprof and os.environ.get("SEGMM_DUMP_GEMMS"):          # per-shape table of the attention launches (diagnostic)
+            agg = {}
+            for (k, B_, H_, dh_, Lq_, La_, Lb_, e0, e1) in aprof:
+                a = agg.setdefault((k, B_, H_, dh_, Lq_, La_, Lb_), [0, 0.0])
+                a[0] += 1
+                a[1] += e0.elapsed_time(e1)
+            with open(os.environ["SEGMM_DUMP_GEMMS"] + ".attn", "w") as f:
+                f.write("kind B H dh Lq La Lb launches_per_step avg_us ms_per_step\n")
+                for key, (n, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                    f.write(" ".join(str(x) for x in key) + " %.1f %.1f %.4f\n" % (n / psteps, 1e3 * ms / n, ms / psteps))
         if aprof:
             att_w = {"fwd": 4.0, "bwd": 14.0, "bwd1": 0.0, "bwd2": 6.0, "bwd3": 8.0, "bwd4": 10.0}      # fused: S and dP computed once
             att_flops = sum(att_w[k] * dh_ * Lq_ * (La_ + Lb_) * B_ * H_ for (k, B_, H_, dh_, Lq_, La_, Lb_, _, _) in aprof)

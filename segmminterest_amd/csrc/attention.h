@@ -755,12 +755,14 @@ __device__ __forceinline__ uint32_t quad_bcast(uint32_t v) {
 // NW = waves per workgroup the launch bound is made for (blockDim.x <= 64 NW); 3 waves per SIMD: up to 6 waves two workgroups share a CU
 // (<= 168 registers), so that one head's staging / dQ reduction phases run under the other's MFMA phase.
 // ONE: Lq <= 48, a single chunk known at compile time (the chunk loop disappears: 538 us instead of 597 at config 2).
-template <int DH, int NW, bool ONE>
+// QCH: rows of the staged query chunk (16 / 32 for single-chunk launches with few queries -- config 3: Lq = 20 and 1 -- so that
+// the staging loops, the zero fill and the LDS footprint follow the real row count; 48 otherwise)
+template <int DH, int NW, bool ONE, int QCH = ATT_FUSED_QCHUNK>
 __global__ __launch_bounds__(64 * NW, 4) void attn_bwd_fused_kernel(const AttnArgs p) {
     using C = AttnCfg<DH>;
     constexpr int RS = DH + 4;                 // LDS row stride (floats): 16-byte aligned rows, conflict-free fragment reads
     constexpr int TS = 20;                     // row stride of the 16 x 16 transpose scratch
-    constexpr int QC = ATT_FUSED_QCHUNK;       // queries staged at a time (3 query tiles)
+    constexpr int QC = QCH;                    // queries staged at a time (1 - 3 query tiles)
     constexpr int MAXQT = QC / 16;
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;

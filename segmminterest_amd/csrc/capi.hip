@@ -131,7 +131,9 @@ static int attn_launch_bwd(AttnArgs& a, int phase, hipStream_t s) {
     }
     if (phase == 4) {          // fused dQ + dK + dV: one workgroup per (b, h, key block); forms D = rowsum(dO * O) itself
         const int nta = ((a.La + 15) & ~15) >> 4, ntb = ((a.Lb + 15) & ~15) >> 4;
-        const int Lq_p = ATT_FUSED_QCHUNK;                 // LDS is sized for one chunk of the query side
+        // LDS is sized for one chunk of the query side: 48 rows, or 16 / 32 when all queries fit (fp32 kernel only)
+        const int Lq_small = a.Lq <= 16 ? 16 : a.Lq <= 32 ? 32 : ATT_FUSED_QCHUNK;
+        int Lq_p = ATT_FUSED_QCHUNK;
         SEGMM_REQUIRE(nta <= ATT_FUSED_MAXW && ntb <= ATT_FUSED_MAXW, "attn_bwd phase 4: built for <= 12 key tiles per block (%d + %d tiles)", nta, ntb);
         static const int fmode = getenv("SEGMM_ATT_FUSED_LAUNCH") ? atoi(getenv("SEGMM_ATT_FUSED_LAUNCH")) : 2;
         const int nmax = nta > ntb ? nta : ntb;
@@ -142,14 +144,17 @@ static int attn_launch_bwd(AttnArgs& a, int phase, hipStream_t s) {
             const int nw = fmode == 1 ? nmax : (blk == 0 ? nta : ntb);
             if (nw == 0) continue;
             a.hpb = fmode == 1 ? 2 : blk;
-            const size_t lds = ((size_t)3 * Lq_p * (DH + 4) + 3 * Lq_p + (size_t)nw * 16 * 20 + 4 + 36 + (size_t)Lq_p * (DH / 4)) * 4 + Lq_p + Tp;
             const dim3 grid((fmode == 1 ? 2 : 1) * a.B * a.H), block(64 * nw);
             const bool one = a.Lq <= ATT_FUSED_QCHUNK;
+            Lq_p = ATT_FUSED_QCHUNK;
+            size_t lds = ((size_t)3 * Lq_p * (DH + 4) + 3 * Lq_p + (size_t)nw * 16 * 20 + 4 + 36 + (size_t)Lq_p * (DH / 4)) * 4 + Lq_p + Tp;
             if constexpr (DH % 16 == 0 && DH <= 48) {
-                // fp16x3 matrix-core form (attention16.h).  Single-chunk launches only by default: with several query chunks the
-                // kernel needs more than the 128 registers that keep two 7-wave workgroups on a CU and loses to the fp32 form
-                // (Lq = 100: 1 459 vs 1 199 us); SEGMM_ATTN=f16all forces it everywhere it is built (parity tests)
-                if (attn_f16() >= (one ? 1 : 2)) {
+                // fp16x3 matrix-core form (attention16.h).  By default only single-chunk launches with more than 32 queries: with
+                // several query chunks the kernel needs more than the 128 registers that keep two 7-wave workgroups on a CU and
+                // loses to the fp32 form (Lq = 100: 1 459 vs 1 199 us), and with a handful of queries (config 3: Lq = 20 and 1)
+                // the in-place conversion pass costs more than the products save (1.81 vs 1.65 ms of attention per step).
+                // segmm_attn_mode(2) / SEGMM_ATTN=f16all forces it everywhere it is built (parity tests)
+                if (attn_f16() >= ((one && a.Lq > 32) ? 1 : 2)) {
 #define FUSED16(NWV) do { if (one) hipLaunchKernelGGL((attn_bwd_fused16_kernel<DH, NWV, true>), grid, block, lds, s, a); \
                           else hipLaunchKernelGGL((attn_bwd_fused16_kernel<DH, NWV, false>), grid, block, lds, s, a); } while (0)
                     if (nw <= 4) FUSED16(4);
@@ -159,7 +164,11 @@ static int attn_launch_bwd(AttnArgs& a, int phase, hipStream_t s) {
                     continue;
                 }
             }
-#define FUSED(NWV) do { if (one) hipLaunchKernelGGL((attn_bwd_fused_kernel<DH, NWV, true>), grid, block, lds, s, a); \
+            Lq_p = Lq_small;
+            lds = ((size_t)3 * Lq_p * (DH + 4) + 3 * Lq_p + (size_t)nw * 16 * 20 + 4 + (size_t)Lq_p * (DH / 4)) * 4 + Lq_p + Tp;
+#define FUSED(NWV) do { if (Lq_p == 16) hipLaunchKernelGGL((attn_bwd_fused_kernel<DH, NWV, true, 16>), grid, block, lds, s, a); \
+                        else if (Lq_p == 32) hipLaunchKernelGGL((attn_bwd_fused_kernel<DH, NWV, true, 32>), grid, block, lds, s, a); \
+                        else if (one) hipLaunchKernelGGL((attn_bwd_fused_kernel<DH, NWV, true>), grid, block, lds, s, a); \
                         else hipLaunchKernelGGL((attn_bwd_fused_kernel<DH, NWV, false>), grid, block, lds, s, a); } while (0)
             if (nw <= 4) FUSED(4);
             else if (nw <= 8) FUSED(8);

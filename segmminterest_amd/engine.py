@@ -701,7 +701,10 @@ def _wgrad(store, dY, y_off, X, x_off, Mrows, n_out, n_in, gW, accumulate=False,
            a_amax=dY.slots, b_amax=X.slots)
 
 
-_FEW_TILES = int(os.environ.get("SEGMM_FEW_TILES", "48"))
+# Launches with fewer 256 x 256 output tiles than this go to the 128 x 128 on-the-fly kernel.  Round 2: 48 (the plane kernel
+# had one tile shape and left most CUs idle).  Round 3: 0 -- gemm_pl_nt8 picks 256 x 128 tiles for such launches and is faster
+# on every config-3 shape (user-side GEMMs with M = 1024: 44-189 us -> 37-111 us; 160.0 -> 168.6 k interactions/s)
+_FEW_TILES = int(os.environ.get("SEGMM_FEW_TILES", "0"))
 
 
 def _few_tiles(M, N):

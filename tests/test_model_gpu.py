@@ -239,8 +239,11 @@ def test_train_mode_dropout_statistics_and_seed():
     torch.manual_seed(5)
     b = call_model(model, g["in"], "train", DEV)
     c = call_model(model, g["in"], "train", DEV)
-    assert torch.equal(a["logits"], b["logits"])
-    assert not torch.equal(a["logits"], c["logits"])
+    # same seed => same masks.  Not bitwise: call a splits its GEMM operands with the exact maxima of a site's first use,
+    # call b with the delayed power-of-two scales derived from call a; elements 2^14 below their tensor's maximum then
+    # round differently in the lo term (1e-7 relative).  A different mask moves the logits by > 1e-3 (checked below)
+    assert (a["logits"] - b["logits"]).abs().max().item() < 2e-6 * max(1.0, a["logits"].abs().max().item())
+    assert (a["logits"] - c["logits"]).abs().max().item() > 1e-3
     model.eval()
     e = call_model(model, g["in"], "train", DEV)
     assert (a["logits"] - e["logits"]).abs().max().item() > 1e-3
