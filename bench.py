@@ -85,6 +85,11 @@ def parse_args():
     ap.add_argument("--prefetch", action="store_true",
                     help="Trainer.train_step(batch, next_batch=...): the input stage (L1 normalisation / table gather) of the next batch runs on "
                          "its own stream under the current step.  Off by default: measured +0.2 %% (the GPU is saturated, the overlap buys nothing)")
+    ap.add_argument("--graph", action="store_true",
+                    help="single GPU: Trainer(device_state=True) -- dropout seed words, AdamW step count and the step's site headers live on "
+                         "the device -- and the timed steps are REPLAYS of one hipGraph capture of the step (Trainer.capture / replay): "
+                         "the host enqueues one graph launch + the batch copy per step.  --device-state alone runs the same step eagerly.")
+    ap.add_argument("--device-state", action="store_true", help="the device-state step without graph capture (A/B partner of --graph)")
     ap.add_argument("--no-probe", action="store_true", help="skip the sustained-MFMA probe (roofline.sustained_probe)")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
                     help="gloo: CPU-staged collectives, lets several ranks share one GPU (CI rehearsal of the N > 1 path)")
@@ -113,6 +118,15 @@ def relaunch(args):
     sys.stdout.write(p.stdout)
     sys.stdout.flush()
     sys.exit(p.returncode)
+
+
+def _graph_mode_legs(args):
+    """--graph / --device-state measure the step itself: the extra legs (second trainer on the f32 engine, host-fed inputs)
+    would rebuild the device-side step state under the first trainer."""
+    if args.graph or args.device_state:
+        args.no_f32_engine = True
+        args.no_host_fed = True
+    return args
 
 
 def workload(args, world):
@@ -202,7 +216,7 @@ def union_ms(intervals):
 
 
 def main():
-    args = parse_args()
+    args = _graph_mode_legs(parse_args())
     env_world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and env_world != args.gpus:
         relaunch(args)
@@ -249,7 +263,8 @@ def main():
             from segmminterest_amd.feature_store import ResidentFeatureTable
             g = torch.Generator(device="cpu").manual_seed(99)
             table = ResidentFeatureTable(torch.rand((200000, Din), generator=g).to(dev))
-        return model, Trainer(model, lr=1e-3, weight_decay=1e-4, comm=DPComm(), overlap=not args.no_overlap, feature_table=table)
+        return model, Trainer(model, lr=1e-3, weight_decay=1e-4, comm=DPComm(), overlap=not args.no_overlap, feature_table=table,
+                              device_state=args.graph or args.device_state)
 
     model, trainer = build()
     batches = []
@@ -277,10 +292,17 @@ def main():
         for i in range(n):
             h0 = time.perf_counter()
             nxt = batches[(start + i + 1) % len(batches)] if (args.prefetch and len(batches) > 1) else None
-            out = tr.train_step(batches[(start + i) % len(batches)], next_batch=nxt)
+            if tr._graph is not None and hipabi.GEMM_PROFILE is None:
+                out = tr.replay(batches[(start + i) % len(batches)])
+            else:
+                out = tr.train_step(batches[(start + i) % len(batches)], next_batch=nxt)
             host_s.append(time.perf_counter() - h0)
         return out
 
+    if args.graph:
+        if world > 1 or args.prefetch:
+            raise SystemExit("--graph: single GPU, no prefetch")
+        trainer.capture(batches[0], warmup=max(args.warmup, 3))
     run(trainer, args.warmup)
     barrier()
     t0 = time.perf_counter()
@@ -336,7 +358,7 @@ def main():
                        "rows_per_gpu": B, "global_batch": B * world, "segments": S, "feat_dim": D, "in_dim": Din, "user_tokens": Lt, "layers": N,
                        "parallelism": "dp%d" % world + (" (forced one-rank process group)" if forced_dp else ""),
                        "backend": args.backend if (world > 1 or forced_dp) else None,
-                       "grad_allreduce_overlap": not args.no_overlap, "input_prefetch": bool(args.prefetch and len(batches) > 1),
+                       "grad_allreduce_overlap": not args.no_overlap, "step_mode": ("hipGraph replay (device-side step state)" if args.graph else "eager, device-side step state" if args.device_state else "eager"), "input_prefetch": bool(args.prefetch and len(batches) > 1),
                        "final_loss": round(loss, 6), "replicas_identical": replicas_identical,
                        "delayed_scale_overflows": (model._store.overflow_count() if model._store.engine_p else None),
                        "live_train_flops_per_interaction": ftrain, "gemm_engine": engine,

@@ -254,6 +254,15 @@ int segmm_loss_fwd_bwd(int B, int S, const float* logits, const int64_t* gt, con
 /* K9 -- fused AdamW over one flat fp32 range (torch.optim.AdamW semantics; main_for_seq_leave_earlystop_SegMM.py:226,299) */
 int segmm_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                 float eps, float weight_decay, int step, segmm_stream_t stream);
+/* Device-side step state, so that a whole training step (main_for_seq_leave_earlystop_SegMM.py:265-300) can be captured in a
+ * hipGraph and replayed with unchanged kernel arguments: two dropout seed words and the optimizer's step count with its bias
+ * corrections live in device memory.  segmm_step_set initialises them, segmm_step_advance (one thread; the first launch of a
+ * step) increments the count, derives new seed words and the corrections 1 - beta^t, segmm_step_get reads them back (it
+ * synchronises the stream).  A dropout seed argument with bit 63 set is "live": the kernel XORs the device words into it;
+ * segmm_adamw with step == -1 takes the corrections from the device state. */
+int segmm_step_set(uint64_t seed, int step, float beta1, float beta2, segmm_stream_t stream);
+int segmm_step_advance(float beta1, float beta2, segmm_stream_t stream);
+int segmm_step_get(uint64_t* seed, int* step, float* bias_corrections, segmm_stream_t stream);
 
 
 /* ---- the callers either side of the training step -------------------------------------------

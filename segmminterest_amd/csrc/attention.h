@@ -311,6 +311,7 @@ __global__ __launch_bounds__(ATT_MAX_THREADS, ATT_FWD_WAVES) void attn_fwd_kerne
 __global__ __launch_bounds__(ATT_MAX_THREADS) void attn_fwd_kernel(const AttnArgs p) {
 #endif
     using C = AttnCfg<DH>;
+    const DropCfg drop_ = drop_live(p.drop);
     extern __shared__ uint8_t km[];
     // A workgroup = p.hpb ADJACENT heads of one batch row x wq row tiles: the heads read interleaved 4*DH-byte slices of
     // the same token rows, so their loads, issued together, touch each DRAM page / cache line once instead of once per
@@ -380,8 +381,8 @@ __global__ __launch_bounds__(ATT_MAX_THREADS) void attn_fwd_kernel(const AttnArg
         if (t < nt) {
             const uint32_t kb = *(const uint32_t*)(km + 16 * t + 4 * g);
             f32x4 mult = {1.f, 1.f, 1.f, 1.f};
-            if (p.drop.p > 0.f)
-                mult = drop_apply4(p.drop, (((uint64_t)bh * p.Lq + (q_in ? qi : 0)) * Tp + 16 * t + 4 * g) >> 2,
+            if (drop_.p > 0.f)
+                mult = drop_apply4(drop_, (((uint64_t)bh * p.Lq + (q_in ? qi : 0)) * Tp + 16 * t + 4 * g) >> 2,
                                    f32x4{1.f, 1.f, 1.f, 1.f});
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -448,6 +449,7 @@ __global__ __launch_bounds__(ATT_MAX_THREADS) void attn_fwd_kernel(const AttnArg
 template <int DH, int NT>
 __global__ __launch_bounds__(ATT_BWD_THREADS) void attn_bwd_dq_kernel(const AttnArgs p) {
     using C = AttnCfg<DH>;
+    const DropCfg drop_ = drop_live(p.drop);
     extern __shared__ uint8_t km[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6, wq = wpb / p.hpb;
     const int l15 = lane & 15, g = lane >> 4;
@@ -482,7 +484,7 @@ __global__ __launch_bounds__(ATT_BWD_THREADS) void attn_bwd_dq_kernel(const Attn
         Dq += __shfl_xor(Dq, 32, 64);
         if (p.write_D && g == 0 && q_in) p.Dvec[(size_t)bh * p.Lq + qi] = Dq;
     }
-    const float fac = p.drop.scale * p.scale;        // d(logit)/d(raw) of a live, kept element
+    const float fac = drop_.scale * p.scale;        // d(logit)/d(raw) of a live, kept element
 
     // K and V row fragments of the NEXT tile are fetched under the current tile's MFMAs (two buffers); the K column
     // fragments of the current tile are fetched at its start and land under its 24 score MFMAs and the softmax
@@ -533,8 +535,8 @@ __global__ __launch_bounds__(ATT_BWD_THREADS) void attn_bwd_dq_kernel(const Attn
             }
             const uint32_t kb = *(const uint32_t*)(km + 16 * t + 4 * g);
             f32x4 mult = {1.f, 1.f, 1.f, 1.f};
-            if (p.drop.p > 0.f)
-                mult = drop_apply4(p.drop, (((uint64_t)bh * p.Lq + (q_in ? qi : 0)) * Tp + 16 * t + 4 * g) >> 2,
+            if (drop_.p > 0.f)
+                mult = drop_apply4(drop_, (((uint64_t)bh * p.Lq + (q_in ? qi : 0)) * Tp + 16 * t + 4 * g) >> 2,
                                    f32x4{1.f, 1.f, 1.f, 1.f});
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -595,6 +597,7 @@ __global__ __launch_bounds__(256) void attn_D_kernel(const AttnArgs p) {
 template <int DH, int NQT>
 __global__ __launch_bounds__(ATT_BWD_THREADS) void attn_bwd_dkv_kernel(const AttnArgs p) {
     using C = AttnCfg<DH>;
+    const DropCfg drop_ = drop_live(p.drop);
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6, wq = wpb / p.hpb;
     const int l15 = lane & 15, g = lane >> 4;
@@ -681,7 +684,7 @@ __global__ __launch_bounds__(ATT_BWD_THREADS) void attn_bwd_dkv_kernel(const Att
             const uint32_t qf_ = (qfl >> (8 * r)) & 0xff;
             const bool valid = (qf_ == 1) && (kflag == 1);
             float mult = 1.f;
-            if (p.drop.p > 0.f && qf_ != 2) mult = drop_mult1(p.drop, ((uint64_t)bh * p.Lq + qi) * Tp + jp);
+            if (drop_.p > 0.f && qf_ != 2) mult = drop_mult1(drop_, ((uint64_t)bh * p.Lq + qi) * Tp + jp);
             const float v = logit_xform(s[r], valid, mult, fscale);
             const float pr = (kflag == 2 || qf_ == 2) ? 0.f : fast_exp(v - mxq[r]) * invq[r];
             Pv[r] = pr;
@@ -760,6 +763,7 @@ __device__ __forceinline__ uint32_t quad_bcast(uint32_t v) {
 template <int DH, int NW, bool ONE, int QCH = ATT_FUSED_QCHUNK>
 __global__ __launch_bounds__(64 * NW, 4) void attn_bwd_fused_kernel(const AttnArgs p) {
     using C = AttnCfg<DH>;
+    const DropCfg drop_ = drop_live(p.drop);
     constexpr int RS = DH + 4;                 // LDS row stride (floats): 16-byte aligned rows, conflict-free fragment reads
     constexpr int TS = 20;                     // row stride of the 16 x 16 transpose scratch
     constexpr int QC = QCH;                    // queries staged at a time (1 - 3 query tiles)
@@ -895,9 +899,9 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_bwd_fused_kernel(const AttnAr
                 // lane hashes ONE query's quad (query 4g + (lane & 3)) and the group exchanges the words by DPP broadcasts --
                 // one hash per lane instead of four, bit-identical to drop_mult1.
                 uint32_t dw[4] = {0u, 0u, 0u, 0u};
-                if (p.drop.p > 0.f) {
+                if (drop_.p > 0.f) {
                     const int rr = l15 & 3;
-                    const uint2 hw = drop_rand_quad(p.drop, (((uint64_t)bh * p.Lq + (q0 + 16 * qt + 4 * g + rr)) * Tp + jp) >> 2);
+                    const uint2 hw = drop_rand_quad(drop_, (((uint64_t)bh * p.Lq + (q0 + 16 * qt + 4 * g + rr)) * Tp + jp) >> 2);
                     const uint32_t a0 = quad_bcast<0>(hw.x), a1 = quad_bcast<1>(hw.x), a2 = quad_bcast<2>(hw.x), a3 = quad_bcast<3>(hw.x);
                     const uint32_t b0 = quad_bcast<0>(hw.y), b1 = quad_bcast<1>(hw.y), b2 = quad_bcast<2>(hw.y), b3 = quad_bcast<3>(hw.y);
                     const bool lo_word = rr < 2, hi_half = rr & 1;
@@ -910,7 +914,7 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_bwd_fused_kernel(const AttnAr
                     const uint32_t qf_ = (qfl >> (8 * r)) & 0xff;
                     const bool valid = (qf_ == 1) && (kflag == 1);
                     float mult = 1.f;
-                    if (p.drop.p > 0.f && qf_ != 2) mult = (dw[r] >= p.drop.thresh) ? p.drop.scale : 0.f;
+                    if (drop_.p > 0.f && qf_ != 2) mult = (dw[r] >= drop_.thresh) ? drop_.scale : 0.f;
                     const float v = logit_xform(sv[r], valid, mult, fscale);
                     const float pr = (kflag == 2 || qf_ == 2) ? 0.f : fast_exp(v - mxq[r]) * invq[r];
                     Pv[r] = pr;

@@ -88,6 +88,7 @@ __device__ __forceinline__ float frag_absmax(const float (&f)[N]) {
 template <int DH, int NW, bool ONE>
 __global__ __launch_bounds__(64 * NW, 4) void attn_bwd_fused16_kernel(const AttnArgs p) {
     using C = AttnCfg<DH>;
+    const DropCfg drop_ = drop_live(p.drop);
     static_assert(DH % 16 == 0, "fp16 attention: head dim must be a multiple of 16");
     constexpr int RS = DH + 4;                 // LDS row stride (floats): 16-byte aligned rows, conflict-free row-fragment reads
     constexpr int RSB = RS * 4;                // ... in bytes
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_bwd_fused16_kernel(const Attn
         float mDc = 0.f;
         for (int w = 0; w < ntk; ++w) mDc = fmaxf(mDc, s_wm[24 + w]);
         // |dS| <= P (|dP| + |D|) mult scale, |dP| <= DH max|dO| max|V tile|
-        const float sdS = f16_scale_of(((float)DH * mdO * maxV + mDc) * p.drop.scale * fscale);
+        const float sdS = f16_scale_of(((float)DH * mdO * maxV + mDc) * drop_.scale * fscale);
         const float inv_s = 1.0f / (sQs * sK), inv_dp = 1.0f / (sdOs * sV), inv_dq = 1.0f / (sK * sdS);
         const uint8_t kflag = km[jp];
         {   // dK / dV accumulate in the units of the CURRENT chunk's operand scales: moving on to a chunk with other scales
@@ -262,9 +263,9 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_bwd_fused16_kernel(const Attn
                 const uint32_t qfl = *(const uint32_t*)(qm + 16 * qt + 4 * g);
                 f32x4 Pv, dSv;
                 uint32_t dw[4] = {0u, 0u, 0u, 0u};
-                if (p.drop.p > 0.f) {
+                if (drop_.p > 0.f) {
                     const int rr = l15 & 3;
-                    const uint2 hw = drop_rand_quad(p.drop, (((uint64_t)bh * p.Lq + (q0 + 16 * qt + 4 * g + rr)) * Tp + jp) >> 2);
+                    const uint2 hw = drop_rand_quad(drop_, (((uint64_t)bh * p.Lq + (q0 + 16 * qt + 4 * g + rr)) * Tp + jp) >> 2);
                     const uint32_t a0 = quad_bcast<0>(hw.x), a1 = quad_bcast<1>(hw.x), a2 = quad_bcast<2>(hw.x), a3 = quad_bcast<3>(hw.x);
                     const uint32_t b0 = quad_bcast<0>(hw.y), b1 = quad_bcast<1>(hw.y), b2 = quad_bcast<2>(hw.y), b3 = quad_bcast<3>(hw.y);
                     const bool lo_word = rr < 2, hi_half = rr & 1;
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_bwd_fused16_kernel(const Attn
                     const uint32_t qf_ = (qfl >> (8 * r)) & 0xff;
                     const bool valid = (qf_ == 1) && (kflag == 1);
                     float mult = 1.f;
-                    if (p.drop.p > 0.f && qf_ != 2) mult = (dw[r] >= p.drop.thresh) ? p.drop.scale : 0.f;
+                    if (drop_.p > 0.f && qf_ != 2) mult = (dw[r] >= drop_.thresh) ? drop_.scale : 0.f;
                     const float v = logit_xform(sv[r] * inv_s, valid, mult, fscale);
                     const float pr = (kflag == 2 || qf_ == 2) ? 0.f : fast_exp(v - mxq[r]) * invq[r];
                     Pv[r] = pr;

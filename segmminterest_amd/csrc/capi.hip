@@ -221,6 +221,7 @@ static int attn_launch_bwd(AttnArgs& a, int phase, hipStream_t s) {
     }
 
 __global__ void dropout_mult_kernel(float* out, long long n, DropCfg d) {
+    d = drop_live(d);
     for (long long q = blockIdx.x * (long long)blockDim.x + threadIdx.x; q < ((n + 3) >> 2); q += (long long)gridDim.x * blockDim.x) {
         const f32x4 v = drop_apply4(d, (uint64_t)q, f32x4{1.f, 1.f, 1.f, 1.f});
         for (int k = 0; k < 4; ++k)
@@ -272,10 +273,28 @@ __global__ __launch_bounds__(512, 2) void mfma_rate_kernel(float* out, int iters
 }
 }  // namespace segmm
 
+namespace segmm {
+__global__ void step_set_kernel(uint32_t lo, uint32_t hi, int step, float b1, float b2) {
+    g_step.seed_lo = lo; g_step.seed_hi = hi; g_step.step = step;
+    g_step.bc1 = step > 0 ? (float)(1.0 - pow((double)b1, (double)step)) : 1.f;
+    g_step.bc2_sqrt = step > 0 ? (float)sqrt(1.0 - pow((double)b2, (double)step)) : 1.f;
+}
+__global__ void step_advance_kernel(float b1, float b2) {
+    const int t = g_step.step + 1;
+    g_step.step = t;
+    const uint32_t lo = mix32(g_step.seed_lo + 0x9E3779B9u * (uint32_t)t);
+    g_step.seed_hi = mix32(g_step.seed_hi ^ lo ^ 0x85EBCA6Bu) & 0x7fffffffu;
+    g_step.seed_lo = lo;
+    g_step.bc1 = (float)(1.0 - pow((double)b1, (double)t));
+    g_step.bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, (double)t));
+}
+__global__ void step_get_kernel(StepState* out) { *out = g_step; }
+}  // namespace segmm
+
 extern "C" {
 
 const char* segmm_last_error(void) { return g_segmm_err; }
-int segmm_abi_version(void) { return 17; }
+int segmm_abi_version(void) { return 18; }
 int segmm_attn_mode(int mode) { const int prev = attn_f16(); if (mode >= 0 && mode <= 2) g_attn_mode = mode; return prev; }
 
 static PlaneOut plane_out(uint16_t* planes, int ld2, float* hdr, const float* scale_in) {
@@ -975,15 +994,41 @@ int segmm_loss_fwd_bwd(int B, int S, const float* logits, const int64_t* gt, con
 int segmm_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                 float eps, float weight_decay, int step, segmm_stream_t stream) {
     SEGMM_REQUIRE(p && g && m && v && aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v), "adamw: pointer/alignment");
-    SEGMM_REQUIRE(step >= 1, "adamw: step=%d", step);
+    SEGMM_REQUIRE(step >= 1 || step == -1, "adamw: step=%d (>= 1, or -1: the device-side step state)", step);
     if (n <= 0) return 0;
-    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    const double bc1 = step > 0 ? 1.0 - pow((double)beta1, step) : 1.0, bc2 = step > 0 ? 1.0 - pow((double)beta2, step) : 1.0;
     long long blocks = ((n >> 2) + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)n, lr, beta1,
-                       beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2));
+                       beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), step < 0 ? 1 : 0);
     LAUNCH_CHECK();
+    return 0;
+}
+
+int segmm_step_set(uint64_t seed, int step, float beta1, float beta2, segmm_stream_t stream) {
+    SEGMM_REQUIRE(step >= 0, "step_set: step=%d", step);
+    hipLaunchKernelGGL(step_set_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (uint32_t)seed, (uint32_t)(seed >> 32) & 0x7fffffffu, step, beta1, beta2);
+    LAUNCH_CHECK();
+    return 0;
+}
+int segmm_step_advance(float beta1, float beta2, segmm_stream_t stream) {
+    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, beta1, beta2);
+    LAUNCH_CHECK();
+    return 0;
+}
+int segmm_step_get(uint64_t* seed, int* step, float* bias_corrections, segmm_stream_t stream) {
+    StepState* d = nullptr;
+    StepState h;
+    SEGMM_CHECK_HIP(hipMalloc(&d, sizeof(StepState)));
+    hipLaunchKernelGGL(step_get_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, d);
+    hipError_t e = hipMemcpyAsync(&h, d, sizeof(StepState), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    (void)hipFree(d);
+    SEGMM_CHECK_HIP(e);
+    if (seed) *seed = ((uint64_t)h.seed_hi << 32) | h.seed_lo;
+    if (step) *step = h.step;
+    if (bias_corrections) { bias_corrections[0] = h.bc1; bias_corrections[1] = h.bc2_sqrt; }
     return 0;
 }
 

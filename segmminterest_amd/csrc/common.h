@@ -40,7 +40,19 @@ struct DropCfg {
     uint32_t thresh;      // keep iff r16 >= thresh, thresh = round(p * 65536)
     uint32_t seed_lo, seed_hi;
     uint32_t site;        // distinct per dropout site in the model
+    uint32_t live;        // != 0: the seed is XORed with the DEVICE-side step words (g_step) when the kernel starts
 };
+
+// ---- device-side step state.  A training step captured in a hipGraph replays the SAME kernel arguments every step, so what
+// must change from step to step lives in device memory and is advanced by a one-thread kernel at the head of the step
+// (segmm_step_advance): two seed words for the dropout streams (kernels launched with a "live" seed -- bit 63 of the seed
+// argument -- XOR them into their seed) and AdamW's bias corrections (segmm_adamw with step < 0 reads them).
+struct StepState { uint32_t seed_lo, seed_hi; int step; float bc1, bc2_sqrt; };
+static __device__ StepState g_step;
+__device__ __forceinline__ DropCfg drop_live(DropCfg d) {
+    if (d.live) { d.seed_lo ^= g_step.seed_lo; d.seed_hi ^= g_step.seed_hi; }
+    return d;
+}
 
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
@@ -77,8 +89,9 @@ static inline DropCfg make_drop(float p, uint64_t seed, uint32_t site) {
     d.thresh = p <= 0.f ? 0u : (t >= 65535.0 ? 65535u : (uint32_t)t);
     d.scale = p > 0.f ? (float)(65536.0 / (65536.0 - (double)d.thresh)) : 1.0f;
     d.seed_lo = (uint32_t)seed;
-    d.seed_hi = (uint32_t)(seed >> 32);
+    d.seed_hi = (uint32_t)(seed >> 32) & 0x7fffffffu;
     d.site = site;
+    d.live = (uint32_t)(seed >> 63);
     return d;
 }
 

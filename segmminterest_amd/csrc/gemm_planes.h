@@ -140,7 +140,7 @@ __device__ __forceinline__ void epi_strip_emit(const GemmArgs& p, const PGemmX& 
                     v.x = g.x > 0.f ? v.x : 0.f; v.y = g.y > 0.f ? v.y : 0.f;
                     v.z = g.z > 0.f ? v.z : 0.f; v.w = g.w > 0.f ? v.w : 0.f;
                 }
-                if (p.drop.p > 0.f) v = drop_apply4(p.drop, ((uint64_t)gm * (uint64_t)p.N + gn) >> 2, v);
+                if (p.drop.p > 0.f) v = drop_apply4(drop_live(p.drop), ((uint64_t)gm * (uint64_t)p.N + gn) >> 2, v);
                 if (p.residual) {
                     const int rr = p.res_period >= p.M ? gm : gm % p.res_period;
                     v += *(const f32x4*)(p.residual + (size_t)rr * p.ldr + gn);

@@ -299,6 +299,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_nt8(const GemmArgs p, const PG
         const float inv_ab = (1.f / sa) * (1.f / sb);          // exact powers of two
         const int epi = p.epi;
         const bool has_res = p.residual != nullptr, has_drop = p.drop.p > 0.f;
+        const DropCfg drop_e = drop_live(p.drop);
         const bool aux_r = epi == EPI_DGELU || epi == EPI_DRELU, aux_w = epi == EPI_GELU;
         const bool planes = c_scale > 0.f && q.Cp != nullptr;
         const bool store_c = q.write_c && !(q.dbg & 1);
@@ -423,7 +424,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_nt8(const GemmArgs p, const PG
                             v.x = e[j].x > 0.f ? v.x : 0.f; v.y = e[j].y > 0.f ? v.y : 0.f; v.z = e[j].z > 0.f ? v.z : 0.f; v.w = e[j].w > 0.f ? v.w : 0.f;
                         }
                     }
-                    if (DROP) v = drop_apply4(p.drop, ((uint64_t)gm * (uint64_t)p.N + (uint64_t)(gn0 + 16 * j)) >> 2, v);
+                    if (DROP) v = drop_apply4(drop_e, ((uint64_t)gm * (uint64_t)p.N + (uint64_t)(gn0 + 16 * j)) >> 2, v);
                     if (ACT == 0) v += e[j];                    // e = 0 without a residual
                     else if (has_res) v += e[j];                // (e is the aux tensor of an activation gradient otherwise)
                     c[j] = v;

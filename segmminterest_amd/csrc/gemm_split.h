@@ -411,7 +411,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_mfma(const GemmArgs p, cons
                             v.x = g.x > 0.f ? v.x : 0.f; v.y = g.y > 0.f ? v.y : 0.f;
                             v.z = g.z > 0.f ? v.z : 0.f; v.w = g.w > 0.f ? v.w : 0.f;
                         }
-                        if (p.drop.p > 0.f) v = drop_apply4(p.drop, ((uint64_t)gm * (uint64_t)p.N + gn) >> 2, v);
+                        if (p.drop.p > 0.f) v = drop_apply4(drop_live(p.drop), ((uint64_t)gm * (uint64_t)p.N + gn) >> 2, v);
                         if (p.residual) v += *(const f32x4*)(p.residual + (size_t)(gm % p.res_period) * p.ldr + gn);
                     }
                     *(f32x4*)(Cout + (size_t)gm * p.ldc + gn) = v;

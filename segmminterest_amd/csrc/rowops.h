@@ -48,6 +48,7 @@ template <int V>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                      const float* __restrict__ beta, float* __restrict__ y, float* mean_out,
                                      float* rstd_out, long long rows, int d, float eps, DropCfg drop, float* amax, PlaneOut po) {
+    drop = drop_live(drop);
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -101,6 +102,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                      float* __restrict__ dx_drop, float* __restrict__ part_dgamma,
                                      float* __restrict__ part_dbeta, float* __restrict__ part_dsum, long long rows, int d,
                                      DropCfg drop_y, DropCfg drop_branch, float* amax, PlaneOut po) {
+    drop_y = drop_live(drop_y); drop_branch = drop_live(drop_branch);
     __shared__ f32x4 red[4][64];
     const float ps = plane_scale(po);
     float am = 0.f;          // max |dx_drop| (or |dx| when there is no dropped copy): the tensor the GEMMs consume
@@ -429,7 +431,8 @@ __global__ __launch_bounds__(256) void pe_grad_kernel(const float* __restrict__ 
 // torch.optim.AdamW single-tensor update order (decoupled decay first), bias corrections passed in.
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                              float* __restrict__ v, long long n, float lr, float b1, float b2, float eps, float wd,
-                             float bc1, float bc2_sqrt) {
+                             float bc1, float bc2_sqrt, int live) {
+    if (live) { bc1 = g_step.bc1; bc2_sqrt = g_step.bc2_sqrt; }          // bias corrections of the device-side step count
     const long long n4 = n >> 2;
     const float step = lr / bc1;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {

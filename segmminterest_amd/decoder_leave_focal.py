@@ -340,7 +340,7 @@ class MultiScaleTemporalDetrLeaveFocal(nn.Module):
         st = self._store
         st.ensure()
         training = self.training
-        seed = E.next_seed() if training else 0
+        seed = E.next_seed(st) if training else 0
         it = self.input_type
 
         def pick(kind, image, ident, which):

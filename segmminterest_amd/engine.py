@@ -214,9 +214,35 @@ class ParamStore:
     # >= 3/4 ring (dozens of steps) earlier.  One 2 MB fill every ~10-20 steps instead of 3-4 small ones per step.
     HDR_RING_ROWS = 8192
 
+    def hdr_step_begin(self):
+        """Step-arena mode (Trainer(device_state=True): the step may be replayed from a hipGraph, so every step must use the
+        SAME header rows): hand the rows out from row 0 again and clear what the previous step used -- one fill launch per
+        step, inside the graph."""
+        first = not self.__dict__.get("step_arena", False)
+        self.step_arena = True
+        ring = getattr(self, "_hdr_ring", None)
+        if ring is not None:
+            used = self.HDR_RING_ROWS if first else self.__dict__.get("_hdr_used", 0)
+            if used:
+                ring[:used].zero_()
+        self._hdr_off = 0
+        if first:
+            self._hdr_used = 0
+
     def hdr_rows(self, n: int) -> torch.Tensor:
         dev = self.flat.device
         q = self.HDR_RING_ROWS // 4
+        if self.__dict__.get("step_arena", False):
+            ring = getattr(self, "_hdr_ring", None)
+            if ring is None or ring.device != dev:
+                ring = self._hdr_ring = torch.zeros((self.HDR_RING_ROWS, H.SITE_FLOATS), dtype=torch.float32, device=dev)
+                self._hdr_off, self._hdr_used = 0, 0
+            if self._hdr_off + n > self.HDR_RING_ROWS:
+                raise RuntimeError("step arena: more than %d site headers in one step" % self.HDR_RING_ROWS)
+            r0 = self._hdr_off
+            self._hdr_off += n
+            self._hdr_used = max(self.__dict__.get("_hdr_used", 0), self._hdr_off)
+            return ring[r0:r0 + n]
         if n > q:
             return torch.zeros((n, H.SITE_FLOATS), dtype=torch.float32, device=dev)
         ring = getattr(self, "_hdr_ring", None)
@@ -1354,10 +1380,15 @@ def _group_view(store, first_name, numel, gbuf):
 _STEP_SEED = [0x5E6D0001]
 
 
-def next_seed() -> int:
+def next_seed(store=None) -> int:
     """A fresh dropout seed per training forward, drawn from torch's CPU generator so that
     ``torch.manual_seed`` makes train-mode runs reproducible.  Data-parallel ranks seed torch identically (identical
-    replicas), so the rank is mixed in: every rank drops different elements of its own rows."""
+    replicas), so the rank is mixed in: every rank drops different elements of its own rows.
+    With a device-side step state the ARGUMENT is the same every step (bit 63 set: the kernels XOR in the seed words that
+    segmm_step_advance derives on the device), so that a captured step can be replayed."""
+    live = None if store is None else store.__dict__.get("live_seed")          # set by Trainer(device_state=True)
+    if live is not None:
+        return live
     s = int(torch.randint(0, 2 ** 62, (1,)).item())
     rank = int(os.environ.get("RANK", "0"))
     return (s ^ (rank * 0x9E3779B97F4A7C15)) & (2 ** 62 - 1) if rank else s
@@ -1431,7 +1462,7 @@ def deliver_grads(store, names, gbuf):
 def backbone_apply(store, bb, prefix, usr_feat, usr_mask, vid_feat, vid_mask, training, bb_index=0, seed=None):
     store.ensure()
     if seed is None:
-        seed = next_seed() if training else 0
+        seed = next_seed(store) if training else 0
     names = [n for n in store.live_names if n.startswith(prefix)] if prefix else list(store.live_names)
     params = [store._params[n] for n in names]
     return BackboneFn.apply(store, bb, prefix, bb_index, usr_feat, usr_mask, vid_feat, vid_mask, bool(training), int(seed), *params)

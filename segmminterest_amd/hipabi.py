@@ -15,7 +15,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SEGMM_LIB") or os.path.join(_HERE, "libsegmm_hip.so")      # SEGMM_LIB: A/B builds of the kernels
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 _lib = None
 
@@ -34,6 +34,9 @@ SIGNATURES = {
     "segmm_scales_update": [_p, _p, _i, _p, _p, _i, _p, _p, _p],
     "segmm_probe_mfma_rate": [_i, _i, _p, _p, _p],
     "segmm_attn_mode": [_i],
+    "segmm_step_set": [_u64, _i, _f, _f, _p],
+    "segmm_step_advance": [_f, _f, _p],
+    "segmm_step_get": [_p, _p, _p, _p],
     "segmm_loss_finish": [_p, _i, _p, _p, _p, _p, _i64, _p, _p, _i, _p, _i, _p],
     "segmm_split_p32": [_p, _i64, _i, _i, _p, _i, _p, _i, _p],
     "segmm_split_p32_transpose": [_p, _i, _i, _i, _p, _i, _p, _p],
@@ -350,6 +353,25 @@ def gemm_p(layout, M, N, K, A: "PT", B: "PT", Cout, ldc, c_pt: "PT" = None, writ
 def scales_update(arena, site_idx, n_rows, site_scale, stats, target=12, gain=None, gmax=None):
     _check(lib().segmm_scales_update(arena.data_ptr(), site_idx.data_ptr(), int(n_rows), site_scale.data_ptr(), stats.data_ptr(), int(target),
                                      _ptr(gain), _ptr(gmax), _stream()), "segmm_scales_update")
+
+
+LIVE_SEED = 1 << 63          # dropout seed argument bit: XOR the device-side step words into the seed (segmm_step_advance)
+
+
+def step_set(seed, step, beta1=0.9, beta2=0.999):
+    _check(lib().segmm_step_set(int(seed) & (2 ** 63 - 1), int(step), float(beta1), float(beta2), _stream()), "segmm_step_set")
+
+
+def step_advance(beta1=0.9, beta2=0.999):
+    _check(lib().segmm_step_advance(float(beta1), float(beta2), _stream()), "segmm_step_advance")
+
+
+def step_get():
+    """(seed words, step count, (bc1, sqrt(bc2))) of the device-side step state; synchronises the stream."""
+    import ctypes
+    seed, step, bc = ctypes.c_uint64(0), ctypes.c_int(0), (ctypes.c_float * 2)()
+    _check(lib().segmm_step_get(ctypes.addressof(seed), ctypes.addressof(step), ctypes.addressof(bc), _stream()), "segmm_step_get")
+    return int(seed.value), int(step.value), (float(bc[0]), float(bc[1]))
 
 
 def attn_mode(mode=-1):

@@ -127,8 +127,9 @@ class FusedAdamW:
     def step_range(self, start, end, gbuf=None):
         st = self._state()
         if end > start:
+            # device_state: the bias corrections come from the device-side step count (segmm_step_advance), step = -1
             H.adamw(st.flat, st.gflat if gbuf is None else gbuf, self.m, self.v, end - start, self.lr, self.betas[0], self.betas[1],
-                    self.eps, self.wd, self.step_count, p_off=start)
+                    self.eps, self.wd, -1 if self.__dict__.get("device_state", False) else self.step_count, p_off=start)
 
     def end_step(self):
         self.model._store.fused_version += 1          # the pre-split weight planes of the GEMM engines are now stale
@@ -319,8 +320,14 @@ class Trainer:
     Gradient clipping is a no-op in the reference (exhausted generator at :298) and is therefore absent."""
 
     def __init__(self, model, lr=1e-3, weight_decay=1e-4, comm: Optional[DPComm] = None, overlap=True, dropout=True,
-                 feature_table=None, sparse_tables=True):
+                 feature_table=None, sparse_tables=True, device_state=False):
         self.model = model
+        # device_state: what changes from step to step (dropout seed words, AdamW's step count and bias corrections, the
+        # site-header rows of a step) lives on the device / is laid out per step, so the kernel arguments of a step never
+        # change and ``capture()`` can record one step in a hipGraph that ``replay()`` launches with ~0 host work.  The
+        # eager step in this mode and its replay are bit-identical.
+        self.device_state = bool(device_state)
+        self._graph = None
         # SURVEY.md §8(f)-1: with a device-resident feature table the batch carries INDEX lists ("photo_idx" [B, S],
         # "user_idx" [B, Lt], -1 = padding) instead of feature tensors; gather + pad + mask + L1 normalisation is one
         # HBM-bound kernel (segmm_gather_l1) and the 573 KB/row host->device copy disappears
@@ -347,6 +354,13 @@ class Trainer:
         self._pf = None
         self._pf_stream = None
         self._norm_fresh = False
+        if self.device_state:
+            if self.comm.active:
+                raise RuntimeError("device_state (graph capture) is a single-GPU mode: the data-parallel step issues collectives from Python")
+            self.opt.device_state = True
+            seed0 = int(torch.randint(0, 2 ** 62, (1,)).item())          # torch.manual_seed -> reproducible runs
+            H.step_set(seed0, self.opt.step_count, *self.opt.betas)
+            st.live_seed = H.LIVE_SEED | 0x5E6D0001          # the (constant) seed argument of every dropout launch
 
     def _on_bucket(self, name, after_side=False):
         """Called from inside the backward the moment the gradients of bucket ``name`` are written (``after_side``: part of
@@ -520,6 +534,9 @@ class Trainer:
         if model.training != bool(self.dropout):
             model.train(self.dropout)          # (walks every sub-module: 0.35 ms of host time when done every step)
         self.opt.zero_grad()
+        if self.device_state:          # first launches of the step: advance the device-side step state, fresh header rows
+            H.step_advance(*self.opt.betas)
+            st.hdr_step_begin()
         st._trusted = False
         try:
             usr, um, vid, vm = self._features(batch)          # first ParamStore.ensure() of the step: the full check
@@ -592,6 +609,35 @@ class Trainer:
             self.comm.finish()
         self.opt.step()
         return out
+
+    # ---- hipGraph capture of the whole step (device_state mode)
+    def capture(self, batch: Dict[str, torch.Tensor], warmup: int = 3):
+        """Record one training step on ``batch``'s shapes in a hipGraph.  The batch is copied into static device buffers;
+        ``warmup`` eager steps run first (site scales calibrated, every scratch buffer allocated, both streams created), then
+        the step is captured -- capturing does not execute it.  ``replay(batch)`` copies a batch into the static buffers and
+        launches the graph: one host call per step."""
+        if not self.device_state:
+            raise RuntimeError("capture() needs Trainer(device_state=True)")
+        self._static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+        for _ in range(max(warmup, 1)):
+            self.train_step(self._static)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._static_out = self.train_step(self._static)
+        self._graph = g
+        return self._static_out
+
+    def replay(self, batch: Optional[Dict[str, torch.Tensor]] = None):
+        if self._graph is None:
+            raise RuntimeError("replay() before capture()")
+        if batch is not None and batch is not self._static:
+            for k, v in batch.items():
+                if torch.is_tensor(v):
+                    self._static[k].copy_(v, non_blocking=True)
+        self._graph.replay()
+        self.opt.step_count += 1
+        return self._static_out
 
     def _param_hooks(self) -> bool:
         plist = self.__dict__.get("_hook_plist")

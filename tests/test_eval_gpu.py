@@ -284,3 +284,44 @@ def test_weighted_head_matches_cliprec_forward():
     for got, ref in ((weighted_head(cp, w, dur), z["pred_weighted_masked"]), (weighted_head(cp, None, dur), z["pred_ones_masked"]),
                      (weighted_head(cp, w, None), z["pred_weighted_nomask"])):
         assert float((got.cpu() - torch.from_numpy(ref)).abs().max()) <= 2e-5
+
+
+@pytest.mark.gpu
+def test_graph_replay_equals_eager_device_state_step():
+    """Trainer(device_state=True): dropout seed words, AdamW's step count / bias corrections and the per-step site headers live
+    on the device, so one captured hipGraph of the step (Trainer.capture) can be replayed.  The replayed steps must leave
+    bit-identical parameters to the same steps run eagerly in the same mode (main_for_seq_leave_earlystop_SegMM.py:265-300),
+    with dropout ON (the masks change every step although the kernel arguments do not)."""
+    import torch
+    from segmminterest_amd import hipabi as H
+    from segmminterest_amd.synth import make_batch
+    from segmminterest_amd.trainer import Trainer, default_args, init_model
+    dev = torch.device("cuda:0")
+    B, S, Lt, D, N, h = 64, 20, 10, 64, 2, 4
+    margs = default_args(num_layers_enc=N, d_model=D, nhead=h, input_type={"user": "image", "photo": "image"}, exposure_prob=[1.0] * S)
+    batches = [{k: v.to(dev) for k, v in make_batch(B, S, Lt, D, seed=100 + i).items()} for i in range(4)]
+    T = 12
+
+    def run(graph):
+        torch.manual_seed(3)
+        model = init_model(margs, n_users=50, n_items=500, input_dim=D, max_vid_len=S, max_usr_len=Lt).to(dev)
+        tr = Trainer(model, lr=1e-3, weight_decay=1e-4, device_state=True)
+        losses = []
+        if graph:
+            tr.capture(batches[0], warmup=3)
+        else:
+            for _ in range(3):
+                tr.train_step(batches[0])
+        for t in range(T):
+            out = tr.replay(batches[t % 4]) if graph else tr.train_step(batches[t % 4])
+            losses.append(float(out["loss"].detach()))
+        torch.cuda.synchronize()
+        seed, step, bc = H.step_get()
+        return model._store.flat.detach().clone(), losses, step, seed
+
+    p_eager, l_eager, step_e, seed_e = run(False)
+    p_graph, l_graph, step_g, seed_g = run(True)
+    assert step_e == step_g == 3 + T and seed_e == seed_g
+    assert l_eager == l_graph
+    assert torch.equal(p_eager, p_graph)
+    assert len(set(l_eager)) > 1          # the steps really differ (new masks, new batches)
