@@ -49,6 +49,11 @@ sys.path.insert(0, ROOT)
 # (head-of-line blocking: 7.5 % of the step on one GPU, measured with a forced one-rank process group; 2.4 % with 8 queues).
 # Must be set before the HIP runtime initialises, i.e. before torch is imported; inherited by the ranks bench.py launches.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# --graph: ROCm 7.2's graph executor spreads the captured fork (main + side stream) over several queues by default and pays
+# more for the cross-queue dependencies than the overlap brings (config 4 at 256 rows: 3.74 ms per replayed step, 2.62 ms with
+# one queue, 2.45 ms eager on two streams; tools/probe/graph_env.sh).  Must be set before the HIP runtime initialises.
+if "--graph" in sys.argv:
+    os.environ.setdefault("DEBUG_HIP_FORCE_GRAPH_QUEUES", "1")
 
 PEAK_F32_MFMA_TFLOPS = 157.3          # v_mfma_f32_32x32x2_f32, MI355X_MICROARCH.md
 PEAK_BF16_MFMA_TFLOPS = 2500.0        # dense bf16 / fp16 MFMA, MI355X_MICROARCH.md

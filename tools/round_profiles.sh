@@ -10,6 +10,8 @@ SEGMM_SCALING=exact python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no
 python bench.py --config 3 --steps 20 --warmup 5 > $O/bench_cfg3.json 2>/dev/null
 python bench.py --config 5 --steps 20 --warmup 5 --no-cpu-baseline --no-f32-engine --no-host-fed --no-probe > $O/bench_cfg5.json 2>/dev/null
 python bench.py --config 4 --gpus 1 --global-batch 256 --steps 20 --warmup 5 --no-cpu-baseline --no-f32-engine --no-host-fed --no-probe > $O/bench_cfg4_256rows.json 2>/dev/null
+for M in "" "--device-state" "--graph"; do python bench.py --config 4 --gpus 1 --global-batch 256 --steps 20 --warmup 5 $M --no-cpu-baseline --no-f32-engine --no-host-fed --no-probe 2>/dev/null | tail -1; done > $O/bench_cfg4_256rows_graph_ab.jsonl
+./build/probe/mfma_small > $O/mfma_small_probe.txt 2>&1
 python bench.py --input index --steps 20 --warmup 5 --no-cpu-baseline --no-f32-engine --no-host-fed --no-probe > $O/bench_index_input.json 2>/dev/null
 python bench.py --gpus 2 --backend gloo --steps 6 --warmup 2 --no-cpu-baseline --no-probe > $O/bench_gloo2_one_gpu.json 2>/dev/null
 SEGMM_DP_FORCE=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-f32-engine --no-host-fed --no-probe > $O/bench_dp_forced_one_rank.json 2>/dev/null
