@@ -70,9 +70,13 @@ constexpr uint32_t BUF_OOB = 0x80000000u;          // a byte offset no descripto
 #define STAMP(k) do { } while (0)
 #endif
 
+#ifndef SEGMM_SETPRIO
+#define SEGMM_SETPRIO 0          // probe: raise the wave priority for the compute segments (s_setprio 1 ... 0)
+#endif
 template <int NOUT>          // number of LDS-DMA pieces this wave may leave in flight (0 .. 4)
 __device__ __forceinline__ void end_compute_segment() {
     __builtin_amdgcn_sched_barrier(0);
+    if (SEGMM_SETPRIO) __builtin_amdgcn_s_setprio(0);
     if (NOUT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else if (NOUT == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     else if (NOUT == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -85,6 +89,7 @@ __device__ __forceinline__ void end_load_segment() {
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if (SEGMM_SETPRIO) __builtin_amdgcn_s_setprio(1);
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 }
