@@ -106,6 +106,26 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_bwd_fused16_kernel(const Attn
     if (wave >= ntk) return;                               // surplus wave, or empty block (CrossAtt / SelfAtt ablations)
     const int nthr = 64 * ntk;                             // surviving threads
     const int col0 = h * DH;
+    const float* Qg = isa ? p.Qa : p.Qb;
+    float* dQg = isa ? p.dQa : p.dQb;
+    _Float16* dQgp = isa ? p.dQap : p.dQbp;
+    float s_q = (dQgp && p.sin_q) ? *p.sin_q : 0.f;
+    const float* sin_k = isa ? p.sin_ka : p.sin_kb;
+    float s_k = ((isa ? p.dKap : p.dKbp) && sin_k) ? *sin_k : 0.f;
+    const bool repair = (p.pflags & ATT_REPAIR) != 0;
+    const bool want_q = dQgp && p.sin_q, want_k = (isa ? p.dKap : p.dKbp) && sin_k;          // sites with plane outputs
+    if (repair) {          // (block-uniform, and the same in every workgroup of the launch: nobody writes the headers meanwhile)
+        // unusable = written with no scale at all (a site whose delayed scale is still 0: hdr[0] == 0), overflow flag up, or the
+        // maximum below the fp16 window
+        float* hk_ = isa ? p.hdr_ka : p.hdr_kb;
+        const bool need_q = want_q && !site_planes_ok(p.hdr_q, p.hdr_q[0], lane);
+        const bool need_k = want_k && !site_planes_ok(hk_, hk_[0], lane);
+        if (!need_q && !need_k) return;
+        s_q = need_q ? f16_scale_of(site_amax(p.hdr_q, lane)) : 0.f;
+        s_k = need_k ? f16_scale_of(site_amax(hk_, lane)) : 0.f;
+    }
+    const bool f32_q = !repair && !((p.pflags & ATT_PLANES_ONLY) && want_q);          // fp32 copies of dQ / of dK, dV
+    const bool f32_k = !repair && !((p.pflags & ATT_PLANES_ONLY) && want_k);
     char* sQ = (char*)smem_f;                              // [QC][RSB]: fp32 rows while staging, then [4 hi | 4 lo] groups
     char* sdO = sQ + QC * RSB;
     float* sdQ = (float*)(sdO + QC * RSB);
@@ -158,12 +178,6 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_bwd_fused16_kernel(const Attn
         else { const int jb = j - La_p; v = (jb < p.Lb) ? (p.mkb[(size_t)b * p.Lb + jb] ? 1 : 0) : 2; }
         km[j] = v;
     }
-    const float* Qg = isa ? p.Qa : p.Qb;
-    float* dQg = isa ? p.dQa : p.dQb;
-    _Float16* dQgp = isa ? p.dQap : p.dQbp;
-    const float s_q = (dQgp && p.sin_q) ? *p.sin_q : 0.f;
-    const float* sin_k = isa ? p.sin_ka : p.sin_kb;
-    const float s_k = ((isa ? p.dKap : p.dKbp) && sin_k) ? *sin_k : 0.f;
     const float fscale = p.scale;
     const int jp = 16 * jt + l15;                          // this lane's key (padded index)
     f32x4 dk[C::CT], dv[C::CT];
@@ -331,7 +345,7 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_bwd_fused16_kernel(const Attn
             const int q = i / (DH / 4), c = (i - q * (DH / 4)) * 4;
             const size_t row = (size_t)b * p.Lq + q0 + q;
             const f32x4 v = *(const f32x4*)(sdQ + q * RS + c);
-            *(f32x4*)(dQg + row * p.lddq + col0 + c) = v;
+            if (f32_q) *(f32x4*)(dQg + row * p.lddq + col0 + c) = v;
             if (s_q > 0.f) {
                 if ((col0 & 7) == 0) plane_store4_pair(dQgp, p.lddq2, (long long)row, col0 + c, v, s_q);
                 else plane_store4(dQgp, p.lddq2, (long long)row, col0 + c, v, s_q);
@@ -358,8 +372,10 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_bwd_fused16_kernel(const Attn
             const int ldk2 = ka ? p.lddka2 : p.lddkb2;
 #pragma unroll
             for (int ct = 0; ct < C::CT; ++ct) {
-                *(f32x4*)(dKp + 16 * ct + 4 * g) = dk[ct];
-                *(f32x4*)(dVp + 16 * ct + 4 * g) = dv[ct];
+                if (f32_k) {
+                    *(f32x4*)(dKp + 16 * ct + 4 * g) = dk[ct];
+                    *(f32x4*)(dVp + 16 * ct + 4 * g) = dv[ct];
+                }
                 if (s_k > 0.f) {          // lane (key, g) and lane (key, g ^ 1) hold the two halves of an aligned 8
                     if ((col0 & 7) == 0) {
                         plane_store4_x16(dKpp, ldk2, krow, col0 + 16 * ct + 4 * g, split4(dk[ct], s_k));
@@ -375,10 +391,12 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_bwd_fused16_kernel(const Attn
         float* hk = isa ? p.hdr_ka : p.hdr_kb;
         float* slot = isa ? p.amax_ka : p.amax_kb;
         const bool hdr_writer = bh == 0 && wave == 0 && lane == 0;
-        if (s_k > 0.f) { site_commit(hk, am, blockIdx.x * nw + wave, s_k); if (hdr_writer) hk[0] = s_k; }
-        else if (slot) amax_commit(slot, am, blockIdx.x * nw + wave);
-        if (s_q > 0.f) { site_commit(p.hdr_q, am_q, blockIdx.x * nw + wave, s_q); if (hdr_writer) p.hdr_q[0] = s_q; }
-        else if (p.amax_q) amax_commit(p.amax_q, am_q, blockIdx.x * nw + wave);
+        if (!repair) {
+            if (s_k > 0.f) { site_commit(hk, am, blockIdx.x * nw + wave, s_k); if (hdr_writer) hk[0] = s_k; }
+            else if (slot) amax_commit(slot, am, blockIdx.x * nw + wave);
+            if (s_q > 0.f) { site_commit(p.hdr_q, am_q, blockIdx.x * nw + wave, s_q); if (hdr_writer) p.hdr_q[0] = s_q; }
+            else if (p.amax_q) amax_commit(p.amax_q, am_q, blockIdx.x * nw + wave);
+        }
     }
 }
 

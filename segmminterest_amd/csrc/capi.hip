@@ -135,7 +135,9 @@ static int attn_launch_bwd(AttnArgs& a, int phase, hipStream_t s) {
         const int Lq_small = a.Lq <= 16 ? 16 : a.Lq <= 32 ? 32 : ATT_FUSED_QCHUNK;
         int Lq_p = ATT_FUSED_QCHUNK;
         SEGMM_REQUIRE(nta <= ATT_FUSED_MAXW && ntb <= ATT_FUSED_MAXW, "attn_bwd phase 4: built for <= 12 key tiles per block (%d + %d tiles)", nta, ntb);
-        static const int fmode = getenv("SEGMM_ATT_FUSED_LAUNCH") ? atoi(getenv("SEGMM_ATT_FUSED_LAUNCH")) : 2;
+        static const int fmode_env = getenv("SEGMM_ATT_FUSED_LAUNCH") ? atoi(getenv("SEGMM_ATT_FUSED_LAUNCH")) : 2;
+        // the repair pass is (almost always) a launch of workgroups that leave at once: one launch for both key blocks
+        const int fmode = (a.pflags & ATT_REPAIR) ? 1 : fmode_env;
         const int nmax = nta > ntb ? nta : ntb;
         for (int blk = 0; blk < 2; ++blk) {
             // fmode 2 (default): one launch per key block with its exact wave count -- 539-549 us at config 2;
@@ -294,7 +296,7 @@ __global__ void step_get_kernel(StepState* out) { *out = g_step; }
 extern "C" {
 
 const char* segmm_last_error(void) { return g_segmm_err; }
-int segmm_abi_version(void) { return 18; }
+int segmm_abi_version(void) { return 19; }
 int segmm_attn_mode(int mode) { const int prev = attn_f16(); if (mode >= 0 && mode <= 2) g_attn_mode = mode; return prev; }
 
 static PlaneOut plane_out(uint16_t* planes, int ld2, float* hdr, const float* scale_in) {
@@ -840,8 +842,30 @@ int segmm_attn_bwd(int B, int H, int dh, int Lq, int La, int Lb, const float* Qa
         a.sin_q = pl->sin_q; a.sin_ka = pl->sin_ka; a.sin_kb = pl->sin_kb;
         if (La == 0) { a.dQap = nullptr; a.dKap = a.dKbp; a.dVap = a.dVbp; a.lddka2 = a.lddkb2; a.hdr_ka = a.hdr_kb; a.sin_ka = a.sin_kb; }
         if (Lb == 0) { a.dQbp = nullptr; a.dKbp = a.dKap; a.dVbp = a.dVap; a.lddkb2 = a.lddka2; a.hdr_kb = a.hdr_ka; a.sin_kb = a.sin_ka; }
+        SEGMM_REQUIRE((pl->flags & ~3) == 0, "attn_bwd: plane flags %d", pl->flags);
+        a.pflags = pl->flags;
+    } else {
+        SEGMM_REQUIRE(!pl || pl->flags == 0, "attn_bwd: plane flags need the fused backward (phase 4) with plane outputs");
     }
     ATTN_DISPATCH(attn_launch_bwd, dh, a, phase, (hipStream_t)stream);
+}
+
+namespace segmm {
+__global__ __launch_bounds__(256) void site_fixup_kernel(float* h0, float* h1, float* h2, float* h3, float* stats) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* h = wave == 0 ? h0 : wave == 1 ? h1 : wave == 2 ? h2 : h3;
+    if (!h) return;
+    if (!site_planes_ok(h, h[0], lane)) {          // (also a site written with no scale yet: h[0] == 0)
+        const float sx = f16_scale_of(site_amax(h, lane));
+        if (lane == 0) { h[0] = sx; ((volatile unsigned int*)h)[1] = 0u; if (stats) atomicAdd(stats, 1.0f); }
+    }
+}
+}  // namespace segmm
+int segmm_site_fixup(float* hdr0, float* hdr1, float* hdr2, float* hdr3, float* stats, segmm_stream_t stream) {
+    if (!hdr0 && !hdr1 && !hdr2 && !hdr3) return 0;
+    hipLaunchKernelGGL(site_fixup_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, hdr0, hdr1, hdr2, hdr3, stats);
+    LAUNCH_CHECK();
+    return 0;
 }
 
 int segmm_rowdot(const float* x, int ld, const float* w, const float* bias, float* out, int64_t rows, int d,

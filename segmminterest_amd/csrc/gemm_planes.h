@@ -62,23 +62,6 @@ __device__ __forceinline__ void dma_wait_barrier() {
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 }
-// largest |x| the producers of a site recorded (AMAX_SLOTS partial maxima, four per lane): the same value in every wave
-__device__ __forceinline__ float site_amax(const float* hdr, int lane) {
-    static_assert(AMAX_SLOTS == 256, "one float4 per lane");
-    const f32x4 v = *(const f32x4*)(hdr + SITE_HDR + lane * 4);
-    return wave_max(fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
-}
-// Planes written with the (delayed) scale s are usable iff the tensor's maximum sits inside the fp16 window: below 65504 -- the
-// producers' overflow flag says the same -- AND not so far below it that the lo terms sink into the subnormals: a tensor that
-// SHRANK by more than ~2^9 since its scale was derived (the gradients of a batch whose loss has collapsed) would silently keep
-// 12 bits instead of 22.  max * s >= 2^-2 keeps every element's absolute error below 2^-22 max.  Checked by the CONSUMER, which
-// sees the complete maxima (one 1 KB read per wave); block-uniform.
-__device__ __forceinline__ bool site_planes_ok(const float* hdr, float s, int lane) {
-    if (!(s > 0.f) || __float_as_uint(hdr[1]) != 0u) return false;
-    const float m = site_amax(hdr, lane);
-    // (s at its upper clamp 2^60 -- f16_scale_of / scales_update keep 1/(sa sb) finite: the fallback would use the same scale)
-    return !(m > 0.f) || ((m * s >= 0.25f || s >= 0x1p60f) && m * s < 65504.f);
-}
 // exact scale of a site from its partial maxima (slow path only): every thread of the block gets the same value
 __device__ __forceinline__ float site_exact_scale(const float* hdr, float* red, int tid, int nthreads) {
     float m = 0.f;

@@ -148,6 +148,7 @@ class ParamStore:
         self.overlap = os.environ.get("SEGMM_OVERLAP", "1") != "0"
         self.defer_wgrad = os.environ.get("SEGMM_DEFER_WGRAD", "0") != "0"
         self.tail_balance = os.environ.get("SEGMM_TAIL_BALANCE", "1") != "0"
+        self.attn_planes_only = os.environ.get("SEGMM_ATTN_PLANES_ONLY", "1") != "0"
         # attention backward as D-kernel, then dQ (third stream) next to dK/dV (main stream).  Measured (same box, alternating
         # runs): 80.3 k -> 79.6 k interactions/s, the union of the attention intervals unchanged at 1.10-1.14 ms/step -- the two
         # kernels share the same vector-memory pipeline and simply slow each other down.  OFF by default.
@@ -629,12 +630,13 @@ class Act:
     """A tensor that some GEMM reads: the fp32 values ``t`` ([rows, cols] row-major), its site header ``hdr`` (scale, overflow
     flag, partial maxima -- None on the f32 / bf16x6 engines) and, on the plane engine, the P32 fp16 planes ``planes``
     ([rows, 2 cols]; None when cols is not a multiple of 32: such operands go through the on-the-fly kernel)."""
-    __slots__ = ("t", "hdr", "rows", "cols", "planes", "filled", "po", "scale_ptr")
+    __slots__ = ("t", "hdr", "rows", "cols", "planes", "filled", "po", "scale_ptr", "no_f32")
 
     def __init__(self, t, hdr, rows, cols, planes=None):
         self.t, self.hdr, self.rows, self.cols, self.planes, self.filled = t, hdr, rows, cols, planes, False
         self.po = None              # hipabi.PO when the producer writes the planes itself (delayed scale)
         self.scale_ptr = None
+        self.no_f32 = False         # the producers wrote planes only (and repaired them if need be): consumers get no fp32 fallback
 
     @property
     def slots(self):
@@ -642,7 +644,8 @@ class Act:
 
     def pt(self, c0=0, ncols=None):
         ncols = self.cols - c0 if ncols is None else ncols
-        return H.PT(self.planes, self.hdr, self.rows, ncols, ld2=2 * self.cols, p_off=2 * c0, f32=self.t, ldf=self.cols, f_off=c0)
+        return H.PT(self.planes, self.hdr, self.rows, ncols, ld2=2 * self.cols, p_off=2 * c0, f32=None if self.no_f32 else self.t,
+                    ldf=self.cols, f_off=c0)
 
 
 class AmaxArena:
@@ -1187,7 +1190,12 @@ class BackboneRun:
         Dv = st.buf("attnD", (B * Hh * max(S, Lt),))
         sl_v, sl_u = dYv.slots, (dYu.slots if nu else None)
 
-        def planes_of(dq, dka_, dkb_, views):
+        # planes only: dQ / dK / dV are read by the projection GEMMs alone, as planes; their fp32 copies only ever fed the consumers'
+        # overflow fallback (0.57 GB of stores per step at config 2).  Without them, a REPAIR pass of the same launches follows
+        # the producers (leaves at once unless a site's planes are unusable) and the consumers get no fp32 fallback.
+        ponly = dly and st.attn_planes_only and dYv.po is not None and (not nu or dYu.po is not None)
+
+        def planes_of(dq, dka_, dkb_, views, pflags=0):
             """segmm_attn_planes_t for one fused-backward call: query-side buffer dq, key-block buffers dka_ / dkb_ (Acts)."""
             if not dly or dq.po is None:
                 return None
@@ -1195,6 +1203,7 @@ class BackboneRun:
 
             def pp(act, view):          # plane address of the column slice ``view`` = (fp32 tensor, column offset)
                 return None if (act is None or act.po is None or view is None) else act.planes.data_ptr() + 4 * view[1]
+            pl.flags = pflags
             pl.dqa, pl.dqb, pl.lddq2 = pp(dq, views["Qa"]), pp(dq, views["Qb"]), 2 * dq.cols
             pl.hdr_q, pl.sin_q = dq.hdr.data_ptr(), dq.scale_ptr
             if dka_ is not None and dka_.po is not None and views["Ka"] is not None:
@@ -1207,19 +1216,34 @@ class BackboneRun:
         deferred = [] if st.defer_wgrad else None
         dR1v, dAv = self._side_post_bwd(i, L, "vid", rec["v"], dXv_out, Mv, (K_AO_V, K_MI_V, K_MO_V), gbuf, "v%d" % i, deferred)
         flush_deferred(st, deferred)          # the three weight-gradient GEMMs of this side run under the attention backward
-        _attn_bwd(st, B, Hh, dh, S, vq["La"], vq["Lb"], vq["Qa"], vq["Qb"], vq["ldq"], vq["Ka"], vq["Va"], vq["ldka"], vq["Kb"], vq["Vb"],
-                   vq["ldkb"], self.vm, self.vm, self.um, rec["lse_v"], rec["v"]["A"].t, d, dAv, d, Dv, dvq["Qa"], dvq["Qb"], dvq["ldq"],
-                   dvq["Ka"], dvq["Va"], dvq["ldka"], dvq["Kb"], dvq["Vb"], dvq["ldkb"], drop_p=self.p_drop, seed=self.seed,
-                   site=_site(self.bi, i, K_ATT_V), amax_q=sl_v, amax_ka=sl_v, amax_kb=sl_u, planes=planes_of(dYv, dYv, dYu, dvq))
+        def attn_v(pflags):
+            _attn_bwd(st, B, Hh, dh, S, vq["La"], vq["Lb"], vq["Qa"], vq["Qb"], vq["ldq"], vq["Ka"], vq["Va"], vq["ldka"], vq["Kb"], vq["Vb"],
+                       vq["ldkb"], self.vm, self.vm, self.um, rec["lse_v"], rec["v"]["A"].t, d, dAv, d, Dv, dvq["Qa"], dvq["Qb"], dvq["ldq"],
+                       dvq["Ka"], dvq["Va"], dvq["ldka"], dvq["Kb"], dvq["Vb"], dvq["ldkb"], drop_p=self.p_drop, seed=self.seed,
+                       site=_site(self.bi, i, K_ATT_V), amax_q=sl_v, amax_ka=sl_v, amax_kb=sl_u,
+                       planes=planes_of(dYv, dYv, dYu, dvq, pflags))
+        attn_v(H.ATTN_PLANES_ONLY if ponly else 0)
+        attn_u = None
         dR1u = None
         if full:
             dR1u, dAu = self._side_post_bwd(i, L, "usr", rec["u"], dXu_out, Mu, (K_AO_U, K_MI_U, K_MO_U), gbuf, "u%d" % i, deferred)
             flush_deferred(st, deferred)
-            _attn_bwd(st, B, Hh, dh, Lt, uq["La"], uq["Lb"], uq["Qa"], uq["Qb"], uq["ldq"], uq["Ka"], uq["Va"], uq["ldka"], uq["Kb"],
-                       uq["Vb"], uq["ldkb"], self.um, self.vm, self.um, rec["lse_u"], rec["u"]["A"].t, d, dAu, d, Dv,
-                       duq["Qa"], duq["Qb"], duq["ldq"], duq["Ka"], duq["Va"], duq["ldka"], duq["Kb"], duq["Vb"], duq["ldkb"],
-                       drop_p=self.p_drop, seed=self.seed, site=_site(self.bi, i, K_ATT_U),
-                       amax_q=sl_u, amax_ka=sl_v, amax_kb=sl_u, planes=planes_of(dYu, dYv, dYu, duq))
+            def attn_u(pflags):
+                _attn_bwd(st, B, Hh, dh, Lt, uq["La"], uq["Lb"], uq["Qa"], uq["Qb"], uq["ldq"], uq["Ka"], uq["Va"], uq["ldka"], uq["Kb"],
+                           uq["Vb"], uq["ldkb"], self.um, self.vm, self.um, rec["lse_u"], rec["u"]["A"].t, d, dAu, d, Dv,
+                           duq["Qa"], duq["Qb"], duq["ldq"], duq["Ka"], duq["Va"], duq["ldka"], duq["Kb"], duq["Vb"], duq["ldkb"],
+                           drop_p=self.p_drop, seed=self.seed, site=_site(self.bi, i, K_ATT_U),
+                           amax_q=sl_u, amax_ka=sl_v, amax_kb=sl_u, planes=planes_of(dYu, dYv, dYu, duq, pflags))
+            attn_u(H.ATTN_PLANES_ONLY if ponly else 0)
+        if ponly:          # every producer of the two sites is enqueued: repair pass, then the headers say what the planes carry
+            attn_v(H.ATTN_PLANES_ONLY | H.ATTN_REPAIR)
+            if attn_u is not None:
+                attn_u(H.ATTN_PLANES_ONLY | H.ATTN_REPAIR)
+            H.site_fixup(dYv.hdr if dYv.po is not None else None, dYu.hdr if (nu and dYu.po is not None) else None,
+                         stats=st.scales()[st.MAX_SITES:])
+            dYv.no_f32 = dYv.po is not None
+            if nu:
+                dYu.no_f32 = dYu.po is not None
         if dly:          # every column block of a dY buffer must have been written WITH planes, else fall back to the split pass
             produced(dYv)
             if nu:

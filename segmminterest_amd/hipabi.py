@@ -15,7 +15,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SEGMM_LIB") or os.path.join(_HERE, "libsegmm_hip.so")      # SEGMM_LIB: A/B builds of the kernels
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 _lib = None
 
@@ -34,6 +34,7 @@ SIGNATURES = {
     "segmm_scales_update": [_p, _p, _i, _p, _p, _i, _p, _p, _p],
     "segmm_probe_mfma_rate": [_i, _i, _p, _p, _p],
     "segmm_attn_mode": [_i],
+    "segmm_site_fixup": [_p, _p, _p, _p, _p, _p],
     "segmm_step_set": [_u64, _i, _f, _f, _p],
     "segmm_step_advance": [_f, _f, _p],
     "segmm_step_get": [_p, _p, _p, _p],
@@ -472,7 +473,17 @@ class AttnPlanes(C.Structure):
     _fields_ = [("o", _p), ("ldo2", _i), ("hdr_o", _p), ("sin_o", _p),
                 ("dqa", _p), ("dqb", _p), ("lddq2", _i), ("dka", _p), ("dva", _p), ("lddka2", _i),
                 ("dkb", _p), ("dvb", _p), ("lddkb2", _i), ("hdr_q", _p), ("hdr_ka", _p), ("hdr_kb", _p),
-                ("sin_q", _p), ("sin_ka", _p), ("sin_kb", _p)]
+                ("sin_q", _p), ("sin_ka", _p), ("sin_kb", _p), ("flags", _i)]
+
+
+ATTN_PLANES_ONLY, ATTN_REPAIR = 1, 2
+
+
+def site_fixup(*hdrs, stats=None):
+    """After the repair launches of planes-only producers: record the scale the planes of each site now carry (hdr[0]);
+    ``stats[0]`` counts the repaired sites."""
+    h = [None if x is None else x.data_ptr() for x in hdrs] + [None] * 4
+    _check(lib().segmm_site_fixup(h[0], h[1], h[2], h[3], _ptr(stats), _stream()), "segmm_site_fixup")
 
 
 def attn_fwd(B, H, dh, Lq, La, Lb, Qa, Qb, ldq, Ka, Va, ldka, Kb, Vb, ldkb, mq, mka, mkb, O, ldo, lse,

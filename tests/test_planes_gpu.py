@@ -552,3 +552,44 @@ def test_backward_scales_follow_the_loss_gradient(towers):
     for k, f in enumerate((1.0, 1.0, 1.0, 1e-6, 1.0, 1.0)):
         assert float((g_rel[k] - g_plain[k]).abs().max()) <= 2e-6 * gmax * f, k          # planes and fallback: the same numbers
         assert float((g_rel[k] / f - g_rel[2]).abs().max()) <= 2e-5 * gmax, k            # linear in the loss coefficient
+
+
+@pytest.mark.parametrize("factor", [2.0 ** 22, 2.0 ** -22])
+def test_attention_backward_planes_only_repair_pass(factor):
+    """The fused attention backward writes dQ / dK / dV as planes ONLY (no fp32 copy: engine._layer_bwd, SEGMM_ATTN_PLANES_ONLY);
+    what used to be the consumers' fp32 fallback is a repair pass of the same launches.  Tamper with the loss-relative gains of
+    the two attention-gradient sites so that their delayed scales are 2^22 too large (overflow flag) or too small (maximum
+    below the fp16 window): the step must still produce the gradients of an untampered twin, and the repaired sites are counted."""
+    from segmminterest_amd import hipabi as H
+    from segmminterest_amd.synth import make_batch
+    from segmminterest_amd.trainer import Trainer, default_args, init_model
+    if H.GEMM_ENGINE != H.ENGINE_F16X3P:
+        pytest.skip("plane engine only")
+    B, S, Lt, D, N = 16, 20, 10, 64, 3          # N = 3: one full layer (user queries too) + one video-only layer
+    margs = default_args(num_layers_enc=N, d_model=D, nhead=4, input_type={"user": "image", "photo": "image"}, exposure_prob=[1.0] * S)
+    batches = [{k: v.cuda() for k, v in make_batch(B, S, Lt, D, seed=70 + i).items()} for i in range(2)]
+    grads, counts = [], []
+    for tamper in (False, True):
+        torch.manual_seed(11)
+        model = init_model(margs, n_users=1, n_items=1, input_dim=D, max_vid_len=S, max_usr_len=Lt).cuda()
+        tr = Trainer(model, dropout=False, lr=0.0, weight_decay=0.0)          # lr 0: both twins keep identical parameters
+        st = model._store
+        if not (st.engine_p and st.attn_planes_only and st.attn_fused):
+            pytest.skip("planes-only attention backward disabled")
+        st.scaling = "always"          # delayed scales although dropout is off (deterministic twins)
+        for i in range(3):
+            tr.train_step(batches[i % 2])
+        n0 = st.overflow_count()
+        if tamper:
+            sites = [n for n in st.site_index if "dYv" in n or "dYu" in n]
+            assert sites
+            for n in sites:
+                st.gains()[st.site(n)] *= factor
+        tr.train_step(batches[1])
+        torch.cuda.synchronize()
+        grads.append({k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None})
+        counts.append(st.overflow_count() - n0)
+    assert counts[0] == 0 and counts[1] >= 2          # every tampered site was repaired (and counted)
+    for k, ref in grads[0].items():
+        sc = max(float(ref.abs().max()), 1e-9)
+        assert float((grads[1][k] - ref).abs().max()) <= 2e-6 * sc + 1e-12, k
