@@ -180,16 +180,17 @@ typedef struct {
     const float *sin_q, *sin_ka, *sin_kb;
     /* fused backward only.  bit 0 (SEGMM_ATTN_PLANES_ONLY): gradients whose planes are written get no fp32 copy -- the caller
      * then passes the consumers no fp32 fallback for that site and, after EVERY producer of the site has been enqueued, calls
-     * segmm_attn_bwd again with the same arguments and bit 1 (SEGMM_ATTN_REPAIR) set, followed by segmm_site_fixup on the
-     * site headers: the repair launch ends at once unless the planes of a site are unusable (overflow flag, or the maximum
-     * below the fp16 window), in which case it rewrites them with the exact scale of the recorded maxima. */
+     * segmm_site_fixup on the site headers and then segmm_attn_bwd again with the same arguments and bit 1
+     * (SEGMM_ATTN_REPAIR) set: the repair launch ends at once unless segmm_site_fixup found the planes of a site unusable
+     * (overflow flag, maximum below the fp16 window, or no scale yet), in which case it rewrites them with the exact scale of
+     * the recorded maxima. */
     int flags;
 } segmm_attn_planes_t;
 #define SEGMM_ATTN_PLANES_ONLY 1
 #define SEGMM_ATTN_REPAIR 2
-/* After a repair launch: for each non-NULL site header, if its planes were unusable under hdr[0], record the exact scale of the
- * recorded maxima (the one the repair launch wrote with) in hdr[0], clear the overflow flag and count the site in stats[0]
- * (the counter segmm_scales_update keeps for refused planes; may be NULL). */
+/* Between the producers of planes-only sites and their repair launches: for each non-NULL site header whose planes are
+ * unusable under hdr[0], put the exact scale of the recorded maxima in hdr[0], clear the overflow flag, set hdr[2] (the repair
+ * launches act on it) and count the site in stats[0] (the counter segmm_scales_update keeps for refused planes; may be NULL). */
 int segmm_site_fixup(float* hdr0, float* hdr1, float* hdr2, float* hdr3, float* stats, segmm_stream_t stream);
 int segmm_attn_fwd(int B, int H, int dh, int Lq, int La, int Lb, const float* Qa, const float* Qb, int ldq,
                    const float* Ka, const float* Va, int ldka, const float* Kb, const float* Vb, int ldkb,

@@ -796,15 +796,15 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_bwd_fused_kernel(const AttnAr
     float s_k = ((isa ? p.dKap : p.dKbp) && sin_k) ? *sin_k : 0.f;
     const bool repair = (p.pflags & ATT_REPAIR) != 0;
     const bool want_q = dQgp && p.sin_q, want_k = (isa ? p.dKap : p.dKbp) && sin_k;          // sites with plane outputs
-    if (repair) {          // (block-uniform, and the same in every workgroup of the launch: nobody writes the headers meanwhile)
-        // unusable = written with no scale at all (a site whose delayed scale is still 0: hdr[0] == 0), overflow flag up, or the
-        // maximum below the fp16 window
-        float* hk_ = isa ? p.hdr_ka : p.hdr_kb;
-        const bool need_q = want_q && !site_planes_ok(p.hdr_q, p.hdr_q[0], lane);
-        const bool need_k = want_k && !site_planes_ok(hk_, hk_[0], lane);
+    if (repair) {
+        // segmm_site_fixup has judged the sites between the producers and this launch: hdr[2] != 0 = the planes were unusable
+        // (written with no scale at all, overflow flag up, or the maximum below the fp16 window) and hdr[0] now holds the exact
+        // scale of the recorded maxima, with which this pass rewrites them.  Two scalar loads and out, normally.
+        const float* hk_ = isa ? p.hdr_ka : p.hdr_kb;
+        const bool need_q = want_q && p.hdr_q[2] != 0.f, need_k = want_k && hk_[2] != 0.f;
         if (!need_q && !need_k) return;
-        s_q = need_q ? f16_scale_of(site_amax(p.hdr_q, lane)) : 0.f;
-        s_k = need_k ? f16_scale_of(site_amax(hk_, lane)) : 0.f;
+        s_q = need_q ? p.hdr_q[0] : 0.f;
+        s_k = need_k ? hk_[0] : 0.f;
     }
     const bool f32_q = !repair && !((p.pflags & ATT_PLANES_ONLY) && want_q);          // fp32 copies of dQ / of dK, dV
     const bool f32_k = !repair && !((p.pflags & ATT_PLANES_ONLY) && want_k);

@@ -857,7 +857,7 @@ __global__ __launch_bounds__(256) void site_fixup_kernel(float* h0, float* h1, f
     if (!h) return;
     if (!site_planes_ok(h, h[0], lane)) {          // (also a site written with no scale yet: h[0] == 0)
         const float sx = f16_scale_of(site_amax(h, lane));
-        if (lane == 0) { h[0] = sx; ((volatile unsigned int*)h)[1] = 0u; if (stats) atomicAdd(stats, 1.0f); }
+        if (lane == 0) { h[0] = sx; ((volatile unsigned int*)h)[1] = 0u; h[2] = 1.f; if (stats) atomicAdd(stats, 1.0f); }
     }
 }
 }  // namespace segmm

@@ -148,7 +148,7 @@ class ParamStore:
         self.overlap = os.environ.get("SEGMM_OVERLAP", "1") != "0"
         self.defer_wgrad = os.environ.get("SEGMM_DEFER_WGRAD", "0") != "0"
         self.tail_balance = os.environ.get("SEGMM_TAIL_BALANCE", "1") != "0"
-        self.attn_planes_only = os.environ.get("SEGMM_ATTN_PLANES_ONLY", "1") != "0"
+        self.attn_planes_only = int(os.environ.get("SEGMM_ATTN_PLANES_ONLY", "1"))
         # attention backward as D-kernel, then dQ (third stream) next to dK/dV (main stream).  Measured (same box, alternating
         # runs): 80.3 k -> 79.6 k interactions/s, the union of the attention intervals unchanged at 1.10-1.14 ms/step -- the two
         # kernels share the same vector-memory pipeline and simply slow each other down.  OFF by default.
@@ -1193,7 +1193,10 @@ class BackboneRun:
         # planes only: dQ / dK / dV are read by the projection GEMMs alone, as planes; their fp32 copies only ever fed the consumers'
         # overflow fallback (0.57 GB of stores per step at config 2).  Without them, a REPAIR pass of the same launches follows
         # the producers (leaves at once unless a site's planes are unusable) and the consumers get no fp32 fallback.
-        ponly = dly and st.attn_planes_only and dYv.po is not None and (not nu or dYu.po is not None)
+        # (short query sides -- config 3: 20 and 1 queries -- keep the copies: the tensors are small and the extra launches of the
+        # repair pass cost as much as the stores they save; SEGMM_ATTN_PLANES_ONLY=2 forces the protocol for every shape)
+        ponly = dly and st.attn_planes_only and dYv.po is not None and (not nu or dYu.po is not None) and \
+            (S > 32 or st.attn_planes_only > 1)
 
         def planes_of(dq, dka_, dkb_, views, pflags=0):
             """segmm_attn_planes_t for one fused-backward call: query-side buffer dq, key-block buffers dka_ / dkb_ (Acts)."""
@@ -1235,12 +1238,12 @@ class BackboneRun:
                            drop_p=self.p_drop, seed=self.seed, site=_site(self.bi, i, K_ATT_U),
                            amax_q=sl_u, amax_ka=sl_v, amax_kb=sl_u, planes=planes_of(dYu, dYv, dYu, duq, pflags))
             attn_u(H.ATTN_PLANES_ONLY if ponly else 0)
-        if ponly:          # every producer of the two sites is enqueued: repair pass, then the headers say what the planes carry
+        if ponly:          # every producer of the two sites is enqueued: judge the sites (one tiny launch), then the repair pass
+            H.site_fixup(dYv.hdr if dYv.po is not None else None, dYu.hdr if (nu and dYu.po is not None) else None,
+                         stats=st.scales()[st.MAX_SITES:])
             attn_v(H.ATTN_PLANES_ONLY | H.ATTN_REPAIR)
             if attn_u is not None:
                 attn_u(H.ATTN_PLANES_ONLY | H.ATTN_REPAIR)
-            H.site_fixup(dYv.hdr if dYv.po is not None else None, dYu.hdr if (nu and dYu.po is not None) else None,
-                         stats=st.scales()[st.MAX_SITES:])
             dYv.no_f32 = dYv.po is not None
             if nu:
                 dYu.no_f32 = dYu.po is not None

@@ -480,8 +480,8 @@ ATTN_PLANES_ONLY, ATTN_REPAIR = 1, 2
 
 
 def site_fixup(*hdrs, stats=None):
-    """After the repair launches of planes-only producers: record the scale the planes of each site now carry (hdr[0]);
-    ``stats[0]`` counts the repaired sites."""
+    """Between planes-only producers and their repair launches: judge each site (hdr[2] = needs repair, hdr[0] = the exact
+    scale to repair with); ``stats[0]`` counts the repaired sites."""
     h = [None if x is None else x.data_ptr() for x in hdrs] + [None] * 4
     _check(lib().segmm_site_fixup(h[0], h[1], h[2], h[3], _ptr(stats), _stream()), "segmm_site_fixup")
 

@@ -577,6 +577,7 @@ def test_attention_backward_planes_only_repair_pass(factor):
         if not (st.engine_p and st.attn_planes_only and st.attn_fused):
             pytest.skip("planes-only attention backward disabled")
         st.scaling = "always"          # delayed scales although dropout is off (deterministic twins)
+        st.attn_planes_only = 2          # also for this test's short query side
         for i in range(3):
             tr.train_step(batches[i % 2])
         n0 = st.overflow_count()
