@@ -572,6 +572,9 @@ int segmm_gemm_p(int layout, int M, int N, int K, const uint16_t* a_planes, int 
                 return 0;
             }
         }
+        // the round-2 NT kernels below judge and fall back for operand A only: B must be an exact-split operand (weight planes)
+        SEGMM_REQUIRE(!b_f32, "gemm_p NT: this launch (row-scaled output, residual with a d-activation, or an extent >= 2^31) runs on the "
+                              "round-2 kernel, which has no fp32 fallback for operand B -- pass B without an fp32 copy (exact-split planes)");
         if (pl_var == 4) {          // four-wave form: 128 x 256 tiles, two workgroups per CU
             g.nbm = (M + QBM - 1) / QBM; g.nbn = (N + QBN - 1) / QBN;
             hipLaunchKernelGGL(gemm_pl_nt4, dim3(g.nbm * g.nbn), dim3(256), 0, s, g, q);

@@ -138,7 +138,7 @@ def test_gemm_p_epilogue_matches_on_the_fly(act):
     auxp, auxl = aux0.clone(), aux0.clone()
     kw = dict(bias=bias, residual=res, ldr=N, res_period=40, activation=act, drop_p=0.25, seed=77, site=5, ldaux=N)
     pl, hdr, sc, po = _po(H, M, N, 2.0 ** 9)
-    H.gemm_p(H.LAYOUT_NT, M, N, K, H.to_planes(A, M, K), H.to_planes(W, N, K), Cp, N, c_pt=H.PT(pl, hdr, M, N, f32=Cp),
+    H.gemm_p(H.LAYOUT_NT, M, N, K, H.to_planes(A, M, K), H.to_planes(W, N, K, keep_f32=False), Cp, N, c_pt=H.PT(pl, hdr, M, N, f32=Cp),
              c_scale_ptr=sc.data_ptr(), aux=auxp if act in (1, 2) else None, **kw)
     H.gemm(H.LAYOUT_NT, M, N, K, A, K, W, K, Cl, N, engine=H.ENGINE_F16X3, aux=auxl if act in (1, 2) else None, **kw)
     assert float((Cp - Cl).abs().max()) <= 1e-6 * float(Cl.abs().max())
