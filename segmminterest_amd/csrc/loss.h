@@ -238,7 +238,17 @@ __global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restric
     if (dlogits) {
         __shared__ float gred[4];
         float g = 0.f;
-        for (long long i = threadIdx.x; i < n_dl; i += blockDim.x) g = fmaxf(g, fabsf(dlogits[i]));
+        // one workgroup walks B*S values: 16-byte loads, four of them in flight per thread (the scalar loop was 80 dependent
+        // round trips at config 2 -- most of this launch's 32 us on the step's critical path between forward and backward)
+        const long long n4 = ((reinterpret_cast<uintptr_t>(dlogits) & 15) == 0) ? (n_dl >> 2) : 0;
+        const f32x4* d4 = (const f32x4*)dlogits;
+        long long i4 = threadIdx.x;
+        for (; i4 + 3 * (long long)blockDim.x < n4; i4 += 4 * (long long)blockDim.x) {
+            const f32x4 a = d4[i4], b = d4[i4 + blockDim.x], c2 = d4[i4 + 2 * blockDim.x], e = d4[i4 + 3 * blockDim.x];
+            g = absmax4(absmax4(absmax4(absmax4(g, a), b), c2), e);
+        }
+        for (; i4 < n4; i4 += blockDim.x) g = absmax4(g, d4[i4]);
+        for (long long i = 4 * n4 + threadIdx.x; i < n_dl; i += blockDim.x) g = fmaxf(g, fabsf(dlogits[i]));
         g = wave_max(g);
         if ((threadIdx.x & 63) == 0) gred[threadIdx.x >> 6] = g;
         __syncthreads();
@@ -260,8 +270,16 @@ __global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restric
     }
     const int c = threadIdx.x & 15, r0 = threadIdx.x >> 4;
     float a = 0.f;
-    if (c < 12)
-        for (int r = r0; r < B; r += 16) a += parts[(size_t)r * 12 + c];
+    if (c < 12) {          // (fixed summation order per column: rows r0, r0 + 16, ... in four interleaved chains, then combined)
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int r = r0;
+        for (; r + 48 < B; r += 64) {
+            a0 += parts[(size_t)r * 12 + c]; a1 += parts[(size_t)(r + 16) * 12 + c];
+            a2 += parts[(size_t)(r + 32) * 12 + c]; a3 += parts[(size_t)(r + 48) * 12 + c];
+        }
+        for (; r < B; r += 16) a0 += parts[(size_t)r * 12 + c];
+        a = (a0 + a1) + (a2 + a3);
+    }
     red[r0][c] = a;
     __syncthreads();
     if (threadIdx.x < 16) {

@@ -9,6 +9,8 @@ and ``HeadLossFn``).
 """
 from __future__ import annotations
 
+import contextlib
+
 import torch
 import torch.nn as nn
 
@@ -143,7 +145,7 @@ class HeadLossFn(torch.autograd.Function):
         dv2 = torch.empty(M, d, device=v1.device) if v2 is not None else None
         model._head_bwd(v1, v2, dl, dv1, dv2, ctx.T, M, d, B, S, gbuf)
         if gbuf is None and st.bucket_hook is not None:
-            st.bucket_hook("head")
+            st.bucket_hook("head", after_side=st.head_side)
         ctx.dlogits = ctx.T = None
         return (None, None, dv1.view(B, S, d), dv2.view(B, S, d) if dv2 is not None else None, None) + E.grads_out(st, names, gbuf)
 
@@ -291,9 +293,16 @@ class MultiScaleTemporalDetrLeaveFocal(nn.Module):
 
         def lin_bwd(wname, bname, x, dx, w_off=0, acc_w=False):
             H.rowscale_bcast(dl, st.p(wname), dx, d, M, d, w_off=w_off)
-            E._colsum(st, x, d, M, d, st.g(wname, gbuf).view(-1)[w_off:w_off + d], w=dl, accumulate=acc_w)
-            if bname is not None:
-                H.vecsum(dl, M, st.g(bname, gbuf))
+            # the head's own weight / bias gradients feed nothing in the backward: on the side stream, off the chain
+            # loss -> d(features) -> LayerNorm backward -> first input-gradient GEMM that the main stream is waiting on
+            with (E.side_work(st) if st.head_side else contextlib.nullcontext()):
+                if st.head_side and st.overlap:          # x and dl are autograd-owned tensors: the allocator must not hand their
+                    side = st.side_stream()               # memory out again before the side stream has read them
+                    x.record_stream(side)
+                    dl.record_stream(side)
+                E._colsum(st, x, d, M, d, st.g(wname, gbuf).view(-1)[w_off:w_off + d], w=dl, accumulate=acc_w)
+                if bname is not None:
+                    H.vecsum(dl, M, st.g(bname, gbuf))
 
         if v2 is None:
             lin_bwd("stage_mlp1.weight", "stage_mlp1.bias", v1, dv1)

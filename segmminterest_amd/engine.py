@@ -149,6 +149,7 @@ class ParamStore:
         self.defer_wgrad = os.environ.get("SEGMM_DEFER_WGRAD", "0") != "0"
         self.tail_balance = os.environ.get("SEGMM_TAIL_BALANCE", "1") != "0"
         self.attn_planes_only = int(os.environ.get("SEGMM_ATTN_PLANES_ONLY", "1"))
+        self.head_side = os.environ.get("SEGMM_HEAD_SIDE", "1") != "0"
         # attention backward as D-kernel, then dQ (third stream) next to dK/dV (main stream).  Measured (same box, alternating
         # runs): 80.3 k -> 79.6 k interactions/s, the union of the attention intervals unchanged at 1.10-1.14 ms/step -- the two
         # kernels share the same vector-memory pipeline and simply slow each other down.  OFF by default.
