@@ -297,7 +297,7 @@ def test_graph_replay_equals_eager_device_state_step():
     from segmminterest_amd.synth import make_batch
     from segmminterest_amd.trainer import Trainer, default_args, init_model
     dev = torch.device("cuda:0")
-    B, S, Lt, D, N, h = 64, 20, 10, 64, 2, 4
+    B, S, Lt, D, N, h = 64, 40, 10, 64, 3, 4          # S = 40: the fp16x3 attention backward with planes-only gradients + repair pass; N = 3: user queries too
     margs = default_args(num_layers_enc=N, d_model=D, nhead=h, input_type={"user": "image", "photo": "image"}, exposure_prob=[1.0] * S)
     batches = [{k: v.to(dev) for k, v in make_batch(B, S, Lt, D, seed=100 + i).items()} for i in range(4)]
     T = 12
