@@ -625,6 +625,7 @@ class Trainer:
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             self._static_out = self.train_step(self._static)
+        self.opt.step_count -= 1          # the captured call ran the host bookkeeping of a step that was recorded, not executed
         self._graph = g
         return self._static_out
 

@@ -317,6 +317,7 @@ def test_graph_replay_equals_eager_device_state_step():
             losses.append(float(out["loss"].detach()))
         torch.cuda.synchronize()
         seed, step, bc = H.step_get()
+        assert tr.opt.step_count == step          # the host's count (checkpoints) follows the device's
         return model._store.flat.detach().clone(), losses, step, seed
 
     p_eager, l_eager, step_e, seed_e = run(False)
