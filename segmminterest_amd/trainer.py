@@ -167,6 +167,9 @@ class FusedAdamW:
         self.step_count = max(steps) if steps else 0
         g = sd["param_groups"][0]
         self.lr, self.wd, self.betas, self.eps = g["lr"], g["weight_decay"], tuple(g["betas"]), g["eps"]
+        if self.__dict__.get("device_state", False):          # the device-side step count (bias corrections) follows the checkpoint
+            seed, _, _ = H.step_get()
+            H.step_set(seed, self.step_count, *self.betas)
 
 
 # ------------------------------------------------------------------------------------------------ communication

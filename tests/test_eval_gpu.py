@@ -326,3 +326,36 @@ def test_graph_replay_equals_eager_device_state_step():
     assert l_eager == l_graph
     assert torch.equal(p_eager, p_graph)
     assert len(set(l_eager)) > 1          # the steps really differ (new masks, new batches)
+
+
+@pytest.mark.gpu
+def test_device_state_optimizer_resumes_from_checkpoint():
+    """FusedAdamW.load_state_dict in device_state mode puts the checkpoint's step count into the device-side step state (its
+    bias corrections are what segmm_adamw(step = -1) uses): a trainer restored after 3 steps takes the same 4th step."""
+    import torch
+    from segmminterest_amd import hipabi as H
+    from segmminterest_amd.synth import make_batch
+    from segmminterest_amd.trainer import Trainer, default_args, init_model
+    dev = torch.device("cuda:0")
+    B, S, Lt, D = 16, 20, 6, 32
+    margs = default_args(num_layers_enc=2, d_model=D, nhead=4, input_type={"user": "image", "photo": "image"}, exposure_prob=[1.0] * S)
+    batch = {k: v.to(dev) for k, v in make_batch(B, S, Lt, D, seed=5).items()}
+    torch.manual_seed(1)
+    model = init_model(margs, n_users=5, n_items=5, input_dim=D, max_vid_len=S, max_usr_len=Lt).to(dev)
+    tr = Trainer(model, dropout=False, device_state=True)
+    for _ in range(3):
+        tr.train_step(batch)
+    sd_m = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    sd_o = tr.opt.state_dict()
+    tr.train_step(batch)
+    want = model._store.flat.detach().clone()
+    torch.manual_seed(1)
+    model2 = init_model(margs, n_users=5, n_items=5, input_dim=D, max_vid_len=S, max_usr_len=Lt).to(dev)
+    tr2 = Trainer(model2, dropout=False, device_state=True)          # resets the device state to step 0 ...
+    model2.load_state_dict(sd_m)
+    tr2.opt.load_state_dict(sd_o)                                     # ... and this puts it at step 3
+    assert H.step_get()[1] == 3
+    tr2.train_step(batch)
+    assert H.step_get()[1] == 4
+    got = model2._store.flat.detach()
+    assert float((got - want).abs().max()) <= 1e-6 * max(1.0, float(want.abs().max()))
