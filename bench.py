@@ -458,7 +458,7 @@ def main():
                 for key, (n, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
                     f.write(" ".join(str(x) for x in key) + " %.1f %.1f %.4f\n" % (n / psteps, 1e3 * ms / n, ms / psteps))
         if aprof:
-            att_w = {"fwd": 4.0, "bwd": 14.0, "bwd1": 0.0, "bwd2": 6.0, "bwd3": 8.0, "bwd4": 10.0}      # fused: S and dP computed once
+            att_w = {"fwd": 4.0, "bwd": 14.0, "bwd1": 0.0, "bwd2": 6.0, "bwd3": 8.0, "bwd4": 10.0, "bwd4r": 0.0}      # fused: S and dP computed once; repair launches: no work
             att_flops = sum(att_w[k] * dh_ * Lq_ * (La_ + Lb_) * B_ * H_ for (k, B_, H_, dh_, Lq_, La_, Lb_, _, _) in aprof)
             abase = aprof[0][7]
             att_ms = union_ms((abase.elapsed_time(e0), abase.elapsed_time(e1)) for (*_, e0, e1) in aprof)
@@ -467,16 +467,23 @@ def main():
             rec["roofline_attention"] = {"bound": "mfma", "kernel": hipabi.attn_kernel_name(), "achieved": round(att_tf, 2), "peak": round(apeak, 1),
                                          "unit": "TFLOP/s", "frac": round(att_tf / apeak, 4), "ms_per_step": round(att_ms / psteps, 4),
                                          "note": "unpadded algorithmic FLOPs (4 dh Lq T forward + 10 dh Lq T backward per (b, head)) / union of the "
-                                                 "attention launches' HIP-event intervals"}
+                                                 "attention launches' HIP-event intervals; peak = the exact-fp32 MFMA's (the backward's fp16x3 "
+                                                 "products have a 5x higher bound). A head is 69 KB of operands for 5 MFLOP: NEITHER matrix-core "
+                                                 "bound is the binding one for these kernels -- `hbm` below is the tighter bound, and the kernels "
+                                                 "sit at a third of it because they are latency-bound chains at 3-4 waves per SIMD (DESIGN.md §9)"}
             # the same launches against HBM: a head is 69 KB of operands for 5 MFLOP, so the tensors' one-pass bytes bound the kernels too
             pl = 2.0 if engine == "f16x3p" else 1.0          # outputs written as fp32 + P32 planes
+            # a repair launch in the list = the backward wrote its gradients as planes ONLY (4 B per element, like fp32 alone)
+            pl_b = 1.0 if any(k == "bwd4r" for (k, *_r) in aprof) else pl
             att_bytes, ok = 0.0, True
             for (k, B_, H_, dh_, Lq_, La_, Lb_, _, _) in aprof:
                 eq, ea, eb = 4.0 * B_ * Lq_ * H_ * dh_, 4.0 * B_ * La_ * H_ * dh_, 4.0 * B_ * Lb_ * H_ * dh_
                 if k == "fwd":
                     att_bytes += 2 * eq + 2 * ea + 2 * eb + pl * eq                  # Qa Qb | Ka Va | Kb Vb -> O
                 elif k == "bwd4":
-                    att_bytes += (2 * eq + 2 * ea + 2 * eb + 2 * 2 * eq) + pl * (2 * eq + 2 * ea + 2 * eb)      # + O, dO per key block -> dQ dK dV
+                    att_bytes += (2 * eq + 2 * ea + 2 * eb + 2 * 2 * eq) + pl_b * (2 * eq + 2 * ea + 2 * eb)      # + O, dO per key block -> dQ dK dV
+                elif k == "bwd4r":
+                    continue
                 else:
                     ok = False
             if ok and att_ms > 0:
@@ -484,7 +491,8 @@ def main():
                 rec["roofline_attention"]["hbm"] = {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
                                                     "algorithmic_bytes_per_step": round(att_bytes / psteps),
                                                     "note": "one pass over Q, K, V (O, dO per key block in the backward) and over every output "
-                                                            "(fp32 + planes); the tighter of the two bounds at these shapes"}
+                                                            "(forward: fp32 + planes; backward: planes only when the repair protocol is on); "
+                                                            "the tighter of the two bounds at these shapes"}
         gat = [(nb, e0.elapsed_time(e1)) for (name, nb, e0, e1) in kprof if name == "gather_l1"]
         if gat:
             gb = sum(nb for nb, _ in gat) / 1e9

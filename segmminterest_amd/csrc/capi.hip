@@ -129,7 +129,8 @@ static int attn_launch_bwd(AttnArgs& a, int phase, hipStream_t s) {
         LAUNCH_CHECK();
         return 0;
     }
-    if (phase == 4) {          // fused dQ + dK + dV: one workgroup per (b, h, key block); forms D = rowsum(dO * O) itself
+    if (phase >= 4) {          // fused dQ + dK + dV: one workgroup per (b, h, key block); forms D = rowsum(dO * O) itself
+                               // (5 / 6: key block a / b only -- the two launches are independent and may run on two streams)
         const int nta = ((a.La + 15) & ~15) >> 4, ntb = ((a.Lb + 15) & ~15) >> 4;
         // LDS is sized for one chunk of the query side: 48 rows, or 16 / 32 when all queries fit (fp32 kernel only)
         const int Lq_small = a.Lq <= 16 ? 16 : a.Lq <= 32 ? 32 : ATT_FUSED_QCHUNK;
@@ -143,6 +144,7 @@ static int attn_launch_bwd(AttnArgs& a, int phase, hipStream_t s) {
             // fmode 2 (default): one launch per key block with its exact wave count -- 539-549 us at config 2;
             // fmode 1: ONE launch for both key blocks (workgroups of 64 * max(nta, ntb) threads, surplus waves end at once) -- 680 us
             if (fmode == 1 && blk == 1) break;
+            if (fmode != 1 && phase >= 5 && blk != phase - 5) continue;
             const int nw = fmode == 1 ? nmax : (blk == 0 ? nta : ntb);
             if (nw == 0) continue;
             a.hpb = fmode == 1 ? 2 : blk;
@@ -818,7 +820,7 @@ int segmm_attn_bwd(int B, int H, int dh, int Lq, int La, int Lb, const float* Qa
                    const float* dO, int lddo, float* Dvec, float* dQa, float* dQb, int lddq, float* dKa, float* dVa, int lddka,
                    float* dKb, float* dVb, int lddkb, float drop_p, uint64_t seed, uint32_t site,
                    float* amax_q, float* amax_ka, float* amax_kb, int phase, const segmm_attn_planes_t* pl, segmm_stream_t stream) {
-    SEGMM_REQUIRE(phase >= 0 && phase <= 4, "attn_bwd: phase %d (0 all, 1 D, 2 dQ, 3 dK/dV, 4 fused dQ+dK+dV)", phase);
+    SEGMM_REQUIRE(phase >= 0 && phase <= 6, "attn_bwd: phase %d (0 all, 1 D, 2 dQ, 3 dK/dV, 4 fused dQ+dK+dV, 5 / 6 fused, key block a / b only)", phase);
     AttnArgs a;
     memset(&a, 0, sizeof(a));
     int rc = attn_fill(a, B, H, dh, Lq, La, Lb, Qa, Qb, ldq, Ka, Va, ldka, Kb, Vb, ldkb, mq, mka, mkb, drop_p, seed, site);
@@ -834,7 +836,7 @@ int segmm_attn_bwd(int B, int H, int dh, int Lq, int La, int Lb, const float* Qa
     a.do_bytes = (uint32_t)((((size_t)B * Lq - 1) * lddo + (size_t)H * dh) * 4);
     a.dQa = dQa; a.dQb = dQb; a.lddq = lddq; a.dKa = dKa; a.dVa = dVa; a.lddka = lddka; a.dKb = dKb; a.dVb = dVb; a.lddkb = lddkb;
     a.amax_q = amax_q; a.amax_ka = amax_ka; a.amax_kb = amax_kb;
-    if (pl && phase == 4 && (pl->dqa || pl->dqb || pl->dka || pl->dkb)) {          // plane outputs: fused backward only
+    if (pl && phase >= 4 && (pl->dqa || pl->dqb || pl->dka || pl->dkb)) {          // plane outputs: fused backward only
         SEGMM_REQUIRE(pl->lddq2 % 64 == 0 && pl->lddka2 % 64 == 0 && pl->lddkb2 % 64 == 0, "attn_bwd: plane strides %% 64");
         SEGMM_REQUIRE((!(pl->dqa || pl->dqb) || pl->hdr_q) && (!pl->dka || (pl->dva && pl->hdr_ka)) && (!pl->dkb || (pl->dvb && pl->hdr_kb)),
                       "attn_bwd: plane outputs need their headers (and dK and dV planes come in pairs)");

@@ -150,6 +150,7 @@ class ParamStore:
         self.tail_balance = os.environ.get("SEGMM_TAIL_BALANCE", "1") != "0"
         self.attn_planes_only = int(os.environ.get("SEGMM_ATTN_PLANES_ONLY", "1"))
         self.head_side = os.environ.get("SEGMM_HEAD_SIDE", "1") != "0"
+        self.attn_two_streams = os.environ.get("SEGMM_ATTN_TWO_STREAMS", "0") == "1"
         # attention backward as D-kernel, then dQ (third stream) next to dK/dV (main stream).  Measured (same box, alternating
         # runs): 80.3 k -> 79.6 k interactions/s, the union of the attention intervals unchanged at 1.10-1.14 ms/step -- the two
         # kernels share the same vector-memory pipeline and simply slow each other down.  OFF by default.
@@ -823,6 +824,15 @@ def _attn_bwd(store, *args, **kw):
     if store.attn_fused and max((La_ + 15) // 16, (Lb_ + 15) // 16) <= 12:
         # dQ + dK + dV in ONE kernel per key block: one workgroup per (b, h, block) with the query side staged in LDS and
         # D = rowsum(dO * O) formed during the staging (attention.h: attn_bwd_fused_kernel); 848 -> ~540 us at config 2
+        pl = kw.get("planes")
+        if store.attn_two_streams and store.overlap and La_ > 0 and Lb_ > 0 and not (pl is not None and (pl.flags & H.ATTN_REPAIR)):
+            # the two key blocks' launches are independent (disjoint outputs; shared maxima slots are integer atomic maxima):
+            # block a (the shorter one at config 2) on the side stream, block b on the main stream
+            with side_work(store):
+                H.attn_bwd(*args, phase=5, **kw)
+            H.attn_bwd(*args, phase=6, **kw)
+            join_side(store)
+            return
         H.attn_bwd(*args, phase=4, **kw)
         return
     if not (store.overlap and store.attn_split):

@@ -165,8 +165,9 @@ def attn_peak_tflops():
 
 
 def attn_kernel_name():
-    return ("attn_fwd + attn_bwd_fused (v_mfma_f32_16x16x4_f32, exact fp32; backward = dQ + dK + dV in one kernel per key block, "
-            "S and dP computed once: 10 dh Lq T FLOP instead of 14)")
+    return ("attn_fwd (v_mfma_f32_16x16x4_f32, exact fp32 products) + attn_bwd_fused16 / attn_bwd_fused (dQ + dK + dV in one kernel per key "
+            "block, S and dP computed once: 10 dh Lq T FLOP instead of 14; fp16x3 products -- 3 x v_mfma_f32_16x16x16_f16 -- for single-chunk "
+            "launches with more than 32 queries, exact fp32 products otherwise)")
 ENGINE_F32, ENGINE_BF16X6, ENGINE_F16X3, ENGINE_F16X3P = 0, 1, 2, 3
 # default engine of gemm(): the scaled two-term fp16 split on the fp16 matrix cores (22-bit operands, three exact
 # partial products, fp32 accumulation: measured error vs fp64 at or below the f32-MFMA kernel's on every layout).
@@ -527,7 +528,10 @@ def attn_bwd(B, H, dh, Lq, La, Lb, Qa, Qb, ldq, Ka, Va, ldka, Kb, Vb, ldkb, mq, 
     if prof is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        prof.append(("bwd" if phase == 0 else "bwd%d" % phase, B, H, dh, Lq, La, Lb, e0, e1))
+        repair = planes is not None and (planes.flags & ATTN_REPAIR)
+        kind = "bwd" if phase == 0 else "bwd4r" if repair else "bwd4" if phase >= 4 else "bwd%d" % phase
+        # (phase 5 / 6 = one key block of the fused backward: its FLOPs are the block's; a repair launch does no work normally)
+        prof.append((kind, B, H, dh, Lq, 0 if phase == 6 else La, 0 if phase == 5 else Lb, e0, e1))
 
 
 ARGSORT_MAX = 8192
