@@ -167,7 +167,8 @@ int segmm_colsum(const float* X, int ld, const float* w, int64_t M, int N, float
  * 1 = Dvec = rowsum(dO * O) only; 2 = dQa/dQb only (Dvec not written); 3 = dKa/dVa/dKb/dVb only (reads Dvec) -- phases 2
  * and 3 are independent once phase 1 is complete and may run concurrently on two streams; 4 = dQ, dK and dV in ONE kernel
  * (one workgroup per (b, h, key block), query side staged in LDS in chunks of 48 rows, D formed inside -- Dvec is not
- * used; <= 12 key tiles per block). */
+ * used; <= 12 key tiles per block); 5 / 6 = the same kernel for key block a / b only (the two launches of phase 4 are
+ * independent: disjoint outputs, shared maxima slots are integer atomic maxima -- they may run on two streams). */
 /* optional plane outputs of the attention kernels (see "PLANE OUTPUTS of producers"): the forward's O; in the fused backward
  * (phase 4) the query-side gradients dQa / dQb (one site: they are columns of the same buffer) and the key-side gradients
  * of block a (dKa, dVa) and block b (dKb, dVb).  Each plane pointer addresses the same column slice as its fp32 twin. */
