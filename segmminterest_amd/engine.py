@@ -713,6 +713,13 @@ def finish_act(store, act):
     return act
 
 
+def _needs_f32(act, what):
+    """A launch is about to read ``act.t``: refuse if its producers wrote planes only (engine._layer_bwd, planes-only protocol)."""
+    if getattr(act, "no_f32", False):
+        raise RuntimeError("%s reads the fp32 copy of an operand whose producers wrote planes only (set SEGMM_ATTN_PLANES_ONLY=0 "
+                           "together with SEGMM_FEW_TILES / a non-plane GEMM engine)" % what)
+
+
 def _wgrad(store, dY, y_off, X, x_off, Mrows, n_out, n_in, gW, accumulate=False, gb=None):
     """gW[n_out, n_in] (+)= dY[:, y_off:y_off+n_out]^T . X[:, x_off:x_off+n_in]  (split-K over tokens); dY, X: Act.
     ``gb``: the bias gradient [n_out] = column sums of the same dY columns -- formed inside the weight-gradient kernel on the
@@ -723,6 +730,7 @@ def _wgrad(store, dY, y_off, X, x_off, Mrows, n_out, n_in, gW, accumulate=False,
         H.gemm_p(H.LAYOUT_TN, n_out, n_in, Mrows, dY.pt(y_off, n_out), X.pt(x_off, n_in), gW, n_in, splits=splits, workspace=ws,
                  accumulate=accumulate, colsum_out=gb)
         return
+    _needs_f32(dY, "the on-the-fly weight-gradient GEMM")
     if gb is not None:
         _colsum(store, dY.t, dY.cols, Mrows, n_out, gb, x_off=y_off, accumulate=accumulate)
     splits = _splits_for(n_out, n_in, Mrows)
@@ -769,6 +777,8 @@ def _lin_dgrad(store, M, n_in, n_out, dY, wname, out, c_act=None, **kw):
     """out[M,n_in] = dY[M,n_out] . W[n_out,n_in] (+ epilogue); dY: Act.  With W^T planes this is the NT form (both operands
     k-contiguous), otherwise the NN layout on the fp32 weights."""
     wT = store.wTpt.get(wname) if store.engine_p else None
+    if not (wT is not None and dY.planes is not None and not _few_tiles(M, n_in)):
+        _needs_f32(dY, "the on-the-fly input-gradient GEMM")
     if wT is not None and dY.planes is not None and _few_tiles(M, n_in):
         H.gemm(H.LAYOUT_NN, M, n_in, n_out, dY.t, n_out, store.p(wname), n_in, out, n_in, a_amax=dY.slots, b_amax=wT.hdr[H.SITE_HDR:],
                c_amax=None if c_act is None else c_act.slots, **kw)
