@@ -28,7 +28,9 @@ const char* segmm_last_error(void);
 int segmm_abi_version(void);
 
 /* a1 -- trainer L1 normalisation  x / (sum|x| + 1e-6)  (main_for_seq_leave_earlystop_SegMM.py:272-273).
- * y may be NULL: then only inv_scale[row] = 1/(sum|x|+1e-6) is produced, for the fused a1+a2 GEMM (row_scale).
+ * y may be NULL: then only inv_scale[row] = 1/(sum|x|+1e-6) is produced, for the fused a1+a2 GEMM (row_scale) -- or, with a
+ * plane output, the normalised rows are written as planes only (|y| <= 1: with *scale_in = 2^14 the planes can neither overflow
+ * nor fall below the fp16 window, so their consumers need no fp32 copy to fall back on).
  * amax: optional zeroed [SEGMM_AMAX_SLOTS] array receiving the partial maxima of |y| (see segmm_gemm_h). */
 int segmm_l1norm(const float* x, float* y, float* inv_scale, int64_t rows, int D, float* amax, uint16_t* planes, int ld2, float* hdr,
                  const float* scale_in, segmm_stream_t stream);

@@ -313,7 +313,7 @@ static PlaneOut plane_out(uint16_t* planes, int ld2, float* hdr, const float* sc
 int segmm_l1norm(const float* x, float* y, float* inv_scale, int64_t rows, int D, float* amax, uint16_t* planes, int ld2, float* hdr,
                  const float* scale_in, segmm_stream_t stream) {
     PLANE_OUT_CHECK("l1norm", D);
-    SEGMM_REQUIRE(x && (y || inv_scale), "l1norm: null pointer");
+    SEGMM_REQUIRE(x && (y || inv_scale || (planes && scale_in)), "l1norm: null pointer");
     SEGMM_REQUIRE(D > 0 && D % 4 == 0 && aligned16(x) && (!y || aligned16(y)), "l1norm: D %% 4 / alignment (D=%d)", D);
     if (rows <= 0) return 0;
     const int wpb = 4;

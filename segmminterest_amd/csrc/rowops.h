@@ -25,14 +25,14 @@ __global__ __launch_bounds__(256) void l1norm_kernel(const float* __restrict__ x
     s = wave_sum(s);
     const float inv = 1.0f / (s + 1e-6f);
     if (inv_scale && lane == 0) inv_scale[row] = inv;
-    if (y) {
+    const float ps = plane_scale(po);
+    if (y || ps > 0.f) {          // y == null with a plane output: the normalised rows are written as planes ONLY
         const float den = s + 1e-6f;
-        const float ps = plane_scale(po);
         float am = 0.f;
         for (int c = lane * 4; c < D; c += 256) {
             f32x4 v = *(const f32x4*)(xr + c);
             v.x /= den; v.y /= den; v.z /= den; v.w /= den;
-            *(f32x4*)(y + row * D + c) = v;
+            if (y) *(f32x4*)(y + row * D + c) = v;
             if (ps > 0.f) plane_store4_pair(po.p, po.ld2, row, c, v, ps);
             am = absmax4(am, v);
         }

@@ -150,6 +150,7 @@ class ParamStore:
         self.tail_balance = os.environ.get("SEGMM_TAIL_BALANCE", "1") != "0"
         self.attn_planes_only = int(os.environ.get("SEGMM_ATTN_PLANES_ONLY", "1"))
         self.head_side = os.environ.get("SEGMM_HEAD_SIDE", "1") != "0"
+        self.input_planes_only = os.environ.get("SEGMM_INPUT_PLANES_ONLY", "1") != "0"
         self.attn_two_streams = os.environ.get("SEGMM_ATTN_TWO_STREAMS", "0") == "1"
         # attention backward as D-kernel, then dQ (third stream) next to dK/dV (main stream).  Measured (same box, alternating
         # runs): 80.3 k -> 79.6 k interactions/s, the union of the attention intervals unchanged at 1.10-1.14 ms/step -- the two
@@ -267,6 +268,14 @@ class ParamStore:
         if t is None:
             t = c[key] = torch.arange(n, device=self.flat.device, dtype=dtype)
         return t
+
+    def const_f32(self, value: float) -> torch.Tensor:
+        """A device scalar holding ``value``, made once (a fixed plane scale)."""
+        c = self.__dict__.setdefault("_consts", {})
+        key = ("f32", float(value), self.flat.device)
+        if key not in c:
+            c[key] = torch.full((1,), float(value), dtype=torch.float32, device=self.flat.device)
+        return c[key]
 
     def const_ones(self, shape, dtype) -> torch.Tensor:
         c = self.__dict__.setdefault("_consts", {})
@@ -731,6 +740,7 @@ def _wgrad(store, dY, y_off, X, x_off, Mrows, n_out, n_in, gW, accumulate=False,
                  accumulate=accumulate, colsum_out=gb)
         return
     _needs_f32(dY, "the on-the-fly weight-gradient GEMM")
+    _needs_f32(X, "the on-the-fly weight-gradient GEMM")
     if gb is not None:
         _colsum(store, dY.t, dY.cols, Mrows, n_out, gb, x_off=y_off, accumulate=accumulate)
     splits = _splits_for(n_out, n_in, Mrows)
@@ -754,6 +764,8 @@ def _lin_fwd(store, M, N, K, X, wname, out, ldo, c_act=None, **kw):
     """out[M,N] = X[M,K] . W[N,K]^T (+ epilogue); X: Act; W = the parameter (or fused group starting at) ``wname``;
     ``c_act``: the Act that ``out`` belongs to (receives the partial maxima of |out|)."""
     w = store.wpt.get(wname) if store.engine_p else None
+    if not (w is not None and X.planes is not None and not _few_tiles(M, N)):
+        _needs_f32(X, "the on-the-fly forward GEMM")
     if w is not None and X.planes is not None and _few_tiles(M, N):
         # a handful of 256 x 256 tiles would leave most of the 256 CUs idle (config 3: 1024 user tokens): the 128 x 128
         # on-the-fly kernel has 4x the workgroups; it takes the fp32 operands and the same partial maxima

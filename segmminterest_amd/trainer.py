@@ -421,7 +421,7 @@ class Trainer:
                 return bb.usr_proj.num_embeddings - 1
         return None
 
-    def _input_act(self, key, buf):
+    def _input_act(self, key, buf, planes_only=False):
         """Site header (+ planes, + plane output for the producer kernel) of an input feature tensor the trainer itself
         produces this step (L1 normalisation or table gather).  The Act travels WITH the tensor object (attribute
         ``_segmm_act``), never keyed by its device address: a tensor the trainer did not produce in this step (rand_like for
@@ -446,6 +446,11 @@ class Trainer:
             delayed = (self.model.training and st.scaling != "exact") or st.scaling == "always"
             act.scale_ptr = st.scale_ptr("in." + key, delayed)
             if act.scale_ptr is not None:
+                if planes_only and st.input_planes_only:
+                    # L1-normalised rows: 1/cols <= max |y| <= 1.  With the FIXED scale 2^14 the planes can neither overflow nor
+                    # fall below the fp16 window, whatever the batch: no fp32 copy is written and the consumers get none
+                    act.scale_ptr = st.const_f32(16384.0).data_ptr()
+                    act.no_f32 = True
                 act.po = H.PO(planes, 2 * cols, act.hdr, act.scale_ptr)
         buf._segmm_act = act
         return act
@@ -456,10 +461,12 @@ class Trainer:
         buf = self._norm.get(bk)
         if buf is None or buf.shape != x.shape or buf.device != x.device:
             buf = self._norm[bk] = torch.empty_like(x)
-        act = self._input_act(key, buf)
+        act = self._input_act(key, buf, planes_only=True)
         # the GEMM that reads ``buf`` needs max|buf| (and, on the plane engine, its fp16 planes): both are folded into this
-        # kernel instead of separate passes over the features
-        H.l1norm(x, buf, amax=None if act is None else act.slots, po=None if act is None else act.po)
+        # kernel instead of separate passes over the features.  Planes only (training steps after the first): ``buf`` is then
+        # just the handle that carries the Act -- its fp32 contents are NOT written
+        only = act is not None and act.no_f32
+        H.l1norm(x, None if only else buf, amax=None if act is None else act.slots, po=None if act is None else act.po)
         if act is not None:
             E.produced(act)
         return buf

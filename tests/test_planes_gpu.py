@@ -594,3 +594,43 @@ def test_attention_backward_planes_only_repair_pass(factor):
     for k, ref in grads[0].items():
         sc = max(float(ref.abs().max()), 1e-9)
         assert float((grads[1][k] - ref).abs().max()) <= 2e-6 * sc + 1e-12, k
+
+
+def test_input_features_as_planes_only():
+    """Training steps after the first write the L1-normalised input features as planes ONLY, with the fixed scale 2^14 (rows are
+    L1-normalised: 1/D <= max <= 1, so neither overflow nor the lower window edge is reachable) -- no fp32 copy, no fallback for
+    the consumers (trainer.Trainer._input_act).  Twins with and without the mode must train alike, and a batch with one-hot and
+    all-zero feature rows (the extremes of the range) must stay finite and uncounted."""
+    from segmminterest_amd import hipabi as H
+    from segmminterest_amd.synth import make_batch
+    from segmminterest_amd.trainer import Trainer, default_args, init_model
+    if H.GEMM_ENGINE != H.ENGINE_F16X3P:
+        pytest.skip("plane engine only")
+    B, S, Lt, D, N = 16, 20, 10, 64, 2
+    margs = default_args(num_layers_enc=N, d_model=D, nhead=4, input_type={"user": "image", "photo": "image"}, exposure_prob=[1.0] * S)
+    batches = [{k: v.cuda() for k, v in make_batch(B, S, Lt, D, seed=90 + i).items()} for i in range(3)]
+    with torch.no_grad():          # extremes: a one-hot row (max = 1 after normalisation) and an all-zero row
+        batches[2]["photo"][0, 0].zero_()
+        batches[2]["photo"][0, 0, 5] = 3.0
+        batches[2]["photo"][1, 1].zero_()
+        batches[2]["user"][2, 0].zero_()
+        batches[2]["user"][2, 0, 7] = -2.0
+    res = []
+    for only in (True, False):
+        torch.manual_seed(21)
+        model = init_model(margs, n_users=1, n_items=1, input_dim=D, max_vid_len=S, max_usr_len=Lt).cuda()
+        tr = Trainer(model, dropout=False, lr=0.0, weight_decay=0.0)          # lr 0: the twins keep identical parameters
+        st = model._store
+        st.scaling = "always"
+        st.input_planes_only = only
+        losses = [float(tr.train_step(batches[i % 3])["loss"].detach()) for i in range(6)]
+        torch.cuda.synchronize()
+        res.append((losses, st.gflat.detach().clone(), st.overflow_count()))
+        if only:          # the mode was really on: the last step's input Acts carry no fp32 copy and the fixed scale
+            act = tr._norm[("photo", tr._slot)]._segmm_act
+            assert act.no_f32 and float(act.hdr[0]) == 16384.0 and float(act.hdr[1]) == 0.0
+    (l1, p1, o1), (l0, p0, o0) = res
+    assert o1 == 0 and o0 == 0
+    assert all(abs(a - b) <= 1e-5 * max(1.0, abs(b)) for a, b in zip(l1, l0)), (l1, l0)
+    assert float((p1 - p0).abs().max()) <= 2e-6 * float(p0.abs().max())          # gradients of the last step (extreme rows in it)
+    assert torch.isfinite(p1).all()
