@@ -1,3 +1,5 @@
+"""Reproducer of the store-data hazard (gemm_planes8.h buf_store4): the NT plane GEMM's plain-store epilogue on a small shape,
+row by row against fp64 -- without the explicit wait states rows 12-15 of a tile carry the NEXT float4's .y/.w."""
 import os, sys, torch
 sys.path.insert(0, os.getcwd())
 from segmminterest_amd import hipabi as H

@@ -1,3 +1,4 @@
+"""Development aid: window exits per site of the MLP-variant encoders (SelfMLP / CrossMLP) over a short run."""
 import os, sys, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch

@@ -1,3 +1,4 @@
+"""Development aid: small TN plane GEMMs (split-K, column sums) against fp64, element-wise error map."""
 import sys, torch
 sys.path.insert(0, "/root/repo")
 from segmminterest_amd import hipabi as H
