@@ -86,7 +86,7 @@ __device__ __forceinline__ float frag_absmax(const float (&f)[N]) {
 
 // ------------------------------------------------------------------------------------------ backward: fused dQ + dK + dV
 template <int DH, int NW, bool ONE>
-__global__ __launch_bounds__(64 * NW, 4) void attn_bwd_fused16_kernel(const AttnArgs p) {
+__global__ __launch_bounds__(64 * NW, NW <= 4 ? 3 : 4) void attn_bwd_fused16_kernel(const AttnArgs p) {
     using C = AttnCfg<DH>;
     const DropCfg drop_ = drop_live(p.drop);
     static_assert(DH % 16 == 0, "fp16 attention: head dim must be a multiple of 16");
@@ -102,9 +102,15 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_bwd_fused16_kernel(const Attn
     const int wg = xcd_remap(blockIdx.x, gridDim.x), bh = p.hpb == 2 ? wg >> 1 : wg, b = bh / p.H, h = bh % p.H;
     const bool isa = p.hpb == 2 ? (wg & 1) == 0 : p.hpb == 0;
     const int La_p = round16(p.La), Lb_p = round16(p.Lb), Tp = La_p + Lb_p, nta = La_p >> 4, ntb = Lb_p >> 4;
-    const int ntk = isa ? nta : ntb;                       // key tiles (= working waves) of the block
-    if (wave >= ntk) return;                               // surplus wave, or empty block (CrossAtt / SelfAtt ablations)
-    const int nthr = 64 * ntk;                             // surviving threads
+    const int ntk = isa ? nta : ntb;                       // key tiles of the block
+    // A wave owns key tile `wave` -- and, in a single-chunk launch with fewer waves than tiles, tiles wave + nwv, wave + 2 nwv ...
+    // one PASS after the other over the same staged query side.  The kernel is bound by the latency of its staging loads, i.e. by
+    // the number of workgroups a CU holds (tools/attn_bench.py with SEGMM_ATT_LDS_PAD: 476 us at 4 + 2 workgroups per CU for the
+    // two key blocks, 700 us at 2 + 1): four-wave workgroups fit four to a CU where the seven-wave ones of a 100-key block fit two.
+    const int nwv = min(ntk, nw);
+    if (wave >= nwv) return;                               // surplus wave, or empty block (CrossAtt / SelfAtt ablations)
+    const int npass = ONE ? (ntk + nwv - 1) / nwv : 1;     // (several chunks: the host launches one wave per tile)
+    const int nthr = 64 * nwv;                             // surviving threads
     const int col0 = h * DH;
     const float* Qg = isa ? p.Qa : p.Qb;
     float* dQg = isa ? p.dQa : p.dQb;
@@ -139,7 +145,7 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_bwd_fused16_kernel(const Attn
     uint8_t* qm = (uint8_t*)(s_Dp + QC * (DH / 4));                         // [QC] 1 valid query, 0 masked, 2 pad
     uint8_t* km = qm + QC;                                                  // [Tp]
     // ---- this wave's key tile
-    const int jt = (isa ? 0 : nta) + wave;                                  // padded key tile of this wave
+    int jt = (isa ? 0 : nta) + wave;                                        // padded key tile of this wave (first pass)
     KeyBlocks<DH> kbk;
     kbk.init(p, b, col0, l15, g);
     HL kfh[NCH], vfh[NCH], kch[C::CT];                                      // split K / V row fragments, K column fragments
@@ -179,15 +185,50 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_bwd_fused16_kernel(const Attn
         km[j] = v;
     }
     const float fscale = p.scale;
-    const int jp = 16 * jt + l15;                          // this lane's key (padded index)
     f32x4 dk[C::CT], dv[C::CT];
 #pragma unroll
     for (int ct = 0; ct < C::CT; ++ct) { dk[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    float am_q = 0.f;
+    float am_q = 0.f, am_k = 0.f;
     float unit_dk = 1.f, unit_dv = 1.f;                    // product of the operand scales the dK / dV accumulators are in
     constexpr float SP = 16384.f;                          // scale of P (<= 1)
     // transposed-read address of this lane inside a (query tile, column tile) block: row 4 g + (l15 >> 2), group (l15 & 3)
     const uint32_t tr_lane = (uint32_t)(4 * g + (l15 >> 2)) * RSB + (uint32_t)(l15 & 3) * 16u;
+
+    // dK / dV rows of the current tile: lane (key l15, g), tile ct register r = head column 16 ct + 4 g + r
+    auto emit_dkdv = [&]() {
+        const int jp = 16 * jt + l15;
+        const float inv_dk = 1.0f / unit_dk, inv_dv = 1.0f / unit_dv;
+#pragma unroll
+        for (int ct = 0; ct < C::CT; ++ct) { dk[ct] *= inv_dk; dv[ct] *= inv_dv; }
+        const bool ka = jp < La_p;
+        const int jloc = ka ? jp : jp - La_p;
+        const bool real = ka ? (jloc < p.La) : (jloc < p.Lb);
+        if (real) {
+            float* dKp = (ka ? p.dKa + (size_t)(b * p.La + jloc) * p.lddka : p.dKb + (size_t)(b * p.Lb + jloc) * p.lddkb) + col0;
+            float* dVp = (ka ? p.dVa + (size_t)(b * p.La + jloc) * p.lddka : p.dVb + (size_t)(b * p.Lb + jloc) * p.lddkb) + col0;
+            const long long krow = ka ? (long long)b * p.La + jloc : (long long)b * p.Lb + jloc;
+            _Float16* dKpp = ka ? p.dKap : p.dKbp;
+            _Float16* dVpp = ka ? p.dVap : p.dVbp;
+            const int ldk2 = ka ? p.lddka2 : p.lddkb2;
+#pragma unroll
+            for (int ct = 0; ct < C::CT; ++ct) {
+                if (f32_k) {
+                    *(f32x4*)(dKp + 16 * ct + 4 * g) = dk[ct];
+                    *(f32x4*)(dVp + 16 * ct + 4 * g) = dv[ct];
+                }
+                if (s_k > 0.f) {          // lane (key, g) and lane (key, g ^ 1) hold the two halves of an aligned 8
+                    if ((col0 & 7) == 0) {
+                        plane_store4_x16(dKpp, ldk2, krow, col0 + 16 * ct + 4 * g, split4(dk[ct], s_k));
+                        plane_store4_x16(dVpp, ldk2, krow, col0 + 16 * ct + 4 * g, split4(dv[ct], s_k));
+                    } else {
+                        plane_store4(dKpp, ldk2, krow, col0 + 16 * ct + 4 * g, dk[ct], s_k);
+                        plane_store4(dVpp, ldk2, krow, col0 + 16 * ct + 4 * g, dv[ct], s_k);
+                    }
+                }
+                am_k = absmax4(absmax4(am_k, dk[ct]), dv[ct]);
+            }
+        }
+    };
 
     for (int q0 = 0; ONE ? q0 < 1 : q0 < p.Lq; q0 += QC) {
         const int nq = min(QC, p.Lq - q0);                 // real queries of the chunk
@@ -222,7 +263,7 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_bwd_fused16_kernel(const Attn
         __syncthreads();
         // chunk maxima -> scales; D; every thread converts its own groups in place
         float mQ = 0.f, mdO = 0.f;
-        for (int w = 0; w < ntk; ++w) { mQ = fmaxf(mQ, s_wm[w]); mdO = fmaxf(mdO, s_wm[12 + w]); }
+        for (int w = 0; w < nwv; ++w) { mQ = fmaxf(mQ, s_wm[w]); mdO = fmaxf(mdO, s_wm[12 + w]); }
         const float sQs = f16_scale_of(mQ), sdOs = f16_scale_of(mdO);
         float mD = 0.f;
         for (int q = threadIdx.x; q < QC; q += nthr) {     // D[q]: the DH/4 partials of the row in index order (deterministic)
@@ -245,7 +286,17 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_bwd_fused16_kernel(const Attn
         }
         __syncthreads();
         float mDc = 0.f;
-        for (int w = 0; w < ntk; ++w) mDc = fmaxf(mDc, s_wm[24 + w]);
+        for (int w = 0; w < nwv; ++w) mDc = fmaxf(mDc, s_wm[24 + w]);
+      for (int pass = 0; pass < npass; ++pass) {
+        const int tile = wave + pass * nwv;                // this wave's tile of the pass, 0 .. ntk-1 (the dQ turn order)
+        if (tile >= ntk) break;
+        if (pass > 0) {                                    // next tile of this wave: its K / V fragments, fresh dK / dV sums
+            jt += nwv;
+            load_frags();
+#pragma unroll
+            for (int ct = 0; ct < C::CT; ++ct) { dk[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        }
+        const int jp = 16 * jt + l15;                      // this lane's key (padded index)
         // |dS| <= P (|dP| + |D|) mult scale, |dP| <= DH max|dO| max|V tile|
         const float sdS = f16_scale_of(((float)DH * mdO * maxV + mDc) * drop_.scale * fscale);
         const float inv_s = 1.0f / (sQs * sK), inv_dp = 1.0f / (sdOs * sV), inv_dq = 1.0f / (sK * sdS);
@@ -253,7 +304,7 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_bwd_fused16_kernel(const Attn
         {   // dK / dV accumulate in the units of the CURRENT chunk's operand scales: moving on to a chunk with other scales
             // multiplies what has been summed so far by the ratio -- a power of two, exact
             const float u_dk = sQs * sdS, u_dv = sdOs * SP;
-            if (!ONE && q0 > 0) {
+            if (!ONE && q0 > 0) {          // (one pass per chunk here)
                 const float rk = u_dk / unit_dk, rv = u_dv / unit_dv;
 #pragma unroll
                 for (int ct = 0; ct < C::CT; ++ct) { dk[ct] *= rk; dv[ct] *= rv; }
@@ -319,8 +370,8 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_bwd_fused16_kernel(const Attn
                 f32x4 dqt[C::CT];
 #pragma unroll
                 for (int ct = 0; ct < C::CT; ++ct) dqt[ct] = mfma_hl(kch[ct], dSTh, f32x4{0.f, 0.f, 0.f, 0.f});
-                if (wave > 0)
-                    while (__hip_atomic_load(s_turn + qt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != wave) __builtin_amdgcn_s_sleep(1);
+                if (tile > 0)
+                    while (__hip_atomic_load(s_turn + qt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != tile) __builtin_amdgcn_s_sleep(1);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 {
                     float* row = sdQ + (16 * qt + l15) * RS + 4 * C::CT * g;
@@ -337,9 +388,11 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_bwd_fused16_kernel(const Attn
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                if (lane == 0) __hip_atomic_store(s_turn + qt, wave + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (lane == 0) __hip_atomic_store(s_turn + qt, tile + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
+        if (ONE) emit_dkdv();                              // this tile is complete
+      }
         __syncthreads();                                   // every wave has added its dQ partials of this chunk
         for (int i = threadIdx.x; i < nq * (DH / 4); i += nthr) {
             const int q = i / (DH / 4), c = (i - q * (DH / 4)) * 4;
@@ -354,40 +407,9 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_bwd_fused16_kernel(const Attn
         }
         if (!ONE && q0 + QC < p.Lq) __syncthreads();       // the next chunk's staging overwrites what was just read
     }
-    // dK / dV rows of this tile: lane (key l15, g), tile ct register r = head column 16 ct + 4 g + r
     {
-        const float inv_dk = 1.0f / unit_dk, inv_dv = 1.0f / unit_dv;
-#pragma unroll
-        for (int ct = 0; ct < C::CT; ++ct) { dk[ct] *= inv_dk; dv[ct] *= inv_dv; }
-        const bool ka = jp < La_p;
-        const int jloc = ka ? jp : jp - La_p;
-        const bool real = ka ? (jloc < p.La) : (jloc < p.Lb);
-        float am = 0.f;
-        if (real) {
-            float* dKp = (ka ? p.dKa + (size_t)(b * p.La + jloc) * p.lddka : p.dKb + (size_t)(b * p.Lb + jloc) * p.lddkb) + col0;
-            float* dVp = (ka ? p.dVa + (size_t)(b * p.La + jloc) * p.lddka : p.dVb + (size_t)(b * p.Lb + jloc) * p.lddkb) + col0;
-            const long long krow = ka ? (long long)b * p.La + jloc : (long long)b * p.Lb + jloc;
-            _Float16* dKpp = ka ? p.dKap : p.dKbp;
-            _Float16* dVpp = ka ? p.dVap : p.dVbp;
-            const int ldk2 = ka ? p.lddka2 : p.lddkb2;
-#pragma unroll
-            for (int ct = 0; ct < C::CT; ++ct) {
-                if (f32_k) {
-                    *(f32x4*)(dKp + 16 * ct + 4 * g) = dk[ct];
-                    *(f32x4*)(dVp + 16 * ct + 4 * g) = dv[ct];
-                }
-                if (s_k > 0.f) {          // lane (key, g) and lane (key, g ^ 1) hold the two halves of an aligned 8
-                    if ((col0 & 7) == 0) {
-                        plane_store4_x16(dKpp, ldk2, krow, col0 + 16 * ct + 4 * g, split4(dk[ct], s_k));
-                        plane_store4_x16(dVpp, ldk2, krow, col0 + 16 * ct + 4 * g, split4(dv[ct], s_k));
-                    } else {
-                        plane_store4(dKpp, ldk2, krow, col0 + 16 * ct + 4 * g, dk[ct], s_k);
-                        plane_store4(dVpp, ldk2, krow, col0 + 16 * ct + 4 * g, dv[ct], s_k);
-                    }
-                }
-                am = absmax4(absmax4(am, dk[ct]), dv[ct]);
-            }
-        }
+        if (!ONE) emit_dkdv();
+        const float am = am_k;
         float* hk = isa ? p.hdr_ka : p.hdr_kb;
         float* slot = isa ? p.amax_ka : p.amax_kb;
         const bool hdr_writer = bh == 0 && wave == 0 && lane == 0;

@@ -152,6 +152,8 @@ static int attn_launch_bwd(AttnArgs& a, int phase, hipStream_t s) {
             const bool one = a.Lq <= ATT_FUSED_QCHUNK;
             Lq_p = ATT_FUSED_QCHUNK;
             size_t lds = ((size_t)3 * Lq_p * (DH + 4) + 3 * Lq_p + (size_t)nw * 16 * 20 + 4 + 36 + (size_t)Lq_p * (DH / 4)) * 4 + Lq_p + Tp;
+            static const int lds_pad = getenv("SEGMM_ATT_LDS_PAD") ? atoi(getenv("SEGMM_ATT_LDS_PAD")) : 0;      // probe: fewer workgroups per CU
+            lds += (size_t)lds_pad;
             if constexpr (DH % 16 == 0 && DH <= 48) {
                 // fp16x3 matrix-core form (attention16.h).  By default only single-chunk launches with more than 32 queries: with
                 // several query chunks the kernel needs more than the 128 registers that keep two 7-wave workgroups on a CU and
@@ -159,10 +161,16 @@ static int attn_launch_bwd(AttnArgs& a, int phase, hipStream_t s) {
                 // the in-place conversion pass costs more than the products save (1.81 vs 1.65 ms of attention per step).
                 // segmm_attn_mode(2) / SEGMM_ATTN=f16all forces it everywhere it is built (parity tests)
                 if (attn_f16() >= ((one && a.Lq > 32) ? 1 : 2)) {
-#define FUSED16(NWV) do { if (one) hipLaunchKernelGGL((attn_bwd_fused16_kernel<DH, NWV, true>), grid, block, lds, s, a); \
-                          else hipLaunchKernelGGL((attn_bwd_fused16_kernel<DH, NWV, false>), grid, block, lds, s, a); } while (0)
-                    if (nw <= 4) FUSED16(4);
-                    else if (nw <= 8) FUSED16(8);
+                    // single chunk: at most `wcap` waves per workgroup, a wave walks its key tiles in passes (attention16.h) --
+                    // the 7 tiles of a 100-key block as 4 waves x 2 passes, four workgroups per CU instead of two
+                    static const int wcap = getenv("SEGMM_ATT_WAVES") ? atoi(getenv("SEGMM_ATT_WAVES")) : 4;
+                    const int nw16 = one && wcap >= 1 && nw > wcap ? wcap : nw;
+                    const dim3 block16(64 * nw16);
+                    const size_t lds16 = lds - (size_t)(nw - nw16) * 16 * 20 * 4;
+#define FUSED16(NWV) do { if (one) hipLaunchKernelGGL((attn_bwd_fused16_kernel<DH, NWV, true>), grid, block16, lds16, s, a); \
+                          else hipLaunchKernelGGL((attn_bwd_fused16_kernel<DH, NWV, false>), grid, block16, lds16, s, a); } while (0)
+                    if (nw16 <= 4) FUSED16(4);
+                    else if (nw16 <= 8) FUSED16(8);
                     else FUSED16(12);
 #undef FUSED16
                     continue;
