@@ -113,9 +113,11 @@ static int attn_launch_fwd(AttnArgs& a, hipStream_t s) {
     attn_shape(nqt, a.H, 5, 1, "SEGMM_ATT_HPB_FWD", wq, hpb);          // measured: grouping heads does not pay in the forward
     a.hpb = hpb;
     dim3 grid(a.B * a.H / hpb, (nqt + wq - 1) / wq), block(64 * wq * hpb);       // one wave per 16-query tile of a head
-    if (Tp <= 64) hipLaunchKernelGGL((attn_fwd_kernel<DH, 4>), grid, block, Tp, s, a);
-    else if (Tp <= 160) hipLaunchKernelGGL((attn_fwd_kernel<DH, 10>), grid, block, Tp, s, a);
-    else hipLaunchKernelGGL((attn_fwd_kernel<DH, 12>), grid, block, Tp, s, a);
+    static const int fpad = getenv("SEGMM_ATT_FWD_LDS_PAD") ? atoi(getenv("SEGMM_ATT_FWD_LDS_PAD")) : 0;      // probe: fewer workgroups per CU
+    const size_t lds = (size_t)Tp + (size_t)fpad;
+    if (Tp <= 64) hipLaunchKernelGGL((attn_fwd_kernel<DH, 4>), grid, block, lds, s, a);
+    else if (Tp <= 160) hipLaunchKernelGGL((attn_fwd_kernel<DH, 10>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<DH, 12>), grid, block, lds, s, a);
     LAUNCH_CHECK();
     return 0;
 }
