@@ -224,7 +224,8 @@ int segmm_rowscale_mat(const float* g, const float* X, int ldx, float* out, int 
 
 /* K2' -- id-mode embeddings (encoder.py:426-435,445,484-486), pre-LayerNorm:
  *   vid[b,s,:] = cat(item_table[item_id[b]], frame_w*pos[b,s] + frame_b) + vid_pe[s];   usr[b,0,:] = user_table[uid[b]] + usr_pe[0]
- *   (frame_pos = null: pos[b,s] = s; the 'noPos' ablation passes per-row shuffled positions [B*S], encoder.py:428-429)
+ *   (frame_pos = null: pos[b,s] = s; the 'noPos' ablation passes per-row shuffled positions [B*S], encoder.py:428-429;
+ *   pe = null: no positional embedding is added -- the trainers' --use_pe 0, encoder.py:450-471 else branches)
  * backward: dense table gradients accumulated deterministically over batch rows grouped by id
  * (order = batch rows sorted by id, from a host-side torch.sort; no data-dependent sizes, no sync),
  * and dpe[s,:] = sum_b dpre[b,s,:].  n_rows = rows of the table: an id outside [0, n_rows) (torch.nn.Embedding raises

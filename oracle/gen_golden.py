@@ -91,7 +91,54 @@ CASES = {
                             loss="interestBPR", ablation="CrossMLP"),
     "abl_woatt_N2": dict(user="image", photo="image", d=32, h=4, N=2, S=40, Lt=10, D_in=48, B=8,
                          loss="interestBPR", ablation="w/oAtt"),
+    # --use_pe 0 (main...SegMM.py:515 -> encoder.py:450-471 else branches): no positional-embedding add, one case per input mode
+    "nope_img_d32_N3": dict(user="image", photo="image", d=32, h=4, N=3, S=40, Lt=10, D_in=48, B=8,
+                            loss="interestBPR", use_pe=0, adam=True),
+    "nope_id_d32_N2": dict(user="id", photo="id", d=32, h=4, N=2, S=40, Lt=1, D_in=0, B=8,
+                           loss="interestBPR", n_users=50, n_items=200, use_pe=0, adam=True),
+    "nope_both_fh2": dict(user="both", photo="both", d=32, h=4, N=2, S=40, Lt=10, D_in=48, B=8,
+                          loss="interestBPR", fusion_heads=2, n_users=50, n_items=200, use_pe=0),
 }
+
+# TRAIN-MODE cases (model.train(): dropout on).  The reference's dropout draws are replaced by recorded deterministic keep-masks
+# (torch.nn.functional.dropout is what every nn.Dropout.forward calls) so that the fixture pins WHERE the reference applies
+# dropout and with which p: encoder.py:145,149 (raw logits, mask fills included, before the 1/sqrt(dh) scale), :166-167,
+# :202,205, :461,471, kn_util/nn_utils/layers/mlp.py:22 (hard-wired 0.1), MLP_Block (:210-252).  Written as train_<name>.npz
+# with the masks in CALL ORDER (mask/<k> packed bits, mask_shape/<k>, mask_p[k]).
+TRAIN_CASES = {
+    "train_img_d32_N3": dict(user="image", photo="image", d=32, h=4, N=3, S=40, Lt=10, D_in=48, B=8,
+                             loss="interestBPR,surviveCE", adam=True),
+    "train_id_d32_N2": dict(user="id", photo="id", d=32, h=4, N=2, S=40, Lt=1, D_in=0, B=8,
+                            loss="interestBPR", n_users=50, n_items=200, adam=True),
+    "train_both_fh2": dict(user="both", photo="both", d=32, h=4, N=2, S=40, Lt=10, D_in=48, B=8,
+                           loss="interestBPR", fusion_heads=2, n_users=50, n_items=200),
+    "train_img_d64_h16_N4_Lt100": dict(user="image", photo="image", d=64, h=16, N=4, S=40, Lt=100, D_in=64, B=4,
+                                       loss="interestBPR"),
+    "train_abl_crossatt_N3": dict(user="image", photo="image", d=32, h=4, N=3, S=40, Lt=10, D_in=48, B=8,
+                                  loss="interestBPR", ablation="CrossAtt"),
+    "train_abl_selfatt_N3": dict(user="image", photo="image", d=32, h=4, N=3, S=40, Lt=10, D_in=48, B=8,
+                                 loss="interestBPR", ablation="SelfAtt"),
+    "train_abl_crossmlp_N5": dict(user="image", photo="image", d=32, h=4, N=5, S=40, Lt=10, D_in=48, B=8,
+                                  loss="interestBPR", ablation="CrossMLP"),
+    "train_nope_img_d32_N2": dict(user="image", photo="image", d=32, h=4, N=2, S=40, Lt=10, D_in=48, B=8,
+                                  loss="interestBPR", use_pe=0),
+}
+
+
+class MaskRecorder:
+    """Stand-in for torch.nn.functional.dropout while the REFERENCE runs in train mode: draws the keep-mask from its own
+    generator, records (p, mask) per call, returns input * mask / (1 - p) -- the definition of inverted dropout."""
+
+    def __init__(self, seed):
+        self.g = torch.Generator().manual_seed(seed)
+        self.calls = []
+
+    def __call__(self, input, p=0.5, training=True, inplace=False):
+        if not training or p == 0.0:
+            return input
+        keep = torch.rand(input.shape, generator=self.g) >= p
+        self.calls.append((float(p), keep))
+        return input * (keep.to(input.dtype) / (1.0 - p))
 
 
 def build_reference_model(c, enc, dec):
@@ -108,7 +155,7 @@ def build_reference_model(c, enc, dec):
                        input_type={"user": c["user"], "photo": c["photo"]},
                        learnable_bias=c.get("learnable_bias", 0), exposure_prob=exposure,
                        fusion_heads=c.get("fusion_heads", 2), loss_type_list=loss_list,
-                       loss_weight=dict(ALL_LOSS_W), mask_loss=c.get("mask_loss", 0), use_pe=1)
+                       loss_weight=dict(ALL_LOSS_W), mask_loss=c.get("mask_loss", 0), use_pe=c.get("use_pe", 1))
     N, d, h = c["N"], c["d"], c["h"]
 
     def backbone(user_id_max, video_id_max, max_usr_len):
@@ -116,7 +163,7 @@ def build_reference_model(c, enc, dec):
                               input_vid_dim=max(c["D_in"], 1), input_usr_dim=max(c["D_in"], 1),
                               max_vid_len=S, max_usr_len=max_usr_len,
                               sr_ratio_lvls=[1] * N, use_patch_merge=[False] * N, output_layers=[-1],
-                              model_cfg=cfg, user_id_max=user_id_max, video_id_max=video_id_max, use_pe=1)
+                              model_cfg=cfg, user_id_max=user_id_max, video_id_max=video_id_max, use_pe=c.get("use_pe", 1))
 
     nu, ni = c.get("n_users", 0), c.get("n_items", 0)
     u, p = c["user"], c["photo"]
@@ -195,16 +242,31 @@ def make_inputs(c, seed):
     return inp
 
 
-def gen_case(name, c, enc, dec, outdir):
+def gen_case(name, c, enc, dec, outdir, train=False):
     torch.manual_seed(abs(hash(name)) % (2 ** 31))
     torch.manual_seed(sum(ord(ch) for ch in name))
     model, cfg = build_reference_model(c, enc, dec)
     perturb(model, seed=11 + len(name))
-    model.eval()
+    rec = None
+    if train:
+        import torch.nn.functional as F
+        model.train()
+        rec = MaskRecorder(seed=77 + len(name))
+        F_dropout, F.dropout = F.dropout, rec
+    else:
+        model.eval()
+    try:
+        _gen_case_body(name, c, cfg, model, outdir, rec)
+    finally:
+        if train:
+            F.dropout = F_dropout
+
+
+def _gen_case_body(name, c, cfg, model, outdir, rec):
     FWD_SEED[0] = c.get("fwd_seed")
     inp = make_inputs(c, seed=1234 + len(name))
     blob = {"cfg": np.array(json.dumps(dict(c, exposure_prob=list(cfg.exposure_prob), loss_weight=cfg.loss_weight,
-                                            ablation_type=cfg.ablation_type)))}
+                                            ablation_type=cfg.ablation_type, train=rec is not None)))}
     for k, v in model.state_dict().items():
         blob["sd/" + k] = v.detach().numpy().copy()
     for k, v in inp.items():
@@ -222,9 +284,12 @@ def gen_case(name, c, enc, dec, outdir):
         else:
             blob["grad/" + k] = p.grad.detach().numpy().copy()
     blob["nograd"] = np.array(json.dumps(nograd))
-    with torch.no_grad():
-        inf = run_model(model, inp, "inference")
-    blob["inf/logits"] = inf["logits"].detach().numpy().copy()
+    if rec is not None:
+        blob["mask_calls_fwd"] = np.array(len(rec.calls))          # dropout calls of ONE training forward
+    else:
+        with torch.no_grad():
+            inf = run_model(model, inp, "inference")
+        blob["inf/logits"] = inf["logits"].detach().numpy().copy()
 
     if c.get("adam"):
         opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-4)
@@ -236,7 +301,13 @@ def gen_case(name, c, enc, dec, outdir):
             if step in (1, 3):
                 for k, p in model.named_parameters():
                     blob["adam%d/%s" % (step, k)] = p.detach().numpy().copy()
-        blob["adam_loss3"] = run_model(model, inp, "train")["loss"].detach().numpy().copy()
+        if rec is None:
+            blob["adam_loss3"] = run_model(model, inp, "train")["loss"].detach().numpy().copy()
+    if rec is not None:
+        blob["mask_p"] = np.array([p for p, _ in rec.calls], dtype=np.float64)
+        for k, (_, keep) in enumerate(rec.calls):
+            blob["mask/%d" % k] = np.packbits(keep.numpy().reshape(-1))
+            blob["mask_shape/%d" % k] = np.array(keep.shape, dtype=np.int64)
     path = os.path.join(outdir, name + ".npz")
     np.savez_compressed(path, **blob)
     nlive = sum(1 for k in blob if k.startswith("grad/"))
@@ -317,6 +388,10 @@ def main():
         if a.only and a.only not in name:
             continue
         gen_case(name, c, enc, dec, a.out)
+    for name, c in TRAIN_CASES.items():
+        if a.only and a.only not in name:
+            continue
+        gen_case(name, c, enc, dec, a.out, train=True)
     if not a.only or a.only == "metrics":
         gen_metrics(ev, a.out)
 

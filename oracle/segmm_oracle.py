@@ -67,6 +67,8 @@ def cross_attention(sd, pre, vid, vid_mask, usr, usr_mask, nhead, need_usr=True,
     Lt = usr.shape[1]
     dh = d // nhead
     do = drop if drop is not None else (lambda t: t)
+    # dropout CALL ORDER of the reference (the train-mode fixtures replay its masks by position, tests/test_oracle_golden.py):
+    # v_logits (:145) -> t_logits (:149) -> ff_usr (:166) -> ff_vid (:167)
     vals, logits = [], []
     if mode != "cross":
         vals.append(_lin(sd, pre + ".v2v_proj.2", vid))
@@ -77,22 +79,30 @@ def cross_attention(sd, pre, vid, vid_mask, usr, usr_mask, nhead, need_usr=True,
     v_val = torch.cat(vals, 1)
     v_val = v_val.view(B, v_val.shape[1], nhead, dh)
     v_logits = do(torch.cat(logits, -1)) / math.sqrt(dh)
-    vid_ = torch.einsum("bhqk,bkhd->bqhd", F.softmax(v_logits, -1), v_val).reshape(B, Lv, d)
-    vid_ = do(_lin(sd, pre + ".ff_vid", vid_))
-    vid_out = _ln(sd, pre + ".ln_vid", vid + vid_)
-    usr_out = None
-    if need_usr and mode != "self":          # SelfAtt: the user branch is computed and thrown away (encoder.py:172-173)
-        vals = [_lin(sd, pre + ".v2t_proj.2", vid)]
-        logits = [attn_logits(sd, pre + ".v2t_proj", vid, vid_mask, usr, usr_mask, nhead)]
-        if mode == "joint":
-            vals.append(_lin(sd, pre + ".t2t_proj.2", usr))
-            logits.append(attn_logits(sd, pre + ".t2t_proj", usr, usr_mask, usr, usr_mask, nhead))
+    # the user branch: under SelfAtt the reference computes it (own-side keys) and throws it away (encoder.py:122-135,172-173)
+    usr_side = need_usr
+    if usr_side:
+        if mode == "self":
+            vals = [_lin(sd, pre + ".t2t_proj.2", usr)]
+            logits = [attn_logits(sd, pre + ".t2t_proj", usr, usr_mask, usr, usr_mask, nhead)]
+        else:
+            vals = [_lin(sd, pre + ".v2t_proj.2", vid)]
+            logits = [attn_logits(sd, pre + ".v2t_proj", vid, vid_mask, usr, usr_mask, nhead)]
+            if mode == "joint":
+                vals.append(_lin(sd, pre + ".t2t_proj.2", usr))
+                logits.append(attn_logits(sd, pre + ".t2t_proj", usr, usr_mask, usr, usr_mask, nhead))
         t_val = torch.cat(vals, 1)
         t_val = t_val.view(B, t_val.shape[1], nhead, dh)
         t_logits = do(torch.cat(logits, -1)) / math.sqrt(dh)
+    vid_ = torch.einsum("bhqk,bkhd->bqhd", F.softmax(v_logits, -1), v_val).reshape(B, Lv, d)
+    usr_out = None
+    if usr_side:
         usr_ = torch.einsum("bhqk,bkhd->bqhd", F.softmax(t_logits, -1), t_val).reshape(B, Lt, d)
         usr_ = do(_lin(sd, pre + ".ff_usr", usr_))
-        usr_out = _ln(sd, pre + ".ln_usr", usr + usr_)
+        if mode != "self":
+            usr_out = _ln(sd, pre + ".ln_usr", usr + usr_)
+    vid_ = do(_lin(sd, pre + ".ff_vid", vid_))
+    vid_out = _ln(sd, pre + ".ln_vid", vid + vid_)
     return vid_out, usr_out
 
 
@@ -113,8 +123,9 @@ def encoder_layer(sd, pre, usr, usr_mask, vid, vid_mask, nhead, need_usr=True, d
     return vid, usr_new
 
 
-def embedding(sd, pre, usr_feat, vid_feat, drop=None, abl="ours"):
-    """SegFormerX._get_embedding with use_pe=1 (encoder.py:425-473).  2-D inputs are id tensors
+def embedding(sd, pre, usr_feat, vid_feat, drop=None, abl="ours", use_pe=1):
+    """SegFormerX._get_embedding (encoder.py:425-473); ``use_pe=0`` (trainer flag --use_pe, main...SegMM.py:515) skips the
+    positional-embedding adds (:450-471 else branches), so vid_pe / usr_pe get no gradient.  2-D inputs are id tensors
     ([B,S] item ids broadcast over segments / [B,1] user id), 3-D inputs are features.  'noPos' in the ablation
     type: the segment positions of every row are a fresh ``torch.randperm`` (global CPU generator, :428-429)."""
     do = drop if drop is not None else (lambda t: t)
@@ -133,8 +144,11 @@ def embedding(sd, pre, usr_feat, vid_feat, drop=None, abl="ours"):
         u = F.embedding(usr_feat, sd[pre + ".usr_proj.weight"])
     else:
         u = _lin(sd, pre + ".usr_proj", usr_feat)
-    v = do(_ln(sd, pre + ".vid_ln", v + sd[pre + ".vid_pe.weight"][None, : v.shape[1]]))
-    u = do(_ln(sd, pre + ".usr_ln", u + sd[pre + ".usr_pe.weight"][None, : u.shape[1]]))
+    if use_pe:
+        v = v + sd[pre + ".vid_pe.weight"][None, : v.shape[1]]
+        u = u + sd[pre + ".usr_pe.weight"][None, : u.shape[1]]
+    v = do(_ln(sd, pre + ".vid_ln", v))          # dropout call order: video (:461), then user (:471)
+    u = do(_ln(sd, pre + ".usr_ln", u))
     return v, u
 
 
@@ -149,7 +163,7 @@ def mlp_block(sd, pre, x, drop=None):
 
 
 def backbone_forward(sd, pre, usr_feat, usr_mask, vid_feat, vid_mask, N, nhead, S,
-                     skip_dead=True, drop=None, abl="ours"):
+                     skip_dead=True, drop=None, abl="ours", use_pe=1):
     """SegFormerX.forward + SegFormerXEncoder.forward with output_layers=[-1]
     (encoder.py:475-520, 302-324).  The encoder records the INPUT of every layer
     (encoder.py:316-319) and [-1] selects the input of the last layer, so layer N-1 is dead and
@@ -161,7 +175,7 @@ def backbone_forward(sd, pre, usr_feat, usr_mask, vid_feat, vid_mask, N, nhead, 
     if vid_feat.dim() == 1:                       # encoder.py:484-486 (40 generalised to S)
         vid_feat = vid_feat[:, None].repeat(1, S)
     usr_mask = usr_mask.bool()
-    vid, usr = embedding(sd, pre, usr_feat, vid_feat, drop, abl)
+    vid, usr = embedding(sd, pre, usr_feat, vid_feat, drop, abl, use_pe)
     usr_emb = usr
     if abl == "CrossMLP":                         # encoder.py:503-506: MLP over cat(user, video) tokens, pooled to 40 tokens
         z = mlp_block(sd, pre + ".encoder_mlp.mlp", torch.cat((usr, vid), dim=-2), drop)
@@ -177,7 +191,7 @@ def backbone_forward(sd, pre, usr_feat, usr_mask, vid_feat, vid_mask, N, nhead, 
             out = vid
             if skip_dead:
                 break
-        need_usr = (i < N - 2) or not skip_dead
+        need_usr = (i < N - 2 and mode != "self") or not skip_dead
         vid, usr_new = encoder_layer(sd, "%s.encoder.layers.%d" % (pre, i), usr, usr_mask, vid, vid_mask,
                                      nhead, need_usr, drop, mode)
         if usr_new is not None:
@@ -343,6 +357,7 @@ def model_forward(sd: Dict[str, torch.Tensor], cfg: dict, inp: Dict[str, torch.T
     N, h, S = cfg["N"], cfg["h"], cfg["S"]
     u_t, p_t = cfg["user"], cfg["photo"]
     abl = cfg.get("ablation_type", "ours")
+    pe = cfg.get("use_pe", 1)
     if cfg.get("fwd_seed") is not None:      # fixture hook: the 'noPos' goldens reseed torch before every forward
         torch.manual_seed(cfg["fwd_seed"])
 
@@ -354,15 +369,15 @@ def model_forward(sd: Dict[str, torch.Tensor], cfg: dict, inp: Dict[str, torch.T
     if u_t != "both" and p_t != "both":
         vid, _ = backbone_forward(sd, "backbone1", pick(u_t, inp["usr_image"], inp["usr_id"], 1), inp["usr_mask"],
                                   pick(p_t, inp["vid_image"], inp["vid_id"], 1), inp["vid_mask"], N, h, S,
-                                  skip_dead, drop, abl)
+                                  skip_dead, drop, abl, pe)
         logits = _lin(sd, "stage_mlp1", vid).squeeze(-1)
     else:
         v1, _ = backbone_forward(sd, "backbone1", pick(u_t, inp["usr_image"], inp["usr_id"], 1), inp["usr_mask"],
                                  pick(p_t, inp["vid_image"], inp["vid_id"], 1), inp["vid_mask"], N, h, S,
-                                 skip_dead, drop, abl)
+                                 skip_dead, drop, abl, pe)
         v2, _ = backbone_forward(sd, "backbone2", pick(u_t, inp["usr_image"], inp["usr_id"], 2), inp["usr_mask"],
                                  pick(p_t, inp["vid_image"], inp["vid_id"], 2), inp["vid_mask"], N, h, S,
-                                 skip_dead, drop, abl)
+                                 skip_dead, drop, abl, pe)
         fh = cfg.get("fusion_heads", 2)
         if fh in (-2, -3):
             logits = _lin(sd, "stage_mlp1", v1 + v2).squeeze(-1)

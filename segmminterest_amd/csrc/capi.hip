@@ -933,7 +933,7 @@ int segmm_vecsum(const float* v, int64_t n, float* out, int accumulate, segmm_st
 int segmm_embed_id_vid(const int64_t* item_id, const float* table, int dhalf, const float* frame_w,
                        const float* frame_b, const float* pe, const float* frame_pos, float* out, int B, int S, int64_t n_rows,
                        segmm_stream_t stream) {
-    SEGMM_REQUIRE(item_id && table && frame_w && frame_b && pe && out && n_rows > 0, "embed_id_vid: null pointer / empty table");
+    SEGMM_REQUIRE(item_id && table && frame_w && frame_b && out && n_rows > 0, "embed_id_vid: null pointer / empty table");
     SEGMM_REQUIRE(dhalf % 4 == 0 && aligned16(table) && aligned16(frame_w) && aligned16(frame_b) && aligned16(pe) && aligned16(out), "embed_id_vid: d/2 %% 4 / alignment");
     if (B <= 0) return 0;
     hipLaunchKernelGGL(embed_id_vid_kernel, dim3(B * S), dim3(64), 0, (hipStream_t)stream, (const long long*)item_id, table, dhalf,
@@ -944,7 +944,7 @@ int segmm_embed_id_vid(const int64_t* item_id, const float* table, int dhalf, co
 
 int segmm_embed_id_usr(const int64_t* user_id, const float* table, int d, const float* pe, float* out, int B,
                        int64_t n_rows, segmm_stream_t stream) {
-    SEGMM_REQUIRE(user_id && table && pe && out && n_rows > 0 && d % 4 == 0 && aligned16(table) && aligned16(pe) && aligned16(out), "embed_id_usr: pointer/alignment");
+    SEGMM_REQUIRE(user_id && table && out && n_rows > 0 && d % 4 == 0 && aligned16(table) && aligned16(pe) && aligned16(out), "embed_id_usr: pointer/alignment");
     if (B <= 0) return 0;
     hipLaunchKernelGGL(embed_id_usr_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, (const long long*)user_id, table, d, pe, out, B, (long long)n_rows);
     LAUNCH_CHECK();

@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256) void embed_id_vid_kernel(const long long* __re
         f32x4 v;
         if (c < dhalf) v = ok ? *(const f32x4*)(table + id * dhalf + c) : f32x4{nan, nan, nan, nan};
         else v = *(const f32x4*)(frame_w + (c - dhalf)) * fpos + *(const f32x4*)(frame_b + (c - dhalf));
-        v += *(const f32x4*)(pe + (size_t)s * d + c);
+        if (pe) v += *(const f32x4*)(pe + (size_t)s * d + c);          // pe == null: --use_pe 0 (encoder.py:450-458)
         *(f32x4*)(out + row * d + c) = v;
     }
 }
@@ -353,8 +353,11 @@ __global__ __launch_bounds__(256) void embed_id_usr_kernel(const long long* __re
     const long long id = user_id[b];
     const bool ok = id >= 0 && id < n_rows;
     const float nan = __uint_as_float(0x7fc00000u);
-    for (int c = threadIdx.x * 4; c < d; c += blockDim.x * 4)
-        *(f32x4*)(out + (size_t)b * d + c) = (ok ? *(const f32x4*)(table + id * d + c) : f32x4{nan, nan, nan, nan}) + *(const f32x4*)(pe + c);
+    for (int c = threadIdx.x * 4; c < d; c += blockDim.x * 4) {
+        f32x4 v = ok ? *(const f32x4*)(table + id * d + c) : f32x4{nan, nan, nan, nan};
+        if (pe) v += *(const f32x4*)(pe + c);
+        *(f32x4*)(out + (size_t)b * d + c) = v;
+    }
 }
 // order[k] = index of the k-th smallest id, ties in index order (a STABLE argsort, like torch.argsort(ids, stable=True)): one
 // workgroup, bitonic network over the 64-bit keys (id << 32 | index) in LDS, n <= 8192 (a data-parallel node of 8 ranks x 1024

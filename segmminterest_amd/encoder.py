@@ -168,8 +168,6 @@ class SegFormerX(nn.Module):
             raise NotImplementedError("sr_ratio > 1 / patch merging are disabled in the reference trainers (main...SegMM.py:94)")
         if len(set(num_head_lvls)) != 1:
             raise NotImplementedError("one head count per backbone")
-        if not use_pe:
-            raise NotImplementedError("use_pe=0")
         self.id_vid = video_id_max != -1
         self.id_usr = user_id_max != -1
         if self.id_vid:

@@ -81,6 +81,7 @@ def backbone_layout(prefix: str, bb) -> Tuple[List[Tuple[str, List[List[str]]]],
     mode = attn_mode(bb)
     buckets = []
     usr_live = N >= 2 and mode != "self"       # with N == 1 (or SelfAtt) the user embedding only feeds dead compute
+    use_pe = bool(getattr(bb, "use_pe", 1))    # --use_pe 0 (encoder.py:450-471 else branches): the positional tables stay dead
     if abl in MLP_VARIANTS:
         usr_live = abl == "CrossMLP"
         if abl != "w/oAtt":                    # w/oAtt builds encoder_mlp but never calls it (encoder.py:397-400,510-511)
@@ -109,14 +110,18 @@ def backbone_layout(prefix: str, bb) -> Tuple[List[Tuple[str, List[List[str]]]],
         emb_u = [[prefix + "usr_proj.weight"]]
         if not bb.id_usr:
             emb_u += [[prefix + "usr_proj.bias"]]
-        emb_u += [[prefix + "usr_pe.weight"], [prefix + "usr_ln.weight"], [prefix + "usr_ln.bias"]]
+        if use_pe:
+            emb_u += [[prefix + "usr_pe.weight"]]
+        emb_u += [[prefix + "usr_ln.weight"], [prefix + "usr_ln.bias"]]
         buckets.append((prefix + "embed_u", emb_u))
     emb = [[prefix + "vid_proj.weight"]]
     if bb.id_vid:
         emb += [[prefix + "frameid_proj.weight"], [prefix + "frameid_proj.bias"]]
     else:
         emb += [[prefix + "vid_proj.bias"]]
-    emb += [[prefix + "vid_pe.weight"], [prefix + "vid_ln.weight"], [prefix + "vid_ln.bias"]]
+    if use_pe:
+        emb += [[prefix + "vid_pe.weight"]]
+    emb += [[prefix + "vid_ln.weight"], [prefix + "vid_ln.bias"]]
     buckets.append((prefix + "embed", emb))
     return buckets
 
@@ -948,6 +953,7 @@ class BackboneRun:
         ref = vm
         am = self.am = AmaxArena(st, 8 + 12 * max(self.N - 1, 0) + 2 * (self.n_mlp + 1))
         layered = self.abl not in MLP_VARIANTS and self.N >= 2
+        use_pe = bool(getattr(bb, "use_pe", 1))          # --use_pe 0: no positional-embedding add (encoder.py:450-471)
         usr_is_operand = (layered and self.mode != "self") or self.abl == "CrossMLP"      # does any GEMM read the user embedding?
         # ---- embedding (encoder.py:425-473).  The user-token chain (input Linear -> LayerNorm -> the first layer's fused
         # user-token projection) and the video-token chain are independent until the first attention: with SEGMM_FWD_SIDE=1
@@ -963,7 +969,7 @@ class BackboneRun:
         if bb.id_usr:
             uids = usr_feat.contiguous().to(torch.int64)
             sv["usr_ids"] = uids
-            H.embed_id_usr(uids, st.p(P + "usr_proj.weight"), d, st.p(P + "usr_pe.weight"), pre_u, B)
+            H.embed_id_usr(uids, st.p(P + "usr_proj.weight"), d, st.p(P + "usr_pe.weight") if use_pe else None, pre_u, B)
             H.layernorm_fwd(pre_u, st.p(P + "usr_ln.weight"), st.p(P + "usr_ln.bias"), Eu.t, meu, reu, drop_p=p_drop, seed=seed,
                             site=_site(self.bi, 0, K_EMB_U), amax=Eu.slots, po=Eu.po)
             finish_act(st, produced(Eu))
@@ -974,7 +980,7 @@ class BackboneRun:
 
             def usr_chain():
                 _lin_fwd(st, Mu, d, Din_u, sv["usr_x"], P + "usr_proj.weight", pre_u, d,
-                         bias=st.p(P + "usr_proj.bias"), residual=st.p(P + "usr_pe.weight"), ldr=d, res_period=Lt)
+                         bias=st.p(P + "usr_proj.bias"), **(dict(residual=st.p(P + "usr_pe.weight"), ldr=d, res_period=Lt) if use_pe else {}))
                 H.layernorm_fwd(pre_u, st.p(P + "usr_ln.weight"), st.p(P + "usr_ln.bias"), Eu.t, meu, reu, drop_p=p_drop, seed=seed,
                                 site=_site(self.bi, 0, K_EMB_U), amax=Eu.slots, po=Eu.po)
                 finish_act(st, produced(Eu))
@@ -997,13 +1003,13 @@ class BackboneRun:
                 fpos = torch.stack([torch.randperm(S) for _ in range(B)]).float().to(ids.device).contiguous()
             sv["frame_pos"] = fpos
             H.embed_id_vid(ids, st.p(P + "vid_proj.weight"), d // 2, st.p(P + "frameid_proj.weight"),
-                           st.p(P + "frameid_proj.bias"), st.p(P + "vid_pe.weight"), pre_v, B, S, frame_pos=fpos)
+                           st.p(P + "frameid_proj.bias"), st.p(P + "vid_pe.weight") if use_pe else None, pre_v, B, S, frame_pos=fpos)
         else:
             x = vid_feat.contiguous().float()
             Din = x.shape[-1]
             sv["vid_x"] = self._input_act(x, Mv, Din)
             _lin_fwd(st, Mv, d, Din, sv["vid_x"], P + "vid_proj.weight", pre_v, d,
-                     bias=st.p(P + "vid_proj.bias"), residual=st.p(P + "vid_pe.weight"), ldr=d, res_period=S)
+                     bias=st.p(P + "vid_proj.bias"), **(dict(residual=st.p(P + "vid_pe.weight"), ldr=d, res_period=S) if use_pe else {}))
         mev, rev = _empty(ref, Mv), _empty(ref, Mv)
         Ev = new_act(st, am, Mv, d, planes=layered or self.abl in ("SelfMLP", "CrossMLP"), site=P + "Ev", delayed=self.delayed)
         H.layernorm_fwd(pre_v, st.p(P + "vid_ln.weight"), st.p(P + "vid_ln.bias"), Ev.t, mev, rev, drop_p=p_drop, seed=seed,
@@ -1358,7 +1364,10 @@ class BackboneRun:
         dpre = dpre_act.t
         M = B * L
         is_id = bb.id_vid if side == "vid" else bb.id_usr
-        gpe = st.g(P + "%s_pe.weight" % side, gbuf)
+        if getattr(bb, "use_pe", 1):
+            gpe = st.g(P + "%s_pe.weight" % side, gbuf)
+        else:          # --use_pe 0: the table is dead (grad None); the per-position sums still feed the bias / frame-id gradients
+            gpe = st.buf("gpe_scratch_" + side, (L, d))
         _colsum(st, dpre, L * d, B, L * d, gpe)          # dpe[s,:] = sum_b dpre[b,s,:]: a column sum of the [B, L*d] view
         if gpe.shape[0] > L:
             gpe[L:].zero_()

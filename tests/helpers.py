@@ -10,7 +10,10 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 # metric known answers; config-1 labels of the reference's sample file; data-format fixtures (oracle/gen_golden_io.py)
 NOT_MODEL_CASES = ("metrics_kat.npz", "cfg1_labels.npz", "io_dataloader.npz", "io_cliprec.npz")
-MODEL_CASES = sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and f not in NOT_MODEL_CASES)
+# train_*: TRAIN-mode fixtures (the reference's dropout masks recorded in call order); they pin the oracle's dropout placement
+TRAIN_CASES = sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and f.startswith("train_"))
+MODEL_CASES = sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and f not in NOT_MODEL_CASES
+                     and not f.startswith("train_"))
 
 
 def load_case(name):
@@ -19,11 +22,21 @@ def load_case(name):
     cfg["loss_type_list"] = [x.strip() for x in cfg["loss"].split(",")]
     grp = {"sd": {}, "in": {}, "out": {}, "grad": {}, "adam1": {}, "adam3": {}, "inf": {}}
     for k in z.files:
-        if "/" in k:
+        if "/" in k and not k.startswith("mask"):
             g, n = k.split("/", 1)
             grp[g][n] = torch.from_numpy(z[k])
     nograd = json.loads(str(z["nograd"]))
     extra = {"adam_loss3": float(z["adam_loss3"])} if "adam_loss3" in z.files else {}
+    if "mask_p" in z.files:          # train-mode fixture: dropout keep-masks of the reference in call order
+        ps = z["mask_p"]
+        masks = []
+        for k in range(len(ps)):
+            shape = tuple(int(x) for x in z["mask_shape/%d" % k])
+            n = int(np.prod(shape))
+            keep = np.unpackbits(z["mask/%d" % k])[:n].reshape(shape).astype(bool)
+            masks.append((float(ps[k]), torch.from_numpy(keep)))
+        extra["masks"] = masks
+        extra["mask_calls_fwd"] = int(z["mask_calls_fwd"])
     return cfg, grp, nograd, extra
 
 
@@ -37,13 +50,14 @@ def build_model(cfg, device=None):
                               input_type={"user": cfg["user"], "photo": cfg["photo"]},
                               learnable_bias=cfg.get("learnable_bias", 0), exposure_prob=cfg["exposure_prob"],
                               fusion_heads=cfg.get("fusion_heads", 2), loss_type_list=cfg["loss_type_list"],
-                              loss_weight=cfg["loss_weight"], mask_loss=cfg.get("mask_loss", 0), use_pe=1)
+                              loss_weight=cfg["loss_weight"], mask_loss=cfg.get("mask_loss", 0), use_pe=cfg.get("use_pe", 1))
 
     def backbone(user_id_max, video_id_max, max_usr_len):
         return M.SegFormerX(d_model_in=d, d_model_lvls=[d] * N, num_head_lvls=[h] * N, ff_dim_lvls=[d] * N,
                             input_vid_dim=max(cfg["D_in"], 1), input_usr_dim=max(cfg["D_in"], 1), max_vid_len=S,
                             max_usr_len=max_usr_len, sr_ratio_lvls=[1] * N, use_patch_merge=[False] * N,
-                            output_layers=[-1], model_cfg=args, user_id_max=user_id_max, video_id_max=video_id_max, use_pe=1)
+                            output_layers=[-1], model_cfg=args, user_id_max=user_id_max, video_id_max=video_id_max,
+                            use_pe=cfg.get("use_pe", 1))
 
     nu, ni = cfg.get("n_users", 0), cfg.get("n_items", 0)
     u, p = cfg["user"], cfg["photo"]
