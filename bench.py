@@ -73,6 +73,9 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--windows", type=int, default=5,
+                    help="timed windows of --steps steps each, run back to back after the warm-up; `value` is the MEDIAN window, "
+                         "value_min / value_max the slowest / fastest (box noise and clock transients stay visible)")
     ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4, 5))
     ap.add_argument("--batch", type=int, default=None, help="rows per GPU (default: 512; config 3: 1024)")
     ap.add_argument("--global-batch", type=int, default=None, help="total rows over all GPUs (config 4: 2048)")
@@ -120,9 +123,27 @@ def relaunch(args):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
-    sys.stdout.write(p.stdout)
+    # relay ONLY the JSON line: whatever else the ranks or their libraries wrote to stdout goes to stderr (every rank also
+    # keeps its own stdout clean, see _claim_stdout)
+    lines = p.stdout.splitlines()
+    js = [ln for ln in lines if ln.startswith('{"metric"')]
+    for ln in lines:
+        if not ln.startswith('{"metric"'):
+            sys.stderr.write(ln + "\n")
+    if js:
+        sys.stdout.write(js[-1] + "\n")
     sys.stdout.flush()
-    sys.exit(p.returncode)
+    sys.exit(p.returncode if (js or p.returncode) else 1)
+
+
+def _claim_stdout():
+    """The driver parses stdout as ONE JSON line.  RCCL prints a version banner to the process's stdout when the first
+    communicator is built, and any library may print there: point file descriptor 1 at stderr for the whole run and keep a
+    private handle on the real stdout for the final line (returned)."""
+    sys.stdout.flush()
+    real = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    return real
 
 
 def _graph_mode_legs(args):
@@ -200,10 +221,17 @@ def cpu_baseline(args, w, h):
         ts.append(time.perf_counter() - t0)
     ts.sort()
     med = ts[len(ts) // 2]
+    sweep = ""
+    spath = os.path.join(ROOT, "profiles", "cpu_baseline_threads.json")
+    if os.path.exists(spath):          # tools/cpu_threads_sweep.py on a GPU box: the same step at several thread counts, measured once
+        with open(spath) as f:
+            sj = json.load(f)
+        sweep = "; thread sweep on a %d-thread GPU-box host (%s, git %s): %s interactions/s" % (
+            sj["host_threads"], sj["workload"], sj.get("git", "?"), ", ".join("%s threads %.1f" % (k, v) for k, v in sj["rows_per_s"].items()))
     return {"value": round(Bc / med, 3), "unit": "interactions/s", "cores": cores, "kind": "port",
             "sample": "median of %d timed steps (%d warm-up) of B=%d rows, same S/D/Lt/N, dropout 0.1, dead layers executed like the "
-                      "reference, torch-CPU %d threads of %d host threads (more threads ran slower on this box)"
-                      % (args.cpu_steps, args.cpu_warmup, Bc, cores, host)}
+                      "reference, torch-CPU %d threads of %d host threads%s"
+                      % (args.cpu_steps, args.cpu_warmup, Bc, cores, host, sweep or " (more threads ran slower on this box)")}
 
 
 def union_ms(intervals):
@@ -225,6 +253,7 @@ def main():
     env_world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and env_world != args.gpus:
         relaunch(args)
+    real_stdout = _claim_stdout()
     if args.gpus == 1 and env_world != 1:
         raise SystemExit("--gpus 1 under a %d-rank launcher" % env_world)
     import torch
@@ -309,18 +338,23 @@ def main():
             raise SystemExit("--graph: single GPU, no prefetch")
         trainer.capture(batches[0], warmup=max(args.warmup, 3))
     run(trainer, args.warmup)
-    barrier()
-    t0 = time.perf_counter()
+    # ---- the timed region: `windows` windows of EXACTLY `steps` steps, each bracketed by barrier + synchronize on both sides,
+    # MAX over ranks per window; `value` is the median window (value_min / value_max beside it)
+    win = []
     del host_s[:]
-    out = run(trainer, args.steps, args.warmup)
+    for wi in range(max(args.windows, 1)):
+        barrier()
+        t0 = time.perf_counter()
+        out = run(trainer, args.steps, args.warmup + wi * args.steps)
+        barrier()
+        win.append(time.perf_counter() - t0)
     host_ms = 1e3 * sorted(host_s)[len(host_s) // 2] if host_s else 0.0
-    barrier()
-    elapsed = time.perf_counter() - t0
     loss = float(out["loss"].detach())
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+    t = torch.tensor(win, dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    win = sorted(float(x) for x in t.tolist())
+    elapsed = win[len(win) // 2]
     rows_per_s = world * B * args.steps / elapsed
 
     # ---- instrumented pass: the SAME steps again with a HIP-event pair around every GEMM / attention / optimizer launch
@@ -331,7 +365,7 @@ def main():
     hipabi.KERNEL_PROFILE = kprof = []
     barrier()
     tp0 = time.perf_counter()
-    run(trainer, psteps, args.warmup + args.steps)
+    run(trainer, psteps, args.warmup + len(win) * args.steps)
     barrier()
     prof_elapsed = time.perf_counter() - tp0
     hipabi.GEMM_PROFILE = hipabi.ATTN_PROFILE = hipabi.KERNEL_PROFILE = None
@@ -354,7 +388,8 @@ def main():
                  "f16x3p": "f32 (products via scaled fp16x2 split, 22-bit operands, fp32 accumulate; operands pre-split by their producers)"}[engine]
         rec = {
             "metric": "train interactions/sec (segment-Transformer, B=512·S=40·D=768)",
-            "value": round(rows_per_s, 2), "unit": "interactions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(rows_per_s, 2), "value_min": round(world * B * args.steps / win[-1], 2), "value_max": round(world * B * args.steps / win[0], 2),
+            "windows": len(win), "unit": "interactions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "host_enqueue_ms_per_step": round(host_ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": dtype, "data": "synthetic",
             "config": {"workload": "%s: synthetic SegMM B=%d/GPU x S=%d x D_in=%d -> d=%d, h=%d, %d-layer segment encoder, %s/%s inputs, Lt=%d user "
@@ -572,7 +607,8 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(args, w, h)
-        print(json.dumps(rec), flush=True)
+        real_stdout.write(json.dumps(rec) + "\n")
+        real_stdout.flush()
     if world > 1:
         dist.destroy_process_group()
 

@@ -147,6 +147,12 @@ class HeadLossFn(torch.autograd.Function):
         if gbuf is None and st.bucket_hook is not None:
             st.bucket_hook("head", after_side=st.head_side)
         ctx.dlogits = ctx.T = None
+        if not st.direct_grads or gbuf is not None:
+            # the head's weight / bias gradients were written on the side stream (head_side): autograd consumes the views it is
+            # handed at once on THIS stream (hooks, AccumulateGrad's += on a second backward, clones) and a fresh ``gbuf`` may be
+            # recycled by the caching allocator while the side stream still writes it -- join first.  The trainer's direct
+            # delivery (views of the persistent flat buffer, ordered by the DP hook / the end-of-backward join) stays unjoined.
+            E.join_side(st)
         return (None, None, dv1.view(B, S, d), dv2.view(B, S, d) if dv2 is not None else None, None) + E.grads_out(st, names, gbuf)
 
 

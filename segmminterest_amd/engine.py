@@ -225,33 +225,35 @@ class ParamStore:
 
     def hdr_step_begin(self):
         """Step-arena mode (Trainer(device_state=True): the step may be replayed from a hipGraph, so every step must use the
-        SAME header rows): hand the rows out from row 0 again and clear what the previous step used -- one fill launch per
-        step, inside the graph."""
-        first = not self.__dict__.get("step_arena", False)
+        SAME header rows): hand the rows out from row 0 of the ARENA again and clear what the previous step used -- one fill
+        launch per step, inside the graph.  The arena is only active until ``hdr_step_end`` (the end of train_step): evaluation
+        passes between training steps draw from the wrapping ring below, which recycles its rows (a validation round
+        of >~100 batches used to exhaust the arena)."""
+        if self.flat is None:
+            self.ensure()
+        dev = self.flat.device
+        arena = self.__dict__.get("_hdr_arena")
+        if arena is None or arena.device != dev:
+            arena = self._hdr_arena = torch.zeros((self.HDR_RING_ROWS, H.SITE_FLOATS), dtype=torch.float32, device=dev)
+            self._arena_used = 0
+        elif self._arena_used:
+            arena[:self._arena_used].zero_()
+        self._arena_off, self._arena_used = 0, 0
         self.step_arena = True
-        ring = getattr(self, "_hdr_ring", None)
-        if ring is not None:
-            used = self.HDR_RING_ROWS if first else self.__dict__.get("_hdr_used", 0)
-            if used:
-                ring[:used].zero_()
-        self._hdr_off = 0
-        if first:
-            self._hdr_used = 0
+
+    def hdr_step_end(self):
+        self.step_arena = False
 
     def hdr_rows(self, n: int) -> torch.Tensor:
         dev = self.flat.device
         q = self.HDR_RING_ROWS // 4
         if self.__dict__.get("step_arena", False):
-            ring = getattr(self, "_hdr_ring", None)
-            if ring is None or ring.device != dev:
-                ring = self._hdr_ring = torch.zeros((self.HDR_RING_ROWS, H.SITE_FLOATS), dtype=torch.float32, device=dev)
-                self._hdr_off, self._hdr_used = 0, 0
-            if self._hdr_off + n > self.HDR_RING_ROWS:
+            if self._arena_off + n > self.HDR_RING_ROWS:
                 raise RuntimeError("step arena: more than %d site headers in one step" % self.HDR_RING_ROWS)
-            r0 = self._hdr_off
-            self._hdr_off += n
-            self._hdr_used = max(self.__dict__.get("_hdr_used", 0), self._hdr_off)
-            return ring[r0:r0 + n]
+            r0 = self._arena_off
+            self._arena_off += n
+            self._arena_used = max(self._arena_used, self._arena_off)
+            return self._hdr_arena[r0:r0 + n]
         if n > q:
             return torch.zeros((n, H.SITE_FLOATS), dtype=torch.float32, device=dev)
         ring = getattr(self, "_hdr_ring", None)
@@ -264,6 +266,16 @@ class ParamStore:
         r0 = self._hdr_q * q + self._hdr_off
         self._hdr_off += n
         return ring[r0:r0 + n]
+
+    def tickets(self) -> torch.Tensor:
+        """Ticket words of the in-kernel split-K combine (segmm_gemm_p): zero between launches, one array per stream (a
+        weight-gradient GEMM may run on the main and on the side stream at the same time)."""
+        c = self.__dict__.setdefault("_consts", {})
+        key = ("tickets", bool(self._on_side), self.flat.device)
+        t = c.get(key)
+        if t is None:
+            t = c[key] = torch.zeros((H.SPLITK_TICKETS,), dtype=torch.int32, device=self.flat.device)
+        return t
 
     def const_arange(self, n: int, dtype) -> torch.Tensor:
         """arange(n) on the device, made once (never written afterwards)."""
@@ -730,8 +742,9 @@ def finish_act(store, act):
 def _needs_f32(act, what):
     """A launch is about to read ``act.t``: refuse if its producers wrote planes only (engine._layer_bwd, planes-only protocol)."""
     if getattr(act, "no_f32", False):
-        raise RuntimeError("%s reads the fp32 copy of an operand whose producers wrote planes only (set SEGMM_ATTN_PLANES_ONLY=0 "
-                           "together with SEGMM_FEW_TILES / a non-plane GEMM engine)" % what)
+        raise RuntimeError("%s reads the fp32 copy of an operand whose producers wrote planes only (attention gradients: set "
+                           "SEGMM_ATTN_PLANES_ONLY=0; L1-normalised input features: SEGMM_INPUT_PLANES_ONLY=0 -- needed together with "
+                           "SEGMM_FEW_TILES / a non-plane GEMM engine)" % what)
 
 
 def _wgrad(store, dY, y_off, X, x_off, Mrows, n_out, n_in, gW, accumulate=False, gb=None):
@@ -742,7 +755,7 @@ def _wgrad(store, dY, y_off, X, x_off, Mrows, n_out, n_in, gW, accumulate=False,
         splits = _splits_for_p(n_out, n_in, Mrows)
         ws = store.buf("splitk_ws_side" if store._on_side else "splitk_ws", (max(splits, 1) * (n_out * n_in + n_out),)) if splits > 1 else None
         H.gemm_p(H.LAYOUT_TN, n_out, n_in, Mrows, dY.pt(y_off, n_out), X.pt(x_off, n_in), gW, n_in, splits=splits, workspace=ws,
-                 accumulate=accumulate, colsum_out=gb)
+                 accumulate=accumulate, colsum_out=gb, tickets=store.tickets() if splits > 1 else None)
         return
     _needs_f32(dY, "the on-the-fly weight-gradient GEMM")
     _needs_f32(X, "the on-the-fly weight-gradient GEMM")

@@ -21,6 +21,7 @@ import argparse
 from typing import Dict, List, Optional
 
 import os
+import weakref
 
 import torch
 import torch.nn as nn
@@ -322,6 +323,8 @@ class Trainer:
     the reference's hot loop (main_for_seq_leave_earlystop_SegMM.py:269-300) minus its host syncs.
     Gradient clipping is a no-op in the reference (exhausted generator at :298) and is therefore absent."""
 
+    _device_state_owner = None          # weakref to the Trainer(device_state=True) that owns the process-global device step state
+
     def __init__(self, model, lr=1e-3, weight_decay=1e-4, comm: Optional[DPComm] = None, overlap=True, dropout=True,
                  feature_table=None, sparse_tables=True, device_state=False):
         self.model = model
@@ -346,6 +349,11 @@ class Trainer:
         # ranges are cut out of the dense all-reduce; ``sparse_tables=False`` keeps the dense all-reduce (A/B, tests)
         self.sparse_tables = bool(sparse_tables) and self.comm.active and os.environ.get("SEGMM_SPARSE_TABLES", "1") != "0"
         st.row_exchange = self.comm.gather_rows if self.sparse_tables else None
+        if self.sparse_tables:
+            # dist.new_group is COLLECTIVE over the default group: create the row-exchange group here, where every rank
+            # constructs its Trainer, not lazily inside the first backward (ranks that skip the id-table path on
+            # their first step, or a DPComm on a sub-group, would deadlock)
+            self.comm._row_group()
         self.per_bucket_adamw = os.environ.get("SEGMM_BUCKET_ADAMW", "1") != "0"
         self.bucket_bytes = int(float(os.environ.get("SEGMM_DP_BUCKET_MB", "8")) * (1 << 20))      # merge threshold of _on_bucket
         self._bucket_works = []
@@ -360,6 +368,12 @@ class Trainer:
         if self.device_state:
             if self.comm.active:
                 raise RuntimeError("device_state (graph capture) is a single-GPU mode: the data-parallel step issues collectives from Python")
+            # the device step state (seed words, step count) is ONE process-global __device__ struct: a second device_state
+            # trainer takes it over, the first one must not step any more (it would silently run on the other's seed and count)
+            prev = Trainer._device_state_owner
+            if prev is not None and prev() is not None and prev() is not self:
+                prev()._superseded = True
+            Trainer._device_state_owner = weakref.ref(self)
             self.opt.device_state = True
             seed0 = int(torch.randint(0, 2 ** 62, (1,)).item())          # torch.manual_seed -> reproducible runs
             H.step_set(seed0, self.opt.step_count, *self.opt.betas)
@@ -446,7 +460,7 @@ class Trainer:
             delayed = (self.model.training and st.scaling != "exact") or st.scaling == "always"
             act.scale_ptr = st.scale_ptr("in." + key, delayed)
             if act.scale_ptr is not None:
-                if planes_only and st.input_planes_only:
+                if planes_only and st.input_planes_only and self._plane_consumers_only(key):
                     # L1-normalised rows: 1/cols <= max |y| <= 1.  With the FIXED scale 2^14 the planes can neither overflow nor
                     # fall below the fp16 window, whatever the batch: no fp32 copy is written and the consumers get none
                     act.scale_ptr = st.const_f32(16384.0).data_ptr()
@@ -454,6 +468,21 @@ class Trainer:
                 act.po = H.PO(planes, 2 * cols, act.hdr, act.scale_ptr)
         buf._segmm_act = act
         return act
+
+    def _plane_consumers_only(self, key) -> bool:
+        """Every launch that reads the input features of ``key`` is a plane GEMM (forward projection and its weight gradient):
+        the plane engine, a P32 plane entry for the projection weight and d_model a multiple of 32 (else the weight gradient
+        takes the on-the-fly kernel, which reads the fp32 copy -- ADVICE r3: d_model = 48 raised on the second step)."""
+        st = self.model._store
+        if not st.engine_p:
+            return False
+        kind = "usr" if key == "user" else "vid"
+        for pre, bb in (("backbone1.", self.model.backbone1), ("backbone2.", getattr(self.model, "backbone2", None))):
+            if bb is None or (bb.id_usr if kind == "usr" else bb.id_vid):
+                continue
+            if bb.d_model % 32 or (pre + kind + "_proj.weight") not in st.wpt:
+                return False
+        return True
 
     def normalize(self, key, x):
         """a1: x / (sum|x| + 1e-6) over the feature dim, into a persistent buffer."""
@@ -541,6 +570,9 @@ class Trainer:
         """One optimisation step on ``batch``.  ``next_batch``: the batch of the FOLLOWING step, if known -- its input stage is
         enqueued on a side stream right away (:meth:`prefetch`) and overlaps this step's backward."""
         model, st = self.model, self.model._store
+        if self.__dict__.get("_superseded", False):
+            raise RuntimeError("this Trainer(device_state=True) was superseded by a later one: the device-side step state is "
+                               "process-global (one device_state trainer per process)")
         if model.training != bool(self.dropout):
             model.train(self.dropout)          # (walks every sub-module: 0.35 ms of host time when done every step)
         self.opt.zero_grad()
@@ -556,6 +588,8 @@ class Trainer:
             return self._train_step(batch, usr, um, vid, vm)
         finally:
             st._trusted = False
+            if self.device_state:
+                st.hdr_step_end()          # evaluation passes between steps draw their headers from the wrapping ring
 
     def _train_step(self, batch, usr, um, vid, vm):
         model, st = self.model, self.model._store
@@ -647,7 +681,11 @@ class Trainer:
                 if torch.is_tensor(v):
                     self._static[k].copy_(v, non_blocking=True)
         self._graph.replay()
+        # mirror EVERY host side effect of the eager step: the graph rewrote the weights (AdamW) and re-split the planes at the
+        # head of the step, so the planes are one optimizer step behind the weights again -- the next ensure() outside the
+        # graph (an evaluation pass) must re-split them
         self.opt.step_count += 1
+        self.model._store.fused_version += 1
         return self._static_out
 
     def _param_hooks(self) -> bool:

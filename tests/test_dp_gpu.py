@@ -202,6 +202,23 @@ def test_rccl_single_rank_step_equals_plain_step(name):
         assert v0[k] == v1[k], (k, v0[k], v1[k])
 
 
+def test_bench_forced_one_rank_rccl_stdout_is_one_json_line():
+    """The nccl (= RCCL) path on one GPU (SEGMM_DP_FORCE=1: a one-rank process group, every collective really issued): RCCL's
+    version banner goes to the process's stdout when the communicator is built -- bench.py must keep it off the JSON stream."""
+    import json
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--dim", "64", "--heads", "4", "--lt", "12", "--batch", "32", "--steps", "3",
+           "--warmup", "1", "--windows", "2", "--batches", "2", "--no-cpu-baseline", "--no-f32-engine", "--no-host-fed", "--no-probe"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SEGMM_DP_FORCE="1", NCCL_DEBUG="VERSION")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert p.stdout.count("\n") == 1 and p.stdout.startswith('{"metric"'), p.stdout
+    rec = json.loads(p.stdout)
+    assert rec["config"]["backend"] == "nccl" and "forced one-rank" in rec["config"]["parallelism"]
+
+
 def test_bench_launcher_four_ranks_on_one_gpu():
     """bench.py --gpus N end to end, the way the driver starts it for N > 1 (a child torch.distributed.run, one rank per
     process, rows sharded, global loss normalisers, bucketed all-reduce, per-bucket AdamW): config 4 at a toy width, FOUR
@@ -216,10 +233,11 @@ def test_bench_launcher_four_ranks_on_one_gpu():
     env.pop("RANK", None); env.pop("WORLD_SIZE", None); env.pop("LOCAL_RANK", None)
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
-    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, p.stdout
-    rec = json.loads(lines[0])
+    # stdout is EXACTLY one JSON line (the driver parses it; library banners -- RCCL prints one -- must land on stderr)
+    assert p.stdout.count("\n") == 1 and p.stdout.startswith('{"metric"'), p.stdout
+    rec = json.loads(p.stdout)
     assert rec["n_gpus"] == 4 and rec["scaling"] == "weak" and rec["value"] > 0
+    assert rec["windows"] == 5 and rec["value_min"] <= rec["value"] <= rec["value_max"]
     assert rec["config"]["global_batch"] == 64 and rec["config"]["rows_per_gpu"] == 16
     assert rec["config"]["replicas_identical"] is True
     assert rec["config"]["parallelism"].startswith("dp4")

@@ -359,3 +359,109 @@ def test_device_state_optimizer_resumes_from_checkpoint():
     assert H.step_get()[1] == 4
     got = model2._store.flat.detach()
     assert float((got - want).abs().max()) <= 1e-6 * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.gpu
+def test_graph_replay_with_validation_between_replays():
+    """replay() must mirror every host side effect of the eager step.  The captured graph rewrites the weights and
+    re-splits the weight planes at the head of the step, so outside the graph the planes are one optimizer step stale: an
+    evaluation pass between replays has to re-split them (ParamStore.refresh_planes keyed on fused_version).  Interleaving
+    eval_step with replays must give the same evaluation logits and the same final parameters as the eager device-state run."""
+    import torch
+    from segmminterest_amd.synth import make_batch
+    from segmminterest_amd.trainer import Trainer, default_args, init_model
+    dev = torch.device("cuda:0")
+    B, S, Lt, D, N, h = 32, 40, 10, 64, 2, 4
+    margs = default_args(num_layers_enc=N, d_model=D, nhead=h, input_type={"user": "image", "photo": "image"}, exposure_prob=[1.0] * S)
+    batches = [{k: v.to(dev) for k, v in make_batch(B, S, Lt, D, seed=200 + i).items()} for i in range(3)]
+
+    def run(graph):
+        torch.manual_seed(5)
+        model = init_model(margs, n_users=50, n_items=500, input_dim=D, max_vid_len=S, max_usr_len=Lt).to(dev)
+        tr = Trainer(model, lr=1e-2, weight_decay=1e-4, device_state=True)          # large lr: a stale plane set is visible
+        if graph:
+            tr.capture(batches[0], warmup=2)
+        else:
+            for _ in range(2):
+                tr.train_step(batches[0])
+        evals = []
+        for t in range(6):
+            tr.replay(batches[t % 3]) if graph else tr.train_step(batches[t % 3])
+            if t % 2 == 1:          # validation after steps 2, 4, 6: the SECOND and third must not run on the first one's planes
+                evals.append(tr.eval_step(batches[2], mode="inference")["logits"].detach().clone())
+        torch.cuda.synchronize()
+        return model._store.flat.detach().clone(), evals
+
+    p_e, ev_e = run(False)
+    p_g, ev_g = run(True)
+    assert torch.equal(p_e, p_g)
+    for a, b in zip(ev_e, ev_g):
+        assert torch.equal(a, b)
+    assert float((ev_e[0] - ev_e[2]).abs().max()) > 1e-4          # the weights really moved between the validations
+
+
+@pytest.mark.gpu
+def test_device_state_validation_rounds_do_not_exhaust_the_header_arena():
+    """ADVICE r3: with Trainer(device_state=True) the per-step header arena is handed out from row 0 by train_step only;
+    evaluation passes between steps draw from the wrapping ring.  Several validation rounds of many batches (far more than
+    8192 / ~36 header rows) must run, and training must continue bit-identically to a run without the validations."""
+    import torch
+    from segmminterest_amd.synth import make_batch
+    from segmminterest_amd.trainer import Trainer, default_args, init_model
+    dev = torch.device("cuda:0")
+    B, S, Lt, D = 8, 20, 6, 32
+    margs = default_args(num_layers_enc=3, d_model=D, nhead=4, input_type={"user": "image", "photo": "image"}, exposure_prob=[1.0] * S)
+    batch = {k: v.to(dev) for k, v in make_batch(B, S, Lt, D, seed=9).items()}
+
+    def run(validate):
+        torch.manual_seed(2)
+        model = init_model(margs, n_users=5, n_items=5, input_dim=D, max_vid_len=S, max_usr_len=Lt).to(dev)
+        tr = Trainer(model, device_state=True)
+        for r in range(3):
+            tr.train_step(batch)
+            if validate:
+                m = tr.valid_model([batch] * 150, permutation=0)
+                assert m["HR@10"] >= 0.0
+        torch.cuda.synchronize()
+        return model._store.flat.detach().clone()
+
+    assert torch.equal(run(False), run(True))
+
+
+@pytest.mark.gpu
+def test_second_device_state_trainer_supersedes_the_first():
+    """The device-side step state is one process-global struct: the trainer that lost it refuses to step."""
+    import torch
+    from segmminterest_amd.synth import make_batch
+    from segmminterest_amd.trainer import Trainer, default_args, init_model
+    dev = torch.device("cuda:0")
+    B, S, Lt, D = 8, 20, 6, 32
+    margs = default_args(num_layers_enc=2, d_model=D, nhead=4, input_type={"user": "image", "photo": "image"}, exposure_prob=[1.0] * S)
+    batch = {k: v.to(dev) for k, v in make_batch(B, S, Lt, D, seed=9).items()}
+    m1 = init_model(margs, n_users=5, n_items=5, input_dim=D, max_vid_len=S, max_usr_len=Lt).to(dev)
+    m2 = init_model(margs, n_users=5, n_items=5, input_dim=D, max_vid_len=S, max_usr_len=Lt).to(dev)
+    t1 = Trainer(m1, device_state=True)
+    t1.train_step(batch)
+    t2 = Trainer(m2, device_state=True)
+    t2.train_step(batch)
+    with pytest.raises(RuntimeError, match="superseded"):
+        t1.train_step(batch)
+
+
+@pytest.mark.gpu
+def test_planes_only_input_needs_plane_consumers_d48():
+    """D_in a multiple of 32 but d_model = 48 (3 heads of 16): the embedding weight gradient takes the on-the-fly
+    kernel, which reads the fp32 copy of the L1-normalised features -- the planes-only input protocol must stay off, and
+    several default-settings training steps must run and match the oracle's first-step gradients."""
+    import torch
+    from segmminterest_amd.synth import make_batch
+    from segmminterest_amd.trainer import Trainer, default_args, init_model
+    dev = torch.device("cuda:0")
+    B, S, Lt, D_in, d = 8, 20, 6, 64, 48
+    margs = default_args(num_layers_enc=2, d_model=d, nhead=3, input_type={"user": "image", "photo": "image"}, exposure_prob=[1.0] * S)
+    batch = {k: v.to(dev) for k, v in make_batch(B, S, Lt, D_in, seed=11).items()}
+    torch.manual_seed(4)
+    model = init_model(margs, n_users=5, n_items=5, input_dim=D_in, max_vid_len=S, max_usr_len=Lt).to(dev)
+    tr = Trainer(model, dropout=False)
+    losses = [float(tr.train_step(batch)["loss"].detach()) for _ in range(4)]          # raised on step 2 before the fix
+    assert all(l == l for l in losses) and losses[-1] < losses[0]
