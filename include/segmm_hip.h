@@ -103,16 +103,10 @@ int segmm_gemm_p(int layout, int M, int N, int K, const uint16_t* a_planes, int 
                  const uint16_t* b_planes, int ldb2, const float* b_hdr, const float* b_f32, int ldbf, float* C, int ldc,
                  uint16_t* c_planes, int ldc2, float* c_hdr, const float* c_scale_in, int write_c, const float* bias, const float* row_scale,
                  const float* residual, int ldr, int res_period, int activation, float* aux, int ldaux, float drop_p,
-                 uint64_t seed, uint32_t site, int splits, float* workspace, int accumulate, float* colsum_out, uint32_t* tickets,
-                 segmm_stream_t stream);
+                 uint64_t seed, uint32_t site, int splits, float* workspace, int accumulate, float* colsum_out, segmm_stream_t stream);
 /* colsum_out (TN only, optional): [M] floats receiving sum_k A[k, m] -- the bias gradient of the Linear whose weight gradient
  * the call computes (dW = dY^T . X, db = column sums of dY), formed inside the same kernel (+)= with `accumulate`; with
- * splits > 1 the workspace must hold splits * (M * N + M) floats.
- * tickets (TN, splits > 1, optional): SEGMM_SPLITK_TICKETS 32-bit words owned by the caller, ZERO before the first call and left
- * zero by every call (one array per stream that may run such a GEMM: concurrent launches must not share one).  With it the
- * split-K slabs are combined INSIDE the kernel -- the workgroup that finishes an output tile last sums the tile's slabs in slab
- * order (bit-identical to the separate combine launch, which is what runs when tickets == NULL). */
-#define SEGMM_SPLITK_TICKETS 1024
+ * splits > 1 the workspace must hold splits * (M * N + M) floats. */
 /* fp32 [rows, cols] (row stride ld) -> P32 planes.  mode 0: exact scale from the header's partial maxima (complete when
  * this runs), written to hdr[0], flag cleared.  mode 1: scale = hdr[0] as given; maxima and flag folded into hdr. */
 int segmm_split_p32(const float* x, int64_t rows, int cols, int ld, uint16_t* planes, int ld2, float* hdr, int mode,

@@ -504,8 +504,7 @@ int segmm_gemm_p(int layout, int M, int N, int K, const uint16_t* a_planes, int 
                  const uint16_t* b_planes, int ldb2, const float* b_hdr, const float* b_f32, int ldbf, float* C, int ldc,
                  uint16_t* c_planes, int ldc2, float* c_hdr, const float* c_scale_in, int write_c, const float* bias, const float* row_scale,
                  const float* residual, int ldr, int res_period, int activation, float* aux, int ldaux, float drop_p,
-                 uint64_t seed, uint32_t site, int splits, float* workspace, int accumulate, float* colsum_out, uint32_t* tickets,
-                 segmm_stream_t stream) {
+                 uint64_t seed, uint32_t site, int splits, float* workspace, int accumulate, float* colsum_out, segmm_stream_t stream) {
     SEGMM_REQUIRE(layout == 0 || layout == 2, "gemm_p: layout %d (0 = NT, 2 = TN)", layout);
     SEGMM_REQUIRE(!colsum_out || layout == 2, "gemm_p: colsum_out is an output of the TN form");
     SEGMM_REQUIRE(a_planes && b_planes && a_hdr && b_hdr, "gemm_p: null plane operand / header");
@@ -632,14 +631,10 @@ int segmm_gemm_p(int layout, int M, int N, int K, const uint16_t* a_planes, int 
     // round-3 form (gemm_planes8.h): whole 256 x 256 tiles, plain or split-K stores (no accumulate into C), 32-bit output offsets
     static const int tn_var = getenv("SEGMM_TN_VAR") ? atoi(getenv("SEGMM_TN_VAR")) : 8;
     const bool tn8 = tn_var == 8 && M % PBM == 0 && N % PBN == 0 && !g.residual && (long long)M * (splits > 1 ? N : ldc) * 4 < (1ll << 31);
-    // split-K finished inside the kernel (last-arriver ticket per output tile): the round-3 kernel with a ticket array from the caller
-    static const int fuse_env = getenv("SEGMM_SPLITK_FUSED") ? atoi(getenv("SEGMM_SPLITK_FUSED")) : 1;
-    const bool fused = tn8 && splits > 1 && tickets != nullptr && fuse_env && g.nbm * g.nbn <= SEGMM_SPLITK_TICKETS;
-    if (fused) { q.tickets = tickets; q.Cfin = C; q.ldc_fin = ldc; q.acc_fin = accumulate; }
     if (tn8) hipLaunchKernelGGL(gemm_pl_tn8, dim3(g.nbm * g.nbn, 1, splits), dim3(512), 0, s, g, q);
     else hipLaunchKernelGGL(gemm_pl_tn<0>, dim3(g.nbm * g.nbn, 1, splits), dim3(512), 0, s, g, q);
     LAUNCH_CHECK();
-    if (splits > 1 && !fused) {          // one combine launch for the slabs AND the folded column sums
+    if (splits > 1) {          // one combine launch for the slabs AND the folded column sums
         const long long n4 = (long long)M * (N / 4);
         int blocks = (int)((n4 + 255) / 256);
         if (blocks > 2048) blocks = 2048;

@@ -40,9 +40,6 @@ struct PGemmX {
     const float* c_scale_in;                   // device scalar: scale to write the output planes with (null / 0: none)
     int write_c;                               // 0: the fp32 C is not stored (planes only)
     float* colsum_out; float* colsum_ws;       // TN only: optional [M] column sums of A over k (= bias gradient), split-K partials [splits][M]
-    // TN split-K finished INSIDE the kernel (gemm_pl_tn8): one ticket per output tile (zero between launches); the workgroup that
-    // draws the last ticket of a tile sums the tile's slabs in slab order into Cfin (+= with acc_fin) -- no splitk_reduce launch
-    unsigned int* tickets; float* Cfin; int ldc_fin; int acc_fin;
     int dbg;                                   // timing ablations (SEGMM_PL_FLAGS; results are wrong when set): 1 no C stores, 2 no epilogue
     unsigned long long* stamps;                // SEGMM_STAMPS builds only (tools/probe/gemm_stamps.py): 8 x u64 per workgroup
 };

@@ -767,46 +767,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_tn8(const GemmArgs p, const PG
             buf_store4(rsC, oCT, (uint32_t)(16 * i + 4 * t) * (uint32_t)p.ldc * 4u, *(const f32x4*)(trp + r * 256 + (((l15 ^ r) & 15) << 4)));
         }
     }
-    // ---- split-K combine inside the kernel: the workgroup that draws the LAST ticket of its output tile adds the tile's slabs, in
-    // slab order (the summation order of splitk_reduce: results are bit-identical to the two-launch form), into the final C and
-    // combines the folded column sums.  Slabs of one tile are written from different XCDs (the block order keeps a TOKEN slab on
-    // one L2): the writers' agent-scope release fence writes their L2 lines back, the reader's acquire fence drops stale lines.
-    if (!split || q.tickets == nullptr) return;
-    __threadfence();
-    __syncthreads();
-    int* flag = (int*)(smem + 2 * PSTAGE - 128);
-    if (tid == 0) {
-        const unsigned int tk = __hip_atomic_fetch_add(q.tickets + lb, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        *flag = tk == gridDim.z - 1 ? 1 : 0;
-    }
-    __syncthreads();
-    if (*flag == 0) return;
-    __threadfence();
-    const int nz = (int)gridDim.z;
-    const float* ws = p.C;                         // slab 0 (p.C was pointed at the workspace)
-    const size_t sstr = (size_t)p.slab_stride;
-#pragma unroll 2
-    for (int idx = tid; idx < PBM * (PBN / 4); idx += 512) {
-        const int r = idx >> 6, c = (idx & 63) << 2;
-        const float* p0 = ws + (size_t)(m0 + r) * p.N + n0 + c;
-        f32x4 sacc = *(const f32x4*)p0;
-        int z = 1;
-        for (; z + 4 <= nz; z += 4) {          // four slab loads in flight, summed in slab order
-            const f32x4 a = *(const f32x4*)(p0 + (size_t)z * sstr), b = *(const f32x4*)(p0 + (size_t)(z + 1) * sstr);
-            const f32x4 c2 = *(const f32x4*)(p0 + (size_t)(z + 2) * sstr), d = *(const f32x4*)(p0 + (size_t)(z + 3) * sstr);
-            sacc += a; sacc += b; sacc += c2; sacc += d;
-        }
-        for (; z < nz; ++z) sacc += *(const f32x4*)(p0 + (size_t)z * sstr);
-        float* dst = q.Cfin + (size_t)(m0 + r) * q.ldc_fin + n0 + c;
-        if (q.acc_fin) sacc += *(const f32x4*)dst;
-        *(f32x4*)dst = sacc;
-    }
-    if (do_colsum && tid < PBM && m0 + tid < p.M) {
-        float sc = 0.f;
-        for (int z = 0; z < nz; ++z) sc += q.colsum_ws[(size_t)z * p.M + m0 + tid];
-        q.colsum_out[m0 + tid] = q.acc_fin ? q.colsum_out[m0 + tid] + sc : sc;
-    }
-    if (tid == 0) q.tickets[lb] = 0u;          // ready for the next launch (ordered by the kernel boundary)
 }
 
 }  // namespace segmm

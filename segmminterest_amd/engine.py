@@ -267,16 +267,6 @@ class ParamStore:
         self._hdr_off += n
         return ring[r0:r0 + n]
 
-    def tickets(self) -> torch.Tensor:
-        """Ticket words of the in-kernel split-K combine (segmm_gemm_p): zero between launches, one array per stream (a
-        weight-gradient GEMM may run on the main and on the side stream at the same time)."""
-        c = self.__dict__.setdefault("_consts", {})
-        key = ("tickets", bool(self._on_side), self.flat.device)
-        t = c.get(key)
-        if t is None:
-            t = c[key] = torch.zeros((H.SPLITK_TICKETS,), dtype=torch.int32, device=self.flat.device)
-        return t
-
     def const_arange(self, n: int, dtype) -> torch.Tensor:
         """arange(n) on the device, made once (never written afterwards)."""
         c = self.__dict__.setdefault("_consts", {})
@@ -755,7 +745,7 @@ def _wgrad(store, dY, y_off, X, x_off, Mrows, n_out, n_in, gW, accumulate=False,
         splits = _splits_for_p(n_out, n_in, Mrows)
         ws = store.buf("splitk_ws_side" if store._on_side else "splitk_ws", (max(splits, 1) * (n_out * n_in + n_out),)) if splits > 1 else None
         H.gemm_p(H.LAYOUT_TN, n_out, n_in, Mrows, dY.pt(y_off, n_out), X.pt(x_off, n_in), gW, n_in, splits=splits, workspace=ws,
-                 accumulate=accumulate, colsum_out=gb, tickets=store.tickets() if splits > 1 else None)
+                 accumulate=accumulate, colsum_out=gb)
         return
     _needs_f32(dY, "the on-the-fly weight-gradient GEMM")
     _needs_f32(X, "the on-the-fly weight-gradient GEMM")
@@ -847,12 +837,10 @@ def _ln_bwd(store, dy, x, mean, rstd, gname, bname, gbuf, dx, dx_drop, rows, d, 
     ps = store.buf("ln_ps:" + gname, (parts, d)) if dsum_to is not None else None
     H.layernorm_bwd(dy, x, mean, rstd, store.p(gname), dx, dx_drop, pg, pb, drop_y_p=drop_y[0], drop_y_site=drop_y[1],
                     drop_b_p=drop_b[0], drop_b_site=drop_b[1], seed=seed, amax=amax, part_dsum=ps, po=po)
+    outs = [store.g(gname, gbuf), store.g(bname, gbuf)] + ([dsum_to] if ps is not None else [])
     with (side_work(store) if store.ln_side else contextlib.nullcontext()):
         ws = store.buf("colsum3_ws_side" if store._on_side else "colsum3_ws", (3 * H.colsum_chunks(parts) * d,))
-        Xs, outs = [pg, pb], [store.g(gname, gbuf), store.g(bname, gbuf)]
-        if ps is not None:
-            Xs.append(ps)
-            outs.append(dsum_to)
+        Xs = [pg, pb] + ([ps] if ps is not None else [])
         H.colsum3(Xs, d, parts, d, outs, ws)          # one launch pair instead of three
 
 

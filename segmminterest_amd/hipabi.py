@@ -30,7 +30,7 @@ SIGNATURES = {
     "segmm_gemm_h": [_i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _p, _i, _f, _u64, _u32, _i, _p, _i,
                      _p, _i64, _p, _i64, _p, _i, _p, _i, _p, _p],
     "segmm_gemm_p": [_i, _i, _i, _i, _p, _i, _p, _p, _i, _p, _i, _p, _p, _i, _p, _i, _p, _i, _p, _p, _i, _p, _p, _p, _i, _i, _i, _p, _i, _f, _u64,
-                     _u32, _i, _p, _i, _p, _p, _p],
+                     _u32, _i, _p, _i, _p, _p],
     "segmm_scales_update": [_p, _p, _i, _p, _p, _i, _p, _p, _p],
     "segmm_probe_mfma_rate": [_i, _i, _p, _p, _p],
     "segmm_attn_mode": [_i],
@@ -331,7 +331,7 @@ def to_planes(x, rows, cols, ld=None, x_off=0, keep_f32=True):
 
 def gemm_p(layout, M, N, K, A: "PT", B: "PT", Cout, ldc, c_pt: "PT" = None, write_c=True, bias=None, row_scale=None, residual=None,
            ldr=0, res_period=0, activation=0, aux=None, ldaux=0, drop_p=0.0, seed=0, site=0, splits=1, workspace=None,
-           accumulate=False, c_off=0, c_hdr=None, c_scale_ptr=None, colsum_out=None, tickets=None):
+           accumulate=False, c_off=0, c_hdr=None, c_scale_ptr=None, colsum_out=None):
     """Plane-operand GEMM (segmm_gemm_p).  ``c_pt``: optional plane output (its hdr[0] holds the scale to write with);
     ``c_hdr``: site header that only receives the partial maxima of |C| (no plane output)."""
     prof = GEMM_PROFILE
@@ -345,7 +345,7 @@ def gemm_p(layout, M, N, K, A: "PT", B: "PT", Cout, ldc, c_pt: "PT" = None, writ
                               int(bool(write_c)),
                               _ptr(bias), _ptr(row_scale), _ptr(residual),
                               ldr, res_period, activation, _ptr(aux), ldaux, float(drop_p), int(seed), int(site), int(splits),
-                              _ptr(workspace), int(bool(accumulate)), _ptr(colsum_out), _ptr(tickets), _stream()), "segmm_gemm_p")
+                              _ptr(workspace), int(bool(accumulate)), _ptr(colsum_out), _stream()), "segmm_gemm_p")
     if prof is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
@@ -357,7 +357,6 @@ def scales_update(arena, site_idx, n_rows, site_scale, stats, target=12, gain=No
                                      _ptr(gain), _ptr(gmax), _stream()), "segmm_scales_update")
 
 
-SPLITK_TICKETS = 1024          # SEGMM_SPLITK_TICKETS: ticket words of an in-kernel split-K combine (segmm_gemm_p)
 LIVE_SEED = 1 << 63          # dropout seed argument bit: XOR the device-side step words into the seed (segmm_step_advance)
 
 
