@@ -449,6 +449,218 @@ __global__ __launch_bounds__(ATT_MAX_THREADS) void attn_fwd_kernel(const AttnArg
                  blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0);
 }
 
+// ------------------------------------------------------------------------------------------ forward, LDS-DMA staged (round 4)
+// The direct-load forward above is bound by LATENCY, not by bytes or MFMAs: every wave walks a dependent chain of ~20 rounds of
+// fragment-shaped global loads (one key tile of K, then of V, one tile prefetched) at 3 waves per SIMD, and the three query-tile
+// waves of a head each fetch all of K and V.  Here ONE workgroup owns one (b, h): its waves first issue the head's whole K / V
+// working set (both key blocks, 54 KB at config 2) as LDS-DMA (`buffer_load ... lds`, 16 B per lane, no registers) -- every load
+// of the head in flight at once, a single round of memory latency -- then wait once (vmcnt(0) + one barrier) and run the same
+// S^T = K Q^T -> softmax -> O^T = V^T P^T arithmetic as above with operands read from LDS in fragment form.  Two to three such
+// workgroups share a CU, so one's staging flies under another's MFMAs.  Q rows (used by one wave only) go straight to registers.
+// LDS image: rows of DH floats at a pitch of DH + 4 floats (an ODD number of 16-byte chunks: the 16 rows of a row-fragment
+// read land in distinct bank groups); the pad chunk of a row and the slack behind an array are DMA'd from an out-of-range
+// offset (zeros).  Arithmetic, masks and dropout stream are those of attn_fwd_kernel; with one key group per query tile the results
+// are bit-identical, with several the softmax sums are merged in another order (differences at the 1e-7 level).
+constexpr uint32_t ATT_BUF_OOB = 0x80000000u;
+__device__ __forceinline__ void att_lds_dma16(__amdgpu_buffer_rsrc_t r, void* lds_wave_base, uint32_t voff, uint32_t soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, (int)soff, 0, 0);
+}
+template <int DH> __host__ __device__ constexpr int att_lds_chunks(int rows) { return ((rows * (DH / 4 + 1)) + 63) & ~63; }      // 16-byte chunks of one staged array
+template <int DH>
+inline size_t attn_fwd_lds_bytes(int La, int Lb) {
+    const int La_p = (La + 15) & ~15, Lb_p = (Lb + 15) & ~15;
+    return (size_t)(2 * att_lds_chunks<DH>(La_p) + 2 * att_lds_chunks<DH>(Lb_p)) * 16 + (size_t)(La_p + Lb_p);
+}
+
+template <int DH, int NT>
+__global__ __launch_bounds__(768) void attn_fwd_lds_kernel(const AttnArgs p) {
+    using C = AttnCfg<DH>;
+    constexpr int PC = DH / 4 + 1, PF = 4 * PC;            // row pitch in 16-byte chunks / in floats
+    const DropCfg drop_ = drop_live(p.drop);
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem_att[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int bh = xcd_remap(blockIdx.x, gridDim.x), b = bh / p.H, h = bh % p.H;
+    const int La_p = round16(p.La), Lb_p = round16(p.Lb), Tp = La_p + Lb_p, nta = La_p >> 4, nt = Tp >> 4;
+    const int col0 = h * DH;
+    const int cha = att_lds_chunks<DH>(La_p), chb = att_lds_chunks<DH>(Lb_p);
+    float* sKa = (float*)smem_att;
+    float* sVa = sKa + 4 * cha;
+    float* sKb = sVa + 4 * cha;
+    float* sVb = sKb + 4 * chb;
+    uint8_t* km = (uint8_t*)(sVb + 4 * chb);
+
+    // ---- wave (qt, kg): 16-query tile qt, key-tile group kg of ksp -- the key tiles t = kg, kg + ksp, ... are this wave's, the
+    // groups' partial softmax sums meet in LDS at the end.  More waves per head on the same staged K / V: with one wave per query
+    // tile the compute phase (a chain of ds_read -> MFMA -> softmax -> MFMA per wave at ~1 wave per SIMD) was twice the staging.
+    const int nqt = (p.Lq + 15) >> 4, ksp = nw / nqt;
+    const int qt = wave % nqt, kg = wave / nqt;
+    const int qi = 16 * qt + l15;
+    const bool q_in = qi < p.Lq;
+    const size_t qrow = (size_t)b * p.Lq + min(qi, p.Lq - 1);
+    float qa[C::KS], qb[C::KS];
+    frag_load_ptr<DH>(qa, p.Qa + qrow * p.ldq + col0 + C::row_off(g));
+    frag_load_ptr<DH>(qb, p.Qb + qrow * p.ldq + col0 + C::row_off(g));
+    const bool q_ok = q_in && p.mq[qrow] != 0;
+
+    // ---- stage K and V of both key blocks: chunk pch of an array = (row pch / PC, 16-byte piece pch % PC); a wave issues whole
+    // 64-chunk groups (1 KB of LDS per instruction, lane i at base + 16 i)
+    auto stage = [&](const float* base, uint32_t bytes, int L, int Lp, int ld, float* dst, int nchunks) {
+        if (Lp == 0) return;
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(base, bytes);
+        const uint32_t so = ((uint32_t)(b * L) * (uint32_t)ld + (uint32_t)col0) * 4u;
+        const int total = Lp * PC;
+        for (int c0 = 64 * wave; c0 < nchunks; c0 += 64 * nw) {
+            const int pch = c0 + lane, row = pch / PC, c = pch - row * PC;
+            uint32_t vo = (uint32_t)row * (uint32_t)ld * 4u + (uint32_t)c * 16u;
+            if (c == PC - 1 || pch >= total) vo = ATT_BUF_OOB;          // pad chunk of a row / slack behind the array: zeros
+            att_lds_dma16(rs, (char*)dst + (size_t)c0 * 16, vo, so);
+        }
+    };
+    if (!(p.pflags & 512)) {          // (timing probes, SEGMM_ATT_FWD_DBG: 256 = return after the staging, 512 = no staging; results wrong)
+        stage(p.Ka, p.ka_bytes, p.La, La_p, p.ldka, sKa, cha);
+        stage(p.Kb, p.kb_bytes, p.Lb, Lb_p, p.ldkb, sKb, chb);
+        stage(p.Va, p.ka_bytes, p.La, La_p, p.ldka, sVa, cha);
+        stage(p.Vb, p.kb_bytes, p.Lb, Lb_p, p.ldkb, sVb, chb);
+    }
+    stage_kmask(km, p.mka, p.mkb, b, p.La, p.Lb, La_p, Lb_p);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (p.pflags & 256) return;
+
+    // ---- S^T tiles from LDS: acc[u][r] = sum_c K[16t + 4g + r][c] Q[query][c], t = ksp u + kg
+    f32x4 acc[NT];
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+        acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int t = ksp * u + kg;
+        if (t < nt) {
+            const float* kr = (t < nta ? sKa + (16 * t + l15) * PF : sKb + (16 * (t - nta) + l15) * PF) + C::row_off(g);
+            float kf[C::KS];
+            if (C::KS % 4 == 0) {
+#pragma unroll
+                for (int i = 0; i < C::KS / 4; ++i) {
+                    const f32x4 v = *(const f32x4*)(kr + 16 * i);
+                    kf[4 * i] = v.x; kf[4 * i + 1] = v.y; kf[4 * i + 2] = v.z; kf[4 * i + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < C::KS; ++i) kf[i] = kr[i];
+            }
+            if (t < nta) {
+#pragma unroll
+                for (int c = 0; c < C::KS; ++c) acc[u] = MFMA16(kf[c], qa[c], acc[u]);
+            } else {
+#pragma unroll
+                for (int c = 0; c < C::KS; ++c) acc[u] = MFMA16(kf[c], qb[c], acc[u]);
+            }
+        }
+    }
+    // mask fill, dropout, scale; acc[u][r] is key jp = 16t + 4g + r of query qi
+    float mx = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+        const int t = ksp * u + kg;
+        if (t < nt) {
+            const uint32_t kb = *(const uint32_t*)(km + 16 * t + 4 * g);
+            f32x4 mult = {1.f, 1.f, 1.f, 1.f};
+            if (drop_.p > 0.f)
+                mult = drop_apply4(drop_, (((uint64_t)bh * p.Lq + (q_in ? qi : 0)) * Tp + 16 * t + 4 * g) >> 2,
+                                   f32x4{1.f, 1.f, 1.f, 1.f});
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t k = (kb >> (8 * r)) & 0xff;
+                float v = logit_xform(acc[u][r], q_ok && k == 1, mult[r], p.scale);
+                if (k == 2) v = -INFINITY;
+                acc[u][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+        if (ksp * u + kg < nt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = fast_exp(acc[u][r] - mx);          // (a wave with no tile: mx = -inf, never evaluated)
+                acc[u][r] = e;
+                sum += e;
+            }
+        }
+    }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    // O^T[c][query] = sum_key V[key][c] P^T[key][query] (unnormalised: e = exp(logit - mx)); step s of tile t contracts keys 16t + 4g + s
+    f32x4 o[C::CT];
+#pragma unroll
+    for (int ct = 0; ct < C::CT; ++ct) o[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+        const int t = ksp * u + kg;
+        if (t < nt) {
+            const float* vr = (t < nta ? sVa + (16 * t + 4 * g) * PF : sVb + (16 * (t - nta) + 4 * g) * PF) + C::CT * l15;
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) {
+                float vf[C::CT];
+                if (C::CT * l15 < DH) {
+#pragma unroll
+                    for (int ct = 0; ct < C::CT; ++ct) vf[ct] = vr[s_ * PF + ct];
+                } else {
+#pragma unroll
+                    for (int ct = 0; ct < C::CT; ++ct) vf[ct] = 0.f;
+                }
+                const float pb = acc[u][s_];            // e^T[key 16t+4g+s][query]
+#pragma unroll
+                for (int ct = 0; ct < C::CT; ++ct) o[ct] = MFMA16(vf[ct], pb, o[ct]);
+            }
+        }
+    }
+    // ---- merge the key groups of a query tile (ksp > 1): partials through LDS (the staged K / V are dead by now); group 0 combines
+    // in group order (deterministic): m = max_k m_k, sum = sum_k s_k e^(m_k - m), O = sum_k O_k e^(m_k - m)
+    if (ksp > 1) {
+        __syncthreads();                                   // every wave is done reading K / V
+        float* part = (float*)smem_att + (size_t)wave * (64 * 4 * C::CT + 128);          // [CT][64 lanes] float4 | mx[64] | sum[64]
+#pragma unroll
+        for (int ct = 0; ct < C::CT; ++ct) *(f32x4*)(part + (ct * 64 + lane) * 4) = o[ct];
+        part[64 * 4 * C::CT + lane] = mx;
+        part[64 * 4 * C::CT + 64 + lane] = sum;
+        __syncthreads();
+        if (kg != 0) return;
+        float m = mx;
+        for (int k = 1; k < ksp; ++k) m = fmaxf(m, ((const float*)smem_att)[(size_t)(k * nqt + qt) * (64 * 4 * C::CT + 128) + 64 * 4 * C::CT + lane]);
+        const float f0 = fast_exp(mx - m);
+        sum *= f0;
+#pragma unroll
+        for (int ct = 0; ct < C::CT; ++ct) o[ct] *= f0;
+        for (int k = 1; k < ksp; ++k) {
+            const float* pk = (const float*)smem_att + (size_t)(k * nqt + qt) * (64 * 4 * C::CT + 128);
+            const float mk = pk[64 * 4 * C::CT + lane];
+            const float fk = mk == -INFINITY ? 0.f : fast_exp(mk - m);          // a group without tiles contributes nothing
+            sum += pk[64 * 4 * C::CT + 64 + lane] * fk;
+#pragma unroll
+            for (int ct = 0; ct < C::CT; ++ct) o[ct] += *(const f32x4*)(pk + (ct * 64 + lane) * 4) * fk;
+        }
+        mx = m;
+    }
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int ct = 0; ct < C::CT; ++ct) o[ct] *= inv;
+    if (g == 0 && q_in) {
+        p.lse[(size_t)bh * p.Lq + qi] = mx;
+        p.lse[(size_t)p.B * p.H * p.Lq + (size_t)bh * p.Lq + qi] = inv;
+    }
+    float am = 0.f;
+    const float ps = plane_scale(p.po_o);
+    if (q_in) {
+        if (ps > 0.f) am = col_store_p<DH>(p.O + qrow * p.ldo + col0, p.po_o.p, p.po_o.ld2, (long long)qrow, col0, ps, o, g, am);
+        else am = col_store<DH>(p.O + qrow * p.ldo + col0, o, g, am);
+    }
+    plane_finish(p.po_o, p.amax_o, am, blockIdx.x * nw + wave, ps, blockIdx.x == 0 && threadIdx.x == 0);
+}
+
 // ------------------------------------------------------------------------------------------ backward: dQ (+ D)
 // D[q] = sum_j P[q][j] dP[q][j] = sum_c dO[q][c] O[q][c] (O = P.V with the very same P), so with the saved forward
 // output the kernel is ONE pass over the key tiles with nothing but the dQ accumulators carried along:

@@ -111,6 +111,43 @@ static int attn_launch_fwd(AttnArgs& a, hipStream_t s) {
     const int nqt = (a.Lq + 15) / 16;
     int wq, hpb;
     attn_shape(nqt, a.H, 5, 1, "SEGMM_ATT_HPB_FWD", wq, hpb);          // measured: grouping heads does not pay in the forward
+    // round 4: the LDS-DMA staged form (one workgroup per head: K / V of both key blocks staged once, every load of the head in
+    // flight at once -- the staging alone runs at 5.7 TB/s) for heads with MORE than three query tiles: there one workgroup brings
+    // enough waves (>= 4 per head, two heads per CU) to cover the per-wave instruction chains -- Lq = 100 (user queries of the full
+    // layers of N >= 3 models): 523 -> 430 us.  At Lq = 40 (three waves per head, six per CU: the staged K / V of a head are 66 KB,
+    // so two heads is what a CU holds) the compute phase alone takes 200 us -- issue-bound chains at 1.3 waves per SIMD, PMC in
+    // profiles/r4/attention_fwd_lds_pmc.txt -- against 233 us for the whole direct-load kernel at 3.3 waves per SIMD, and splitting
+    // the key tiles over two or three wave groups per query tile (SEGMM_ATT_FWD_KSPLIT) does not change that: the direct form stays.
+    // SEGMM_ATT_FWD_LDS=0 / 2: never / wherever it fits (A/B, tests).
+    const char* fwd_env = getenv("SEGMM_ATT_FWD_LDS");          // read per call: the tests switch forms inside one process
+    const int fwd_lds = fwd_env ? atoi(fwd_env) : 1;
+    if constexpr (DH >= 16) {
+        const size_t lds2 = attn_fwd_lds_bytes<DH>(a.La, a.Lb);
+        if ((fwd_lds == 2 || (fwd_lds == 1 && nqt >= 4)) && nqt <= 8 && lds2 <= 80 * 1024) {
+            // key-tile groups per query tile (waves per head = nqt * ksp <= 12): more waves on the same staged K / V
+            const char* ksp_env = getenv("SEGMM_ATT_FWD_KSPLIT");
+            int ksp = ksp_env ? atoi(ksp_env) : 1;
+            const int ntile = Tp / 16;
+            if (ksp > ntile) ksp = ntile;
+            if (ksp < 1 || nqt * ksp > 12) ksp = 1;
+            const dim3 grid2(a.B * a.H), block2(64 * nqt * ksp);
+            const size_t merge = ksp > 1 ? (size_t)nqt * ksp * (64 * 4 * ((DH + 15) / 16) + 128) * 4 : 0;          // partials of the key groups
+            const size_t lds3 = lds2 > merge ? lds2 : merge;
+            if (getenv("SEGMM_ATT_FWD_DBG")) a.pflags |= atoi(getenv("SEGMM_ATT_FWD_DBG")) & (256 | 512);
+            static bool lds_optin = false;          // dynamic LDS above 64 KB needs the opt-in, once per kernel
+            if (!lds_optin) {
+                hipFuncSetAttribute((const void*)attn_fwd_lds_kernel<DH, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                hipFuncSetAttribute((const void*)attn_fwd_lds_kernel<DH, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                hipFuncSetAttribute((const void*)attn_fwd_lds_kernel<DH, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                lds_optin = true;
+            }
+            if (Tp <= 64) hipLaunchKernelGGL((attn_fwd_lds_kernel<DH, 4>), grid2, block2, lds3, s, a);
+            else if (Tp <= 160) hipLaunchKernelGGL((attn_fwd_lds_kernel<DH, 10>), grid2, block2, lds3, s, a);
+            else hipLaunchKernelGGL((attn_fwd_lds_kernel<DH, 12>), grid2, block2, lds3, s, a);
+            LAUNCH_CHECK();
+            return 0;
+        }
+    }
     a.hpb = hpb;
     dim3 grid(a.B * a.H / hpb, (nqt + wq - 1) / wq), block(64 * wq * hpb);       // one wave per 16-query tile of a head
     static const int fpad = getenv("SEGMM_ATT_FWD_LDS_PAD") ? atoi(getenv("SEGMM_ATT_FWD_LDS_PAD")) : 0;      // probe: fewer workgroups per CU

@@ -337,6 +337,49 @@ def test_attention_fwd_bwd(B, H_, dh, Lq, La, Lb):
         assert err < 5e-5, (name, err)
 
 
+@pytest.mark.parametrize("B,H_,dh,Lq,La,Lb,p", [(4, 16, 48, 40, 40, 100, 0.1), (3, 4, 16, 40, 40, 10, 0.0), (2, 16, 48, 100, 40, 100, 0.1),
+                                                (5, 8, 32, 20, 20, 1, 0.1), (2, 2, 64, 40, 40, 10, 0.0), (3, 4, 48, 40, 0, 100, 0.1),
+                                                (3, 4, 48, 40, 40, 0, 0.1), (2, 4, 32, 7, 40, 7, 0.0)])
+def test_attention_fwd_lds_staged_form_equals_direct_form(B, H_, dh, Lq, La, Lb, p):
+    """The LDS-DMA staged forward (one workgroup per head, K / V staged once; the default where it fits) against the direct-load
+    form (SEGMM_ATT_FWD_LDS=0): same arithmetic, masks and dropout stream.  With ONE key group per query tile
+    (SEGMM_ATT_FWD_KSPLIT=1) O and the softmax statistics are BIT-IDENTICAL; with the default key split the groups' softmax sums
+    are merged in another order: equal to 2e-6 of the maximum.  Operands are column slices of fused projection buffers (the engine's layout), with NaN poison around them: a staging bug
+    that reads a neighbouring column or row shows up at once."""
+    H = _abi()
+    d = H_ * dh
+    g = torch.Generator().manual_seed(B * 77 + Lq)
+    Yv = (torch.randn(B * max(La, 1), 4 * d, generator=g) * 0.7).to(DEV)
+    Yu = (torch.randn(B * max(Lb, 1), 2 * d, generator=g) * 0.7).to(DEV)
+    Qs = Yv if Lq == La else (torch.randn(B * Lq, 4 * d, generator=g) * 0.7).to(DEV)
+    mq = (torch.rand(B, Lq, generator=g) < 0.8).to(DEV)
+    mka = (torch.rand(B, max(La, 1), generator=g) < 0.8).to(DEV)
+    mkb = (torch.rand(B, max(Lb, 1), generator=g) < 0.7).to(DEV)
+    outs = {}
+    for form in ("0", "1", "k1"):          # direct | staged with the key tiles split over wave groups | staged, one group
+        os.environ["SEGMM_ATT_FWD_LDS"] = "0" if form == "0" else "2"
+        os.environ["SEGMM_ATT_FWD_KSPLIT"] = "1" if form == "k1" else "2"
+        try:
+            O = torch.full((B * Lq, d), float("nan"), device=DEV)
+            lse = torch.full((2, B, H_, Lq), float("nan"), device=DEV)
+            am = torch.zeros(H.AMAX_SLOTS, device=DEV)
+            H.attn_fwd(B, H_, dh, Lq, La, Lb, (Qs, 0), (Qs, d), 4 * d, (Yv, 2 * d) if La else None, (Yv, 3 * d) if La else None, 4 * d,
+                       (Yu, 0) if Lb else None, (Yu, d) if Lb else None, 2 * d, mq, mka[:, :La] if La else None, mkb[:, :Lb] if Lb else None,
+                       O, d, lse, drop_p=p, seed=11, site=3, amax_o=am)
+            outs[form] = (O, lse, am)
+        finally:
+            os.environ.pop("SEGMM_ATT_FWD_LDS", None)
+            os.environ.pop("SEGMM_ATT_FWD_KSPLIT", None)
+    assert torch.isfinite(outs["1"][0]).all() and torch.isfinite(outs["1"][1]).all()
+    assert torch.equal(outs["0"][0], outs["k1"][0]) and torch.equal(outs["0"][1], outs["k1"][1])
+    assert float(outs["0"][2].max()) == float(outs["k1"][2].max()) == float(outs["k1"][0].abs().max())      # (slot positions differ)
+    omax = float(outs["0"][0].abs().max())
+    assert float((outs["0"][0] - outs["1"][0]).abs().max()) <= 2e-6 * omax
+    assert float((outs["0"][1][0] - outs["1"][1][0]).abs().max()) <= 1e-6 * float(outs["0"][1][0].abs().max())                       # row maxima
+    assert float(((outs["0"][1][1] - outs["1"][1][1]) / outs["0"][1][1]).abs().max()) <= 2e-6                                       # 1 / row sums
+    assert float(outs["1"][2].max()) == float(outs["1"][0].abs().max())
+
+
 def test_attention_dropout_consistency():
     """Train-mode logits dropout: forward equals the reference with the kernel's own mask; the
     backward regenerates the same mask (checked against autograd through that mask)."""
