@@ -337,6 +337,53 @@ int segmm_colsum3(const float* X0, const float* X1, const float* X2, int ld, int
 int segmm_pool_tokens(const float* U, int Lu, const float* V, int Lv, float* out, int B, int d, int bins, segmm_stream_t stream);
 int segmm_pool_tokens_bwd(const float* dOut, float* dU, int Lu, float* dV, int Lv, int B, int d, int bins, segmm_stream_t stream);
 
+/* ---- Recorded launch sequences: the training step (main_for_seq_leave_earlystop_SegMM.py:265-300) enqueued from C -----------
+ * SURVEY.md 8(b) asks for coarse entry points (embedding, encoder layer, head + loss, optimizer tail) so that a host language
+ * does not pay a foreign-function call per kernel.  A PHASE is the resolved launch list of one such part of the step: an array
+ * of commands, each naming one stream-taking entry point of this header (op = index into segmm_cmd_op_name) with its arguments
+ * in declaration order as 8-byte slots (pointers and integers in .i / .p, float parameters as double in .f) and the stream slot
+ * it is enqueued on (0 = main, 1 = side stream).  Two pseudo-ops order the two streams: SEGMM_OP_FORK (the side stream waits
+ * for everything enqueued on the main stream so far) and SEGMM_OP_JOIN (the main stream waits for the side stream).
+ * The host builds a phase ONCE per workload shape -- segmminterest_amd/hipabi.py records the per-op calls of one eager step --
+ * and replays it every step: kernel arguments do not change from step to step when the per-step state lives on the device
+ * (segmm_step_advance: dropout seed words, optimizer step count) and buffers are persistent; the few that do (the batch's
+ * tensors) are patched in place by the host before the call.  Ownership: the command array, structs and host arrays its
+ * pointer arguments name (segmm_attn_planes_t, the loss coefficient arrays) belong to the caller and must outlive the call.
+ * segmm_run_phase returns the first non-zero return code of a command (0 = everything enqueued); it never synchronises.
+ * The named entry points are segmm_run_phase restricted to one kind of phase (they refuse a descriptor of another kind):
+ * they are what a maintainer binds per part of the reference's step -- _get_embedding (encoder.py:425-473), one
+ * SegFormerXEncoderLayer (encoder.py:189-208) forward / backward, head + compute_loss (decoder_leave_focal.py:490-658),
+ * optimizer.step (main...SegMM.py:299). */
+#define SEGMM_CMD_MAX_ARGS 48
+typedef union { int64_t i; double f; void* p; } segmm_arg_t;
+typedef struct { int32_t op; int32_t stream; segmm_arg_t a[SEGMM_CMD_MAX_ARGS]; } segmm_cmd_t;
+#define SEGMM_OP_FORK (-1)
+#define SEGMM_OP_JOIN (-2)
+enum { SEGMM_PHASE_STEP_BEGIN = 0, SEGMM_PHASE_EMBED_FWD = 1, SEGMM_PHASE_LAYER_FWD = 2, SEGMM_PHASE_HEAD_LOSS_FWD = 3,
+       SEGMM_PHASE_HEAD_LOSS_BWD = 4, SEGMM_PHASE_LAYER_BWD = 5, SEGMM_PHASE_EMBED_BWD = 6, SEGMM_PHASE_STEP_TAIL = 7, SEGMM_PHASE_KINDS = 8 };
+typedef struct {
+    int32_t kind;          /* SEGMM_PHASE_* */
+    int32_t backbone;      /* 0 / 1: which backbone of a two-tower ('both') model; 0 otherwise */
+    int32_t layer;         /* encoder layer of a LAYER_* phase, else 0 */
+    int32_t n_cmds;
+    const segmm_cmd_t* cmds;
+} segmm_phase_t;
+/* number of dispatchable entry points / the name of op `op` (NULL outside [0, n)): hosts map names to op ids at load time */
+int segmm_cmd_op_count(void);
+const char* segmm_cmd_op_name(int op);
+/* ev_fork / ev_join: two hipEvent_t of the caller (disable-timing events), used by the fork / join pseudo-ops */
+int segmm_run_phase(const segmm_phase_t* phase, segmm_stream_t main_stream, segmm_stream_t side_stream, void* ev_fork, void* ev_join);
+int segmm_step_begin(const segmm_phase_t* phase, segmm_stream_t main_stream, segmm_stream_t side_stream, void* ev_fork, void* ev_join);
+int segmm_embed_fwd(const segmm_phase_t* phase, segmm_stream_t main_stream, segmm_stream_t side_stream, void* ev_fork, void* ev_join);
+int segmm_layer_fwd(const segmm_phase_t* phase, segmm_stream_t main_stream, segmm_stream_t side_stream, void* ev_fork, void* ev_join);
+int segmm_head_loss_fwd(const segmm_phase_t* phase, segmm_stream_t main_stream, segmm_stream_t side_stream, void* ev_fork, void* ev_join);
+int segmm_head_loss_bwd(const segmm_phase_t* phase, segmm_stream_t main_stream, segmm_stream_t side_stream, void* ev_fork, void* ev_join);
+int segmm_layer_bwd(const segmm_phase_t* phase, segmm_stream_t main_stream, segmm_stream_t side_stream, void* ev_fork, void* ev_join);
+int segmm_embed_bwd(const segmm_phase_t* phase, segmm_stream_t main_stream, segmm_stream_t side_stream, void* ev_fork, void* ev_join);
+int segmm_step_tail(const segmm_phase_t* phase, segmm_stream_t main_stream, segmm_stream_t side_stream, void* ev_fork, void* ev_join);
+/* bytes of p[0 .. bytes) = 0 on `stream` (the clears of the step path as a recordable command) */
+int segmm_fill_zero(void* p, int64_t bytes, segmm_stream_t stream);
+
 /* test hook: multiplier (0 or 1/(1-p)) of elements [0,n) of a dropout site */
 int segmm_dropout_mult(float* out, int64_t n, float p, uint64_t seed, uint32_t site, segmm_stream_t stream);
 

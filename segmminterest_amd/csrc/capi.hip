@@ -136,9 +136,9 @@ static int attn_launch_fwd(AttnArgs& a, hipStream_t s) {
             if (getenv("SEGMM_ATT_FWD_DBG")) a.pflags |= atoi(getenv("SEGMM_ATT_FWD_DBG")) & (256 | 512);
             static bool lds_optin = false;          // dynamic LDS above 64 KB needs the opt-in, once per kernel
             if (!lds_optin) {
-                hipFuncSetAttribute((const void*)attn_fwd_lds_kernel<DH, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                hipFuncSetAttribute((const void*)attn_fwd_lds_kernel<DH, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                hipFuncSetAttribute((const void*)attn_fwd_lds_kernel<DH, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void*)attn_fwd_lds_kernel<DH, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void*)attn_fwd_lds_kernel<DH, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void*)attn_fwd_lds_kernel<DH, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 lds_optin = true;
             }
             if (Tp <= 64) hipLaunchKernelGGL((attn_fwd_lds_kernel<DH, 4>), grid2, block2, lds3, s, a);
@@ -345,7 +345,7 @@ __global__ void step_get_kernel(StepState* out) { *out = g_step; }
 extern "C" {
 
 const char* segmm_last_error(void) { return g_segmm_err; }
-int segmm_abi_version(void) { return 20; }
+int segmm_abi_version(void) { return 21; }
 int segmm_attn_mode(int mode) { const int prev = attn_f16(); if (mode >= 0 && mode <= 2) g_attn_mode = mode; return prev; }
 
 static PlaneOut plane_out(uint16_t* planes, int ld2, float* hdr, const float* scale_in) {
@@ -1218,5 +1218,56 @@ int segmm_probe_mfma_rate(int workgroups, int iters, float* scratch, double* flo
     if (flops_out) *flops_out = (double)workgroups * 8.0 * iters * 96.0 * 16384.0;          // 96 MFMAs of 16 x 16 x 32 per wave and iteration
     return 0;
 }
+
+/* ---- recorded launch sequences (include/segmm_hip.h: "Recorded launch sequences") */
+int segmm_fill_zero(void* p, int64_t bytes, segmm_stream_t stream) {
+    SEGMM_REQUIRE(p && bytes >= 0, "fill_zero: null pointer / negative size");
+    if (bytes == 0) return 0;
+    const hipError_t e = hipMemsetAsync(p, 0, (size_t)bytes, (hipStream_t)stream);
+    SEGMM_REQUIRE(e == hipSuccess, "fill_zero: hipMemsetAsync: %s", hipGetErrorString(e));
+    return 0;
+}
+
+#include "cmd_dispatch.inc"
+
+int segmm_cmd_op_count(void) { return SEGMM_N_CMD_OPS; }
+const char* segmm_cmd_op_name(int op) { return (op >= 0 && op < SEGMM_N_CMD_OPS) ? segmm_cmd_names[op] : nullptr; }
+
+int segmm_run_phase(const segmm_phase_t* ph, segmm_stream_t main_stream, segmm_stream_t side_stream, void* ev_fork, void* ev_join) {
+    SEGMM_REQUIRE(ph && ph->n_cmds >= 0 && (ph->n_cmds == 0 || ph->cmds), "run_phase: null descriptor");
+    SEGMM_REQUIRE(ph->kind >= 0 && ph->kind < SEGMM_PHASE_KINDS, "run_phase: phase kind %d", ph->kind);
+    for (int i = 0; i < ph->n_cmds; ++i) {
+        const segmm_cmd_t& c = ph->cmds[i];
+        SEGMM_REQUIRE(c.stream == 0 || c.stream == 1, "run_phase: command %d names stream slot %d (0 main, 1 side)", i, c.stream);
+        if (c.op == SEGMM_OP_FORK || c.op == SEGMM_OP_JOIN) {
+            SEGMM_REQUIRE(side_stream && ev_fork && ev_join, "run_phase: a fork / join command needs the side stream and both events");
+            const bool fork = c.op == SEGMM_OP_FORK;
+            hipEvent_t ev = (hipEvent_t)(fork ? ev_fork : ev_join);
+            hipError_t e = hipEventRecord(ev, (hipStream_t)(fork ? main_stream : side_stream));
+            if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)(fork ? side_stream : main_stream), ev, 0);
+            SEGMM_REQUIRE(e == hipSuccess, "run_phase: command %d (%s): %s", i, fork ? "fork" : "join", hipGetErrorString(e));
+            continue;
+        }
+        SEGMM_REQUIRE(c.op >= 0 && c.op < SEGMM_N_CMD_OPS, "run_phase: command %d has op %d (0 .. %d)", i, c.op, SEGMM_N_CMD_OPS - 1);
+        SEGMM_REQUIRE(c.stream == 0 || side_stream, "run_phase: command %d is for the side stream, none given", i);
+        const int rc = segmm_cmd_dispatch(c.op, c.a, c.stream == 0 ? main_stream : side_stream);
+        if (rc != 0) return rc;          // (segmm_last_error holds the failing entry point's message)
+    }
+    return 0;
+}
+#define SEGMM_PHASE_ENTRY(fn, KIND)                                                                                                   \
+    int fn(const segmm_phase_t* ph, segmm_stream_t main_stream, segmm_stream_t side_stream, void* ev_fork, void* ev_join) {           \
+        SEGMM_REQUIRE(ph && ph->kind == KIND, #fn ": the descriptor is not a " #KIND " phase");                                       \
+        return segmm_run_phase(ph, main_stream, side_stream, ev_fork, ev_join);                                                       \
+    }
+SEGMM_PHASE_ENTRY(segmm_step_begin, SEGMM_PHASE_STEP_BEGIN)
+SEGMM_PHASE_ENTRY(segmm_embed_fwd, SEGMM_PHASE_EMBED_FWD)
+SEGMM_PHASE_ENTRY(segmm_layer_fwd, SEGMM_PHASE_LAYER_FWD)
+SEGMM_PHASE_ENTRY(segmm_head_loss_fwd, SEGMM_PHASE_HEAD_LOSS_FWD)
+SEGMM_PHASE_ENTRY(segmm_head_loss_bwd, SEGMM_PHASE_HEAD_LOSS_BWD)
+SEGMM_PHASE_ENTRY(segmm_layer_bwd, SEGMM_PHASE_LAYER_BWD)
+SEGMM_PHASE_ENTRY(segmm_embed_bwd, SEGMM_PHASE_EMBED_BWD)
+SEGMM_PHASE_ENTRY(segmm_step_tail, SEGMM_PHASE_STEP_TAIL)
+#undef SEGMM_PHASE_ENTRY
 
 }  // extern "C"

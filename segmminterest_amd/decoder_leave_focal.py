@@ -75,6 +75,7 @@ class HeadLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, want_loss, v1, v2, gt, *params):
         st = model._store
+        H.mark(H.PHASE_HEAD_LOSS_FWD)
         B, S, d = v1.shape
         M = B * S
         v1c = v1.contiguous()
@@ -132,6 +133,7 @@ class HeadLossFn(torch.autograd.Function):
         names = model._head_param_names()
         if g_total is None:          # the loss took no part in the differentiated scalar
             return (None,) * (5 + len(names))
+        H.mark(H.PHASE_HEAD_LOSS_BWD)
         gbuf = E._pick_gbuf(st, names)
         unit = getattr(model, "_unit_grad", None)
         # the trainer's constant-one seed (Trainer.train_step) also selects the direct gradient delivery for the whole backward
@@ -141,9 +143,10 @@ class HeadLossFn(torch.autograd.Function):
             dl = ctx.dlogits.view(M)          # d loss / d loss == 1
         else:
             dl = (ctx.dlogits * g_total).view(M)
-        dv1 = torch.empty(M, d, device=v1.device)
-        dv2 = torch.empty(M, d, device=v1.device) if v2 is not None else None
-        model._head_bwd(v1, v2, dl, dv1, dv2, ctx.T, M, d, B, S, gbuf)
+        with st.rec_pool():
+            dv1 = torch.empty(M, d, device=v1.device)
+            dv2 = torch.empty(M, d, device=v1.device) if v2 is not None else None
+            model._head_bwd(v1, v2, dl, dv1, dv2, ctx.T, M, d, B, S, gbuf)
         if gbuf is None and st.bucket_hook is not None:
             st.bucket_hook("head", after_side=st.head_side)
         ctx.dlogits = ctx.T = None
@@ -342,8 +345,8 @@ class MultiScaleTemporalDetrLeaveFocal(nn.Module):
             gbb = st.g("bias_bias", gbuf)
             gbw = st.g("bias_weight", gbuf)
             if Sb != S:
-                gbb.zero_()
-                gbw.zero_()
+                H.fill_zero(gbb)
+                H.fill_zero(gbw)
             E._colsum(st, dl, S, B, S, gbb)
             pos = torch.arange(1, S + 1, device=dl.device, dtype=torch.float32)
             gbw.view(-1)[:S].copy_(gbb.view(-1)[:S] * pos)

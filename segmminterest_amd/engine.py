@@ -237,7 +237,7 @@ class ParamStore:
             arena = self._hdr_arena = torch.zeros((self.HDR_RING_ROWS, H.SITE_FLOATS), dtype=torch.float32, device=dev)
             self._arena_used = 0
         elif self._arena_used:
-            arena[:self._arena_used].zero_()
+            H.fill_zero(arena[:self._arena_used])
         self._arena_off, self._arena_used = 0, 0
         self.step_arena = True
 
@@ -262,10 +262,17 @@ class ParamStore:
             self._hdr_q, self._hdr_off = 0, 0
         if self._hdr_off + n > q:          # the rest of this quarter is too small: enter the next one, clearing it first
             self._hdr_q, self._hdr_off = (self._hdr_q + 1) % 4, 0
-            ring[self._hdr_q * q:(self._hdr_q + 1) * q].zero_()
+            H.fill_zero(ring[self._hdr_q * q:(self._hdr_q + 1) * q])
         r0 = self._hdr_q * q + self._hdr_off
         self._hdr_off += n
         return ring[r0:r0 + n]
+
+    def rec_pool(self):
+        """Allocation context of a step that is being RECORDED (Trainer.record): every tensor the step allocates comes from a
+        private memory pool that is kept for the life of the recording, so the addresses the recorded commands name stay
+        reserved for the replays.  (torch's pool context is per thread: the autograd engine runs the backward on its own.)"""
+        pool = self.__dict__.get("_rec_pool")
+        return torch.cuda.use_mem_pool(pool) if (pool is not None and H.RECORDER is not None) else contextlib.nullcontext()
 
     def const_arange(self, n: int, dtype) -> torch.Tensor:
         """arange(n) on the device, made once (never written afterwards)."""
@@ -612,6 +619,8 @@ def side_work(store):
     ev = torch.cuda.Event()
     ev.record(main)
     side.wait_event(ev)
+    if H.RECORDER is not None:
+        H.RECORDER.pseudo(H.OP_FORK)
     store._on_side = True
     try:
         with torch.cuda.stream(side):
@@ -642,6 +651,8 @@ def flush_deferred(store, deferred):
 def join_side(store):
     if store.overlap and store._side_stream is not None:
         torch.cuda.current_stream().wait_stream(store._side_stream)
+        if H.RECORDER is not None:
+            H.RECORDER.pseudo(H.OP_JOIN)
 
 
 class Act:
@@ -962,6 +973,7 @@ class BackboneRun:
         # interactions/s -- the GEMMs of both chains share the same power-limited matrix pipes, so the knob is OFF by default.
         # Every buffer is allocated HERE, on the main stream (the caching allocator must never hand a side-stream block to
         # the next step while main-stream kernels of this step still read it).
+        H.mark(H.PHASE_EMBED_FWD, self.bi)
         pre_u = _empty(ref, Mu, d)
         meu, reu = _empty(ref, Mu), _empty(ref, Mu)
         Eu = new_act(st, am, Mu, d, planes=usr_is_operand, site=P + "Eu", delayed=self.delayed)
@@ -1024,6 +1036,7 @@ class BackboneRun:
             am.close(st)
             return out.view(B, -1, d), Eu.t.view(B, Lt, d)
         for i in range(max(self.N - 1, 0)):
+            H.mark(H.PHASE_LAYER_FWD, self.bi, i)
             Xv, Xu = self._layer_fwd(i, Xv, Xu, Yu_ready=Yu0 if i == 0 else None)
         am.close(st)
         return Xv.t.view(B, S, d), Eu.t.view(B, Lt, d)
@@ -1332,6 +1345,7 @@ class BackboneRun:
                 on_bucket(P + "mlp", after_side=True)
         else:
             for i in reversed(range(max(self.N - 1, 0))):
+                H.mark(H.PHASE_LAYER_BWD, self.bi, i)
                 dXv, dXu = self._layer_bwd(i, sv["layers"][i], dXv, dXu, gbuf)
                 if on_bucket is not None:
                     # no join: the hook issues the bucket's all-reduce from the side stream's context (ordered behind both
@@ -1339,6 +1353,7 @@ class BackboneRun:
                     on_bucket("%slayer%d" % (P, i), after_side=True)
         # ---- embedding backward.  User side first: its weight gradient (the larger one) queues on the side stream
         # behind the projection weight gradients still running there, the video side's runs on the main stream.
+        H.mark(H.PHASE_EMBED_BWD, self.bi)
         if dXu is not None:
             dpre_u = new_act(st, self.amb, Mu, d, key="dpre_u", planes=not bb.id_usr, site=P + "dpre_u", delayed=self.delayed)
             _ln_bwd(st, dXu, sv["pre_u"], sv["meu"], sv["reu"], P + "usr_ln.weight", P + "usr_ln.bias", gbuf, dpre_u.t, None, Mu, d,
@@ -1371,7 +1386,7 @@ class BackboneRun:
             gpe = st.buf("gpe_scratch_" + side, (L, d))
         _colsum(st, dpre, L * d, B, L * d, gpe)          # dpe[s,:] = sum_b dpre[b,s,:]: a column sum of the [B, L*d] view
         if gpe.shape[0] > L:
-            gpe[L:].zero_()
+            H.fill_zero(gpe[L:])
         gtab = st.g(P + "%s_proj.weight" % side, gbuf)
         if is_id:
             ids = sv["%s_ids" % side]
@@ -1382,7 +1397,7 @@ class BackboneRun:
             if gbuf is None and prev is not None and prev[0] == gtab.data_ptr() and prev[1].device == gtab.device:
                 H.zero_rows(gtab, prev[1])
             else:
-                gtab.zero_()
+                H.fill_zero(gtab)
             st._tab_rows.pop(P + side, None)
             if st.row_exchange is not None:
                 # Data parallel: a rank touches at most B rows of the table, so the ranks exchange
@@ -1391,7 +1406,7 @@ class BackboneRun:
                 # segment sum over the G*B gathered rows and ends with the bitwise-identical global table gradient.
                 rows = st.buf("idrows_" + side, (B, width))
                 ar, ar32 = st.const_arange(B, torch.int64), st.const_arange(B, torch.int32)
-                rows.zero_()                                                               # the kernel accumulates into its output
+                H.fill_zero(rows)                                                          # the kernel accumulates into its output
                 H.embed_id_bwd(dpre, L, d, 0, width, ar32, ar, rows, B)                    # rows[b] = sum_s dpre[b, s, :width]
                 pending = st.row_exchange(ids, rows)          # asynchronous all-gather: waited for below, after the work that needs no rows
             else:
@@ -1484,7 +1499,8 @@ class BackboneFn(torch.autograd.Function):
         gbuf = _pick_gbuf(store, ctx.names)
         if d_vid is None:      # the video states took no part in the differentiated scalar
             d_vid = torch.zeros((run.B, run.S if run.abl != "CrossMLP" else POOL_BINS, run.d), device=store.flat.device)
-        run.backward(d_vid, gbuf, on_bucket=store.bucket_hook if gbuf is None else None)
+        with store.rec_pool():
+            run.backward(d_vid, gbuf, on_bucket=store.bucket_hook if gbuf is None else None)
         ctx.run = None
         return (None,) * 10 + grads_out(store, ctx.names, gbuf)
 

@@ -15,7 +15,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SEGMM_LIB") or os.path.join(_HERE, "libsegmm_hip.so")      # SEGMM_LIB: A/B builds of the kernels
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 _lib = None
 
@@ -78,10 +78,31 @@ SIGNATURES = {
     "segmm_colsum3": [_p, _p, _p, _i, _i64, _i, _p, _p, _p, _p, _p],
     "segmm_pool_tokens": [_p, _i, _p, _i, _p, _i, _i, _i, _p],
     "segmm_pool_tokens_bwd": [_p, _p, _i, _p, _i, _i, _i, _i, _p],
+    "segmm_fill_zero": [_p, _i64, _p],
+    "segmm_cmd_op_count": [],
+    "segmm_run_phase": [_p, _p, _p, _p, _p],
+    "segmm_step_begin": [_p, _p, _p, _p, _p],
+    "segmm_embed_fwd": [_p, _p, _p, _p, _p],
+    "segmm_layer_fwd": [_p, _p, _p, _p, _p],
+    "segmm_head_loss_fwd": [_p, _p, _p, _p, _p],
+    "segmm_head_loss_bwd": [_p, _p, _p, _p, _p],
+    "segmm_layer_bwd": [_p, _p, _p, _p, _p],
+    "segmm_embed_bwd": [_p, _p, _p, _p, _p],
+    "segmm_step_tail": [_p, _p, _p, _p, _p],
 }
 
 
 def lib():
+    """The shared library (loaded once; raises if it has not been built) -- or, while a step is being recorded, a proxy that
+    records every dispatchable call before making it."""
+    L = _lib_real()
+    rec = RECORDER
+    if rec is not None:
+        return _RecLib(L, rec)
+    return L
+
+
+def _lib_real():
     """Loads the shared library once; raises if it has not been built (``python -c 'import __graft_entry__ as g; g.build()'``)."""
     global _lib
     if _lib is not None:
@@ -94,6 +115,8 @@ def lib():
     L.segmm_last_error.argtypes = []
     L.segmm_abi_version.restype = _i
     L.segmm_abi_version.argtypes = []
+    L.segmm_cmd_op_name.restype = C.c_char_p
+    L.segmm_cmd_op_name.argtypes = [_i]
     for name, at in SIGNATURES.items():
         fn = getattr(L, name)
         fn.argtypes = at
@@ -104,9 +127,148 @@ def lib():
     return L
 
 
+# =============================================================================================== recorded launch sequences
+# include/segmm_hip.h "Recorded launch sequences": the per-op calls of ONE eager training step are recorded (entry point, its
+# arguments, the stream slot) and replayed every step from C by segmm_run_phase / the named phase entry points -- one
+# foreign-function call per part of the step instead of one per kernel (+ the Python that sequences them).
+CMD_MAX_ARGS = 48
+OP_FORK, OP_JOIN = -1, -2
+(PHASE_STEP_BEGIN, PHASE_EMBED_FWD, PHASE_LAYER_FWD, PHASE_HEAD_LOSS_FWD, PHASE_HEAD_LOSS_BWD, PHASE_LAYER_BWD, PHASE_EMBED_BWD,
+ PHASE_STEP_TAIL) = range(8)
+PHASE_ENTRY = ("segmm_step_begin", "segmm_embed_fwd", "segmm_layer_fwd", "segmm_head_loss_fwd", "segmm_head_loss_bwd",
+               "segmm_layer_bwd", "segmm_embed_bwd", "segmm_step_tail")
+
+
+class CmdArg(C.Union):
+    _fields_ = [("i", C.c_int64), ("f", C.c_double), ("p", C.c_void_p)]
+
+
+class Cmd(C.Structure):
+    """segmm_cmd_t"""
+    _fields_ = [("op", C.c_int32), ("stream", C.c_int32), ("a", CmdArg * CMD_MAX_ARGS)]
+
+
+class Phase(C.Structure):
+    """segmm_phase_t"""
+    _fields_ = [("kind", C.c_int32), ("backbone", C.c_int32), ("layer", C.c_int32), ("n_cmds", C.c_int32), ("cmds", C.POINTER(Cmd))]
+
+
+_op_ids = None
+
+
+def op_ids():
+    """{entry point name: op id} of the library's dispatch table (segmm_cmd_op_name)."""
+    global _op_ids
+    if _op_ids is None:
+        L = lib()
+        _op_ids = {L.segmm_cmd_op_name(i).decode(): i for i in range(L.segmm_cmd_op_count())}
+    return _op_ids
+
+
+RECORDER = None          # a Recorder while Trainer.record() runs its one eager step
+
+
+class Recorder:
+    """Collects the C-ABI calls of one eager step, split into phases by :func:`mark`."""
+
+    def __init__(self, main_stream: int, side_stream: int):
+        self.streams = {int(main_stream): 0, int(side_stream): 1}
+        self.phases = []          # [kind, backbone, layer, [(op, slot, [(field, value)])]]
+        self.keep = []            # host structs / arrays the recorded pointer arguments name
+        self.ops = op_ids()
+
+    def mark(self, kind, backbone=0, layer=0):
+        self.phases.append([int(kind), int(backbone), int(layer), []])
+
+    def _cmds(self):
+        if not self.phases:
+            raise RuntimeError("recorder: a launch before the first phase marker")
+        return self.phases[-1][3]
+
+    def pseudo(self, op):
+        self._cmds().append((op, 0, []))
+
+    def call(self, name, args):
+        at = SIGNATURES[name]
+        if len(args) != len(at) or at[-1] is not _p:
+            raise RuntimeError("recorder: %s called with %d arguments" % (name, len(args)))
+        slot = self.streams.get(int(args[-1] or 0))
+        if slot is None:
+            raise RuntimeError("recorder: %s was enqueued on a stream that is neither the step's main nor its side stream; this "
+                               "launch sequence cannot be replayed (prefetch / third-stream knobs must be off)" % name)
+        vals = []
+        for k, (ct, v) in enumerate(zip(at[:-1], args[:-1])):
+            if ct is _f:
+                vals.append(("f", float(v)))
+            elif ct is _p:
+                if v is None:
+                    vals.append(("p", None))
+                elif isinstance(v, int):
+                    vals.append(("p", v or None))
+                else:          # byref(struct) / cast(array) / ctypes instance: a host object that must outlive the replay
+                    obj = getattr(v, "_obj", v)
+                    self.keep.append((v, obj))
+                    addr = v.value if isinstance(v, C.c_void_p) else C.addressof(obj)
+                    vals.append(("p", addr))
+            else:
+                iv = int(v)
+                vals.append(("i", iv - (1 << 64) if iv >= (1 << 63) else iv))
+        self._cmds().append((self.ops[name], slot, vals))
+
+    def finish(self):
+        """-> list of (Phase struct, Cmd array); the arrays are referenced by the Phase structs (keep both)."""
+        out = []
+        for kind, bb, layer, cmds in self.phases:
+            arr = (Cmd * max(len(cmds), 1))()
+            for c, (op, slot, vals) in zip(arr, cmds):
+                c.op, c.stream = op, slot
+                for k, (fld, v) in enumerate(vals):
+                    setattr(c.a[k], fld, v)
+            ph = Phase(kind=kind, backbone=bb, layer=layer, n_cmds=len(cmds), cmds=C.cast(arr, C.POINTER(Cmd)))
+            out.append((ph, arr))
+        return out
+
+
+class _RecLib:
+    """``lib()`` while recording: every dispatchable entry point is recorded, then executed."""
+
+    def __init__(self, real, rec):
+        self._real, self._rec = real, rec
+
+    def __getattr__(self, name):
+        fn = getattr(self._real, name)
+        rec = self._rec
+        if name not in rec.ops:
+            return fn
+
+        def call(*args):
+            rec.call(name, args)
+            return fn(*args)
+        return call
+
+
+def mark(kind, backbone=0, layer=0):
+    """Phase boundary of the step (no-op unless a step is being recorded)."""
+    if RECORDER is not None:
+        RECORDER.mark(kind, backbone, layer)
+
+
+def run_phase(phase: "Phase", main_stream: int, side_stream: int, ev_fork: int, ev_join: int):
+    L = _lib_real()
+    _check(getattr(L, PHASE_ENTRY[phase.kind])(C.addressof(phase), main_stream, side_stream, ev_fork, ev_join), PHASE_ENTRY[phase.kind])
+
+
+def fill_zero(t: torch.Tensor):
+    """``t.zero_()`` through the C ABI (a recordable command; contiguous tensors only)."""
+    if not t.is_contiguous():
+        raise RuntimeError("fill_zero: non-contiguous view")
+    if t.numel():
+        _check(lib().segmm_fill_zero(t.data_ptr(), t.numel() * t.element_size(), _stream()), "segmm_fill_zero")
+
+
 def _check(rc, what):
     if rc != 0:
-        raise RuntimeError("%s failed (%d): %s" % (what, rc, lib().segmm_last_error().decode()))
+        raise RuntimeError("%s failed (%d): %s" % (what, rc, _lib_real().segmm_last_error().decode()))
 
 
 def _ptr(t: Optional[torch.Tensor]):

@@ -576,6 +576,7 @@ class Trainer:
         if model.training != bool(self.dropout):
             model.train(self.dropout)          # (walks every sub-module: 0.35 ms of host time when done every step)
         self.opt.zero_grad()
+        H.mark(H.PHASE_STEP_BEGIN)
         if self.device_state:          # first launches of the step: advance the device-side step state, fresh header rows
             H.step_advance(*self.opt.betas)
             st.hdr_step_begin()
@@ -651,6 +652,7 @@ class Trainer:
                 for w in works:
                     w.wait()
             self.comm.finish()
+        H.mark(H.PHASE_STEP_TAIL)
         self.opt.step()
         return out
 
@@ -687,6 +689,96 @@ class Trainer:
         self.opt.step_count += 1
         self.model._store.fused_version += 1
         return self._static_out
+
+    # ---- the step as recorded launch sequences replayed from C (include/segmm_hip.h "Recorded launch sequences")
+    def record(self, batch: Dict[str, torch.Tensor], warmup: int = 3):
+        """Record the launch sequence of one training step on ``batch``'s shapes: ``warmup`` eager steps (site scales calibrated,
+        every persistent buffer allocated, both streams created), then ONE more eager step during which every C-ABI call is
+        recorded -- entry point, arguments, stream slot, fork / join points of the two streams -- split into the phases of the
+        step (step begin, embedding, each encoder layer, head + loss, their backwards, optimizer tail).  The step's allocations
+        come from a private memory pool kept for the life of the recording, the per-step state lives on the device
+        (``device_state``): the recorded arguments are valid for every later step, except the batch's own tensors, whose
+        addresses are patched per step.  ``run_recorded(batch)`` then enqueues a step with one C call per phase
+        (segmm_step_begin, segmm_embed_fwd, segmm_layer_fwd, ...): the eager two-stream schedule without the per-launch host
+        work.  Results are bit-identical to ``train_step`` in the same mode."""
+        if not self.device_state:
+            raise RuntimeError("record() needs Trainer(device_state=True): the per-step state must live on the device")
+        if self.comm.active:
+            raise RuntimeError("record(): the data-parallel step issues its collectives from Python (not recorded)")
+        model, st = self.model, self.model._store
+        for bb in (model.backbone1, getattr(model, "backbone2", None)):
+            abl = getattr(bb, "ablation_type", "ours") if bb is not None else "ours"
+            if "noUser" in abl or "noPos" in abl:
+                raise RuntimeError("record(): ablation %r draws random inputs on the host every step" % abl)
+        spec = getattr(model, "_loss_spec", None)
+        if (spec is not None and spec.has_focal) or model.bias_weight is not None or self._param_hooks():
+            raise RuntimeError("record(): focal loss (rewrites gt with torch ops), learnable_bias and parameter hooks keep torch "
+                               "kernels inside the step; use train_step")
+        for k, v in batch.items():
+            if torch.is_tensor(v) and not v.is_contiguous():
+                raise RuntimeError("record(): batch[%r] is not contiguous" % k)
+        for _ in range(max(warmup, 1)):
+            self.train_step(batch)
+        torch.cuda.synchronize()
+        main = H._stream()
+        side = st.side_stream().cuda_stream
+        st._rec_pool = torch.cuda.MemPool()
+        rec = H.Recorder(main, side)
+        H.RECORDER = rec
+        try:
+            with st.rec_pool():
+                out = self.train_step(batch)
+        finally:
+            H.RECORDER = None
+        torch.cuda.synchronize()
+        phases = rec.finish()
+        # the batch's tensors: every recorded pointer that falls inside one of them is re-based per step
+        spans = [(k, v.data_ptr(), v.numel() * v.element_size(), tuple(v.shape), v.dtype) for k, v in batch.items() if torch.is_tensor(v) and v.numel()]
+        relocs = []
+        for ph, arr in phases:
+            for ci in range(ph.n_cmds):
+                c = arr[ci]
+                if c.op < 0:
+                    continue
+                for ai in range(H.CMD_MAX_ARGS):
+                    pv = c.a[ai].p
+                    if not pv:
+                        continue
+                    for k, base, nb, _, _ in spans:
+                        if base <= pv < base + nb:
+                            relocs.append((arr, ci, ai, k, pv - base))
+                            break
+        evs = (torch.cuda.Event(), torch.cuda.Event())
+        for e in evs:
+            e.record()
+        self._recorded = dict(phases=phases, keep=rec.keep, out=out, relocs=relocs, spans={k: (sh, dt) for k, _, _, sh, dt in spans},
+                              main=main, side=side, events=evs, ev_handles=(evs[0].cuda_event, evs[1].cuda_event),
+                              n_cmds=sum(ph.n_cmds for ph, _ in phases))
+        return out
+
+    def run_recorded(self, batch: Dict[str, torch.Tensor]):
+        """One training step from the recorded launch sequences (see :meth:`record`): patch the batch's addresses, then one C
+        call per phase.  Must be called with torch's current stream = the stream ``record`` ran on."""
+        r = self.__dict__.get("_recorded")
+        if r is None:
+            raise RuntimeError("run_recorded() before record()")
+        if self.__dict__.get("_superseded", False):
+            raise RuntimeError("this Trainer(device_state=True) was superseded by a later one")
+        for k, (sh, dt) in r["spans"].items():
+            v = batch[k]
+            if tuple(v.shape) != sh or v.dtype != dt or not v.is_contiguous():
+                raise RuntimeError("run_recorded(): batch[%r] is %s %s, the step was recorded for %s %s" % (k, tuple(v.shape), v.dtype, sh, dt))
+        for arr, ci, ai, k, off in r["relocs"]:
+            arr[ci].a[ai].p = batch[k].data_ptr() + off
+        main, side, (ef, ej) = r["main"], r["side"], r["ev_handles"]
+        if H._stream() != main:
+            raise RuntimeError("run_recorded(): the current stream is not the stream the step was recorded on")
+        for ph, _ in r["phases"]:
+            H.run_phase(ph, main, side, ef, ej)
+        # mirror the host side effects of the eager step (FusedAdamW.begin_step / end_step)
+        self.opt.step_count += 1
+        self.model._store.fused_version += 1
+        return r["out"]
 
     def _param_hooks(self) -> bool:
         plist = self.__dict__.get("_hook_plist")

@@ -469,3 +469,53 @@ def test_planes_only_input_needs_plane_consumers_d48():
     tr = Trainer(model, dropout=False)
     losses = [float(tr.train_step(batch)["loss"].detach()) for _ in range(4)]          # raised on step 2 before the fix
     assert all(l == l for l in losses) and losses[-1] < losses[0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,N,B,S,Lt,D,h", [("image", 3, 64, 40, 10, 64, 4), ("id", 4, 64, 20, 1, 64, 4), ("image", 2, 32, 40, 100, 96, 2),
+                                               ("both", 2, 16, 40, 10, 64, 4)])
+def test_recorded_step_equals_eager_device_state_step(kind, N, B, S, Lt, D, h):
+    """Trainer.record / run_recorded (include/segmm_hip.h "Recorded launch sequences"; the loop body of
+    main_for_seq_leave_earlystop_SegMM.py:265-300 enqueued by one C call per phase: segmm_step_begin, segmm_embed_fwd,
+    segmm_layer_fwd, segmm_head_loss_fwd, segmm_head_loss_bwd, segmm_layer_bwd, segmm_embed_bwd, segmm_step_tail): 20 steps on
+    rotating batches with dropout ON leave BIT-IDENTICAL parameters, optimizer moments and losses to the same steps enqueued
+    launch by launch from Python in the same mode; an evaluation between recorded steps sees the current weights."""
+    import torch
+    from segmminterest_amd import hipabi as H
+    from segmminterest_amd.synth import make_batch
+    from segmminterest_amd.trainer import Trainer, default_args, init_model
+    dev = torch.device("cuda:0")
+    margs = default_args(num_layers_enc=N, d_model=D, nhead=h, input_type={"user": kind, "photo": kind}, exposure_prob=[1.0] * S)
+    batches = [{k: v.to(dev) for k, v in make_batch(B, S, Lt, D, n_users=50, n_items=500, seed=300 + i).items()} for i in range(4)]
+    T = 20
+
+    def run(recorded):
+        torch.manual_seed(7)
+        model = init_model(margs, n_users=50, n_items=500, input_dim=D, max_vid_len=S, max_usr_len=Lt).to(dev)
+        tr = Trainer(model, lr=1e-3, weight_decay=1e-4, device_state=True)
+        losses, evals = [], []
+        if recorded:
+            tr.record(batches[0], warmup=3)          # 3 eager steps + the recorded one
+        else:
+            for _ in range(4):
+                tr.train_step(batches[0])
+        for t in range(T):
+            out = tr.run_recorded(batches[t % 4]) if recorded else tr.train_step(batches[t % 4])
+            losses.append(float(out["loss"].detach()))
+            if t in (5, 11):
+                evals.append(tr.eval_step(batches[3], mode="inference")["logits"].detach().clone())
+        torch.cuda.synchronize()
+        seed, step, _ = H.step_get()
+        assert tr.opt.step_count == step == 4 + T
+        if recorded:
+            kinds = [ph.kind for ph, _ in tr._recorded["phases"]]
+            assert kinds[0] == H.PHASE_STEP_BEGIN and kinds[-1] == H.PHASE_STEP_TAIL and H.PHASE_LAYER_FWD in kinds and H.PHASE_LAYER_BWD in kinds
+            assert len(tr._recorded["relocs"]) >= 3
+        return model._store.flat.detach().clone(), tr.opt.m.clone(), tr.opt.v.clone(), losses, evals, seed
+
+    pe, me, ve, le, ee, se = run(False)
+    pr, mr, vr, lr_, er, sr = run(True)
+    assert se == sr and le == lr_ and len(set(le)) > 1
+    assert torch.equal(pe, pr) and torch.equal(me, mr) and torch.equal(ve, vr)
+    for a, b in zip(ee, er):
+        assert torch.equal(a, b)

@@ -2,6 +2,7 @@
 exported names, the C ABI symbol table, and the no-fallback rule."""
 import ctypes
 import os
+import sys
 import re
 
 import pytest
@@ -65,12 +66,53 @@ def test_c_abi_exports_every_declared_symbol():
     lib = ctypes.CDLL(hipabi.LIB_PATH)
     for sym in declared:
         assert hasattr(lib, sym), sym
-    assert declared == set(hipabi.SIGNATURES) | {"segmm_last_error", "segmm_abi_version"}
+    assert declared == set(hipabi.SIGNATURES) | {"segmm_last_error", "segmm_abi_version", "segmm_cmd_op_name"}
     L = hipabi.lib()
     assert L.segmm_abi_version() == hipabi.ABI_VERSION
     # argument validation works without touching the GPU
     assert L.segmm_gemm(7, 1, 4, 4, None, 4, None, 4, None, 4, None, None, None, 0, 0, 0, None, 0, 0.0, 0, 0, 1, None, 0, 0, None) != 0
     assert b"layout" in L.segmm_last_error()
+
+
+def test_recorded_phase_entry_points_and_dispatch_table():
+    """include/segmm_hip.h "Recorded launch sequences": the dispatch table names exactly the stream-taking entry points of the
+    header (generated, tools/gen_cmd_dispatch.py --check), the ctypes mirror of segmm_cmd_t / segmm_phase_t has the C layout, and
+    the phase entry points validate their descriptor without touching the GPU (kind mismatch, bad op, bad stream slot)."""
+    import subprocess
+    from segmminterest_amd import hipabi as H
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_cmd_dispatch.py"), "--check"])
+    ops = H.op_ids()
+    streamed = {n for n, at in H.SIGNATURES.items() if at and at[-1] is H._p and n not in H.PHASE_ENTRY and n not in
+                ("segmm_run_phase", "segmm_step_get", "segmm_probe_mfma_rate")}
+    assert set(ops) == streamed and sorted(ops, key=ops.get) == sorted(ops)
+    assert ctypes.sizeof(H.CmdArg) == 8 and ctypes.sizeof(H.Cmd) == 8 + 8 * H.CMD_MAX_ARGS and ctypes.sizeof(H.Phase) == 24
+    L = H.lib()
+    arr = (H.Cmd * 2)()
+    arr[0].op, arr[0].stream = H.OP_FORK, 0
+    arr[1].op, arr[1].stream = ops["segmm_fill_zero"], 0
+    ph = H.Phase(kind=H.PHASE_LAYER_FWD, backbone=0, layer=1, n_cmds=2, cmds=ctypes.cast(arr, ctypes.POINTER(H.Cmd)))
+    assert L.segmm_embed_fwd(ctypes.addressof(ph), None, None, None, None) != 0 and b"EMBED_FWD" in L.segmm_last_error()
+    assert L.segmm_layer_fwd(ctypes.addressof(ph), None, None, None, None) != 0 and b"fork" in L.segmm_last_error()      # no side stream / events
+    arr[0].op = 10 ** 6
+    assert L.segmm_run_phase(ctypes.addressof(ph), None, None, None, None) != 0 and b"op" in L.segmm_last_error()
+    arr[0].op, arr[0].stream = ops["segmm_fill_zero"], 3
+    assert L.segmm_run_phase(ctypes.addressof(ph), None, None, None, None) != 0 and b"stream slot" in L.segmm_last_error()
+    arr[0].stream = 0          # a command whose own argument check fails (null pointer): its return code and message come through
+    assert L.segmm_run_phase(ctypes.addressof(ph), None, None, None, None) != 0 and b"fill_zero" in L.segmm_last_error()
+    ph.n_cmds = 0
+    assert L.segmm_layer_fwd(ctypes.addressof(ph), None, None, None, None) == 0
+    # the recorder converts arguments by the signature table
+    rec = H.Recorder(111, 222)
+    rec.mark(H.PHASE_STEP_TAIL)
+    rec.call("segmm_adamw", (4096, 8192, 0, None, 10, 1e-3, 0.9, 0.999, 1e-8, 1e-4, -1, 222))
+    rec.call("segmm_l1norm", (1, 2, None, 5, 32, None, None, 0, None, None, (1 << 63) | 5 if False else 111))
+    rec.pseudo(H.OP_JOIN)
+    (phs, a2), = rec.finish()
+    assert phs.kind == H.PHASE_STEP_TAIL and phs.n_cmds == 3
+    assert a2[0].op == ops["segmm_adamw"] and a2[0].stream == 1 and a2[0].a[0].p == 4096 and a2[0].a[3].p is None
+    assert a2[0].a[5].f == 1e-3 and a2[0].a[10].i == -1 and a2[1].stream == 0 and a2[2].op == H.OP_JOIN
+    with pytest.raises(RuntimeError, match="neither"):
+        rec.call("segmm_fill_zero", (1, 2, 333))
 
 
 def test_product_package_never_imports_oracle():
