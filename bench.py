@@ -98,6 +98,10 @@ def parse_args():
                          "the device -- and the timed steps are REPLAYS of one hipGraph capture of the step (Trainer.capture / replay): "
                          "the host enqueues one graph launch + the batch copy per step.  --device-state alone runs the same step eagerly.")
     ap.add_argument("--device-state", action="store_true", help="the device-state step without graph capture (A/B partner of --graph)")
+    ap.add_argument("--recorded", action="store_true",
+                    help="single GPU: Trainer(device_state=True).record() -- the step's launch sequence is recorded once and every timed step "
+                         "is enqueued from C, one call per phase (segmm_step_begin, segmm_embed_fwd, segmm_layer_fwd, ... segmm_step_tail): "
+                         "the eager two-stream schedule without the per-launch host work")
     ap.add_argument("--no-probe", action="store_true", help="skip the sustained-MFMA probe (roofline.sustained_probe)")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
                     help="gloo: CPU-staged collectives, lets several ranks share one GPU (CI rehearsal of the N > 1 path)")
@@ -149,7 +153,7 @@ def _claim_stdout():
 def _graph_mode_legs(args):
     """--graph / --device-state measure the step itself: the extra legs (second trainer on the f32 engine, host-fed inputs)
     would rebuild the device-side step state under the first trainer."""
-    if args.graph or args.device_state:
+    if args.graph or args.device_state or args.recorded:
         args.no_f32_engine = True
         args.no_host_fed = True
     return args
@@ -298,7 +302,7 @@ def main():
             g = torch.Generator(device="cpu").manual_seed(99)
             table = ResidentFeatureTable(torch.rand((200000, Din), generator=g).to(dev))
         return model, Trainer(model, lr=1e-3, weight_decay=1e-4, comm=DPComm(), overlap=not args.no_overlap, feature_table=table,
-                              device_state=args.graph or args.device_state)
+                              device_state=args.graph or args.device_state or args.recorded)
 
     model, trainer = build()
     batches = []
@@ -326,7 +330,9 @@ def main():
         for i in range(n):
             h0 = time.perf_counter()
             nxt = batches[(start + i + 1) % len(batches)] if (args.prefetch and len(batches) > 1) else None
-            if tr._graph is not None and hipabi.GEMM_PROFILE is None:
+            if tr.__dict__.get("_recorded") is not None and hipabi.GEMM_PROFILE is None:
+                out = tr.run_recorded(batches[(start + i) % len(batches)])
+            elif tr._graph is not None and hipabi.GEMM_PROFILE is None:
                 out = tr.replay(batches[(start + i) % len(batches)])
             else:
                 out = tr.train_step(batches[(start + i) % len(batches)], next_batch=nxt)
@@ -337,6 +343,10 @@ def main():
         if world > 1 or args.prefetch:
             raise SystemExit("--graph: single GPU, no prefetch")
         trainer.capture(batches[0], warmup=max(args.warmup, 3))
+    if args.recorded:
+        if world > 1 or args.prefetch:
+            raise SystemExit("--recorded: single GPU, no prefetch")
+        trainer.record(batches[0], warmup=max(args.warmup, 3))
     run(trainer, args.warmup)
     # ---- the timed region: `windows` windows of EXACTLY `steps` steps, each bracketed by barrier + synchronize on both sides,
     # MAX over ranks per window; `value` is the median window (value_min / value_max beside it)
@@ -398,7 +408,9 @@ def main():
                        "rows_per_gpu": B, "global_batch": B * world, "segments": S, "feat_dim": D, "in_dim": Din, "user_tokens": Lt, "layers": N,
                        "parallelism": "dp%d" % world + (" (forced one-rank process group)" if forced_dp else ""),
                        "backend": args.backend if (world > 1 or forced_dp) else None,
-                       "grad_allreduce_overlap": not args.no_overlap, "step_mode": ("hipGraph replay (device-side step state)" if args.graph else "eager, device-side step state" if args.device_state else "eager"), "input_prefetch": bool(args.prefetch and len(batches) > 1),
+                       "grad_allreduce_overlap": not args.no_overlap, "step_mode": ("hipGraph replay (device-side step state)" if args.graph else
+                                     "recorded launch sequences replayed from C, one call per phase (device-side step state)" if args.recorded else
+                                     "eager, device-side step state" if args.device_state else "eager"), "input_prefetch": bool(args.prefetch and len(batches) > 1),
                        "final_loss": round(loss, 6), "replicas_identical": replicas_identical,
                        "delayed_scale_overflows": (model._store.overflow_count() if model._store.engine_p else None),
                        "live_train_flops_per_interaction": ftrain, "gemm_engine": engine,

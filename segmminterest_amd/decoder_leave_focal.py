@@ -143,10 +143,9 @@ class HeadLossFn(torch.autograd.Function):
             dl = ctx.dlogits.view(M)          # d loss / d loss == 1
         else:
             dl = (ctx.dlogits * g_total).view(M)
-        with st.rec_pool():
-            dv1 = torch.empty(M, d, device=v1.device)
-            dv2 = torch.empty(M, d, device=v1.device) if v2 is not None else None
-            model._head_bwd(v1, v2, dl, dv1, dv2, ctx.T, M, d, B, S, gbuf)
+        dv1 = torch.empty(M, d, device=v1.device)
+        dv2 = torch.empty(M, d, device=v1.device) if v2 is not None else None
+        model._head_bwd(v1, v2, dl, dv1, dv2, ctx.T, M, d, B, S, gbuf)
         if gbuf is None and st.bucket_hook is not None:
             st.bucket_hook("head", after_side=st.head_side)
         ctx.dlogits = ctx.T = None

@@ -267,12 +267,18 @@ class ParamStore:
         self._hdr_off += n
         return ring[r0:r0 + n]
 
-    def rec_pool(self):
-        """Allocation context of a step that is being RECORDED (Trainer.record): every tensor the step allocates comes from a
-        private memory pool that is kept for the life of the recording, so the addresses the recorded commands name stay
-        reserved for the replays.  (torch's pool context is per thread: the autograd engine runs the backward on its own.)"""
-        pool = self.__dict__.get("_rec_pool")
-        return torch.cuda.use_mem_pool(pool) if (pool is not None and H.RECORDER is not None) else contextlib.nullcontext()
+    @contextlib.contextmanager
+    def rec_pool(self, pool):
+        """Allocation context of the step that is being RECORDED (Trainer.record): every tensor allocated while it is open -- by
+        any thread: the autograd engine runs the backward on its own -- comes from the private memory pool ``pool``, which the
+        trainer keeps for the life of the recording, so the addresses the recorded commands name stay reserved for the replays."""
+        dev = self.flat.device.index if self.flat.device.index is not None else torch.cuda.current_device()
+        torch._C._cuda_beginAllocateToPool(dev, pool.id)          # every allocation of every thread and stream
+        try:
+            yield
+        finally:
+            torch._C._cuda_endAllocateToPool(dev, pool.id)
+            torch._C._cuda_releasePool(dev, pool.id)
 
     def const_arange(self, n: int, dtype) -> torch.Tensor:
         """arange(n) on the device, made once (never written afterwards)."""
@@ -1499,8 +1505,7 @@ class BackboneFn(torch.autograd.Function):
         gbuf = _pick_gbuf(store, ctx.names)
         if d_vid is None:      # the video states took no part in the differentiated scalar
             d_vid = torch.zeros((run.B, run.S if run.abl != "CrossMLP" else POOL_BINS, run.d), device=store.flat.device)
-        with store.rec_pool():
-            run.backward(d_vid, gbuf, on_bucket=store.bucket_hook if gbuf is None else None)
+        run.backward(d_vid, gbuf, on_bucket=store.bucket_hook if gbuf is None else None)
         ctx.run = None
         return (None,) * 10 + grads_out(store, ctx.names, gbuf)
 

@@ -717,16 +717,21 @@ class Trainer:
         for k, v in batch.items():
             if torch.is_tensor(v) and not v.is_contiguous():
                 raise RuntimeError("record(): batch[%r] is not contiguous" % k)
-        for _ in range(max(warmup, 1)):
+        # the step may name tensors of the PREVIOUS step's batch (id mode: the rows the last backward scattered into the table
+        # gradient are cleared by id list): the last warm-up step runs on a copy of the batch, so that such pointers can be told
+        # from the current batch's and re-based to the previous batch at replay
+        prev = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+        for _ in range(max(warmup - 1, 0)):
             self.train_step(batch)
+        self.train_step(prev)
         torch.cuda.synchronize()
         main = H._stream()
         side = st.side_stream().cuda_stream
-        st._rec_pool = torch.cuda.MemPool()
+        pool = torch.cuda.MemPool()
         rec = H.Recorder(main, side)
         H.RECORDER = rec
         try:
-            with st.rec_pool():
+            with st.rec_pool(pool):
                 out = self.train_step(batch)
         finally:
             H.RECORDER = None
@@ -734,6 +739,7 @@ class Trainer:
         phases = rec.finish()
         # the batch's tensors: every recorded pointer that falls inside one of them is re-based per step
         spans = [(k, v.data_ptr(), v.numel() * v.element_size(), tuple(v.shape), v.dtype) for k, v in batch.items() if torch.is_tensor(v) and v.numel()]
+        pspans = [(k, v.data_ptr(), v.numel() * v.element_size()) for k, v in prev.items() if torch.is_tensor(v) and v.numel()]
         relocs = []
         for ph, arr in phases:
             for ci in range(ph.n_cmds):
@@ -746,12 +752,17 @@ class Trainer:
                         continue
                     for k, base, nb, _, _ in spans:
                         if base <= pv < base + nb:
-                            relocs.append((arr, ci, ai, k, pv - base))
+                            relocs.append((arr, ci, ai, k, pv - base, 0))
                             break
+                    else:
+                        for k, base, nb in pspans:
+                            if base <= pv < base + nb:
+                                relocs.append((arr, ci, ai, k, pv - base, 1))
+                                break
         evs = (torch.cuda.Event(), torch.cuda.Event())
         for e in evs:
             e.record()
-        self._recorded = dict(phases=phases, keep=rec.keep, out=out, relocs=relocs, spans={k: (sh, dt) for k, _, _, sh, dt in spans},
+        self._recorded = dict(phases=phases, keep=rec.keep, pool=pool, prev_batch=batch, out=out, relocs=relocs, spans={k: (sh, dt) for k, _, _, sh, dt in spans},
                               main=main, side=side, events=evs, ev_handles=(evs[0].cuda_event, evs[1].cuda_event),
                               n_cmds=sum(ph.n_cmds for ph, _ in phases))
         return out
@@ -768,8 +779,10 @@ class Trainer:
             v = batch[k]
             if tuple(v.shape) != sh or v.dtype != dt or not v.is_contiguous():
                 raise RuntimeError("run_recorded(): batch[%r] is %s %s, the step was recorded for %s %s" % (k, tuple(v.shape), v.dtype, sh, dt))
-        for arr, ci, ai, k, off in r["relocs"]:
-            arr[ci].a[ai].p = batch[k].data_ptr() + off
+        pb = r["prev_batch"]
+        for arr, ci, ai, k, off, lag in r["relocs"]:
+            arr[ci].a[ai].p = (pb if lag else batch)[k].data_ptr() + off
+        r["prev_batch"] = batch          # (also keeps the tensors a lag-1 pointer names alive until the next step has run)
         main, side, (ef, ej) = r["main"], r["side"], r["ev_handles"]
         if H._stream() != main:
             raise RuntimeError("run_recorded(): the current stream is not the stream the step was recorded on")
