@@ -99,7 +99,7 @@ def parse_args():
                          "the host enqueues one graph launch + the batch copy per step.  --device-state alone runs the same step eagerly.")
     ap.add_argument("--device-state", action="store_true", help="the device-state step without graph capture (A/B partner of --graph)")
     ap.add_argument("--recorded", action="store_true",
-                    help="single GPU: Trainer(device_state=True).record() -- the step's launch sequence is recorded once and every timed step "
+                    help="Trainer(device_state=True).record() -- the step's launch sequence is recorded once and every timed step "
                          "is enqueued from C, one call per phase (segmm_step_begin, segmm_embed_fwd, segmm_layer_fwd, ... segmm_step_tail): "
                          "the eager two-stream schedule without the per-launch host work")
     ap.add_argument("--no-probe", action="store_true", help="skip the sustained-MFMA probe (roofline.sustained_probe)")
@@ -344,8 +344,8 @@ def main():
             raise SystemExit("--graph: single GPU, no prefetch")
         trainer.capture(batches[0], warmup=max(args.warmup, 3))
     if args.recorded:
-        if world > 1 or args.prefetch:
-            raise SystemExit("--recorded: single GPU, no prefetch")
+        if args.prefetch:
+            raise SystemExit("--recorded: no prefetch")
         trainer.record(batches[0], warmup=max(args.warmup, 3))
     run(trainer, args.warmup)
     # ---- the timed region: `windows` windows of EXACTLY `steps` steps, each bracketed by barrier + synchronize on both sides,

@@ -383,6 +383,8 @@ int segmm_embed_bwd(const segmm_phase_t* phase, segmm_stream_t main_stream, segm
 int segmm_step_tail(const segmm_phase_t* phase, segmm_stream_t main_stream, segmm_stream_t side_stream, void* ev_fork, void* ev_join);
 /* bytes of p[0 .. bytes) = 0 on `stream` (the clears of the step path as a recordable command) */
 int segmm_fill_zero(void* p, int64_t bytes, segmm_stream_t stream);
+/* dst[0 .. bytes) = src[0 .. bytes), device to device, on `stream` (non-overlapping ranges) */
+int segmm_copy_bytes(void* dst, const void* src, int64_t bytes, segmm_stream_t stream);
 
 /* test hook: multiplier (0 or 1/(1-p)) of elements [0,n) of a dropout site */
 int segmm_dropout_mult(float* out, int64_t n, float p, uint64_t seed, uint32_t site, segmm_stream_t stream);

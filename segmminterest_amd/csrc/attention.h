@@ -593,7 +593,10 @@ __global__ __launch_bounds__(768) void attn_fwd_lds_kernel(const AttnArgs p) {
     }
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
-    // O^T[c][query] = sum_key V[key][c] P^T[key][query] (unnormalised: e = exp(logit - mx)); step s of tile t contracts keys 16t + 4g + s
+    // one key group: normalised probabilities go into the second product, exactly like attn_fwd_kernel (bit-identical results);
+    // several groups: unnormalised e = exp(logit - mx_group), normalised after the merge
+    const float pnorm = ksp == 1 ? 1.0f / sum : 1.0f;
+    // O^T[c][query] = sum_key V[key][c] P^T[key][query]; step s of tile t contracts keys 16t + 4g + s
     f32x4 o[C::CT];
 #pragma unroll
     for (int ct = 0; ct < C::CT; ++ct) o[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -612,7 +615,7 @@ __global__ __launch_bounds__(768) void attn_fwd_lds_kernel(const AttnArgs p) {
 #pragma unroll
                     for (int ct = 0; ct < C::CT; ++ct) vf[ct] = 0.f;
                 }
-                const float pb = acc[u][s_];            // e^T[key 16t+4g+s][query]
+                const float pb = acc[u][s_] * pnorm;            // P^T (or e^T) [key 16t+4g+s][query]
 #pragma unroll
                 for (int ct = 0; ct < C::CT; ++ct) o[ct] = MFMA16(vf[ct], pb, o[ct]);
             }
@@ -645,9 +648,11 @@ __global__ __launch_bounds__(768) void attn_fwd_lds_kernel(const AttnArgs p) {
         }
         mx = m;
     }
-    const float inv = 1.0f / sum;
+    const float inv = ksp == 1 ? pnorm : 1.0f / sum;
+    if (ksp > 1) {
 #pragma unroll
-    for (int ct = 0; ct < C::CT; ++ct) o[ct] *= inv;
+        for (int ct = 0; ct < C::CT; ++ct) o[ct] *= inv;
+    }
     if (g == 0 && q_in) {
         p.lse[(size_t)bh * p.Lq + qi] = mx;
         p.lse[(size_t)p.B * p.H * p.Lq + (size_t)bh * p.Lq + qi] = inv;

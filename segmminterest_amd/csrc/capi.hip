@@ -1228,6 +1228,14 @@ int segmm_fill_zero(void* p, int64_t bytes, segmm_stream_t stream) {
     return 0;
 }
 
+int segmm_copy_bytes(void* dst, const void* src, int64_t bytes, segmm_stream_t stream) {
+    SEGMM_REQUIRE(dst && src && bytes >= 0, "copy_bytes: null pointer / negative size");
+    if (bytes == 0) return 0;
+    const hipError_t e = hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+    SEGMM_REQUIRE(e == hipSuccess, "copy_bytes: hipMemcpyAsync: %s", hipGetErrorString(e));
+    return 0;
+}
+
 #include "cmd_dispatch.inc"
 
 int segmm_cmd_op_count(void) { return SEGMM_N_CMD_OPS; }

@@ -1414,7 +1414,11 @@ class BackboneRun:
                 ar, ar32 = st.const_arange(B, torch.int64), st.const_arange(B, torch.int32)
                 H.fill_zero(rows)                                                          # the kernel accumulates into its output
                 H.embed_id_bwd(dpre, L, d, 0, width, ar32, ar, rows, B)                    # rows[b] = sum_s dpre[b, s, :width]
-                pending = st.row_exchange(ids, rows)          # asynchronous all-gather: waited for below, after the work that needs no rows
+                # (the ids travel from a persistent copy: the exchange is a host action that a recorded step calls again every
+                # step with the tensors it was given at record time -- the batch's own tensor changes from step to step)
+                ids_p = st.buf("idrows_ids_" + side, (ids.numel(),), torch.int64)
+                H.copy_bytes(ids_p, ids.reshape(-1))
+                pending = st.row_exchange(ids_p, rows)          # asynchronous all-gather: waited for below, after the work that needs no rows
             else:
                 pending = None
             if side == "vid":

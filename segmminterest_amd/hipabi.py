@@ -79,6 +79,7 @@ SIGNATURES = {
     "segmm_pool_tokens": [_p, _i, _p, _i, _p, _i, _i, _i, _p],
     "segmm_pool_tokens_bwd": [_p, _p, _i, _p, _i, _i, _i, _i, _p],
     "segmm_fill_zero": [_p, _i64, _p],
+    "segmm_copy_bytes": [_p, _p, _i64, _p],
     "segmm_cmd_op_count": [],
     "segmm_run_phase": [_p, _p, _p, _p, _p],
     "segmm_step_begin": [_p, _p, _p, _p, _p],
@@ -181,12 +182,19 @@ class Recorder:
         self.phases.append([int(kind), int(backbone), int(layer), []])
 
     def _cmds(self):
-        if not self.phases:
+        if not self.phases or callable(self.phases[-1]):
             raise RuntimeError("recorder: a launch before the first phase marker")
         return self.phases[-1][3]
 
     def pseudo(self, op):
         self._cmds().append((op, 0, []))
+
+    def callback(self, fn):
+        """A host action between launches (a data-parallel collective, a wait for one): replayed by calling ``fn`` again at the
+        same point of the launch order.  The launches that follow continue the current phase in a new fragment."""
+        last = self.phases[-1] if self.phases else [PHASE_STEP_BEGIN, 0, 0, []]
+        self.phases.append(fn)
+        self.phases.append([last[0], last[1], last[2], []])
 
     def call(self, name, args):
         at = SIGNATURES[name]
@@ -218,7 +226,13 @@ class Recorder:
     def finish(self):
         """-> list of (Phase struct, Cmd array); the arrays are referenced by the Phase structs (keep both)."""
         out = []
-        for kind, bb, layer, cmds in self.phases:
+        for item in self.phases:
+            if callable(item):
+                out.append((item, None))
+                continue
+            kind, bb, layer, cmds = item
+            if not cmds:          # (an empty fragment behind a callback)
+                continue
             arr = (Cmd * max(len(cmds), 1))()
             for c, (op, slot, vals) in zip(arr, cmds):
                 c.op, c.stream = op, slot
@@ -253,6 +267,13 @@ def mark(kind, backbone=0, layer=0):
         RECORDER.mark(kind, backbone, layer)
 
 
+def host_action(fn):
+    """Run ``fn()`` now; while a step is being recorded, also note it as a host action of the step (Recorder.callback)."""
+    if RECORDER is not None:
+        RECORDER.callback(fn)
+    return fn()
+
+
 def run_phase(phase: "Phase", main_stream: int, side_stream: int, ev_fork: int, ev_join: int):
     L = _lib_real()
     _check(getattr(L, PHASE_ENTRY[phase.kind])(C.addressof(phase), main_stream, side_stream, ev_fork, ev_join), PHASE_ENTRY[phase.kind])
@@ -264,6 +285,15 @@ def fill_zero(t: torch.Tensor):
         raise RuntimeError("fill_zero: non-contiguous view")
     if t.numel():
         _check(lib().segmm_fill_zero(t.data_ptr(), t.numel() * t.element_size(), _stream()), "segmm_fill_zero")
+
+
+def copy_bytes(dst: torch.Tensor, src: torch.Tensor):
+    """``dst.copy_(src)`` of same-sized contiguous tensors through the C ABI (a recordable, re-basable command)."""
+    nb = src.numel() * src.element_size()
+    if not (dst.is_contiguous() and src.is_contiguous()) or dst.numel() * dst.element_size() != nb:
+        raise RuntimeError("copy_bytes: contiguous tensors of the same byte size")
+    if nb:
+        _check(lib().segmm_copy_bytes(dst.data_ptr(), src.data_ptr(), nb, _stream()), "segmm_copy_bytes")
 
 
 def _check(rc, what):

@@ -18,6 +18,7 @@ data parallelism is what this build adds:
 from __future__ import annotations
 
 import argparse
+import functools
 from typing import Dict, List, Optional
 
 import os
@@ -201,6 +202,15 @@ class DPComm:
             return None
         return self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group, async_op=async_op)
 
+    def _pbuf(self, key, shape, dtype, device):
+        """Persistent staging buffer of a collective: the SAME tensor every step, so that a recorded step (Trainer.record),
+        whose kernels name the results by address, can be replayed around the collectives."""
+        bufs = self.__dict__.setdefault("_bufs", {})
+        b = bufs.get(key)
+        if b is None or tuple(b.shape) != tuple(shape) or b.dtype != dtype or b.device != device:
+            b = bufs[key] = torch.empty(shape, dtype=dtype, device=device)
+        return b
+
     def global_label_stats(self, v, v2, norms):
         """(v_all, v2_all, norms_global): all-gather the per-row view lengths, sum the 3 normalisers.  Returns the triple
         (single process) or a closure that waits for the asynchronous collective and returns it."""
@@ -210,24 +220,36 @@ class DPComm:
         # summed locally from the gathered copies, in rank order on every rank (identical results everywhere)
         # The collective is ASYNCHRONOUS: the caller gets a closure and calls it right before the loss kernel, so the
         # all-gather (and the rank skew it absorbs) runs under the backbone forward instead of in front of it.
-        B = v.shape[0]
-        mine = torch.cat([v, v2, norms.to(v.dtype)])
-        work = None
-        if self.host_staged and mine.is_cuda:
-            hg = torch.empty((self.world * mine.shape[0],), dtype=mine.dtype)
-            self.dist.all_gather_into_tensor(hg, mine.cpu(), group=self.group)
-            gathered = hg.to(mine.device)
-        else:
-            gathered = torch.empty((self.world * mine.shape[0],), dtype=mine.dtype, device=mine.device)
-            work = self.dist.all_gather_into_tensor(gathered, mine, group=self.group, async_op=True)
+        B, n, dev, G = v.shape[0], 2 * v.shape[0] + 3, v.device, self.world
+        mine = self._pbuf("ls_mine", (n,), v.dtype, dev)
+        gathered = self._pbuf("ls_gathered", (G * n,), v.dtype, dev)
+        v_all, v2_all = self._pbuf("ls_v", (G * B,), v.dtype, dev), self._pbuf("ls_v2", (G * B,), v.dtype, dev)
+        norms_g = self._pbuf("ls_norms", (3,), norms.dtype, dev)
+        state = {}
+
+        def start():
+            mine[:B].copy_(v)
+            mine[B:2 * B].copy_(v2)
+            mine[2 * B:].copy_(norms)
+            if self.host_staged and mine.is_cuda:
+                hg = torch.empty((G * n,), dtype=mine.dtype)
+                self.dist.all_gather_into_tensor(hg, mine.cpu(), group=self.group)
+                gathered.copy_(hg)
+                state["work"] = None
+            else:
+                state["work"] = self.dist.all_gather_into_tensor(gathered, mine, group=self.group, async_op=True)
 
         def finish():
+            work = state.pop("work", None)
             if work is not None:
                 work.wait()          # stream-level wait on the communication stream, no host sync
-            g = gathered.view(self.world, mine.shape[0])
-            norms_g = g[:, 2 * B:].sum(0).to(norms.dtype)      # counts: exact in fp32 below 2^24
-            return g[:, :B].reshape(-1).contiguous(), g[:, B:2 * B].reshape(-1).contiguous(), norms_g
-        return finish
+            g = gathered.view(G, n)
+            v_all.view(G, B).copy_(g[:, :B])
+            v2_all.view(G, B).copy_(g[:, B:2 * B])
+            torch.sum(g[:, 2 * B:], 0, out=norms_g)          # counts: exact in fp32 below 2^24
+            return v_all, v2_all, norms_g
+        H.host_action(start)
+        return lambda: H.host_action(finish)
 
     def gather_rows(self, ids, rows):
         """Sparse exchange of id-table gradients: returns a CLOSURE that yields (ids of all ranks [G*B], rows of all ranks
@@ -240,24 +262,38 @@ class DPComm:
         if not self.active:
             return lambda: (ids, rows)
         ids, rows = ids.contiguous(), rows.contiguous()
+        if ids.dtype != torch.int64:
+            ids = ids.to(torch.int64)
         B, w = rows.shape
-        packed = torch.empty((B, w + 2), dtype=torch.float32, device=rows.device)
-        packed[:, :w] = rows
-        packed[:, w:] = ids.to(torch.int64).view(B, 1).view(torch.float32)          # bit pattern of the id, not a conversion
-        if self.host_staged and rows.is_cuda:
-            hg = torch.empty((self.world * B, w + 2), dtype=torch.float32)
-            self.dist.all_gather_into_tensor(hg, packed.cpu(), group=self.group)
-            gathered, work = hg.to(rows.device), None
-        else:
-            gathered = torch.empty((self.world * B, w + 2), dtype=torch.float32, device=rows.device)
-            work = self.dist.all_gather_into_tensor(gathered, packed, group=self._row_group(), async_op=True)
+        G, dev = self.world, rows.device
+        seq = self.__dict__.get("_gr_seq", 0)          # (which exchange of the step: reset by Trainer at the head of the backward)
+        self._gr_seq = seq + 1
+        packed = self._pbuf(("gr_packed", seq), (B, w + 2), torch.float32, dev)
+        gathered = self._pbuf(("gr_gathered", seq), (G * B, w + 2), torch.float32, dev)
+        ids_all = self._pbuf(("gr_ids", seq), (G * B,), torch.int64, dev)
+        rows_all = self._pbuf(("gr_rows", seq), (G * B, w), torch.float32, dev)
+        state = {}
+
+        def start():
+            packed[:, :w].copy_(rows)
+            packed[:, w:].copy_(ids.view(B, 1).view(torch.float32))          # bit pattern of the id, not a conversion
+            if self.host_staged and rows.is_cuda:
+                hg = torch.empty((G * B, w + 2), dtype=torch.float32)
+                self.dist.all_gather_into_tensor(hg, packed.cpu(), group=self.group)
+                gathered.copy_(hg)
+                state["work"] = None
+            else:
+                state["work"] = self.dist.all_gather_into_tensor(gathered, packed, group=self._row_group(), async_op=True)
 
         def finish():
+            work = state.pop("work", None)
             if work is not None:
                 work.wait()          # stream-level wait on the row group's communication stream, no host sync
-            ids_all = gathered[:, w:].contiguous().view(torch.int64).view(-1)
-            return ids_all.to(ids.dtype), gathered[:, :w].contiguous()
-        return finish
+            ids_all.copy_(gathered[:, w:].contiguous().view(torch.int64).view(-1))
+            rows_all.copy_(gathered[:, :w])
+            return ids_all, rows_all
+        H.host_action(start)
+        return lambda: H.host_action(finish)
 
     def _row_group(self):
         """Process group of the row exchange (same ranks as the gradient group; created on first use, by every rank at the
@@ -366,8 +402,6 @@ class Trainer:
         self._pf_stream = None
         self._norm_fresh = False
         if self.device_state:
-            if self.comm.active:
-                raise RuntimeError("device_state (graph capture) is a single-GPU mode: the data-parallel step issues collectives from Python")
             # the device step state (seed words, step count) is ONE process-global __device__ struct: a second device_state
             # trainer takes it over, the first one must not step any more (it would silently run on the other's seed and count)
             prev = Trainer._device_state_owner
@@ -376,10 +410,26 @@ class Trainer:
             Trainer._device_state_owner = weakref.ref(self)
             self.opt.device_state = True
             seed0 = int(torch.randint(0, 2 ** 62, (1,)).item())          # torch.manual_seed -> reproducible runs
+            if self.comm.rank:          # data-parallel ranks seed torch identically: every rank drops different elements of its rows
+                seed0 = (seed0 ^ (self.comm.rank * 0x9E3779B97F4A7C15)) & (2 ** 62 - 1)
             H.step_set(seed0, self.opt.step_count, *self.opt.betas)
             st.live_seed = H.LIVE_SEED | 0x5E6D0001          # the (constant) seed argument of every dropout launch
 
     def _on_bucket(self, name, after_side=False):
+        # a host action of the step: a recorded step (record / run_recorded) calls it again at the same point of the launch order
+        H.host_action(functools.partial(self._on_bucket_now, name, after_side))
+
+    def _reset_buckets(self):
+        self._bucket_works = []
+        self._pending_range = None
+        self.comm._gr_seq = 0
+
+    def _wait_buckets(self, idxs):
+        for i in idxs:
+            for w in self._bucket_works[i][2]:
+                w.wait()
+
+    def _on_bucket_now(self, name, after_side=False):
         """Called from inside the backward the moment the gradients of bucket ``name`` are written (``after_side``: part of
         them by launches still in flight on the engine's side stream).  Adjacent buckets are MERGED until ``bucket_bytes`` of
         gradients are pending (a collective call costs ~0.2 ms of host time, whatever its size), then one asynchronous
@@ -605,8 +655,10 @@ class Trainer:
                 usr_id = torch.randint(1, max(n_users, 2), usr_id.shape, device=usr_id.device)
         out = model(usr_image=usr, usr_id=usr_id, usr_mask=um, vid_image=vid,
                     vid_id=batch["photo_identity_id"], vid_mask=vm, gt=batch["label"], mode="train")
-        self._bucket_works = []
-        self._pending_range = None
+        if self.comm.active:
+            H.host_action(self._reset_buckets)          # (a host action of the recorded data-parallel step)
+        else:
+            self._reset_buckets()
         # seed the backward with the model's own constant-one tensor: the head recognises it (same storage) and skips both the
         # ones_like fill autograd would launch and the dlogits * 1 multiply
         if self._param_hooks():
@@ -619,33 +671,34 @@ class Trainer:
         else:
             torch.autograd.backward(out["loss"], grad_tensors=[model.unit_grad(out["loss"].device)])
         if self.comm.active and self.overlap:
-            self._flush_bucket()          # the tail of the backward (embedding gradients) that stayed below the merge threshold
+            H.host_action(self._flush_bucket)          # the tail of the backward (embedding gradients) that stayed below the merge threshold
         if self.comm.active and self.overlap and self.per_bucket_adamw and self._covers_live(st):
             # AdamW per bucket, in completion order: each launch waits (stream-level) only for its own bucket's all-reduce, so
             # the optimizer of the early buckets runs under the collectives of the late ones and only the last, small bucket
             # (the video-side embedding) is exposed
             # ... in TWO launches: every cross-stream wait costs ~15 us of queue time on the GPU, so the buckets that
             # completed early (a contiguous prefix of the flat buffer: head | layers ...) are stepped together, then the last one
+            H.mark(H.PHASE_STEP_TAIL)
             self.opt.begin_step()
-            bw = sorted(self._bucket_works, key=lambda x: x[0])
-            last = self._bucket_works[-1]
-            early = [x for x in bw if x is not last]
-            if early and early[-1][1] <= last[0] and all(a[1] == b[0] for a, b in zip(early, early[1:])):
-                for _, _, works in early:
-                    for w in works:
-                        w.wait()
-                self.opt.step_range(early[0][0], early[-1][1])
-                for w in last[2]:
-                    w.wait()
-                self.opt.step_range(last[0], last[1])
+            works = self._bucket_works
+            order = sorted(range(len(works)), key=lambda i: works[i][0])
+            last = len(works) - 1
+            early = [i for i in order if i != last]
+            if early and works[early[-1]][1] <= works[last][0] and all(works[a][1] == works[b][0] for a, b in zip(early, early[1:])):
+                H.host_action(functools.partial(self._wait_buckets, early))
+                self.opt.step_range(works[early[0]][0], works[early[-1]][1])
+                H.host_action(functools.partial(self._wait_buckets, [last]))
+                self.opt.step_range(works[last][0], works[last][1])
             else:          # not a prefix + tail (two backbones interleave their buckets): one launch per bucket
-                for s, e, works in self._bucket_works:
-                    for w in works:
-                        w.wait()
-                    self.opt.step_range(s, e)
+                for i in range(len(works)):
+                    H.host_action(functools.partial(self._wait_buckets, [i]))
+                    self.opt.step_range(works[i][0], works[i][1])
             self.opt.end_step()
             return out
         if self.comm.active:
+            if H.RECORDER is not None:
+                raise RuntimeError("record(): the data-parallel step is recorded in its default schedule only (overlapped bucket "
+                                   "all-reduces, per-bucket AdamW)")
             if not self.overlap:
                 self._reduce_dense(0, st.n_live)
             for _, _, works in self._bucket_works:
@@ -664,6 +717,8 @@ class Trainer:
         launches the graph: one host call per step."""
         if not self.device_state:
             raise RuntimeError("capture() needs Trainer(device_state=True)")
+        if self.comm.active:
+            raise RuntimeError("capture(): the data-parallel step issues its collectives from Python; use record() / run_recorded()")
         self._static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
         for _ in range(max(warmup, 1)):
             self.train_step(self._static)
@@ -703,8 +758,6 @@ class Trainer:
         work.  Results are bit-identical to ``train_step`` in the same mode."""
         if not self.device_state:
             raise RuntimeError("record() needs Trainer(device_state=True): the per-step state must live on the device")
-        if self.comm.active:
-            raise RuntimeError("record(): the data-parallel step issues its collectives from Python (not recorded)")
         model, st = self.model, self.model._store
         for bb in (model.backbone1, getattr(model, "backbone2", None)):
             abl = getattr(bb, "ablation_type", "ours") if bb is not None else "ours"
@@ -742,6 +795,8 @@ class Trainer:
         pspans = [(k, v.data_ptr(), v.numel() * v.element_size()) for k, v in prev.items() if torch.is_tensor(v) and v.numel()]
         relocs = []
         for ph, arr in phases:
+            if arr is None:
+                continue
             for ci in range(ph.n_cmds):
                 c = arr[ci]
                 if c.op < 0:
@@ -764,7 +819,7 @@ class Trainer:
             e.record()
         self._recorded = dict(phases=phases, keep=rec.keep, pool=pool, prev_batch=batch, out=out, relocs=relocs, spans={k: (sh, dt) for k, _, _, sh, dt in spans},
                               main=main, side=side, events=evs, ev_handles=(evs[0].cuda_event, evs[1].cuda_event),
-                              n_cmds=sum(ph.n_cmds for ph, _ in phases))
+                              n_cmds=sum(ph.n_cmds for ph, a in phases if a is not None))
         return out
 
     def run_recorded(self, batch: Dict[str, torch.Tensor]):
@@ -786,8 +841,11 @@ class Trainer:
         main, side, (ef, ej) = r["main"], r["side"], r["ev_handles"]
         if H._stream() != main:
             raise RuntimeError("run_recorded(): the current stream is not the stream the step was recorded on")
-        for ph, _ in r["phases"]:
-            H.run_phase(ph, main, side, ef, ej)
+        for ph, arr in r["phases"]:
+            if arr is None:
+                ph()          # a host action of the step (data-parallel collective / wait), at its place in the launch order
+            else:
+                H.run_phase(ph, main, side, ef, ej)
         # mirror the host side effects of the eager step (FusedAdamW.begin_step / end_step)
         self.opt.step_count += 1
         self.model._store.fused_version += 1

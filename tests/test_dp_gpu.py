@@ -241,3 +241,73 @@ def test_bench_launcher_four_ranks_on_one_gpu():
     assert rec["config"]["global_batch"] == 64 and rec["config"]["rows_per_gpu"] == 16
     assert rec["config"]["replicas_identical"] is True
     assert rec["config"]["parallelism"].startswith("dp4")
+
+
+def _run_recorded_dp(rank, world, port, name, backend, recorded, q):
+    """``world`` ranks on cuda:0 (gloo: host-staged collectives; nccl: one forced rank), device-state trainer, dropout ON; the
+    steps are enqueued launch by launch from Python (recorded = 0) or as recorded launch sequences replayed from C around the
+    step's collectives (recorded = 1: Trainer.record / run_recorded)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      SEGMM_DP_FORCE="1" if world == 1 else "0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from segmminterest_amd.trainer import DPComm, Trainer, shard_rows
+    torch.cuda.set_device(0)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cfg, g, _, _ = load_case(name)
+        torch.manual_seed(11)
+        model = build_model(cfg)
+        model.load_state_dict(g["sd"])
+        model = model.cuda()
+        tr = Trainer(model, comm=DPComm(), overlap=True, dropout=True, device_state=True)
+        assert tr.comm.active
+        fulls = [_batch(cfg, 16)] + [{k: (v.roll(3 * i, 0) if torch.is_tensor(v) else v) for k, v in _batch(cfg, 16).items()} for i in (1, 2)]
+        s, e = shard_rows(16, world, rank)
+        shards = [{k: v[s:e].contiguous().cuda() for k, v in f.items()} for f in fulls]
+        losses = []
+        if recorded:
+            tr.record(shards[0], warmup=2)
+        else:
+            for _ in range(3):
+                tr.train_step(shards[0])
+        for t in range(6):
+            out = tr.run_recorded(shards[t % 3]) if recorded else tr.train_step(shards[t % 3])
+            losses.append(float(tr.comm.sum_scalar(out["loss"].detach().clone())))
+        torch.cuda.synchronize()
+        if recorded:
+            n_host = sum(1 for _, a in tr._recorded["phases"] if a is None)
+            assert n_host >= 6          # label statistics (2), bucket hooks, waits
+        if rank == 0:
+            q.put((losses, model._store.flat.detach().cpu().numpy(), tr.opt.m.cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,backend,world", [("img_d32_N3_alllosses", "nccl", 1), ("id_d32_N2", "nccl", 1), ("img_d32_N3_alllosses", "gloo", 2),
+                                                ("id_d32_N2", "gloo", 2)])
+def test_recorded_data_parallel_step_equals_eager(name, backend, world):
+    """The data-parallel step as recorded launch sequences (main_for_seq_leave_earlystop_SegMM.py:265-300 under DP):
+    the collectives stay host actions -- label-statistics all-gather, merged bucket all-reduces issued from inside the backward,
+    waits before each AdamW range, the id tables' sparse row exchange -- replayed at their places between the C phases.  Six steps
+    on rotating shards, dropout on: losses, parameters and optimizer moments BIT-IDENTICAL to the same steps enqueued from Python,
+    through RCCL (one forced rank) and with two host-staged ranks sharing the GPU."""
+    ctx = mp.get_context("spawn")
+    res = {}
+    for recorded in (0, 1):
+        q = ctx.Queue()
+        port = 29850 + (os.getpid() + 3 * recorded + (11 if name.startswith("id") else 0) + (23 if backend == "gloo" else 0)) % 120
+        procs = [ctx.Process(target=_run_recorded_dp, args=(r, world, port, name, backend, recorded, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res[recorded] = q.get(timeout=300)
+        for p in procs:
+            p.join(60)
+            assert p.exitcode == 0
+    (l0, p0, m0), (l1, p1, m1) = res[0], res[1]
+    assert l0 == l1, (l0, l1)
+    assert (p0 == p1).all() and (m0 == m1).all()

@@ -508,6 +508,7 @@ def test_recorded_step_equals_eager_device_state_step(kind, N, B, S, Lt, D, h):
         seed, step, _ = H.step_get()
         assert tr.opt.step_count == step == 4 + T
         if recorded:
+            assert all(a is not None for _, a in tr._recorded["phases"])          # single GPU: C phases only, no host action
             kinds = [ph.kind for ph, _ in tr._recorded["phases"]]
             assert kinds[0] == H.PHASE_STEP_BEGIN and kinds[-1] == H.PHASE_STEP_TAIL and H.PHASE_LAYER_FWD in kinds and H.PHASE_LAYER_BWD in kinds
             assert len(tr._recorded["relocs"]) >= 3
