@@ -99,9 +99,11 @@ def parse_args():
                          "the host enqueues one graph launch + the batch copy per step.  --device-state alone runs the same step eagerly.")
     ap.add_argument("--device-state", action="store_true", help="the device-state step without graph capture (A/B partner of --graph)")
     ap.add_argument("--recorded", action="store_true",
-                    help="Trainer(device_state=True).record() -- the step's launch sequence is recorded once and every timed step "
-                         "is enqueued from C, one call per phase (segmm_step_begin, segmm_embed_fwd, segmm_layer_fwd, ... segmm_step_tail): "
-                         "the eager two-stream schedule without the per-launch host work")
+                    help="(the default step mode) Trainer(device_state=True).record() -- the step's launch sequence is recorded once and every "
+                         "timed step is enqueued from C, one call per phase (segmm_step_begin, segmm_embed_fwd, segmm_layer_fwd, ... "
+                         "segmm_step_tail), data-parallel collectives as host actions in between: the eager two-stream schedule without the "
+                         "per-launch host work.  Bit-identical to the per-launch step (tests/test_eval_gpu.py, tests/test_dp_gpu.py)")
+    ap.add_argument("--eager", action="store_true", help="enqueue every launch of every step from Python (the round-1..3 step mode; A/B partner of the default)")
     ap.add_argument("--no-probe", action="store_true", help="skip the sustained-MFMA probe (roofline.sustained_probe)")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
                     help="gloo: CPU-staged collectives, lets several ranks share one GPU (CI rehearsal of the N > 1 path)")
@@ -153,7 +155,9 @@ def _claim_stdout():
 def _graph_mode_legs(args):
     """--graph / --device-state measure the step itself: the extra legs (second trainer on the f32 engine, host-fed inputs)
     would rebuild the device-side step state under the first trainer."""
-    if args.graph or args.device_state or args.recorded:
+    if not (args.eager or args.graph or args.device_state or args.prefetch):
+        args.recorded = True
+    if args.graph:
         args.no_f32_engine = True
         args.no_host_fed = True
     return args
@@ -343,10 +347,28 @@ def main():
         if world > 1 or args.prefetch:
             raise SystemExit("--graph: single GPU, no prefetch")
         trainer.capture(batches[0], warmup=max(args.warmup, 3))
+    # ---- instrumented pass: steps with a HIP-event pair around every GEMM / attention / optimizer launch (recorded on the
+    # launch's own stream), enqueued launch by launch.  Kept OUT of the timed region (the event pairs cost queue time) and, in the
+    # default step mode, run BEFORE the step is recorded: it is the same launch sequence on the same two streams.
+    def instrumented(start):
+        psteps_ = min(args.steps, 10)
+        hipabi.GEMM_PROFILE, hipabi.ATTN_PROFILE, hipabi.KERNEL_PROFILE = [], [], []
+        barrier()
+        tp0_ = time.perf_counter()
+        run(trainer, psteps_, start)
+        barrier()
+        el = time.perf_counter() - tp0_
+        res = (psteps_, hipabi.GEMM_PROFILE, hipabi.ATTN_PROFILE, hipabi.KERNEL_PROFILE, el)
+        hipabi.GEMM_PROFILE = hipabi.ATTN_PROFILE = hipabi.KERNEL_PROFILE = None
+        return res
+
+    inst = None
     if args.recorded:
         if args.prefetch:
             raise SystemExit("--recorded: no prefetch")
-        trainer.record(batches[0], warmup=max(args.warmup, 3))
+        run(trainer, max(args.warmup, 3))
+        inst = instrumented(args.warmup)
+        trainer.record(batches[0], warmup=2)
     run(trainer, args.warmup)
     # ---- the timed region: `windows` windows of EXACTLY `steps` steps, each bracketed by barrier + synchronize on both sides,
     # MAX over ranks per window; `value` is the median window (value_min / value_max beside it)
@@ -367,18 +389,9 @@ def main():
     elapsed = win[len(win) // 2]
     rows_per_s = world * B * args.steps / elapsed
 
-    # ---- instrumented pass: the SAME steps again with a HIP-event pair around every GEMM / attention / optimizer launch
-    # (recorded on the launch's own stream).  Kept out of the timed region: the event pairs cost queue time.
-    psteps = min(args.steps, 10)
-    hipabi.GEMM_PROFILE = prof = []
-    hipabi.ATTN_PROFILE = aprof = []
-    hipabi.KERNEL_PROFILE = kprof = []
-    barrier()
-    tp0 = time.perf_counter()
-    run(trainer, psteps, args.warmup + len(win) * args.steps)
-    barrier()
-    prof_elapsed = time.perf_counter() - tp0
-    hipabi.GEMM_PROFILE = hipabi.ATTN_PROFILE = hipabi.KERNEL_PROFILE = None
+    if inst is None:
+        inst = instrumented(args.warmup + len(win) * args.steps)
+    psteps, prof, aprof, kprof, prof_elapsed = inst
 
     # data parallel: the replicas must still hold the SAME parameters (fp64 checksums of the flat parameter buffer of every rank)
     replicas_identical = None
@@ -480,8 +493,8 @@ def main():
                                "frac": round(achieved / peak, 4), "traffic": traffic, "algorithmic_bytes_per_launch": round(alg_bytes),
                                "launches": len(prof), "profiled_steps": psteps, "gemm_busy_ms_per_step": round(gemm_ms / psteps, 4),
                                "ms_per_step_with_events": round(1e3 * prof_elapsed / psteps, 4),
-                               "note": "achieved = algorithmic 2MNK of every GEMM launch of the instrumented pass (same steps, run right after the "
-                                       "timed region) / union of their HIP-event intervals (weight-gradient GEMMs overlap input-gradient GEMMs on a "
+                               "note": "achieved = algorithmic 2MNK of every GEMM launch of the instrumented pass (the same steps enqueued launch by launch with "
+                                       "an event pair per GEMM, outside the timed region) / union of their HIP-event intervals (weight-gradient GEMMs overlap input-gradient GEMMs on a "
                                        "second stream); peak = dense MFMA peak of the instruction used"
                                        + {"bf16x6": " / 6 partial products", "f16x3": " / 3 partial products", "f16x3p": " / 3 partial products", "f32": ""}[engine]
                                        + traffic_note}
@@ -579,7 +592,10 @@ def main():
                 torch.cuda.current_stream().wait_event(ready[j])
                 b = dict(batches[i % len(batches)])
                 b.update(dbuf[j])
-                trainer.train_step(b)
+                if trainer.__dict__.get("_recorded") is not None:
+                    trainer.run_recorded(b)
+                else:
+                    trainer.train_step(b)
                 consumed[j].record()
 
         hsteps = min(args.steps, 10)

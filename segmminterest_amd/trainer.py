@@ -636,7 +636,11 @@ class Trainer:
             st._trusted = True
             if next_batch is not None:
                 self.prefetch(next_batch)
-            return self._train_step(batch, usr, um, vid, vm)
+            out = self._train_step(batch, usr, um, vid, vm)
+            r = self.__dict__.get("_recorded")
+            if r is not None and H.RECORDER is None:
+                r["prev_batch"] = batch          # a recorded step that follows names this step's batch as "the previous one"
+            return out
         finally:
             st._trusted = False
             if self.device_state:
@@ -814,10 +818,17 @@ class Trainer:
                             if base <= pv < base + nb:
                                 relocs.append((arr, ci, ai, k, pv - base, 1))
                                 break
+        # host-side state of the eager path that names a batch tensor (id mode: the id list whose table-gradient rows the NEXT
+        # backward clears): kept current by run_recorded, so that eager steps and recorded steps can be mixed
+        tab_keys = []
+        for ek, (gptr, t) in getattr(st, "_tab_rows", {}).items():
+            for k, base, nb, _, _ in spans:
+                if base <= t.data_ptr() < base + nb and t.data_ptr() == base and t.numel() * t.element_size() == nb:
+                    tab_keys.append((ek, gptr, k))
         evs = (torch.cuda.Event(), torch.cuda.Event())
         for e in evs:
             e.record()
-        self._recorded = dict(phases=phases, keep=rec.keep, pool=pool, prev_batch=batch, out=out, relocs=relocs, spans={k: (sh, dt) for k, _, _, sh, dt in spans},
+        self._recorded = dict(phases=phases, keep=rec.keep, pool=pool, prev_batch=batch, tab_keys=tab_keys, out=out, relocs=relocs, spans={k: (sh, dt) for k, _, _, sh, dt in spans},
                               main=main, side=side, events=evs, ev_handles=(evs[0].cuda_event, evs[1].cuda_event),
                               n_cmds=sum(ph.n_cmds for ph, a in phases if a is not None))
         return out
@@ -846,9 +857,13 @@ class Trainer:
                 ph()          # a host action of the step (data-parallel collective / wait), at its place in the launch order
             else:
                 H.run_phase(ph, main, side, ef, ej)
-        # mirror the host side effects of the eager step (FusedAdamW.begin_step / end_step)
+        # mirror the host side effects of the eager step (FusedAdamW.begin_step / end_step; the id list of the table rows this
+        # step's backward scattered into)
         self.opt.step_count += 1
-        self.model._store.fused_version += 1
+        st = self.model._store
+        st.fused_version += 1
+        for ek, gptr, k in r["tab_keys"]:
+            st._tab_rows[ek] = (gptr, batch[k].reshape(-1))
         return r["out"]
 
     def _param_hooks(self) -> bool:
