@@ -167,6 +167,11 @@ class ParamStore:
         # video-token chain.  On-the-fly engines: -0.3 % (off); plane engine (one workgroup per CU: the tail of one kernel and the
         # HBM-bound LayerNorms fill under the other chain's GEMMs): +1.2 %, same-box alternating runs (on)
         self.fwd_side = os.environ.get("SEGMM_FWD_SIDE", "1" if H.GEMM_ENGINE == H.ENGINE_F16X3P else "0") != "0"
+        # full layers (N >= 3): the user-token chain of a layer (attention with user queries -> ff -> LayerNorm -> MLP -> LayerNorm,
+        # and its backward) is independent of the video-token chain between the fused projections and the next layer: it runs on
+        # the side stream.  At config 3 its GEMMs have M = 1024 rows (4 - 12 tiles on 256 CUs) and used to sit on the main stream
+        # between the video side's kernels.
+        self.usr_side = os.environ.get("SEGMM_USR_SIDE", "1") != "0"
         self.ln_side = os.environ.get("SEGMM_LN_SIDE", "0") != "0"      # measured: -2 % (kept as a knob)     # measured: no gain (kept as a knob)
         # pre-split bf16 planes of the weights for the bf16x6 GEMM engine: W planes (forward) and W^T planes (dgrad
         # in the NT form), refreshed when the parameters change (one split pass per optimizer step)
@@ -617,7 +622,7 @@ def side_work(store):
     their workgroups fill the CUs that the last, partial round of a 960-workgroup dgrad GEMM leaves idle
     (profiles/README.md: 1.875 rounds on 512 slots).  Buffers these launches read carry the layer index in
     their scratch name, so the main stream never overwrites them before the join."""
-    if not store.overlap:
+    if not store.overlap or store._on_side:          # (nested: the caller already runs on the side stream)
         yield
         return
     main = torch.cuda.current_stream()
@@ -1097,31 +1102,34 @@ class BackboneRun:
         H.pool_tokens(Zu, Lt, Zv, S, out, B, d, POOL_BINS)       # AdaptiveAvgPool1d(40) over cat(user, video) tokens
         return out
 
-    def _side_post(self, i, L, side, X, A, M, kinds, out_is_operand):
+    def _side_post_alloc(self, i, side, ref, M, out_is_operand):
+        """Buffers and Acts of _side_post, allocated by the caller on the MAIN stream (the chain itself may run on the side
+        stream: the caching allocator must never see a block whose first owner is the side stream)."""
+        st, d, am = self.store, self.d, self.am
+        sn = "%sL%d.%s." % (self.pre, i, side)
+        return dict(R1=_empty(ref, M, d), m1=_empty(ref, M), r1=_empty(ref, M),
+                    X1=new_act(st, am, M, d, site=sn + "X1", delayed=self.delayed), G=_empty(ref, M, d),
+                    Hh=new_act(st, am, M, d, site=sn + "H", delayed=self.delayed), R2=_empty(ref, M, d), m2=_empty(ref, M), r2=_empty(ref, M),
+                    X2=new_act(st, am, M, d, planes=out_is_operand, site=sn + "X2", delayed=self.delayed))
+
+    def _side_post(self, i, L, side, X, A, M, kinds, out_is_operand, bufs=None):
         """R1 = X + drop(A.Wff^T+b); X1 = LN(R1); H = drop(gelu(X1.W0^T+b0)); R2 = X1 + drop(H.W1^T+b1); X2 = LN(R2).
         X, A: Acts; returns (X2 Act, saved)."""
-        st, d, seed, am = self.store, self.d, self.seed, self.am
+        st, d, seed = self.store, self.d, self.seed
         k_ao, k_mi, k_mo = kinds
         ca = L + "cross_attn."
-        R1 = _empty(X.t, M, d)
+        b = bufs if bufs is not None else self._side_post_alloc(i, side, X.t, M, out_is_operand)
+        R1, m1, r1, X1, G, Hh, R2, m2, r2, X2 = (b[k] for k in ("R1", "m1", "r1", "X1", "G", "Hh", "R2", "m2", "r2", "X2"))
         _lin_fwd(st, M, d, d, A, ca + "ff_%s.weight" % side, R1, d, bias=st.p(ca + "ff_%s.bias" % side),
                  residual=X.t, ldr=d, res_period=M, drop_p=self.p_drop, seed=seed, site=_site(self.bi, i, k_ao))
-        m1, r1 = _empty(X.t, M), _empty(X.t, M)
-        sn = "%sL%d.%s." % (self.pre, i, side)
-        X1 = new_act(st, am, M, d, site=sn + "X1", delayed=self.delayed)
         H.layernorm_fwd(R1, st.p(ca + "ln_%s.weight" % side), st.p(ca + "ln_%s.bias" % side), X1.t, m1, r1, amax=X1.slots, po=X1.po)
         finish_act(st, produced(X1))
-        G = _empty(X.t, M, d)
-        Hh = new_act(st, am, M, d, site=sn + "H", delayed=self.delayed)
         ff = L + "ff_%s.layers." % side
         _lin_fwd(st, M, d, d, X1, ff + "0.weight", Hh.t, d, bias=st.p(ff + "0.bias"), c_act=Hh,
                  activation=H.ACT_GELU, aux=G, ldaux=d, drop_p=self.p_inner, seed=seed, site=_site(self.bi, i, k_mi))
         finish_act(st, Hh)
-        R2 = _empty(X.t, M, d)
         _lin_fwd(st, M, d, d, Hh, ff + "1.weight", R2, d, bias=st.p(ff + "1.bias"),
                  residual=X1.t, ldr=d, res_period=M, drop_p=self.p_drop, seed=seed, site=_site(self.bi, i, k_mo))
-        m2, r2 = _empty(X.t, M), _empty(X.t, M)
-        X2 = new_act(st, am, M, d, planes=out_is_operand, site=sn + "X2", delayed=self.delayed)
         H.layernorm_fwd(R2, st.p(L + "ln_%s.weight" % side), st.p(L + "ln_%s.bias" % side), X2.t, m2, r2, amax=X2.slots, po=X2.po)
         finish_act(st, produced(X2))
         return X2, dict(A=A, R1=R1, X1=X1, m1=m1, r1=r1, G=G, Hh=Hh, R2=R2, m2=m2, r2=r2)
@@ -1172,21 +1180,36 @@ class BackboneRun:
         vq, uq = self._attn_views(full, Yv, Yu, nv, nu)
         lse_v = _empty(Xv.t, 2, B, Hh, S)
         Av = new_act(st, am, Mv, d, site="%sL%d.vid.A" % (P, i), delayed=self.delayed)
+        rec = dict(full=full, Xv=Xv, Xu=Xu, Yv=Yv, Yu=Yu, lse_v=lse_v)
+        X2u = None
+        usr_ctx = None
+        if full:
+            # the user-token chain: every buffer allocated here, on the main stream, then the launches on the side stream
+            lse_u = _empty(Xv.t, 2, B, Hh, Lt)
+            Au = new_act(st, am, Mu, d, site="%sL%d.usr.A" % (P, i), delayed=self.delayed)
+            bufs_u = self._side_post_alloc(i, "usr", Xv.t, Mu, True)
+
+            def usr_chain():
+                H.attn_fwd(B, Hh, dh, Lt, uq["La"], uq["Lb"], uq["Qa"], uq["Qb"], uq["ldq"], uq["Ka"], uq["Va"], uq["ldka"], uq["Kb"],
+                           uq["Vb"], uq["ldkb"], self.um, self.vm, self.um, Au.t, d, lse_u, drop_p=self.p_drop,
+                           seed=self.seed, site=_site(self.bi, i, K_ATT_U), amax_o=Au.slots, po=Au.po)
+                finish_act(st, produced(Au))
+                return self._side_post(i, L, "usr", Xu, Au, Mu, (K_AO_U, K_MI_U, K_MO_U), out_is_operand=True, bufs=bufs_u)
+            if st.usr_side and st.overlap:
+                with side_work(st):          # (both fused projections are enqueued on the main stream: the fork orders the chain behind them)
+                    X2u, sv_u = usr_chain()
+                usr_ctx = True
         H.attn_fwd(B, Hh, dh, S, vq["La"], vq["Lb"], vq["Qa"], vq["Qb"], vq["ldq"], vq["Ka"], vq["Va"], vq["ldka"], vq["Kb"], vq["Vb"],
                    vq["ldkb"], self.vm, self.vm, self.um, Av.t, d, lse_v, drop_p=self.p_drop, seed=self.seed,
                    site=_site(self.bi, i, K_ATT_V), amax_o=Av.slots, po=Av.po)
         finish_act(st, produced(Av))
         X2v, sv_v = self._side_post(i, L, "vid", Xv, Av, Mv, (K_AO_V, K_MI_V, K_MO_V), out_is_operand=i < self.N - 2)
-        rec = dict(full=full, Xv=Xv, Xu=Xu, Yv=Yv, Yu=Yu, lse_v=lse_v, v=sv_v)
-        X2u = None
+        rec["v"] = sv_v
         if full:
-            lse_u = _empty(Xv.t, 2, B, Hh, Lt)
-            Au = new_act(st, am, Mu, d, site="%sL%d.usr.A" % (P, i), delayed=self.delayed)
-            H.attn_fwd(B, Hh, dh, Lt, uq["La"], uq["Lb"], uq["Qa"], uq["Qb"], uq["ldq"], uq["Ka"], uq["Va"], uq["ldka"], uq["Kb"],
-                       uq["Vb"], uq["ldkb"], self.um, self.vm, self.um, Au.t, d, lse_u, drop_p=self.p_drop,
-                       seed=self.seed, site=_site(self.bi, i, K_ATT_U), amax_o=Au.slots, po=Au.po)
-            finish_act(st, produced(Au))
-            X2u, sv_u = self._side_post(i, L, "usr", Xu, Au, Mu, (K_AO_U, K_MI_U, K_MO_U), out_is_operand=True)
+            if usr_ctx:
+                join_side(st)          # the next layer's projections (main stream) read the user chain's output
+            else:
+                X2u, sv_u = usr_chain()
             rec["lse_u"], rec["u"] = lse_u, sv_u
         self.sv["layers"].append(rec)
         return X2v, (X2u if full else Xu)
@@ -1276,6 +1299,30 @@ class BackboneRun:
                 pl.hdr_kb, pl.sin_kb = dkb_.hdr.data_ptr(), dkb_.scale_ptr
             return pl
         deferred = [] if st.defer_wgrad else None
+        attn_u = None
+        dR1u = None
+        usr_on_side = full and st.usr_side and st.overlap
+        if full:
+            Dv_u = st.buf("attnD_u", (B * Hh * max(S, Lt),))
+
+            def usr_bwd():
+                dR1u_, dAu = self._side_post_bwd(i, L, "usr", rec["u"], dXu_out, Mu, (K_AO_U, K_MI_U, K_MO_U), gbuf, "u%d" % i, deferred)
+                flush_deferred(st, deferred)
+
+                def attn_u_(pflags):
+                    _attn_bwd(st, B, Hh, dh, Lt, uq["La"], uq["Lb"], uq["Qa"], uq["Qb"], uq["ldq"], uq["Ka"], uq["Va"], uq["ldka"], uq["Kb"],
+                               uq["Vb"], uq["ldkb"], self.um, self.vm, self.um, rec["lse_u"], rec["u"]["A"].t, d, dAu, d, Dv_u,
+                               duq["Qa"], duq["Qb"], duq["ldq"], duq["Ka"], duq["Va"], duq["ldka"], duq["Kb"], duq["Vb"], duq["ldkb"],
+                               drop_p=self.p_drop, seed=self.seed, site=_site(self.bi, i, K_ATT_U),
+                               amax_q=sl_u, amax_ka=sl_v, amax_kb=sl_u, planes=planes_of(dYu, dYv, dYu, duq, pflags))
+                attn_u_(H.ATTN_PLANES_ONLY if ponly else 0)
+                return dR1u_, attn_u_
+            if usr_on_side:
+                # the user-token chain of the layer's backward (LayerNorms, MLP and ff gradients, attention with user queries) on the
+                # side stream, next to the video-token chain: the two only meet in the fused dY buffers, where they write disjoint
+                # column blocks (the shared maxima slots are integer atomic maxima)
+                with side_work(st):
+                    dR1u, attn_u = usr_bwd()
         dR1v, dAv = self._side_post_bwd(i, L, "vid", rec["v"], dXv_out, Mv, (K_AO_V, K_MI_V, K_MO_V), gbuf, "v%d" % i, deferred)
         flush_deferred(st, deferred)          # the three weight-gradient GEMMs of this side run under the attention backward
         def attn_v(pflags):
@@ -1285,18 +1332,11 @@ class BackboneRun:
                        site=_site(self.bi, i, K_ATT_V), amax_q=sl_v, amax_ka=sl_v, amax_kb=sl_u,
                        planes=planes_of(dYv, dYv, dYu, dvq, pflags))
         attn_v(H.ATTN_PLANES_ONLY if ponly else 0)
-        attn_u = None
-        dR1u = None
         if full:
-            dR1u, dAu = self._side_post_bwd(i, L, "usr", rec["u"], dXu_out, Mu, (K_AO_U, K_MI_U, K_MO_U), gbuf, "u%d" % i, deferred)
-            flush_deferred(st, deferred)
-            def attn_u(pflags):
-                _attn_bwd(st, B, Hh, dh, Lt, uq["La"], uq["Lb"], uq["Qa"], uq["Qb"], uq["ldq"], uq["Ka"], uq["Va"], uq["ldka"], uq["Kb"],
-                           uq["Vb"], uq["ldkb"], self.um, self.vm, self.um, rec["lse_u"], rec["u"]["A"].t, d, dAu, d, Dv,
-                           duq["Qa"], duq["Qb"], duq["ldq"], duq["Ka"], duq["Va"], duq["ldka"], duq["Kb"], duq["Vb"], duq["ldkb"],
-                           drop_p=self.p_drop, seed=self.seed, site=_site(self.bi, i, K_ATT_U),
-                           amax_q=sl_u, amax_ka=sl_v, amax_kb=sl_u, planes=planes_of(dYu, dYv, dYu, duq, pflags))
-            attn_u(H.ATTN_PLANES_ONLY if ponly else 0)
+            if usr_on_side:
+                join_side(st)
+            else:
+                dR1u, attn_u = usr_bwd()
         if ponly:          # every producer of the two sites is enqueued: judge the sites (one tiny launch), then the repair pass
             H.site_fixup(dYv.hdr if dYv.po is not None else None, dYu.hdr if (nu and dYu.po is not None) else None,
                          stats=st.scales()[st.MAX_SITES:])
