@@ -271,6 +271,19 @@ int segmm_loss_fwd_bwd(int B, int S, const float* logits, const int64_t* gt, con
 /* K9 -- fused AdamW over one flat fp32 range (torch.optim.AdamW semantics; main_for_seq_leave_earlystop_SegMM.py:226,299) */
 int segmm_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                 float eps, float weight_decay, int step, segmm_stream_t stream);
+/* AdamW over an id-embedding table [n_rows, width] (encoder.py:352-362: nn.Embedding inputs) whose gradient is zero outside the
+ * rows listed in ids -- the batch's rows (duplicates allowed; ids outside [0, n_rows) are ignored) -- in TWO passes that together
+ * are the dense torch.optim.AdamW step (moments and weights of rows without a gradient still decay), element for element with the
+ * arithmetic of segmm_adamw:
+ *   phase 0: marks the listed rows in `flags`, then updates every UNMARKED row with g = 0.  It reads no gradient, so it can be
+ *            enqueued at the START of the step on a stream of its own (the forward and backward only read the listed rows of
+ *            the table): 28 B x 90 M parameters of HBM traffic leave the end of the step (config 3's 352 494 x 256 item table);
+ *   phase 1: the listed rows, each once (a mark is claimed and cleared by whoever updates the row), with their gradient rows
+ *            from g (the dense [n_rows, width] gradient).  Enqueue it after phase 0 AND the backward have completed.
+ * flags: n_rows 32-bit words owned by the caller, zero before the first call; zero again after phase 1.  step as in segmm_adamw. */
+int segmm_adamw_table(float* p, const float* g, float* m, float* v, int64_t n_rows, int width, const int64_t* ids, int n_ids,
+                      uint32_t* flags, float lr, float beta1, float beta2, float eps, float weight_decay, int step, int phase,
+                      segmm_stream_t stream);
 /* Device-side step state, so that a whole training step (main_for_seq_leave_earlystop_SegMM.py:265-300) can be captured in a
  * hipGraph and replayed with unchanged kernel arguments: two dropout seed words and the optimizer's step count with its bias
  * corrections live in device memory.  segmm_step_set initialises them, segmm_step_advance (one thread; the first launch of a
@@ -342,8 +355,9 @@ int segmm_pool_tokens_bwd(const float* dOut, float* dU, int Lu, float* dV, int L
  * does not pay a foreign-function call per kernel.  A PHASE is the resolved launch list of one such part of the step: an array
  * of commands, each naming one stream-taking entry point of this header (op = index into segmm_cmd_op_name) with its arguments
  * in declaration order as 8-byte slots (pointers and integers in .i / .p, float parameters as double in .f) and the stream slot
- * it is enqueued on (0 = main, 1 = side stream).  Two pseudo-ops order the two streams: SEGMM_OP_FORK (the side stream waits
- * for everything enqueued on the main stream so far) and SEGMM_OP_JOIN (the main stream waits for the side stream).
+ * it is enqueued on (0 = main stream, 1 = side stream, 2 = auxiliary stream).  Two pseudo-ops order a stream s >= 1 against the
+ * main stream: SEGMM_OP_FORK (stream s waits for everything enqueued on the main stream so far) and SEGMM_OP_JOIN (the main
+ * stream waits for stream s); s travels in the command's `stream` field.
  * The host builds a phase ONCE per workload shape -- segmminterest_amd/hipabi.py records the per-op calls of one eager step --
  * and replays it every step: kernel arguments do not change from step to step when the per-step state lives on the device
  * (segmm_step_advance: dropout seed words, optimizer step count) and buffers are persistent; the few that do (the batch's
@@ -371,16 +385,18 @@ typedef struct {
 /* number of dispatchable entry points / the name of op `op` (NULL outside [0, n)): hosts map names to op ids at load time */
 int segmm_cmd_op_count(void);
 const char* segmm_cmd_op_name(int op);
-/* ev_fork / ev_join: two hipEvent_t of the caller (disable-timing events), used by the fork / join pseudo-ops */
-int segmm_run_phase(const segmm_phase_t* phase, segmm_stream_t main_stream, segmm_stream_t side_stream, void* ev_fork, void* ev_join);
-int segmm_step_begin(const segmm_phase_t* phase, segmm_stream_t main_stream, segmm_stream_t side_stream, void* ev_fork, void* ev_join);
-int segmm_embed_fwd(const segmm_phase_t* phase, segmm_stream_t main_stream, segmm_stream_t side_stream, void* ev_fork, void* ev_join);
-int segmm_layer_fwd(const segmm_phase_t* phase, segmm_stream_t main_stream, segmm_stream_t side_stream, void* ev_fork, void* ev_join);
-int segmm_head_loss_fwd(const segmm_phase_t* phase, segmm_stream_t main_stream, segmm_stream_t side_stream, void* ev_fork, void* ev_join);
-int segmm_head_loss_bwd(const segmm_phase_t* phase, segmm_stream_t main_stream, segmm_stream_t side_stream, void* ev_fork, void* ev_join);
-int segmm_layer_bwd(const segmm_phase_t* phase, segmm_stream_t main_stream, segmm_stream_t side_stream, void* ev_fork, void* ev_join);
-int segmm_embed_bwd(const segmm_phase_t* phase, segmm_stream_t main_stream, segmm_stream_t side_stream, void* ev_fork, void* ev_join);
-int segmm_step_tail(const segmm_phase_t* phase, segmm_stream_t main_stream, segmm_stream_t side_stream, void* ev_fork, void* ev_join);
+/* streams[0 .. n_streams): hipStream_t of the slots (streams[0] = main; n_streams <= SEGMM_MAX_STREAMS); events[2 (s - 1)] and
+ * events[2 (s - 1) + 1]: two hipEvent_t of the caller (disable-timing events) per stream s >= 1, used by its fork / join pseudo-ops */
+#define SEGMM_MAX_STREAMS 3
+int segmm_run_phase(const segmm_phase_t* phase, const segmm_stream_t* streams, int n_streams, void* const* events);
+int segmm_step_begin(const segmm_phase_t* phase, const segmm_stream_t* streams, int n_streams, void* const* events);
+int segmm_embed_fwd(const segmm_phase_t* phase, const segmm_stream_t* streams, int n_streams, void* const* events);
+int segmm_layer_fwd(const segmm_phase_t* phase, const segmm_stream_t* streams, int n_streams, void* const* events);
+int segmm_head_loss_fwd(const segmm_phase_t* phase, const segmm_stream_t* streams, int n_streams, void* const* events);
+int segmm_head_loss_bwd(const segmm_phase_t* phase, const segmm_stream_t* streams, int n_streams, void* const* events);
+int segmm_layer_bwd(const segmm_phase_t* phase, const segmm_stream_t* streams, int n_streams, void* const* events);
+int segmm_embed_bwd(const segmm_phase_t* phase, const segmm_stream_t* streams, int n_streams, void* const* events);
+int segmm_step_tail(const segmm_phase_t* phase, const segmm_stream_t* streams, int n_streams, void* const* events);
 /* bytes of p[0 .. bytes) = 0 on `stream` (the clears of the step path as a recordable command) */
 int segmm_fill_zero(void* p, int64_t bytes, segmm_stream_t stream);
 /* dst[0 .. bytes) = src[0 .. bytes), device to device, on `stream` (non-overlapping ranges) */

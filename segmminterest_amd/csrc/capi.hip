@@ -345,7 +345,7 @@ __global__ void step_get_kernel(StepState* out) { *out = g_step; }
 extern "C" {
 
 const char* segmm_last_error(void) { return g_segmm_err; }
-int segmm_abi_version(void) { return 21; }
+int segmm_abi_version(void) { return 22; }
 int segmm_attn_mode(int mode) { const int prev = attn_f16(); if (mode >= 0 && mode <= 2) g_attn_mode = mode; return prev; }
 
 static PlaneOut plane_out(uint16_t* planes, int ld2, float* hdr, const float* scale_in) {
@@ -1082,6 +1082,36 @@ int segmm_adamw(float* p, const float* g, float* m, float* v, int64_t n, float l
     return 0;
 }
 
+int segmm_adamw_table(float* p, const float* g, float* m, float* v, int64_t n_rows, int width, const int64_t* ids, int n_ids,
+                      uint32_t* flags, float lr, float beta1, float beta2, float eps, float weight_decay, int step, int phase,
+                      segmm_stream_t stream) {
+    SEGMM_REQUIRE(p && m && v && flags && (ids || n_ids == 0) && aligned16(p) && aligned16(m) && aligned16(v), "adamw_table: pointer/alignment");
+    SEGMM_REQUIRE(phase == 0 || (phase == 1 && g && aligned16(g)), "adamw_table: phase %d (0: rows without a gradient, 1: the listed rows; needs g)", phase);
+    SEGMM_REQUIRE(width > 0 && width % 4 == 0 && n_rows >= 0 && n_ids >= 0, "adamw_table: width %% 4, sizes");
+    SEGMM_REQUIRE(step >= 1 || step == -1, "adamw_table: step=%d (>= 1, or -1: the device-side step state)", step);
+    if (n_rows == 0) return 0;
+    const double bc1 = step > 0 ? 1.0 - pow((double)beta1, step) : 1.0, bc2 = step > 0 ? 1.0 - pow((double)beta2, step) : 1.0;
+    hipStream_t s = (hipStream_t)stream;
+    const int w4 = width / 4;
+    if (phase == 0) {
+        if (n_ids > 0) {
+            hipLaunchKernelGGL(table_mark_kernel, dim3((n_ids + 255) / 256), dim3(256), 0, s, (const long long*)ids, n_ids, (long long)n_rows, flags);
+            LAUNCH_CHECK();
+        }
+        long long blocks = (n_rows * w4 + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(adamw_table_rest_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, m, v, (long long)n_rows, w4, (const unsigned int*)flags,
+                           lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), step < 0 ? 1 : 0);
+        LAUNCH_CHECK();
+        return 0;
+    }
+    if (n_ids == 0) return 0;
+    hipLaunchKernelGGL(adamw_table_rows_kernel, dim3((n_ids + 3) / 4), dim3(256), 0, s, p, g, m, v, (long long)n_rows, w4, (const long long*)ids, n_ids,
+                       flags, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), step < 0 ? 1 : 0);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 int segmm_step_set(uint64_t seed, int step, float beta1, float beta2, segmm_stream_t stream) {
     SEGMM_REQUIRE(step >= 0, "step_set: step=%d", step);
     hipLaunchKernelGGL(step_set_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (uint32_t)seed, (uint32_t)(seed >> 32) & 0x7fffffffu, step, beta1, beta2);
@@ -1241,32 +1271,35 @@ int segmm_copy_bytes(void* dst, const void* src, int64_t bytes, segmm_stream_t s
 int segmm_cmd_op_count(void) { return SEGMM_N_CMD_OPS; }
 const char* segmm_cmd_op_name(int op) { return (op >= 0 && op < SEGMM_N_CMD_OPS) ? segmm_cmd_names[op] : nullptr; }
 
-int segmm_run_phase(const segmm_phase_t* ph, segmm_stream_t main_stream, segmm_stream_t side_stream, void* ev_fork, void* ev_join) {
+int segmm_run_phase(const segmm_phase_t* ph, const segmm_stream_t* streams, int n_streams, void* const* events) {
     SEGMM_REQUIRE(ph && ph->n_cmds >= 0 && (ph->n_cmds == 0 || ph->cmds), "run_phase: null descriptor");
     SEGMM_REQUIRE(ph->kind >= 0 && ph->kind < SEGMM_PHASE_KINDS, "run_phase: phase kind %d", ph->kind);
+    SEGMM_REQUIRE(n_streams >= 0 && n_streams <= SEGMM_MAX_STREAMS && (n_streams == 0 || streams), "run_phase: %d streams (<= %d)", n_streams, SEGMM_MAX_STREAMS);
     for (int i = 0; i < ph->n_cmds; ++i) {
         const segmm_cmd_t& c = ph->cmds[i];
-        SEGMM_REQUIRE(c.stream == 0 || c.stream == 1, "run_phase: command %d names stream slot %d (0 main, 1 side)", i, c.stream);
+        SEGMM_REQUIRE(c.stream >= 0 && c.stream < SEGMM_MAX_STREAMS, "run_phase: command %d names stream slot %d (0 main, 1 side, 2 auxiliary)", i, c.stream);
         if (c.op == SEGMM_OP_FORK || c.op == SEGMM_OP_JOIN) {
-            SEGMM_REQUIRE(side_stream && ev_fork && ev_join, "run_phase: a fork / join command needs the side stream and both events");
             const bool fork = c.op == SEGMM_OP_FORK;
-            hipEvent_t ev = (hipEvent_t)(fork ? ev_fork : ev_join);
-            hipError_t e = hipEventRecord(ev, (hipStream_t)(fork ? main_stream : side_stream));
-            if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)(fork ? side_stream : main_stream), ev, 0);
+            SEGMM_REQUIRE(c.stream >= 1 && c.stream < n_streams && events && events[2 * (c.stream - 1)] && events[2 * (c.stream - 1) + 1],
+                          "run_phase: command %d, a %s of stream slot %d, needs that stream and its two events", i, fork ? "fork" : "join", c.stream);
+            hipEvent_t ev = (hipEvent_t)events[2 * (c.stream - 1) + (fork ? 0 : 1)];
+            hipStream_t from = (hipStream_t)(fork ? streams[0] : streams[c.stream]), to = (hipStream_t)(fork ? streams[c.stream] : streams[0]);
+            hipError_t e = hipEventRecord(ev, from);
+            if (e == hipSuccess) e = hipStreamWaitEvent(to, ev, 0);
             SEGMM_REQUIRE(e == hipSuccess, "run_phase: command %d (%s): %s", i, fork ? "fork" : "join", hipGetErrorString(e));
             continue;
         }
         SEGMM_REQUIRE(c.op >= 0 && c.op < SEGMM_N_CMD_OPS, "run_phase: command %d has op %d (0 .. %d)", i, c.op, SEGMM_N_CMD_OPS - 1);
-        SEGMM_REQUIRE(c.stream == 0 || side_stream, "run_phase: command %d is for the side stream, none given", i);
-        const int rc = segmm_cmd_dispatch(c.op, c.a, c.stream == 0 ? main_stream : side_stream);
+        SEGMM_REQUIRE(c.stream < n_streams || c.stream == 0, "run_phase: command %d is for stream slot %d, %d streams given", i, c.stream, n_streams);
+        const int rc = segmm_cmd_dispatch(c.op, c.a, n_streams > 0 ? streams[c.stream] : nullptr);
         if (rc != 0) return rc;          // (segmm_last_error holds the failing entry point's message)
     }
     return 0;
 }
 #define SEGMM_PHASE_ENTRY(fn, KIND)                                                                                                   \
-    int fn(const segmm_phase_t* ph, segmm_stream_t main_stream, segmm_stream_t side_stream, void* ev_fork, void* ev_join) {           \
+    int fn(const segmm_phase_t* ph, const segmm_stream_t* streams, int n_streams, void* const* events) {                              \
         SEGMM_REQUIRE(ph && ph->kind == KIND, #fn ": the descriptor is not a " #KIND " phase");                                       \
-        return segmm_run_phase(ph, main_stream, side_stream, ev_fork, ev_join);                                                       \
+        return segmm_run_phase(ph, streams, n_streams, events);                                                                       \
     }
 SEGMM_PHASE_ENTRY(segmm_step_begin, SEGMM_PHASE_STEP_BEGIN)
 SEGMM_PHASE_ENTRY(segmm_embed_fwd, SEGMM_PHASE_EMBED_FWD)

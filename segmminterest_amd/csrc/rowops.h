@@ -430,6 +430,20 @@ __global__ __launch_bounds__(256) void pe_grad_kernel(const float* __restrict__ 
     }
 }
 
+// One AdamW update of four elements.  Floating-point contraction is OFF: adamw_kernel and the two table kernels below must give
+// bit-identical results for the same element whatever the surrounding code lets the compiler fuse.
+__device__ __forceinline__ void adamw_elem4(f32x4& pp, const f32x4 gg, f32x4& mm, f32x4& vv, float lr, float b1, float b2, float eps, float wd,
+                                            float step, float bc2_sqrt) {
+#pragma clang fp contract(off)
+    pp *= (1.0f - lr * wd);
+    mm = mm * b1 + gg * (1.0f - b1);
+    vv = vv * b2 + gg * gg * (1.0f - b2);
+    f32x4 den;
+    den.x = sqrtf(vv.x) / bc2_sqrt + eps; den.y = sqrtf(vv.y) / bc2_sqrt + eps;
+    den.z = sqrtf(vv.z) / bc2_sqrt + eps; den.w = sqrtf(vv.w) / bc2_sqrt + eps;
+    pp.x -= step * (mm.x / den.x); pp.y -= step * (mm.y / den.y);
+    pp.z -= step * (mm.z / den.z); pp.w -= step * (mm.w / den.w);
+}
 // ---------------------------------------------------------------- fused AdamW over a flat range (a13 / K9)
 // torch.optim.AdamW single-tensor update order (decoupled decay first), bias corrections passed in.
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
@@ -442,25 +456,62 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
         f32x4 pp = ((f32x4*)p)[i];
         const f32x4 gg = ((const f32x4*)g)[i];
         f32x4 mm = ((f32x4*)m)[i], vv = ((f32x4*)v)[i];
-        pp *= (1.0f - lr * wd);
-        mm = mm * b1 + gg * (1.0f - b1);
-        vv = vv * b2 + gg * gg * (1.0f - b2);
-        f32x4 den;
-        den.x = sqrtf(vv.x) / bc2_sqrt + eps; den.y = sqrtf(vv.y) / bc2_sqrt + eps;
-        den.z = sqrtf(vv.z) / bc2_sqrt + eps; den.w = sqrtf(vv.w) / bc2_sqrt + eps;
-        pp.x -= step * (mm.x / den.x); pp.y -= step * (mm.y / den.y);
-        pp.z -= step * (mm.z / den.z); pp.w -= step * (mm.w / den.w);
+        adamw_elem4(pp, gg, mm, vv, lr, b1, b2, eps, wd, step, bc2_sqrt);
         ((f32x4*)p)[i] = pp; ((f32x4*)m)[i] = mm; ((f32x4*)v)[i] = vv;
     }
     // tail (n % 4)
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const long long i = (n4 << 2) + threadIdx.x;
-        float pp = p[i] * (1.0f - lr * wd);
-        const float gg = g[i];
-        const float mm = m[i] * b1 + gg * (1.0f - b1);
-        const float vv = v[i] * b2 + gg * gg * (1.0f - b2);
-        pp -= step * (mm / (sqrtf(vv) / bc2_sqrt + eps));
-        p[i] = pp; m[i] = mm; v[i] = vv;
+        f32x4 pp = {p[i], 0.f, 0.f, 0.f}, mm = {m[i], 0.f, 0.f, 0.f}, vv = {v[i], 0.f, 0.f, 0.f};
+        adamw_elem4(pp, f32x4{g[i], 0.f, 0.f, 0.f}, mm, vv, lr, b1, b2, eps, wd, step, bc2_sqrt);
+        p[i] = pp.x; m[i] = mm.x; v[i] = vv.x;
+    }
+}
+
+// AdamW of an id-embedding table in two passes (segmm_adamw_table): the arithmetic of adamw_kernel, element for element
+__global__ __launch_bounds__(256) void table_mark_kernel(const long long* __restrict__ ids, int n, long long n_rows, unsigned int* __restrict__ flags) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) {
+        const long long id = ids[k];
+        if (id >= 0 && id < n_rows) flags[id] = 1u;
+    }
+}
+// every row WITHOUT a mark, g = 0
+__global__ __launch_bounds__(256) void adamw_table_rest_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, long long n_rows,
+                                                               int w4, const unsigned int* __restrict__ flags, float lr, float b1, float b2,
+                                                               float eps, float wd, float bc1, float bc2_sqrt, int live) {
+    if (live) { bc1 = g_step.bc1; bc2_sqrt = g_step.bc2_sqrt; }
+    const float step = lr / bc1;
+    const long long n4 = n_rows * w4;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        if (flags[i / w4] != 0u) continue;
+        f32x4 pp = ((f32x4*)p)[i], mm = ((f32x4*)m)[i], vv = ((f32x4*)v)[i];
+        adamw_elem4(pp, zero, mm, vv, lr, b1, b2, eps, wd, step, bc2_sqrt);
+        ((f32x4*)p)[i] = pp; ((f32x4*)m)[i] = mm; ((f32x4*)v)[i] = vv;
+    }
+}
+// the marked rows, each once: one wave per list entry; lane 0 claims (and clears) the row's mark
+__global__ __launch_bounds__(256) void adamw_table_rows_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                               float* __restrict__ v, long long n_rows, int w4, const long long* __restrict__ ids,
+                                                               int n_ids, unsigned int* __restrict__ flags, float lr, float b1, float b2, float eps,
+                                                               float wd, float bc1, float bc2_sqrt, int live) {
+    if (live) { bc1 = g_step.bc1; bc2_sqrt = g_step.bc2_sqrt; }
+    const float step = lr / bc1;
+    const int lane = threadIdx.x & 63;
+    const int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (k >= n_ids) return;
+    const long long id = ids[k];
+    if (id < 0 || id >= n_rows) return;
+    unsigned int mine = 0u;
+    if (lane == 0) mine = atomicExch(flags + id, 0u);
+    mine = (unsigned int)__builtin_amdgcn_readfirstlane((int)mine);
+    if (mine == 0u) return;          // another entry of the list holds the same id and has taken the row
+    for (int c = lane; c < w4; c += 64) {
+        const long long i = id * w4 + c;
+        f32x4 pp = ((f32x4*)p)[i], mm = ((f32x4*)m)[i], vv = ((f32x4*)v)[i];
+        adamw_elem4(pp, ((const f32x4*)g)[i], mm, vv, lr, b1, b2, eps, wd, step, bc2_sqrt);
+        ((f32x4*)p)[i] = pp; ((f32x4*)m)[i] = mm; ((f32x4*)v)[i] = vv;
     }
 }
 

@@ -361,6 +361,12 @@ class ParamStore:
             self._side_stream = torch.cuda.Stream(device=self.flat.device, priority=int(os.environ.get("SEGMM_SIDE_PRIORITY", "1")))
         return self._side_stream
 
+    def aux_stream(self):
+        a = self.__dict__.get("_aux_stream")
+        if a is None or a.device != self.flat.device:
+            a = self._aux_stream = torch.cuda.Stream(device=self.flat.device, priority=int(os.environ.get("SEGMM_SIDE_PRIORITY", "1")))
+        return a
+
     def attn_stream(self):
         if self._attn_stream is None or self._attn_stream.device != self.flat.device:
             self._attn_stream = torch.cuda.Stream(device=self.flat.device)
@@ -631,7 +637,7 @@ def side_work(store):
     ev.record(main)
     side.wait_event(ev)
     if H.RECORDER is not None:
-        H.RECORDER.pseudo(H.OP_FORK)
+        H.RECORDER.pseudo(H.OP_FORK, 1)
     store._on_side = True
     try:
         with torch.cuda.stream(side):
@@ -659,11 +665,33 @@ def flush_deferred(store, deferred):
         deferred.clear()
 
 
+@contextlib.contextmanager
+def aux_work(store):
+    """A third HIP stream (lowest priority) for work that is independent of the whole forward / backward -- the early pass of
+    the id-table optimizer (FusedAdamW.table_early): forked from the main stream here, joined by ``join_aux``."""
+    main = torch.cuda.current_stream()
+    aux = store.aux_stream()
+    ev = torch.cuda.Event()
+    ev.record(main)
+    aux.wait_event(ev)
+    if H.RECORDER is not None:
+        H.RECORDER.pseudo(H.OP_FORK, 2)
+    with torch.cuda.stream(aux):
+        yield
+
+
+def join_aux(store):
+    if store.__dict__.get("_aux_stream") is not None:
+        torch.cuda.current_stream().wait_stream(store._aux_stream)
+        if H.RECORDER is not None:
+            H.RECORDER.pseudo(H.OP_JOIN, 2)
+
+
 def join_side(store):
     if store.overlap and store._side_stream is not None:
         torch.cuda.current_stream().wait_stream(store._side_stream)
         if H.RECORDER is not None:
-            H.RECORDER.pseudo(H.OP_JOIN)
+            H.RECORDER.pseudo(H.OP_JOIN, 1)
 
 
 class Act:

@@ -15,7 +15,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SEGMM_LIB") or os.path.join(_HERE, "libsegmm_hip.so")      # SEGMM_LIB: A/B builds of the kernels
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 _lib = None
 
@@ -69,6 +69,7 @@ SIGNATURES = {
     "segmm_label_stats": [_p, _i, _i, _i, _p, _p, _p, _p],
     "segmm_loss_fwd_bwd": [_i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p],
     "segmm_adamw": [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _i, _p],
+    "segmm_adamw_table": [_p, _p, _p, _p, _i64, _i, _p, _i, _p, _f, _f, _f, _f, _f, _i, _i, _p],
     "segmm_dropout_mult": [_p, _i64, _f, _u64, _u32, _p],
     "segmm_rank_leave": [_p, _i, _p, _p, _i, _i, _i, _i, _p, _p, _p],
     "segmm_auc_counts": [_p, _p, _p, _i, _p, _p],
@@ -81,15 +82,15 @@ SIGNATURES = {
     "segmm_fill_zero": [_p, _i64, _p],
     "segmm_copy_bytes": [_p, _p, _i64, _p],
     "segmm_cmd_op_count": [],
-    "segmm_run_phase": [_p, _p, _p, _p, _p],
-    "segmm_step_begin": [_p, _p, _p, _p, _p],
-    "segmm_embed_fwd": [_p, _p, _p, _p, _p],
-    "segmm_layer_fwd": [_p, _p, _p, _p, _p],
-    "segmm_head_loss_fwd": [_p, _p, _p, _p, _p],
-    "segmm_head_loss_bwd": [_p, _p, _p, _p, _p],
-    "segmm_layer_bwd": [_p, _p, _p, _p, _p],
-    "segmm_embed_bwd": [_p, _p, _p, _p, _p],
-    "segmm_step_tail": [_p, _p, _p, _p, _p],
+    "segmm_run_phase": [_p, _p, _i, _p],
+    "segmm_step_begin": [_p, _p, _i, _p],
+    "segmm_embed_fwd": [_p, _p, _i, _p],
+    "segmm_layer_fwd": [_p, _p, _i, _p],
+    "segmm_head_loss_fwd": [_p, _p, _i, _p],
+    "segmm_head_loss_bwd": [_p, _p, _i, _p],
+    "segmm_layer_bwd": [_p, _p, _i, _p],
+    "segmm_embed_bwd": [_p, _p, _i, _p],
+    "segmm_step_tail": [_p, _p, _i, _p],
 }
 
 
@@ -172,8 +173,10 @@ RECORDER = None          # a Recorder while Trainer.record() runs its one eager 
 class Recorder:
     """Collects the C-ABI calls of one eager step, split into phases by :func:`mark`."""
 
-    def __init__(self, main_stream: int, side_stream: int):
+    def __init__(self, main_stream: int, side_stream: int, aux_stream: int = 0):
         self.streams = {int(main_stream): 0, int(side_stream): 1}
+        if aux_stream:
+            self.streams[int(aux_stream)] = 2
         self.phases = []          # [kind, backbone, layer, [(op, slot, [(field, value)])]]
         self.keep = []            # host structs / arrays the recorded pointer arguments name
         self.ops = op_ids()
@@ -186,8 +189,8 @@ class Recorder:
             raise RuntimeError("recorder: a launch before the first phase marker")
         return self.phases[-1][3]
 
-    def pseudo(self, op):
-        self._cmds().append((op, 0, []))
+    def pseudo(self, op, slot=1):
+        self._cmds().append((op, slot, []))
 
     def callback(self, fn):
         """A host action between launches (a data-parallel collective, a wait for one): replayed by calling ``fn`` again at the
@@ -202,7 +205,7 @@ class Recorder:
             raise RuntimeError("recorder: %s called with %d arguments" % (name, len(args)))
         slot = self.streams.get(int(args[-1] or 0))
         if slot is None:
-            raise RuntimeError("recorder: %s was enqueued on a stream that is neither the step's main nor its side stream; this "
+            raise RuntimeError("recorder: %s was enqueued on a stream that is neither the step's main, side nor auxiliary stream; this "
                                "launch sequence cannot be replayed (prefetch / third-stream knobs must be off)" % name)
         vals = []
         for k, (ct, v) in enumerate(zip(at[:-1], args[:-1])):
@@ -274,9 +277,18 @@ def host_action(fn):
     return fn()
 
 
-def run_phase(phase: "Phase", main_stream: int, side_stream: int, ev_fork: int, ev_join: int):
+def stream_table(streams, events):
+    """(ctypes array of hipStream_t, count, ctypes array of hipEvent_t) for :func:`run_phase`: ``streams`` = raw handles of the main,
+    side (and auxiliary) stream, ``events`` = two raw event handles per non-main stream."""
+    sa = (C.c_void_p * len(streams))(*[int(x) for x in streams])
+    ea = (C.c_void_p * max(len(events), 1))(*[int(x) for x in events])
+    return sa, len(streams), ea
+
+
+def run_phase(phase: "Phase", table):
     L = _lib_real()
-    _check(getattr(L, PHASE_ENTRY[phase.kind])(C.addressof(phase), main_stream, side_stream, ev_fork, ev_join), PHASE_ENTRY[phase.kind])
+    sa, n, ea = table
+    _check(getattr(L, PHASE_ENTRY[phase.kind])(C.addressof(phase), sa, n, ea), PHASE_ENTRY[phase.kind])
 
 
 def fill_zero(t: torch.Tensor):
@@ -814,6 +826,16 @@ def loss_fwd_bwd(B, S, logits, gt, bias_w, bias_b, exposure, coef, enabled, rew_
 def adamw(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, p_off=0):
     with _kprof("adamw", 28 * int(n)):
         _adamw(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, p_off)
+
+
+def adamw_table(p, g, m, v, off, n_rows, width, ids, flags, lr, beta1, beta2, eps, weight_decay, step, phase):
+    """segmm_adamw_table on the table that starts ``off`` floats into the flat buffers (phase 0: rows without a gradient, g = 0;
+    phase 1: the rows listed in ``ids``)."""
+    with _kprof("adamw", (24 if phase == 0 else 28) * int(n_rows if phase == 0 else ids.numel()) * int(width)):
+        _check(lib().segmm_adamw_table(p.data_ptr() + 4 * off, None if g is None else g.data_ptr() + 4 * off, m.data_ptr() + 4 * off,
+                                       v.data_ptr() + 4 * off, int(n_rows), int(width), ids.data_ptr(), ids.numel(), flags.data_ptr(),
+                                       float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step), int(phase),
+                                       _stream()), "segmm_adamw_table")
 
 
 def _adamw(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, p_off=0):

@@ -103,8 +103,34 @@ class FusedAdamW:
 
     def step(self, gbuf=None):
         self.begin_step()
-        self.step_range(0, self._state().n_live, gbuf)
+        st = self._state()
+        pos = 0
+        # id tables whose rows without a gradient were already stepped at the head of the step (table_early): the listed rows
+        # now, with their gradients; everything else as contiguous ranges around them
+        for o, n, rows, width, ids, flags in sorted(self.__dict__.pop("_early", []), key=lambda e: e[0]):
+            self.step_range(pos, o, gbuf)
+            H.adamw_table(st.flat, st.gflat if gbuf is None else gbuf, self.m, self.v, o, rows, width, ids, flags, self.lr, self.betas[0],
+                          self.betas[1], self.eps, self.wd, -1 if self.__dict__.get("device_state", False) else self.step_count, 1)
+            pos = o + n
+        self.step_range(pos, st.n_live, gbuf)
         self.end_step()
+
+    def table_early(self, name, ids):
+        """First pass of the two-pass update of the id-embedding table ``name`` (segmm_adamw_table): every row that is NOT in
+        ``ids`` -- the rows the coming backward gives no gradient -- takes its AdamW step of THIS optimizer step now, with g = 0,
+        on the current stream (the trainer calls this at the head of the step on a stream of its own: the forward and backward
+        only read the listed rows).  ``step()`` then updates the listed rows and skips the table's range.  Element for element
+        the arithmetic of the one-launch dense update."""
+        st = self._state()
+        o, n = st.index[name]
+        rows, width = st._params[name].shape
+        fl = self.__dict__.setdefault("_table_flags", {})
+        flags = fl.get(name)
+        if flags is None or flags.numel() != rows or flags.device != st.flat.device:
+            flags = fl[name] = torch.zeros((rows,), dtype=torch.int32, device=st.flat.device)
+        H.adamw_table(st.flat, None, self.m, self.v, o, rows, width, ids, flags, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
+                      -1 if self.__dict__.get("device_state", False) else self.step_count + 1, 0)
+        self.__dict__.setdefault("_early", []).append((o, n, rows, width, ids, flags))
 
     # one optimizer step as several launches over disjoint ranges that together cover the live range: the data-parallel
     # trainer steps each gradient bucket as soon as ITS all-reduce has completed (begin_step, step_range ..., end_step)
@@ -391,6 +417,7 @@ class Trainer:
             # their first step, or a DPComm on a sub-group, would deadlock)
             self.comm._row_group()
         self.per_bucket_adamw = os.environ.get("SEGMM_BUCKET_ADAMW", "1") != "0"
+        self.table_two_pass = os.environ.get("SEGMM_TABLE_TWO_PASS", "1") != "0"
         self.bucket_bytes = int(float(os.environ.get("SEGMM_DP_BUCKET_MB", "8")) * (1 << 20))      # merge threshold of _on_bucket
         self._bucket_works = []
         self._pending_range = None
@@ -519,6 +546,27 @@ class Trainer:
         buf._segmm_act = act
         return act
 
+    def _tables_early(self, batch):
+        """Id mode, single process: the dense AdamW over the item table (config 3: 352 494 x 256 floats = 2.5 GB of optimizer
+        traffic, 0.54 ms alone at the END of the step) is split in two -- the rows of this batch (the only ones with a gradient,
+        known from the batch's ids) are stepped after the backward as before, every other row now, with g = 0, on an auxiliary
+        stream under the forward and backward, which never touch those rows.  (Data parallel: the listed rows are those of ALL
+        ranks, known only after the row exchange -- the dense update stays.)"""
+        if self.comm.active or not self.table_two_pass or self._param_hooks():
+            return
+        model, st = self.model, self.model._store
+        ids = batch.get("photo_identity_id")
+        if ids is None or ids.dtype != torch.int64 or not ids.is_contiguous():
+            return
+        for pre, bb in (("backbone1.", model.backbone1), ("backbone2.", getattr(model, "backbone2", None))):
+            if bb is None or not bb.id_vid:
+                continue
+            name = pre + "vid_proj.weight"
+            if name not in st.index or name not in st.live_names or st._params[name].shape[1] % 4:
+                continue
+            with E.aux_work(st):
+                self.opt.table_early(name, ids.reshape(-1))
+
     def _plane_consumers_only(self, key) -> bool:
         """Every launch that reads the input features of ``key`` is a plane GEMM (forward projection and its weight gradient):
         the plane engine, a P32 plane entry for the projection weight and d_model a multiple of 32 (else the weight gradient
@@ -634,6 +682,7 @@ class Trainer:
         try:
             usr, um, vid, vm = self._features(batch)          # first ParamStore.ensure() of the step: the full check
             st._trusted = True
+            self._tables_early(batch)
             if next_batch is not None:
                 self.prefetch(next_batch)
             out = self._train_step(batch, usr, um, vid, vm)
@@ -710,6 +759,8 @@ class Trainer:
                     w.wait()
             self.comm.finish()
         H.mark(H.PHASE_STEP_TAIL)
+        if self.opt.__dict__.get("_early"):
+            E.join_aux(st)          # the tables' first pass (aux stream) is complete before their listed rows are stepped
         self.opt.step()
         return out
 
@@ -785,7 +836,8 @@ class Trainer:
         main = H._stream()
         side = st.side_stream().cuda_stream
         pool = torch.cuda.MemPool()
-        rec = H.Recorder(main, side)
+        aux = st.__dict__.get("_aux_stream")
+        rec = H.Recorder(main, side, aux.cuda_stream if aux is not None else 0)
         H.RECORDER = rec
         try:
             with st.rec_pool(pool):
@@ -825,11 +877,12 @@ class Trainer:
             for k, base, nb, _, _ in spans:
                 if base <= t.data_ptr() < base + nb and t.data_ptr() == base and t.numel() * t.element_size() == nb:
                     tab_keys.append((ek, gptr, k))
-        evs = (torch.cuda.Event(), torch.cuda.Event())
+        evs = tuple(torch.cuda.Event() for _ in range(4))
         for e in evs:
             e.record()
+        streams = [main, side] + ([aux.cuda_stream] if aux is not None else [])
         self._recorded = dict(phases=phases, keep=rec.keep, pool=pool, prev_batch=batch, tab_keys=tab_keys, out=out, relocs=relocs, spans={k: (sh, dt) for k, _, _, sh, dt in spans},
-                              main=main, side=side, events=evs, ev_handles=(evs[0].cuda_event, evs[1].cuda_event),
+                              main=main, events=evs, table=H.stream_table(streams, [e.cuda_event for e in evs[:2 * (len(streams) - 1)]]),
                               n_cmds=sum(ph.n_cmds for ph, a in phases if a is not None))
         return out
 
@@ -849,14 +902,14 @@ class Trainer:
         for arr, ci, ai, k, off, lag in r["relocs"]:
             arr[ci].a[ai].p = (pb if lag else batch)[k].data_ptr() + off
         r["prev_batch"] = batch          # (also keeps the tensors a lag-1 pointer names alive until the next step has run)
-        main, side, (ef, ej) = r["main"], r["side"], r["ev_handles"]
+        main, table = r["main"], r["table"]
         if H._stream() != main:
             raise RuntimeError("run_recorded(): the current stream is not the stream the step was recorded on")
         for ph, arr in r["phases"]:
             if arr is None:
                 ph()          # a host action of the step (data-parallel collective / wait), at its place in the launch order
             else:
-                H.run_phase(ph, main, side, ef, ej)
+                H.run_phase(ph, table)
         # mirror the host side effects of the eager step (FusedAdamW.begin_step / end_step; the id list of the table rows this
         # step's backward scattered into)
         self.opt.step_count += 1

@@ -521,3 +521,77 @@ def test_recorded_step_equals_eager_device_state_step(kind, N, B, S, Lt, D, h):
     assert torch.equal(pe, pr) and torch.equal(me, mr) and torch.equal(ve, vr)
     for a, b in zip(ee, er):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_adamw_table_two_passes_equal_dense_update():
+    """segmm_adamw_table (main_for_seq_leave_earlystop_KuaiRand.py:259-261 / optimizer.step at :299 over an nn.Embedding table,
+    encoder.py:352-362): phase 0 (rows without a gradient, g = 0, run early) + phase 1 (the batch's rows) leave BIT-IDENTICAL
+    parameters and moments to one dense segmm_adamw launch over the table; duplicate and out-of-range ids, flags left zero."""
+    import torch
+    from segmminterest_amd import hipabi as H
+    H.lib()
+    dev = "cuda"
+    g0 = torch.Generator().manual_seed(3)
+    rows, width, off = 5000, 64, 96
+    n = rows * width
+    flat = torch.randn(off + n + 32, generator=g0).to(dev)
+    m = (0.01 * torch.randn(off + n + 32, generator=g0)).to(dev)
+    v = (1e-4 * torch.rand(off + n + 32, generator=g0)).to(dev)
+    ids = torch.randint(0, rows, (300,), generator=g0)
+    ids[:20] = ids[20:40]                                  # duplicates
+    ids = torch.cat([ids, torch.tensor([-1, rows, rows + 7])]).to(dev)          # ignored
+    grad = torch.zeros(off + n + 32, device=dev)
+    gt = grad[off:off + n].view(rows, width)
+    valid = ids[(ids >= 0) & (ids < rows)]
+    gt[valid] = torch.randn(valid.numel(), width, generator=g0).to(dev)
+    for step in (1, 7):
+        p1, m1, v1 = flat.clone(), m.clone(), v.clone()
+        H.adamw(p1, grad, m1, v1, n, 1e-3, 0.9, 0.999, 1e-8, 1e-4, step, p_off=off)
+        p2, m2, v2 = flat.clone(), m.clone(), v.clone()
+        flags = torch.zeros(rows, dtype=torch.int32, device=dev)
+        H.adamw_table(p2, None, m2, v2, off, rows, width, ids, flags, 1e-3, 0.9, 0.999, 1e-8, 1e-4, step, 0)
+        assert int(flags.sum()) == int(valid.unique().numel())
+        H.adamw_table(p2, grad, m2, v2, off, rows, width, ids, flags, 1e-3, 0.9, 0.999, 1e-8, 1e-4, step, 1)
+        assert int(flags.abs().sum()) == 0
+        assert torch.equal(p1, p2) and torch.equal(m1, m2) and torch.equal(v1, v2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("device_state", [False, True])
+def test_id_table_two_pass_step_equals_dense_step(device_state):
+    """Trainer in id mode: the item table's optimizer step split in two (rows outside the batch early, on the auxiliary stream;
+    the batch's rows after the backward) against the one-launch dense AdamW (SEGMM_TABLE_TWO_PASS=0): bit-identical parameters
+    and moments after 6 steps on rotating batches, eager and as recorded launch sequences."""
+    import torch
+    from segmminterest_amd.synth import make_batch
+    from segmminterest_amd.trainer import Trainer, default_args, init_model
+    dev = torch.device("cuda:0")
+    B, S, D, N, h = 64, 20, 64, 3, 4
+    margs = default_args(num_layers_enc=N, d_model=D, nhead=h, input_type={"user": "id", "photo": "id"}, exposure_prob=[1.0] * S)
+    batches = [{k: v.to(dev) for k, v in make_batch(B, S, 1, D, n_users=50, n_items=3000, seed=400 + i, features=False).items()} for i in range(3)]
+
+    def run(two_pass):
+        os.environ["SEGMM_TABLE_TWO_PASS"] = "1" if two_pass else "0"
+        try:
+            torch.manual_seed(9)
+            model = init_model(margs, n_users=50, n_items=3000, input_dim=D, max_vid_len=S, max_usr_len=1).to(dev)
+            tr = Trainer(model, device_state=device_state)
+            assert tr.table_two_pass == two_pass
+            if device_state:
+                tr.record(batches[0], warmup=2)
+            else:
+                for _ in range(3):
+                    tr.train_step(batches[0])
+            for t in range(6):
+                (tr.run_recorded if device_state else tr.train_step)(batches[t % 3])
+            torch.cuda.synchronize()
+            if two_pass:
+                assert tr.opt._table_flags and all(int(f.abs().sum()) == 0 for f in tr.opt._table_flags.values())
+            return model._store.flat.detach().clone(), tr.opt.m.clone(), tr.opt.v.clone()
+        finally:
+            os.environ.pop("SEGMM_TABLE_TWO_PASS", None)
+
+    a, b = run(False), run(True)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)

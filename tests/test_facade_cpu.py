@@ -91,22 +91,23 @@ def test_recorded_phase_entry_points_and_dispatch_table():
     arr[0].op, arr[0].stream = H.OP_FORK, 0
     arr[1].op, arr[1].stream = ops["segmm_fill_zero"], 0
     ph = H.Phase(kind=H.PHASE_LAYER_FWD, backbone=0, layer=1, n_cmds=2, cmds=ctypes.cast(arr, ctypes.POINTER(H.Cmd)))
-    assert L.segmm_embed_fwd(ctypes.addressof(ph), None, None, None, None) != 0 and b"EMBED_FWD" in L.segmm_last_error()
-    assert L.segmm_layer_fwd(ctypes.addressof(ph), None, None, None, None) != 0 and b"fork" in L.segmm_last_error()      # no side stream / events
+    arr[0].stream = 1
+    assert L.segmm_embed_fwd(ctypes.addressof(ph), None, 0, None) != 0 and b"EMBED_FWD" in L.segmm_last_error()
+    assert L.segmm_layer_fwd(ctypes.addressof(ph), None, 0, None) != 0 and b"fork" in L.segmm_last_error()      # no side stream / events
     arr[0].op = 10 ** 6
-    assert L.segmm_run_phase(ctypes.addressof(ph), None, None, None, None) != 0 and b"op" in L.segmm_last_error()
+    assert L.segmm_run_phase(ctypes.addressof(ph), None, 0, None) != 0 and b"op" in L.segmm_last_error()
     arr[0].op, arr[0].stream = ops["segmm_fill_zero"], 3
-    assert L.segmm_run_phase(ctypes.addressof(ph), None, None, None, None) != 0 and b"stream slot" in L.segmm_last_error()
+    assert L.segmm_run_phase(ctypes.addressof(ph), None, 0, None) != 0 and b"stream slot" in L.segmm_last_error()
     arr[0].stream = 0          # a command whose own argument check fails (null pointer): its return code and message come through
-    assert L.segmm_run_phase(ctypes.addressof(ph), None, None, None, None) != 0 and b"fill_zero" in L.segmm_last_error()
+    assert L.segmm_run_phase(ctypes.addressof(ph), None, 0, None) != 0 and b"fill_zero" in L.segmm_last_error()
     ph.n_cmds = 0
-    assert L.segmm_layer_fwd(ctypes.addressof(ph), None, None, None, None) == 0
+    assert L.segmm_layer_fwd(ctypes.addressof(ph), None, 0, None) == 0
     # the recorder converts arguments by the signature table
     rec = H.Recorder(111, 222)
     rec.mark(H.PHASE_STEP_TAIL)
     rec.call("segmm_adamw", (4096, 8192, 0, None, 10, 1e-3, 0.9, 0.999, 1e-8, 1e-4, -1, 222))
     rec.call("segmm_l1norm", (1, 2, None, 5, 32, None, None, 0, None, None, (1 << 63) | 5 if False else 111))
-    rec.pseudo(H.OP_JOIN)
+    rec.pseudo(H.OP_JOIN, 1)
     (phs, a2), = rec.finish()
     assert phs.kind == H.PHASE_STEP_TAIL and phs.n_cmds == 3
     assert a2[0].op == ops["segmm_adamw"] and a2[0].stream == 1 and a2[0].a[0].p == 4096 and a2[0].a[3].p is None
