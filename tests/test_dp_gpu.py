@@ -199,7 +199,10 @@ def test_rccl_single_rank_step_equals_plain_step(name):
         for k in sd0:
             assert (sd0[k] == sd1[k]).all(), k
     for k in v0:
-        assert v0[k] == v1[k], (k, v0[k], v1[k])
+        if name.startswith("id") and k == "valid_loss":          # (parameters agree to rounding only, see above)
+            assert abs(v0[k] - v1[k]) <= 1e-5 * max(1.0, abs(v0[k])), (k, v0[k], v1[k])
+        else:
+            assert v0[k] == v1[k], (k, v0[k], v1[k])
 
 
 def test_bench_forced_one_rank_rccl_stdout_is_one_json_line():
