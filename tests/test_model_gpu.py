@@ -500,16 +500,17 @@ def _check_live_grads(model, rgrads):
     return errs
 
 
-def test_config3_full_item_table_matches_oracle():
+@pytest.mark.parametrize("B", [256, 1024])
+def test_config3_full_item_table_matches_oracle(B):
     """BASELINE config 3 (main_for_seq_leave_earlystop_KuaiRand.py:259-261; encoder.py:426-435) with the FULL item table
-    (352 494 rows) and user table: id/id inputs, S = 20, d = 512, h = 16, N = 4, on a 256-row subset of the 1024-row batch
-    (the oracle's dense 352 k x 256 table gradient and four 512-wide layers stay at a few seconds of CPU).  Logits, loss,
+    (352 494 rows) and user table: id/id inputs, S = 20, d = 512, h = 16, N = 4, at the config's full 1024-row batch and on a
+    256-row batch (the oracle's dense 352 k x 256 table gradient and four 512-wide layers: seconds of CPU).  Logits, loss,
     every live gradient -- the item-table gradient compared on ALL rows: touched rows against the oracle's, untouched rows
     exactly zero -- and the parameters after one fused AdamW step (the dense update that bounds the config: every row decays)."""
     import segmm_oracle as O
     from segmminterest_amd.synth import make_batch
     from segmminterest_amd.trainer import FusedAdamW, default_args, init_model
-    S, d, N, h, B, n_users, n_items = 20, 512, 4, 16, 256, 30000, 352494
+    S, d, N, h, n_users, n_items = 20, 512, 4, 16, 30000, 352494
     args = default_args(num_layers_enc=N, d_model=d, nhead=h, input_type={"user": "id", "photo": "id"}, exposure_prob=[1.0] * S)
     torch.manual_seed(5)
     model = init_model(args, n_users=n_users, n_items=n_items, input_dim=d, max_vid_len=S, max_usr_len=1)
