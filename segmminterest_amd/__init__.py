@@ -9,7 +9,8 @@ import os as _os
 # Data-parallel ranks use more streams (main, side, RCCL's) than HIP's default 4 hardware queues: sharing one lets an all-reduce
 # that waits for the side stream stall the main stream behind it (bench.py).  Only effective if this import
 # happens before the HIP runtime initialises (import this package, or set the variable, before the first CUDA call).
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+if _os.environ.get("SEGMM_NO_ENV_DEFAULTS", "0") != "1":          # (opt out: the importing application owns the process environment)
+    _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 from .encoder import (MLP, MLP_Block, SegFormerX, SegFormerXAttention, SegFormerXEncoder,  # noqa: F401
                       SegFormerXEncoderLayer, SegFormerXFPN, clones)
