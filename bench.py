@@ -363,12 +363,20 @@ def main():
         return res
 
     inst = None
+    record_note = None
     if args.recorded:
         if args.prefetch:
             raise SystemExit("--recorded: no prefetch")
         run(trainer, max(args.warmup, 3))
         inst = instrumented(args.warmup)
-        trainer.record(batches[0], warmup=2)
+        try:
+            trainer.record(batches[0], warmup=2)
+        except RuntimeError as e:          # a configuration record() refuses (it says why): the per-launch step, and the line says so
+            if world > 1:
+                raise
+            sys.stderr.write("bench.py: recording the step failed (%s); timing the per-launch step\n" % e)
+            args.recorded = False
+            record_note = "eager, device-side step state (record() refused: %s)" % str(e)[:120]
     run(trainer, args.warmup)
     # ---- the timed region: `windows` windows of EXACTLY `steps` steps, each bracketed by barrier + synchronize on both sides,
     # MAX over ranks per window; `value` is the median window (value_min / value_max beside it)
@@ -421,7 +429,7 @@ def main():
                        "rows_per_gpu": B, "global_batch": B * world, "segments": S, "feat_dim": D, "in_dim": Din, "user_tokens": Lt, "layers": N,
                        "parallelism": "dp%d" % world + (" (forced one-rank process group)" if forced_dp else ""),
                        "backend": args.backend if (world > 1 or forced_dp) else None,
-                       "grad_allreduce_overlap": not args.no_overlap, "step_mode": ("hipGraph replay (device-side step state)" if args.graph else
+                       "grad_allreduce_overlap": not args.no_overlap, "step_mode": record_note if record_note else ("hipGraph replay (device-side step state)" if args.graph else
                                      "recorded launch sequences replayed from C, one call per phase (device-side step state)" if args.recorded else
                                      "eager, device-side step state" if args.device_state else "eager"), "input_prefetch": bool(args.prefetch and len(batches) > 1),
                        "final_loss": round(loss, 6), "replicas_identical": replicas_identical,
