@@ -85,8 +85,11 @@ __device__ __forceinline__ float frag_absmax(const float (&f)[N]) {
 }
 
 // ------------------------------------------------------------------------------------------ backward: fused dQ + dK + dV
+#ifndef SEGMM_ATT16_WPS
+#define SEGMM_ATT16_WPS 3          // waves per SIMD the four-wave form is compiled for (probe: 4 = 128 registers, spills)
+#endif
 template <int DH, int NW, bool ONE>
-__global__ __launch_bounds__(64 * NW, NW <= 4 ? 3 : 4) void attn_bwd_fused16_kernel(const AttnArgs p) {
+__global__ __launch_bounds__(64 * NW, NW <= 4 ? SEGMM_ATT16_WPS : 4) void attn_bwd_fused16_kernel(const AttnArgs p) {
     using C = AttnCfg<DH>;
     const DropCfg drop_ = drop_live(p.drop);
     static_assert(DH % 16 == 0, "fp16 attention: head dim must be a multiple of 16");
@@ -151,32 +154,38 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 3 : 4) void attn_bwd_fused16_ker
     HL kfh[NCH], vfh[NCH], kch[C::CT];                                      // split K / V row fragments, K column fragments
     float sK = 1.f, sV = 1.f;
     float maxV = 0.f;
-    auto load_frags = [&]() {
-        float kf[C::KS], vf[C::KS], kc[4][C::CT];
+    // K / V fragments of the current tile: the loads (issue_frags: 18 buffer loads in flight, raw values in kf_ / vf_ / kc_) and
+    // the scale derivation + split (finish_frags) are separate, so that a single-chunk launch requests its first tile BEFORE the
+    // query-side staging and splits it after -- one round of memory latency for both instead of two
+    float kf_[C::KS], vf_[C::KS], kc_[4][C::CT];
+    auto issue_frags = [&]() {
         if (isa) {
             const uint32_t so = (uint32_t)(16 * jt) * kbk.pitch_a;
-            frag_load<DH>(kf, kbk.ka, kbk.row_a, so);
-            frag_load<DH>(vf, kbk.va, kbk.row_a, so);
+            frag_load<DH>(kf_, kbk.ka, kbk.row_a, so);
+            frag_load<DH>(vf_, kbk.va, kbk.row_a, so);
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) col_load<DH>(kc[s4], kbk.ka, kbk.col_a, (uint32_t)(16 * jt + s4) * kbk.pitch_a, l15);
+            for (int s4 = 0; s4 < 4; ++s4) col_load<DH>(kc_[s4], kbk.ka, kbk.col_a, (uint32_t)(16 * jt + s4) * kbk.pitch_a, l15);
         } else {
             const uint32_t so = (uint32_t)(16 * (jt - nta)) * kbk.pitch_b;
-            frag_load<DH>(kf, kbk.kb, kbk.row_b, so);
-            frag_load<DH>(vf, kbk.vb, kbk.row_b, so);
+            frag_load<DH>(kf_, kbk.kb, kbk.row_b, so);
+            frag_load<DH>(vf_, kbk.vb, kbk.row_b, so);
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) col_load<DH>(kc[s4], kbk.kb, kbk.col_b, (uint32_t)(16 * (jt - nta) + s4) * kbk.pitch_b, l15);
+            for (int s4 = 0; s4 < 4; ++s4) col_load<DH>(kc_[s4], kbk.kb, kbk.col_b, (uint32_t)(16 * (jt - nta) + s4) * kbk.pitch_b, l15);
         }
-        const float mK = frag_absmax(kf);
-        maxV = frag_absmax(vf);
+    };
+    auto finish_frags = [&]() {
+        const float mK = frag_absmax(kf_);
+        maxV = frag_absmax(vf_);
         sK = f16_scale_of(mK); sV = f16_scale_of(maxV);
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            kfh[i] = split4f(kf[4 * i], kf[4 * i + 1], kf[4 * i + 2], kf[4 * i + 3], sK);
-            vfh[i] = split4f(vf[4 * i], vf[4 * i + 1], vf[4 * i + 2], vf[4 * i + 3], sV);
+            kfh[i] = split4f(kf_[4 * i], kf_[4 * i + 1], kf_[4 * i + 2], kf_[4 * i + 3], sK);
+            vfh[i] = split4f(vf_[4 * i], vf_[4 * i + 1], vf_[4 * i + 2], vf_[4 * i + 3], sV);
         }
 #pragma unroll
-        for (int ct = 0; ct < C::CT; ++ct) kch[ct] = split4f(kc[0][ct], kc[1][ct], kc[2][ct], kc[3][ct], sK);
+        for (int ct = 0; ct < C::CT; ++ct) kch[ct] = split4f(kc_[0][ct], kc_[1][ct], kc_[2][ct], kc_[3][ct], sK);
     };
+    auto load_frags = [&]() { issue_frags(); finish_frags(); };
     if (!ONE) load_frags();
     for (int j = threadIdx.x; j < Tp; j += nthr) {         // key flags
         uint8_t v;
@@ -234,21 +243,35 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 3 : 4) void attn_bwd_fused16_ker
         const int nq = min(QC, p.Lq - q0);                 // real queries of the chunk
         const int nqt = (nq + 15) >> 4;
         float mq_ = 0.f, mdo_ = 0.f;
-        for (int i = threadIdx.x; i < QC * (DH / 4); i += nthr) {
-            const int q = i / (DH / 4), c = (i - q * (DH / 4)) * 4;
-            f32x4 va = {0.f, 0.f, 0.f, 0.f}, vo = va, oo = va;
-            if (q < nq) {
-                const size_t row = (size_t)b * p.Lq + q0 + q;
-                va = *(const f32x4*)(Qg + row * p.ldq + col0 + c);
-                vo = *(const f32x4*)(p.dO + row * p.lddo + col0 + c);
-                oo = *(const f32x4*)(p.O + row * p.ldo + col0 + c);
+        if (ONE) issue_frags();                            // first tile of this wave: in flight under the staging
+        // three items per thread and round: all nine loads are requested before the first LDS store (one round of latency)
+        for (int i0 = threadIdx.x; i0 < QC * (DH / 4); i0 += 3 * nthr) {
+            f32x4 va[3], vo[3], oo[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int i = i0 + u * nthr;
+                const int q = i / (DH / 4), c = (i - q * (DH / 4)) * 4;
+                va[u] = f32x4{0.f, 0.f, 0.f, 0.f}; vo[u] = va[u]; oo[u] = va[u];
+                if (i < QC * (DH / 4) && q < nq) {
+                    const size_t row = (size_t)b * p.Lq + q0 + q;
+                    va[u] = *(const f32x4*)(Qg + row * p.ldq + col0 + c);
+                    vo[u] = *(const f32x4*)(p.dO + row * p.lddo + col0 + c);
+                    oo[u] = *(const f32x4*)(p.O + row * p.ldo + col0 + c);
+                }
             }
-            *(f32x4*)(sQ + q * RSB + c * 4) = va;
-            *(f32x4*)(sdO + q * RSB + c * 4) = vo;
-            *(f32x4*)(sdQ + q * RS + c) = f32x4{0.f, 0.f, 0.f, 0.f};
-            s_Dp[i] = (vo.x * oo.x + vo.y * oo.y) + (vo.z * oo.z + vo.w * oo.w);
-            mq_ = absmax4(mq_, va);
-            mdo_ = absmax4(mdo_, vo);
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int i = i0 + u * nthr;
+                if (i < QC * (DH / 4)) {
+                    const int q = i / (DH / 4), c = (i - q * (DH / 4)) * 4;
+                    *(f32x4*)(sQ + q * RSB + c * 4) = va[u];
+                    *(f32x4*)(sdO + q * RSB + c * 4) = vo[u];
+                    *(f32x4*)(sdQ + q * RS + c) = f32x4{0.f, 0.f, 0.f, 0.f};
+                    s_Dp[i] = (vo[u].x * oo[u].x + vo[u].y * oo[u].y) + (vo[u].z * oo[u].z + vo[u].w * oo[u].w);
+                    mq_ = absmax4(mq_, va[u]);
+                    mdo_ = absmax4(mdo_, vo[u]);
+                }
+            }
         }
         mq_ = wave_max(mq_); mdo_ = wave_max(mdo_);
         if (lane == 0) { s_wm[wave] = mq_; s_wm[12 + wave] = mdo_; }
@@ -259,8 +282,11 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 3 : 4) void attn_bwd_fused16_ker
             qm[q] = in ? (p.mq[(size_t)b * p.Lq + q0 + q] ? 1 : 0) : 2;
         }
         if (threadIdx.x < 4) s_turn[threadIdx.x] = 0;
-        if (ONE) load_frags();
+        if (ONE) finish_frags();
         __syncthreads();
+#ifdef SEGMM_ATT_PROBE
+        if (p.pflags & 1024) return;          // timing probe: staging loads + K / V fragments only
+#endif
         // chunk maxima -> scales; D; every thread converts its own groups in place
         float mQ = 0.f, mdO = 0.f;
         for (int w = 0; w < nwv; ++w) { mQ = fmaxf(mQ, s_wm[w]); mdO = fmaxf(mdO, s_wm[12 + w]); }
@@ -285,6 +311,9 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 3 : 4) void attn_bwd_fused16_ker
             *(uint4*)ad = make_uint4(hd.h0, hd.h1, hd.l0, hd.l1);
         }
         __syncthreads();
+#ifdef SEGMM_ATT_PROBE
+        if (p.pflags & 2048) return;          // timing probe: ... + the in-place conversion
+#endif
         float mDc = 0.f;
         for (int w = 0; w < nwv; ++w) mDc = fmaxf(mDc, s_wm[24 + w]);
       for (int pass = 0; pass < npass; ++pass) {
@@ -313,6 +342,9 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 3 : 4) void attn_bwd_fused16_ker
         }
 #pragma unroll
         for (int qt = 0; qt < MAXQT; ++qt) {
+#ifdef SEGMM_ATT_PROBE
+            if (p.pflags & 4096) break;          // timing probe: no pair loop
+#endif
             if (qt < nqt) {
                 // row fragments (lane&15 = query): group 4 i + g of the row = elements 16 i + 4 g .. + 3, [hi | lo]
                 f32x4 sv = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};

@@ -203,6 +203,9 @@ static int attn_launch_bwd(AttnArgs& a, int phase, hipStream_t s) {
                     // single chunk: at most `wcap` waves per workgroup, a wave walks its key tiles in passes (attention16.h) --
                     // the 7 tiles of a 100-key block as 4 waves x 2 passes, four workgroups per CU instead of two
                     static const int wcap = getenv("SEGMM_ATT_WAVES") ? atoi(getenv("SEGMM_ATT_WAVES")) : 4;
+#ifdef SEGMM_ATT_PROBE
+                    if (getenv("SEGMM_ATT_BWD_DBG")) a.pflags |= atoi(getenv("SEGMM_ATT_BWD_DBG")) & (1024 | 2048 | 4096);          // timing probes (results wrong)
+#endif
                     const int nw16 = one && wcap >= 1 && nw > wcap ? wcap : nw;
                     const dim3 block16(64 * nw16);
                     const size_t lds16 = lds - (size_t)(nw - nw16) * 16 * 20 * 4;

@@ -109,10 +109,24 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// max over the wave, the same value in every lane.  Not the xor butterfly of wave_sum: six ds_bpermute round trips (the LDS
+// crossbar, ~100 cycles each and serial) are what the attention kernels' per-tile scale derivation waited on.  Inside a row
+// of 16 lanes the partners come through DPP (lane xor 1, xor 2, then the mirrored half-row and row: every lane of a row ends
+// with the row's maximum), the four rows meet through v_readlane.  max is exact and order-independent, so nothing changes
+// numerically.  Needs every lane of the wave active (like the shuffle form).
+template <int CTRL>
+__device__ __forceinline__ float dpp_row_move(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_row_move<0xB1>(v));           // quad_perm [1,0,3,2]
+    v = fmaxf(v, dpp_row_move<0x4E>(v));           // quad_perm [2,3,0,1]
+    v = fmaxf(v, dpp_row_move<0x141>(v));          // row_half_mirror
+    v = fmaxf(v, dpp_row_move<0x140>(v));          // row_mirror
+    const int i = __float_as_int(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(i, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(i, 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(i, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(i, 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 // ---- running max|x| of a tensor, for the fp16x3 GEMM engine's per-tensor scale.  A producer kernel keeps a
 // per-lane running maximum of what it stores and folds it, once per wave, into one of AMAX_SLOTS partial maxima

@@ -373,13 +373,14 @@ class MultiScaleTemporalDetrLeaveFocal(nn.Module):
             return E.BackboneFn.apply(st, bb, prefix, idx, u, usr_mask, v, vid_mask, training, seed + idx, *params)[0]
 
         self._stats = None
+        pre = self.__dict__.pop("_stats_pre", None)          # Trainer._features: the statistics of THIS batch, launched early on the auxiliary stream
         if mode in ("train", "test"):
             # label statistics depend on gt only: computed (and, data-parallel, all-gathered) BEFORE the backbones, so that the
             # collective and its rank skew hide under the forward instead of stalling every rank between forward and loss
             if self._loss_spec is None:
                 self._loss_spec = LossSpec(self.model_cfg)
             gtc = gt.contiguous().to(torch.int64)
-            self._stats = self._label_stats(gtc, gtc.shape[0], gtc.shape[1])
+            self._stats = pre if pre is not None else self._label_stats(gtc, gtc.shape[0], gtc.shape[1])
         v1 = run(self.backbone1, "backbone1.", 0, 1)
         v2 = run(self.backbone2, "backbone2.", 1, 2) if self.backbone2 is not None else None
         hp = [st._params[n] for n in self._head_param_names()]

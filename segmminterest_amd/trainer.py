@@ -418,6 +418,7 @@ class Trainer:
             self.comm._row_group()
         self.per_bucket_adamw = os.environ.get("SEGMM_BUCKET_ADAMW", "1") != "0"
         self.table_two_pass = os.environ.get("SEGMM_TABLE_TWO_PASS", "1") != "0"
+        self.begin_overlap = os.environ.get("SEGMM_BEGIN_OVERLAP", "1") != "0"          # head of the step on two streams (_features)
         self.bucket_bytes = int(float(os.environ.get("SEGMM_DP_BUCKET_MB", "8")) * (1 << 20))      # merge threshold of _on_bucket
         self._bucket_works = []
         self._pending_range = None
@@ -602,28 +603,53 @@ class Trainer:
         """(usr, usr_mask, vid, vid_mask): L1-normalised feature tensors of a batch, from the tensors it carries or --
         index batches -- gathered from the resident table.  Taken from :meth:`prefetch` when that ran for this very batch."""
         st = self.model._store
-        st.ensure()
         pf, self._pf = self._pf, None
         if pf is not None and pf["batch"] is batch:
+            st.ensure()
             torch.cuda.current_stream().wait_event(pf["done"])          # the main stream waits for the prefetch stream's kernels
             usr, um, vid, vm = pf["out"]
             self._norm_amax, self._norm_fresh = pf["amax"], pf["fresh"]
+        elif self.begin_overlap and st.flat is not None and st.overlap:
+            # The head of the step is a serial chain on one stream: weight maxima + split (32 us at config 2), user features,
+            # video features, label statistics -- and the user-token chain, which bounds the forward up to the first attention
+            # (the side stream's embedding GEMM -> LayerNorm -> projection), cannot fork before the last of them is enqueued.
+            # Only the weight planes and the user features are in ITS way: the video features and the label statistics go to the
+            # auxiliary stream (low priority), which the main stream joins before the model's forward.  The stage is HBM-bound
+            # (0.6 GB), so what this buys is the small launches and their gaps, not the copies.
+            it = self.model.input_type
+            both = it["user"] != "id" and it["photo"] != "id"
+            rows = st.hdr_rows(2) if st.engine_h else None          # taken (and, at a ring quarter, cleared) in main-stream order
+            with E.aux_work(st):
+                early = self._features_compute(batch, hdr_rows=rows, only="photo") if both else None
+                gt = batch.get("label")
+                if (self.model._dp_hook is None and gt is not None and gt.dtype == torch.int64 and gt.is_contiguous() and gt.dim() == 2
+                        and getattr(self.model, "_loss_spec", None) is not None):
+                    self.model._stats_pre = self.model._label_stats(gt, gt.shape[0], gt.shape[1])
+            st.ensure()          # first ParamStore.ensure() of the step: the full check, the weight planes of this step
+            usr, um, vid, vm = self._features_compute(batch, hdr_rows=None if both else rows, only="user" if both else None, flip=not both)
+            if early is not None:
+                vid, vm = early[2], early[3]
+            E.join_aux(st)
         else:
+            st.ensure()
             usr, um, vid, vm = self._features_compute(batch)
         if st.engine_p and self._norm_amax is not None and self._norm_fresh:
             st.update_scales(self._norm_amax, ["in.user", "in.photo"], 2)          # the input sites' scales of the next step
         return usr, um, vid, vm
 
-    def _features_compute(self, batch, hdr_rows=None):
+    def _features_compute(self, batch, hdr_rows=None, only=None, flip=True):
+        """``only``: one of the two inputs ("user" / "photo"; _features enqueues them on different streams); ``flip``: alternate
+        the output buffer set (once per step)."""
         it = self.model.input_type
         usr = vid = None
         um, vm = batch.get("user_mask"), batch.get("photo_mask")
-        self._slot ^= 1                      # two sets of output buffers, alternated: see prefetch()
-        self._norm_fresh = False
+        if flip:
+            self._slot ^= 1                      # two sets of output buffers, alternated: see prefetch()
+            self._norm_fresh = False
         if hdr_rows is not None:
             self._norm_amax, self._norm_fresh = hdr_rows, True
         for key, kind in (("user", it["user"]), ("photo", it["photo"])):
-            if kind == "id":
+            if kind == "id" or (only is not None and key != only):
                 continue
             if key + "_idx" in batch:
                 out, mask = self.feature_table.buffers(key, batch[key + "_idx"], self._slot)
