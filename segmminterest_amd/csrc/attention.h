@@ -998,22 +998,35 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_bwd_fused_kernel(const AttnAr
     // p.hpb: 0 / 1 = this launch handles key block a / b only (exact wave count per launch); 2 = both blocks in one launch,
     // workgroup 2 bh + blk, sized for the larger block -- the surplus waves of the smaller block's workgroups END here, before
     // any barrier (s_barrier waits for surviving waves only), so small and large workgroups mix on a CU
+    // p.hpb == 3 ("merged", single-chunk launches of short heads -- config 3: 20 x (20 + 1) and 1 x (1 + 20)): ONE workgroup per
+    // (b, h) for BOTH key blocks, waves 0 .. nta-1 on the tiles of block a, the next ntb on block b.  dO, O, the softmax
+    // statistics and the flags are staged once instead of once per block (and the one-key block of a config-3 head no longer
+    // pays a whole staging pass and launch of its own); each block keeps its own staged Q projection, its own dQ accumulator and
+    // its own turn counters, so every sum is formed in the order of the per-block launches: bit-identical results.
+    const bool merged = p.hpb == 3;
     const int wg = xcd_remap(blockIdx.x, gridDim.x), bh = p.hpb == 2 ? wg >> 1 : wg, b = bh / p.H, h = bh % p.H;
-    const bool isa = p.hpb == 2 ? (wg & 1) == 0 : p.hpb == 0;
     const int La_p = round16(p.La), Lb_p = round16(p.Lb), Tp = La_p + Lb_p, nta = La_p >> 4, ntb = Lb_p >> 4;
-    const int ntk = isa ? nta : ntb;                       // key tiles (= working waves) of the block
+    const bool isa = merged ? wave < nta : (p.hpb == 2 ? (wg & 1) == 0 : p.hpb == 0);
+    const int ntk = merged ? nta + ntb : (isa ? nta : ntb);          // working waves of the workgroup
     if (wave >= ntk) return;                               // surplus wave, or empty block (CrossAtt / SelfAtt ablations)
+    const int wib = (merged && !isa) ? wave - nta : wave;  // this wave's place among the waves of ITS key block (the dQ turn order)
     const int nthr = 64 * ntk;                             // surviving threads
     const int col0 = h * DH;
-    const float* Qg = isa ? p.Qa : p.Qb;
+    const float* Qg = (isa || merged) ? p.Qa : p.Qb;      // (merged: Qa and Qb are both staged)
     float* dQg = isa ? p.dQa : p.dQb;
     _Float16* dQgp = isa ? p.dQap : p.dQbp;
-    float s_q = (dQgp && p.sin_q) ? *p.sin_q : 0.f;
+    float s_q = ((merged ? (p.dQap || p.dQbp) : dQgp != nullptr) && p.sin_q) ? *p.sin_q : 0.f;
     const float* sin_k = isa ? p.sin_ka : p.sin_kb;
     float s_k = ((isa ? p.dKap : p.dKbp) && sin_k) ? *sin_k : 0.f;
     const bool repair = (p.pflags & ATT_REPAIR) != 0;
-    const bool want_q = dQgp && p.sin_q, want_k = (isa ? p.dKap : p.dKbp) && sin_k;          // sites with plane outputs
-    if (repair) {
+    const bool want_q = (merged ? (p.dQap || p.dQbp) : dQgp != nullptr) && p.sin_q, want_k = (isa ? p.dKap : p.dKbp) && sin_k;          // sites with plane outputs
+    if (repair && merged) {          // (the decision to leave must be the same in every wave of the workgroup: both blocks' sites)
+        const bool need_q = want_q && p.hdr_q[2] != 0.f;
+        const bool need_ka = p.dKap && p.sin_ka && p.hdr_ka[2] != 0.f, need_kb = p.dKbp && p.sin_kb && p.hdr_kb[2] != 0.f;
+        if (!need_q && !need_ka && !need_kb) return;
+        s_q = need_q ? p.hdr_q[0] : 0.f;
+        s_k = (isa ? need_ka : need_kb) ? (isa ? p.hdr_ka : p.hdr_kb)[0] : 0.f;
+    } else if (repair) {
         // segmm_site_fixup has judged the sites between the producers and this launch: hdr[2] != 0 = the planes were unusable
         // (written with no scale at all, overflow flag up, or the maximum below the fp16 window) and hdr[0] now holds the exact
         // scale of the recorded maxima, with which this pass rewrites them.  Two scalar loads and out, normally.
@@ -1029,19 +1042,23 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_bwd_fused_kernel(const AttnAr
     const bool att_trace_on = blockIdx.x == gridDim.x / 2 + 5;
 #endif
     ATT_MARK(0);
-    float* sQ = smem_f;                                    // [QC][RS] query rows of the current chunk
-    float* sdO = sQ + QC * RS;
-    float* sdQ = sdO + QC * RS;
-    float* s_mx = sdQ + QC * RS;
+    const int nQ = merged ? 2 : 1;                         // staged Q projections / dQ accumulators
+    float* sQ0 = smem_f;                                   // [nQ][QC][RS] query rows of the current chunk
+    float* sdO = sQ0 + nQ * QC * RS;
+    float* sdQ0 = sdO + QC * RS;
+    float* sQ = sQ0 + ((merged && !isa) ? QC * RS : 0);   // this wave's block: its Q rows, its dQ accumulator
+    float* sdQ = sdQ0 + ((merged && !isa) ? QC * RS : 0);
+    float* s_mx = sdQ0 + nQ * QC * RS;
     float* s_inv = s_mx + QC;
     float* s_D = s_inv + QC;
     float* s_tr = s_D + QC + wave * (16 * TS);                              // this wave's transpose scratch
-    int* s_turn = (int*)(s_D + QC + nw * (16 * TS));                        // [4] whose turn it is to add dQ of query tile qt
-    float* s_Dp = (float*)(s_turn + 4);                                     // [QC][DH/4] partial products dO . O
+    int* s_turn0 = (int*)(s_D + QC + nw * (16 * TS));                       // [nQ][4] whose turn it is to add dQ of query tile qt
+    int* s_turn = s_turn0 + ((merged && !isa) ? 4 : 0);
+    float* s_Dp = (float*)(s_turn0 + 4 * nQ);                               // [QC][DH/4] partial products dO . O
     uint8_t* qm = (uint8_t*)(s_Dp + QC * (DH / 4));                         // [QC] 1 valid query, 0 masked, 2 pad
     uint8_t* km = qm + QC;                                                  // [Tp]
     // ---- this wave's key tile
-    const int jt = (isa ? 0 : nta) + wave;                                  // padded key tile of this wave
+    const int jt = (isa ? 0 : nta) + wib;                                   // padded key tile of this wave
     KeyBlocks<DH> kbk;
     kbk.init(p, b, col0, l15, g);
     float kf[C::KS], vf[C::KS], kc[4][C::CT];
@@ -1062,7 +1079,8 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_bwd_fused_kernel(const AttnAr
     };
     // single chunk (Lq <= 48): requested AFTER the staging loads (loads return in order: the first barrier then waits for the
     // staging data only; 542 -> 518 us); several chunks: requested first, their latency hides under the first chunk's staging
-    // (the other order costs 18 % at Lq = 100)
+    // (the other order costs 18 % at Lq = 100).  (Round 4: two staging items per thread in flight + the fragments right behind
+    // them, for the short chunks of config 3: no gain at Lq = 20, 86 -> 97 us at Lq = 1 -- removed.)
     if (!ONE) load_frags();
     for (int j = threadIdx.x; j < Tp; j += nthr) {         // key flags (stage_kmask with the surviving thread count)
         uint8_t v;
@@ -1084,16 +1102,21 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_bwd_fused_kernel(const AttnAr
         // stage whole rows (float4), rows >= nq zero; zero the dQ accumulator; partial products of D = rowsum(dO * O)
         for (int i = threadIdx.x; i < QC * (DH / 4); i += nthr) {
             const int q = i / (DH / 4), c = (i - q * (DH / 4)) * 4;
-            f32x4 va = {0.f, 0.f, 0.f, 0.f}, vo = va, oo = va;
+            f32x4 va = {0.f, 0.f, 0.f, 0.f}, vo = va, oo = va, vb = va;
             if (q < nq) {
                 const size_t row = (size_t)b * p.Lq + q0 + q;
                 va = *(const f32x4*)(Qg + row * p.ldq + col0 + c);
+                if (merged) vb = *(const f32x4*)(p.Qb + row * p.ldq + col0 + c);
                 vo = *(const f32x4*)(p.dO + row * p.lddo + col0 + c);
                 oo = *(const f32x4*)(p.O + row * p.ldo + col0 + c);
             }
-            *(f32x4*)(sQ + q * RS + c) = va;
+            *(f32x4*)((merged ? sQ0 : sQ) + q * RS + c) = va;
             *(f32x4*)(sdO + q * RS + c) = vo;
-            *(f32x4*)(sdQ + q * RS + c) = f32x4{0.f, 0.f, 0.f, 0.f};
+            *(f32x4*)((merged ? sdQ0 : sdQ) + q * RS + c) = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (merged) {
+                *(f32x4*)(sQ0 + (QC + q) * RS + c) = vb;
+                *(f32x4*)(sdQ0 + (QC + q) * RS + c) = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
             s_Dp[i] = (vo.x * oo.x + vo.y * oo.y) + (vo.z * oo.z + vo.w * oo.w);
         }
         for (int q = threadIdx.x; q < QC; q += nthr) {
@@ -1102,7 +1125,7 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_bwd_fused_kernel(const AttnAr
             s_inv[q] = in ? p.lse[(size_t)p.B * p.H * p.Lq + (size_t)bh * p.Lq + q0 + q] : 0.f;
             qm[q] = in ? (p.mq[(size_t)b * p.Lq + q0 + q] ? 1 : 0) : 2;
         }
-        if (threadIdx.x < 4) s_turn[threadIdx.x] = 0;
+        if (threadIdx.x < 4 * nQ) s_turn0[threadIdx.x] = 0;
         if (ONE) load_frags();
         ATT_MARK(1);
         __syncthreads();
@@ -1188,8 +1211,8 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_bwd_fused_kernel(const AttnAr
                     for (int ct = 0; ct < C::CT; ++ct) dqt[ct] = MFMA16(kc[s4][ct], dST[s4], dqt[ct]);
                 // ordered accumulation: lane (query l15, g) holds head columns CT*(4g + r) + ct (col_load mapping of kc),
                 // i.e. the 4*CT contiguous columns from 4*CT*g of row 16 qt + l15
-                if (wave > 0)
-                    while (__hip_atomic_load(s_turn + qt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != wave) __builtin_amdgcn_s_sleep(1);
+                if (wib > 0)
+                    while (__hip_atomic_load(s_turn + qt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != wib) __builtin_amdgcn_s_sleep(1);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 if (4 * C::CT * g < DH) {
                     float* row = sdQ + (16 * qt + l15) * RS + 4 * C::CT * g;
@@ -1206,22 +1229,27 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_bwd_fused_kernel(const AttnAr
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                if (lane == 0) __hip_atomic_store(s_turn + qt, wave + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (lane == 0) __hip_atomic_store(s_turn + qt, wib + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
         ATT_MARK(3);
         __syncthreads();                                   // every wave has added its dQ partials of this chunk
         ATT_MARK(4);
-        for (int i = threadIdx.x; i < nq * (DH / 4); i += nthr) {
-            const int q = i / (DH / 4), c = (i - q * (DH / 4)) * 4;
-            const size_t row = (size_t)b * p.Lq + q0 + q;
-            const f32x4 v = *(const f32x4*)(sdQ + q * RS + c);
-            if (f32_q) *(f32x4*)(dQg + row * p.lddq + col0 + c) = v;
-            if (s_q > 0.f) {          // adjacent threads hold adjacent float4 groups of one row (DH / 4 even, col0 % 8 == 0)
-                if ((DH & 7) == 0 && (col0 & 7) == 0) plane_store4_pair(dQgp, p.lddq2, (long long)row, col0 + c, v, s_q);
-                else plane_store4(dQgp, p.lddq2, (long long)row, col0 + c, v, s_q);
+        for (int blk = 0; blk < nQ; ++blk) {              // (merged: dQa from the first accumulator, dQb from the second)
+            const float* acc_ = merged ? sdQ0 + blk * QC * RS : sdQ;
+            float* dq_ = merged ? (blk == 0 ? p.dQa : p.dQb) : dQg;
+            _Float16* dqp_ = merged ? (blk == 0 ? p.dQap : p.dQbp) : dQgp;
+            for (int i = threadIdx.x; i < nq * (DH / 4); i += nthr) {
+                const int q = i / (DH / 4), c = (i - q * (DH / 4)) * 4;
+                const size_t row = (size_t)b * p.Lq + q0 + q;
+                const f32x4 v = *(const f32x4*)(acc_ + q * RS + c);
+                if (f32_q) *(f32x4*)(dq_ + row * p.lddq + col0 + c) = v;
+                if (s_q > 0.f && dqp_) {          // adjacent threads hold adjacent float4 groups of one row (DH / 4 even, col0 % 8 == 0)
+                    if ((DH & 7) == 0 && (col0 & 7) == 0) plane_store4_pair(dqp_, p.lddq2, (long long)row, col0 + c, v, s_q);
+                    else plane_store4(dqp_, p.lddq2, (long long)row, col0 + c, v, s_q);
+                }
+                am_q = absmax4(am_q, v);
             }
-            am_q = absmax4(am_q, v);
         }
         if (!ONE && q0 + QC < p.Lq) __syncthreads();       // the next chunk's staging overwrites what was just read
     }
@@ -1263,7 +1291,7 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_bwd_fused_kernel(const AttnAr
         // the scale the planes were written with is recorded by ONE deterministic surviving wave per header: wave 0 of the
         // workgroup(s) of (b, h) = (0, 0) -- the 'a' workgroup for hdr_ka, the 'b' workgroup for hdr_kb, both for hdr_q.  (A
         // "key % 1024 == 0" rule left hdr_kb unwritten on small grids: consumers then saw s == 0 and took the fp32 path.)
-        const bool hdr_writer = bh == 0 && wave == 0 && lane == 0;
+        const bool hdr_writer = bh == 0 && wib == 0 && lane == 0;          // (merged: the first wave of each block for its key header)
         if (!repair) {          // (the repair pass leaves the headers as they are: every workgroup of it must read the same ones)
             if (s_k > 0.f) { site_commit(hk, am, blockIdx.x * nw + wave, s_k); if (hdr_writer) hk[0] = s_k; }
             else if (slot) amax_commit(slot, am, blockIdx.x * nw + wave);

@@ -179,6 +179,24 @@ static int attn_launch_bwd(AttnArgs& a, int phase, hipStream_t s) {
         // the repair pass is (almost always) a launch of workgroups that leave at once: one launch for both key blocks
         const int fmode = (a.pflags & ATT_REPAIR) ? 1 : fmode_env;
         const int nmax = nta > ntb ? nta : ntb;
+        // short heads (config 3: 20 x (20 + 1) and 1 x (1 + 20), three key tiles): ONE workgroup per head for both key blocks
+        // (p.hpb == 3, attention.h) -- the query side is staged once, one launch instead of two; bit-identical to the per-block
+        // launches.  SEGMM_ATT_MERGE=0 restores them (A/B, tests)
+        {
+            const char* me = getenv("SEGMM_ATT_MERGE");          // read per call: the tests switch forms inside one process
+            const bool f16_takes_it = (DH % 16 == 0 && DH <= 48) && attn_f16() >= 2;
+            if ((!me || atoi(me) != 0) && phase == 4 && a.Lq <= 32 && nta > 0 && ntb > 0 && nta + ntb <= 4 && !f16_takes_it) {
+                const int nw = nta + ntb;
+                a.hpb = 3;
+                const dim3 grid(a.B * a.H), block(64 * nw);
+                Lq_p = Lq_small;
+                const size_t lds = ((size_t)5 * Lq_p * (DH + 4) + 3 * Lq_p + (size_t)nw * 16 * 20 + 8 + (size_t)Lq_p * (DH / 4)) * 4 + Lq_p + Tp;
+                if (Lq_p == 16) hipLaunchKernelGGL((attn_bwd_fused_kernel<DH, 4, true, 16>), grid, block, lds, s, a);
+                else hipLaunchKernelGGL((attn_bwd_fused_kernel<DH, 4, true, 32>), grid, block, lds, s, a);
+                LAUNCH_CHECK();
+                return 0;
+            }
+        }
         for (int blk = 0; blk < 2; ++blk) {
             // fmode 2 (default): one launch per key block with its exact wave count -- 539-549 us at config 2;
             // fmode 1: ONE launch for both key blocks (workgroups of 64 * max(nta, ntb) threads, surplus waves end at once) -- 680 us

@@ -825,3 +825,42 @@ def _attention_bwd_phases(H, B, H_, dh, Lq, La, Lb):
         assert torch.equal(a, b)                  # dQ: the kernel computes its own D either way
     for a, b in zip(ref[2:], got[2:]):
         assert (a - b).abs().max().item() < 2e-5 * max(1.0, a.abs().max().item())        # dK/dV read the D kernel's D
+
+
+@pytest.mark.parametrize("B,H_,dh,Lq,La,Lb", [(6, 16, 32, 20, 20, 1), (6, 16, 32, 1, 1, 20), (3, 4, 16, 20, 20, 7), (2, 2, 64, 31, 17, 30), (3, 4, 8, 7, 40, 7)])
+@pytest.mark.parametrize("p_drop", [0.0, 0.1])
+def test_attention_bwd_merged_key_blocks_is_bitwise_the_per_block_form(B, H_, dh, Lq, La, Lb, p_drop, monkeypatch):
+    """Short heads (config 3: 20 x (20 + 1), 1 x (1 + 20)): the fused backward runs ONE workgroup per head for both key blocks
+    (query side staged once, one launch).  Every sum keeps the order of the per-block launches: results are bit-identical
+    (SEGMM_ATT_MERGE=0 = the per-block launches; models/encoder.py:138-161 is what both compute)."""
+    H = _abi()
+    prev = H.attn_mode(0)          # the exact-fp32 fused kernel (what short heads take by default)
+    try:
+        d = H_ * dh
+        g = torch.Generator().manual_seed(91)
+        mk = lambda L: (torch.randn(B, L, d, generator=g) * 0.7).to(DEV)
+        Qa, Qb, Ka, Va, Kb, Vb = mk(Lq), mk(Lq), mk(La), mk(La), mk(Lb), mk(Lb)
+        mq = (torch.rand(B, Lq, generator=g) < 0.8).to(DEV)
+        mka = (torch.rand(B, La, generator=g) < 0.8).to(DEV)
+        mkb = (torch.rand(B, Lb, generator=g) < 0.7).to(DEV)
+        O = torch.empty(B * Lq, d, device=DEV)
+        lse = torch.empty(2, B, H_, Lq, device=DEV)
+        z = lambda t: (t, 0)
+        H.attn_fwd(B, H_, dh, Lq, La, Lb, z(Qa), z(Qb), d, z(Ka), z(Va), d, z(Kb), z(Vb), d, mq, mka, mkb, O, d, lse, drop_p=p_drop, seed=5, site=3)
+        dO = torch.randn(B * Lq, d, generator=g).to(DEV)
+
+        def run(merge):
+            monkeypatch.setenv("SEGMM_ATT_MERGE", merge)
+            Dv = torch.empty((B, H_, Lq), device=DEV)
+            outs = [torch.full_like(t, float("nan")) for t in (Qa, Qb, Ka, Va, Kb, Vb)]
+            H.attn_bwd(B, H_, dh, Lq, La, Lb, z(Qa), z(Qb), d, z(Ka), z(Va), d, z(Kb), z(Vb), d, mq, mka, mkb, lse, O, d, dO, d, Dv,
+                       z(outs[0]), z(outs[1]), d, z(outs[2]), z(outs[3]), d, z(outs[4]), z(outs[5]), d, drop_p=p_drop, seed=5, site=3, phase=4)
+            torch.cuda.synchronize()
+            return outs
+        a, b = run("0"), run("1")
+        for name, x, y in zip(("dQa", "dQb", "dKa", "dVa", "dKb", "dVb"), a, b):
+            assert not torch.isnan(y).any(), name
+            assert torch.equal(x, y), (name, (x - y).abs().max().item())
+    finally:
+        H.attn_mode(prev)
+
