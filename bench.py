@@ -256,6 +256,32 @@ def union_ms(intervals):
     return tot + ce - cs
 
 
+def merged_intervals(intervals):
+    out = []
+    for s_, e_ in sorted(intervals):
+        if out and s_ <= out[-1][1]:
+            out[-1][1] = max(out[-1][1], e_)
+        else:
+            out.append([s_, e_])
+    return out
+
+
+def overlap_ms(a, b):
+    """Length of the intersection of two interval sets (each given as any list of intervals)."""
+    a, b = merged_intervals(a), merged_intervals(b)
+    i = j = 0
+    tot = 0.0
+    while i < len(a) and j < len(b):
+        lo, hi = max(a[i][0], b[j][0]), min(a[i][1], b[j][1])
+        if hi > lo:
+            tot += hi - lo
+        if a[i][1] < b[j][1]:
+            i += 1
+        else:
+            j += 1
+    return tot
+
+
 def main():
     args = _graph_mode_legs(parse_args())
     env_world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -497,13 +523,19 @@ def main():
                 if tj.get("engine") == engine and args.config == 2 and not (args.batch or args.dim or args.layers or args.segments or args.global_batch):
                     traffic = round(tj["hbm_bytes_per_launch"])
                     traffic_note = "; traffic = mean HBM-side bytes per GEMM launch from profiles/hbm_traffic.json (git %s; %s)" % (tj.get("git", "?"), tj["method"])
+            # weight-gradient GEMMs enqueued beside the attention backward share the chip with it: that part of the GEMM-busy time
+            shared_ms = overlap_ms([(base.elapsed_time(e0), base.elapsed_time(e1)) for (_, _, _, _, e0, e1) in prof],
+                                   [(base.elapsed_time(e0), base.elapsed_time(e1)) for (*_, e0, e1) in aprof]) if aprof else 0.0
             rec["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                                "frac": round(achieved / peak, 4), "traffic": traffic, "algorithmic_bytes_per_launch": round(alg_bytes),
                                "launches": len(prof), "profiled_steps": psteps, "gemm_busy_ms_per_step": round(gemm_ms / psteps, 4),
+                               "gemm_busy_shared_with_attention_ms_per_step": round(shared_ms / psteps, 4),
                                "ms_per_step_with_events": round(1e3 * prof_elapsed / psteps, 4),
                                "note": "achieved = algorithmic 2MNK of every GEMM launch of the instrumented pass (the same steps enqueued launch by launch with "
                                        "an event pair per GEMM, outside the timed region) / union of their HIP-event intervals (weight-gradient GEMMs overlap input-gradient GEMMs on a "
-                                       "second stream); peak = dense MFMA peak of the instruction used"
+                                       "second stream, and -- round 4, segment axes > 32 -- the attention backward: gemm_busy_shared_with_attention_ms_per_step of the union is "
+                                       "time in which attention launches hold part of the CUs, so the same kernels read a LOWER rate here than in rounds 1-3 while the step got faster); "
+                                       "peak = dense MFMA peak of the instruction used"
                                        + {"bf16x6": " / 6 partial products", "f16x3": " / 3 partial products", "f16x3p": " / 3 partial products", "f32": ""}[engine]
                                        + traffic_note}
             if adamw_roof is not None:
@@ -532,8 +564,11 @@ def main():
             att_ms = union_ms((abase.elapsed_time(e0), abase.elapsed_time(e1)) for (*_, e0, e1) in aprof)
             att_tf = att_flops / (att_ms * 1e-3) / 1e12 if att_ms > 0 else 0.0
             apeak = hipabi.attn_peak_tflops()
+            att_shared = overlap_ms([(abase.elapsed_time(e0), abase.elapsed_time(e1)) for (*_, e0, e1) in aprof],
+                                    [(abase.elapsed_time(e0), abase.elapsed_time(e1)) for (_, _, _, _, e0, e1) in prof]) if prof else 0.0
             rec["roofline_attention"] = {"bound": "mfma", "kernel": hipabi.attn_kernel_name(), "achieved": round(att_tf, 2), "peak": round(apeak, 1),
                                          "unit": "TFLOP/s", "frac": round(att_tf / apeak, 4), "ms_per_step": round(att_ms / psteps, 4),
+                                         "ms_per_step_shared_with_gemms": round(att_shared / psteps, 4),
                                          "note": "unpadded algorithmic FLOPs (4 dh Lq T forward + 10 dh Lq T backward per (b, head)) / union of the "
                                                  "attention launches' HIP-event intervals; peak = the exact-fp32 MFMA's (the backward's fp16x3 "
                                                  "products have a 5x higher bound). A head is 69 KB of operands for 5 MFLOP: NEITHER matrix-core "

@@ -151,7 +151,16 @@ class ParamStore:
         self._side_stream = None
         self._on_side = False
         self.overlap = os.environ.get("SEGMM_OVERLAP", "1") != "0"
-        self.defer_wgrad = os.environ.get("SEGMM_DEFER_WGRAD", "0") != "0"
+        # weight gradients of a layer's ff / MLP Linears enqueued (side stream) right before the attention backward instead of
+        # next to their input-gradient GEMMs; the LayerNorm-backward column sums on the side stream.  Both were measured +-0 / -2 %
+        # while the host enqueued the step launch by launch; with the recorded step (host 0.3 ms) and the round-4 attention
+        # kernels: config 2 133.5 -> 136.2 k/s together (same box, alternating runs: +1.2 % and +0.4 % alone) -- the attention
+        # backward leaves CUs idle while its workgroups wait on memory, and a GEMM tile that gets such a CU is productive -- but
+        # config 3 (20 segments: short attention launches, K = 512 GEMMs) 185.4 -> 181.8 k/s.  "auto" (default): on for
+        # segment axes > 32 (BackboneRun.backward); SEGMM_DEFER_WGRAD / SEGMM_LN_SIDE = 0 / 1 force them.
+        self._defer_wgrad_env = os.environ.get("SEGMM_DEFER_WGRAD", "auto")
+        self._ln_side_env = os.environ.get("SEGMM_LN_SIDE", "auto")
+        self.defer_wgrad = self._defer_wgrad_env not in ("0", "auto")
         self.tail_balance = os.environ.get("SEGMM_TAIL_BALANCE", "1") != "0"
         self.attn_planes_only = int(os.environ.get("SEGMM_ATTN_PLANES_ONLY", "1"))
         self.head_side = os.environ.get("SEGMM_HEAD_SIDE", "1") != "0"
@@ -172,7 +181,7 @@ class ParamStore:
         # the side stream.  At config 3 its GEMMs have M = 1024 rows (4 - 12 tiles on 256 CUs) and used to sit on the main stream
         # between the video side's kernels.
         self.usr_side = os.environ.get("SEGMM_USR_SIDE", "1") != "0"
-        self.ln_side = os.environ.get("SEGMM_LN_SIDE", "0") != "0"      # measured: -2 % (kept as a knob)     # measured: no gain (kept as a knob)
+        self.ln_side = self._ln_side_env not in ("0", "auto")          # (see defer_wgrad above)
         # pre-split bf16 planes of the weights for the bf16x6 GEMM engine: W planes (forward) and W^T planes (dgrad
         # in the NT form), refreshed when the parameters change (one split pass per optimizer step)
         # (fp16x3 engine: two fp16 planes scaled by one power of two derived from ``wamax``, the partial maxima of
@@ -1406,6 +1415,10 @@ class BackboneRun:
         B, S, Lt, Mv, Mu = self.B, self.S, self.Lt, self.Mv, self.Mu
         dXv = d_vid_out.contiguous().view(-1, d)
         dXu = None
+        if st._defer_wgrad_env == "auto":
+            st.defer_wgrad = S > 32
+        if st._ln_side_env == "auto":
+            st.ln_side = S > 32
         self.amb = AmaxArena(st, 4 + 8 * max(self.N - 1, 0) + 2 * (self.n_mlp + 2))
         if self.abl in MLP_VARIANTS:
             if self.abl == "CrossMLP":
