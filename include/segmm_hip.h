@@ -153,6 +153,18 @@ int segmm_layernorm_bwd(const float* dy, const float* x, const float* mean, cons
                         float* dx, float* dx_drop, float* part_dgamma, float* part_dbeta, float* part_dsum, int64_t rows,
                         int d, float drop_y_p, uint32_t drop_y_site, float drop_b_p, uint32_t drop_b_site, uint64_t seed,
                         float* amax, uint16_t* planes, int ld2, float* hdr, const float* scale_in, segmm_stream_t stream);
+/* The embedding LayerNorms' backward (encoder.py:450-471: y = LN(proj(x) + pe[s])): the same launch on a grid of
+ * segmm_layernorm_bwd_pos_parts(rows, period) workgroups (0: no such grid; part_dgamma / part_dbeta / part_dsum then have that
+ * many rows) whose waves each walk rows of ONE position s = row mod period, and leave their sum of dx in part_pos[4 * parts, d]
+ * (partial row p holds position p mod period).  segmm_colsum_pos: out[s, :] = sum of the partial rows p = s (mod period), in
+ * index order -- the positional-embedding gradient without a second pass over dx. */
+int segmm_layernorm_bwd_pos_parts(int64_t rows, int period);
+int segmm_layernorm_bwd_pos(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                            float* dx, float* dx_drop, float* part_dgamma, float* part_dbeta, float* part_dsum, int64_t rows,
+                            int d, float drop_y_p, uint32_t drop_y_site, float drop_b_p, uint32_t drop_b_site, uint64_t seed,
+                            float* amax, uint16_t* planes, int ld2, float* hdr, const float* scale_in, float* part_pos, int period,
+                            segmm_stream_t stream);
+int segmm_colsum_pos(const float* part, int n_rows, int period, int d, float* out, segmm_stream_t stream);
 
 /* out[n] (+)= sum_m w[m] * X[m,n]  (bias gradients, LayerNorm partial combine, head weight gradient).
  * workspace: segmm_colsum_chunks(M) * N floats. */

@@ -101,16 +101,20 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                      const float* __restrict__ gamma, float* __restrict__ dx,
                                      float* __restrict__ dx_drop, float* __restrict__ part_dgamma,
                                      float* __restrict__ part_dbeta, float* __restrict__ part_dsum, long long rows, int d,
-                                     DropCfg drop_y, DropCfg drop_branch, float* amax, PlaneOut po) {
+                                     DropCfg drop_y, DropCfg drop_branch, float* amax, PlaneOut po, float* __restrict__ part_pos = nullptr) {
     drop_y = drop_live(drop_y); drop_branch = drop_live(drop_branch);
     __shared__ f32x4 red[4][64];
     const float ps = plane_scale(po);
     float am = 0.f;          // max |dx_drop| (or |dx| when there is no dropped copy): the tensor the GEMMs consume
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    f32x4 ag[V], ab[V], as[V], gm[V];
+    // part_pos (embedding LayerNorms): this WAVE's sum of dx over the rows it walks, one partial row per wave.  The host picks the
+    // grid so that the wave stride gridDim * nw is a multiple of the sequence length L: every row of a wave then sits at the
+    // same position s = (blockIdx * nw + wave) % L, and d pe[s, :] = the sum of the partial rows p = s (mod L) (segmm_colsum_pos)
+    // -- 12 MB of partials instead of a second pass over the 157 MB gradient (the positional-embedding gradient, encoder.py:450-471)
+    f32x4 ag[V], ab[V], as[V], gm[V], ap[V];
 #pragma unroll
     for (int i = 0; i < V; ++i) {
-        ag[i] = f32x4{0.f, 0.f, 0.f, 0.f}; ab[i] = ag[i]; as[i] = ag[i];
+        ag[i] = f32x4{0.f, 0.f, 0.f, 0.f}; ab[i] = ag[i]; as[i] = ag[i]; ap[i] = ag[i];
         const int c = lane * 4 + i * 256;
         gm[i] = (c < d) ? *(const f32x4*)(gamma + c) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -149,11 +153,19 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                 }
                 if (ps > 0.f) plane_store4_pair(po.p, po.ld2, row, c, od, ps);
                 as[i] += od;
+                ap[i] += o;
                 am = absmax4(am, od);
             }
         }
     }
     plane_finish(po, amax, am, blockIdx.x * nw + wave, ps, blockIdx.x == 0 && threadIdx.x == 0);
+    if (part_pos) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const int c = lane * 4 + i * 256;
+            if (c < d) *(f32x4*)(part_pos + ((size_t)blockIdx.x * nw + wave) * d + c) = ap[i];
+        }
+    }
     // cross-wave reduce of the partials, one partial row per workgroup.  One 256-column chunk at a time through a 4 KB
     // buffer: the kernel usually runs NEXT TO a GEMM that holds 120 of the CU's 160 KB of LDS, and a 12 KB buffer
     // would cap it at three workgroups per CU there.
@@ -248,6 +260,16 @@ __global__ __launch_bounds__(256) void colsum_final3_kernel(const float* __restr
     red[ty][tx] = acc;
     __syncthreads();
     if (ty == 0 && n < N) *(f32x4*)(a.out[blockIdx.z] + n) = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+}
+
+// out[s][n] = sum over the partial rows p = s, s + period, s + 2 period, ... of part[p][n], in that order (deterministic):
+// the per-position sums of a LayerNorm backward's per-wave partials (layernorm_bwd_kernel part_pos)
+__global__ __launch_bounds__(256) void colsum_pos_kernel(const float* __restrict__ part, int P, int period, int N, float* __restrict__ out) {
+    const int n = (blockIdx.x * 256 + threadIdx.x) * 4, s_ = blockIdx.y;
+    if (n >= N) return;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int p_ = s_; p_ < P; p_ += period) acc += *(const f32x4*)(part + (size_t)p_ * N + n);
+    *(f32x4*)(out + (size_t)s_ * N + n) = acc;
 }
 
 // ---------------------------------------------------------------- interest head: Linear(d,1)  (decoder_leave_focal.py:451,596)

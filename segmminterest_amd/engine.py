@@ -158,6 +158,7 @@ class ParamStore:
         # backward leaves CUs idle while its workgroups wait on memory, and a GEMM tile that gets such a CU is productive -- but
         # config 3 (20 segments: short attention launches, K = 512 GEMMs) 185.4 -> 181.8 k/s.  "auto" (default): on for
         # segment axes > 32 (BackboneRun.backward); SEGMM_DEFER_WGRAD / SEGMM_LN_SIDE = 0 / 1 force them.
+        self.ln_pos = os.environ.get("SEGMM_LN_POS", "1") != "0"          # embedding LayerNorm backward leaves per-position sums (_ln_bwd)
         self._defer_wgrad_env = os.environ.get("SEGMM_DEFER_WGRAD", "auto")
         self._ln_side_env = os.environ.get("SEGMM_LN_SIDE", "auto")
         self.defer_wgrad = self._defer_wgrad_env not in ("0", "auto")
@@ -884,23 +885,34 @@ def _colsum(store, X, ld, M, N, out, x_off=0, w=None, accumulate=False):
 
 
 def _ln_bwd(store, dy, x, mean, rstd, gname, bname, gbuf, dx, dx_drop, rows, d, drop_y=(0.0, 0), drop_b=(0.0, 0), seed=0,
-            amax=None, dsum_to=None, po=None):
+            amax=None, dsum_to=None, po=None, pos_period=0):
     """LayerNorm backward + its affine gradients.  ``dsum_to``: gradient tensor that receives the column sums of the
     forwarded gradient (dx_drop, or dx): the bias gradient of the Linear feeding this LayerNorm's residual branch,
-    accumulated inside the same kernel instead of by a second pass over [rows, d]."""
-    parts = H.layernorm_bwd_parts(rows)
+    accumulated inside the same kernel instead of by a second pass over [rows, d].
+    ``pos_period`` = L (embedding LayerNorms, rows = B * L): the launch takes the per-position grid and the per-wave sums of dx
+    it leaves are returned ([4 * parts, d], partial row p = position p mod L; None when no such grid exists) -- the
+    positional-embedding gradient then is a sum over ~40 partial rows per position instead of a pass over dx."""
+    pparts = H.layernorm_bwd_pos_parts(rows, pos_period) if (pos_period and store.ln_pos) else 0
+    parts = pparts if pparts > 0 else H.layernorm_bwd_parts(rows)
     # partial buffers named after the parameter so that their reductions MAY run on the side stream (SEGMM_LN_SIDE=1;
     # measured 2 % slower than keeping these tiny launches on the main stream, so off by default)
     pg = store.buf("ln_pg:" + gname, (parts, d))
     pb = store.buf("ln_pb:" + gname, (parts, d))
     ps = store.buf("ln_ps:" + gname, (parts, d)) if dsum_to is not None else None
-    H.layernorm_bwd(dy, x, mean, rstd, store.p(gname), dx, dx_drop, pg, pb, drop_y_p=drop_y[0], drop_y_site=drop_y[1],
-                    drop_b_p=drop_b[0], drop_b_site=drop_b[1], seed=seed, amax=amax, part_dsum=ps, po=po)
+    pp = None
+    if pparts > 0:
+        pp = store.buf("ln_pp:" + gname, (4 * pparts, d))
+        H.layernorm_bwd_pos(dy, x, mean, rstd, store.p(gname), dx, dx_drop, pg, pb, pp, pos_period, drop_y_p=drop_y[0], drop_y_site=drop_y[1],
+                            drop_b_p=drop_b[0], drop_b_site=drop_b[1], seed=seed, amax=amax, part_dsum=ps, po=po)
+    else:
+        H.layernorm_bwd(dy, x, mean, rstd, store.p(gname), dx, dx_drop, pg, pb, drop_y_p=drop_y[0], drop_y_site=drop_y[1],
+                        drop_b_p=drop_b[0], drop_b_site=drop_b[1], seed=seed, amax=amax, part_dsum=ps, po=po)
     outs = [store.g(gname, gbuf), store.g(bname, gbuf)] + ([dsum_to] if ps is not None else [])
     with (side_work(store) if store.ln_side else contextlib.nullcontext()):
         ws = store.buf("colsum3_ws_side" if store._on_side else "colsum3_ws", (3 * H.colsum_chunks(parts) * d,))
         Xs = [pg, pb] + ([ps] if ps is not None else [])
         H.colsum3(Xs, d, parts, d, outs, ws)          # one launch pair instead of three
+    return pp
 
 
 def _attn_bwd(store, *args, **kw):
@@ -1443,26 +1455,26 @@ class BackboneRun:
         H.mark(H.PHASE_EMBED_BWD, self.bi)
         if dXu is not None:
             dpre_u = new_act(st, self.amb, Mu, d, key="dpre_u", planes=not bb.id_usr, site=P + "dpre_u", delayed=self.delayed)
-            _ln_bwd(st, dXu, sv["pre_u"], sv["meu"], sv["reu"], P + "usr_ln.weight", P + "usr_ln.bias", gbuf, dpre_u.t, None, Mu, d,
-                    drop_y=(self.p_drop, _site(self.bi, 0, K_EMB_U)), seed=self.seed, amax=dpre_u.slots, po=dpre_u.po)
+            pp_u = _ln_bwd(st, dXu, sv["pre_u"], sv["meu"], sv["reu"], P + "usr_ln.weight", P + "usr_ln.bias", gbuf, dpre_u.t, None, Mu, d,
+                           drop_y=(self.p_drop, _site(self.bi, 0, K_EMB_U)), seed=self.seed, amax=dpre_u.slots, po=dpre_u.po, pos_period=Lt)
             finish_act(st, produced(dpre_u))
-            self._embed_bwd("usr", dpre_u, B, Lt, gbuf)
+            self._embed_bwd("usr", dpre_u, B, Lt, gbuf, pp_u)
             if on_bucket is not None:
                 # the user-side embedding gradients: LayerNorm / positional parts were written on the main stream, the weight
                 # gradient is still in flight on the side stream -- the hook orders the all-reduce behind BOTH without making the
                 # main stream (which goes on with the video side) wait for the side stream
                 on_bucket(P + "embed_u", after_side=True)
         dpre_v = new_act(st, self.amb, Mv, d, key="dpre_v", planes=not bb.id_vid, site=P + "dpre_v", delayed=self.delayed)
-        _ln_bwd(st, dXv, sv["pre_v"], sv["mev"], sv["rev"], P + "vid_ln.weight", P + "vid_ln.bias", gbuf, dpre_v.t, None, Mv, d,
-                drop_y=(self.p_drop, _site(self.bi, 0, K_EMB_V)), seed=self.seed, amax=dpre_v.slots, po=dpre_v.po)
+        pp_v = _ln_bwd(st, dXv, sv["pre_v"], sv["mev"], sv["rev"], P + "vid_ln.weight", P + "vid_ln.bias", gbuf, dpre_v.t, None, Mv, d,
+                       drop_y=(self.p_drop, _site(self.bi, 0, K_EMB_V)), seed=self.seed, amax=dpre_v.slots, po=dpre_v.po, pos_period=S)
         finish_act(st, produced(dpre_v))
-        self._embed_bwd("vid", dpre_v, B, S, gbuf)
+        self._embed_bwd("vid", dpre_v, B, S, gbuf, pp_v)
         join_side(st)
         self.amb.close(st, backward=True)
         if on_bucket is not None:
             on_bucket(P + "embed")
 
-    def _embed_bwd(self, side, dpre_act, B, L, gbuf):
+    def _embed_bwd(self, side, dpre_act, B, L, gbuf, part_pos=None):
         st, bb, P, d, sv = self.store, self.bb, self.pre, self.d, self.sv
         dpre = dpre_act.t
         M = B * L
@@ -1471,7 +1483,10 @@ class BackboneRun:
             gpe = st.g(P + "%s_pe.weight" % side, gbuf)
         else:          # --use_pe 0: the table is dead (grad None); the per-position sums still feed the bias / frame-id gradients
             gpe = st.buf("gpe_scratch_" + side, (L, d))
-        _colsum(st, dpre, L * d, B, L * d, gpe)          # dpe[s,:] = sum_b dpre[b,s,:]: a column sum of the [B, L*d] view
+        if part_pos is not None:          # the LayerNorm backward left per-wave, per-position sums of dpre (12 MB instead of a pass over dpre)
+            H.colsum_pos(part_pos, L, gpe)
+        else:
+            _colsum(st, dpre, L * d, B, L * d, gpe)          # dpe[s,:] = sum_b dpre[b,s,:]: a column sum of the [B, L*d] view
         if gpe.shape[0] > L:
             H.fill_zero(gpe[L:])
         gtab = st.g(P + "%s_proj.weight" % side, gbuf)

@@ -15,7 +15,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SEGMM_LIB") or os.path.join(_HERE, "libsegmm_hip.so")      # SEGMM_LIB: A/B builds of the kernels
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 _lib = None
 
@@ -50,6 +50,9 @@ SIGNATURES = {
     "segmm_layernorm_fwd": [_p, _p, _p, _p, _p, _p, _i64, _i, _f, _f, _u64, _u32, _p, _p, _i, _p, _p, _p],
     "segmm_layernorm_bwd_parts": [_i64],
     "segmm_layernorm_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _f, _u32, _f, _u32, _u64, _p, _p, _i, _p, _p, _p],
+    "segmm_layernorm_bwd_pos_parts": [_i64, _i],
+    "segmm_layernorm_bwd_pos": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _f, _u32, _f, _u32, _u64, _p, _p, _i, _p, _p, _p, _i, _p],
+    "segmm_colsum_pos": [_p, _i, _i, _i, _p, _p],
     "segmm_colsum_chunks": [_i64],
     "segmm_colsum": [_p, _i, _p, _i64, _i, _p, _i, _p, _p],
     "segmm_attn_fwd": [_i] * 6 + [_p, _p, _i, _p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _i, _p, _f, _u64, _u32, _p, _p, _p],
@@ -661,6 +664,28 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dx_drop, part_dgamma, part_dbeta
                                      _ptr(part_dgamma), _ptr(part_dbeta), _ptr(part_dsum), x.numel() // d, d, float(drop_y_p),
                                      int(drop_y_site), float(drop_b_p), int(drop_b_site), int(seed), _ptr(amax), *_po(po), _stream()),
            "segmm_layernorm_bwd")
+
+
+def layernorm_bwd_pos_parts(rows, period):
+    return lib().segmm_layernorm_bwd_pos_parts(rows, period)
+
+
+def layernorm_bwd_pos(dy, x, mean, rstd, gamma, dx, dx_drop, part_dgamma, part_dbeta, part_pos, period, drop_y_p=0.0, drop_y_site=0,
+                      drop_b_p=0.0, drop_b_site=0, seed=0, amax=None, part_dsum=None, po=None):
+    """LayerNorm backward on the per-position grid: also leaves the per-wave sums of dx in ``part_pos`` [4 * parts, d]."""
+    _dev(dy, x, dx)
+    d = x.shape[-1]
+    _check(lib().segmm_layernorm_bwd_pos(_ptr(dy), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(dx), _ptr(dx_drop),
+                                         _ptr(part_dgamma), _ptr(part_dbeta), _ptr(part_dsum), x.numel() // d, d, float(drop_y_p),
+                                         int(drop_y_site), float(drop_b_p), int(drop_b_site), int(seed), _ptr(amax), *_po(po),
+                                         _ptr(part_pos), int(period), _stream()),
+           "segmm_layernorm_bwd_pos")
+
+
+def colsum_pos(part, period, out):
+    """out[s, :] = sum of the rows p = s (mod period) of ``part`` [P, d]."""
+    _dev(part, out)
+    _check(lib().segmm_colsum_pos(_ptr(part), part.shape[0], int(period), part.shape[1], _ptr(out), _stream()), "segmm_colsum_pos")
 
 
 def colsum_chunks(M):

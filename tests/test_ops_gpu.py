@@ -864,3 +864,38 @@ def test_attention_bwd_merged_key_blocks_is_bitwise_the_per_block_form(B, H_, dh
     finally:
         H.attn_mode(prev)
 
+
+@pytest.mark.parametrize("B,L,d", [(512, 100, 768), (512, 40, 768), (37, 20, 256), (64, 1, 512), (9, 7, 64), (3, 33, 1024)])
+def test_layernorm_bwd_per_position_sums(B, L, d):
+    """Embedding LayerNorms (encoder.py:450-471): the backward on the per-position grid leaves per-wave sums of dx whose
+    segmm_colsum_pos combine is the positional-embedding gradient sum_b dx[b, s, :]; dx and the affine partials are those of
+    the plain launch (bit-identical dx; the partial sums only differ by their grouping)."""
+    H = _abi()
+    rows = B * L
+    g = torch.Generator().manual_seed(5)
+    dy = torch.randn(rows, d, generator=g).to(DEV)
+    x = (torch.randn(rows, d, generator=g) * 2 + 0.5).to(DEV)
+    gamma = (1 + 0.1 * torch.randn(d, generator=g)).to(DEV)
+    mean = x.mean(-1)
+    rstd = 1.0 / torch.sqrt(x.var(-1, unbiased=False) + 1e-12)
+    parts0 = H.layernorm_bwd_parts(rows)
+    dx0 = torch.empty_like(x)
+    pg0, pb0 = torch.empty(parts0, d, device=DEV), torch.empty(parts0, d, device=DEV)
+    H.layernorm_bwd(dy, x, mean, rstd, gamma, dx0, None, pg0, pb0, drop_y_p=0.1, drop_y_site=3, seed=11)
+    parts = H.layernorm_bwd_pos_parts(rows, L)
+    assert parts > 0 and (4 * parts) % L == 0 and parts <= 1024
+    dx = torch.empty_like(x)
+    pg, pb = torch.empty(parts, d, device=DEV), torch.empty(parts, d, device=DEV)
+    pp = torch.full((4 * parts, d), float("nan"), device=DEV)
+    H.layernorm_bwd_pos(dy, x, mean, rstd, gamma, dx, None, pg, pb, pp, L, drop_y_p=0.1, drop_y_site=3, seed=11)
+    out = torch.full((L, d), float("nan"), device=DEV)
+    H.colsum_pos(pp, L, out)
+    torch.cuda.synchronize()
+    assert torch.equal(dx, dx0)
+    ref = dx0.double().view(B, L, d).sum(0)
+    assert (out.double() - ref).abs().max().item() < 2e-6 * max(1.0, ref.abs().max().item()) * max(1.0, B ** 0.5 / 4)
+    for a, b in ((pg, pg0), (pb, pb0)):
+        ra, rb = a.double().sum(0), b.double().sum(0)
+        assert (ra - rb).abs().max().item() < 1e-5 * max(1.0, rb.abs().max().item())
+    assert H.layernorm_bwd_pos_parts(rows + 1, L) == 0 or (rows + 1) % L == 0
+
