@@ -1003,7 +1003,8 @@ __global__ __launch_bounds__(64 * NW, 4) void attn_bwd_fused_kernel(const AttnAr
     // statistics and the flags are staged once instead of once per block (and the one-key block of a config-3 head no longer
     // pays a whole staging pass and launch of its own); each block keeps its own staged Q projection, its own dQ accumulator and
     // its own turn counters, so every sum is formed in the order of the per-block launches: bit-identical results.
-    const bool merged = p.hpb == 3;
+    constexpr bool CAN_MERGE = ONE && QCH < ATT_FUSED_QCHUNK;          // (the host merges short single-chunk launches only: compile the
+    const bool merged = CAN_MERGE && p.hpb == 3;                       //  48-row instances without the second accumulator / pointer set)
     const int wg = xcd_remap(blockIdx.x, gridDim.x), bh = p.hpb == 2 ? wg >> 1 : wg, b = bh / p.H, h = bh % p.H;
     const int La_p = round16(p.La), Lb_p = round16(p.Lb), Tp = La_p + Lb_p, nta = La_p >> 4, ntb = Lb_p >> 4;
     const bool isa = merged ? wave < nta : (p.hpb == 2 ? (wg & 1) == 0 : p.hpb == 0);
