@@ -157,7 +157,7 @@ class ParamStore:
         # kernels: config 2 133.5 -> 136.2 k/s together (same box, alternating runs: +1.2 % and +0.4 % alone) -- the attention
         # backward leaves CUs idle while its workgroups wait on memory, and a GEMM tile that gets such a CU is productive -- but
         # config 3 (20 segments: short attention launches, K = 512 GEMMs) 185.4 -> 181.8 k/s.  "auto" (default): on for
-        # segment axes > 32 (BackboneRun.backward); SEGMM_DEFER_WGRAD / SEGMM_LN_SIDE = 0 / 1 force them.
+        # segment axes > 32 on the plane engine (BackboneRun.backward); SEGMM_DEFER_WGRAD / SEGMM_LN_SIDE = 0 / 1 force them.
         self.ln_pos = os.environ.get("SEGMM_LN_POS", "1") != "0"          # embedding LayerNorm backward leaves per-position sums (_ln_bwd)
         self._defer_wgrad_env = os.environ.get("SEGMM_DEFER_WGRAD", "auto")
         self._ln_side_env = os.environ.get("SEGMM_LN_SIDE", "auto")
@@ -1427,10 +1427,10 @@ class BackboneRun:
         B, S, Lt, Mv, Mu = self.B, self.S, self.Lt, self.Mv, self.Mu
         dXv = d_vid_out.contiguous().view(-1, d)
         dXu = None
-        if st._defer_wgrad_env == "auto":
-            st.defer_wgrad = S > 32
+        if st._defer_wgrad_env == "auto":          # (plane engine only: on the exact-fp32 engine the deferral costs 1.5 %)
+            st.defer_wgrad = S > 32 and st.engine_p
         if st._ln_side_env == "auto":
-            st.ln_side = S > 32
+            st.ln_side = S > 32 and st.engine_p
         self.amb = AmaxArena(st, 4 + 8 * max(self.N - 1, 0) + 2 * (self.n_mlp + 2))
         if self.abl in MLP_VARIANTS:
             if self.abl == "CrossMLP":
