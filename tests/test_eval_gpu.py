@@ -595,3 +595,46 @@ def test_id_table_two_pass_step_equals_dense_step(device_state):
     a, b = run(False), run(True)
     for x, y in zip(a, b):
         assert torch.equal(x, y)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("device_state", [False, True])
+def test_step_schedule_knobs_do_not_change_the_step(device_state):
+    """Round 4's schedule changes only move launches between streams: the head of the step on two streams (SEGMM_BEGIN_OVERLAP),
+    the layer's weight gradients beside the attention backward (SEGMM_DEFER_WGRAD) and the LayerNorm column sums on the side
+    stream (SEGMM_LN_SIDE) -- on for segment axes > 32 -- must leave parameters and moments BIT-identical to the serial
+    schedule, eager and as recorded launch sequences (config-2-like image / image model, S = 40, dropout on)."""
+    import torch
+    from segmminterest_amd.synth import make_batch
+    from segmminterest_amd.trainer import Trainer, default_args, init_model
+    dev = torch.device("cuda:0")
+    B, S, Lt, D, N, h = 12, 40, 20, 64, 3, 4
+    margs = default_args(num_layers_enc=N, d_model=D, nhead=h, input_type={"user": "image", "photo": "image"}, exposure_prob=[1.0] * S)
+    batches = [{k: v.to(dev) for k, v in make_batch(B, S, Lt, D, seed=700 + i).items()} for i in range(3)]
+    knobs = ("SEGMM_BEGIN_OVERLAP", "SEGMM_DEFER_WGRAD", "SEGMM_LN_SIDE")
+
+    def run(on):
+        for k in knobs:
+            os.environ[k] = "1" if on else "0"
+        try:
+            torch.manual_seed(21)
+            model = init_model(margs, input_dim=D, max_vid_len=S, max_usr_len=Lt).to(dev)
+            tr = Trainer(model, device_state=device_state)
+            assert tr.begin_overlap == on and model._store.defer_wgrad == on and model._store.ln_side == on
+            if device_state:
+                tr.record(batches[0], warmup=2)
+            else:
+                for _ in range(3):
+                    tr.train_step(batches[0])
+            for t in range(5):
+                (tr.run_recorded if device_state else tr.train_step)(batches[t % 3])
+            torch.cuda.synchronize()
+            return model._store.flat.detach().clone(), tr.opt.m.clone(), tr.opt.v.clone()
+        finally:
+            for k in knobs:
+                os.environ.pop(k, None)
+
+    a, b = run(False), run(True)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+
