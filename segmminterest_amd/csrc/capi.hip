@@ -385,8 +385,17 @@ int segmm_l1norm(const float* x, float* y, float* inv_scale, int64_t rows, int D
     SEGMM_REQUIRE(D > 0 && D % 4 == 0 && aligned16(x) && (!y || aligned16(y)), "l1norm: D %% 4 / alignment (D=%d)", D);
     if (rows <= 0) return 0;
     const int wpb = 4;
-    hipLaunchKernelGGL(l1norm_kernel, dim3((unsigned)((rows + wpb - 1) / wpb)), dim3(64 * wpb), 0, (hipStream_t)stream,
-                       x, y, inv_scale, (long long)rows, D, amax, plane_out(planes, ld2, hdr, scale_in));
+    static const int reg_form = getenv("SEGMM_L1NORM_REG") ? atoi(getenv("SEGMM_L1NORM_REG")) : 1;
+    const dim3 grid((unsigned)((rows + wpb - 1) / wpb)), block(64 * wpb);
+#define L1R(V) hipLaunchKernelGGL((l1norm_reg_kernel<V>), grid, block, 0, (hipStream_t)stream, x, y, inv_scale, (long long)rows, D, amax, plane_out(planes, ld2, hdr, scale_in))
+    if (reg_form && D <= 256) L1R(1);
+    else if (reg_form && D <= 512) L1R(2);
+    else if (reg_form && D <= 768) L1R(3);
+    else if (reg_form && D <= 1024) L1R(4);
+    else if (reg_form && D <= 1536) L1R(6);
+    else if (reg_form && D <= 2048) L1R(8);
+    else hipLaunchKernelGGL(l1norm_kernel, grid, block, 0, (hipStream_t)stream, x, y, inv_scale, (long long)rows, D, amax, plane_out(planes, ld2, hdr, scale_in));
+#undef L1R
     LAUNCH_CHECK();
     return 0;
 }
