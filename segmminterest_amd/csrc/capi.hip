@@ -862,7 +862,7 @@ int segmm_layernorm_bwd_pos(const float* dy, const float* x, const float* mean, 
 
 int segmm_colsum_pos(const float* part, int n_rows, int period, int d, float* out, segmm_stream_t stream) {
     SEGMM_REQUIRE(part && out && n_rows > 0 && period > 0 && d > 0 && d % 4 == 0 && aligned16(part) && aligned16(out), "colsum_pos: arguments");
-    hipLaunchKernelGGL(colsum_pos_kernel, dim3((unsigned)((d / 4 + 255) / 256), (unsigned)period), dim3(256), 0, (hipStream_t)stream, part, n_rows, period, d, out);
+    hipLaunchKernelGGL(colsum_pos_kernel, dim3((unsigned)((d / 4 + 15) / 16), (unsigned)period), dim3(256), 0, (hipStream_t)stream, part, n_rows, period, d, out);
     LAUNCH_CHECK();
     return 0;
 }

@@ -302,14 +302,25 @@ __global__ __launch_bounds__(256) void colsum_final3_kernel(const float* __restr
     if (ty == 0 && n < N) *(f32x4*)(a.out[blockIdx.z] + n) = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
 }
 
-// out[s][n] = sum over the partial rows p = s, s + period, s + 2 period, ... of part[p][n], in that order (deterministic):
-// the per-position sums of a LayerNorm backward's per-wave partials (layernorm_bwd_kernel part_pos)
+// out[s][n] = sum over the partial rows p = s, s + period, s + 2 period, ... of part[p][n] (a fixed order: deterministic):
+// the per-position sums of a LayerNorm backward's per-wave partials (layernorm_bwd_kernel part_pos).  A workgroup takes 64
+// columns of one position; 16 row lanes share the position's partial rows (a short sequence has few positions and many rows
+// each: one thread per column walked 1 024 dependent loads at period 1), then one lane adds the 16 partials in lane order.
 __global__ __launch_bounds__(256) void colsum_pos_kernel(const float* __restrict__ part, int P, int period, int N, float* __restrict__ out) {
-    const int n = (blockIdx.x * 256 + threadIdx.x) * 4, s_ = blockIdx.y;
-    if (n >= N) return;
+    __shared__ f32x4 red[16][16];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int n = (blockIdx.x * 16 + tx) * 4, s_ = blockIdx.y;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int p_ = s_; p_ < P; p_ += period) acc += *(const f32x4*)(part + (size_t)p_ * N + n);
-    *(f32x4*)(out + (size_t)s_ * N + n) = acc;
+    if (n < N)
+        for (long long p_ = s_ + (long long)period * ty; p_ < P; p_ += 16ll * period) acc += *(const f32x4*)(part + (size_t)p_ * N + n);
+    red[ty][tx] = acc;
+    __syncthreads();
+    if (ty == 0 && n < N) {
+        f32x4 t = red[0][tx];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) t += red[k][tx];
+        *(f32x4*)(out + (size_t)s_ * N + n) = t;
+    }
 }
 
 // ---------------------------------------------------------------- interest head: Linear(d,1)  (decoder_leave_focal.py:451,596)

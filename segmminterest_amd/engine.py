@@ -892,7 +892,8 @@ def _ln_bwd(store, dy, x, mean, rstd, gname, bname, gbuf, dx, dx_drop, rows, d, 
     ``pos_period`` = L (embedding LayerNorms, rows = B * L): the launch takes the per-position grid and the per-wave sums of dx
     it leaves are returned ([4 * parts, d], partial row p = position p mod L; None when no such grid exists) -- the
     positional-embedding gradient then is a sum over ~40 partial rows per position instead of a pass over dx."""
-    pparts = H.layernorm_bwd_pos_parts(rows, pos_period) if (pos_period and store.ln_pos) else 0
+    # (worth it when the second pass it saves is long: short sequences / small tensors keep the plain column sum)
+    pparts = H.layernorm_bwd_pos_parts(rows, pos_period) if (pos_period >= 8 and store.ln_pos and rows * d >= (1 << 23)) else 0
     parts = pparts if pparts > 0 else H.layernorm_bwd_parts(rows)
     # partial buffers named after the parameter so that their reductions MAY run on the side stream (SEGMM_LN_SIDE=1;
     # measured 2 % slower than keeping these tiny launches on the main stream, so off by default)
