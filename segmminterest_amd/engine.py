@@ -364,17 +364,31 @@ class ParamStore:
         return int(self.scales()[self.MAX_SITES].item())
 
     # -- second HIP stream for weight/bias gradients (see class SideWork)
-    def side_stream(self):
-        if self._side_stream is None or self._side_stream.device != self.flat.device:
+    # The side / auxiliary streams are ONE pair per device and process, shared by every store: HIP maps streams onto
+    # GPU_MAX_HW_QUEUES hardware queues as they are created, and a second model in the same process (bench.py's exact-fp32 leg, a
+    # test that builds two trainers) that brought its own pair ended up sharing queues with the main stream -- its step ran 13 %
+    # slower than the same model alone (49.5 k -> 43.6 k interactions/s on the fp32 engine).
+    _shared_streams = {}
+
+    @classmethod
+    def _shared_stream(cls, device, kind):
+        key = (str(device), kind)
+        s = cls._shared_streams.get(key)
+        if s is None:
             # LOWEST priority: the side stream's weight-gradient GEMMs fill idle CUs, they must not starve the main
             # stream's kernels (a 49 us LayerNorm backward was seen taking 470 us next to a same-priority GEMM)
-            self._side_stream = torch.cuda.Stream(device=self.flat.device, priority=int(os.environ.get("SEGMM_SIDE_PRIORITY", "1")))
+            s = cls._shared_streams[key] = torch.cuda.Stream(device=device, priority=int(os.environ.get("SEGMM_SIDE_PRIORITY", "1")))
+        return s
+
+    def side_stream(self):
+        if self._side_stream is None or self._side_stream.device != self.flat.device:
+            self._side_stream = self._shared_stream(self.flat.device, "side")
         return self._side_stream
 
     def aux_stream(self):
         a = self.__dict__.get("_aux_stream")
         if a is None or a.device != self.flat.device:
-            a = self._aux_stream = torch.cuda.Stream(device=self.flat.device, priority=int(os.environ.get("SEGMM_SIDE_PRIORITY", "1")))
+            a = self._aux_stream = self._shared_stream(self.flat.device, "aux")
         return a
 
     def attn_stream(self):
