@@ -20,6 +20,17 @@ def _batch(cfg, B):
     return make_batch(B, cfg["S"], cfg["Lt"], cfg["D_in"], n_users=cfg.get("n_users", 5) or 5, n_items=cfg.get("n_items", 5) or 5, seed=21)
 
 
+def _case(name):
+    """(cfg, state dict or None): a golden fixture, or ``synth_cfg3``: BASELINE config 3's width (id / id, d = 512, h = 16 -> dh = 32,
+    N = 4, S = 20, one user token) with the facade's own initialisation under a fixed seed (identical in every process)."""
+    if name == "synth_cfg3":
+        cfg = dict(S=20, N=4, d=512, h=16, user="id", photo="id", Lt=1, D_in=4, n_users=200, n_items=1000, exposure_prob=[1.0] * 20,
+                   loss_type_list=["interestBPR"], loss_weight={"interestBPR": 1.0, "mse": 1.0})
+        return cfg, None
+    cfg, g, _, _ = load_case(name)
+    return cfg, g["sd"]
+
+
 def _run(rank, world, port, name, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
@@ -30,9 +41,11 @@ def _run(rank, world, port, name, q):
         dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         torch.cuda.set_device(0)
-        cfg, g, _, _ = load_case(name)
+        cfg, sd0 = _case(name)
+        torch.manual_seed(5)
         model = build_model(cfg)
-        model.load_state_dict(g["sd"])
+        if sd0 is not None:
+            model.load_state_dict(sd0)
         model = model.cuda()
         tr = Trainer(model, comm=DPComm(), overlap=True, dropout=False)
         full = _batch(cfg, 16)
@@ -56,7 +69,8 @@ def _run(rank, world, port, name, q):
 
 
 @pytest.mark.parametrize("name,ranks", [("img_d32_N3_alllosses", 2), ("both_fh2", 2), ("id_d32_N2", 2),      # id tables: sparse row exchange
-                                        ("img_d32_N3_alllosses", 4), ("id_d32_N2", 4)])                        # 4 ranks x 4 rows on the one GPU
+                                        ("img_d32_N3_alllosses", 4), ("id_d32_N2", 4),                         # 4 ranks x 4 rows on the one GPU
+                                        ("synth_cfg3", 2), ("synth_cfg3", 4)])                                  # BASELINE config 3's width, "DP over 2 and 4"
 def test_two_ranks_equal_single_process(name, ranks):
     ctx = mp.get_context("spawn")
     results = {}
