@@ -718,6 +718,7 @@ class Trainer:
             return out
         finally:
             st._trusted = False
+            model.__dict__.pop("_stats_pre", None)          # (a step that failed before its forward must not leave this batch's statistics behind)
             if self.device_state:
                 st.hdr_step_end()          # evaluation passes between steps draw their headers from the wrapping ring
 
