@@ -153,6 +153,13 @@ int segmm_layernorm_bwd(const float* dy, const float* x, const float* mean, cons
                         float* dx, float* dx_drop, float* part_dgamma, float* part_dbeta, float* part_dsum, int64_t rows,
                         int d, float drop_y_p, uint32_t drop_y_site, float drop_b_p, uint32_t drop_b_site, uint64_t seed,
                         float* amax, uint16_t* planes, int ld2, float* hdr, const float* scale_in, segmm_stream_t stream);
+/* segmm_layernorm_bwd whose incoming gradient is the outer product dy[row, c] = dy_row[row] * dy_col[c]: what the Linear(d, 1)
+ * interest head (decoder_leave_focal.py:451,596) sends into the last LayerNorm of the backbone -- formed inside the launch
+ * instead of by segmm_rowscale_bcast (same products, bit-identical results). */
+int segmm_layernorm_bwd_outer(const float* dy_row, const float* dy_col, const float* x, const float* mean, const float* rstd, const float* gamma,
+                              float* dx, float* dx_drop, float* part_dgamma, float* part_dbeta, float* part_dsum, int64_t rows,
+                              int d, float drop_y_p, uint32_t drop_y_site, float drop_b_p, uint32_t drop_b_site, uint64_t seed,
+                              float* amax, uint16_t* planes, int ld2, float* hdr, const float* scale_in, segmm_stream_t stream);
 /* The embedding LayerNorms' backward (encoder.py:450-471: y = LN(proj(x) + pe[s])): the same launch on a grid of
  * segmm_layernorm_bwd_pos_parts(rows, period) workgroups (0: no such grid; part_dgamma / part_dbeta / part_dsum then have that
  * many rows) whose waves each walk rows of ONE position s = row mod period, and leave their sum of dx in part_pos[4 * parts, d]

@@ -366,7 +366,7 @@ __global__ void step_get_kernel(StepState* out) { *out = g_step; }
 extern "C" {
 
 const char* segmm_last_error(void) { return g_segmm_err; }
-int segmm_abi_version(void) { return 23; }
+int segmm_abi_version(void) { return 24; }
 int segmm_attn_mode(int mode) { const int prev = attn_f16(); if (mode >= 0 && mode <= 2) g_attn_mode = mode; return prev; }
 
 static PlaneOut plane_out(uint16_t* planes, int ld2, float* hdr, const float* scale_in) {
@@ -817,13 +817,14 @@ int segmm_layernorm_bwd_parts(int64_t rows) {
 static int ln_bwd_launch(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                          float* dx, float* dx_drop, float* part_dgamma, float* part_dbeta, float* part_dsum, int64_t rows,
                          int d, float drop_y_p, uint32_t drop_y_site, float drop_b_p, uint32_t drop_b_site, uint64_t seed,
-                         float* amax, uint16_t* planes, int ld2, float* hdr, const float* scale_in, float* part_pos, int parts, segmm_stream_t stream) {
+                         float* amax, uint16_t* planes, int ld2, float* hdr, const float* scale_in, float* part_pos, int parts, segmm_stream_t stream,
+                         const float* dy_col = nullptr) {
     SEGMM_REQUIRE(dy && x && mean && rstd && gamma && dx && part_dgamma && part_dbeta, "layernorm_bwd: null pointer");
     PLANE_OUT_CHECK("layernorm_bwd", d);
     SEGMM_REQUIRE(d > 0 && d % 4 == 0 && d <= 256 * ROW_MAXV, "layernorm_bwd: d=%d unsupported", d);
-    SEGMM_REQUIRE(aligned16(dy) && aligned16(x) && aligned16(dx) && aligned16(gamma) && (!dx_drop || aligned16(dx_drop)), "layernorm_bwd: alignment");
+    SEGMM_REQUIRE((dy_col ? aligned16(dy_col) : aligned16(dy)) && aligned16(x) && aligned16(dx) && aligned16(gamma) && (!dx_drop || aligned16(dx_drop)), "layernorm_bwd: alignment");
     const DropCfg dy_ = make_drop(drop_y_p, seed, drop_y_site), db_ = make_drop(drop_b_p, seed, drop_b_site);
-#define LNB(V) hipLaunchKernelGGL((layernorm_bwd_kernel<V>), dim3(parts), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma, dx, dx_drop, part_dgamma, part_dbeta, part_dsum, (long long)rows, d, dy_, db_, amax, plane_out(planes, ld2, hdr, scale_in), part_pos)
+#define LNB(V) hipLaunchKernelGGL((layernorm_bwd_kernel<V>), dim3(parts), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma, dx, dx_drop, part_dgamma, part_dbeta, part_dsum, (long long)rows, d, dy_, db_, amax, plane_out(planes, ld2, hdr, scale_in), part_pos, dy_col)
     if (d <= 256) LNB(1); else if (d <= 512) LNB(2); else if (d <= 768) LNB(3); else if (d <= 1024) LNB(4); else LNB(8);
 #undef LNB
     LAUNCH_CHECK();
@@ -836,6 +837,15 @@ int segmm_layernorm_bwd(const float* dy, const float* x, const float* mean, cons
                         float* amax, uint16_t* planes, int ld2, float* hdr, const float* scale_in, segmm_stream_t stream) {
     return ln_bwd_launch(dy, x, mean, rstd, gamma, dx, dx_drop, part_dgamma, part_dbeta, part_dsum, rows, d, drop_y_p, drop_y_site, drop_b_p,
                          drop_b_site, seed, amax, planes, ld2, hdr, scale_in, nullptr, segmm_layernorm_bwd_parts(rows), stream);
+}
+
+int segmm_layernorm_bwd_outer(const float* dy_row, const float* dy_col, const float* x, const float* mean, const float* rstd, const float* gamma,
+                              float* dx, float* dx_drop, float* part_dgamma, float* part_dbeta, float* part_dsum, int64_t rows,
+                              int d, float drop_y_p, uint32_t drop_y_site, float drop_b_p, uint32_t drop_b_site, uint64_t seed,
+                              float* amax, uint16_t* planes, int ld2, float* hdr, const float* scale_in, segmm_stream_t stream) {
+    SEGMM_REQUIRE(dy_row && dy_col, "layernorm_bwd_outer: null pointer");
+    return ln_bwd_launch(dy_row, x, mean, rstd, gamma, dx, dx_drop, part_dgamma, part_dbeta, part_dsum, rows, d, drop_y_p, drop_y_site, drop_b_p,
+                         drop_b_site, seed, amax, planes, ld2, hdr, scale_in, nullptr, segmm_layernorm_bwd_parts(rows), stream, dy_col);
 }
 
 // workgroups (4 waves each) of the per-position form: the wave stride 4 * parts must be a multiple of the sequence length

@@ -141,7 +141,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                      const float* __restrict__ gamma, float* __restrict__ dx,
                                      float* __restrict__ dx_drop, float* __restrict__ part_dgamma,
                                      float* __restrict__ part_dbeta, float* __restrict__ part_dsum, long long rows, int d,
-                                     DropCfg drop_y, DropCfg drop_branch, float* amax, PlaneOut po, float* __restrict__ part_pos = nullptr) {
+                                     DropCfg drop_y, DropCfg drop_branch, float* amax, PlaneOut po, float* __restrict__ part_pos = nullptr,
+                                     const float* __restrict__ dy_col = nullptr) {
+    // dy_col != null: the incoming gradient is an OUTER PRODUCT dy[row, c] = dy[row] * dy_col[c] (``dy`` then holds one value per
+    // row) -- the gradient the Linear(d, 1) interest head sends into the last LayerNorm (d logits[row] * w[c],
+    // decoder_leave_focal.py:451,596): formed here instead of being written out by one kernel and read back by this one.
     drop_y = drop_live(drop_y); drop_branch = drop_live(drop_branch);
     __shared__ f32x4 red[4][64];
     const float ps = plane_scale(po);
@@ -167,7 +171,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
             const int c = lane * 4 + i * 256;
             g[i] = f32x4{0.f, 0.f, 0.f, 0.f}; xh[i] = g[i];
             if (c < d) {
-                f32x4 t = *(const f32x4*)(dy + row * d + c);
+                f32x4 t = dy_col ? *(const f32x4*)(dy_col + c) * dy[row] : *(const f32x4*)(dy + row * d + c);
                 if (drop_y.p > 0.f) t = drop_apply4(drop_y, ((uint64_t)row * d + c) >> 2, t);
                 xh[i] = (*(const f32x4*)(x + row * d + c) - mu) * rs;
                 ab[i] += t;

@@ -299,8 +299,11 @@ class MultiScaleTemporalDetrLeaveFocal(nn.Module):
         st = self._store
         fh = self.fusion_heads
 
-        def lin_bwd(wname, bname, x, dx, w_off=0, acc_w=False):
-            H.rowscale_bcast(dl, st.p(wname), dx, d, M, d, w_off=w_off)
+        def lin_bwd(wname, bname, x, dx, w_off=0, acc_w=False, lazy=False):
+            if lazy:          # dx stays unwritten: the backbone's first LayerNorm backward forms dl[row] * w[c] itself (engine.BackboneRun.backward)
+                st._lazy_dy = (dx.data_ptr(), dl, st.p(wname).view(-1)[w_off:w_off + d])
+            else:
+                H.rowscale_bcast(dl, st.p(wname), dx, d, M, d, w_off=w_off)
             # the head's own weight / bias gradients feed nothing in the backward: on the side stream, off the chain
             # loss -> d(features) -> LayerNorm backward -> first input-gradient GEMM that the main stream is waiting on
             with (E.side_work(st) if st.head_side else contextlib.nullcontext()):
@@ -313,7 +316,9 @@ class MultiScaleTemporalDetrLeaveFocal(nn.Module):
                     H.vecsum(dl, M, st.g(bname, gbuf))
 
         if v2 is None:
-            lin_bwd("stage_mlp1.weight", "stage_mlp1.bias", v1, dv1)
+            # (only on the trainer's own step: there dv1 goes straight from this Function to BackboneFn.backward, no hook, no
+            # accumulation, no other consumer can look at it in between)
+            lin_bwd("stage_mlp1.weight", "stage_mlp1.bias", v1, dv1, lazy=bool(st.lazy_head_grad and st.direct_grads and gbuf is None))
         elif fh in (-2, -3):
             lin_bwd("stage_mlp1.weight", "stage_mlp1.bias", v1, dv1)
             lin_bwd("stage_mlp1.weight", None, v2, dv2, acc_w=True)

@@ -159,6 +159,7 @@ class ParamStore:
         # config 3 (20 segments: short attention launches, K = 512 GEMMs) 185.4 -> 181.8 k/s.  "auto" (default): on for
         # segment axes > 32 on the plane engine (BackboneRun.backward); SEGMM_DEFER_WGRAD / SEGMM_LN_SIDE = 0 / 1 force them.
         self.ln_pos = os.environ.get("SEGMM_LN_POS", "1") != "0"          # embedding LayerNorm backward leaves per-position sums (_ln_bwd)
+        self.lazy_head_grad = os.environ.get("SEGMM_LAZY_HEAD_GRAD", "1") != "0"          # head gradient formed inside the first LayerNorm backward
         self._defer_wgrad_env = os.environ.get("SEGMM_DEFER_WGRAD", "auto")
         self._ln_side_env = os.environ.get("SEGMM_LN_SIDE", "auto")
         self.defer_wgrad = self._defer_wgrad_env not in ("0", "auto")
@@ -899,7 +900,7 @@ def _colsum(store, X, ld, M, N, out, x_off=0, w=None, accumulate=False):
 
 
 def _ln_bwd(store, dy, x, mean, rstd, gname, bname, gbuf, dx, dx_drop, rows, d, drop_y=(0.0, 0), drop_b=(0.0, 0), seed=0,
-            amax=None, dsum_to=None, po=None, pos_period=0):
+            amax=None, dsum_to=None, po=None, pos_period=0, dy_outer=None):
     """LayerNorm backward + its affine gradients.  ``dsum_to``: gradient tensor that receives the column sums of the
     forwarded gradient (dx_drop, or dx): the bias gradient of the Linear feeding this LayerNorm's residual branch,
     accumulated inside the same kernel instead of by a second pass over [rows, d].
@@ -920,8 +921,12 @@ def _ln_bwd(store, dy, x, mean, rstd, gname, bname, gbuf, dx, dx_drop, rows, d, 
         H.layernorm_bwd_pos(dy, x, mean, rstd, store.p(gname), dx, dx_drop, pg, pb, pp, pos_period, drop_y_p=drop_y[0], drop_y_site=drop_y[1],
                             drop_b_p=drop_b[0], drop_b_site=drop_b[1], seed=seed, amax=amax, part_dsum=ps, po=po)
     else:
-        H.layernorm_bwd(dy, x, mean, rstd, store.p(gname), dx, dx_drop, pg, pb, drop_y_p=drop_y[0], drop_y_site=drop_y[1],
-                        drop_b_p=drop_b[0], drop_b_site=drop_b[1], seed=seed, amax=amax, part_dsum=ps, po=po)
+        if dy_outer is not None:          # dy[row, c] = dl[row] * w[c] (the interest head's gradient), formed inside the launch
+            H.layernorm_bwd_outer(dy_outer[0], dy_outer[1], x, mean, rstd, store.p(gname), dx, dx_drop, pg, pb, drop_y_p=drop_y[0],
+                                  drop_y_site=drop_y[1], drop_b_p=drop_b[0], drop_b_site=drop_b[1], seed=seed, amax=amax, part_dsum=ps, po=po)
+        else:
+            H.layernorm_bwd(dy, x, mean, rstd, store.p(gname), dx, dx_drop, pg, pb, drop_y_p=drop_y[0], drop_y_site=drop_y[1],
+                            drop_b_p=drop_b[0], drop_b_site=drop_b[1], seed=seed, amax=amax, part_dsum=ps, po=po)
     outs = [store.g(gname, gbuf), store.g(bname, gbuf)] + ([dsum_to] if ps is not None else [])
     with (side_work(store) if store.ln_side else contextlib.nullcontext()):
         ws = store.buf("colsum3_ws_side" if store._on_side else "colsum3_ws", (3 * H.colsum_chunks(parts) * d,))
@@ -1285,8 +1290,12 @@ class BackboneRun:
         st, d = self.store, self.d
         has_drop = drop_b[0] > 0
         a = new_act(st, self.amb, M, d, t=None if has_drop else dx, key=key, site=self.pre + key, delayed=self.delayed)
+        lazy = self.__dict__.get("_lazy_dy")          # (backward(): the head left its gradient as an outer product, unmaterialised)
+        outer = None
+        if lazy is not None and dy.data_ptr() == lazy[0]:
+            outer, self._lazy_dy = (lazy[1], lazy[2]), None
         _ln_bwd(st, dy, x, mean, rstd, gname, bname, gbuf, dx, a.t if has_drop else None, M, d, drop_b=drop_b, seed=self.seed,
-                amax=a.slots, dsum_to=dsum_to, po=a.po)
+                amax=a.slots, dsum_to=dsum_to, po=a.po, dy_outer=outer)
         return finish_act(st, produced(a))
 
     def _side_post_bwd(self, i, L, side, sv, dX2, M, kinds, gbuf, tag, deferred=None):
@@ -1442,6 +1451,17 @@ class BackboneRun:
         B, S, Lt, Mv, Mu = self.B, self.S, self.Lt, self.Mv, self.Mu
         dXv = d_vid_out.contiguous().view(-1, d)
         dXu = None
+        # The interest head (Linear(d, 1), single backbone, trainer's direct gradient delivery) hands over d_vid UNWRITTEN, with
+        # (address, d logits per row, head weight) on the store: the first consumer -- the last layer's LayerNorm backward --
+        # forms dl[row] * w[c] itself (segmm_layernorm_bwd_outer: one launch and a 63 MB round trip less on the critical chain
+        # loss -> first input-gradient GEMM).  Any other first consumer gets it written out first.
+        lazy = st.__dict__.pop("_lazy_dy", None)
+        self._lazy_dy = None
+        if lazy is not None and lazy[0] == dXv.data_ptr():
+            if self.abl in MLP_VARIANTS or max(self.N - 1, 0) == 0:
+                H.rowscale_bcast(lazy[1], lazy[2], dXv, d, dXv.shape[0], d)
+            else:
+                self._lazy_dy = lazy
         if st._defer_wgrad_env == "auto":          # (plane engine only: on the exact-fp32 engine the deferral costs 1.5 %)
             st.defer_wgrad = S > 32 and st.engine_p
         if st._ln_side_env == "auto":

@@ -15,7 +15,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SEGMM_LIB") or os.path.join(_HERE, "libsegmm_hip.so")      # SEGMM_LIB: A/B builds of the kernels
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 _lib = None
 
@@ -50,6 +50,7 @@ SIGNATURES = {
     "segmm_layernorm_fwd": [_p, _p, _p, _p, _p, _p, _i64, _i, _f, _f, _u64, _u32, _p, _p, _i, _p, _p, _p],
     "segmm_layernorm_bwd_parts": [_i64],
     "segmm_layernorm_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _f, _u32, _f, _u32, _u64, _p, _p, _i, _p, _p, _p],
+    "segmm_layernorm_bwd_outer": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _f, _u32, _f, _u32, _u64, _p, _p, _i, _p, _p, _p],
     "segmm_layernorm_bwd_pos_parts": [_i64, _i],
     "segmm_layernorm_bwd_pos": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _f, _u32, _f, _u32, _u64, _p, _p, _i, _p, _p, _p, _i, _p],
     "segmm_colsum_pos": [_p, _i, _i, _i, _p, _p],
@@ -664,6 +665,17 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dx_drop, part_dgamma, part_dbeta
                                      _ptr(part_dgamma), _ptr(part_dbeta), _ptr(part_dsum), x.numel() // d, d, float(drop_y_p),
                                      int(drop_y_site), float(drop_b_p), int(drop_b_site), int(seed), _ptr(amax), *_po(po), _stream()),
            "segmm_layernorm_bwd")
+
+
+def layernorm_bwd_outer(dy_row, dy_col, x, mean, rstd, gamma, dx, dx_drop, part_dgamma, part_dbeta, drop_y_p=0.0, drop_y_site=0,
+                        drop_b_p=0.0, drop_b_site=0, seed=0, amax=None, part_dsum=None, po=None):
+    """layernorm_bwd with the incoming gradient dy[row, c] = dy_row[row] * dy_col[c] formed inside the launch."""
+    _dev(dy_row, x, dx)
+    d = x.shape[-1]
+    _check(lib().segmm_layernorm_bwd_outer(_ptr(dy_row), _ptr(dy_col), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(dx), _ptr(dx_drop),
+                                           _ptr(part_dgamma), _ptr(part_dbeta), _ptr(part_dsum), x.numel() // d, d, float(drop_y_p),
+                                           int(drop_y_site), float(drop_b_p), int(drop_b_site), int(seed), _ptr(amax), *_po(po), _stream()),
+           "segmm_layernorm_bwd_outer")
 
 
 def layernorm_bwd_pos_parts(rows, period):
