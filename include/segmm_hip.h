@@ -148,6 +148,12 @@ int segmm_split3_transpose(const float* x, int R, int C, int ld, uint16_t* plane
 int segmm_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                         int64_t rows, int d, float eps, float drop_p, uint64_t seed, uint32_t site, float* amax,
                         uint16_t* planes, int ld2, float* hdr, const float* scale_in, segmm_stream_t stream);
+/* segmm_layernorm_fwd that also returns dot_out[row] = y[row, :] . dot_w (+ dot_b[0]): the Linear(d, 1) interest head
+ * (decoder_leave_focal.py:451,596) applied to the backbone's last LayerNorm output without a second pass over it. */
+int segmm_layernorm_fwd_dot(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                            int64_t rows, int d, float eps, float drop_p, uint64_t seed, uint32_t site, float* amax,
+                            uint16_t* planes, int ld2, float* hdr, const float* scale_in, const float* dot_w, const float* dot_b,
+                            float* dot_out, segmm_stream_t stream);
 int segmm_layernorm_bwd_parts(int64_t rows);
 int segmm_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                         float* dx, float* dx_drop, float* part_dgamma, float* part_dbeta, float* part_dsum, int64_t rows,

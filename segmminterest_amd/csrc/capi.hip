@@ -366,7 +366,7 @@ __global__ void step_get_kernel(StepState* out) { *out = g_step; }
 extern "C" {
 
 const char* segmm_last_error(void) { return g_segmm_err; }
-int segmm_abi_version(void) { return 24; }
+int segmm_abi_version(void) { return 25; }
 int segmm_attn_mode(int mode) { const int prev = attn_f16(); if (mode >= 0 && mode <= 2) g_attn_mode = mode; return prev; }
 
 static PlaneOut plane_out(uint16_t* planes, int ld2, float* hdr, const float* scale_in) {
@@ -790,21 +790,37 @@ int segmm_split3_transpose(const float* x, int R, int Cc, int ld, uint16_t* plan
     return 0;
 }
 
-int segmm_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
-                        int64_t rows, int d, float eps, float drop_p, uint64_t seed, uint32_t site, float* amax,
-                        uint16_t* planes, int ld2, float* hdr, const float* scale_in, segmm_stream_t stream) {
+static int ln_fwd_launch(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                         int64_t rows, int d, float eps, float drop_p, uint64_t seed, uint32_t site, float* amax,
+                         uint16_t* planes, int ld2, float* hdr, const float* scale_in, const float* dot_w, const float* dot_b, float* dot_out,
+                         segmm_stream_t stream) {
     SEGMM_REQUIRE(x && gamma && beta && y && mean && rstd, "layernorm_fwd: null pointer");
+    SEGMM_REQUIRE(!dot_w || (dot_out && aligned16(dot_w)), "layernorm_fwd_dot: head weight / output");
     PLANE_OUT_CHECK("layernorm_fwd", d);
     SEGMM_REQUIRE(d > 0 && d % 4 == 0 && d <= 256 * ROW_MAXV, "layernorm_fwd: d=%d unsupported", d);
     SEGMM_REQUIRE(aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta), "layernorm_fwd: alignment");
     if (rows <= 0) return 0;
     const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
     const DropCfg dc = make_drop(drop_p, seed, site);
-#define LNF(V) hipLaunchKernelGGL((layernorm_fwd_kernel<V>), grid, block, 0, (hipStream_t)stream, x, gamma, beta, y, mean, rstd, (long long)rows, d, eps, dc, amax, plane_out(planes, ld2, hdr, scale_in))
+#define LNF(V) hipLaunchKernelGGL((layernorm_fwd_kernel<V>), grid, block, 0, (hipStream_t)stream, x, gamma, beta, y, mean, rstd, (long long)rows, d, eps, dc, amax, plane_out(planes, ld2, hdr, scale_in), dot_w, dot_b, dot_out)
     if (d <= 256) LNF(1); else if (d <= 512) LNF(2); else if (d <= 768) LNF(3); else if (d <= 1024) LNF(4); else LNF(8);
 #undef LNF
     LAUNCH_CHECK();
     return 0;
+}
+
+int segmm_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                        int64_t rows, int d, float eps, float drop_p, uint64_t seed, uint32_t site, float* amax,
+                        uint16_t* planes, int ld2, float* hdr, const float* scale_in, segmm_stream_t stream) {
+    return ln_fwd_launch(x, gamma, beta, y, mean, rstd, rows, d, eps, drop_p, seed, site, amax, planes, ld2, hdr, scale_in, nullptr, nullptr, nullptr, stream);
+}
+
+int segmm_layernorm_fwd_dot(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                            int64_t rows, int d, float eps, float drop_p, uint64_t seed, uint32_t site, float* amax,
+                            uint16_t* planes, int ld2, float* hdr, const float* scale_in, const float* dot_w, const float* dot_b,
+                            float* dot_out, segmm_stream_t stream) {
+    SEGMM_REQUIRE(dot_w && dot_out, "layernorm_fwd_dot: null pointer");
+    return ln_fwd_launch(x, gamma, beta, y, mean, rstd, rows, d, eps, drop_p, seed, site, amax, planes, ld2, hdr, scale_in, dot_w, dot_b, dot_out, stream);
 }
 
 int segmm_layernorm_bwd_parts(int64_t rows) {

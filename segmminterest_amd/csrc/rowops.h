@@ -87,7 +87,12 @@ __global__ __launch_bounds__(256) void l1norm_reg_kernel(const float* __restrict
 template <int V>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                      const float* __restrict__ beta, float* __restrict__ y, float* mean_out,
-                                     float* rstd_out, long long rows, int d, float eps, DropCfg drop, float* amax, PlaneOut po) {
+                                     float* rstd_out, long long rows, int d, float eps, DropCfg drop, float* amax, PlaneOut po,
+                                     const float* __restrict__ dot_w = nullptr, const float* __restrict__ dot_b = nullptr,
+                                     float* __restrict__ dot_out = nullptr) {
+    // dot_w != null: also dot_out[row] = y[row, :] . dot_w (+ dot_b[0]) -- the Linear(d, 1) interest head on the backbone's last
+    // LayerNorm (decoder_leave_focal.py:451,596), taken from the registers that hold y instead of by a pass over y (rowdot_kernel's
+    // per-lane order and wave reduction)
     drop = drop_live(drop);
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -114,7 +119,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     }
     const float rstd = rsqrtf(wave_sum(q) / d + eps);
     if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
-    float am = 0.f;
+    float am = 0.f, dsum = 0.f;
 #pragma unroll
     for (int i = 0; i < V; ++i) {
         const int c = lane * 4 + i * 256;
@@ -124,7 +129,15 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
             *(f32x4*)(y + row * d + c) = o;
             if (ps > 0.f) plane_store4_pair(po.p, po.ld2, row, c, o, ps);
             am = absmax4(am, o);
+            if (dot_w) {
+                const f32x4 b = *(const f32x4*)(dot_w + c);
+                dsum += o.x * b.x + o.y * b.y + o.z * b.z + o.w * b.w;
+            }
         }
+    }
+    if (dot_w) {
+        dsum = wave_sum(dsum);
+        if (lane == 0) dot_out[row] = dot_b ? dsum + dot_b[0] : dsum;
     }
     plane_finish(po, amax, am, (unsigned)row, ps, row == 0 && lane == 0);
 }

@@ -80,8 +80,13 @@ class HeadLossFn(torch.autograd.Function):
         M = B * S
         v1c = v1.contiguous()
         v2c = v2.contiguous() if v2 is not None else None
-        raw = torch.empty(M, dtype=torch.float32, device=v1.device)
-        T = model._head_fwd(v1c, v2c, raw, M, d)
+        pre = model.__dict__.pop("_raw_pre", None)          # (model.forward: logits buffer handed to the backbone's last LayerNorm)
+        if pre is not None and v2 is None and pre.numel() == M and st.__dict__.get("_head_dot_done") == pre.data_ptr():
+            raw, T = pre, None          # the Linear(d, 1) head ran inside that launch (segmm_layernorm_fwd_dot)
+        else:
+            raw = torch.empty(M, dtype=torch.float32, device=v1.device)
+            T = model._head_fwd(v1c, v2c, raw, M, d)
+        st._head_dot_done = None
         ctx.model, ctx.dims, ctx.T = model, (B, S, d), T
         ctx.has_v2 = v2 is not None
         ctx.set_materialize_grads(False)          # no zero tensors for the two non-differentiable outputs (two fill launches)
@@ -386,6 +391,13 @@ class MultiScaleTemporalDetrLeaveFocal(nn.Module):
                 self._loss_spec = LossSpec(self.model_cfg)
             gtc = gt.contiguous().to(torch.int64)
             self._stats = pre if pre is not None else self._label_stats(gtc, gtc.shape[0], gtc.shape[1])
+        self.__dict__.pop("_raw_pre", None)
+        st.__dict__.pop("_head_dot", None)
+        if (st.head_dot and self.backbone2 is None and vid_mask is not None and getattr(self.backbone1, "ablation_type", "ours") not in E.MLP_VARIANTS
+                and self.backbone1.n_layers >= 2):
+            # single backbone, Linear(d, 1) head: its logits come out of the backbone's last LayerNorm launch (engine._side_post)
+            self._raw_pre = torch.empty(vid_mask.shape[0] * vid_mask.shape[1], dtype=torch.float32, device=st.flat.device)
+            st._head_dot = (st.p("stage_mlp1.weight"), st.p("stage_mlp1.bias"), self._raw_pre)
         v1 = run(self.backbone1, "backbone1.", 0, 1)
         v2 = run(self.backbone2, "backbone2.", 1, 2) if self.backbone2 is not None else None
         hp = [st._params[n] for n in self._head_param_names()]

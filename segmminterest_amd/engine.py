@@ -160,6 +160,7 @@ class ParamStore:
         # segment axes > 32 on the plane engine (BackboneRun.backward); SEGMM_DEFER_WGRAD / SEGMM_LN_SIDE = 0 / 1 force them.
         self.ln_pos = os.environ.get("SEGMM_LN_POS", "1") != "0"          # embedding LayerNorm backward leaves per-position sums (_ln_bwd)
         self.lazy_head_grad = os.environ.get("SEGMM_LAZY_HEAD_GRAD", "1") != "0"          # head gradient formed inside the first LayerNorm backward
+        self.head_dot = os.environ.get("SEGMM_HEAD_DOT", "1") != "0"          # ... and the head's logits inside the last LayerNorm forward
         self._defer_wgrad_env = os.environ.get("SEGMM_DEFER_WGRAD", "auto")
         self._ln_side_env = os.environ.get("SEGMM_LN_SIDE", "auto")
         self.defer_wgrad = self._defer_wgrad_env not in ("0", "auto")
@@ -1019,6 +1020,10 @@ class BackboneRun:
         p_drop = float(bb.dropout_p) if train else 0.0
         p_inner = MLP_INNER_DROPOUT if train else 0.0
         self.p_drop, self.p_inner, self.seed = p_drop, p_inner, seed
+        # (head weight, head bias, logits buffer) left by the model for a single-backbone Linear(d, 1) head: the output LayerNorm
+        # of the last live layer then computes the raw logits too (_side_post); st._head_dot_done tells the head
+        self._head_dot = st.__dict__.pop("_head_dot", None)
+        st._head_dot_done = None
         # producer-written planes with delayed scales in training passes; exact split passes otherwise (evaluation stays
         # bitwise reproducible and independent of what ran before)
         self.delayed = st.engine_p and ((train and st.scaling != "exact") or st.scaling == "always")
@@ -1181,7 +1186,7 @@ class BackboneRun:
                     Hh=new_act(st, am, M, d, site=sn + "H", delayed=self.delayed), R2=_empty(ref, M, d), m2=_empty(ref, M), r2=_empty(ref, M),
                     X2=new_act(st, am, M, d, planes=out_is_operand, site=sn + "X2", delayed=self.delayed))
 
-    def _side_post(self, i, L, side, X, A, M, kinds, out_is_operand, bufs=None):
+    def _side_post(self, i, L, side, X, A, M, kinds, out_is_operand, bufs=None, head_dot=None):
         """R1 = X + drop(A.Wff^T+b); X1 = LN(R1); H = drop(gelu(X1.W0^T+b0)); R2 = X1 + drop(H.W1^T+b1); X2 = LN(R2).
         X, A: Acts; returns (X2 Act, saved)."""
         st, d, seed = self.store, self.d, self.seed
@@ -1199,7 +1204,12 @@ class BackboneRun:
         finish_act(st, Hh)
         _lin_fwd(st, M, d, d, Hh, ff + "1.weight", R2, d, bias=st.p(ff + "1.bias"),
                  residual=X1.t, ldr=d, res_period=M, drop_p=self.p_drop, seed=seed, site=_site(self.bi, i, k_mo))
-        H.layernorm_fwd(R2, st.p(L + "ln_%s.weight" % side), st.p(L + "ln_%s.bias" % side), X2.t, m2, r2, amax=X2.slots, po=X2.po)
+        if head_dot is not None:          # the backbone's output LayerNorm: the Linear(d, 1) head's logits from the same launch
+            H.layernorm_fwd_dot(R2, st.p(L + "ln_%s.weight" % side), st.p(L + "ln_%s.bias" % side), X2.t, m2, r2, head_dot[0], head_dot[1],
+                                head_dot[2], amax=X2.slots, po=X2.po)
+            st._head_dot_done = head_dot[2].data_ptr()
+        else:
+            H.layernorm_fwd(R2, st.p(L + "ln_%s.weight" % side), st.p(L + "ln_%s.bias" % side), X2.t, m2, r2, amax=X2.slots, po=X2.po)
         finish_act(st, produced(X2))
         return X2, dict(A=A, R1=R1, X1=X1, m1=m1, r1=r1, G=G, Hh=Hh, R2=R2, m2=m2, r2=r2)
 
@@ -1272,7 +1282,8 @@ class BackboneRun:
                    vq["ldkb"], self.vm, self.vm, self.um, Av.t, d, lse_v, drop_p=self.p_drop, seed=self.seed,
                    site=_site(self.bi, i, K_ATT_V), amax_o=Av.slots, po=Av.po)
         finish_act(st, produced(Av))
-        X2v, sv_v = self._side_post(i, L, "vid", Xv, Av, Mv, (K_AO_V, K_MI_V, K_MO_V), out_is_operand=i < self.N - 2)
+        hd = self.__dict__.get("_head_dot") if i == self.N - 2 else None          # last live layer: its video-side output IS the backbone's
+        X2v, sv_v = self._side_post(i, L, "vid", Xv, Av, Mv, (K_AO_V, K_MI_V, K_MO_V), out_is_operand=i < self.N - 2, head_dot=hd)
         rec["v"] = sv_v
         if full:
             if usr_ctx:

@@ -15,7 +15,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SEGMM_LIB") or os.path.join(_HERE, "libsegmm_hip.so")      # SEGMM_LIB: A/B builds of the kernels
-ABI_VERSION = 24
+ABI_VERSION = 25
 
 _lib = None
 
@@ -48,6 +48,7 @@ SIGNATURES = {
     "segmm_split3": [_p, _p, _i64, _i64, _p],
     "segmm_split3_transpose": [_p, _i, _i, _i, _p, _i64, _p],
     "segmm_layernorm_fwd": [_p, _p, _p, _p, _p, _p, _i64, _i, _f, _f, _u64, _u32, _p, _p, _i, _p, _p, _p],
+    "segmm_layernorm_fwd_dot": [_p, _p, _p, _p, _p, _p, _i64, _i, _f, _f, _u64, _u32, _p, _p, _i, _p, _p, _p, _p, _p, _p],
     "segmm_layernorm_bwd_parts": [_i64],
     "segmm_layernorm_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _f, _u32, _f, _u32, _u64, _p, _p, _i, _p, _p, _p],
     "segmm_layernorm_bwd_outer": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _f, _u32, _f, _u32, _u64, _p, _p, _i, _p, _p, _p],
@@ -651,6 +652,16 @@ def layernorm_fwd(x, gamma, beta, y, mean, rstd, eps=1e-12, drop_p=0.0, seed=0, 
     _check(lib().segmm_layernorm_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd),
                                      x.numel() // d, d, eps, float(drop_p), int(seed), int(site), _ptr(amax), *_po(po), _stream()),
            "segmm_layernorm_fwd")
+
+
+def layernorm_fwd_dot(x, gamma, beta, y, mean, rstd, dot_w, dot_b, dot_out, eps=1e-12, drop_p=0.0, seed=0, site=0, amax=None, po=None):
+    """layernorm_fwd that also leaves dot_out[row] = y[row, :] . dot_w (+ dot_b[0])."""
+    _dev(x, y)
+    d = x.shape[-1]
+    _check(lib().segmm_layernorm_fwd_dot(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd),
+                                         x.numel() // d, d, eps, float(drop_p), int(seed), int(site), _ptr(amax), *_po(po),
+                                         _ptr(dot_w), _ptr(dot_b), _ptr(dot_out), _stream()),
+           "segmm_layernorm_fwd_dot")
 
 
 def layernorm_bwd_parts(rows):

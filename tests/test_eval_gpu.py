@@ -611,8 +611,9 @@ def test_step_schedule_knobs_do_not_change_the_step(device_state):
     B, S, Lt, D, N, h = 12, 40, 20, 64, 3, 4
     margs = default_args(num_layers_enc=N, d_model=D, nhead=h, input_type={"user": "image", "photo": "image"}, exposure_prob=[1.0] * S)
     batches = [{k: v.to(dev) for k, v in make_batch(B, S, Lt, D, seed=700 + i).items()} for i in range(3)]
-    knobs = ("SEGMM_BEGIN_OVERLAP", "SEGMM_DEFER_WGRAD", "SEGMM_LN_SIDE", "SEGMM_LAZY_HEAD_GRAD")          # (the last: the head's gradient
-    # formed inside the first LayerNorm backward instead of written out -- same products)
+    knobs = ("SEGMM_BEGIN_OVERLAP", "SEGMM_DEFER_WGRAD", "SEGMM_LN_SIDE", "SEGMM_LAZY_HEAD_GRAD", "SEGMM_HEAD_DOT")          # (the last two: the
+    # head's gradient formed inside the first LayerNorm backward instead of written out, its logits inside the last LayerNorm forward
+    # instead of by a pass over the output -- same products, same summation order)
 
     def run(on):
         for k in knobs:
@@ -621,7 +622,7 @@ def test_step_schedule_knobs_do_not_change_the_step(device_state):
             torch.manual_seed(21)
             model = init_model(margs, input_dim=D, max_vid_len=S, max_usr_len=Lt).to(dev)
             tr = Trainer(model, device_state=device_state)
-            assert tr.begin_overlap == on and model._store.defer_wgrad == on and model._store.ln_side == on and model._store.lazy_head_grad == on
+            assert tr.begin_overlap == on and model._store.defer_wgrad == on and model._store.ln_side == on and model._store.lazy_head_grad == on and model._store.head_dot == on
             if device_state:
                 tr.record(batches[0], warmup=2)
             else:
