@@ -139,6 +139,7 @@ class HeadLossFn(torch.autograd.Function):
         if g_total is None:          # the loss took no part in the differentiated scalar
             return (None,) * (5 + len(names))
         H.mark(H.PHASE_HEAD_LOSS_BWD)
+        st.__dict__.pop("_lazy_dy", None)          # (a marker no backbone backward consumed -- frozen backbone -- must not meet a later tensor at the same address)
         gbuf = E._pick_gbuf(st, names)
         unit = getattr(model, "_unit_grad", None)
         # the trainer's constant-one seed (Trainer.train_step) also selects the direct gradient delivery for the whole backward
