@@ -39,6 +39,17 @@
 
 namespace segmm {
 
+// Input planes of the planes-in forward (attention_pl.h): the P32 fp16 planes of the Q / K / V column slices, as their producer
+// GEMMs wrote them, with the site headers that say whether they are usable.  K and V of a key block are views of one buffer.
+struct AttnInPlanes {
+    const _Float16 *Qa, *Qb; int ldq2;      // same column slices as AttnArgs::Qa / Qb (null: no input planes)
+    const _Float16 *baseA, *baseB;          // lowest plane address of key block a's / b's K and V views
+    uint32_t offKa, offVa, offKb, offVb;    // byte offsets of the four views from their base
+    uint32_t bytesA, bytesB;                // extents from the base (buffer range check)
+    int ldka2, ldkb2;
+    const float *hdr_q, *hdr_ka, *hdr_kb;   // site headers: hdr[0] scale, hdr[1] overflow flag, partial maxima
+};
+
 struct AttnArgs {
     int B, H, Lq, La, Lb;
     const float *Qa, *Qb; int ldq;      // [B*Lq, ldq], head h at column h*DH
@@ -79,6 +90,7 @@ struct AttnArgs {
     // flag up, or the maximum below the window), in which case it recomputes its tile and rewrites that site's planes with the
     // exact scale of the recorded maxima (headers untouched; segmm_site_fixup then records the scale)
     int pflags;
+    AttnInPlanes in;
 };
 constexpr int ATT_PLANES_ONLY = 1, ATT_REPAIR = 2;
 

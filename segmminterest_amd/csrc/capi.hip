@@ -7,6 +7,7 @@
 
 #include "../../include/segmm_hip.h"
 #include "attention16.h"
+#include "attention_pl.h"
 #include "common.h"
 #include "evalops.h"
 #include "gemm.h"
@@ -105,8 +106,51 @@ static void attn_shape(int n, int H, int max_waves, int want_default, const char
         if (H % c == 0 && c * wq <= max_waves) { hpb = c; break; }
 }
 
+// round 5: the planes-in forward (attention_pl.h) when the caller hands the Q / K / V planes of the projection GEMMs and the
+// shape qualifies.  SEGMM_ATT_FWD_PL=0 keeps the fp32-operand kernels (A/B, tests).
+template <int DH>
+static bool attn_fwd_pl_takes(const AttnArgs& a) {
+    if constexpr (DH % 16 != 0) return false;
+    else {
+        const char* e = getenv("SEGMM_ATT_FWD_PL");          // read per call: the tests switch forms inside one process
+        if (e && atoi(e) == 0) return false;
+        const int nqt = (a.Lq + 15) / 16, T = a.La + a.Lb;
+        return a.in.Qa && a.La % 4 == 0 && a.Lb % 4 == 0 && nqt <= ATT_PL_MAXW && T <= 16 * 12 &&
+               attn_fwd_pl_lds_bytes<DH>(a.La, a.Lb) <= 160 * 1024 && (((uintptr_t)a.mka | (uintptr_t)a.mkb) & 3u) == 0;
+    }
+}
+template <int DH>
+static int attn_launch_fwd_pl(AttnArgs& a, hipStream_t s) {
+    if constexpr (DH % 16 == 0) {
+        const int nqt = (a.Lq + 15) / 16, T = a.La + a.Lb;
+        const size_t lds = attn_fwd_pl_lds_bytes<DH>(a.La, a.Lb);
+        // instances: key-block-a length 40 with all 9 tiles present (configs 2 / 4 / 5: tile classes resolved at compile time, a
+        // branch-free body), and the run-time forms for <= 4 / 9 / 12 key tiles
+        const bool hot = DH == 48 && a.La == 40 && T > 128 && T <= 144;
+        static bool optin = false;          // dynamic LDS above 64 KB needs the opt-in, once per kernel
+        if (!optin) {
+            (void)hipFuncSetAttribute((const void*)attn_fwd_pl_kernel<DH, 4, -1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)attn_fwd_pl_kernel<DH, 9, -1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)attn_fwd_pl_kernel<DH, 12, -1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if constexpr (DH == 48) (void)hipFuncSetAttribute((const void*)attn_fwd_pl_kernel<48, 9, 40, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            optin = true;
+        }
+#ifdef SEGMM_ATT_PROBE
+        if (getenv("SEGMM_ATT_FWD_DBG")) a.pflags |= atoi(getenv("SEGMM_ATT_FWD_DBG")) & (256 | 512);          // timing probes (results wrong)
+#endif
+        const dim3 grid(a.B * a.H), block(64 * nqt);
+        if (hot) { if constexpr (DH == 48) hipLaunchKernelGGL((attn_fwd_pl_kernel<48, 9, 40, true>), grid, block, lds, s, a); }
+        else if (T <= 64) hipLaunchKernelGGL((attn_fwd_pl_kernel<DH, 4, -1, false>), grid, block, lds, s, a);
+        else if (T <= 144) hipLaunchKernelGGL((attn_fwd_pl_kernel<DH, 9, -1, false>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((attn_fwd_pl_kernel<DH, 12, -1, false>), grid, block, lds, s, a);
+        LAUNCH_CHECK();
+    }
+    return 0;
+}
+
 template <int DH>
 static int attn_launch_fwd(AttnArgs& a, hipStream_t s) {
+    if (attn_fwd_pl_takes<DH>(a)) return attn_launch_fwd_pl<DH>(a, s);
     const int Tp = ((a.La + 15) & ~15) + ((a.Lb + 15) & ~15);
     const int nqt = (a.Lq + 15) / 16;
     int wq, hpb;
@@ -366,7 +410,7 @@ __global__ void step_get_kernel(StepState* out) { *out = g_step; }
 extern "C" {
 
 const char* segmm_last_error(void) { return g_segmm_err; }
-int segmm_abi_version(void) { return 25; }
+int segmm_abi_version(void) { return 26; }
 int segmm_attn_mode(int mode) { const int prev = attn_f16(); if (mode >= 0 && mode <= 2) g_attn_mode = mode; return prev; }
 
 static PlaneOut plane_out(uint16_t* planes, int ld2, float* hdr, const float* scale_in) {
@@ -949,6 +993,30 @@ int segmm_attn_fwd(int B, int H, int dh, int Lq, int La, int Lb, const float* Qa
     if (pl && pl->o) {
         SEGMM_REQUIRE(pl->hdr_o && pl->ldo2 % 64 == 0 && aligned16(pl->o) && (H * dh) % 32 == 0, "attn_fwd: plane output needs a header, ld2 %% 64, width %% 32");
         a.po_o = plane_out(pl->o, pl->ldo2, pl->hdr_o, pl->sin_o);
+    }
+    if (pl && pl->qa_in) {          // input planes (round 5): the views of an empty key block are aliased to the other block's, like attn_fill
+        const uint16_t *ka = pl->ka_in, *va = pl->va_in, *kb = pl->kb_in, *vb = pl->vb_in;
+        const float *ha = pl->hdr_ka_in, *hb = pl->hdr_kb_in;
+        int lda2 = pl->ldka2_in, ldb2 = pl->ldkb2_in;
+        if (La == 0) { ka = kb; va = vb; ha = hb; lda2 = ldb2; }
+        if (Lb == 0) { kb = ka; vb = va; hb = ha; ldb2 = lda2; }
+        SEGMM_REQUIRE(pl->qb_in && ka && va && kb && vb && pl->hdr_q_in && ha && hb, "attn_fwd: input planes need every view and header");
+        SEGMM_REQUIRE(pl->ldq2_in % 64 == 0 && lda2 % 64 == 0 && ldb2 % 64 == 0, "attn_fwd: input plane strides %% 64");
+        SEGMM_REQUIRE(aligned16(pl->qa_in) && aligned16(pl->qb_in) && aligned16(ka) && aligned16(va) && aligned16(kb) && aligned16(vb), "attn_fwd: input plane alignment");
+        AttnInPlanes& in = a.in;
+        in.Qa = (const _Float16*)pl->qa_in; in.Qb = (const _Float16*)pl->qb_in; in.ldq2 = pl->ldq2_in;
+        in.hdr_q = pl->hdr_q_in; in.hdr_ka = ha; in.hdr_kb = hb;
+        in.ldka2 = lda2; in.ldkb2 = ldb2;
+        const uintptr_t bA = (uintptr_t)ka < (uintptr_t)va ? (uintptr_t)ka : (uintptr_t)va, bB = (uintptr_t)kb < (uintptr_t)vb ? (uintptr_t)kb : (uintptr_t)vb;
+        const size_t offKa = (uintptr_t)ka - bA, offVa = (uintptr_t)va - bA, offKb = (uintptr_t)kb - bB, offVb = (uintptr_t)vb - bB;
+        // extent of a view: last row's start + the head columns' planes (2 bytes x 2 terms per column, rounded up to a whole block)
+        const size_t extA = ((size_t)B * (La ? La : Lb) - 1) * (size_t)lda2 * 2 + (size_t)((H * dh + 31) / 32) * 128;
+        const size_t extB = ((size_t)B * (Lb ? Lb : La) - 1) * (size_t)ldb2 * 2 + (size_t)((H * dh + 31) / 32) * 128;
+        const size_t bytesA = (offKa > offVa ? offKa : offVa) + extA, bytesB = (offKb > offVb ? offKb : offVb) + extB;
+        SEGMM_REQUIRE(bytesA < (1ull << 31) && bytesB < (1ull << 31), "attn_fwd: an input plane view exceeds the 2 GiB buffer-addressing window");
+        in.baseA = (const _Float16*)bA; in.baseB = (const _Float16*)bB;
+        in.offKa = (uint32_t)offKa; in.offVa = (uint32_t)offVa; in.offKb = (uint32_t)offKb; in.offVb = (uint32_t)offVb;
+        in.bytesA = (uint32_t)bytesA; in.bytesB = (uint32_t)bytesB;
     }
     ATTN_DISPATCH(attn_launch_fwd, dh, a, (hipStream_t)stream);
 }

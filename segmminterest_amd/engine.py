@@ -166,6 +166,8 @@ class ParamStore:
         self.defer_wgrad = self._defer_wgrad_env not in ("0", "auto")
         self.tail_balance = os.environ.get("SEGMM_TAIL_BALANCE", "1") != "0"
         self.attn_planes_only = int(os.environ.get("SEGMM_ATTN_PLANES_ONLY", "1"))
+        # round 5: the attention forward reads the Q / K / V planes the fused projection GEMMs write (csrc/attention_pl.h)
+        self.attn_pl = os.environ.get("SEGMM_ATT_PL", "0") != "0"
         self.head_side = os.environ.get("SEGMM_HEAD_SIDE", "1") != "0"
         self.input_planes_only = os.environ.get("SEGMM_INPUT_PLANES_ONLY", "1") != "0"
         self.attn_two_streams = os.environ.get("SEGMM_ATTN_TWO_STREAMS", "0") == "1"
@@ -1048,7 +1050,7 @@ class BackboneRun:
         self.vm, self.um = vm, um
         sv = self.sv
         ref = vm
-        am = self.am = AmaxArena(st, 8 + 12 * max(self.N - 1, 0) + 2 * (self.n_mlp + 1))
+        am = self.am = AmaxArena(st, 8 + 14 * max(self.N - 1, 0) + 2 * (self.n_mlp + 1))
         layered = self.abl not in MLP_VARIANTS and self.N >= 2
         use_pe = bool(getattr(bb, "use_pe", 1))          # --use_pe 0: no positional-embedding add (encoder.py:450-471)
         usr_is_operand = (layered and self.mode != "self") or self.abl == "CrossMLP"      # does any GEMM read the user embedding?
@@ -1085,7 +1087,7 @@ class BackboneRun:
                 if Yu0 is not None:
                     self._usr_proj_fwd(0, Eu, Yu0)
             if fwd_side:
-                Yu0 = _empty(ref, Mu, len(layer_plan(self.mode, 0 < self.N - 2)[1]) * d)
+                Yu0 = self._proj_act(0, "Yu", Mu, len(layer_plan(self.mode, 0 < self.N - 2)[1]) * d)
                 with side_work(st):
                     usr_chain()
             else:
@@ -1230,6 +1232,19 @@ class BackboneRun:
                       Kb=g(cu, "t2t_proj.1"), Vb=g(cu, "t2t_proj.2"), ldkb=ldu, La=S, Lb=0 if mode == "cross" else Lt)
         return vq, uq
 
+    def _attn_planes_in(self):
+        """Does the attention forward of this pass read the Q / K / V planes of the fused projection GEMMs (csrc/attention_pl.h)?
+        Training passes with delayed scales on the plane engine, shapes the planes-in kernel takes (SEGMM_ATT_PL=0: never)."""
+        st = self.store
+        return bool(self.delayed and st.engine_p and st.attn_pl and self.dh % 16 == 0 and self.S % 4 == 0 and self.Lt % 4 == 0 and
+                    max(self.S, self.Lt) <= 112 and self.d % 32 == 0)
+
+    def _proj_act(self, i, which, rows, cols):
+        """The fused projection output Yv / Yu of layer i as an Act: with the planes-in attention its producer GEMM also writes the
+        P32 planes (delayed scale of the site) the attention forward stages; otherwise a plain fp32 buffer with a header."""
+        st = self.store
+        return new_act(st, self.am, rows, cols, planes=self._attn_planes_in(), site="%sL%d.%s" % (self.pre, i, which), delayed=self.delayed)
+
     def _usr_proj_fwd(self, i, Xu, Yu):
         """Yu = Xu . [fused user-token projections of layer i]^T + b."""
         st, d = self.store, self.d
@@ -1237,7 +1252,11 @@ class BackboneRun:
         usrP = layer_plan(self.mode, full)[1]
         ca = "%sencoder.layers.%d.cross_attn." % (self.pre, i)
         nu = len(usrP)
-        _lin_fwd(st, self.Mu, nu * d, d, Xu, ca + usrP[0] + ".weight", Yu, nu * d, bias=st.p(ca + usrP[0] + ".bias"))
+        # (c_act also on a site's first pass, when it has no scale yet: the GEMM then only records the maxima the scale comes from)
+        _lin_fwd(st, self.Mu, nu * d, d, Xu, ca + usrP[0] + ".weight", Yu.t, nu * d, bias=st.p(ca + usrP[0] + ".bias"),
+                 c_act=Yu if Yu.planes is not None else None)
+        if Yu.po is None:
+            Yu.planes = None          # (no calibrated scale yet / evaluation: the attention reads the fp32 views)
 
     def _layer_fwd(self, i, Xv, Xu, Yu_ready=None):
         st, d, P, am = self.store, self.d, self.pre, self.am
@@ -1247,16 +1266,29 @@ class BackboneRun:
         nv, nu = len(vidP), len(usrP)
         L = "%sencoder.layers.%d." % (P, i)
         ca = L + "cross_attn."
-        Yv = _empty(Xv.t, Mv, nv * d)
-        _lin_fwd(st, Mv, nv * d, d, Xv, ca + vidP[0] + ".weight", Yv, nv * d, bias=st.p(ca + vidP[0] + ".bias"))
-        Yu = None
+        Yv_a = self._proj_act(i, "Yv", Mv, nv * d)
+        _lin_fwd(st, Mv, nv * d, d, Xv, ca + vidP[0] + ".weight", Yv_a.t, nv * d, bias=st.p(ca + vidP[0] + ".bias"),
+                 c_act=Yv_a if Yv_a.planes is not None else None)
+        if Yv_a.po is None:
+            Yv_a.planes = None
+        Yu_a = None
         if Yu_ready is not None:      # computed on the side stream together with the user embedding (forward())
-            Yu = Yu_ready
+            Yu_a = Yu_ready
             join_side(st)
         elif nu:
-            Yu = _empty(Xv.t, Mu, nu * d)
-            self._usr_proj_fwd(i, Xu, Yu)
+            Yu_a = self._proj_act(i, "Yu", Mu, nu * d)
+            self._usr_proj_fwd(i, Xu, Yu_a)
+        Yv, Yu = Yv_a.t, (Yu_a.t if Yu_a is not None else None)
         vq, uq = self._attn_views(full, Yv, Yu, nv, nu)
+        # input planes of the attention forward: the producer GEMMs wrote them (delayed scales); the kernel judges the site headers
+        # itself and stages an unusable site from the fp32 views
+        pl_v = (Yv_a.planes, Yv_a.hdr, 2 * nv * d) if Yv_a.po is not None else None
+        pl_u = (Yu_a.planes, Yu_a.hdr, 2 * nu * d) if (Yu_a is not None and Yu_a.po is not None) else None
+        pin_v = pin_u = None
+        if pl_v is not None and (pl_u is not None or vq["Lb"] == 0):
+            pin_v = dict(q=pl_v, a=pl_v if vq["La"] else None, b=pl_u if vq["Lb"] else None)
+        if full and pl_v is not None and pl_u is not None:
+            pin_u = dict(q=pl_u, a=pl_v, b=pl_u if uq["Lb"] else None)
         lse_v = _empty(Xv.t, 2, B, Hh, S)
         Av = new_act(st, am, Mv, d, site="%sL%d.vid.A" % (P, i), delayed=self.delayed)
         rec = dict(full=full, Xv=Xv, Xu=Xu, Yv=Yv, Yu=Yu, lse_v=lse_v)
@@ -1271,7 +1303,7 @@ class BackboneRun:
             def usr_chain():
                 H.attn_fwd(B, Hh, dh, Lt, uq["La"], uq["Lb"], uq["Qa"], uq["Qb"], uq["ldq"], uq["Ka"], uq["Va"], uq["ldka"], uq["Kb"],
                            uq["Vb"], uq["ldkb"], self.um, self.vm, self.um, Au.t, d, lse_u, drop_p=self.p_drop,
-                           seed=self.seed, site=_site(self.bi, i, K_ATT_U), amax_o=Au.slots, po=Au.po)
+                           seed=self.seed, site=_site(self.bi, i, K_ATT_U), amax_o=Au.slots, po=Au.po, pin=pin_u)
                 finish_act(st, produced(Au))
                 return self._side_post(i, L, "usr", Xu, Au, Mu, (K_AO_U, K_MI_U, K_MO_U), out_is_operand=True, bufs=bufs_u)
             if st.usr_side and st.overlap:
@@ -1280,7 +1312,7 @@ class BackboneRun:
                 usr_ctx = True
         H.attn_fwd(B, Hh, dh, S, vq["La"], vq["Lb"], vq["Qa"], vq["Qb"], vq["ldq"], vq["Ka"], vq["Va"], vq["ldka"], vq["Kb"], vq["Vb"],
                    vq["ldkb"], self.vm, self.vm, self.um, Av.t, d, lse_v, drop_p=self.p_drop, seed=self.seed,
-                   site=_site(self.bi, i, K_ATT_V), amax_o=Av.slots, po=Av.po)
+                   site=_site(self.bi, i, K_ATT_V), amax_o=Av.slots, po=Av.po, pin=pin_v)
         finish_act(st, produced(Av))
         hd = self.__dict__.get("_head_dot") if i == self.N - 2 else None          # last live layer: its video-side output IS the backbone's
         X2v, sv_v = self._side_post(i, L, "vid", Xv, Av, Mv, (K_AO_V, K_MI_V, K_MO_V), out_is_operand=i < self.N - 2, head_dot=hd)

@@ -15,7 +15,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SEGMM_LIB") or os.path.join(_HERE, "libsegmm_hip.so")      # SEGMM_LIB: A/B builds of the kernels
-ABI_VERSION = 25
+ABI_VERSION = 26
 
 _lib = None
 
@@ -726,7 +726,10 @@ class AttnPlanes(C.Structure):
     _fields_ = [("o", _p), ("ldo2", _i), ("hdr_o", _p), ("sin_o", _p),
                 ("dqa", _p), ("dqb", _p), ("lddq2", _i), ("dka", _p), ("dva", _p), ("lddka2", _i),
                 ("dkb", _p), ("dvb", _p), ("lddkb2", _i), ("hdr_q", _p), ("hdr_ka", _p), ("hdr_kb", _p),
-                ("sin_q", _p), ("sin_ka", _p), ("sin_kb", _p), ("flags", _i)]
+                ("sin_q", _p), ("sin_ka", _p), ("sin_kb", _p), ("flags", _i),
+                ("qa_in", _p), ("qb_in", _p), ("ldq2_in", _i), ("hdr_q_in", _p),
+                ("ka_in", _p), ("va_in", _p), ("ldka2_in", _i), ("hdr_ka_in", _p),
+                ("kb_in", _p), ("vb_in", _p), ("ldkb2_in", _i), ("hdr_kb_in", _p)]
 
 
 ATTN_PLANES_ONLY, ATTN_REPAIR = 1, 2
@@ -740,11 +743,17 @@ def site_fixup(*hdrs, stats=None):
 
 
 def attn_fwd(B, H, dh, Lq, La, Lb, Qa, Qb, ldq, Ka, Va, ldka, Kb, Vb, ldkb, mq, mka, mkb, O, ldo, lse,
-             drop_p=0.0, seed=0, site=0, amax_o=None, po=None):
+             drop_p=0.0, seed=0, site=0, amax_o=None, po=None, pin=None):
     """Q*/K*/V* are (tensor, element_offset) pairs: column slices of the fused projection buffers.  A key block may be
-    empty (La == 0 or Lb == 0, its pairs None): the CrossAtt / SelfAtt ablations attend to one block only."""
+    empty (La == 0 or Lb == 0, its pairs None): the CrossAtt / SelfAtt ablations attend to one block only.
+    ``pin`` (optional): the INPUT planes of the same slices, ``dict(q=(planes, hdr, ld2), a=(planes, hdr, ld2), b=...)`` --
+    the P32 plane tensors of the buffers the query views / the key block a views / the key block b views slice (planes
+    [rows, ld2] fp16) with their site headers; the planes-in forward (csrc/attention_pl.h) then runs where the shape qualifies."""
     def P(x):
         return 0 if x is None else x[0].data_ptr() + 4 * x[1]
+
+    def PP(side, x):          # plane address of the column slice x = (fp32 tensor, column offset): 2 fp16 per column
+        return None if (x is None or pin.get(side) is None) else pin[side][0].data_ptr() + 4 * x[1]
     prof = ATTN_PROFILE
     if prof is not None:
         e0 = torch.cuda.Event(enable_timing=True)
@@ -752,7 +761,16 @@ def attn_fwd(B, H, dh, Lq, La, Lb, Qa, Qb, ldq, Ka, Va, ldka, Kb, Vb, ldkb, mq, 
     pl = None
     if po is not None:
         a = po.args()
-        pl = C.byref(AttnPlanes(o=a[0], ldo2=a[1], hdr_o=a[2], sin_o=a[3]))
+        pl = AttnPlanes(o=a[0], ldo2=a[1], hdr_o=a[2], sin_o=a[3])
+    if pin is not None:
+        pl = pl if pl is not None else AttnPlanes()
+        pl.qa_in, pl.qb_in, pl.ldq2_in, pl.hdr_q_in = PP("q", Qa if Qa is not None else Qb), PP("q", Qb if Qb is not None else Qa), pin["q"][2], pin["q"][1].data_ptr()
+        if pin.get("a") is not None and Ka is not None:
+            pl.ka_in, pl.va_in, pl.ldka2_in, pl.hdr_ka_in = PP("a", Ka), PP("a", Va), pin["a"][2], pin["a"][1].data_ptr()
+        if pin.get("b") is not None and Kb is not None:
+            pl.kb_in, pl.vb_in, pl.ldkb2_in, pl.hdr_kb_in = PP("b", Kb), PP("b", Vb), pin["b"][2], pin["b"][1].data_ptr()
+    if pl is not None:
+        pl = C.byref(pl)
     _check(lib().segmm_attn_fwd(B, H, dh, Lq, La, Lb, P(Qa), P(Qb), ldq, P(Ka), P(Va), ldka, P(Kb), P(Vb), ldkb,
                                 _ptr(mq), _ptr(mka), _ptr(mkb), _ptr(O), ldo, _ptr(lse), float(drop_p), int(seed),
                                 int(site), _ptr(amax_o), pl, _stream()), "segmm_attn_fwd")

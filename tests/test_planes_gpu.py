@@ -359,6 +359,89 @@ def test_attention_producers_write_the_split_pass_planes(Hh, dh, B):
     assert float(hv[H.SITE_HDR:].max()) == float(dYv.abs().max()) and float(hu[H.SITE_HDR:].max()) == float(dYu.abs().max())
 
 
+def _site_planes(H, x, rows, cols, scale=None):
+    """P32 planes + complete site header of x: written with ``scale`` (mode 1: maxima / flag folded in, like a fused producer)
+    or with the exact scale of its maxima (mode 0)."""
+    hdr = H.new_site(x.device)[0]
+    pl = torch.empty((rows, 2 * cols), dtype=torch.float16, device=x.device)
+    if scale is None:
+        H.absmax(x, rows, cols, cols, out=hdr[H.SITE_HDR:])
+        H.split_p32(x, rows, cols, cols, pl, 2 * cols, hdr, mode=0)
+    else:
+        hdr[0] = scale
+        H.split_p32(x, rows, cols, cols, pl, 2 * cols, hdr, mode=1)
+    return pl, hdr
+
+
+@pytest.mark.parametrize("B,H_,dh,Lq,La,Lb,p,case", [
+    (4, 16, 48, 40, 40, 100, 0.1, "ok"), (3, 16, 48, 40, 40, 100, 0.0, "ok"), (2, 16, 48, 100, 40, 100, 0.1, "ok"),
+    (5, 8, 32, 20, 20, 12, 0.1, "ok"), (2, 2, 64, 40, 40, 8, 0.0, "ok"), (3, 4, 48, 40, 0, 100, 0.1, "ok"),
+    (3, 4, 48, 40, 40, 0, 0.1, "ok"), (2, 4, 16, 8, 40, 8, 0.0, "ok"), (3, 4, 48, 20, 20, 100, 0.1, "ok"),
+    (3, 16, 48, 40, 40, 100, 0.1, "overflow_a"), (3, 16, 48, 40, 40, 100, 0.1, "tiny_b"), (3, 16, 48, 40, 40, 100, 0.1, "overflow_q"),
+    (2, 16, 48, 40, 40, 100, 0.1, "scales_differ")])
+def test_attention_fwd_on_input_planes(B, H_, dh, Lq, La, Lb, p, case):
+    """The planes-in forward (csrc/attention_pl.h: Q / K / V as the P32 planes their producer GEMMs wrote, K / V staged by
+    LDS-DMA, three fp16 MFMAs per product) against the fp32-operand forward on the same column slices, masks and dropout
+    stream, and against an fp64 reference: O within 3e-6 of the maximum, softmax statistics to 2e-6.  Unusable sites (overflow
+    flag up; a maximum far below the fp16 window; the query site) take the in-kernel fallback from the fp32 views."""
+    H = _abi()
+    d = H_ * dh
+    g = torch.Generator().manual_seed(B * 131 + Lq + La)
+    nv, nu = 4, 2
+    Yv = (torch.randn(B * max(La, 1), nv * d, generator=g) * 0.7).to(DEV)
+    Yu = (torch.randn(B * max(Lb, 1), nu * d, generator=g) * (3.0 if case == "scales_differ" else 0.7)).to(DEV)
+    Qs = Yv if Lq == La else (torch.randn(B * Lq, nv * d, generator=g) * 0.7).to(DEV)
+    mq = (torch.rand(B, Lq, generator=g) < 0.8).to(DEV)
+    mka = (torch.rand(B, max(La, 1), generator=g) < 0.8).to(DEV)
+    mkb = (torch.rand(B, max(Lb, 1), generator=g) < 0.7).to(DEV)
+    mq[0, 0] = False
+    sc = {"overflow_a": (2.0 ** 15, None, None), "tiny_b": (None, 2.0 ** -9, None), "overflow_q": (None, None, 2.0 ** 15),
+          "scales_differ": (2.0 ** 12, 2.0 ** 9, None)}.get(case, (None, None, None))
+    plv, hv = _site_planes(H, Yv, Yv.shape[0], nv * d, sc[0])
+    plu, hu = _site_planes(H, Yu, Yu.shape[0], nu * d, sc[1])
+    if Qs is Yv and sc[2] is None:
+        plq, hq = plv, hv
+    else:
+        plq, hq = _site_planes(H, Qs, Qs.shape[0], nv * d, sc[2])
+    if case == "overflow_a":
+        assert float(hv[1]) != 0.0          # some |Yv| 2^15 > 65504: the producer raised the flag
+    args = (B, H_, dh, Lq, La, Lb, (Qs, 0), (Qs, d), nv * d, (Yv, 2 * d) if La else None, (Yv, 3 * d) if La else None, nv * d,
+            (Yu, 0) if Lb else None, (Yu, d) if Lb else None, nu * d, mq, mka[:, :La].contiguous() if La else None,
+            mkb[:, :Lb].contiguous() if Lb else None)
+    outs = {}
+    for form in ("f32", "pl"):
+        O = torch.full((B * Lq, d), float("nan"), device=DEV)
+        lse = torch.full((2, B, H_, Lq), float("nan"), device=DEV)
+        am = torch.zeros(H.AMAX_SLOTS, device=DEV)
+        pin = dict(q=(plq, hq, 2 * nv * d), a=(plv, hv, 2 * nv * d), b=(plu, hu, 2 * nu * d)) if form == "pl" else None
+        H.attn_fwd(*args, O, d, lse, drop_p=p, seed=11, site=3, amax_o=am, pin=pin)
+        outs[form] = (O, lse, am)
+    O0, O1 = outs["f32"][0], outs["pl"][0]
+    assert torch.isfinite(O1).all() and torch.isfinite(outs["pl"][1]).all()
+    omax = float(O0.abs().max())
+    assert float((O0 - O1).abs().max()) <= 3e-6 * omax, float((O0 - O1).abs().max()) / omax
+    l0, l1 = outs["f32"][1], outs["pl"][1]
+    assert float((l0[0] - l1[0]).abs().max()) <= 2e-6 * float(l0[0].abs().max())
+    assert float(((l0[1] - l1[1]) / l0[1]).abs().max()) <= 4e-6
+    assert float(outs["pl"][2].max()) == float(O1.abs().max())
+    if p == 0.0:          # fp64 reference (no dropout): the fp16x3 products are as exact as the fp32 matrix cores'
+        sl = lambda Y, k, L, n: Y.view(B, L, n * d)[:, :, k * d:(k + 1) * d].double()
+        Qa_, Qb_ = sl(Qs, 0, Lq, nv), sl(Qs, 1, Lq, nv)
+        z = torch.zeros(B, 0, d, dtype=torch.float64, device=DEV)
+        Ka_, Va_ = (sl(Yv, 2, La, nv), sl(Yv, 3, La, nv)) if La else (z, z)
+        Kb_, Vb_ = (sl(Yu, 0, Lb, nu), sl(Yu, 1, Lb, nu)) if Lb else (z, z)
+        from test_ops_gpu import _attn_ref
+        ref = _attn_ref(Qa_, Qb_, Ka_, Va_, Kb_, Vb_, mq, mka[:, :La], mkb[:, :Lb], H_)
+        e0 = float((O0.view(B, Lq, d).double() - ref).abs().max()); e1 = float((O1.view(B, Lq, d).double() - ref).abs().max())
+        assert e1 <= max(1.5 * e0, 2e-6 * omax), (e0, e1)
+    # plane output of O (the out-projection GEMM's operand) from the planes-in form equals a split pass over its own fp32 O
+    pl_o, hdr_o, sc_o, po = _po(H, B * Lq, d, 2.0 ** 12)
+    O2 = torch.empty(B * Lq, d, device=DEV); lse2 = torch.empty(2, B, H_, Lq, device=DEV)
+    H.attn_fwd(*args, O2, d, lse2, drop_p=p, seed=11, site=3, po=po, pin=dict(q=(plq, hq, 2 * nv * d), a=(plv, hv, 2 * nv * d), b=(plu, hu, 2 * nu * d)))
+    ref_pl, _ = _ref_planes(H, O2, B * Lq, d, 2.0 ** 12)
+    assert torch.equal(O2, O1) and torch.equal(pl_o, ref_pl) and float(hdr_o[0]) == 2.0 ** 12
+
+
 def test_scales_update():
     H = _abi()
     arena = H.new_site(DEV, 4)

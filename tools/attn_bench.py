@@ -21,6 +21,21 @@ dO = torch.randn(B * Lq, d, device=dev); Dv = torch.empty(B, Hh, Lq, device=dev)
 dYv = torch.empty_like(Yv); dYu = torch.empty_like(Yu); dQs = dYv if Lq == La else torch.empty_like(Qsrc)
 fwd = lambda: H.attn_fwd(B, Hh, dh, Lq, La, Lb, (Qsrc, 0), (Qsrc, d), 4 * d, (Yv, 2 * d), (Yv, 3 * d), 4 * d, (Yu, 0), (Yu, d), 2 * d,
                          qm, vm, um, O, d, lse, drop_p=p_drop, seed=1, site=3)
+def _site(x, cols):
+    hdr = H.new_site(dev)[0]
+    H.absmax(x, x.shape[0], cols, cols, out=hdr[H.SITE_HDR:])
+    pl = torch.empty((x.shape[0], 2 * cols), dtype=torch.float16, device=dev)
+    H.split_p32(x, x.shape[0], cols, cols, pl, 2 * cols, hdr, mode=0)
+    return pl, hdr
+plv, hv = _site(Yv, 4 * d); plu, hu = _site(Yu, 2 * d)
+plq, hq = (plv, hv) if Qsrc is Yv else _site(Qsrc, 4 * d)
+PIN = dict(q=(plq, hq, 8 * d), a=(plv, hv, 8 * d), b=(plu, hu, 4 * d))
+plo = torch.empty((B * Lq, 2 * d), dtype=torch.float16, device=dev); ho = H.new_site(dev)[0]; so = torch.tensor([4096.0], device=dev)
+PO = H.PO(plo, 2 * d, ho, so.data_ptr())
+fwd_pl = lambda: H.attn_fwd(B, Hh, dh, Lq, La, Lb, (Qsrc, 0), (Qsrc, d), 4 * d, (Yv, 2 * d), (Yv, 3 * d), 4 * d, (Yu, 0), (Yu, d), 2 * d,
+                            qm, vm, um, O, d, lse, drop_p=p_drop, seed=1, site=3, pin=PIN, po=PO)
+fwd_po = lambda: H.attn_fwd(B, Hh, dh, Lq, La, Lb, (Qsrc, 0), (Qsrc, d), 4 * d, (Yv, 2 * d), (Yv, 3 * d), 4 * d, (Yu, 0), (Yu, d), 2 * d,
+                            qm, vm, um, O, d, lse, drop_p=p_drop, seed=1, site=3, po=PO)
 bwd_ph = lambda ph: H.attn_bwd(B, Hh, dh, Lq, La, Lb, (Qsrc, 0), (Qsrc, d), 4 * d, (Yv, 2 * d), (Yv, 3 * d), 4 * d, (Yu, 0), (Yu, d), 2 * d,
                                qm, vm, um, lse, O, d, dO, d, Dv, (dQs, 0), (dQs, d), 4 * d, (dYv, 2 * d), (dYv, 3 * d), 4 * d, (dYu, 0), (dYu, d), 2 * d,
                                drop_p=p_drop, seed=1, site=3, phase=ph)
@@ -28,7 +43,7 @@ bwd = lambda: bwd_ph(0)
 def bwd_fused():
     bwd_ph(4)
 T = La + Lb
-cases = [("fwd", fwd, 4.0 * dh * Lq * T), ("bwd(dq+dkv)", bwd, 14.0 * dh * Lq * T), ("bwd D only", lambda: bwd_ph(1), 0.0)]
+cases = [("fwd", fwd, 4.0 * dh * Lq * T), ("fwd+planes out", fwd_po, 4.0 * dh * Lq * T), ("fwd planes-in", fwd_pl, 4.0 * dh * Lq * T), ("bwd(dq+dkv)", bwd, 14.0 * dh * Lq * T), ("bwd D only", lambda: bwd_ph(1), 0.0)]
 if True:
     cases.append(("bwd(fused)", bwd_fused, 14.0 * dh * Lq * T))
 for name, fn, flops in cases:
