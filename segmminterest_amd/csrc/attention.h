@@ -45,7 +45,7 @@ struct AttnInPlanes {
     const _Float16 *Qa, *Qb; int ldq2;      // same column slices as AttnArgs::Qa / Qb (null: no input planes)
     const _Float16 *baseA, *baseB;          // lowest plane address of key block a's / b's K and V views
     uint32_t offKa, offVa, offKb, offVb;    // byte offsets of the four views from their base
-    uint32_t bytesA, bytesB;                // extents from the base (buffer range check)
+    uint32_t bytesA, bytesB, bytesQ;        // extents from the base / from the lower of Qa, Qb (buffer range check)
     int ldka2, ldkb2;
     const float *hdr_q, *hdr_ka, *hdr_kb;   // site headers: hdr[0] scale, hdr[1] overflow flag, partial maxima
 };

@@ -165,7 +165,11 @@ __global__ __launch_bounds__(64 * ATT_PL_MAXW) void attn_fwd_pl_kernel(const Att
         if (!ok_b) s_b = f16_scale_of(mx4(mb4));
         // one accumulator serves both key blocks of O = P V: P of a block is split with the scale SP_x = 2^14 min(1, s_y / s_x), so that
         // SP_a s_a = SP_b s_b; scales further apart than 2^10 (a block's P terms would sink): both blocks restaged at the smaller scale
-        if (La > 0 && Lb > 0 && (s_a > 1024.f * s_b || s_b > 1024.f * s_a)) { ok_a = ok_b = false; s_a = s_b = fminf(s_a, s_b); }
+        const bool have_f32 = p.Qa != nullptr;
+        if (have_f32 && La > 0 && Lb > 0 && (s_a > 1024.f * s_b || s_b > 1024.f * s_a)) { ok_a = ok_b = false; s_a = s_b = fminf(s_a, s_b); }
+        // no fp32 views (the projection GEMMs write planes only): an unusable site was REPAIRED by its producer -- rewritten with
+        // the exact scale of its maxima, the one derived above -- so the staged planes are the operands in every case
+        if (!have_f32) ok_q = ok_a = ok_b = true;
         if (La == 0) { ok_a = true; s_a = s_b; }
         if (Lb == 0) { ok_b = true; s_b = s_a; }
     }
@@ -339,6 +343,448 @@ __global__ __launch_bounds__(64 * ATT_PL_MAXW) void attn_fwd_pl_kernel(const Att
         }
     }
     plane_finish(p.po_o, p.amax_o, am, blockIdx.x * nw + wave, ps, blockIdx.x == 0 && threadIdx.x == 0);
+}
+
+
+// LDS bytes of attn_bwd_pl_kernel for a query chunk of QC rows, nw waves and Tp padded keys (keep in step with the kernel's layout)
+template <int DH>
+inline size_t attn_bwd_pl_lds_bytes(int QC, int nw, int /*Tp*/) {
+    return ((size_t)2 * QC * (DH + 4) + 3 * QC + 4 + 36) * 4 + (size_t)QC * (DH / 4 + 1) * 16 + (size_t)nw * 16 * (DH / 4 + 1) * 16 + QC;
+}
+
+// ------------------------------------------------------------------------------------------ backward: fused dQ + dK + dV on input planes
+// attn_bwd_fused16_kernel (attention16.h: same workgroup = (b, h, key block), same wave = key tile in passes, same ordered dQ
+// accumulation, dropout stream, plane outputs and repair protocol) with Q, K and V read from the P32 planes of the projection
+// GEMMs instead of their fp32 views -- which then need not exist (the GEMMs write planes only):
+//   * the chunk's Q rows are staged by LDS-DMA into a chunk image (16-byte chunks, hi then lo, one pad chunk per row) that serves
+//     the row-fragment reads of S = Q K^T and the transposed reads of dK^T = Q^T dS -- no loads through registers, no maxima
+//     exchange, no in-place conversion pass for Q;
+//   * a wave's K tile goes by LDS-DMA into its own 3 KB image (row fragments for S, transposed fragments for dQ^T = K^T dS^T), its V
+//     row fragments straight to registers -- no per-tile maxima, no split (a third of the fp16x3 kernel's vector work);
+//   * operand scales are the sites' (a site that is unusable under its header's scale was rewritten by the producer's repair
+//     launch with the exact scale of its maxima: both sides derive that scale from the same header).
+// dO and O still arrive as fp32 (staged and converted like before).
+template <int DH, int NW, bool ONE>
+__global__ __launch_bounds__(64 * NW, NW <= 4 ? SEGMM_ATT16_WPS : 4) void attn_bwd_pl_kernel(const AttnArgs p) {
+    using C = AttnCfg<DH>;
+    const DropCfg drop_ = drop_live(p.drop);
+    static_assert(DH % 16 == 0, "fp16 attention: head dim must be a multiple of 16");
+    constexpr int RS = DH + 4;                 // LDS row stride (floats): 16-byte aligned rows, conflict-free row-fragment reads
+    constexpr int RSB = RS * 4;                // ... in bytes
+    constexpr int TS = 20;                     // row stride of the 16 x 16 transpose scratch
+    constexpr int QC = ATT_FUSED_QCHUNK;       // queries staged at a time (3 query tiles)
+    constexpr int MAXQT = QC / 16;
+    constexpr int NCH = DH / 16;               // k = 16 blocks of a product over the head dim (= C::CT)
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;          // (uniform: LDS-DMA bases)
+    const int l15 = lane & 15, g = lane >> 4;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x), bh = p.hpb == 2 ? wg >> 1 : wg, b = bh / p.H, h = bh % p.H;
+    const bool isa = p.hpb == 2 ? (wg & 1) == 0 : p.hpb == 0;
+    const int La_p = round16(p.La), Lb_p = round16(p.Lb), Tp = La_p + Lb_p, nta = La_p >> 4, ntb = Lb_p >> 4;
+    const int ntk = isa ? nta : ntb;                       // key tiles of the block
+    // A wave owns key tile `wave` -- and, in a single-chunk launch with fewer waves than tiles, tiles wave + nwv, wave + 2 nwv ...
+    // one PASS after the other over the same staged query side.  The kernel is bound by the latency of its staging loads, i.e. by
+    // the number of workgroups a CU holds (tools/attn_bench.py with SEGMM_ATT_LDS_PAD: 476 us at 4 + 2 workgroups per CU for the
+    // two key blocks, 700 us at 2 + 1): four-wave workgroups fit four to a CU where the seven-wave ones of a 100-key block fit two.
+    const int nwv = min(ntk, nw);
+    if (wave >= nwv) return;                               // surplus wave, or empty block (CrossAtt / SelfAtt ablations)
+    const int npass = ONE ? (ntk + nwv - 1) / nwv : 1;     // (several chunks: the host launches one wave per tile)
+    const int nthr = 64 * nwv;                             // surviving threads
+    const int col0 = h * DH;
+    const float* Qg = isa ? p.Qa : p.Qb;
+    float* dQg = isa ? p.dQa : p.dQb;
+    _Float16* dQgp = isa ? p.dQap : p.dQbp;
+    float s_q = (dQgp && p.sin_q) ? *p.sin_q : 0.f;
+    const float* sin_k = isa ? p.sin_ka : p.sin_kb;
+    float s_k = ((isa ? p.dKap : p.dKbp) && sin_k) ? *sin_k : 0.f;
+    const bool repair = (p.pflags & ATT_REPAIR) != 0;
+    const bool want_q = dQgp && p.sin_q, want_k = (isa ? p.dKap : p.dKbp) && sin_k;          // sites with plane outputs
+    if (repair) {
+        // segmm_site_fixup has judged the sites between the producers and this launch: hdr[2] != 0 = the planes were unusable
+        // (written with no scale at all, overflow flag up, or the maximum below the fp16 window) and hdr[0] now holds the exact
+        // scale of the recorded maxima, with which this pass rewrites them.  Two scalar loads and out, normally.
+        const float* hk_ = isa ? p.hdr_ka : p.hdr_kb;
+        const bool need_q = want_q && p.hdr_q[2] != 0.f, need_k = want_k && hk_[2] != 0.f;
+        if (!need_q && !need_k) return;
+        s_q = need_q ? p.hdr_q[0] : 0.f;
+        s_k = need_k ? hk_[0] : 0.f;
+    }
+    const bool f32_q = !repair && !((p.pflags & ATT_PLANES_ONLY) && want_q);          // fp32 copies of dQ / of dK, dV
+    const bool f32_k = !repair && !((p.pflags & ATT_PLANES_ONLY) && want_k);
+    // chunk images (sQ, this wave's K tile): rows of DH/8 hi chunks, DH/8 lo chunks (16 bytes = 8 columns each) and ONE pad chunk:
+    // an odd number of chunks per row makes the row-fragment reads (16 rows x one chunk per 32-lane half) conflict-free without a
+    // rotation -- every read offset is a lane base + an instruction immediate -- and leaves the transposed reads (8 rows x two
+    // adjacent chunks per half) at 3 doubly used bank groups of 16
+    constexpr int CPR = DH / 4, HC = DH / 8, PCH = CPR + 1, ROWB = PCH * 16, IPB = (16 * PCH + 63) / 64;
+    char* sdO = (char*)smem_f;                             // [QC][RSB]: fp32 rows while staging, then [4 hi | 4 lo] groups
+    float* sdQ = (float*)(sdO + QC * RSB);                 // [QC][RS] dQ accumulators (zeroed after D is formed)
+    float* s_Dp = sdQ;                                     // [QC][DH/4] partial products dO . O: alive from the staging to D only
+    float* s_mx = sdQ + QC * RS;
+    float* s_inv = s_mx + QC;
+    float* s_D = s_inv + QC;
+    int* s_turn = (int*)(s_D + QC);                                         // [4] whose turn it is to add dQ of query tile qt
+    float* s_wm = (float*)(s_turn + 4);                                     // [3][12] per-wave maxima: (unused), |dO|, |D|
+    char* sQ = (char*)(s_wm + 36);                                          // [QC][ROWB]: the chunk image of the Q planes (LDS-DMA)
+    char* sKt = sQ + QC * ROWB + wave * (16 * ROWB);                        // this wave's K tile [16][ROWB] (LDS-DMA) ...
+    float* s_tr = (float*)sKt;                                              // ... and, once its fragments are in registers, its transpose scratch
+    uint8_t* qm = (uint8_t*)(sQ + QC * ROWB + nw * (16 * ROWB));            // [QC] 1 valid query, 0 masked, 2 pad
+    static_assert(16 * TS * 4 <= 16 * ROWB, "transpose scratch inside the K image");
+    // ---- input planes: sites, scales.  A site that is not usable under its header's scale was REPAIRED by its producer (the
+    // projection GEMM's repair launch rewrote the planes with the exact scale of the recorded maxima): take that scale
+    const AttnInPlanes& in = p.in;
+    const float* hdr_kx = isa ? in.hdr_ka : in.hdr_kb;
+    float sQs = 1.f, sK = 1.f, sV = 1.f, maxV = 0.f;                         // (set by judge_sites, after the first staging round)
+    // ---- read offsets inside a staged row: row fragment (lane (row l15, g): columns 16 i + 4 g .. + 3) = byte 8 g + 32 i of the hi
+    // chunks (+ 16 HC: lo); transposed read (lane 4 q + pq of a 16-lane group supplies row q, columns 16 ct + 4 pq .. + 3) = byte
+    // 8 pq + 32 ct
+    const uint32_t bR = 8u * (uint32_t)g, bC = 8u * (uint32_t)(l15 & 3);
+    constexpr uint32_t LO = 16u * HC;
+    // ---- DMA source of this lane inside a 16-row block of a chunk image: slot 64 i + lane = (row rr, chunk j) of the block;
+    // column part and row are the same for every block (computed once), the row stride differs between Q and K
+    uint32_t dco[IPB];
+    uint32_t drow = 0;                                                       // the IPB rows, 8 bits each (0xff: no slot / pad chunk)
+#pragma unroll
+    for (int i = 0; i < IPB; ++i) {
+        const int sl = 64 * i + lane, rr = sl / PCH, j = sl - rr * PCH;
+        const bool dead = sl >= 16 * PCH;
+        dco[i] = j == CPR ? ATT_BUF_OOB : p32_chunk_off(col0 + 8 * (j >= HC ? j - HC : j)) + (j >= HC ? 64u : 0u);
+        drow |= (uint32_t)(dead ? 0xff : rr) << (8 * i);
+    }
+    static_assert(IPB <= 4, "row bytes packed in one register");
+    auto dma_block = [&](const __amdgpu_buffer_rsrc_t rs, char* dst, uint32_t ld2b, int left, uint32_t so) {
+#pragma unroll
+        for (int i = 0; i < IPB; ++i) {
+            const uint32_t rr = (drow >> (8 * i)) & 0xffu;
+            if (rr != 0xffu) att_lds_dma16(rs, dst + 1024 * i, (int)rr < left ? rr * ld2b + dco[i] : ATT_BUF_OOB, so);          // (rows behind the data: zeros)
+        }
+    };
+    const uint32_t ldq2b = (uint32_t)in.ldq2 * 2u, ldk2b = (uint32_t)(isa ? in.ldka2 : in.ldkb2) * 2u;
+    const __amdgpu_buffer_rsrc_t rsQ = make_rsrc(isa ? in.Qa : in.Qb, in.bytesQ);
+    const __amdgpu_buffer_rsrc_t rsKV = make_rsrc(isa ? in.baseA : in.baseB, isa ? in.bytesA : in.bytesB);
+    const int Lk = isa ? p.La : p.Lb;                                        // keys of this block
+    const uint32_t soK0 = (uint32_t)(b * Lk) * ldk2b + (isa ? in.offKa : in.offKb), soV0 = (uint32_t)(b * Lk) * ldk2b + (isa ? in.offVa : in.offVb);
+    // ---- this wave's key tile
+    int jt = (isa ? 0 : nta) + wave;                                        // padded key tile of this wave (first pass)
+    HL kfh[NCH], vfh[NCH], kch[C::CT];                                      // K / V row fragments, K column fragments (hi, lo as staged)
+    uint2 vraw[NCH][2];
+    // K tile of the current pass: three LDS-DMA instructions into this wave's image (rows behind the block: zeros); V row
+    // fragments straight to registers (lane (key l15, g): columns 16 i + 4 g .. + 3, hi and lo).  issue / finish are separate so
+    // that a single-chunk launch requests its first tile BEFORE the query-side staging
+    const uint8_t* mkx = isa ? p.mka + (size_t)b * p.La : p.mkb + (size_t)b * p.Lb;
+    uint8_t kraw = 0;
+    auto issue_frags = [&]() {
+        const int tl = jt - (isa ? 0 : nta);                                // tile inside the block
+        dma_block(rsKV, sKt, ldk2b, Lk - 16 * tl, soK0 + (uint32_t)(16 * tl) * ldk2b);
+        const int kr = min(16 * tl + l15, Lk - 1);                          // (keys behind the block: clamped, finite; their P is 0)
+        const uint32_t vo = soV0 + (uint32_t)kr * ldk2b;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const uint32_t co = vo + p32_chunk_off(col0 + 16 * i + 4 * g);
+            const u32x2a h_ = __builtin_bit_cast(u32x2a, __builtin_amdgcn_raw_buffer_load_b64(rsKV, (int)co, 0, 0));
+            const u32x2a l_ = __builtin_bit_cast(u32x2a, __builtin_amdgcn_raw_buffer_load_b64(rsKV, (int)(co + 64u), 0, 0));
+            vraw[i][0] = make_uint2(h_.x, h_.y); vraw[i][1] = make_uint2(l_.x, l_.y);
+        }
+        kraw = mkx[kr];                                                     // this lane's key flag (key 16 tl + l15 of the block)
+    };
+    auto finish_frags = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // this wave's DMA has landed in its own image
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            vfh[i] = HL{vraw[i][0].x, vraw[i][0].y, vraw[i][1].x, vraw[i][1].y};
+            const char* kr_ = sKt + (size_t)l15 * ROWB + bR;
+            const u32x2a hh = lds_b64(kr_ + 32 * i), ll = lds_b64(kr_ + 32 * i + LO);
+            kfh[i] = HL{hh.x, hh.y, ll.x, ll.y};
+        }
+        const char* kc = sKt + (size_t)(4 * g + (l15 >> 2)) * ROWB + bC;
+#pragma unroll
+        for (int ct = 0; ct < C::CT; ++ct) {
+            const u32x2a hh = lds_tr4(kc + 32 * ct), ll = lds_tr4(kc + 32 * ct + LO);
+            kch[ct] = HL{hh.x, hh.y, ll.x, ll.y};
+        }
+    };
+    auto load_frags = [&]() { issue_frags(); finish_frags(); };
+    if (!ONE) load_frags();
+    const float fscale = p.scale;
+    f32x4 dk[C::CT], dv[C::CT];
+#pragma unroll
+    for (int ct = 0; ct < C::CT; ++ct) { dk[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    float am_q = 0.f, am_k = 0.f;
+    float unit_dk = 1.f, unit_dv = 1.f;                    // product of the operand scales the dK / dV accumulators are in
+    constexpr float SP = 16384.f;                          // scale of P (<= 1)
+    // transposed-read address of this lane inside a (query tile, column tile) block: row 4 g + (l15 >> 2), group (l15 & 3)
+    const uint32_t tr_lane = (uint32_t)(4 * g + (l15 >> 2)) * RSB + (uint32_t)(l15 & 3) * 16u;
+
+    // dK / dV rows of the current tile: lane (key l15, g), tile ct register r = head column 16 ct + 4 g + r
+    auto emit_dkdv = [&]() {
+        const int jp = 16 * jt + l15;
+        const float inv_dk = 1.0f / unit_dk, inv_dv = 1.0f / unit_dv;
+#pragma unroll
+        for (int ct = 0; ct < C::CT; ++ct) { dk[ct] *= inv_dk; dv[ct] *= inv_dv; }
+        const bool ka = jp < La_p;
+        const int jloc = ka ? jp : jp - La_p;
+        const bool real = ka ? (jloc < p.La) : (jloc < p.Lb);
+        if (real) {
+            float* dKp = (ka ? p.dKa + (size_t)(b * p.La + jloc) * p.lddka : p.dKb + (size_t)(b * p.Lb + jloc) * p.lddkb) + col0;
+            float* dVp = (ka ? p.dVa + (size_t)(b * p.La + jloc) * p.lddka : p.dVb + (size_t)(b * p.Lb + jloc) * p.lddkb) + col0;
+            const long long krow = ka ? (long long)b * p.La + jloc : (long long)b * p.Lb + jloc;
+            _Float16* dKpp = ka ? p.dKap : p.dKbp;
+            _Float16* dVpp = ka ? p.dVap : p.dVbp;
+            const int ldk2 = ka ? p.lddka2 : p.lddkb2;
+#pragma unroll
+            for (int ct = 0; ct < C::CT; ++ct) {
+                if (f32_k) {
+                    *(f32x4*)(dKp + 16 * ct + 4 * g) = dk[ct];
+                    *(f32x4*)(dVp + 16 * ct + 4 * g) = dv[ct];
+                }
+                if (s_k > 0.f) {          // lane (key, g) and lane (key, g ^ 1) hold the two halves of an aligned 8
+                    if ((col0 & 7) == 0) {
+                        plane_store4_x16(dKpp, ldk2, krow, col0 + 16 * ct + 4 * g, split4(dk[ct], s_k));
+                        plane_store4_x16(dVpp, ldk2, krow, col0 + 16 * ct + 4 * g, split4(dv[ct], s_k));
+                    } else {
+                        plane_store4(dKpp, ldk2, krow, col0 + 16 * ct + 4 * g, dk[ct], s_k);
+                        plane_store4(dVpp, ldk2, krow, col0 + 16 * ct + 4 * g, dv[ct], s_k);
+                    }
+                }
+                am_k = absmax4(absmax4(am_k, dk[ct]), dv[ct]);
+            }
+        }
+    };
+
+    for (int q0 = 0; ONE ? q0 < 1 : q0 < p.Lq; q0 += QC) {
+        const int nq = min(QC, p.Lq - q0);                 // real queries of the chunk
+        const int nqt = (nq + 15) >> 4;
+        float mdo_ = 0.f;
+        // ===== ONE round of memory latency: every load of the chunk is requested before the first result is used =====
+        if (ONE) issue_frags();                            // first tile of this wave: K image, V fragments, key flag
+        // the chunk's Q rows: 16-row blocks of the chunk image by LDS-DMA (rows behind the last query: zeros)
+        for (int blk = wave; blk < QC / 16; blk += nwv)
+            dma_block(rsQ, sQ + (size_t)(16 * blk) * ROWB, ldq2b, nq - 16 * blk, (uint32_t)(b * p.Lq + q0 + 16 * blk) * ldq2b);
+        // softmax statistics and query flags (one query per thread; QC <= 64 <= nthr)
+        float r_mx = 0.f, r_inv = 0.f;
+        uint8_t r_qm = 2;
+        if ((int)threadIdx.x < nq) {
+            r_mx = p.lse[(size_t)bh * p.Lq + q0 + threadIdx.x];
+            r_inv = p.lse[(size_t)p.B * p.H * p.Lq + (size_t)bh * p.Lq + q0 + threadIdx.x];
+            r_qm = p.mq[(size_t)b * p.Lq + q0 + threadIdx.x] ? 1 : 0;
+        }
+        // the site headers of the input planes (first chunk; judged below): scale, flag, four partial maxima per lane
+        float hq0 = 0.f, hk0 = 0.f, hq1 = 0.f, hk1 = 0.f;
+        f32x4 hq4 = {0.f, 0.f, 0.f, 0.f}, hk4 = hq4;
+        if (q0 == 0) {
+            hq0 = in.hdr_q[0]; hq1 = in.hdr_q[1]; hk0 = hdr_kx[0]; hk1 = hdr_kx[1];
+            hq4 = *(const f32x4*)(in.hdr_q + SITE_HDR + lane * 4); hk4 = *(const f32x4*)(hdr_kx + SITE_HDR + lane * 4);
+        }
+        // dO and O: three items per thread and round, all six loads requested before the first LDS store
+        for (int i0 = threadIdx.x; i0 < QC * (DH / 4); i0 += 3 * nthr) {
+            f32x4 vo[3], oo[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int i = i0 + u * nthr;
+                const int q = i / (DH / 4), c = (i - q * (DH / 4)) * 4;
+                vo[u] = f32x4{0.f, 0.f, 0.f, 0.f}; oo[u] = vo[u];
+                if (i < QC * (DH / 4) && q < nq) {
+                    const size_t row = (size_t)b * p.Lq + q0 + q;
+                    vo[u] = *(const f32x4*)(p.dO + row * p.lddo + col0 + c);
+                    oo[u] = *(const f32x4*)(p.O + row * p.ldo + col0 + c);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int i = i0 + u * nthr;
+                if (i < QC * (DH / 4)) {
+                    const int q = i / (DH / 4), c = (i - q * (DH / 4)) * 4;
+                    *(f32x4*)(sdO + q * RSB + c * 4) = vo[u];
+                    s_Dp[i] = (vo[u].x * oo[u].x + vo[u].y * oo[u].y) + (vo[u].z * oo[u].z + vo[u].w * oo[u].w);
+                    mdo_ = absmax4(mdo_, vo[u]);
+                }
+            }
+        }
+        mdo_ = wave_max(mdo_);
+        if (lane == 0) s_wm[12 + wave] = mdo_;
+        if (threadIdx.x < QC) { s_mx[threadIdx.x] = r_mx; s_inv[threadIdx.x] = r_inv; qm[threadIdx.x] = r_qm; }
+        if (threadIdx.x < 4) s_turn[threadIdx.x] = 0;
+        if (q0 == 0) {
+            // the input sites: a site that is not usable under its header's scale was REPAIRED by its producer (the projection
+            // GEMM's repair launch rewrote the planes with the exact scale of the recorded maxima): take that scale
+            const float amax_q = wave_max(fmaxf(fmaxf(hq4.x, hq4.y), fmaxf(hq4.z, hq4.w)));
+            const float amax_k = wave_max(fmaxf(fmaxf(hk4.x, hk4.y), fmaxf(hk4.z, hk4.w)));
+            auto okf = [](float s, uint32_t flag, float m) { return s > 0.f && flag == 0u && (!(m > 0.f) || ((m * s >= 0.25f || s >= 0x1p60f) && m * s < 65504.f)); };
+            sQs = okf(hq0, __float_as_uint(hq1), amax_q) ? hq0 : f16_scale_of(amax_q);
+            sK = okf(hk0, __float_as_uint(hk1), amax_k) ? hk0 : f16_scale_of(amax_k);
+            sV = sK;                                       // K and V of a block are columns of one buffer
+            maxV = amax_k;                                 // bound of |V| (the site's maximum)
+        }
+        if (ONE) finish_frags();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's Q blocks have landed
+        __syncthreads();
+#ifdef SEGMM_ATT_PROBE
+        if (p.pflags & 1024) return;          // timing probe: staging loads + K / V fragments only
+#endif
+        // chunk maxima -> scales; D; every thread converts its own groups in place
+        float mdO = 0.f;
+        for (int w = 0; w < nwv; ++w) mdO = fmaxf(mdO, s_wm[12 + w]);
+        const float sdOs = f16_scale_of(mdO);
+        float mD = 0.f;
+        for (int q = threadIdx.x; q < QC; q += nthr) {     // D[q]: the DH/4 partials of the row in index order (deterministic)
+            float d_ = 0.f;
+#pragma unroll
+            for (int j = 0; j < DH / 4; ++j) d_ += s_Dp[q * (DH / 4) + j];
+            s_D[q] = d_;
+            mD = fmaxf(mD, fabsf(d_));
+        }
+        mD = wave_max(mD);
+        if (lane == 0) s_wm[24 + wave] = mD;
+        for (int i = threadIdx.x; i < QC * (DH / 4); i += nthr) {
+            const int q = i / (DH / 4), c = (i - q * (DH / 4)) * 4;
+            char* ad = sdO + q * RSB + c * 4;
+            const f32x4 vo = *(const f32x4*)ad;
+            const HL hd = split4c(vo, sdOs);
+            *(uint4*)ad = make_uint4(hd.h0, hd.h1, hd.l0, hd.l1);
+        }
+        __syncthreads();                                   // D is formed: the partial products are dead, their space becomes the dQ accumulators
+        for (int i = threadIdx.x; i < QC * (DH / 4); i += nthr) {
+            const int q = i / (DH / 4), c = (i - q * (DH / 4)) * 4;
+            *(f32x4*)(sdQ + q * RS + c) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        __syncthreads();
+#ifdef SEGMM_ATT_PROBE
+        if (p.pflags & 2048) return;          // timing probe: ... + the in-place conversion
+#endif
+        float mDc = 0.f;
+        for (int w = 0; w < nwv; ++w) mDc = fmaxf(mDc, s_wm[24 + w]);
+      for (int pass = 0; pass < npass; ++pass) {
+        const int tile = wave + pass * nwv;                // this wave's tile of the pass, 0 .. ntk-1 (the dQ turn order)
+        if (tile >= ntk) break;
+        if (pass > 0) {                                    // next tile of this wave: its K / V fragments, fresh dK / dV sums
+            jt += nwv;
+            load_frags();
+#pragma unroll
+            for (int ct = 0; ct < C::CT; ++ct) { dk[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        }
+        const int jp = 16 * jt + l15;                      // this lane's key (padded index)
+        // |dS| <= P (|dP| + |D|) mult scale, |dP| <= DH max|dO| max|V tile|
+        const float sdS = f16_scale_of(((float)DH * mdO * maxV + mDc) * drop_.scale * fscale);
+        const float inv_s = 1.0f / (sQs * sK), inv_dp = 1.0f / (sdOs * sV), inv_dq = 1.0f / (sK * sdS);
+        const uint8_t kflag = (16 * (jt - (isa ? 0 : nta)) + l15 < Lk) ? (kraw ? 1 : 0) : 2;          // 1 valid key, 0 masked, 2 pad
+        {   // dK / dV accumulate in the units of the CURRENT chunk's operand scales: moving on to a chunk with other scales
+            // multiplies what has been summed so far by the ratio -- a power of two, exact
+            const float u_dk = sQs * sdS, u_dv = sdOs * SP;
+            if (!ONE && q0 > 0) {          // (one pass per chunk here)
+                const float rk = u_dk / unit_dk, rv = u_dv / unit_dv;
+#pragma unroll
+                for (int ct = 0; ct < C::CT; ++ct) { dk[ct] *= rk; dv[ct] *= rv; }
+            }
+            unit_dk = u_dk; unit_dv = u_dv;
+        }
+#pragma unroll
+        for (int qt = 0; qt < MAXQT; ++qt) {
+#ifdef SEGMM_ATT_PROBE
+            if (p.pflags & 4096) break;          // timing probe: no pair loop
+#endif
+            if (qt < nqt) {
+                // row fragments (lane&15 = query): group 4 i + g of the row = elements 16 i + 4 g .. + 3, [hi | lo]
+                f32x4 sv = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                const char* rq = sQ + (size_t)(16 * qt + l15) * ROWB + bR;
+                const char* rd = sdO + (16 * qt + l15) * RSB + g * 16;
+#pragma unroll
+                for (int i = 0; i < NCH; ++i) {
+                    const u32x2a qh_ = lds_b64(rq + 32 * i), ql_ = lds_b64(rq + 32 * i + LO);
+                    sv = mfma_hl(HL{qh_.x, qh_.y, ql_.x, ql_.y}, kfh[i], sv);
+                    dp = mfma_hl(lds_hl(rd + 64 * i), vfh[i], dp);
+                }
+                const f32x4 mxq = *(const f32x4*)(s_mx + 16 * qt + 4 * g), invq = *(const f32x4*)(s_inv + 16 * qt + 4 * g);
+                const f32x4 Dq = *(const f32x4*)(s_D + 16 * qt + 4 * g);
+                const uint32_t qfl = *(const uint32_t*)(qm + 16 * qt + 4 * g);
+                f32x4 Pv, dSv;
+                uint32_t dw[4] = {0u, 0u, 0u, 0u};
+                if (drop_.p > 0.f) {
+                    const int rr = l15 & 3;
+                    const uint2 hw = drop_rand_quad(drop_, (((uint64_t)bh * p.Lq + (q0 + 16 * qt + 4 * g + rr)) * Tp + jp) >> 2);
+                    const uint32_t a0 = quad_bcast<0>(hw.x), a1 = quad_bcast<1>(hw.x), a2 = quad_bcast<2>(hw.x), a3 = quad_bcast<3>(hw.x);
+                    const uint32_t b0 = quad_bcast<0>(hw.y), b1 = quad_bcast<1>(hw.y), b2 = quad_bcast<2>(hw.y), b3 = quad_bcast<3>(hw.y);
+                    const bool lo_word = rr < 2, hi_half = rr & 1;
+                    const uint32_t w0 = lo_word ? a0 : b0, w1 = lo_word ? a1 : b1, w2 = lo_word ? a2 : b2, w3 = lo_word ? a3 : b3;
+                    dw[0] = hi_half ? (w0 >> 16) : (w0 & 0xffffu); dw[1] = hi_half ? (w1 >> 16) : (w1 & 0xffffu);
+                    dw[2] = hi_half ? (w2 >> 16) : (w2 & 0xffffu); dw[3] = hi_half ? (w3 >> 16) : (w3 & 0xffffu);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const uint32_t qf_ = (qfl >> (8 * r)) & 0xff;
+                    const bool valid = (qf_ == 1) && (kflag == 1);
+                    float mult = 1.f;
+                    if (drop_.p > 0.f && qf_ != 2) mult = (dw[r] >= drop_.thresh) ? drop_.scale : 0.f;
+                    const float v = logit_xform(sv[r] * inv_s, valid, mult, fscale);
+                    const float pr = (kflag == 2 || qf_ == 2) ? 0.f : fast_exp(v - mxq[r]) * invq[r];
+                    Pv[r] = pr;
+                    dSv[r] = valid ? pr * (dp[r] * inv_dp - Dq[r]) * mult * fscale : 0.f;
+                }
+                const HL Ph = split4c(Pv, SP), dSh = split4c(dSv, sdS);
+                // column fragments (4 consecutive queries 16 qt + 4 g .. + 3 of head column 16 ct + l15) by transposed reads
+#pragma unroll
+                for (int ct = 0; ct < C::CT; ++ct) {
+                    const uint32_t o = (uint32_t)(16 * qt) * RSB + (uint32_t)ct * 64u + tr_lane;
+                    const u32x2a dh_ = lds_tr4(sdO + o), dl_ = lds_tr4(sdO + o + 8);
+                    const char* qc = sQ + (size_t)(16 * qt + 4 * g + (l15 >> 2)) * ROWB + bC;
+                    const u32x2a qh_ = lds_tr4(qc + 32 * ct), ql_ = lds_tr4(qc + 32 * ct + LO);
+                    dv[ct] = mfma_hl(HL{dh_.x, dh_.y, dl_.x, dl_.y}, Ph, dv[ct]);
+                    dk[ct] = mfma_hl(HL{qh_.x, qh_.y, ql_.x, ql_.y}, dSh, dk[ct]);
+                }
+                // dS[query 4g+r][key l15] -> dS^T fragments (lane&15 = query, registers = keys 4g..4g+3) through the scratch
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s_tr[(4 * g + r) * TS + l15] = dSv[r];
+                __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0): this wave's own LDS writes have landed
+                __builtin_amdgcn_wave_barrier();
+                const f32x4 dST = *(const f32x4*)(s_tr + l15 * TS + 4 * g);
+                __builtin_amdgcn_wave_barrier();
+                const HL dSTh = split4c(dST, sdS);
+                f32x4 dqt[C::CT];
+#pragma unroll
+                for (int ct = 0; ct < C::CT; ++ct) dqt[ct] = mfma_hl(kch[ct], dSTh, f32x4{0.f, 0.f, 0.f, 0.f});
+                if (tile > 0)
+                    while (__hip_atomic_load(s_turn + qt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != tile) __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                {   // lane (query l15, g), tile ct, register r = head column 16 ct + 4 g + r (the K column fragments are in natural order)
+                    float* row = sdQ + (16 * qt + l15) * RS + 4 * g;
+#pragma unroll
+                    for (int ct = 0; ct < C::CT; ++ct) {
+                        f32x4 a = *(f32x4*)(row + 16 * ct);
+                        a += dqt[ct] * inv_dq;
+                        *(f32x4*)(row + 16 * ct) = a;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) __hip_atomic_store(s_turn + qt, tile + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        if (ONE) emit_dkdv();                              // this tile is complete
+      }
+        __syncthreads();                                   // every wave has added its dQ partials of this chunk
+        for (int i = threadIdx.x; i < nq * (DH / 4); i += nthr) {
+            const int q = i / (DH / 4), c = (i - q * (DH / 4)) * 4;
+            const size_t row = (size_t)b * p.Lq + q0 + q;
+            const f32x4 v = *(const f32x4*)(sdQ + q * RS + c);
+            if (f32_q) *(f32x4*)(dQg + row * p.lddq + col0 + c) = v;
+            if (s_q > 0.f) {
+                if ((col0 & 7) == 0) plane_store4_pair(dQgp, p.lddq2, (long long)row, col0 + c, v, s_q);
+                else plane_store4(dQgp, p.lddq2, (long long)row, col0 + c, v, s_q);
+            }
+            am_q = absmax4(am_q, v);
+        }
+        if (!ONE && q0 + QC < p.Lq) __syncthreads();       // the next chunk's staging overwrites what was just read
+    }
+    {
+        if (!ONE) emit_dkdv();
+        const float am = am_k;
+        float* hk = isa ? p.hdr_ka : p.hdr_kb;
+        float* slot = isa ? p.amax_ka : p.amax_kb;
+        const bool hdr_writer = bh == 0 && wave == 0 && lane == 0;
+        if (!repair) {
+            if (s_k > 0.f) { site_commit(hk, am, blockIdx.x * nw + wave, s_k); if (hdr_writer) hk[0] = s_k; }
+            else if (slot) amax_commit(slot, am, blockIdx.x * nw + wave);
+            if (s_q > 0.f) { site_commit(p.hdr_q, am_q, blockIdx.x * nw + wave, s_q); if (hdr_writer) p.hdr_q[0] = s_q; }
+            else if (p.amax_q) amax_commit(p.amax_q, am_q, blockIdx.x * nw + wave);
+        }
+    }
 }
 
 }  // namespace segmm

@@ -50,14 +50,15 @@ using namespace segmm;
 static int attn_fill(AttnArgs& a, int B, int H, int dh, int Lq, int La, int Lb, const float* Qa, const float* Qb, int ldq,
                      const float* Ka, const float* Va, int ldka, const float* Kb, const float* Vb, int ldkb,
                      const uint8_t* mq, const uint8_t* mka, const uint8_t* mkb, float drop_p, uint64_t seed,
-                     uint32_t site) {
+                     uint32_t site, bool planes_in = false) {
     SEGMM_REQUIRE(B > 0 && H > 0 && Lq > 0 && La >= 0 && Lb >= 0 && La + Lb > 0, "attn: empty dimension");
     // One key block may be EMPTY (La == 0 or Lb == 0): the CrossAtt / SelfAtt ablations of the reference attend to one
     // block only (encoder.py:108-135).  Its pointers may then be null; reads are aliased to the other block's tensors
     // (never dereferenced for a key tile, the query fragment of the empty block is loaded but unused).
     if (La == 0) { Qa = Qb; Ka = Kb; Va = Vb; ldka = ldkb; mka = mkb; }
     if (Lb == 0) { Qb = Qa; Kb = Ka; Vb = Va; ldkb = ldka; mkb = mka; }
-    SEGMM_REQUIRE(Qa && Qb && Ka && Va && Kb && Vb && mq && mka && mkb, "attn: null pointer");
+    // (with input planes the fp32 views of Q / K / V are optional: a caller whose projection GEMMs write planes only has none)
+    SEGMM_REQUIRE(((Qa && Qb && Ka && Va && Kb && Vb) || (planes_in && !Qa && !Qb && !Ka && !Va && !Kb && !Vb)) && mq && mka && mkb, "attn: null pointer");
     SEGMM_REQUIRE(dh == 4 || dh == 8 || dh == 16 || dh == 32 || dh == 48 || dh == 64, "attn: head dim %d not built (4,8,16,32,48,64)", dh);
     SEGMM_REQUIRE(ldq % 4 == 0 && ldka % 4 == 0 && ldkb % 4 == 0, "attn: leading dims %% 4");
     SEGMM_REQUIRE(aligned16(Qa) && aligned16(Qb) && aligned16(Ka) && aligned16(Va) && aligned16(Kb) && aligned16(Vb), "attn: alignment");
@@ -256,6 +257,18 @@ static int attn_launch_bwd(AttnArgs& a, int phase, hipStream_t s) {
             static const int lds_pad = getenv("SEGMM_ATT_LDS_PAD") ? atoi(getenv("SEGMM_ATT_LDS_PAD")) : 0;      // probe: fewer workgroups per CU
             lds += (size_t)lds_pad;
             if constexpr (DH % 16 == 0 && DH <= 48) {
+                if (a.in.Qa) {          // round 5: Q / K / V from the projection GEMMs' planes (attention_pl.h); always in passes of <= 4 waves
+                    const int nwp = one && nw > 4 ? 4 : nw;
+                    const size_t ldsp = attn_bwd_pl_lds_bytes<DH>(Lq_p, nwp, Tp);
+                    const dim3 blockp(64 * nwp);
+#define FUSEDPL(NWV) do { if (one) hipLaunchKernelGGL((attn_bwd_pl_kernel<DH, NWV, true>), grid, blockp, ldsp, s, a); \
+                          else hipLaunchKernelGGL((attn_bwd_pl_kernel<DH, NWV, false>), grid, blockp, ldsp, s, a); } while (0)
+                    if (nwp <= 4) FUSEDPL(4);
+                    else if (nwp <= 8) FUSEDPL(8);
+                    else FUSEDPL(12);
+#undef FUSEDPL
+                    continue;
+                }
                 // fp16x3 matrix-core form (attention16.h).  By default only single-chunk launches with more than 32 queries: with
                 // several query chunks the kernel needs more than the 128 registers that keep two 7-wave workgroups on a CU and
                 // loses to the fp32 form (Lq = 100: 1 459 vs 1 199 us), and with a handful of queries (config 3: Lq = 20 and 1)
@@ -980,13 +993,44 @@ int segmm_colsum(const float* X, int ld, const float* w, int64_t M, int N, float
     return 0;
 }
 
+// input planes of the attention kernels (round 5): the views of an empty key block are aliased to the other block's, like attn_fill
+static int attn_fill_in(AttnArgs& a, const segmm_attn_planes_t* pl, int B, int H, int dh, int Lq, int La, int Lb, const char* who) {
+    if (!(pl && pl->qa_in)) return 0;
+    const uint16_t *ka = pl->ka_in, *va = pl->va_in, *kb = pl->kb_in, *vb = pl->vb_in;
+    const float *ha = pl->hdr_ka_in, *hb = pl->hdr_kb_in;
+    int lda2 = pl->ldka2_in, ldb2 = pl->ldkb2_in;
+    if (La == 0) { ka = kb; va = vb; ha = hb; lda2 = ldb2; }
+    if (Lb == 0) { kb = ka; vb = va; hb = ha; ldb2 = lda2; }
+    const uint16_t *qa = pl->qa_in, *qb = pl->qb_in ? pl->qb_in : pl->qa_in;
+    SEGMM_REQUIRE(ka && va && kb && vb && pl->hdr_q_in && ha && hb, "%s: input planes need every view and header", who);
+    SEGMM_REQUIRE(pl->ldq2_in % 64 == 0 && lda2 % 64 == 0 && ldb2 % 64 == 0, "%s: input plane strides %% 64", who);
+    SEGMM_REQUIRE(aligned16(qa) && aligned16(qb) && aligned16(ka) && aligned16(va) && aligned16(kb) && aligned16(vb), "%s: input plane alignment", who);
+    AttnInPlanes& in = a.in;
+    in.Qa = (const _Float16*)qa; in.Qb = (const _Float16*)qb; in.ldq2 = pl->ldq2_in;
+    in.hdr_q = pl->hdr_q_in; in.hdr_ka = ha; in.hdr_kb = hb;
+    in.ldka2 = lda2; in.ldkb2 = ldb2;
+    const uintptr_t bA = (uintptr_t)ka < (uintptr_t)va ? (uintptr_t)ka : (uintptr_t)va, bB = (uintptr_t)kb < (uintptr_t)vb ? (uintptr_t)kb : (uintptr_t)vb;
+    const size_t offKa = (uintptr_t)ka - bA, offVa = (uintptr_t)va - bA, offKb = (uintptr_t)kb - bB, offVb = (uintptr_t)vb - bB;
+    // extent of a view: last row's start + the head columns' planes (2 bytes x 2 terms per column, rounded up to a whole block)
+    const size_t headb = (size_t)((H * dh + 31) / 32) * 128;
+    const size_t extA = ((size_t)B * (La ? La : Lb) - 1) * (size_t)lda2 * 2 + headb;
+    const size_t extB = ((size_t)B * (Lb ? Lb : La) - 1) * (size_t)ldb2 * 2 + headb;
+    const size_t bytesA = (offKa > offVa ? offKa : offVa) + extA, bytesB = (offKb > offVb ? offKb : offVb) + extB;
+    const size_t bytesQ = ((size_t)B * Lq - 1) * (size_t)pl->ldq2_in * 2 + headb;
+    SEGMM_REQUIRE(bytesA < (1ull << 31) && bytesB < (1ull << 31) && bytesQ < (1ull << 31), "%s: an input plane view exceeds the 2 GiB buffer-addressing window", who);
+    in.baseA = (const _Float16*)bA; in.baseB = (const _Float16*)bB;
+    in.offKa = (uint32_t)offKa; in.offVa = (uint32_t)offVa; in.offKb = (uint32_t)offKb; in.offVb = (uint32_t)offVb;
+    in.bytesA = (uint32_t)bytesA; in.bytesB = (uint32_t)bytesB; in.bytesQ = (uint32_t)bytesQ;
+    return 0;
+}
+
 int segmm_attn_fwd(int B, int H, int dh, int Lq, int La, int Lb, const float* Qa, const float* Qb, int ldq,
                    const float* Ka, const float* Va, int ldka, const float* Kb, const float* Vb, int ldkb,
                    const uint8_t* mq, const uint8_t* mka, const uint8_t* mkb, float* O, int ldo, float* lse,
                    float drop_p, uint64_t seed, uint32_t site, float* amax_o, const segmm_attn_planes_t* pl, segmm_stream_t stream) {
     AttnArgs a;
     memset(&a, 0, sizeof(a));
-    int rc = attn_fill(a, B, H, dh, Lq, La, Lb, Qa, Qb, ldq, Ka, Va, ldka, Kb, Vb, ldkb, mq, mka, mkb, drop_p, seed, site);
+    int rc = attn_fill(a, B, H, dh, Lq, La, Lb, Qa, Qb, ldq, Ka, Va, ldka, Kb, Vb, ldkb, mq, mka, mkb, drop_p, seed, site, pl && pl->qa_in);
     if (rc) return rc;
     SEGMM_REQUIRE(O && lse && aligned16(O) && ldo % 4 == 0, "attn_fwd: output pointer/alignment");
     a.O = O; a.ldo = ldo; a.lse = lse; a.amax_o = amax_o;
@@ -994,30 +1038,8 @@ int segmm_attn_fwd(int B, int H, int dh, int Lq, int La, int Lb, const float* Qa
         SEGMM_REQUIRE(pl->hdr_o && pl->ldo2 % 64 == 0 && aligned16(pl->o) && (H * dh) % 32 == 0, "attn_fwd: plane output needs a header, ld2 %% 64, width %% 32");
         a.po_o = plane_out(pl->o, pl->ldo2, pl->hdr_o, pl->sin_o);
     }
-    if (pl && pl->qa_in) {          // input planes (round 5): the views of an empty key block are aliased to the other block's, like attn_fill
-        const uint16_t *ka = pl->ka_in, *va = pl->va_in, *kb = pl->kb_in, *vb = pl->vb_in;
-        const float *ha = pl->hdr_ka_in, *hb = pl->hdr_kb_in;
-        int lda2 = pl->ldka2_in, ldb2 = pl->ldkb2_in;
-        if (La == 0) { ka = kb; va = vb; ha = hb; lda2 = ldb2; }
-        if (Lb == 0) { kb = ka; vb = va; hb = ha; ldb2 = lda2; }
-        SEGMM_REQUIRE(pl->qb_in && ka && va && kb && vb && pl->hdr_q_in && ha && hb, "attn_fwd: input planes need every view and header");
-        SEGMM_REQUIRE(pl->ldq2_in % 64 == 0 && lda2 % 64 == 0 && ldb2 % 64 == 0, "attn_fwd: input plane strides %% 64");
-        SEGMM_REQUIRE(aligned16(pl->qa_in) && aligned16(pl->qb_in) && aligned16(ka) && aligned16(va) && aligned16(kb) && aligned16(vb), "attn_fwd: input plane alignment");
-        AttnInPlanes& in = a.in;
-        in.Qa = (const _Float16*)pl->qa_in; in.Qb = (const _Float16*)pl->qb_in; in.ldq2 = pl->ldq2_in;
-        in.hdr_q = pl->hdr_q_in; in.hdr_ka = ha; in.hdr_kb = hb;
-        in.ldka2 = lda2; in.ldkb2 = ldb2;
-        const uintptr_t bA = (uintptr_t)ka < (uintptr_t)va ? (uintptr_t)ka : (uintptr_t)va, bB = (uintptr_t)kb < (uintptr_t)vb ? (uintptr_t)kb : (uintptr_t)vb;
-        const size_t offKa = (uintptr_t)ka - bA, offVa = (uintptr_t)va - bA, offKb = (uintptr_t)kb - bB, offVb = (uintptr_t)vb - bB;
-        // extent of a view: last row's start + the head columns' planes (2 bytes x 2 terms per column, rounded up to a whole block)
-        const size_t extA = ((size_t)B * (La ? La : Lb) - 1) * (size_t)lda2 * 2 + (size_t)((H * dh + 31) / 32) * 128;
-        const size_t extB = ((size_t)B * (Lb ? Lb : La) - 1) * (size_t)ldb2 * 2 + (size_t)((H * dh + 31) / 32) * 128;
-        const size_t bytesA = (offKa > offVa ? offKa : offVa) + extA, bytesB = (offKb > offVb ? offKb : offVb) + extB;
-        SEGMM_REQUIRE(bytesA < (1ull << 31) && bytesB < (1ull << 31), "attn_fwd: an input plane view exceeds the 2 GiB buffer-addressing window");
-        in.baseA = (const _Float16*)bA; in.baseB = (const _Float16*)bB;
-        in.offKa = (uint32_t)offKa; in.offVa = (uint32_t)offVa; in.offKb = (uint32_t)offKb; in.offVb = (uint32_t)offVb;
-        in.bytesA = (uint32_t)bytesA; in.bytesB = (uint32_t)bytesB;
-    }
+    rc = attn_fill_in(a, pl, B, H, dh, Lq, La, Lb, "attn_fwd");
+    if (rc) return rc;
     ATTN_DISPATCH(attn_launch_fwd, dh, a, (hipStream_t)stream);
 }
 
@@ -1030,8 +1052,13 @@ int segmm_attn_bwd(int B, int H, int dh, int Lq, int La, int Lb, const float* Qa
     SEGMM_REQUIRE(phase >= 0 && phase <= 6, "attn_bwd: phase %d (0 all, 1 D, 2 dQ, 3 dK/dV, 4 fused dQ+dK+dV, 5 / 6 fused, key block a / b only)", phase);
     AttnArgs a;
     memset(&a, 0, sizeof(a));
-    int rc = attn_fill(a, B, H, dh, Lq, La, Lb, Qa, Qb, ldq, Ka, Va, ldka, Kb, Vb, ldkb, mq, mka, mkb, drop_p, seed, site);
+    const bool planes_in = pl && pl->qa_in;
+    SEGMM_REQUIRE(!planes_in || phase >= 4, "attn_bwd: input planes need the fused backward (phase 4 / 5 / 6)");
+    int rc = attn_fill(a, B, H, dh, Lq, La, Lb, Qa, Qb, ldq, Ka, Va, ldka, Kb, Vb, ldkb, mq, mka, mkb, drop_p, seed, site, planes_in);
     if (rc) return rc;
+    rc = attn_fill_in(a, pl, B, H, dh, Lq, La, Lb, "attn_bwd");
+    if (rc) return rc;
+    SEGMM_REQUIRE(!planes_in || (dh % 16 == 0 && dh <= 48), "attn_bwd: input planes are built for head dims 16, 32, 48 (got %d)", dh);
     SEGMM_REQUIRE(lse && O && dO && Dvec, "attn_bwd: null pointer");
     SEGMM_REQUIRE((La == 0 || (dQa && dKa && dVa)) && (Lb == 0 || (dQb && dKb && dVb)), "attn_bwd: null gradient pointer of a non-empty key block");
     if (La == 0) { dQa = nullptr; dKa = dKb; dVa = dVb; lddka = lddkb; }      // dQ of an empty block is not written

@@ -742,6 +742,19 @@ def site_fixup(*hdrs, stats=None):
     _check(lib().segmm_site_fixup(h[0], h[1], h[2], h[3], _ptr(stats), _stream()), "segmm_site_fixup")
 
 
+def _fill_pin(pl, pin, Qa, Qb, Ka, Va, Kb, Vb):
+    """Input-plane fields of a segmm_attn_planes_t from ``pin = dict(q=(planes, hdr, ld2), a=..., b=...)`` and the (tensor,
+    column offset) pairs of the fp32 views (only the offsets are used: 2 fp16 per column)."""
+    def PP(side, x):
+        return None if (x is None or pin.get(side) is None) else pin[side][0].data_ptr() + 4 * x[1]
+    pl.qa_in, pl.qb_in = PP("q", Qa if Qa is not None else Qb), PP("q", Qb if Qb is not None else Qa)
+    pl.ldq2_in, pl.hdr_q_in = pin["q"][2], pin["q"][1].data_ptr()
+    if pin.get("a") is not None and Ka is not None:
+        pl.ka_in, pl.va_in, pl.ldka2_in, pl.hdr_ka_in = PP("a", Ka), PP("a", Va), pin["a"][2], pin["a"][1].data_ptr()
+    if pin.get("b") is not None and Kb is not None:
+        pl.kb_in, pl.vb_in, pl.ldkb2_in, pl.hdr_kb_in = PP("b", Kb), PP("b", Vb), pin["b"][2], pin["b"][1].data_ptr()
+
+
 def attn_fwd(B, H, dh, Lq, La, Lb, Qa, Qb, ldq, Ka, Va, ldka, Kb, Vb, ldkb, mq, mka, mkb, O, ldo, lse,
              drop_p=0.0, seed=0, site=0, amax_o=None, po=None, pin=None):
     """Q*/K*/V* are (tensor, element_offset) pairs: column slices of the fused projection buffers.  A key block may be
@@ -750,10 +763,7 @@ def attn_fwd(B, H, dh, Lq, La, Lb, Qa, Qb, ldq, Ka, Va, ldka, Kb, Vb, ldkb, mq, 
     the P32 plane tensors of the buffers the query views / the key block a views / the key block b views slice (planes
     [rows, ld2] fp16) with their site headers; the planes-in forward (csrc/attention_pl.h) then runs where the shape qualifies."""
     def P(x):
-        return 0 if x is None else x[0].data_ptr() + 4 * x[1]
-
-    def PP(side, x):          # plane address of the column slice x = (fp32 tensor, column offset): 2 fp16 per column
-        return None if (x is None or pin.get(side) is None) else pin[side][0].data_ptr() + 4 * x[1]
+        return 0 if (x is None or x[0] is None) else x[0].data_ptr() + 4 * x[1]
     prof = ATTN_PROFILE
     if prof is not None:
         e0 = torch.cuda.Event(enable_timing=True)
@@ -764,11 +774,7 @@ def attn_fwd(B, H, dh, Lq, La, Lb, Qa, Qb, ldq, Ka, Va, ldka, Kb, Vb, ldkb, mq, 
         pl = AttnPlanes(o=a[0], ldo2=a[1], hdr_o=a[2], sin_o=a[3])
     if pin is not None:
         pl = pl if pl is not None else AttnPlanes()
-        pl.qa_in, pl.qb_in, pl.ldq2_in, pl.hdr_q_in = PP("q", Qa if Qa is not None else Qb), PP("q", Qb if Qb is not None else Qa), pin["q"][2], pin["q"][1].data_ptr()
-        if pin.get("a") is not None and Ka is not None:
-            pl.ka_in, pl.va_in, pl.ldka2_in, pl.hdr_ka_in = PP("a", Ka), PP("a", Va), pin["a"][2], pin["a"][1].data_ptr()
-        if pin.get("b") is not None and Kb is not None:
-            pl.kb_in, pl.vb_in, pl.ldkb2_in, pl.hdr_kb_in = PP("b", Kb), PP("b", Vb), pin["b"][2], pin["b"][1].data_ptr()
+        _fill_pin(pl, pin, Qa, Qb, Ka, Va, Kb, Vb)
     if pl is not None:
         pl = C.byref(pl)
     _check(lib().segmm_attn_fwd(B, H, dh, Lq, La, Lb, P(Qa), P(Qb), ldq, P(Ka), P(Va), ldka, P(Kb), P(Vb), ldkb,
@@ -782,10 +788,15 @@ def attn_fwd(B, H, dh, Lq, La, Lb, Qa, Qb, ldq, Ka, Va, ldka, Kb, Vb, ldkb, mq, 
 
 def attn_bwd(B, H, dh, Lq, La, Lb, Qa, Qb, ldq, Ka, Va, ldka, Kb, Vb, ldkb, mq, mka, mkb, lse, O, ldo, dO, lddo, Dvec,
              dQa, dQb, lddq, dKa, dVa, lddka, dKb, dVb, lddkb, drop_p=0.0, seed=0, site=0, amax_q=None, amax_ka=None,
-             amax_kb=None, phase=0, planes=None):
-    """``phase``: 0 whole backward; 1 Dvec only; 2 dQ only; 3 dK/dV only (2 and 3 may run concurrently after 1)."""
+             amax_kb=None, phase=0, planes=None, pin=None):
+    """``phase``: 0 whole backward; 1 Dvec only; 2 dQ only; 3 dK/dV only (2 and 3 may run concurrently after 1).
+    ``pin`` (fused backward, phase >= 4): the INPUT planes of Q / K / V like attn_fwd's; the Q / K / V pairs then only name
+    column offsets and their tensors may be None (a caller whose projection GEMMs write planes only): ``(None, offset)``."""
     def P(x):
-        return 0 if x is None else x[0].data_ptr() + 4 * x[1]
+        return 0 if (x is None or x[0] is None) else x[0].data_ptr() + 4 * x[1]
+    if pin is not None:
+        planes = planes if planes is not None else AttnPlanes()
+        _fill_pin(planes, pin, Qa, Qb, Ka, Va, Kb, Vb)
     prof = ATTN_PROFILE
     if prof is not None:
         e0 = torch.cuda.Event(enable_timing=True)

@@ -442,6 +442,72 @@ def test_attention_fwd_on_input_planes(B, H_, dh, Lq, La, Lb, p, case):
     assert torch.equal(O2, O1) and torch.equal(pl_o, ref_pl) and float(hdr_o[0]) == 2.0 ** 12
 
 
+@pytest.mark.parametrize("B,H_,dh,Lq,La,Lb,p,case", [
+    (4, 16, 48, 40, 40, 100, 0.1, "ok"), (3, 16, 48, 40, 40, 100, 0.0, "ok"), (2, 16, 48, 100, 40, 100, 0.1, "ok"),
+    (5, 8, 32, 20, 20, 12, 0.1, "ok"), (3, 4, 48, 40, 0, 100, 0.1, "ok"), (3, 4, 48, 40, 40, 0, 0.1, "ok"),
+    (2, 4, 16, 8, 40, 8, 0.0, "ok"), (3, 4, 48, 20, 20, 100, 0.1, "ok"), (3, 16, 48, 40, 40, 100, 0.1, "repaired"),
+    (3, 16, 48, 40, 40, 100, 0.1, "no_f32")])
+def test_attention_bwd_on_input_planes(B, H_, dh, Lq, La, Lb, p, case):
+    """The planes-in fused backward (csrc/attention_pl.h: Q / K / V from the projection GEMMs' P32 planes -- the chunk's Q rows
+    and each wave's K tile by LDS-DMA, no operand splits) against the fp16x3 fused backward on the fp32 views: same masks,
+    dropout stream, softmax statistics; gradients within 3e-6 of each tensor's maximum.  ``repaired``: the site headers carry a
+    scale under which the planes overflowed (flag up) while the planes hold the producer's repair (exact scale of the maxima) --
+    both sides derive that scale from the header.  ``no_f32``: the fp32 views are not passed at all (forward and backward)."""
+    H = _abi()
+    d = H_ * dh
+    g = torch.Generator().manual_seed(B * 17 + Lq + La)
+    nv, nu = 4, 2
+    Yv = (torch.randn(B * max(La, 1), nv * d, generator=g) * 0.7).to(DEV)
+    Yu = (torch.randn(B * max(Lb, 1), nu * d, generator=g) * 0.7).to(DEV)
+    Qs = Yv if Lq == La else (torch.randn(B * Lq, nv * d, generator=g) * 0.7).to(DEV)
+    mq = (torch.rand(B, Lq, generator=g) < 0.8).to(DEV)
+    mka = (torch.rand(B, max(La, 1), generator=g) < 0.8).to(DEV)
+    mkb = (torch.rand(B, max(Lb, 1), generator=g) < 0.7).to(DEV)
+    mq[0, 0] = False
+    plv, hv = _site_planes(H, Yv, Yv.shape[0], nv * d)
+    plu, hu = _site_planes(H, Yu, Yu.shape[0], nu * d)
+    plq, hq = (plv, hv) if Qs is Yv else _site_planes(H, Qs, Qs.shape[0], nv * d)
+    if case == "repaired":
+        for h_ in {id(hv): hv, id(hu): hu, id(hq): hq}.values():
+            h_[0] = float(h_[0]) * 4.0          # max * s in [2^16, 2^17): the delayed write would have overflowed
+            h_[1] = 1.0
+    mka_, mkb_ = (mka[:, :La].contiguous() if La else None), (mkb[:, :Lb].contiguous() if Lb else None)
+    pin = dict(q=(plq, hq, 2 * nv * d), a=(plv, hv, 2 * nv * d), b=(plu, hu, 2 * nu * d))
+
+    def views(with_f32):
+        t = (lambda x: x) if with_f32 else (lambda x: None)
+        return ((t(Qs), 0), (t(Qs), d), nv * d, (t(Yv), 2 * d) if La else None, (t(Yv), 3 * d) if La else None, nv * d,
+                (t(Yu), 0) if Lb else None, (t(Yu), d) if Lb else None, nu * d)
+    O = torch.empty(B * Lq, d, device=DEV); lse = torch.empty(2, B, H_, Lq, device=DEV)
+    H.attn_fwd(B, H_, dh, Lq, La, Lb, *views(True), mq, mka_, mkb_, O, d, lse, drop_p=p, seed=11, site=3)
+    if case == "no_f32":          # the planes-in forward without fp32 views: equal to the one with them
+        O2 = torch.empty_like(O); lse2 = torch.empty_like(lse)
+        H.attn_fwd(B, H_, dh, Lq, La, Lb, *views(True), mq, mka_, mkb_, O2, d, lse2, drop_p=p, seed=11, site=3, pin=pin)
+        O3 = torch.empty_like(O); lse3 = torch.empty_like(lse)
+        H.attn_fwd(B, H_, dh, Lq, La, Lb, *views(False), mq, mka_, mkb_, O3, d, lse3, drop_p=p, seed=11, site=3, pin=pin)
+        assert torch.equal(O2, O3) and torch.equal(lse2, lse3)
+    dO = torch.randn(B * Lq, d, generator=g).to(DEV)
+    Dv = torch.empty(B * H_ * Lq, device=DEV)
+    outs = {}
+    prev = H.attn_mode(2)          # the fp16x3 fused backward wherever it is built: the comparison form
+    try:
+        for form in ("f32", "pl"):
+            dQs = torch.zeros(B * Lq, nv * d, device=DEV) if Qs is not Yv else None
+            dYv, dYu = torch.zeros_like(Yv), torch.zeros_like(Yu)
+            dq = dYv if Qs is Yv else dQs
+            H.attn_bwd(B, H_, dh, Lq, La, Lb, *views(form == "f32" or case != "no_f32"), mq, mka_, mkb_, lse, O, d, dO, d, Dv,
+                       (dq, 0), (dq, d), nv * d, (dYv, 2 * d) if La else None, (dYv, 3 * d) if La else None, nv * d,
+                       (dYu, 0) if Lb else None, (dYu, d) if Lb else None, nu * d, drop_p=p, seed=11, site=3, phase=4,
+                       pin=pin if form == "pl" else None)
+            outs[form] = (dq.clone(), dYv.clone(), dYu.clone())
+    finally:
+        H.attn_mode(prev)
+    for name, a_, b_ in zip(("dQ", "dYv", "dYu"), outs["f32"], outs["pl"]):
+        assert torch.isfinite(b_).all(), name
+        m = float(a_.abs().max())
+        assert float((a_ - b_).abs().max()) <= 3e-6 * max(m, 1e-30), (name, float((a_ - b_).abs().max()) / max(m, 1e-30))
+
+
 def test_scales_update():
     H = _abi()
     arena = H.new_site(DEV, 4)

@@ -40,12 +40,16 @@ bwd_ph = lambda ph: H.attn_bwd(B, Hh, dh, Lq, La, Lb, (Qsrc, 0), (Qsrc, d), 4 * 
                                qm, vm, um, lse, O, d, dO, d, Dv, (dQs, 0), (dQs, d), 4 * d, (dYv, 2 * d), (dYv, 3 * d), 4 * d, (dYu, 0), (dYu, d), 2 * d,
                                drop_p=p_drop, seed=1, site=3, phase=ph)
 bwd = lambda: bwd_ph(0)
+bwd_pl = lambda: H.attn_bwd(B, Hh, dh, Lq, La, Lb, (None, 0), (None, d), 4 * d, (None, 2 * d), (None, 3 * d), 4 * d, (None, 0), (None, d), 2 * d,
+                            qm, vm, um, lse, O, d, dO, d, Dv, (dQs, 0), (dQs, d), 4 * d, (dYv, 2 * d), (dYv, 3 * d), 4 * d, (dYu, 0), (dYu, d), 2 * d,
+                            drop_p=p_drop, seed=1, site=3, phase=4, pin=PIN)
 def bwd_fused():
     bwd_ph(4)
 T = La + Lb
 cases = [("fwd", fwd, 4.0 * dh * Lq * T), ("fwd+planes out", fwd_po, 4.0 * dh * Lq * T), ("fwd planes-in", fwd_pl, 4.0 * dh * Lq * T), ("bwd(dq+dkv)", bwd, 14.0 * dh * Lq * T), ("bwd D only", lambda: bwd_ph(1), 0.0)]
 if True:
     cases.append(("bwd(fused)", bwd_fused, 14.0 * dh * Lq * T))
+    cases.append(("bwd planes-in", bwd_pl, 14.0 * dh * Lq * T))
 for name, fn, flops in cases:
     for _ in range(2):
         fn()

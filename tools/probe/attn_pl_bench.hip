@@ -86,6 +86,61 @@ int main(int argc, char** argv) {
     CK(hipEventElapsedTime(&ms, e0, e1));
     const double us = ms * 1e3 / iters, fl = 4.0 * DH * Lq * (La + Lb) * B * H;
     const double bytes = 4.0 * (2.0 * Lq + 2.0 * (La + Lb)) * DH * B * H + 8.0 * Lq * DH * B * H;
+    if (argc > 5 && !strcmp(argv[5], "bwd")) {          // backward: ./attn_pl_bench iters pflags drop Lq bwd   (planes-in fused backward and the fp16x3 fused backward beside it)
+        float *dO, *Dq, *dYv, *dYu;
+        uint16_t *pdv, *pdu;
+        CK(hipMalloc(&dO, 4 * (size_t)B * Lq * d)); CK(hipMemset(dO, 0, 4 * (size_t)B * Lq * d));
+        CK(hipMalloc(&dYv, 4 * nYv)); CK(hipMalloc(&dYu, 4 * nYu)); CK(hipMalloc(&pdv, 4 * nYv)); CK(hipMalloc(&pdu, 4 * nYu));
+        {   // dO, O: small random values; lse: max 0, 1/sum 1/140
+            std::vector<float> r((size_t)B * Lq * d);
+            for (auto& x : r) x = (float)((rand() % 2001) - 1000) * 1e-3f;
+            CK(hipMemcpy(dO, r.data(), 4 * r.size(), hipMemcpyHostToDevice)); CK(hipMemcpy(O, r.data(), 4 * r.size(), hipMemcpyHostToDevice));
+            std::vector<float> l(2 * (size_t)B * H * Lq, 0.f);
+            for (size_t i = l.size() / 2; i < l.size(); ++i) l[i] = 1.f / 140.f;
+            CK(hipMemcpy(lse, l.data(), 4 * l.size(), hipMemcpyHostToDevice));
+            std::vector<float> f(nYv);
+            for (auto& x : f) x = (float)((rand() % 2001) - 1000) * 1e-3f;
+            CK(hipMemcpy(fv, f.data(), 4 * nYv, hipMemcpyHostToDevice)); CK(hipMemcpy(fu, f.data(), 4 * nYu, hipMemcpyHostToDevice));
+        }
+        a.dO = dO; a.lddo = d; a.Dvec = nullptr;
+        a.dQa = dYv; a.dQb = dYv + d; a.lddq = nv * d; a.dKa = dYv + 2 * d; a.dVa = dYv + 3 * d; a.lddka = nv * d; a.dKb = dYu; a.dVb = dYu + d; a.lddkb = nu * d;
+        a.dQap = (_Float16*)pdv; a.dQbp = (_Float16*)pdv + 2 * d; a.lddq2 = 2 * nv * d;
+        a.dKap = (_Float16*)pdv + 4 * d; a.dVap = (_Float16*)pdv + 6 * d; a.lddka2 = 2 * nv * d;
+        a.dKbp = (_Float16*)pdu; a.dVbp = (_Float16*)pdu + 2 * d; a.lddkb2 = 2 * nu * d;
+        float* hd; CK(hipMalloc(&hd, 4 * 3 * SITE_FLOATS)); CK(hipMemset(hd, 0, 4 * 3 * SITE_FLOATS));
+        { float sc = 1024.f; CK(hipMemcpy(hd + 2 * SITE_FLOATS + 7, &sc, 4, hipMemcpyHostToDevice)); }
+        a.hdr_q = hd; a.hdr_ka = hd; a.hdr_kb = hd + SITE_FLOATS; a.sin_q = a.sin_ka = a.sin_kb = hd + 2 * SITE_FLOATS + 7;
+        a.pflags = ATT_PLANES_ONLY | pflags;
+        const int Tp = 48 + 112, QC = ATT_FUSED_QCHUNK;
+        for (int form = 0; form < 2; ++form) {
+            double tot = 0;
+            for (int blk = 0; blk < 2; ++blk) {
+                const int nt = blk == 0 ? 3 : 7, nwp = nt > 4 ? 4 : nt;
+                a.hpb = blk;
+                const size_t l16 = ((size_t)3 * QC * (DH + 4) + 3 * QC + (size_t)nwp * 16 * 20 + 4 + 36 + (size_t)QC * (DH / 4)) * 4 + QC + Tp;
+                const size_t lpl = attn_bwd_pl_lds_bytes<DH>(QC, nwp, Tp);
+                int oc = 0;
+                if (form == 0) CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&oc, attn_bwd_fused16_kernel<DH, 4, true>, 64 * nwp, l16));
+                else CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&oc, attn_bwd_pl_kernel<DH, 4, true>, 64 * nwp, lpl));
+                auto go = [&]() {
+                    if (form == 0) hipLaunchKernelGGL((attn_bwd_fused16_kernel<DH, 4, true>), dim3(B * H), dim3(64 * nwp), l16, 0, a);
+                    else hipLaunchKernelGGL((attn_bwd_pl_kernel<DH, 4, true>), dim3(B * H), dim3(64 * nwp), lpl, 0, a);
+                };
+                for (int i = 0; i < 3; ++i) go();
+                CK(hipDeviceSynchronize());
+                CK(hipEventRecord(e0));
+                for (int i = 0; i < iters; ++i) go();
+                CK(hipEventRecord(e1));
+                CK(hipDeviceSynchronize());
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                printf("  %s block %c: lds %zu occ %d  %8.1f us\n", form ? "attn_bwd_pl     " : "attn_bwd_fused16", blk ? 'b' : 'a', form ? lpl : l16, oc, ms * 1e3 / iters);
+                tot += ms * 1e3 / iters;
+            }
+            printf("%s pflags=%d p=%.2f Lq=%d: %8.1f us  %6.2f TFLOP/s (14 dh Lq T)\n", form ? "attn_bwd_pl     " : "attn_bwd_fused16", pflags, drop_p, Lq, tot,
+                   14.0 * DH * Lq * (La + Lb) * B * H / tot / 1e6);
+        }
+        return 0;
+    }
     printf("attn_fwd_pl pflags=%d p=%.2f Lq=%d lds=%zu occ=%d wg/CU: %8.1f us  %6.2f TFLOP/s  %6.0f GB/s (Q+K+V in, O fp32+planes out)\n", pflags, drop_p, Lq, lds, occ, us,
            fl / us / 1e6, bytes / us / 1e3);
     return 0;
