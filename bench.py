@@ -120,6 +120,15 @@ def parse_args():
 def relaunch(args):
     """--gpus N without a launcher: start torch.distributed.run as a CHILD process (before anything touches the GPU in this
     process -- a process that has initialised HIP must never exec), relay its JSON line and exit with its code."""
+    if args.backend == "nccl":
+        # fail HERE, loudly and before any GPU call, when the node does not have one GPU per rank (torch.cuda.device_count() does
+        # not initialise the HIP runtime on this image): RCCL ranks sharing a device would hang in the first collective
+        import torch
+        n_dev = torch.cuda.device_count()
+        if n_dev < args.gpus:
+            sys.stderr.write("bench.py: --gpus %d with the RCCL backend needs %d visible GPUs, this node shows %d "
+                             "(--backend gloo lets ranks share a GPU for a functional check)\n" % (args.gpus, args.gpus, n_dev))
+            sys.exit(2)
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -236,7 +245,9 @@ def cpu_baseline(args, w, h):
             sj = json.load(f)
         sweep = "; thread sweep on a %d-thread GPU-box host (%s, git %s): %s interactions/s" % (
             sj["host_threads"], sj["workload"], sj.get("git", "?"), ", ".join("%s threads %.1f" % (k, v) for k, v in sj["rows_per_s"].items()))
-    return {"value": round(Bc / med, 3), "unit": "interactions/s", "cores": cores, "kind": "port",
+    return {"value": round(Bc / med, 3), "unit": "interactions/s", "cores": cores, "kind": "port", "rows_timed": Bc,
+            "rows_of_workload": w["B"], "extrapolation": "value = rows_timed / median step time of a %d-row step; the workload's step has %d "
+            "rows per GPU (CPU time per row is flat in the batch size at these shapes: the step is GEMM-bound on the host too)" % (Bc, w["B"]),
             "sample": "median of %d timed steps (%d warm-up) of B=%d rows, same S/D/Lt/N, dropout 0.1, dead layers executed like the "
                       "reference, torch-CPU %d threads of %d host threads%s"
                       % (args.cpu_steps, args.cpu_warmup, Bc, cores, host, sweep or " (more threads ran slower on this box)")}
@@ -288,8 +299,8 @@ def main():
     if args.gpus > 1 and env_world != args.gpus:
         relaunch(args)
     real_stdout = _claim_stdout()
-    if args.gpus == 1 and env_world != 1:
-        raise SystemExit("--gpus 1 under a %d-rank launcher" % env_world)
+    if args.gpus != env_world:
+        raise SystemExit("--gpus %d under a %d-rank launcher (WORLD_SIZE): the two must agree" % (args.gpus, env_world))
     import torch
     world, rank, local_rank = env_world, int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
     n_dev = max(torch.cuda.device_count(), 1)
@@ -455,6 +466,7 @@ def main():
                        "rows_per_gpu": B, "global_batch": B * world, "segments": S, "feat_dim": D, "in_dim": Din, "user_tokens": Lt, "layers": N,
                        "parallelism": "dp%d" % world + (" (forced one-rank process group)" if forced_dp else ""),
                        "backend": args.backend if (world > 1 or forced_dp) else None,
+                       "backend_ranks": dist.get_world_size() if dist is not None else None,
                        "grad_allreduce_overlap": not args.no_overlap, "step_mode": record_note if record_note else ("hipGraph replay (device-side step state)" if args.graph else
                                      "recorded launch sequences replayed from C, one call per phase (device-side step state)" if args.recorded else
                                      "eager, device-side step state" if args.device_state else "eager"), "input_prefetch": bool(args.prefetch and len(batches) > 1),
@@ -468,16 +480,26 @@ def main():
         # table-gradient kernels as a sub-object priced against HBM
         adamw_roof = None
         if w["id_mode"]:
-            # algorithmic bytes per launch = 28 B per live parameter (p, g, m, v read; p, m, v written)
+            # Every optimizer launch of the instrumented steps is priced with what IT moves, over the UNION of the launches' intervals:
+            # with the two-pass table update (segmm_adamw_table) a step has three kinds of them -- the early pass over the rows
+            # without a gradient (24 B per element: p, m, v read and written; on the auxiliary stream, under the forward), the listed
+            # rows after the backward (28 B) and the dense rest (28 B per live parameter: p, g, m, v read; p, m, v written)
             opt = [(nb, e0, e1) for (name, nb, e0, e1) in kprof if name == "adamw"]
             if opt:
-                ms = sum(e0.elapsed_time(e1) for (_, e0, e1) in opt) / len(opt)
-                nbytes = opt[0][0]
+                base0 = opt[0][1]
+                ivs = [(base0.elapsed_time(e0), base0.elapsed_time(e1)) for (_, e0, e1) in opt]
+                ms = union_ms(ivs)
+                nbytes = sum(nb for (nb, _, _) in opt)
                 gbs = nbytes / (ms * 1e-3) / 1e9
-                adamw_roof = {"bound": "hbm", "kernel": "adamw (fused AdamW over the flat live range incl. the 352 k-row item table)",
+                adamw_roof = {"bound": "hbm", "kernel": "adamw + adamw_table (fused AdamW: early pass over the item table's rows without a gradient, "
+                                                        "listed rows, dense rest of the live range)",
                               "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
-                              "algorithmic_bytes_per_launch": int(nbytes), "ms_per_launch": round(ms, 4), "launches": len(opt),
-                              "note": "28 B per live parameter (p, g, m, v read; p, m, v written) / HIP-event duration of the launch"}
+                              "algorithmic_bytes_per_step": int(nbytes / psteps), "ms_per_step": round(ms / psteps, 4), "launches_per_step": len(opt) / psteps,
+                              "largest_launch": {"bytes": int(max(nb for nb, _, _ in opt)),
+                                                 "ms": round(max((e0.elapsed_time(e1), nb) for nb, e0, e1 in opt if nb == max(n_ for n_, _, _ in opt))[0], 4)},
+                              "note": "sum over the optimizer launches of the instrumented steps of the bytes each one moves / the length of the union of "
+                                      "their HIP-event intervals (the early table pass runs on the auxiliary stream beside the forward: its interval "
+                                      "includes the time it shares the HBM with the forward's kernels)"}
                 tab = [(name, nb, e0.elapsed_time(e1)) for (name, nb, e0, e1) in kprof if name != "adamw"]
                 by = {}
                 for name, nb, ms_ in tab:
@@ -538,6 +560,33 @@ def main():
                                        "peak = dense MFMA peak of the instruction used"
                                        + {"bf16x6": " / 6 partial products", "f16x3": " / 3 partial products", "f16x3p": " / 3 partial products", "f32": ""}[engine]
                                        + traffic_note}
+            # per kernel family, from the same instrumented pass: FLOPs / SUM of the launches' own durations (what a rocprofv3
+            # --stats average duration gives) -- comparable from round to round whatever the two-stream schedule does to the union
+            fam = {}
+            for (lay, M, Nn, K, e0, e1) in prof:
+                name = ("gemm_pl_" if lay >= 10 else "gemm_split_mfma/") + ("nt", "nn", "tn")[lay % 10] + ("8 (+ splitk_reduce share excluded)" if lay == 12 else "8" if lay >= 10 else "")
+                a = fam.setdefault(name, [0, 0.0, 0.0])
+                a[0] += 1
+                a[1] += 2.0 * M * Nn * K
+                a[2] += e0.elapsed_time(e1)
+            rec["roofline"]["per_kernel"] = [
+                {"kernel": k, "launches_per_step": round(v[0] / psteps, 2), "GF_per_step": round(v[1] / psteps / 1e9, 1),
+                 "avg_us": round(1e3 * v[2] / v[0], 1), "ms_per_step": round(v[2] / psteps, 4),
+                 "TFLOP/s": round(v[1] / (v[2] * 1e-3) / 1e12, 1), "frac": round(v[1] / (v[2] * 1e-3) / 1e12 / peak, 4)}
+                for k, v in sorted(fam.items(), key=lambda kv: -kv[1][2])]
+            if aprof:
+                afam = {}
+                for (kind_, B_, H_, dh_, Lq_, La_, Lb_, e0, e1) in aprof:
+                    fl = {"fwd": 4.0, "bwd": 14.0, "bwd1": 0.0, "bwd2": 6.0, "bwd3": 8.0, "bwd4": 10.0, "bwd4r": 0.0}[kind_] * dh_ * Lq_ * (La_ + Lb_) * B_ * H_
+                    a = afam.setdefault("attn_" + kind_, [0, 0.0, 0.0])
+                    a[0] += 1
+                    a[1] += fl
+                    a[2] += e0.elapsed_time(e1)
+                rec["roofline"]["per_kernel"] += [
+                    {"kernel": k, "launches_per_step": round(v[0] / psteps, 2), "GF_per_step": round(v[1] / psteps / 1e9, 2),
+                     "avg_us": round(1e3 * v[2] / v[0], 1), "ms_per_step": round(v[2] / psteps, 4),
+                     "TFLOP/s": round(v[1] / (v[2] * 1e-3) / 1e12, 1), "frac_of_f32_mfma_peak": round(v[1] / (v[2] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
+                    for k, v in sorted(afam.items(), key=lambda kv: -kv[1][2]) if v[2] > 0]
             if adamw_roof is not None:
                 rec["roofline"]["optimizer"] = adamw_roof
             if engine in ("f16x3", "f16x3p") and not args.no_probe:

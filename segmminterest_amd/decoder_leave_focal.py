@@ -99,7 +99,7 @@ class HeadLossFn(torch.autograd.Function):
             ctx.mark_non_differentiable(logits)
             return logits.new_zeros(()), logits.new_zeros(12), logits
         spec = model._loss_spec
-        gt = gt.contiguous().to(torch.int64)
+        gt = E._as(gt, torch.int64, "the labels")
         stats = model._label_stats(gt, B, S) if model._stats is None else model._stats
         if callable(stats):          # data-parallel: the all-gather was issued before the backbones; wait for it here
             stats = stats()
@@ -390,7 +390,7 @@ class MultiScaleTemporalDetrLeaveFocal(nn.Module):
             # collective and its rank skew hide under the forward instead of stalling every rank between forward and loss
             if self._loss_spec is None:
                 self._loss_spec = LossSpec(self.model_cfg)
-            gtc = gt.contiguous().to(torch.int64)
+            gtc = E._as(gt, torch.int64, "the labels")
             self._stats = pre if pre is not None else self._label_stats(gtc, gtc.shape[0], gtc.shape[1])
         self.__dict__.pop("_raw_pre", None)
         st.__dict__.pop("_head_dot", None)

@@ -976,8 +976,19 @@ def vq_tiles(L):
 
 
 def _mask_u8(m: torch.Tensor) -> torch.Tensor:
-    m = m.to(torch.bool).contiguous()
+    if m.dtype != torch.bool or not m.is_contiguous():
+        H.torch_fallback("the conversion of a %s mask to contiguous bool" % str(m.dtype).replace("torch.", ""))
+        m = m.to(torch.bool).contiguous()
     return m.view(torch.uint8)
+
+
+def _as(t: torch.Tensor, dtype, what: str) -> torch.Tensor:
+    """``t`` as a contiguous tensor of ``dtype`` -- zero-copy when it already is one (the recordable case)."""
+    if t.dtype != dtype or not t.is_contiguous():
+        H.torch_fallback("the conversion of %s (%s%s) to contiguous %s" % (what, str(t.dtype).replace("torch.", ""),
+                                                                       "" if t.is_contiguous() else ", strided", str(dtype).replace("torch.", "")))
+        t = t.contiguous().to(dtype)
+    return t
 
 
 # =============================================================================================== backbone
@@ -1067,14 +1078,14 @@ class BackboneRun:
         Yu0 = None
         fwd_side = st.overlap and st.fwd_side and not bb.id_usr and layered and self.mode != "self"
         if bb.id_usr:
-            uids = usr_feat.contiguous().to(torch.int64)
+            uids = _as(usr_feat, torch.int64, "the user ids")
             sv["usr_ids"] = uids
             H.embed_id_usr(uids, st.p(P + "usr_proj.weight"), d, st.p(P + "usr_pe.weight") if use_pe else None, pre_u, B)
             H.layernorm_fwd(pre_u, st.p(P + "usr_ln.weight"), st.p(P + "usr_ln.bias"), Eu.t, meu, reu, drop_p=p_drop, seed=seed,
                             site=_site(self.bi, 0, K_EMB_U), amax=Eu.slots, po=Eu.po)
             finish_act(st, produced(Eu))
         else:
-            xu = usr_feat.contiguous().float()
+            xu = _as(usr_feat, torch.float32, "the user features")
             Din_u = xu.shape[-1]
             sv["usr_x"] = self._input_act(xu, Mu, Din_u)
 
@@ -1095,7 +1106,7 @@ class BackboneRun:
         sv["pre_u"], sv["meu"], sv["reu"] = pre_u, meu, reu
         pre_v = _empty(ref, Mv, d)
         if bb.id_vid:
-            ids = vid_feat.contiguous().to(torch.int64)
+            ids = _as(vid_feat, torch.int64, "the item ids")
             sv["vid_ids"] = ids
             fpos = None
             if "noPos" in self.abl:      # a fresh shuffle of the segment positions per row and per call, from torch's CPU
@@ -1105,7 +1116,7 @@ class BackboneRun:
             H.embed_id_vid(ids, st.p(P + "vid_proj.weight"), d // 2, st.p(P + "frameid_proj.weight"),
                            st.p(P + "frameid_proj.bias"), st.p(P + "vid_pe.weight") if use_pe else None, pre_v, B, S, frame_pos=fpos)
         else:
-            x = vid_feat.contiguous().float()
+            x = _as(vid_feat, torch.float32, "the video features")
             Din = x.shape[-1]
             sv["vid_x"] = self._input_act(x, Mv, Din)
             _lin_fwd(st, Mv, d, Din, sv["vid_x"], P + "vid_proj.weight", pre_v, d,
@@ -1635,6 +1646,7 @@ def _argsort_ids(ids):
     ids = ids.reshape(-1).contiguous()
     if ids.numel() <= H.ARGSORT_MAX and ids.dtype == torch.int64:
         return H.argsort_ids(ids)
+    H.torch_fallback("the argsort of %d table ids (%s)" % (ids.numel(), str(ids.dtype).replace("torch.", "")))
     return torch.argsort(ids, stable=True).to(torch.int32)
 
 

@@ -184,6 +184,7 @@ class Recorder:
             self.streams[int(aux_stream)] = 2
         self.phases = []          # [kind, backbone, layer, [(op, slot, [(field, value)])]]
         self.keep = []            # host structs / arrays the recorded pointer arguments name
+        self.pslots = {}          # finish(): index in its result -> [(command, argument slot)] of the pointer arguments
         self.ops = op_ids()
 
     def mark(self, kind, backbone=0, layer=0):
@@ -242,10 +243,14 @@ class Recorder:
             if not cmds:          # (an empty fragment behind a callback)
                 continue
             arr = (Cmd * max(len(cmds), 1))()
-            for c, (op, slot, vals) in zip(arr, cmds):
+            pslots = []          # (command, argument slot) of every non-null POINTER argument: what a replay may re-base
+            for ci, (c, (op, slot, vals)) in enumerate(zip(arr, cmds)):
                 c.op, c.stream = op, slot
                 for k, (fld, v) in enumerate(vals):
                     setattr(c.a[k], fld, v)
+                    if fld == "p" and v:
+                        pslots.append((ci, k))
+            self.pslots[len(out)] = pslots
             ph = Phase(kind=kind, backbone=bb, layer=layer, n_cmds=len(cmds), cmds=C.cast(arr, C.POINTER(Cmd)))
             out.append((ph, arr))
         return out
@@ -267,6 +272,15 @@ class _RecLib:
             rec.call(name, args)
             return fn(*args)
         return call
+
+
+def torch_fallback(what):
+    """A torch kernel (dtype / layout conversion, sort, copy) is about to run inside the step: fine in an eager step, fatal
+    while the step is being recorded -- the launch would be missing from the replay, which would keep using the record-time
+    result without any error."""
+    if RECORDER is not None:
+        raise RuntimeError("record(): %s runs a torch kernel inside the step; a recorded step would silently drop it "
+                           "(pass bool masks, int64 ids / labels and contiguous fp32 features, at most %d ids per table lookup)" % (what, ARGSORT_MAX))
 
 
 def mark(kind, backbone=0, layer=0):

@@ -150,6 +150,7 @@ class FusedAdamW:
             if g is not None:
                 o, k = st.index[n]
                 if g.data_ptr() != base + 4 * o or not g.is_contiguous():
+                    H.torch_fallback("the copy of %s.grad into the flat gradient buffer" % n)
                     st.gflat[o:o + k].view(g.shape).copy_(g)
 
     def step_range(self, start, end, gbuf=None):
@@ -553,6 +554,14 @@ class Trainer:
         known from the batch's ids) are stepped after the backward as before, every other row now, with g = 0, on an auxiliary
         stream under the forward and backward, which never touch those rows.  (Data parallel: the listed rows are those of ALL
         ranks, known only after the row exchange -- the dense update stays.)"""
+        # a step that failed between this pass and opt.step() (forward / backward error, OOM) left its entry queued and its rows
+        # flagged: drop both before queueing this step's, or the table's range would be stepped twice and the failed batch's rows
+        # skipped (ADVICE r4)
+        stale = self.opt.__dict__.pop("_early", None)
+        if stale:
+            E.join_aux(self.model._store)
+            for _, _, _, _, _, flags in stale:
+                flags.zero_()
         if self.comm.active or not self.table_two_pass or self._param_hooks():
             return
         model, st = self.model, self.model._store
@@ -852,6 +861,14 @@ class Trainer:
         for k, v in batch.items():
             if torch.is_tensor(v) and not v.is_contiguous():
                 raise RuntimeError("record(): batch[%r] is not contiguous" % k)
+            # the zero-copy paths of the step: anything else is converted by a torch kernel, which a replay would drop (the
+            # conversions also raise by themselves while recording: hipabi.torch_fallback)
+            if torch.is_tensor(v) and v.is_floating_point() and v.dtype != torch.float32:
+                raise RuntimeError("record(): batch[%r] is %s; the recorded step takes fp32 features" % (k, v.dtype))
+            if torch.is_tensor(v) and k.endswith("_mask") and v.dtype != torch.bool:
+                raise RuntimeError("record(): batch[%r] is %s; the recorded step takes bool masks" % (k, v.dtype))
+            if torch.is_tensor(v) and not v.is_floating_point() and v.dtype not in (torch.bool, torch.int64):
+                raise RuntimeError("record(): batch[%r] is %s; the recorded step takes int64 ids and labels" % (k, v.dtype))
         # the step may name tensors of the PREVIOUS step's batch (id mode: the rows the last backward scattered into the table
         # gradient are cleared by id list): the last warm-up step runs on a copy of the batch, so that such pointers can be told
         # from the current batch's and re-based to the previous batch at replay
@@ -877,26 +894,22 @@ class Trainer:
         spans = [(k, v.data_ptr(), v.numel() * v.element_size(), tuple(v.shape), v.dtype) for k, v in batch.items() if torch.is_tensor(v) and v.numel()]
         pspans = [(k, v.data_ptr(), v.numel() * v.element_size()) for k, v in prev.items() if torch.is_tensor(v) and v.numel()]
         relocs = []
-        for ph, arr in phases:
+        for pi, (ph, arr) in enumerate(phases):
             if arr is None:
                 continue
-            for ci in range(ph.n_cmds):
-                c = arr[ci]
-                if c.op < 0:
-                    continue
-                for ai in range(H.CMD_MAX_ARGS):
-                    pv = c.a[ai].p
-                    if not pv:
-                        continue
-                    for k, base, nb, _, _ in spans:
+            # only the slots recorded as POINTER arguments (Recorder.pslots): an integer / float slot -- a seed, a byte count, the
+            # bit pattern of lr -- that happens to fall inside a batch tensor's address range must never be rewritten
+            for ci, ai in rec.pslots[pi]:
+                pv = arr[ci].a[ai].p
+                for k, base, nb, _, _ in spans:
+                    if base <= pv < base + nb:
+                        relocs.append((arr, ci, ai, k, pv - base, 0))
+                        break
+                else:
+                    for k, base, nb in pspans:
                         if base <= pv < base + nb:
-                            relocs.append((arr, ci, ai, k, pv - base, 0))
+                            relocs.append((arr, ci, ai, k, pv - base, 1))
                             break
-                    else:
-                        for k, base, nb in pspans:
-                            if base <= pv < base + nb:
-                                relocs.append((arr, ci, ai, k, pv - base, 1))
-                                break
         # host-side state of the eager path that names a batch tensor (id mode: the id list whose table-gradient rows the NEXT
         # backward clears): kept current by run_recorded, so that eager steps and recorded steps can be mixed
         tab_keys = []
@@ -910,7 +923,8 @@ class Trainer:
         streams = [main, side] + ([aux.cuda_stream] if aux is not None else [])
         self._recorded = dict(phases=phases, keep=rec.keep, pool=pool, prev_batch=batch, tab_keys=tab_keys, out=out, relocs=relocs, spans={k: (sh, dt) for k, _, _, sh, dt in spans},
                               main=main, events=evs, table=H.stream_table(streams, [e.cuda_event for e in evs[:2 * (len(streams) - 1)]]),
-                              n_cmds=sum(ph.n_cmds for ph, a in phases if a is not None))
+                              n_cmds=sum(ph.n_cmds for ph, a in phases if a is not None),
+                              hyper=(self.opt.lr, self.opt.wd, tuple(self.opt.betas), self.opt.eps))
         return out
 
     def run_recorded(self, batch: Dict[str, torch.Tensor]):
@@ -921,6 +935,10 @@ class Trainer:
             raise RuntimeError("run_recorded() before record()")
         if self.__dict__.get("_superseded", False):
             raise RuntimeError("this Trainer(device_state=True) was superseded by a later one")
+        if (self.opt.lr, self.opt.wd, tuple(self.opt.betas), self.opt.eps) != r["hyper"]:
+            # the recorded segmm_adamw / segmm_adamw_table commands carry lr, weight decay, betas and eps BY VALUE
+            raise RuntimeError("run_recorded(): the optimizer's hyperparameters changed since record() (%r -> %r): record() again"
+                               % (r["hyper"], (self.opt.lr, self.opt.wd, tuple(self.opt.betas), self.opt.eps)))
         for k, (sh, dt) in r["spans"].items():
             v = batch[k]
             if tuple(v.shape) != sh or v.dtype != dt or not v.is_contiguous():

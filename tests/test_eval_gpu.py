@@ -524,6 +524,59 @@ def test_recorded_step_equals_eager_device_state_step(kind, N, B, S, Lt, D, h):
 
 
 @pytest.mark.gpu
+def test_record_refuses_what_a_replay_would_drop():
+    """a recorded step replays C-ABI launches only, so record() must refuse every input whose handling needs a torch
+    kernel inside the step -- uint8 / float masks, int32 ids, fp16 features -- instead of freezing the record-time result; the
+    torch fallbacks themselves raise while a step is being recorded (argsort of more than ARGSORT_MAX ids); a change of the
+    optimizer's hyperparameters after record() makes run_recorded() refuse (they are recorded by value); and the relocation
+    table is built from pointer slots only."""
+    import torch
+    from segmminterest_amd import engine as E, hipabi as H
+    from segmminterest_amd.synth import make_batch
+    from segmminterest_amd.trainer import Trainer, default_args, init_model
+    dev = torch.device("cuda:0")
+    B, S, Lt, D = 16, 40, 10, 64
+    margs = default_args(num_layers_enc=2, d_model=D, nhead=4, input_type={"user": "image", "photo": "image"}, exposure_prob=[1.0] * S)
+    batch = {k: v.to(dev) for k, v in make_batch(B, S, Lt, D, n_users=50, n_items=500, seed=1).items()}
+    torch.manual_seed(3)
+    model = init_model(margs, n_users=50, n_items=500, input_dim=D, max_vid_len=S, max_usr_len=Lt).to(dev)
+    tr = Trainer(model, lr=1e-3, weight_decay=1e-4, device_state=True)
+    for key, bad in (("photo_mask", batch["photo_mask"].to(torch.uint8)), ("user_mask", batch["user_mask"].float()),
+                     ("photo_identity_id", batch["photo_identity_id"].to(torch.int32)), ("photo", batch["photo"].half())):
+        b2 = dict(batch)
+        b2[key] = bad
+        with pytest.raises(RuntimeError, match="record\\(\\)"):
+            tr.record(b2, warmup=1)
+        assert H.RECORDER is None
+    tr.train_step(batch)          # the refused record() calls left the trainer usable
+    # the fallbacks announce themselves while a recorder is installed
+    H.RECORDER = H.Recorder(H._stream(), 0)
+    try:
+        with pytest.raises(RuntimeError, match="argsort"):
+            E._argsort_ids(torch.arange(H.ARGSORT_MAX + 8, device=dev))
+        with pytest.raises(RuntimeError, match="mask"):
+            E._mask_u8(torch.ones(4, 4, dtype=torch.uint8, device=dev))
+        assert E._mask_u8(torch.ones(4, 4, dtype=torch.bool, device=dev)).dtype == torch.uint8          # zero-copy: fine
+    finally:
+        H.RECORDER = None
+    assert E._argsort_ids(torch.arange(H.ARGSORT_MAX + 8, device=dev)).numel() == H.ARGSORT_MAX + 8          # eager: torch's sort
+    tr.record(batch, warmup=2)
+    r = tr._recorded
+    kinds = set()
+    for arr, ci, ai, k, off, lag in r["relocs"]:
+        kinds.add(k)
+        assert arr[ci].a[ai].p == (batch if not lag else r["prev_batch"])[k].data_ptr() + off
+    assert {"photo", "user", "label"} <= kinds
+    tr.run_recorded(batch)
+    tr.opt.lr = 5e-4          # an LR schedule / a resumed checkpoint: the recorded AdamW launches carry the old value
+    with pytest.raises(RuntimeError, match="hyperparameters"):
+        tr.run_recorded(batch)
+    tr.record(batch, warmup=1)
+    tr.run_recorded(batch)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
 def test_adamw_table_two_passes_equal_dense_update():
     """segmm_adamw_table (main_for_seq_leave_earlystop_KuaiRand.py:259-261 / optimizer.step at :299 over an nn.Embedding table,
     encoder.py:352-362): phase 0 (rows without a gradient, g = 0, run early) + phase 1 (the batch's rows) leave BIT-IDENTICAL
