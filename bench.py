@@ -49,12 +49,6 @@ sys.path.insert(0, ROOT)
 # (head-of-line blocking: 7.5 % of the step on one GPU, measured with a forced one-rank process group; 2.4 % with 8 queues).
 # Must be set before the HIP runtime initialises, i.e. before torch is imported; inherited by the ranks bench.py launches.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-# --graph: ROCm 7.2's graph executor spreads the captured fork (main + side stream) over several queues by default and pays
-# more for the cross-queue dependencies than the overlap brings (config 4 at 256 rows: 3.74 ms per replayed step, 2.62 ms with
-# one queue, 2.45 ms eager on two streams; tools/probe/graph_env.sh).  Must be set before the HIP runtime initialises.
-if "--graph" in sys.argv:
-    os.environ.setdefault("DEBUG_HIP_FORCE_GRAPH_QUEUES", "1")
-
 PEAK_F32_MFMA_TFLOPS = 157.3          # v_mfma_f32_32x32x2_f32, MI355X_MICROARCH.md
 PEAK_BF16_MFMA_TFLOPS = 2500.0        # dense bf16 / fp16 MFMA, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0                 # HBM3E spec, MI355X_MICROARCH.md
@@ -93,11 +87,7 @@ def parse_args():
     ap.add_argument("--prefetch", action="store_true",
                     help="Trainer.train_step(batch, next_batch=...): the input stage (L1 normalisation / table gather) of the next batch runs on "
                          "its own stream under the current step.  Off by default: measured +0.2 %% (the GPU is saturated, the overlap buys nothing)")
-    ap.add_argument("--graph", action="store_true",
-                    help="single GPU: Trainer(device_state=True) -- dropout seed words, AdamW step count and the step's site headers live on "
-                         "the device -- and the timed steps are REPLAYS of one hipGraph capture of the step (Trainer.capture / replay): "
-                         "the host enqueues one graph launch + the batch copy per step.  --device-state alone runs the same step eagerly.")
-    ap.add_argument("--device-state", action="store_true", help="the device-state step without graph capture (A/B partner of --graph)")
+    ap.add_argument("--device-state", action="store_true", help="the device-state step enqueued launch by launch (A/B partner of the recorded step)")
     ap.add_argument("--recorded", action="store_true",
                     help="(the default step mode) Trainer(device_state=True).record() -- the step's launch sequence is recorded once and every "
                          "timed step is enqueued from C, one call per phase (segmm_step_begin, segmm_embed_fwd, segmm_layer_fwd, ... "
@@ -161,14 +151,10 @@ def _claim_stdout():
     return real
 
 
-def _graph_mode_legs(args):
-    """--graph / --device-state measure the step itself: the extra legs (second trainer on the f32 engine, host-fed inputs)
-    would rebuild the device-side step state under the first trainer."""
-    if not (args.eager or args.graph or args.device_state or args.prefetch):
+def _step_mode(args):
+    """The default step mode is the recorded step (--eager / --device-state / --prefetch choose another)."""
+    if not (args.eager or args.device_state or args.prefetch):
         args.recorded = True
-    if args.graph:
-        args.no_f32_engine = True
-        args.no_host_fed = True
     return args
 
 
@@ -294,7 +280,7 @@ def overlap_ms(a, b):
 
 
 def main():
-    args = _graph_mode_legs(parse_args())
+    args = _step_mode(parse_args())
     env_world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and env_world != args.gpus:
         relaunch(args)
@@ -343,7 +329,7 @@ def main():
             g = torch.Generator(device="cpu").manual_seed(99)
             table = ResidentFeatureTable(torch.rand((200000, Din), generator=g).to(dev))
         return model, Trainer(model, lr=1e-3, weight_decay=1e-4, comm=DPComm(), overlap=not args.no_overlap, feature_table=table,
-                              device_state=args.graph or args.device_state or args.recorded)
+                              device_state=args.device_state or args.recorded)
 
     model, trainer = build()
     batches = []
@@ -373,17 +359,11 @@ def main():
             nxt = batches[(start + i + 1) % len(batches)] if (args.prefetch and len(batches) > 1) else None
             if tr.__dict__.get("_recorded") is not None and hipabi.GEMM_PROFILE is None:
                 out = tr.run_recorded(batches[(start + i) % len(batches)])
-            elif tr._graph is not None and hipabi.GEMM_PROFILE is None:
-                out = tr.replay(batches[(start + i) % len(batches)])
             else:
                 out = tr.train_step(batches[(start + i) % len(batches)], next_batch=nxt)
             host_s.append(time.perf_counter() - h0)
         return out
 
-    if args.graph:
-        if world > 1 or args.prefetch:
-            raise SystemExit("--graph: single GPU, no prefetch")
-        trainer.capture(batches[0], warmup=max(args.warmup, 3))
     # ---- instrumented pass: steps with a HIP-event pair around every GEMM / attention / optimizer launch (recorded on the
     # launch's own stream), enqueued launch by launch.  Kept OUT of the timed region (the event pairs cost queue time) and, in the
     # default step mode, run BEFORE the step is recorded: it is the same launch sequence on the same two streams.
@@ -467,8 +447,7 @@ def main():
                        "parallelism": "dp%d" % world + (" (forced one-rank process group)" if forced_dp else ""),
                        "backend": args.backend if (world > 1 or forced_dp) else None,
                        "backend_ranks": dist.get_world_size() if dist is not None else None,
-                       "grad_allreduce_overlap": not args.no_overlap, "step_mode": record_note if record_note else ("hipGraph replay (device-side step state)" if args.graph else
-                                     "recorded launch sequences replayed from C, one call per phase (device-side step state)" if args.recorded else
+                       "grad_allreduce_overlap": not args.no_overlap, "step_mode": record_note if record_note else ("recorded launch sequences replayed from C, one call per phase (device-side step state)" if args.recorded else
                                      "eager, device-side step state" if args.device_state else "eager"), "input_prefetch": bool(args.prefetch and len(batches) > 1),
                        "final_loss": round(loss, 6), "replicas_identical": replicas_identical,
                        "delayed_scale_overflows": (model._store.overflow_count() if model._store.engine_p else None),

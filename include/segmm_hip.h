@@ -319,12 +319,18 @@ int segmm_adamw(float* p, const float* g, float* m, float* v, int64_t n, float l
 int segmm_adamw_table(float* p, const float* g, float* m, float* v, int64_t n_rows, int width, const int64_t* ids, int n_ids,
                       uint32_t* flags, float lr, float beta1, float beta2, float eps, float weight_decay, int step, int phase,
                       segmm_stream_t stream);
-/* Device-side step state, so that a whole training step (main_for_seq_leave_earlystop_SegMM.py:265-300) can be captured in a
- * hipGraph and replayed with unchanged kernel arguments: two dropout seed words and the optimizer's step count with its bias
- * corrections live in device memory.  segmm_step_set initialises them, segmm_step_advance (one thread; the first launch of a
+/* Device-side step state, so that a whole training step (main_for_seq_leave_earlystop_SegMM.py:265-300) can be replayed from its
+ * recorded launch sequences with unchanged kernel arguments: two dropout seed words and the optimizer's step count with its bias
+ * corrections live in device memory -- a struct of segmm_step_state_bytes() bytes in CALLER-OWNED, 16-byte aligned device memory
+ * that segmm_step_bind names for the calls that follow (host-side: each launch carries the pointer in its arguments, the library
+ * keeps no __device__ state; several trainers in one process bind their own state before they step).  With nothing bound (or
+ * segmm_step_bind(NULL)) the calls use one default state the library allocates on first use.  segmm_step_set initialises the
+ * bound state, segmm_step_advance (one thread; the first launch of a
  * step) increments the count, derives new seed words and the corrections 1 - beta^t, segmm_step_get reads them back (it
  * synchronises the stream).  A dropout seed argument with bit 63 set is "live": the kernel XORs the device words into it;
  * segmm_adamw with step == -1 takes the corrections from the device state. */
+int segmm_step_state_bytes(void);
+int segmm_step_bind(void* state);
 int segmm_step_set(uint64_t seed, int step, float beta1, float beta2, segmm_stream_t stream);
 int segmm_step_advance(float beta1, float beta2, segmm_stream_t stream);
 int segmm_step_get(uint64_t* seed, int* step, float* bias_corrections, segmm_stream_t stream);
@@ -369,6 +375,15 @@ int segmm_probe_mfma_rate(int workgroups, int iters, float* scratch, double* flo
  * env SEGMM_ATTN=f32|f16|f16all sets the initial value), 2 = fp16x3 wherever it is built.  Returns the previous mode; mode < 0
  * only queries.  Results of the two forms agree to ~1e-6 relative; both are deterministic. */
 int segmm_attn_mode(int mode);
+
+/* Tuning / A-B knobs of the library (tile shapes, kernel forms, probes that change occupancy -- none changes results beyond the
+ * documented equivalences).  They are read from the environment ONCE, at the first use of the library (SEGMM_<NAME>), and live
+ * in one table: segmm_config_dump writes "SEGMM_<NAME>=<value>  # what it selects" lines into buf (at most n bytes incl. the
+ * terminator) and returns the length the full listing needs; segmm_config_set changes a knob by its name (without the SEGMM_
+ * prefix) and returns its previous value, or a negative error code for an unknown name.  No launch path reads the environment.
+ * Timing probes whose results are wrong exist in -DSEGMM_ATT_PROBE / -DSEGMM_GEMM_PROBE builds only. */
+int segmm_config_set(const char* name, int value);
+int segmm_config_dump(char* buf, int n);
 
 /* (f)-3 SegRec weighted head (ClipRec.forward, SegRec/models/context/ClipRec.py:163-181): out[r] = sum_seg pred[r, seg] *
  * weight[r, seg] * (seg < duration[r]); weight == null: ones, duration == null: no duration mask. */

@@ -529,7 +529,10 @@ __global__ __launch_bounds__(768) void attn_fwd_lds_kernel(const AttnArgs p) {
             att_lds_dma16(rs, (char*)dst + (size_t)c0 * 16, vo, so);
         }
     };
-    if (!(p.pflags & 512)) {          // (timing probes, SEGMM_ATT_FWD_DBG: 256 = return after the staging, 512 = no staging; results wrong)
+#ifdef SEGMM_ATT_PROBE
+    if (!(p.pflags & 512))            // (timing probes of -DSEGMM_ATT_PROBE builds, SEGMM_ATT_FWD_DBG: 256 = return after the staging, 512 = no staging; results wrong)
+#endif
+    {
         stage(p.Ka, p.ka_bytes, p.La, La_p, p.ldka, sKa, cha);
         stage(p.Kb, p.kb_bytes, p.Lb, Lb_p, p.ldkb, sKb, chb);
         stage(p.Va, p.ka_bytes, p.La, La_p, p.ldka, sVa, cha);
@@ -538,7 +541,9 @@ __global__ __launch_bounds__(768) void attn_fwd_lds_kernel(const AttnArgs p) {
     stage_kmask(km, p.mka, p.mkb, b, p.La, p.Lb, La_p, Lb_p);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+#ifdef SEGMM_ATT_PROBE
     if (p.pflags & 256) return;
+#endif
 
     // ---- S^T tiles from LDS: acc[u][r] = sum_c K[16t + 4g + r][c] Q[query][c], t = ksp u + kg
     f32x4 acc[NT];

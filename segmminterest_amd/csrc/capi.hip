@@ -45,6 +45,19 @@ int segmm_fail(int code, const char* fmt, ...) {
 
 #define LAUNCH_CHECK() SEGMM_CHECK_HIP(hipGetLastError())
 
+// ---- device-side step state (common.h StepState): caller-owned, named by segmm_step_bind; the library's own default state
+// serves callers that never bind one (a single trainer per process)
+StepState* g_segmm_step = nullptr;
+static StepState* g_step_default = nullptr;
+StepState* segmm_step_current() {
+    if (g_segmm_step) return g_segmm_step;
+    if (!g_step_default) {
+        if (hipMalloc((void**)&g_step_default, sizeof(StepState)) != hipSuccess) return nullptr;
+        (void)hipMemset(g_step_default, 0, sizeof(StepState));
+    }
+    return g_step_default;
+}
+
 using namespace segmm;
 
 static int attn_fill(AttnArgs& a, int B, int H, int dh, int Lq, int La, int Lb, const float* Qa, const float* Qb, int ldq,
@@ -79,16 +92,76 @@ static int attn_fill(AttnArgs& a, int B, int H, int dh, int Lq, int La, int Lb, 
     return 0;
 }
 
-// SEGMM_ATTN=f32 keeps every attention kernel on the exact-fp32 matrix-core form (attention.h); default: the fp16x3 form
-// (attention16.h) where it is built (head dims 16, 32, 48) and measured faster
-static int g_attn_mode = -1;
-static int attn_f16() {          // 0: exact-fp32 kernels only; 1 (default): fp16x3 where it is faster; 2: fp16x3 wherever it is built
-    if (g_attn_mode < 0) g_attn_mode = !getenv("SEGMM_ATTN") ? 1 : !strcmp(getenv("SEGMM_ATTN"), "f32") ? 0 : !strcmp(getenv("SEGMM_ATTN"), "f16all") ? 2 : 1;
-    return g_attn_mode;
+// ---------------------------------------------------------------- tuning / A-B knobs
+// Every run-time choice of the library that is not an argument lives in ONE table: read from the environment once (first use of
+// the library; SEGMM_<NAME>), listed by segmm_config_dump, changed afterwards only through segmm_config_set -- no getenv on a
+// launch path.  Knobs whose non-default values give WRONG results (timing probes) do not exist in this build: they are compiled
+// in by -DSEGMM_ATT_PROBE / -DSEGMM_GEMM_PROBE only.
+enum {
+    K_ATTN, K_ATT_FWD_PL, K_ATT_FWD_LDS, K_ATT_FWD_KSPLIT, K_ATT_FWD_LDS_PAD, K_ATT_FUSED_LAUNCH, K_ATT_MERGE, K_ATT_LDS_PAD, K_ATT_WAVES,
+    K_ATT_HPB_FWD, K_ATT_HPB_DQ, K_ATT_HPB_DKV, K_L1NORM_REG, K_GEMM_BN, K_PL_VAR, K_PL_NJ, K_TN_VAR, K_COUNT
+};
+struct Knob { const char* name; int value; const char* doc; };
+static Knob g_knobs[K_COUNT] = {
+    {"ATTN", 1, "attention arithmetic: 0 (env: f32) exact-fp32 kernels only, 1 fp16x3 where measured faster, 2 (env: f16all) fp16x3 wherever built"},
+    {"ATT_FWD_PL", 1, "planes-in forward when the caller hands input planes (0: never)"},
+    {"ATT_FWD_LDS", 1, "LDS-DMA staged fp32 forward: 0 never, 1 heads with >= 4 query tiles, 2 wherever it fits"},
+    {"ATT_FWD_KSPLIT", 1, "staged forward: key-tile groups per query tile"},
+    {"ATT_FWD_LDS_PAD", 0, "probe: extra LDS bytes per forward workgroup (fewer workgroups per CU)"},
+    {"ATT_FUSED_LAUNCH", 2, "fused backward: 2 one launch per key block, 1 one launch for both"},
+    {"ATT_MERGE", 1, "short heads: one workgroup per head for both key blocks in the fused backward"},
+    {"ATT_LDS_PAD", 0, "probe: extra LDS bytes per backward workgroup"},
+    {"ATT_WAVES", 4, "fused fp16x3 backward: waves per workgroup (key tiles in passes)"},
+    {"ATT_HPB_FWD", 0, "forward workgroup shape heads | tiles << 8 (env: \"heads[,tiles]\"; 0: built-in)"},
+    {"ATT_HPB_DQ", 0, "dQ kernel workgroup shape, as above"},
+    {"ATT_HPB_DKV", 0, "dK/dV kernel workgroup shape, as above"},
+    {"L1NORM_REG", 1, "L1 normalisation with the row held in registers"},
+    {"GEMM_BN", 0, "on-the-fly GEMM: tile width override (0: built-in choice)"},
+    {"PL_VAR", 8, "plane NT GEMM: 8 gemm_pl_nt8 (round 3), 0-2 / 4 round-2 forms"},
+    {"PL_NJ", 0, "plane NT GEMM: tile width in 64-column units (0: modelled choice)"},
+    {"TN_VAR", 8, "plane TN GEMM: 8 gemm_pl_tn8 (round 3), 0 round-2 form"},
+};
+static bool g_knobs_ready = false;
+static void knobs_init() {
+    if (g_knobs_ready) return;
+    g_knobs_ready = true;
+    for (int k = 0; k < K_COUNT; ++k) {
+        char name[64];
+        snprintf(name, sizeof(name), "SEGMM_%s", g_knobs[k].name);
+        const char* e = getenv(name);
+        if (!e || !*e) continue;
+        if (k == K_ATTN) g_knobs[k].value = !strcmp(e, "f32") ? 0 : !strcmp(e, "f16all") ? 2 : 1;
+        else if (k == K_ATT_HPB_FWD || k == K_ATT_HPB_DQ || k == K_ATT_HPB_DKV) {
+            const char* c = strchr(e, ',');
+            g_knobs[k].value = (atoi(e) > 0 ? atoi(e) : 0) | ((c && atoi(c + 1) > 0 ? atoi(c + 1) : 0) << 8);
+        } else g_knobs[k].value = atoi(e);
+    }
+}
+static inline int knob(int k) { knobs_init(); return g_knobs[k].value; }
+int segmm_config_set(const char* name, int value) {
+    knobs_init();
+    for (int k = 0; k < K_COUNT; ++k)
+        if (!strcmp(name, g_knobs[k].name)) { const int prev = g_knobs[k].value; g_knobs[k].value = value; return prev; }
+    return segmm_fail(-1, "segmm_config_set: no knob named %s (see segmm_config_dump)", name);
+}
+int segmm_config_dump(char* buf, int n) {          // "NAME=value  # doc\n" per knob; returns the length needed (without the terminator)
+    knobs_init();
+    int need = 0;
+    for (int k = 0; k < K_COUNT; ++k) {
+        char line[320];
+        const int m = snprintf(line, sizeof(line), "SEGMM_%s=%d  # %s\n", g_knobs[k].name, g_knobs[k].value, g_knobs[k].doc);
+        if (buf && need + m < n) memcpy(buf + need, line, (size_t)m + 1);
+        need += m;
+    }
+    return need;
 }
 
+// SEGMM_ATTN=f32 keeps every attention kernel on the exact-fp32 matrix-core form (attention.h); default: the fp16x3 form
+// (attention16.h) where it is built (head dims 16, 32, 48) and measured faster
+static int attn_f16() { return knob(K_ATTN); }          // 0: exact-fp32 kernels only; 1 (default): fp16x3 where it is faster; 2: fp16x3 wherever it is built
+
 // workgroup shape for n row tiles per head: wq tiles x hpb adjacent heads, at most max_waves waves, every wave busy
-static void attn_shape(int n, int H, int max_waves, int want_default, const char* env, int& wq, int& hpb) {
+static void attn_shape(int n, int H, int max_waves, int want_default, int kn, int& wq, int& hpb) {
     wq = n;
     if (n > 5) {
         wq = 4;
@@ -96,12 +169,11 @@ static void attn_shape(int n, int H, int max_waves, int want_default, const char
             if (n % w == 0) { wq = w; break; }
     }
     hpb = 1;
-    const char* e = getenv(env);          // A/B knob (SEGMM_ATT_HPB_FWD / _DQ / _DKV = "heads[,tiles]")
+    const int e = knob(kn);          // A/B knob (SEGMM_ATT_HPB_FWD / _DQ / _DKV = "heads[,tiles]")
     int want = want_default;
-    if (e && atoi(e) > 0) {
-        want = atoi(e);
-        const char* c = strchr(e, ',');
-        if (c && atoi(c + 1) > 0 && atoi(c + 1) <= n) wq = atoi(c + 1);
+    if (e & 0xff) {
+        want = e & 0xff;
+        if ((e >> 8) > 0 && (e >> 8) <= n) wq = e >> 8;
     }
     for (int c = want; c >= 1; --c)
         if (H % c == 0 && c * wq <= max_waves) { hpb = c; break; }
@@ -113,8 +185,7 @@ template <int DH>
 static bool attn_fwd_pl_takes(const AttnArgs& a) {
     if constexpr (DH % 16 != 0) return false;
     else {
-        const char* e = getenv("SEGMM_ATT_FWD_PL");          // read per call: the tests switch forms inside one process
-        if (e && atoi(e) == 0) return false;
+        if (knob(K_ATT_FWD_PL) == 0) return false;
         const int nqt = (a.Lq + 15) / 16, T = a.La + a.Lb;
         return a.in.Qa && a.La % 4 == 0 && a.Lb % 4 == 0 && nqt <= ATT_PL_MAXW && T <= 16 * 12 &&
                attn_fwd_pl_lds_bytes<DH>(a.La, a.Lb) <= 160 * 1024 && (((uintptr_t)a.mka | (uintptr_t)a.mkb) & 3u) == 0;
@@ -137,7 +208,7 @@ static int attn_launch_fwd_pl(AttnArgs& a, hipStream_t s) {
             optin = true;
         }
 #ifdef SEGMM_ATT_PROBE
-        if (getenv("SEGMM_ATT_FWD_DBG")) a.pflags |= atoi(getenv("SEGMM_ATT_FWD_DBG")) & (256 | 512);          // timing probes (results wrong)
+        if (getenv("SEGMM_ATT_FWD_DBG")) a.pflags |= atoi(getenv("SEGMM_ATT_FWD_DBG")) & (256 | 512);          // timing probes (results wrong; probe builds only)
 #endif
         const dim3 grid(a.B * a.H), block(64 * nqt);
         if (hot) { if constexpr (DH == 48) hipLaunchKernelGGL((attn_fwd_pl_kernel<48, 9, 40, true>), grid, block, lds, s, a); }
@@ -155,7 +226,7 @@ static int attn_launch_fwd(AttnArgs& a, hipStream_t s) {
     const int Tp = ((a.La + 15) & ~15) + ((a.Lb + 15) & ~15);
     const int nqt = (a.Lq + 15) / 16;
     int wq, hpb;
-    attn_shape(nqt, a.H, 5, 1, "SEGMM_ATT_HPB_FWD", wq, hpb);          // measured: grouping heads does not pay in the forward
+    attn_shape(nqt, a.H, 5, 1, K_ATT_HPB_FWD, wq, hpb);          // measured: grouping heads does not pay in the forward
     // round 4: the LDS-DMA staged form (one workgroup per head: K / V of both key blocks staged once, every load of the head in
     // flight at once -- the staging alone runs at 5.7 TB/s) for heads with MORE than three query tiles: there one workgroup brings
     // enough waves (>= 4 per head, two heads per CU) to cover the per-wave instruction chains -- Lq = 100 (user queries of the full
@@ -164,21 +235,21 @@ static int attn_launch_fwd(AttnArgs& a, hipStream_t s) {
     // profiles/r4/attention_fwd_lds_pmc.txt -- against 233 us for the whole direct-load kernel at 3.3 waves per SIMD, and splitting
     // the key tiles over two or three wave groups per query tile (SEGMM_ATT_FWD_KSPLIT) does not change that: the direct form stays.
     // SEGMM_ATT_FWD_LDS=0 / 2: never / wherever it fits (A/B, tests).
-    const char* fwd_env = getenv("SEGMM_ATT_FWD_LDS");          // read per call: the tests switch forms inside one process
-    const int fwd_lds = fwd_env ? atoi(fwd_env) : 1;
+    const int fwd_lds = knob(K_ATT_FWD_LDS);
     if constexpr (DH >= 16) {
         const size_t lds2 = attn_fwd_lds_bytes<DH>(a.La, a.Lb);
         if ((fwd_lds == 2 || (fwd_lds == 1 && nqt >= 4)) && nqt <= 8 && lds2 <= 80 * 1024) {
             // key-tile groups per query tile (waves per head = nqt * ksp <= 12): more waves on the same staged K / V
-            const char* ksp_env = getenv("SEGMM_ATT_FWD_KSPLIT");
-            int ksp = ksp_env ? atoi(ksp_env) : 1;
+            int ksp = knob(K_ATT_FWD_KSPLIT);
             const int ntile = Tp / 16;
             if (ksp > ntile) ksp = ntile;
             if (ksp < 1 || nqt * ksp > 12) ksp = 1;
             const dim3 grid2(a.B * a.H), block2(64 * nqt * ksp);
             const size_t merge = ksp > 1 ? (size_t)nqt * ksp * (64 * 4 * ((DH + 15) / 16) + 128) * 4 : 0;          // partials of the key groups
             const size_t lds3 = lds2 > merge ? lds2 : merge;
-            if (getenv("SEGMM_ATT_FWD_DBG")) a.pflags |= atoi(getenv("SEGMM_ATT_FWD_DBG")) & (256 | 512);
+#ifdef SEGMM_ATT_PROBE
+            if (getenv("SEGMM_ATT_FWD_DBG")) a.pflags |= atoi(getenv("SEGMM_ATT_FWD_DBG")) & (256 | 512);          // timing probes (results wrong; probe builds only)
+#endif
             static bool lds_optin = false;          // dynamic LDS above 64 KB needs the opt-in, once per kernel
             if (!lds_optin) {
                 (void)hipFuncSetAttribute((const void*)attn_fwd_lds_kernel<DH, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -195,7 +266,7 @@ static int attn_launch_fwd(AttnArgs& a, hipStream_t s) {
     }
     a.hpb = hpb;
     dim3 grid(a.B * a.H / hpb, (nqt + wq - 1) / wq), block(64 * wq * hpb);       // one wave per 16-query tile of a head
-    static const int fpad = getenv("SEGMM_ATT_FWD_LDS_PAD") ? atoi(getenv("SEGMM_ATT_FWD_LDS_PAD")) : 0;      // probe: fewer workgroups per CU
+    const int fpad = knob(K_ATT_FWD_LDS_PAD);      // probe: fewer workgroups per CU
     const size_t lds = (size_t)Tp + (size_t)fpad;
     if (Tp <= 64) hipLaunchKernelGGL((attn_fwd_kernel<DH, 4>), grid, block, lds, s, a);
     else if (Tp <= 160) hipLaunchKernelGGL((attn_fwd_kernel<DH, 10>), grid, block, lds, s, a);
@@ -220,7 +291,7 @@ static int attn_launch_bwd(AttnArgs& a, int phase, hipStream_t s) {
         const int Lq_small = a.Lq <= 16 ? 16 : a.Lq <= 32 ? 32 : ATT_FUSED_QCHUNK;
         int Lq_p = ATT_FUSED_QCHUNK;
         SEGMM_REQUIRE(nta <= ATT_FUSED_MAXW && ntb <= ATT_FUSED_MAXW, "attn_bwd phase 4: built for <= 12 key tiles per block (%d + %d tiles)", nta, ntb);
-        static const int fmode_env = getenv("SEGMM_ATT_FUSED_LAUNCH") ? atoi(getenv("SEGMM_ATT_FUSED_LAUNCH")) : 2;
+        const int fmode_env = knob(K_ATT_FUSED_LAUNCH);
         // the repair pass is (almost always) a launch of workgroups that leave at once: one launch for both key blocks
         const int fmode = (a.pflags & ATT_REPAIR) ? 1 : fmode_env;
         const int nmax = nta > ntb ? nta : ntb;
@@ -228,9 +299,8 @@ static int attn_launch_bwd(AttnArgs& a, int phase, hipStream_t s) {
         // (p.hpb == 3, attention.h) -- the query side is staged once, one launch instead of two; bit-identical to the per-block
         // launches.  SEGMM_ATT_MERGE=0 restores them (A/B, tests)
         {
-            const char* me = getenv("SEGMM_ATT_MERGE");          // read per call: the tests switch forms inside one process
             const bool f16_takes_it = (DH % 16 == 0 && DH <= 48) && attn_f16() >= 2;
-            if ((!me || atoi(me) != 0) && phase == 4 && a.Lq <= 32 && nta > 0 && ntb > 0 && nta + ntb <= 4 && !f16_takes_it) {
+            if (knob(K_ATT_MERGE) != 0 && phase == 4 && a.Lq <= 32 && nta > 0 && ntb > 0 && nta + ntb <= 4 && !f16_takes_it) {
                 const int nw = nta + ntb;
                 a.hpb = 3;
                 const dim3 grid(a.B * a.H), block(64 * nw);
@@ -254,7 +324,7 @@ static int attn_launch_bwd(AttnArgs& a, int phase, hipStream_t s) {
             const bool one = a.Lq <= ATT_FUSED_QCHUNK;
             Lq_p = ATT_FUSED_QCHUNK;
             size_t lds = ((size_t)3 * Lq_p * (DH + 4) + 3 * Lq_p + (size_t)nw * 16 * 20 + 4 + 36 + (size_t)Lq_p * (DH / 4)) * 4 + Lq_p + Tp;
-            static const int lds_pad = getenv("SEGMM_ATT_LDS_PAD") ? atoi(getenv("SEGMM_ATT_LDS_PAD")) : 0;      // probe: fewer workgroups per CU
+            const int lds_pad = knob(K_ATT_LDS_PAD);      // probe: fewer workgroups per CU
             lds += (size_t)lds_pad;
             if constexpr (DH % 16 == 0 && DH <= 48) {
                 if (a.in.Qa) {          // round 5: Q / K / V from the projection GEMMs' planes (attention_pl.h); always in passes of <= 4 waves
@@ -277,7 +347,7 @@ static int attn_launch_bwd(AttnArgs& a, int phase, hipStream_t s) {
                 if (attn_f16() >= ((one && a.Lq > 32) ? 1 : 2)) {
                     // single chunk: at most `wcap` waves per workgroup, a wave walks its key tiles in passes (attention16.h) --
                     // the 7 tiles of a 100-key block as 4 waves x 2 passes, four workgroups per CU instead of two
-                    static const int wcap = getenv("SEGMM_ATT_WAVES") ? atoi(getenv("SEGMM_ATT_WAVES")) : 4;
+                    const int wcap = knob(K_ATT_WAVES);
 #ifdef SEGMM_ATT_PROBE
                     if (getenv("SEGMM_ATT_BWD_DBG")) a.pflags |= atoi(getenv("SEGMM_ATT_BWD_DBG")) & (1024 | 2048 | 4096);          // timing probes (results wrong)
 #endif
@@ -311,7 +381,7 @@ static int attn_launch_bwd(AttnArgs& a, int phase, hipStream_t s) {
     if (phase == 0 || phase == 2) {
         const int nqt = (a.Lq + 15) / 16;
         int wq, hpb;
-        attn_shape(nqt, a.H, 12, 1, "SEGMM_ATT_HPB_DQ", wq, hpb);
+        attn_shape(nqt, a.H, 12, 1, K_ATT_HPB_DQ, wq, hpb);
         a.hpb = hpb;
         dim3 grid(a.B * a.H / hpb, (nqt + wq - 1) / wq), block(64 * wq * hpb);
         if (Tp <= 64) hipLaunchKernelGGL((attn_bwd_dq_kernel<DH, 4>), grid, block, Tp, s, a);
@@ -322,10 +392,10 @@ static int attn_launch_bwd(AttnArgs& a, int phase, hipStream_t s) {
     if (phase == 0 || phase == 3) {
         const int nt = Tp / 16;
         int wq, hpb;
-        attn_shape(nt, a.H, 12, 1, "SEGMM_ATT_HPB_DKV", wq, hpb);
+        attn_shape(nt, a.H, 12, 1, K_ATT_HPB_DKV, wq, hpb);
         // small workgroups: at 3 waves/SIMD a CU holds 12 waves = six 2-wave groups, but only two 5-wave ones
         // (measured for 10 key tiles: 2 waves 533 us, 1 wave 544, 4 waves 611, 5 waves 722)
-        if (!getenv("SEGMM_ATT_HPB_DKV")) wq = nt >= 2 ? 2 : 1;
+        if (!knob(K_ATT_HPB_DKV)) wq = nt >= 2 ? 2 : 1;
         a.hpb = hpb;
         dim3 grid(a.B * a.H / hpb, (nt + wq - 1) / wq), block(64 * wq * hpb);   // one wave per 16-key tile of a head
         const int Lq_p = (a.Lq + 15) & ~15;
@@ -403,28 +473,27 @@ __global__ __launch_bounds__(512, 2) void mfma_rate_kernel(float* out, int iters
 }  // namespace segmm
 
 namespace segmm {
-__global__ void step_set_kernel(uint32_t lo, uint32_t hi, int step, float b1, float b2) {
-    g_step.seed_lo = lo; g_step.seed_hi = hi; g_step.step = step;
-    g_step.bc1 = step > 0 ? (float)(1.0 - pow((double)b1, (double)step)) : 1.f;
-    g_step.bc2_sqrt = step > 0 ? (float)sqrt(1.0 - pow((double)b2, (double)step)) : 1.f;
+__global__ void step_set_kernel(StepState* st, uint32_t lo, uint32_t hi, int step, float b1, float b2) {
+    st->seed_lo = lo; st->seed_hi = hi; st->step = step;
+    st->bc1 = step > 0 ? (float)(1.0 - pow((double)b1, (double)step)) : 1.f;
+    st->bc2_sqrt = step > 0 ? (float)sqrt(1.0 - pow((double)b2, (double)step)) : 1.f;
 }
-__global__ void step_advance_kernel(float b1, float b2) {
-    const int t = g_step.step + 1;
-    g_step.step = t;
-    const uint32_t lo = mix32(g_step.seed_lo + 0x9E3779B9u * (uint32_t)t);
-    g_step.seed_hi = mix32(g_step.seed_hi ^ lo ^ 0x85EBCA6Bu) & 0x7fffffffu;
-    g_step.seed_lo = lo;
-    g_step.bc1 = (float)(1.0 - pow((double)b1, (double)t));
-    g_step.bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, (double)t));
+__global__ void step_advance_kernel(StepState* st, float b1, float b2) {
+    const int t = st->step + 1;
+    st->step = t;
+    const uint32_t lo = mix32(st->seed_lo + 0x9E3779B9u * (uint32_t)t);
+    st->seed_hi = mix32(st->seed_hi ^ lo ^ 0x85EBCA6Bu) & 0x7fffffffu;
+    st->seed_lo = lo;
+    st->bc1 = (float)(1.0 - pow((double)b1, (double)t));
+    st->bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, (double)t));
 }
-__global__ void step_get_kernel(StepState* out) { *out = g_step; }
 }  // namespace segmm
 
 extern "C" {
 
 const char* segmm_last_error(void) { return g_segmm_err; }
 int segmm_abi_version(void) { return 26; }
-int segmm_attn_mode(int mode) { const int prev = attn_f16(); if (mode >= 0 && mode <= 2) g_attn_mode = mode; return prev; }
+int segmm_attn_mode(int mode) { const int prev = attn_f16(); if (mode >= 0 && mode <= 2) g_knobs[K_ATTN].value = mode; return prev; }
 
 static PlaneOut plane_out(uint16_t* planes, int ld2, float* hdr, const float* scale_in) {
     PlaneOut po;
@@ -442,7 +511,7 @@ int segmm_l1norm(const float* x, float* y, float* inv_scale, int64_t rows, int D
     SEGMM_REQUIRE(D > 0 && D % 4 == 0 && aligned16(x) && (!y || aligned16(y)), "l1norm: D %% 4 / alignment (D=%d)", D);
     if (rows <= 0) return 0;
     const int wpb = 4;
-    static const int reg_form = getenv("SEGMM_L1NORM_REG") ? atoi(getenv("SEGMM_L1NORM_REG")) : 1;
+    const int reg_form = knob(K_L1NORM_REG);
     const dim3 grid((unsigned)((rows + wpb - 1) / wpb)), block(64 * wpb);
 #define L1R(V) hipLaunchKernelGGL((l1norm_reg_kernel<V>), grid, block, 0, (hipStream_t)stream, x, y, inv_scale, (long long)rows, D, amax, plane_out(planes, ld2, hdr, scale_in))
     if (reg_form && D <= 256) L1R(1);
@@ -502,7 +571,7 @@ static int gemm_impl(int layout, int M, int N, int K, const float* A, int lda, c
     // transposed in registers) once it has >= 36 wide tiles -- measured on one box, same run: TN 1536x768x51200 634 -> 562 us,
     // TN 3072x768x20480 491 -> 470 us, but TN 768x768xK 139 -> 154 us and every NT shape (weights pre-split) 2-7 % slower
     // at the two workgroups per CU the wide tile allows.  SEGMM_GEMM_BN=128 / 256 forces one of them (A/B knob).
-    static const int bn_env = getenv("SEGMM_GEMM_BN") ? atoi(getenv("SEGMM_GEMM_BN")) : 0;
+    const int bn_env = knob(K_GEMM_BN);
     const bool wide = engine == 2 && !a_planes && N > 128 && bn_env != 128 &&
                       (bn_env == 256 || (layout == 2 && (long long)((M + 127) / 128) * ((N + 255) / 256) >= 36));
     const int BN = wide ? 256 : GBN;
@@ -659,7 +728,11 @@ int segmm_gemm_p(int layout, int M, int N, int K, const uint16_t* a_planes, int 
     q.A.p = (const _Float16*)a_planes; q.A.ld2 = lda2; q.A.hdr = a_hdr; q.A.f32 = a_f32; q.A.ldf = ldaf;
     q.B.p = (const _Float16*)b_planes; q.B.ld2 = ldb2; q.B.hdr = b_hdr; q.B.f32 = b_f32; q.B.ldf = ldbf;
     q.Cp = (_Float16*)c_planes; q.ldc2 = ldc2; q.c_hdr = c_hdr; q.c_scale_in = c_scale_in; q.write_c = C ? (write_c != 0) : 0;
-    static const int pl_flags = getenv("SEGMM_PL_FLAGS") ? atoi(getenv("SEGMM_PL_FLAGS")) : 0;
+#ifdef SEGMM_GEMM_PROBE
+    static const int pl_flags = getenv("SEGMM_PL_FLAGS") ? atoi(getenv("SEGMM_PL_FLAGS")) : 0;          // timing ablations (results wrong; probe builds only)
+#else
+    constexpr int pl_flags = 0;
+#endif
     q.dbg = pl_flags;
     hipStream_t s = (hipStream_t)stream;
     if (splits < 1) splits = 1;
@@ -672,7 +745,7 @@ int segmm_gemm_p(int layout, int M, int N, int K, const uint16_t* a_planes, int 
             SEGMM_REQUIRE(!residual && C, "gemm_p: accumulate and residual are exclusive");
             g.residual = C; g.ldr = ldc; g.res_period = M;
         }
-        static const int pl_var = getenv("SEGMM_PL_VAR") ? atoi(getenv("SEGMM_PL_VAR")) : 8;          // 8: gemm_pl_nt8 (round 3); 0-2, 4: round-2 forms (A/B)
+        const int pl_var = knob(K_PL_VAR);          // 8: gemm_pl_nt8 (round 3); 0-2, 4: round-2 forms (A/B)
 #ifdef SEGMM_STAMPS
         q.stamps = g_segmm_stamps;
 #endif
@@ -687,7 +760,7 @@ int segmm_gemm_p(int layout, int M, int N, int K, const uint16_t* a_planes, int 
                 // tile width 64 NJ: the one that needs the fewest CU-rounds.  Measured tile times at K = 768 (stand-alone, round 3):
                 // 60.7 / 49 / 38 us for NJ = 4 / 3 / 2 = 15 + 11.4 NJ us -- a narrower tile carries the same A traffic, prologue and
                 // barrier count for less work -- so it only wins when it saves a whole round or more; near-ties go to the widest tile
-                static const int nj_env = getenv("SEGMM_PL_NJ") ? atoi(getenv("SEGMM_PL_NJ")) : 0;
+                const int nj_env = knob(K_PL_NJ);
                 int best = 4;
                 if (nj_env >= 2 && nj_env <= 4) best = nj_env;
                 else {
@@ -753,7 +826,7 @@ int segmm_gemm_p(int layout, int M, int N, int K, const uint16_t* a_planes, int 
     }
     q.colsum_out = colsum_out;
     // round-3 form (gemm_planes8.h): whole 256 x 256 tiles, plain or split-K stores (no accumulate into C), 32-bit output offsets
-    static const int tn_var = getenv("SEGMM_TN_VAR") ? atoi(getenv("SEGMM_TN_VAR")) : 8;
+    const int tn_var = knob(K_TN_VAR);
     const bool tn8 = tn_var == 8 && M % PBM == 0 && N % PBN == 0 && !g.residual && (long long)M * (splits > 1 ? N : ldc) * 4 < (1ll << 31);
     if (tn8) hipLaunchKernelGGL(gemm_pl_tn8, dim3(g.nbm * g.nbn, 1, splits), dim3(512), 0, s, g, q);
     else hipLaunchKernelGGL(gemm_pl_tn<0>, dim3(g.nbm * g.nbn, 1, splits), dim3(512), 0, s, g, q);
@@ -1264,7 +1337,7 @@ int segmm_adamw(float* p, const float* g, float* m, float* v, int64_t n, float l
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)n, lr, beta1,
-                       beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), step < 0 ? 1 : 0);
+                       beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), step < 0 ? (const StepState*)segmm_step_current() : (const StepState*)nullptr);
     LAUNCH_CHECK();
     return 0;
 }
@@ -1288,36 +1361,44 @@ int segmm_adamw_table(float* p, const float* g, float* m, float* v, int64_t n_ro
         long long blocks = (n_rows * w4 + 255) / 256;
         if (blocks > 4096) blocks = 4096;
         hipLaunchKernelGGL(adamw_table_rest_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, m, v, (long long)n_rows, w4, (const unsigned int*)flags,
-                           lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), step < 0 ? 1 : 0);
+                           lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), step < 0 ? (const StepState*)segmm_step_current() : (const StepState*)nullptr);
         LAUNCH_CHECK();
         return 0;
     }
     if (n_ids == 0) return 0;
     hipLaunchKernelGGL(adamw_table_rows_kernel, dim3((n_ids + 3) / 4), dim3(256), 0, s, p, g, m, v, (long long)n_rows, w4, (const long long*)ids, n_ids,
-                       flags, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), step < 0 ? 1 : 0);
+                       flags, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), step < 0 ? (const StepState*)segmm_step_current() : (const StepState*)nullptr);
     LAUNCH_CHECK();
     return 0;
 }
 
+int segmm_step_state_bytes(void) { return (int)sizeof(StepState); }
+int segmm_step_bind(void* state) {
+    SEGMM_REQUIRE(!state || aligned16(state), "step_bind: the state must be 16-byte aligned device memory");
+    g_segmm_step = (StepState*)state;
+    return 0;
+}
 int segmm_step_set(uint64_t seed, int step, float beta1, float beta2, segmm_stream_t stream) {
     SEGMM_REQUIRE(step >= 0, "step_set: step=%d", step);
-    hipLaunchKernelGGL(step_set_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (uint32_t)seed, (uint32_t)(seed >> 32) & 0x7fffffffu, step, beta1, beta2);
+    StepState* st = segmm_step_current();
+    SEGMM_REQUIRE(st, "step_set: no step state");
+    hipLaunchKernelGGL(step_set_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, st, (uint32_t)seed, (uint32_t)(seed >> 32) & 0x7fffffffu, step, beta1, beta2);
     LAUNCH_CHECK();
     return 0;
 }
 int segmm_step_advance(float beta1, float beta2, segmm_stream_t stream) {
-    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, beta1, beta2);
+    StepState* st = segmm_step_current();
+    SEGMM_REQUIRE(st, "step_advance: no step state");
+    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, st, beta1, beta2);
     LAUNCH_CHECK();
     return 0;
 }
 int segmm_step_get(uint64_t* seed, int* step, float* bias_corrections, segmm_stream_t stream) {
-    StepState* d = nullptr;
+    const StepState* st = segmm_step_current();
+    SEGMM_REQUIRE(st, "step_get: no step state");
     StepState h;
-    SEGMM_CHECK_HIP(hipMalloc(&d, sizeof(StepState)));
-    hipLaunchKernelGGL(step_get_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, d);
-    hipError_t e = hipMemcpyAsync(&h, d, sizeof(StepState), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    hipError_t e = hipMemcpyAsync(&h, st, sizeof(StepState), hipMemcpyDeviceToHost, (hipStream_t)stream);
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
-    (void)hipFree(d);
     SEGMM_CHECK_HIP(e);
     if (seed) *seed = ((uint64_t)h.seed_hi << 32) | h.seed_lo;
     if (step) *step = h.step;

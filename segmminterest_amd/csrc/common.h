@@ -40,17 +40,22 @@ struct DropCfg {
     uint32_t thresh;      // keep iff r16 >= thresh, thresh = round(p * 65536)
     uint32_t seed_lo, seed_hi;
     uint32_t site;        // distinct per dropout site in the model
-    uint32_t live;        // != 0: the seed is XORed with the DEVICE-side step words (g_step) when the kernel starts
+    uint32_t live;        // != 0: the seed is XORed with the DEVICE-side step words (*st) when the kernel starts
+    const struct StepState* st;          // the step state bound when the launch was made (segmm_step_bind); null unless live
 };
 
 // ---- device-side step state.  A training step captured in a hipGraph replays the SAME kernel arguments every step, so what
 // must change from step to step lives in device memory and is advanced by a one-thread kernel at the head of the step
 // (segmm_step_advance): two seed words for the dropout streams (kernels launched with a "live" seed -- bit 63 of the seed
 // argument -- XOR them into their seed) and AdamW's bias corrections (segmm_adamw with step < 0 reads them).
-struct StepState { uint32_t seed_lo, seed_hi; int step; float bc1, bc2_sqrt; };
-static __device__ StepState g_step;
+// The state is a small struct in CALLER-OWNED device memory (segmm_step_state_bytes; segmm_step_bind names the one the following
+// launches use -- two trainers in one process each bind their own before they step); with nothing bound the library falls back to
+// one default state of its own.  The pointer travels inside the launch's arguments: no __device__ global.
+struct StepState { uint32_t seed_lo, seed_hi; int step; float bc1, bc2_sqrt; uint32_t pad_[3]; };
+extern StepState* g_segmm_step;          // host: the bound state (capi.hip)
+StepState* segmm_step_current();         // host: the bound state, or the library's default one (allocated on first use)
 __device__ __forceinline__ DropCfg drop_live(DropCfg d) {
-    if (d.live) { d.seed_lo ^= g_step.seed_lo; d.seed_hi ^= g_step.seed_hi; }
+    if (d.live) { d.seed_lo ^= d.st->seed_lo; d.seed_hi ^= d.st->seed_hi; }
     return d;
 }
 
@@ -92,6 +97,7 @@ static inline DropCfg make_drop(float p, uint64_t seed, uint32_t site) {
     d.seed_hi = (uint32_t)(seed >> 32) & 0x7fffffffu;
     d.site = site;
     d.live = (uint32_t)(seed >> 63);
+    d.st = d.live ? segmm_step_current() : nullptr;
     return d;
 }
 

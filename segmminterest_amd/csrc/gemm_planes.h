@@ -44,6 +44,13 @@ struct PGemmX {
     unsigned long long* stamps;                // SEGMM_STAMPS builds only (tools/probe/gemm_stamps.py): 8 x u64 per workgroup
 };
 
+// timing ablations of the plane GEMMs (PGemmX::dbg; results wrong): compiled in by -DSEGMM_GEMM_PROBE only
+#ifdef SEGMM_GEMM_PROBE
+#define SEGMM_GEMM_DBG(q) ((q).dbg)
+#else
+#define SEGMM_GEMM_DBG(q) 0
+#endif
+
 constexpr int PBM = 256, PBN = 256, PBK = 32;
 constexpr int PSTAGE = (PBM + PBN) * 128;      // bytes per stage
 
@@ -129,7 +136,7 @@ __device__ __forceinline__ void epi_strip_emit(const GemmArgs& p, const PGemmX& 
                     v += *(const f32x4*)(p.residual + (size_t)rr * p.ldr + gn);
                 }
             }
-            if ((SPLITK || q.write_c) && !(q.dbg & 1)) {
+            if ((SPLITK || q.write_c) && !(SEGMM_GEMM_DBG(q) & 1)) {
 #if SEGMM_NT_STORES
                 if (!SPLITK) __builtin_nontemporal_store(v, (f32x4*)(Cout + (size_t)gm * p.ldc + gn));
                 else
@@ -367,7 +374,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_nt(const GemmArgs p, const PGe
     const float inv_ab = (1.f / sa) * (1.f / sb);          // exact powers of two
     const float c_scale = (q.Cp && q.c_scale_in) ? *q.c_scale_in : 0.f;
     float am = 0.f;
-    if (q.dbg & 2) {
+    if (SEGMM_GEMM_DBG(q) & 2) {
         float t = 0.f;          // keeps every accumulator alive (no dead-code elimination of MFMAs)
 #pragma unroll
         for (int i = 0; i < 4; ++i)

@@ -293,7 +293,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_nt8(const GemmArgs p, const PG
     // is for pieces that sit in front of stores issued a quarter earlier at least.  No extra operand: no loads, no waits, no
     // barriers.  Registers: none (the ring of prefetched rows it replaces spilled).
     float am = 0.f;
-    if (q.dbg & 2) {
+    if (SEGMM_GEMM_DBG(q) & 2) {
         float t = 0.f;          // timing ablation: keep every accumulator alive, skip the epilogue
 #pragma unroll
         for (int i = 0; i < 8; ++i)
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_nt8(const GemmArgs p, const PG
         const DropCfg drop_e = drop_live(p.drop);
         const bool aux_r = epi == EPI_DGELU || epi == EPI_DRELU, aux_w = epi == EPI_GELU;
         const bool planes = c_scale > 0.f && q.Cp != nullptr;
-        const bool store_c = q.write_c && !(q.dbg & 1);
+        const bool store_c = q.write_c && !(SEGMM_GEMM_DBG(q) & 1);
         const bool periodic = has_res && p.res_period < p.M;
         const int res_rows = has_res ? min(p.res_period, p.M) : 0;
         const bool has_e = has_res || aux_r;

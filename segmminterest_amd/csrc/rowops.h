@@ -538,8 +538,8 @@ __device__ __forceinline__ void adamw_elem4(f32x4& pp, const f32x4 gg, f32x4& mm
 // torch.optim.AdamW single-tensor update order (decoupled decay first), bias corrections passed in.
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                              float* __restrict__ v, long long n, float lr, float b1, float b2, float eps, float wd,
-                             float bc1, float bc2_sqrt, int live) {
-    if (live) { bc1 = g_step.bc1; bc2_sqrt = g_step.bc2_sqrt; }          // bias corrections of the device-side step count
+                             float bc1, float bc2_sqrt, const StepState* live) {
+    if (live) { bc1 = live->bc1; bc2_sqrt = live->bc2_sqrt; }          // bias corrections of the device-side step count
     const long long n4 = n >> 2;
     const float step = lr / bc1;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
@@ -569,8 +569,8 @@ __global__ __launch_bounds__(256) void table_mark_kernel(const long long* __rest
 // every row WITHOUT a mark, g = 0
 __global__ __launch_bounds__(256) void adamw_table_rest_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, long long n_rows,
                                                                int w4, const unsigned int* __restrict__ flags, float lr, float b1, float b2,
-                                                               float eps, float wd, float bc1, float bc2_sqrt, int live) {
-    if (live) { bc1 = g_step.bc1; bc2_sqrt = g_step.bc2_sqrt; }
+                                                               float eps, float wd, float bc1, float bc2_sqrt, const StepState* live) {
+    if (live) { bc1 = live->bc1; bc2_sqrt = live->bc2_sqrt; }
     const float step = lr / bc1;
     const long long n4 = n_rows * w4;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -585,8 +585,8 @@ __global__ __launch_bounds__(256) void adamw_table_rest_kernel(float* __restrict
 __global__ __launch_bounds__(256) void adamw_table_rows_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                                float* __restrict__ v, long long n_rows, int w4, const long long* __restrict__ ids,
                                                                int n_ids, unsigned int* __restrict__ flags, float lr, float b1, float b2, float eps,
-                                                               float wd, float bc1, float bc2_sqrt, int live) {
-    if (live) { bc1 = g_step.bc1; bc2_sqrt = g_step.bc2_sqrt; }
+                                                               float wd, float bc1, float bc2_sqrt, const StepState* live) {
+    if (live) { bc1 = live->bc1; bc2_sqrt = live->bc2_sqrt; }
     const float step = lr / bc1;
     const int lane = threadIdx.x & 63;
     const int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);

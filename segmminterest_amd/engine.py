@@ -243,9 +243,9 @@ class ParamStore:
     HDR_RING_ROWS = 8192
 
     def hdr_step_begin(self):
-        """Step-arena mode (Trainer(device_state=True): the step may be replayed from a hipGraph, so every step must use the
+        """Step-arena mode (Trainer(device_state=True): the step is replayed from its recorded launch sequences, so every step must use the
         SAME header rows): hand the rows out from row 0 of the ARENA again and clear what the previous step used -- one fill
-        launch per step, inside the graph.  The arena is only active until ``hdr_step_end`` (the end of train_step): evaluation
+        launch per step, inside the step.  The arena is only active until ``hdr_step_end`` (the end of train_step): evaluation
         passes between training steps draw from the wrapping ring below, which recycles its rows (a validation round
         of >~100 batches used to exhaust the arena)."""
         if self.flat is None:

@@ -34,7 +34,11 @@ SIGNATURES = {
     "segmm_scales_update": [_p, _p, _i, _p, _p, _i, _p, _p, _p],
     "segmm_probe_mfma_rate": [_i, _i, _p, _p, _p],
     "segmm_attn_mode": [_i],
+    "segmm_config_set": [_p, _i],
+    "segmm_config_dump": [_p, _i],
     "segmm_site_fixup": [_p, _p, _p, _p, _p, _p],
+    "segmm_step_bind": [_p],
+    "segmm_step_state_bytes": [],
     "segmm_step_set": [_u64, _i, _f, _f, _p],
     "segmm_step_advance": [_f, _f, _p],
     "segmm_step_get": [_p, _p, _p, _p],
@@ -583,6 +587,16 @@ def scales_update(arena, site_idx, n_rows, site_scale, stats, target=12, gain=No
 LIVE_SEED = 1 << 63          # dropout seed argument bit: XOR the device-side step words into the seed (segmm_step_advance)
 
 
+def step_state_bytes():
+    return int(lib().segmm_step_state_bytes())
+
+
+def step_bind(state):
+    """``segmm_step_bind``: the device-side step state (a caller-owned device tensor of step_state_bytes() bytes, or None: the
+    library's own default state) that the launches which follow use -- the pointer travels in their arguments."""
+    _check(_lib_real().segmm_step_bind(None if state is None else state.data_ptr()), "segmm_step_bind")
+
+
 def step_set(seed, step, beta1=0.9, beta2=0.999):
     _check(lib().segmm_step_set(int(seed) & (2 ** 63 - 1), int(step), float(beta1), float(beta2), _stream()), "segmm_step_set")
 
@@ -597,6 +611,27 @@ def step_get():
     seed, step, bc = ctypes.c_uint64(0), ctypes.c_int(0), (ctypes.c_float * 2)()
     _check(lib().segmm_step_get(ctypes.addressof(seed), ctypes.addressof(step), ctypes.addressof(bc), _stream()), "segmm_step_get")
     return int(seed.value), int(step.value), (float(bc[0]), float(bc[1]))
+
+
+def config_set(name, value):
+    """``segmm_config_set``: set the tuning knob ``name`` (without the SEGMM_ prefix; see :func:`config_dump`); returns the previous value."""
+    r = int(lib().segmm_config_set(name.encode(), int(value)))
+    if r < 0 and name not in config_dump():
+        _check(r, "segmm_config_set")
+    return r
+
+
+def config_dump():
+    """{knob name: (value, doc)} of the library's tuning table (``segmm_config_dump``)."""
+    n = int(lib().segmm_config_dump(None, 0)) + 1
+    buf = C.create_string_buffer(n)
+    lib().segmm_config_dump(buf, n)
+    out = {}
+    for ln in buf.value.decode().splitlines():
+        k, rest = ln.split("=", 1)
+        v, doc = rest.split("#", 1)
+        out[k.replace("SEGMM_", "", 1)] = (int(v), doc.strip())
+    return out
 
 
 def attn_mode(mode=-1):

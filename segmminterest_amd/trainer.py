@@ -22,7 +22,6 @@ import functools
 from typing import Dict, List, Optional
 
 import os
-import weakref
 
 import torch
 import torch.nn as nn
@@ -197,6 +196,7 @@ class FusedAdamW:
         g = sd["param_groups"][0]
         self.lr, self.wd, self.betas, self.eps = g["lr"], g["weight_decay"], tuple(g["betas"]), g["eps"]
         if self.__dict__.get("device_state", False):          # the device-side step count (bias corrections) follows the checkpoint
+            H.step_bind(self._step_state)
             seed, _, _ = H.step_get()
             H.step_set(seed, self.step_count, *self.betas)
 
@@ -386,17 +386,15 @@ class Trainer:
     the reference's hot loop (main_for_seq_leave_earlystop_SegMM.py:269-300) minus its host syncs.
     Gradient clipping is a no-op in the reference (exhausted generator at :298) and is therefore absent."""
 
-    _device_state_owner = None          # weakref to the Trainer(device_state=True) that owns the process-global device step state
 
     def __init__(self, model, lr=1e-3, weight_decay=1e-4, comm: Optional[DPComm] = None, overlap=True, dropout=True,
                  feature_table=None, sparse_tables=True, device_state=False):
         self.model = model
         # device_state: what changes from step to step (dropout seed words, AdamW's step count and bias corrections, the
         # site-header rows of a step) lives on the device / is laid out per step, so the kernel arguments of a step never
-        # change and ``capture()`` can record one step in a hipGraph that ``replay()`` launches with ~0 host work.  The
-        # eager step in this mode and its replay are bit-identical.
+        # change and ``record()`` can note its launch sequence once for ``run_recorded()`` to replay from C.  The eager step in
+        # this mode and the recorded step are bit-identical.
         self.device_state = bool(device_state)
-        self._graph = None
         # SURVEY.md §8(f)-1: with a device-resident feature table the batch carries INDEX lists ("photo_idx" [B, S],
         # "user_idx" [B, Lt], -1 = padding) instead of feature tensors; gather + pad + mask + L1 normalisation is one
         # HBM-bound kernel (segmm_gather_l1) and the 573 KB/row host->device copy disappears
@@ -431,12 +429,11 @@ class Trainer:
         self._pf_stream = None
         self._norm_fresh = False
         if self.device_state:
-            # the device step state (seed words, step count) is ONE process-global __device__ struct: a second device_state
-            # trainer takes it over, the first one must not step any more (it would silently run on the other's seed and count)
-            prev = Trainer._device_state_owner
-            if prev is not None and prev() is not None and prev() is not self:
-                prev()._superseded = True
-            Trainer._device_state_owner = weakref.ref(self)
+            # the device step state (seed words, step count, bias corrections) is a small struct in memory THIS trainer owns
+            # (segmm_step_bind names it for the launches that follow): several device_state trainers coexist in one process
+            self._step_state = torch.zeros((H.step_state_bytes() + 3) // 4, dtype=torch.int32, device=next(model.parameters()).device)
+            H.step_bind(self._step_state)
+            self.opt._step_state = self._step_state
             self.opt.device_state = True
             seed0 = int(torch.randint(0, 2 ** 62, (1,)).item())          # torch.manual_seed -> reproducible runs
             if self.comm.rank:          # data-parallel ranks seed torch identically: every rank drops different elements of its rows
@@ -703,9 +700,8 @@ class Trainer:
         """One optimisation step on ``batch``.  ``next_batch``: the batch of the FOLLOWING step, if known -- its input stage is
         enqueued on a side stream right away (:meth:`prefetch`) and overlaps this step's backward."""
         model, st = self.model, self.model._store
-        if self.__dict__.get("_superseded", False):
-            raise RuntimeError("this Trainer(device_state=True) was superseded by a later one: the device-side step state is "
-                               "process-global (one device_state trainer per process)")
+        if self.device_state:
+            H.step_bind(self._step_state)          # (a host-side pointer: the launches below carry it in their arguments)
         if model.training != bool(self.dropout):
             model.train(self.dropout)          # (walks every sub-module: 0.35 ms of host time when done every step)
         self.opt.zero_grad()
@@ -799,42 +795,6 @@ class Trainer:
             E.join_aux(st)          # the tables' first pass (aux stream) is complete before their listed rows are stepped
         self.opt.step()
         return out
-
-    # ---- hipGraph capture of the whole step (device_state mode)
-    def capture(self, batch: Dict[str, torch.Tensor], warmup: int = 3):
-        """Record one training step on ``batch``'s shapes in a hipGraph.  The batch is copied into static device buffers;
-        ``warmup`` eager steps run first (site scales calibrated, every scratch buffer allocated, both streams created), then
-        the step is captured -- capturing does not execute it.  ``replay(batch)`` copies a batch into the static buffers and
-        launches the graph: one host call per step."""
-        if not self.device_state:
-            raise RuntimeError("capture() needs Trainer(device_state=True)")
-        if self.comm.active:
-            raise RuntimeError("capture(): the data-parallel step issues its collectives from Python; use record() / run_recorded()")
-        self._static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
-        for _ in range(max(warmup, 1)):
-            self.train_step(self._static)
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self._static_out = self.train_step(self._static)
-        self.opt.step_count -= 1          # the captured call ran the host bookkeeping of a step that was recorded, not executed
-        self._graph = g
-        return self._static_out
-
-    def replay(self, batch: Optional[Dict[str, torch.Tensor]] = None):
-        if self._graph is None:
-            raise RuntimeError("replay() before capture()")
-        if batch is not None and batch is not self._static:
-            for k, v in batch.items():
-                if torch.is_tensor(v):
-                    self._static[k].copy_(v, non_blocking=True)
-        self._graph.replay()
-        # mirror EVERY host side effect of the eager step: the graph rewrote the weights (AdamW) and re-split the planes at the
-        # head of the step, so the planes are one optimizer step behind the weights again -- the next ensure() outside the
-        # graph (an evaluation pass) must re-split them (ADVICE r3)
-        self.opt.step_count += 1
-        self.model._store.fused_version += 1
-        return self._static_out
 
     # ---- the step as recorded launch sequences replayed from C (include/segmm_hip.h "Recorded launch sequences")
     def record(self, batch: Dict[str, torch.Tensor], warmup: int = 3):
@@ -933,8 +893,7 @@ class Trainer:
         r = self.__dict__.get("_recorded")
         if r is None:
             raise RuntimeError("run_recorded() before record()")
-        if self.__dict__.get("_superseded", False):
-            raise RuntimeError("this Trainer(device_state=True) was superseded by a later one")
+        H.step_bind(self._step_state)
         if (self.opt.lr, self.opt.wd, tuple(self.opt.betas), self.opt.eps) != r["hyper"]:
             # the recorded segmm_adamw / segmm_adamw_table commands carry lr, weight decay, betas and eps BY VALUE
             raise RuntimeError("run_recorded(): the optimizer's hyperparameters changed since record() (%r -> %r): record() again"

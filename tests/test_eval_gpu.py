@@ -287,48 +287,6 @@ def test_weighted_head_matches_cliprec_forward():
 
 
 @pytest.mark.gpu
-def test_graph_replay_equals_eager_device_state_step():
-    """Trainer(device_state=True): dropout seed words, AdamW's step count / bias corrections and the per-step site headers live
-    on the device, so one captured hipGraph of the step (Trainer.capture) can be replayed.  The replayed steps must leave
-    bit-identical parameters to the same steps run eagerly in the same mode (main_for_seq_leave_earlystop_SegMM.py:265-300),
-    with dropout ON (the masks change every step although the kernel arguments do not)."""
-    import torch
-    from segmminterest_amd import hipabi as H
-    from segmminterest_amd.synth import make_batch
-    from segmminterest_amd.trainer import Trainer, default_args, init_model
-    dev = torch.device("cuda:0")
-    B, S, Lt, D, N, h = 64, 40, 10, 64, 3, 4          # S = 40: the fp16x3 attention backward with planes-only gradients + repair pass; N = 3: user queries too
-    margs = default_args(num_layers_enc=N, d_model=D, nhead=h, input_type={"user": "image", "photo": "image"}, exposure_prob=[1.0] * S)
-    batches = [{k: v.to(dev) for k, v in make_batch(B, S, Lt, D, seed=100 + i).items()} for i in range(4)]
-    T = 12
-
-    def run(graph):
-        torch.manual_seed(3)
-        model = init_model(margs, n_users=50, n_items=500, input_dim=D, max_vid_len=S, max_usr_len=Lt).to(dev)
-        tr = Trainer(model, lr=1e-3, weight_decay=1e-4, device_state=True)
-        losses = []
-        if graph:
-            tr.capture(batches[0], warmup=3)
-        else:
-            for _ in range(3):
-                tr.train_step(batches[0])
-        for t in range(T):
-            out = tr.replay(batches[t % 4]) if graph else tr.train_step(batches[t % 4])
-            losses.append(float(out["loss"].detach()))
-        torch.cuda.synchronize()
-        seed, step, bc = H.step_get()
-        assert tr.opt.step_count == step          # the host's count (checkpoints) follows the device's
-        return model._store.flat.detach().clone(), losses, step, seed
-
-    p_eager, l_eager, step_e, seed_e = run(False)
-    p_graph, l_graph, step_g, seed_g = run(True)
-    assert step_e == step_g == 3 + T and seed_e == seed_g
-    assert l_eager == l_graph
-    assert torch.equal(p_eager, p_graph)
-    assert len(set(l_eager)) > 1          # the steps really differ (new masks, new batches)
-
-
-@pytest.mark.gpu
 def test_device_state_optimizer_resumes_from_checkpoint():
     """FusedAdamW.load_state_dict in device_state mode puts the checkpoint's step count into the device-side step state (its
     bias corrections are what segmm_adamw(step = -1) uses): a trainer restored after 3 steps takes the same 4th step."""
@@ -362,11 +320,11 @@ def test_device_state_optimizer_resumes_from_checkpoint():
 
 
 @pytest.mark.gpu
-def test_graph_replay_with_validation_between_replays():
-    """replay() must mirror every host side effect of the eager step.  The captured graph rewrites the weights and
-    re-splits the weight planes at the head of the step, so outside the graph the planes are one optimizer step stale: an
-    evaluation pass between replays has to re-split them (ParamStore.refresh_planes keyed on fused_version).  Interleaving
-    eval_step with replays must give the same evaluation logits and the same final parameters as the eager device-state run."""
+def test_recorded_steps_with_validation_between_them():
+    """run_recorded() must mirror every host side effect of the eager step.  The recorded step rewrites the weights and
+    re-splits the weight planes at the head of the step, so outside it the planes are one optimizer step stale: an evaluation
+    pass between recorded steps has to re-split them (ParamStore.refresh_planes keyed on fused_version).  Interleaving eval_step
+    with recorded steps must give the same evaluation logits and the same final parameters as the eager device-state run."""
     import torch
     from segmminterest_amd.synth import make_batch
     from segmminterest_amd.trainer import Trainer, default_args, init_model
@@ -380,13 +338,13 @@ def test_graph_replay_with_validation_between_replays():
         model = init_model(margs, n_users=50, n_items=500, input_dim=D, max_vid_len=S, max_usr_len=Lt).to(dev)
         tr = Trainer(model, lr=1e-2, weight_decay=1e-4, device_state=True)          # large lr: a stale plane set is visible
         if graph:
-            tr.capture(batches[0], warmup=2)
+            tr.record(batches[0], warmup=2)          # 2 eager steps + the recorded one
         else:
-            for _ in range(2):
+            for _ in range(3):
                 tr.train_step(batches[0])
         evals = []
         for t in range(6):
-            tr.replay(batches[t % 3]) if graph else tr.train_step(batches[t % 3])
+            tr.run_recorded(batches[t % 3]) if graph else tr.train_step(batches[t % 3])
             if t % 2 == 1:          # validation after steps 2, 4, 6: the SECOND and third must not run on the first one's planes
                 evals.append(tr.eval_step(batches[2], mode="inference")["logits"].detach().clone())
         torch.cuda.synchronize()
@@ -433,23 +391,38 @@ def test_device_state_validation_rounds_do_not_exhaust_the_header_arena():
 
 
 @pytest.mark.gpu
-def test_second_device_state_trainer_supersedes_the_first():
-    """The device-side step state is one process-global struct: the trainer that lost it refuses to step."""
+def test_two_device_state_trainers_coexist():
+    """The device-side step state is caller-owned memory named by segmm_step_bind (round 5; it used to be one process-global
+    __device__ struct and a second device_state trainer superseded the first): two trainers stepping alternately end with the
+    parameters each reaches alone, and their device-side step counts are their own."""
     import torch
+    from segmminterest_amd import hipabi as H
     from segmminterest_amd.synth import make_batch
     from segmminterest_amd.trainer import Trainer, default_args, init_model
     dev = torch.device("cuda:0")
     B, S, Lt, D = 8, 20, 6, 32
     margs = default_args(num_layers_enc=2, d_model=D, nhead=4, input_type={"user": "image", "photo": "image"}, exposure_prob=[1.0] * S)
     batch = {k: v.to(dev) for k, v in make_batch(B, S, Lt, D, seed=9).items()}
-    m1 = init_model(margs, n_users=5, n_items=5, input_dim=D, max_vid_len=S, max_usr_len=Lt).to(dev)
-    m2 = init_model(margs, n_users=5, n_items=5, input_dim=D, max_vid_len=S, max_usr_len=Lt).to(dev)
-    t1 = Trainer(m1, device_state=True)
-    t1.train_step(batch)
-    t2 = Trainer(m2, device_state=True)
-    t2.train_step(batch)
-    with pytest.raises(RuntimeError, match="superseded"):
-        t1.train_step(batch)
+
+    def fresh(seed):
+        torch.manual_seed(seed)
+        m = init_model(margs, n_users=5, n_items=5, input_dim=D, max_vid_len=S, max_usr_len=Lt).to(dev)
+        return m, Trainer(m, device_state=True)
+    alone = []
+    for seed, n in ((1, 4), (2, 2)):
+        m, t = fresh(seed)
+        for _ in range(n):
+            t.train_step(batch)
+        alone.append(m._store.flat.detach().clone())
+    m1, t1 = fresh(1)
+    m2, t2 = fresh(2)          # (draws its dropout seed after t1's: the same draws as in the runs above, seeded per trainer)
+    t1.train_step(batch); t2.train_step(batch); t1.train_step(batch); t1.train_step(batch); t2.train_step(batch); t1.train_step(batch)
+    torch.cuda.synchronize()
+    assert torch.equal(m1._store.flat, alone[0]) and torch.equal(m2._store.flat, alone[1])
+    H.step_bind(t1._step_state)
+    assert H.step_get()[1] == 4
+    H.step_bind(t2._step_state)
+    assert H.step_get()[1] == 2
 
 
 @pytest.mark.gpu

@@ -83,7 +83,7 @@ def test_recorded_phase_entry_points_and_dispatch_table():
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_cmd_dispatch.py"), "--check"])
     ops = H.op_ids()
     streamed = {n for n, at in H.SIGNATURES.items() if at and at[-1] is H._p and n not in H.PHASE_ENTRY and n not in
-                ("segmm_run_phase", "segmm_step_get", "segmm_probe_mfma_rate")}
+                ("segmm_run_phase", "segmm_step_get", "segmm_probe_mfma_rate", "segmm_step_bind")}
     assert set(ops) == streamed and sorted(ops, key=ops.get) == sorted(ops)
     assert ctypes.sizeof(H.CmdArg) == 8 and ctypes.sizeof(H.Cmd) == 8 + 8 * H.CMD_MAX_ARGS and ctypes.sizeof(H.Phase) == 24
     L = H.lib()
@@ -142,3 +142,17 @@ def test_early_stop_rule_matches_reference_loop():
         for vals in itertools.product([0.1, 0.2, 0.3], repeat=n):
             for es in (0, 1, 2, 3):
                 assert early_stop_reached(list(vals), es) == reference(list(vals), es), (vals, es)
+
+
+def test_config_table_is_listed_and_settable():
+    """The library's tuning knobs live in one table (segmm_config_dump / segmm_config_set): no launch path reads the environment,
+    and no knob of this build selects a timing probe with wrong results (those exist in -D probe builds only)."""
+    from segmminterest_amd import hipabi as H
+    cfg = H.config_dump()
+    assert {"ATTN", "ATT_FWD_LDS", "ATT_MERGE", "PL_VAR", "TN_VAR", "L1NORM_REG"} <= set(cfg)
+    assert not any("DBG" in k or "FLAGS" in k for k in cfg)
+    prev = H.config_set("ATT_WAVES", 3)
+    assert H.config_dump()["ATT_WAVES"][0] == 3 and prev == cfg["ATT_WAVES"][0]
+    H.config_set("ATT_WAVES", prev)
+    with pytest.raises(RuntimeError):
+        H.config_set("NO_SUCH_KNOB", 1)

@@ -456,6 +456,78 @@ def test_config1_sample_file_labels_vs_oracle():
         assert float(dev_m[k]) == float(ref_m[k]), (k, dev_m[k], ref_m[k])
 
 
+def test_config1_whole_sample_file_vs_oracle():
+    """BASELINE config 1 at its stated size: ALL 10 000 interactions of the reference's sample file (tests/golden/cfg1_labels.npz:
+    every label row of SegMM_inter_sample.csv, truncated / padded to S = 20), d = 128, h = 16, N = 2, Lt = 100, synthetic
+    features, evaluated in 512-row batches like the reference's validation loop (main_for_seq_leave_earlystop_SegMM.py:143-181:
+    mode="train" forward in eval, sigmoid(logits) * exposure_prob, TOP_K_leave per batch, the per-batch values averaged with equal
+    weight).  Every logit of every row within 1e-4 of the CPU oracle's; the integer leave ranks of the device path equal the
+    numpy oracle's on the same interests in every batch, so HR@k / NDCG@k over the whole file are EQUAL (==); the ranks the
+    oracle derives from its OWN logits differ in at most a handful of near-tied rows."""
+    import argparse
+    import numpy as np
+    import segmm_oracle as O
+    import segmminterest_amd as M
+    from helpers import GOLDEN
+    from segmminterest_amd.my_evaluation import TOP_K_leave_device
+    from segmminterest_amd.synth import make_batch, l1_normalize
+    z = np.load(os.path.join(GOLDEN, "cfg1_labels.npz"))
+    labels = torch.from_numpy(z["label"].astype(np.int64))
+    n_rows, S = labels.shape
+    assert n_rows == 10000 and S == 20
+    Lt, D, N, h, BS = 100, 128, 2, 16, 512
+    torch.manual_seed(1)
+    args = argparse.Namespace(debug=0, num_layers_enc=N, ablation_type="ours", d_model=D, nhead=h,
+                              input_type={"user": "image", "photo": "image"}, learnable_bias=0, exposure_prob=[1.0] * S,
+                              fusion_heads=2, loss_type_list=["interestBPR"], loss_weight={"interestBPR": 1.0, "mse": 1.0}, mask_loss=0)
+    bb = M.SegFormerX(d_model_in=D, d_model_lvls=[D] * N, num_head_lvls=[h] * N, ff_dim_lvls=[D] * N, input_vid_dim=D,
+                      input_usr_dim=D, max_vid_len=S, max_usr_len=Lt, sr_ratio_lvls=[1] * N, use_patch_merge=[False] * N,
+                      output_layers=[-1], model_cfg=args)
+    model = M.MultiScaleTemporalDetrLeaveFocal(bb, None, None, torch.nn.Identity(), args)
+    with torch.no_grad():
+        for n_, p in model.named_parameters():
+            if p.dim() == 2 and "proj" in n_ and "backbone1.vid_proj" not in n_ and "backbone1.usr_proj" not in n_:
+                p.mul_(4.0)
+            if n_.endswith("vid_proj.weight") or n_.endswith("usr_proj.weight"):
+                p.mul_(60.0)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    cfg = dict(N=N, h=h, S=S, user="image", photo="image", loss_type_list=["interestBPR"], loss_weight={"interestBPR": 1.0, "mse": 1.0},
+               exposure_prob=[1.0] * S)
+    model = model.cuda().eval()
+    keys = ("HR@1", "HR@3", "HR@5", "HR@10", "NDCG@1", "NDCG@3", "NDCG@5", "NDCG@10")
+    dev_vals, ref_vals = {k: [] for k in keys}, {k: [] for k in keys}
+    worst, flips, n_valid = 0.0, 0, 0
+    for bi, r0 in enumerate(range(0, n_rows, BS)):
+        label = labels[r0:r0 + BS]
+        B = label.shape[0]
+        b = make_batch(B, S, Lt, D, seed=500 + bi)
+        pm = label != -2
+        inp = dict(usr_image=l1_normalize(b["user"]), usr_id=b["user_identity_id"], usr_mask=b["user_mask"],
+                   vid_image=l1_normalize(b["photo"] * pm[:, :, None]), vid_id=b["photo_identity_id"], vid_mask=pm, gt=label)
+        with torch.no_grad():
+            out = call_model(model, inp, "train", DEV)
+            ref = O.model_forward(sd, cfg, inp, mode="train")
+        worst = max(worst, (out["logits"].cpu() - ref["logits"].detach()).abs().max().item())
+        interests = torch.sigmoid(out["logits"].detach())
+        dev_m = TOP_K_leave_device(interests, label.to(DEV), permutation=0)
+        view = (label == 1).sum(1, keepdim=True).numpy()
+        ref_m = O.top_k_leave(interests.cpu().numpy(), view, pm.numpy(), permutation=0, S=S)
+        for k in keys:
+            assert float(dev_m[k]) == float(ref_m[k]), (bi, k, dev_m[k], ref_m[k])
+            dev_vals[k].append(float(dev_m[k]))
+            ref_vals[k].append(float(ref_m[k]))
+        # the ranks the oracle derives from its own logits: equal except where two segments are tied to ~1e-6
+        own = O.top_k_leave(torch.sigmoid(ref["logits"].detach()).numpy(), view, pm.numpy(), permutation=0, S=S)
+        valid = int((view.flatten() < S).sum())
+        n_valid += valid
+        flips += int(round(abs(float(own["HR@1"]) - float(ref_m["HR@1"])) * valid))
+    assert worst < 1e-4, worst
+    assert len(dev_vals["HR@1"]) == 20 and n_valid > 6000
+    for k in keys:          # the reference's epoch value: per-batch metrics averaged with equal weight (main...SegMM.py:179-181)
+        assert sum(dev_vals[k]) / len(dev_vals[k]) == sum(ref_vals[k]) / len(ref_vals[k]), k
+    assert flips <= 3, flips
+
+
 def _cfg2_model(B, seed=1, scale_layers=2.0, scale_in=100.0, Din=768):
     """BASELINE config 2's model and a batch of B rows (``Din`` = 1536: config 5, mixed visual + audio features)."""
     import segmminterest_amd as M

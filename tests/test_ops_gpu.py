@@ -342,8 +342,8 @@ def test_attention_fwd_bwd(B, H_, dh, Lq, La, Lb):
                                                 (3, 4, 48, 40, 40, 0, 0.1), (2, 4, 32, 7, 40, 7, 0.0)])
 def test_attention_fwd_lds_staged_form_equals_direct_form(B, H_, dh, Lq, La, Lb, p):
     """The LDS-DMA staged forward (one workgroup per head, K / V staged once; the default where it fits) against the direct-load
-    form (SEGMM_ATT_FWD_LDS=0): same arithmetic, masks and dropout stream.  With ONE key group per query tile
-    (SEGMM_ATT_FWD_KSPLIT=1) O and the softmax statistics are BIT-IDENTICAL; with the default key split the groups' softmax sums
+    form (knob ATT_FWD_LDS = 0): same arithmetic, masks and dropout stream.  With ONE key group per query tile
+    (knob ATT_FWD_KSPLIT = 1) O and the softmax statistics are BIT-IDENTICAL; with the default key split the groups' softmax sums
     are merged in another order: equal to 2e-6 of the maximum.  Operands are column slices of fused projection buffers (the engine's layout), with NaN poison around them: a staging bug
     that reads a neighbouring column or row shows up at once."""
     H = _abi()
@@ -357,8 +357,8 @@ def test_attention_fwd_lds_staged_form_equals_direct_form(B, H_, dh, Lq, La, Lb,
     mkb = (torch.rand(B, max(Lb, 1), generator=g) < 0.7).to(DEV)
     outs = {}
     for form in ("0", "1", "k1"):          # direct | staged with the key tiles split over wave groups | staged, one group
-        os.environ["SEGMM_ATT_FWD_LDS"] = "0" if form == "0" else "2"
-        os.environ["SEGMM_ATT_FWD_KSPLIT"] = "1" if form == "k1" else "2"
+        prev_lds = H.config_set("ATT_FWD_LDS", 0 if form == "0" else 2)
+        prev_ksp = H.config_set("ATT_FWD_KSPLIT", 1 if form == "k1" else 2)
         try:
             O = torch.full((B * Lq, d), float("nan"), device=DEV)
             lse = torch.full((2, B, H_, Lq), float("nan"), device=DEV)
@@ -368,8 +368,8 @@ def test_attention_fwd_lds_staged_form_equals_direct_form(B, H_, dh, Lq, La, Lb,
                        O, d, lse, drop_p=p, seed=11, site=3, amax_o=am)
             outs[form] = (O, lse, am)
         finally:
-            os.environ.pop("SEGMM_ATT_FWD_LDS", None)
-            os.environ.pop("SEGMM_ATT_FWD_KSPLIT", None)
+            H.config_set("ATT_FWD_LDS", prev_lds)
+            H.config_set("ATT_FWD_KSPLIT", prev_ksp)
     assert torch.isfinite(outs["1"][0]).all() and torch.isfinite(outs["1"][1]).all()
     assert torch.equal(outs["0"][0], outs["k1"][0]) and torch.equal(outs["0"][1], outs["k1"][1])
     assert float(outs["0"][2].max()) == float(outs["k1"][2].max()) == float(outs["k1"][0].abs().max())      # (slot positions differ)
@@ -850,7 +850,7 @@ def test_attention_bwd_merged_key_blocks_is_bitwise_the_per_block_form(B, H_, dh
         dO = torch.randn(B * Lq, d, generator=g).to(DEV)
 
         def run(merge):
-            monkeypatch.setenv("SEGMM_ATT_MERGE", merge)
+            H.config_set("ATT_MERGE", int(merge))
             Dv = torch.empty((B, H_, Lq), device=DEV)
             outs = [torch.full_like(t, float("nan")) for t in (Qa, Qb, Ka, Va, Kb, Vb)]
             H.attn_bwd(B, H_, dh, Lq, La, Lb, z(Qa), z(Qb), d, z(Ka), z(Va), d, z(Kb), z(Vb), d, mq, mka, mkb, lse, O, d, dO, d, Dv,
@@ -863,6 +863,7 @@ def test_attention_bwd_merged_key_blocks_is_bitwise_the_per_block_form(B, H_, dh
             assert torch.equal(x, y), (name, (x - y).abs().max().item())
     finally:
         H.attn_mode(prev)
+        H.config_set("ATT_MERGE", 1)
 
 
 @pytest.mark.parametrize("B,L,d", [(512, 100, 768), (512, 40, 768), (37, 20, 256), (64, 1, 512), (9, 7, 64), (3, 33, 1024)])

@@ -13,6 +13,8 @@
 thread_local char g_segmm_err[512];
 int segmm_fail(int code, const char*, ...) { return code; }
 #include "attention_pl.h"
+StepState* g_segmm_step = nullptr;
+StepState* segmm_step_current() { return g_segmm_step; }
 using namespace segmm;
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)

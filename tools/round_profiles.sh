@@ -11,7 +11,7 @@ SEGMM_SCALING=exact python bench.py --steps 20 --warmup 5 $X > $O/bench_n1_exact
 python bench.py --config 3 --steps 20 --warmup 5 > $O/bench_cfg3.json 2>/dev/null
 python bench.py --config 5 --steps 20 --warmup 5 $X > $O/bench_cfg5.json 2>/dev/null
 python bench.py --config 4 --gpus 1 --global-batch 256 --steps 20 --warmup 5 $X > $O/bench_cfg4_256rows.json 2>/dev/null
-for M in "--eager" "--device-state" "--graph" ""; do python bench.py --config 4 --gpus 1 --global-batch 256 --steps 20 --warmup 5 $M $X 2>/dev/null | tail -1; done > $O/bench_cfg4_256rows_step_modes.jsonl
+for M in "--eager" "--device-state" ""; do python bench.py --config 4 --gpus 1 --global-batch 256 --steps 20 --warmup 5 $M $X 2>/dev/null | tail -1; done > $O/bench_cfg4_256rows_step_modes.jsonl
 python bench.py --input index --steps 20 --warmup 5 $X > $O/bench_index_input.json 2>/dev/null
 python bench.py --gpus 2 --backend gloo --steps 6 --warmup 2 --windows 2 --no-cpu-baseline --no-probe > $O/bench_gloo2_one_gpu.json 2>/dev/null
 SEGMM_DP_FORCE=1 python bench.py --steps 20 --warmup 5 $X > $O/bench_dp_forced_one_rank.json 2>/dev/null
