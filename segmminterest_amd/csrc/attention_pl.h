@@ -349,21 +349,26 @@ __global__ __launch_bounds__(64 * ATT_PL_MAXW) void attn_fwd_pl_kernel(const Att
 // LDS bytes of attn_bwd_pl_kernel for a query chunk of QC rows, nw waves and Tp padded keys (keep in step with the kernel's layout)
 template <int DH>
 inline size_t attn_bwd_pl_lds_bytes(int QC, int nw, int /*Tp*/) {
-    return ((size_t)2 * QC * (DH + 4) + 3 * QC + 4 + 36) * 4 + (size_t)QC * (DH / 4 + 1) * 16 + (size_t)nw * 16 * (DH / 4 + 1) * 16 + QC;
+    return ((size_t)3 * QC * (DH + 4) + 3 * QC + 4 + 36) * 4 + (size_t)nw * 2 * 16 * (DH * 2 + 8) + QC;
 }
 
 // ------------------------------------------------------------------------------------------ backward: fused dQ + dK + dV on input planes
 // attn_bwd_fused16_kernel (attention16.h: same workgroup = (b, h, key block), same wave = key tile in passes, same ordered dQ
 // accumulation, dropout stream, plane outputs and repair protocol) with Q, K and V read from the P32 planes of the projection
 // GEMMs instead of their fp32 views -- which then need not exist (the GEMMs write planes only):
-//   * the chunk's Q rows are staged by LDS-DMA into a chunk image (16-byte chunks, hi then lo, one pad chunk per row) that serves
-//     the row-fragment reads of S = Q K^T and the transposed reads of dK^T = Q^T dS -- no loads through registers, no maxima
-//     exchange, no in-place conversion pass for Q;
-//   * a wave's K tile goes by LDS-DMA into its own 3 KB image (row fragments for S, transposed fragments for dQ^T = K^T dS^T), its V
-//     row fragments straight to registers -- no per-tile maxima, no split (a third of the fp16x3 kernel's vector work);
+//   * a lane's 4 consecutive reduction elements of a row fragment are 8 contiguous bytes of hi terms and 8 of lo terms in the
+//     planes: the K / V row fragments of a wave's key tile come STRAIGHT TO REGISTERS (12 eight-byte loads per lane) with the
+//     site's scale -- no per-tile maxima, no operand splits (a third of the fp16x3 kernel's vector work);
+//   * the K column fragments of the dQ^T = K^T dS^T product (4 consecutive keys of one head column) are read back transposed
+//     (ds_read_b64_tr_b16) from a [key][column] image the wave writes into its own LDS from those registers -- no second,
+//     fragment-shaped fetch of K (12 more loads per lane in the fp32 kernels);
+//   * the chunk's Q rows are staged like before, but their two 8-byte pieces go into the [4 hi | 4 lo] image AS THEY ARE: no
+//     maxima exchange, no in-place conversion pass for Q;
 //   * operand scales are the sites' (a site that is unusable under its header's scale was rewritten by the producer's repair
 //     launch with the exact scale of its maxima: both sides derive that scale from the same header).
-// dO and O still arrive as fp32 (staged and converted like before).
+// dO and O still arrive as fp32 (staged and converted like before).  (A first version staged Q and the K tile by LDS-DMA: an
+// LDS-DMA tile on the critical path -- issue, land, ds_read -- was 24 us slower per launch than fragments straight to registers,
+// profiles/r5/attention_planes_in.txt.)
 template <int DH, int NW, bool ONE>
 __global__ __launch_bounds__(64 * NW, NW <= 4 ? SEGMM_ATT16_WPS : 4) void attn_bwd_pl_kernel(const AttnArgs p) {
     using C = AttnCfg<DH>;
@@ -376,7 +381,7 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? SEGMM_ATT16_WPS : 4) void attn_b
     constexpr int MAXQT = QC / 16;
     constexpr int NCH = DH / 16;               // k = 16 blocks of a product over the head dim (= C::CT)
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;          // (uniform: LDS-DMA bases)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     const int wg = xcd_remap(blockIdx.x, gridDim.x), bh = p.hpb == 2 ? wg >> 1 : wg, b = bh / p.H, h = bh % p.H;
     const bool isa = p.hpb == 2 ? (wg & 1) == 0 : p.hpb == 0;
@@ -411,96 +416,76 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? SEGMM_ATT16_WPS : 4) void attn_b
     }
     const bool f32_q = !repair && !((p.pflags & ATT_PLANES_ONLY) && want_q);          // fp32 copies of dQ / of dK, dV
     const bool f32_k = !repair && !((p.pflags & ATT_PLANES_ONLY) && want_k);
-    // chunk images (sQ, this wave's K tile): rows of DH/8 hi chunks, DH/8 lo chunks (16 bytes = 8 columns each) and ONE pad chunk:
-    // an odd number of chunks per row makes the row-fragment reads (16 rows x one chunk per 32-lane half) conflict-free without a
-    // rotation -- every read offset is a lane base + an instruction immediate -- and leaves the transposed reads (8 rows x two
-    // adjacent chunks per half) at 3 doubly used bank groups of 16
-    constexpr int CPR = DH / 4, HC = DH / 8, PCH = CPR + 1, ROWB = PCH * 16, IPB = (16 * PCH + 63) / 64;
-    char* sdO = (char*)smem_f;                             // [QC][RSB]: fp32 rows while staging, then [4 hi | 4 lo] groups
-    float* sdQ = (float*)(sdO + QC * RSB);                 // [QC][RS] dQ accumulators (zeroed after D is formed)
+    constexpr int KTP = DH * 2 + 8;                                        // row pitch (bytes) of a wave's K tile image: [16 keys][DH fp16] + pad
+    char* sQ = (char*)smem_f;                              // [QC][RSB]: [4 hi | 4 lo] groups of the Q planes (written as staged)
+    char* sdO = sQ + QC * RSB;                             // [QC][RSB]: fp32 rows while staging, then [4 hi | 4 lo] groups
+    float* sdQ = (float*)(sdO + QC * RSB);                 // [QC][RS] dQ accumulators (zeroed once D is formed)
     float* s_Dp = sdQ;                                     // [QC][DH/4] partial products dO . O: alive from the staging to D only
     float* s_mx = sdQ + QC * RS;
     float* s_inv = s_mx + QC;
     float* s_D = s_inv + QC;
-    int* s_turn = (int*)(s_D + QC);                                         // [4] whose turn it is to add dQ of query tile qt
+    char* sKt = (char*)(s_D + QC) + wave * (2 * 16 * KTP);                  // this wave's K tile, hi image then lo image (row fragments in,
+    float* s_tr = (float*)sKt;                                              // transposed fragments out) ... and then its transpose scratch
+    int* s_turn = (int*)((char*)(s_D + QC) + nw * (2 * 16 * KTP));          // [4] whose turn it is to add dQ of query tile qt
     float* s_wm = (float*)(s_turn + 4);                                     // [3][12] per-wave maxima: (unused), |dO|, |D|
-    char* sQ = (char*)(s_wm + 36);                                          // [QC][ROWB]: the chunk image of the Q planes (LDS-DMA)
-    char* sKt = sQ + QC * ROWB + wave * (16 * ROWB);                        // this wave's K tile [16][ROWB] (LDS-DMA) ...
-    float* s_tr = (float*)sKt;                                              // ... and, once its fragments are in registers, its transpose scratch
-    uint8_t* qm = (uint8_t*)(sQ + QC * ROWB + nw * (16 * ROWB));            // [QC] 1 valid query, 0 masked, 2 pad
-    static_assert(16 * TS * 4 <= 16 * ROWB, "transpose scratch inside the K image");
-    // ---- input planes: sites, scales.  A site that is not usable under its header's scale was REPAIRED by its producer (the
-    // projection GEMM's repair launch rewrote the planes with the exact scale of the recorded maxima): take that scale
+    uint8_t* qm = (uint8_t*)(s_wm + 36);                                    // [QC] 1 valid query, 0 masked, 2 pad
+    static_assert(16 * TS * 4 <= 2 * 16 * KTP, "transpose scratch inside the K image");
+    // ---- input planes (the P32 planes of the projection GEMMs; see attn_fwd_pl_kernel): a lane's 4 consecutive reduction elements
+    // of a row fragment ARE 8 contiguous bytes of the hi terms and 8 of the lo terms -- fragments come straight to registers with
+    // the site's scale, no per-tile maxima, no splits
     const AttnInPlanes& in = p.in;
     const float* hdr_kx = isa ? in.hdr_ka : in.hdr_kb;
-    float sQs = 1.f, sK = 1.f, sV = 1.f, maxV = 0.f;                         // (set by judge_sites, after the first staging round)
-    // ---- read offsets inside a staged row: row fragment (lane (row l15, g): columns 16 i + 4 g .. + 3) = byte 8 g + 32 i of the hi
-    // chunks (+ 16 HC: lo); transposed read (lane 4 q + pq of a 16-lane group supplies row q, columns 16 ct + 4 pq .. + 3) = byte
-    // 8 pq + 32 ct
-    const uint32_t bR = 8u * (uint32_t)g, bC = 8u * (uint32_t)(l15 & 3);
-    constexpr uint32_t LO = 16u * HC;
-    // ---- DMA source of this lane inside a 16-row block of a chunk image: slot 64 i + lane = (row rr, chunk j) of the block;
-    // column part and row are the same for every block (computed once), the row stride differs between Q and K
-    uint32_t dco[IPB];
-    uint32_t drow = 0;                                                       // the IPB rows, 8 bits each (0xff: no slot / pad chunk)
-#pragma unroll
-    for (int i = 0; i < IPB; ++i) {
-        const int sl = 64 * i + lane, rr = sl / PCH, j = sl - rr * PCH;
-        const bool dead = sl >= 16 * PCH;
-        dco[i] = j == CPR ? ATT_BUF_OOB : p32_chunk_off(col0 + 8 * (j >= HC ? j - HC : j)) + (j >= HC ? 64u : 0u);
-        drow |= (uint32_t)(dead ? 0xff : rr) << (8 * i);
-    }
-    static_assert(IPB <= 4, "row bytes packed in one register");
-    auto dma_block = [&](const __amdgpu_buffer_rsrc_t rs, char* dst, uint32_t ld2b, int left, uint32_t so) {
-#pragma unroll
-        for (int i = 0; i < IPB; ++i) {
-            const uint32_t rr = (drow >> (8 * i)) & 0xffu;
-            if (rr != 0xffu) att_lds_dma16(rs, dst + 1024 * i, (int)rr < left ? rr * ld2b + dco[i] : ATT_BUF_OOB, so);          // (rows behind the data: zeros)
-        }
-    };
-    const uint32_t ldq2b = (uint32_t)in.ldq2 * 2u, ldk2b = (uint32_t)(isa ? in.ldka2 : in.ldkb2) * 2u;
+    float sQs = 1.f, sK = 1.f, sV = 1.f, maxV = 0.f;                         // (set from the site headers after the first staging round)
     const __amdgpu_buffer_rsrc_t rsQ = make_rsrc(isa ? in.Qa : in.Qb, in.bytesQ);
     const __amdgpu_buffer_rsrc_t rsKV = make_rsrc(isa ? in.baseA : in.baseB, isa ? in.bytesA : in.bytesB);
     const int Lk = isa ? p.La : p.Lb;                                        // keys of this block
+    const uint32_t ldq2b = (uint32_t)in.ldq2 * 2u, ldk2b = (uint32_t)(isa ? in.ldka2 : in.ldkb2) * 2u;
     const uint32_t soK0 = (uint32_t)(b * Lk) * ldk2b + (isa ? in.offKa : in.offKb), soV0 = (uint32_t)(b * Lk) * ldk2b + (isa ? in.offVa : in.offVb);
+    uint32_t fco[NCH];                                                       // byte offset of this lane's fragment piece i inside a plane row
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) fco[i] = p32_chunk_off(col0 + 16 * i + 4 * g);
+    const uint8_t* mkx = isa ? p.mka + (size_t)b * p.La : p.mkb + (size_t)b * p.Lb;
     // ---- this wave's key tile
     int jt = (isa ? 0 : nta) + wave;                                        // padded key tile of this wave (first pass)
     HL kfh[NCH], vfh[NCH], kch[C::CT];                                      // K / V row fragments, K column fragments (hi, lo as staged)
-    uint2 vraw[NCH][2];
-    // K tile of the current pass: three LDS-DMA instructions into this wave's image (rows behind the block: zeros); V row
-    // fragments straight to registers (lane (key l15, g): columns 16 i + 4 g .. + 3, hi and lo).  issue / finish are separate so
-    // that a single-chunk launch requests its first tile BEFORE the query-side staging
-    const uint8_t* mkx = isa ? p.mka + (size_t)b * p.La : p.mkb + (size_t)b * p.Lb;
+    u32x2a kraw_[NCH][2], vraw_[NCH][2];
     uint8_t kraw = 0;
+    // issue / finish are separate so that a single-chunk launch requests its first tile BEFORE the query-side staging
     auto issue_frags = [&]() {
         const int tl = jt - (isa ? 0 : nta);                                // tile inside the block
-        dma_block(rsKV, sKt, ldk2b, Lk - 16 * tl, soK0 + (uint32_t)(16 * tl) * ldk2b);
-        const int kr = min(16 * tl + l15, Lk - 1);                          // (keys behind the block: clamped, finite; their P is 0)
-        const uint32_t vo = soV0 + (uint32_t)kr * ldk2b;
+        const int kr = min(16 * tl + l15, Lk - 1);                          // (keys behind the block: clamped, finite; their P and dS are 0)
+        const uint32_t ko = soK0 + (uint32_t)kr * ldk2b, vo = soV0 + (uint32_t)kr * ldk2b;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            const uint32_t co = vo + p32_chunk_off(col0 + 16 * i + 4 * g);
-            const u32x2a h_ = __builtin_bit_cast(u32x2a, __builtin_amdgcn_raw_buffer_load_b64(rsKV, (int)co, 0, 0));
-            const u32x2a l_ = __builtin_bit_cast(u32x2a, __builtin_amdgcn_raw_buffer_load_b64(rsKV, (int)(co + 64u), 0, 0));
-            vraw[i][0] = make_uint2(h_.x, h_.y); vraw[i][1] = make_uint2(l_.x, l_.y);
+            kraw_[i][0] = __builtin_bit_cast(u32x2a, __builtin_amdgcn_raw_buffer_load_b64(rsKV, (int)(ko + fco[i]), 0, 0));
+            kraw_[i][1] = __builtin_bit_cast(u32x2a, __builtin_amdgcn_raw_buffer_load_b64(rsKV, (int)(ko + fco[i] + 64u), 0, 0));
+            vraw_[i][0] = __builtin_bit_cast(u32x2a, __builtin_amdgcn_raw_buffer_load_b64(rsKV, (int)(vo + fco[i]), 0, 0));
+            vraw_[i][1] = __builtin_bit_cast(u32x2a, __builtin_amdgcn_raw_buffer_load_b64(rsKV, (int)(vo + fco[i] + 64u), 0, 0));
         }
         kraw = mkx[kr];                                                     // this lane's key flag (key 16 tl + l15 of the block)
     };
     auto finish_frags = [&]() {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // this wave's DMA has landed in its own image
+        const bool live_key = 16 * (jt - (isa ? 0 : nta)) + l15 < Lk;       // (a clamped row must not enter dQ = dS K: its dS is 0, its K finite)
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            vfh[i] = HL{vraw[i][0].x, vraw[i][0].y, vraw[i][1].x, vraw[i][1].y};
-            const char* kr_ = sKt + (size_t)l15 * ROWB + bR;
-            const u32x2a hh = lds_b64(kr_ + 32 * i), ll = lds_b64(kr_ + 32 * i + LO);
-            kfh[i] = HL{hh.x, hh.y, ll.x, ll.y};
+            kfh[i] = HL{kraw_[i][0].x, kraw_[i][0].y, kraw_[i][1].x, kraw_[i][1].y};
+            vfh[i] = HL{vraw_[i][0].x, vraw_[i][0].y, vraw_[i][1].x, vraw_[i][1].y};
+            // the tile as a [key][column] image in this wave's LDS: lane (key l15, g) owns columns 16 i + 4 g .. + 3
+            *(u32x2a*)(sKt + l15 * KTP + 32 * i + 8 * g) = kraw_[i][0];
+            *(u32x2a*)(sKt + 16 * KTP + l15 * KTP + 32 * i + 8 * g) = kraw_[i][1];
         }
-        const char* kc = sKt + (size_t)(4 * g + (l15 >> 2)) * ROWB + bC;
+        (void)live_key;
+        __builtin_amdgcn_s_waitcnt(0xc07f);                                 // lgkmcnt(0): this wave's own LDS writes have landed
+        __builtin_amdgcn_wave_barrier();
+        // column fragments for dQ^T = K^T dS^T: lane 4 q + pq of a 16-lane group supplies key row 4 g + q, columns 16 ct + 4 pq .. + 3
+        const char* kc = sKt + (4 * g + (l15 >> 2)) * KTP + 8 * (l15 & 3);
 #pragma unroll
         for (int ct = 0; ct < C::CT; ++ct) {
-            const u32x2a hh = lds_tr4(kc + 32 * ct), ll = lds_tr4(kc + 32 * ct + LO);
+            const u32x2a hh = lds_tr4(kc + 32 * ct), ll = lds_tr4(kc + 16 * KTP + 32 * ct);
             kch[ct] = HL{hh.x, hh.y, ll.x, ll.y};
         }
+        __builtin_amdgcn_s_waitcnt(0xc07f);                                 // the fragments are in registers before the image becomes the scratch
+        __builtin_amdgcn_wave_barrier();
     };
     auto load_frags = [&]() { issue_frags(); finish_frags(); };
     if (!ONE) load_frags();
@@ -555,10 +540,7 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? SEGMM_ATT16_WPS : 4) void attn_b
         const int nqt = (nq + 15) >> 4;
         float mdo_ = 0.f;
         // ===== ONE round of memory latency: every load of the chunk is requested before the first result is used =====
-        if (ONE) issue_frags();                            // first tile of this wave: K image, V fragments, key flag
-        // the chunk's Q rows: 16-row blocks of the chunk image by LDS-DMA (rows behind the last query: zeros)
-        for (int blk = wave; blk < QC / 16; blk += nwv)
-            dma_block(rsQ, sQ + (size_t)(16 * blk) * ROWB, ldq2b, nq - 16 * blk, (uint32_t)(b * p.Lq + q0 + 16 * blk) * ldq2b);
+        if (ONE) issue_frags();                            // first tile of this wave: K / V fragments, key flag
         // softmax statistics and query flags (one query per thread; QC <= 64 <= nthr)
         float r_mx = 0.f, r_inv = 0.f;
         uint8_t r_qm = 2;
@@ -574,16 +556,22 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? SEGMM_ATT16_WPS : 4) void attn_b
             hq0 = in.hdr_q[0]; hq1 = in.hdr_q[1]; hk0 = hdr_kx[0]; hk1 = hdr_kx[1];
             hq4 = *(const f32x4*)(in.hdr_q + SITE_HDR + lane * 4); hk4 = *(const f32x4*)(hdr_kx + SITE_HDR + lane * 4);
         }
-        // dO and O: three items per thread and round, all six loads requested before the first LDS store
+        // Q (hi and lo terms of 4 columns: two 8-byte pieces of the planes -> one [4 hi | 4 lo] group of the image, as is), dO and O:
+        // three items per thread and round, all twelve loads requested before the first LDS store
         for (int i0 = threadIdx.x; i0 < QC * (DH / 4); i0 += 3 * nthr) {
             f32x4 vo[3], oo[3];
+            u32x2a qh[3], ql[3];
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
                 const int i = i0 + u * nthr;
                 const int q = i / (DH / 4), c = (i - q * (DH / 4)) * 4;
                 vo[u] = f32x4{0.f, 0.f, 0.f, 0.f}; oo[u] = vo[u];
+                qh[u] = u32x2a{0u, 0u}; ql[u] = qh[u];
                 if (i < QC * (DH / 4) && q < nq) {
                     const size_t row = (size_t)b * p.Lq + q0 + q;
+                    const uint32_t qo = (uint32_t)row * ldq2b + p32_chunk_off(col0 + c);
+                    qh[u] = __builtin_bit_cast(u32x2a, __builtin_amdgcn_raw_buffer_load_b64(rsQ, (int)qo, 0, 0));
+                    ql[u] = __builtin_bit_cast(u32x2a, __builtin_amdgcn_raw_buffer_load_b64(rsQ, (int)(qo + 64u), 0, 0));
                     vo[u] = *(const f32x4*)(p.dO + row * p.lddo + col0 + c);
                     oo[u] = *(const f32x4*)(p.O + row * p.ldo + col0 + c);
                 }
@@ -593,6 +581,7 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? SEGMM_ATT16_WPS : 4) void attn_b
                 const int i = i0 + u * nthr;
                 if (i < QC * (DH / 4)) {
                     const int q = i / (DH / 4), c = (i - q * (DH / 4)) * 4;
+                    *(uint4*)(sQ + q * RSB + c * 4) = make_uint4(qh[u].x, qh[u].y, ql[u].x, ql[u].y);
                     *(f32x4*)(sdO + q * RSB + c * 4) = vo[u];
                     s_Dp[i] = (vo[u].x * oo[u].x + vo[u].y * oo[u].y) + (vo[u].z * oo[u].z + vo[u].w * oo[u].w);
                     mdo_ = absmax4(mdo_, vo[u]);
@@ -615,7 +604,6 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? SEGMM_ATT16_WPS : 4) void attn_b
             maxV = amax_k;                                 // bound of |V| (the site's maximum)
         }
         if (ONE) finish_frags();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's Q blocks have landed
         __syncthreads();
 #ifdef SEGMM_ATT_PROBE
         if (p.pflags & 1024) return;          // timing probe: staging loads + K / V fragments only
@@ -684,12 +672,11 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? SEGMM_ATT16_WPS : 4) void attn_b
             if (qt < nqt) {
                 // row fragments (lane&15 = query): group 4 i + g of the row = elements 16 i + 4 g .. + 3, [hi | lo]
                 f32x4 sv = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-                const char* rq = sQ + (size_t)(16 * qt + l15) * ROWB + bR;
+                const char* rq = sQ + (16 * qt + l15) * RSB + g * 16;
                 const char* rd = sdO + (16 * qt + l15) * RSB + g * 16;
 #pragma unroll
                 for (int i = 0; i < NCH; ++i) {
-                    const u32x2a qh_ = lds_b64(rq + 32 * i), ql_ = lds_b64(rq + 32 * i + LO);
-                    sv = mfma_hl(HL{qh_.x, qh_.y, ql_.x, ql_.y}, kfh[i], sv);
+                    sv = mfma_hl(lds_hl(rq + 64 * i), kfh[i], sv);
                     dp = mfma_hl(lds_hl(rd + 64 * i), vfh[i], dp);
                 }
                 const f32x4 mxq = *(const f32x4*)(s_mx + 16 * qt + 4 * g), invq = *(const f32x4*)(s_inv + 16 * qt + 4 * g);
@@ -724,8 +711,7 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? SEGMM_ATT16_WPS : 4) void attn_b
                 for (int ct = 0; ct < C::CT; ++ct) {
                     const uint32_t o = (uint32_t)(16 * qt) * RSB + (uint32_t)ct * 64u + tr_lane;
                     const u32x2a dh_ = lds_tr4(sdO + o), dl_ = lds_tr4(sdO + o + 8);
-                    const char* qc = sQ + (size_t)(16 * qt + 4 * g + (l15 >> 2)) * ROWB + bC;
-                    const u32x2a qh_ = lds_tr4(qc + 32 * ct), ql_ = lds_tr4(qc + 32 * ct + LO);
+                    const u32x2a qh_ = lds_tr4(sQ + o), ql_ = lds_tr4(sQ + o + 8);
                     dv[ct] = mfma_hl(HL{dh_.x, dh_.y, dl_.x, dl_.y}, Ph, dv[ct]);
                     dk[ct] = mfma_hl(HL{qh_.x, qh_.y, ql_.x, ql_.y}, dSh, dk[ct]);
                 }
