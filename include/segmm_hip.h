@@ -95,9 +95,14 @@ int segmm_gemm_h(int layout, int M, int N, int K, const float* A, int lda, const
  * 163-167,183-184,438,445; kn_util/nn_utils/layers/mlp.py:17-23).
  *   layout 0 (NT): C[M,N] = A[M,K] . B[N,K]^T  A planes [M][2K], B planes [N][2K]          (forward; dgrad on W^T planes)
  *   layout 2 (TN): C[M,N] = A[K,M]^T . B[K,N]  A planes [K][2M], B planes [K][2N], split-K  (weight gradients)
- * Output: fp32 C (unless write_c == 0) and/or P32 planes c_planes written with the scale *c_scale_in; the partial maxima
- * of |C|, the overflow flag and the scale used are folded into c_hdr (caller zeroes the header).  Epilogue as
- * segmm_gemm.  NT: K % 32 == 0; TN: M, N % 32 == 0 (token tails are zero-filled). */
+ * Output: fp32 C (unless bit 0 of write_c is clear) and/or P32 planes c_planes written with the scale *c_scale_in; the partial
+ * maxima of |C|, the overflow flag and the scale used are folded into c_hdr (caller zeroes the header).  Epilogue as
+ * segmm_gemm.  NT: K % 32 == 0; TN: M, N % 32 == 0 (token tails are zero-filled).
+ * PLANES-ONLY outputs (round 5; NT, write_c = 0: the projection outputs the planes-in attention kernels read): with no fp32 copy
+ * a consumer cannot fall back when the delayed scale turns out wrong, so the caller enqueues the SAME call once more with bit 1
+ * of write_c set -- the REPAIR launch: every workgroup judges the output site from c_hdr (scale, flag, complete maxima) and
+ * leaves at once when the planes are usable; otherwise it recomputes its tile and rewrites the planes with the exact scale of
+ * the recorded maxima, leaving c_hdr untouched.  Consumers judge the same header and derive the same scale. */
 #define SEGMM_SITE_HDR 8
 int segmm_gemm_p(int layout, int M, int N, int K, const uint16_t* a_planes, int lda2, const float* a_hdr, const float* a_f32, int ldaf,
                  const uint16_t* b_planes, int ldb2, const float* b_hdr, const float* b_f32, int ldbf, float* C, int ldc,

@@ -701,7 +701,7 @@ int segmm_gemm_p(int layout, int M, int N, int K, const uint16_t* a_planes, int 
     SEGMM_REQUIRE(layout == 0 || layout == 2, "gemm_p: layout %d (0 = NT, 2 = TN)", layout);
     SEGMM_REQUIRE(!colsum_out || layout == 2, "gemm_p: colsum_out is an output of the TN form");
     SEGMM_REQUIRE(a_planes && b_planes && a_hdr && b_hdr, "gemm_p: null plane operand / header");
-    SEGMM_REQUIRE(C || (c_planes && !write_c), "gemm_p: no output");
+    SEGMM_REQUIRE(C || (c_planes && !(write_c & 1)), "gemm_p: no output");
     if (M <= 0 || N <= 0) return 0;
     SEGMM_REQUIRE(K > 0 && (layout == 2 || K % 32 == 0), "gemm_p: K %% 32 != 0 (K=%d)", K);      // TN: token tails are zero-filled by the buffer range check
     SEGMM_REQUIRE(N % 4 == 0 && (!C || (ldc % 4 == 0 && aligned16(C))), "gemm_p: N/ldc %% 4, alignment");
@@ -727,7 +727,10 @@ int segmm_gemm_p(int layout, int M, int N, int K, const uint16_t* a_planes, int 
     memset(&q, 0, sizeof(q));
     q.A.p = (const _Float16*)a_planes; q.A.ld2 = lda2; q.A.hdr = a_hdr; q.A.f32 = a_f32; q.A.ldf = ldaf;
     q.B.p = (const _Float16*)b_planes; q.B.ld2 = ldb2; q.B.hdr = b_hdr; q.B.f32 = b_f32; q.B.ldf = ldbf;
-    q.Cp = (_Float16*)c_planes; q.ldc2 = ldc2; q.c_hdr = c_hdr; q.c_scale_in = c_scale_in; q.write_c = C ? (write_c != 0) : 0;
+    q.Cp = (_Float16*)c_planes; q.ldc2 = ldc2; q.c_hdr = c_hdr; q.c_scale_in = c_scale_in; q.write_c = C ? ((write_c & 1) != 0) : 0;
+    q.repair = (write_c & 2) != 0;
+    SEGMM_REQUIRE(!q.repair || (layout == 0 && c_planes && c_hdr && !q.write_c && !aux && !residual && !row_scale && !accumulate),
+                  "gemm_p: a repair launch (write_c bit 1) rewrites the planes of a planes-only NT output: c_planes + c_hdr, no fp32 C, no aux / residual");
 #ifdef SEGMM_GEMM_PROBE
     static const int pl_flags = getenv("SEGMM_PL_FLAGS") ? atoi(getenv("SEGMM_PL_FLAGS")) : 0;          // timing ablations (results wrong; probe builds only)
 #else
@@ -774,6 +777,7 @@ int segmm_gemm_p(int layout, int M, int N, int K, const uint16_t* a_planes, int 
                 }
                 g.nbm = (M + PBM - 1) / PBM; g.nbn = (N + 64 * best - 1) / (64 * best);
                 const dim3 grid(g.nbm * g.nbn);
+                // (the tile width of a repair launch need not match the first launch's: both write whole elements)
                 if (best == 4) hipLaunchKernelGGL(gemm_pl_nt8<4>, grid, dim3(512), 0, s, g, q);
                 else if (best == 3) hipLaunchKernelGGL(gemm_pl_nt8<3>, grid, dim3(512), 0, s, g, q);
                 else hipLaunchKernelGGL(gemm_pl_nt8<2>, grid, dim3(512), 0, s, g, q);
@@ -781,6 +785,7 @@ int segmm_gemm_p(int layout, int M, int N, int K, const uint16_t* a_planes, int 
                 return 0;
             }
         }
+        SEGMM_REQUIRE(!q.repair, "gemm_p: this launch does not run on gemm_pl_nt8, which alone has the repair mode");
         // the round-2 NT kernels below judge and fall back for operand A only: B must be an exact-split operand (weight planes)
         SEGMM_REQUIRE(!b_f32, "gemm_p NT: this launch (row-scaled output, residual with a d-activation, or an extent >= 2^31) runs on the "
                               "round-2 kernel, which has no fp32 fallback for operand B -- pass B without an fp32 copy (exact-split planes)");

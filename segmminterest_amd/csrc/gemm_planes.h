@@ -39,6 +39,7 @@ struct PGemmX {
     _Float16* Cp; int ldc2; float* c_hdr;      // optional plane output; amax / flag / the scale used are folded into c_hdr
     const float* c_scale_in;                   // device scalar: scale to write the output planes with (null / 0: none)
     int write_c;                               // 0: the fp32 C is not stored (planes only)
+    int repair;                                // gemm_pl_nt8 only: REPAIR launch of a planes-only output (see segmm_gemm_p)
     float* colsum_out; float* colsum_ws;       // TN only: optional [M] column sums of A over k (= bias gradient), split-K partials [splits][M]
     int dbg;                                   // timing ablations (SEGMM_PL_FLAGS; results are wrong when set): 1 no C stores, 2 no epilogue
     unsigned long long* stamps;                // SEGMM_STAMPS builds only (tools/probe/gemm_stamps.py): 8 x u64 per workgroup

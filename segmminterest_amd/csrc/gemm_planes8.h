@@ -108,6 +108,20 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_nt8(const GemmArgs p, const PG
     const int lb = xcd_remap(blockIdx.x, p.nbm * p.nbn);
     const int m0 = (lb / p.nbn) * PBM, n0 = (lb % p.nbn) * BNW;
     STAMP(0);
+    // ---- REPAIR launch of a planes-only output (no fp32 C to fall back on): the first launch wrote the planes with the site's
+    // delayed scale and recorded maxima + overflow flag in c_hdr.  Judge the site like a consumer would: usable -> every workgroup
+    // leaves at once (one header read); unusable (flag up, maximum below the fp16 window, no scale yet) -> recompute the tile and
+    // rewrite the planes with the EXACT scale of the recorded maxima.  The header is left as it is: consumers derive the same
+    // scale from the same maxima (attention_pl.h), and segmm_scales_update counts the site as refused.
+    float c_repair = 0.f;
+    if (q.repair) {
+        const float hc0 = q.c_hdr[0];
+        const uint32_t hc1 = __float_as_uint(q.c_hdr[1]);
+        const f32x4 amc = *(const f32x4*)(q.c_hdr + SITE_HDR + lane * 4);
+        const float m = wave_max(fmaxf(fmaxf(amc.x, amc.y), fmaxf(amc.z, amc.w)));
+        if (hc0 > 0.f && hc1 == 0u && (!(m > 0.f) || ((m * hc0 >= 0.25f || hc0 >= 0x1p60f) && m * hc0 < 65504.f))) return;
+        c_repair = f16_scale_of(m);
+    }
 
     // ---- LDS-DMA: a wave-instruction moves 8 rows x 128 B.  Per load segment a wave issues
     //   A share of its group (4 pieces): piece pi = 4 wn + i of 16; tile rows 128 (pi >> 3) + 64 grp + 8 (pi & 7) .. + 7
@@ -161,7 +175,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_nt8(const GemmArgs p, const PG
     };
     const bool slowA = q.A.f32 != nullptr && !planes_ok(sa_hdr, uni(ha1), ama);
     const bool slowB = q.B.f32 != nullptr && !planes_ok(sb_hdr, uni(hb1), amb);
-    const float c_scale = uni(cs_in);
+    const float c_scale = q.repair ? uni(c_repair) : uni(cs_in);
 
     // ---- fragment read addressing (lane: row l15 of a 16-row block, logical chunk 4 plane + lq; physical = logical ^ swz)
     const int swz = (l15 >> 1) & 7;
@@ -511,6 +525,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_nt8(const GemmArgs p, const PG
         }
     }
     STAMP(3);
+    if (q.repair) return;          // (the header keeps the first launch's verdict)
     if (q.c_hdr) {
         site_commit(q.c_hdr, am, blockIdx.x * 8 + wave, c_scale);
         if (c_scale > 0.f && scale_writer(blockIdx.x * 8 + wave)) q.c_hdr[0] = c_scale;

@@ -167,7 +167,9 @@ class ParamStore:
         self.tail_balance = os.environ.get("SEGMM_TAIL_BALANCE", "1") != "0"
         self.attn_planes_only = int(os.environ.get("SEGMM_ATTN_PLANES_ONLY", "1"))
         # round 5: the attention forward reads the Q / K / V planes the fused projection GEMMs write (csrc/attention_pl.h)
-        self.attn_pl = os.environ.get("SEGMM_ATT_PL", "0") != "0"
+        # 1 (default): with the projection outputs Yv / Yu as planes ONLY (no fp32 copy: the planes-in backward reads them too, a repair
+        # launch of the GEMM covers a wrong delayed scale); 2: planes beside the fp32 copy, forward only (measured -1.5 %); 0: off
+        self.attn_pl = int(os.environ.get("SEGMM_ATT_PL", "1"))
         self.head_side = os.environ.get("SEGMM_HEAD_SIDE", "1") != "0"
         self.input_planes_only = os.environ.get("SEGMM_INPUT_PLANES_ONLY", "1") != "0"
         self.attn_two_streams = os.environ.get("SEGMM_ATTN_TWO_STREAMS", "0") == "1"
@@ -858,9 +860,16 @@ def _lin_fwd(store, M, N, K, X, wname, out, ldo, c_act=None, **kw):
         H.gemm(H.LAYOUT_NT, M, N, K, X.t, K, store.p(wname), K, out, ldo, a_amax=X.slots, b_amax=w.hdr[H.SITE_HDR:],
                c_amax=None if c_act is None else c_act.slots, **kw)
         return
+    if out is None and not (w is not None and X.planes is not None and not _few_tiles(M, N) and c_act is not None and c_act.po is not None):
+        raise RuntimeError("a planes-only output needs the plane GEMM with a calibrated output site (%s)" % wname)
     if w is not None and X.planes is not None:
         if c_act is not None and c_act.po is not None:
-            H.gemm_p(H.LAYOUT_NT, M, N, K, X.pt(), w, out, ldo, c_pt=c_act.pt(), c_scale_ptr=c_act.scale_ptr, **kw)
+            H.gemm_p(H.LAYOUT_NT, M, N, K, X.pt(), w, out, ldo, c_pt=c_act.pt(), c_scale_ptr=c_act.scale_ptr, write_c=out is not None, **kw)
+            if out is None:
+                # planes only (the projection outputs the planes-in attention kernels read): no fp32 copy a consumer could fall
+                # back on, so the REPAIR launch follows -- workgroups that read the site header and leave, unless the delayed scale
+                # turned out wrong, in which case the planes are rewritten with the exact scale of the recorded maxima
+                H.gemm_p(H.LAYOUT_NT, M, N, K, X.pt(), w, None, ldo, c_pt=c_act.pt(), c_scale_ptr=c_act.scale_ptr, write_c=False, repair=True, **kw)
             c_act.filled = True
         else:
             H.gemm_p(H.LAYOUT_NT, M, N, K, X.pt(), w, out, ldo, c_hdr=None if c_act is None else c_act.hdr, **kw)
@@ -1244,17 +1253,32 @@ class BackboneRun:
         return vq, uq
 
     def _attn_planes_in(self):
-        """Does the attention forward of this pass read the Q / K / V planes of the fused projection GEMMs (csrc/attention_pl.h)?
-        Training passes with delayed scales on the plane engine, shapes the planes-in kernel takes (SEGMM_ATT_PL=0: never)."""
+        """Do the attention kernels of this pass read the Q / K / V planes of the fused projection GEMMs (csrc/attention_pl.h)?
+        Training passes with delayed scales on the plane engine, shapes both planes-in kernels take (SEGMM_ATT_PL=0: never)."""
         st = self.store
-        return bool(self.delayed and st.engine_p and st.attn_pl and self.dh % 16 == 0 and self.S % 4 == 0 and self.Lt % 4 == 0 and
-                    max(self.S, self.Lt) <= 112 and self.d % 32 == 0)
+        return bool(self.delayed and st.engine_p and st.attn_pl and st.attn_fused and self.dh % 16 == 0 and self.dh <= 48 and
+                    self.S % 4 == 0 and self.Lt % 4 == 0 and max(self.S, self.Lt) <= 112 and self.d % 32 == 0 and _FEW_TILES == 0)
 
     def _proj_act(self, i, which, rows, cols):
-        """The fused projection output Yv / Yu of layer i as an Act: with the planes-in attention its producer GEMM also writes the
-        P32 planes (delayed scale of the site) the attention forward stages; otherwise a plain fp32 buffer with a header."""
+        """The fused projection output Yv / Yu of layer i as an Act.  With the planes-in attention and a calibrated site its producer
+        GEMM writes the P32 planes (delayed scale of the site) and NOTHING else: the Act has no fp32 tensor (``t is None``).  On the
+        site's first pass (no scale yet), in evaluation and for shapes the planes-in kernels do not take: a plain fp32 buffer whose
+        header records the maxima the scale will come from."""
         st = self.store
-        return new_act(st, self.am, rows, cols, planes=self._attn_planes_in(), site="%sL%d.%s" % (self.pre, i, which), delayed=self.delayed)
+        site = "%sL%d.%s" % (self.pre, i, which)
+        want = self._attn_planes_in()
+        if want and st.attn_pl == 1:
+            sp = st.scale_ptr(site, self.delayed)
+            # (both projection outputs of the layer or neither: an attention call reads Q / K / V from both)
+            full = i < self.N - 2 and self.mode != "self"
+            has_u = len(layer_plan(self.mode, full)[1]) > 0
+            other = st.scale_ptr("%sL%d.%s" % (self.pre, i, "Yu" if which == "Yv" else "Yv"), self.delayed) if (which == "Yu" or has_u) else True
+            if sp is not None and other is not None:
+                planes = torch.empty((rows, 2 * cols), dtype=torch.float16, device=st.flat.device)
+                a = Act(None, self.am.new(site), rows, cols, planes)
+                a.scale_ptr, a.po, a.no_f32 = sp, H.PO(planes, 2 * cols, a.hdr, sp), True
+                return a
+        return new_act(st, self.am, rows, cols, planes=want, site=site, delayed=self.delayed)
 
     def _usr_proj_fwd(self, i, Xu, Yu):
         """Yu = Xu . [fused user-token projections of layer i]^T + b."""
@@ -1302,7 +1326,9 @@ class BackboneRun:
             pin_u = dict(q=pl_u, a=pl_v, b=pl_u if uq["Lb"] else None)
         lse_v = _empty(Xv.t, 2, B, Hh, S)
         Av = new_act(st, am, Mv, d, site="%sL%d.vid.A" % (P, i), delayed=self.delayed)
-        rec = dict(full=full, Xv=Xv, Xu=Xu, Yv=Yv, Yu=Yu, lse_v=lse_v)
+        rec = dict(full=full, Xv=Xv, Xu=Xu, Yv=Yv, Yu=Yu, lse_v=lse_v, pin_v=pin_v, pin_u=pin_u)
+        if (Yv is None or (nu and Yu is None)) and (pin_v is None or (full and pin_u is None)):
+            raise RuntimeError("planes-only projection outputs without input planes for every attention call of the layer")
         X2u = None
         usr_ctx = None
         if full:
@@ -1441,7 +1467,7 @@ class BackboneRun:
                                uq["Vb"], uq["ldkb"], self.um, self.vm, self.um, rec["lse_u"], rec["u"]["A"].t, d, dAu, d, Dv_u,
                                duq["Qa"], duq["Qb"], duq["ldq"], duq["Ka"], duq["Va"], duq["ldka"], duq["Kb"], duq["Vb"], duq["ldkb"],
                                drop_p=self.p_drop, seed=self.seed, site=_site(self.bi, i, K_ATT_U),
-                               amax_q=sl_u, amax_ka=sl_v, amax_kb=sl_u, planes=planes_of(dYu, dYv, dYu, duq, pflags))
+                               amax_q=sl_u, amax_ka=sl_v, amax_kb=sl_u, planes=planes_of(dYu, dYv, dYu, duq, pflags), pin=rec.get("pin_u"))
                 attn_u_(H.ATTN_PLANES_ONLY if ponly else 0)
                 return dR1u_, attn_u_
             if usr_on_side:
@@ -1457,7 +1483,7 @@ class BackboneRun:
                        vq["ldkb"], self.vm, self.vm, self.um, rec["lse_v"], rec["v"]["A"].t, d, dAv, d, Dv, dvq["Qa"], dvq["Qb"], dvq["ldq"],
                        dvq["Ka"], dvq["Va"], dvq["ldka"], dvq["Kb"], dvq["Vb"], dvq["ldkb"], drop_p=self.p_drop, seed=self.seed,
                        site=_site(self.bi, i, K_ATT_V), amax_q=sl_v, amax_ka=sl_v, amax_kb=sl_u,
-                       planes=planes_of(dYv, dYv, dYu, dvq, pflags))
+                       planes=planes_of(dYv, dYv, dYu, dvq, pflags), pin=rec.get("pin_v"))
         attn_v(H.ATTN_PLANES_ONLY if ponly else 0)
         if full:
             if usr_on_side:

@@ -558,10 +558,12 @@ def to_planes(x, rows, cols, ld=None, x_off=0, keep_f32=True):
 
 def gemm_p(layout, M, N, K, A: "PT", B: "PT", Cout, ldc, c_pt: "PT" = None, write_c=True, bias=None, row_scale=None, residual=None,
            ldr=0, res_period=0, activation=0, aux=None, ldaux=0, drop_p=0.0, seed=0, site=0, splits=1, workspace=None,
-           accumulate=False, c_off=0, c_hdr=None, c_scale_ptr=None, colsum_out=None):
+           accumulate=False, c_off=0, c_hdr=None, c_scale_ptr=None, colsum_out=None, repair=False):
     """Plane-operand GEMM (segmm_gemm_p).  ``c_pt``: optional plane output (its hdr[0] holds the scale to write with);
-    ``c_hdr``: site header that only receives the partial maxima of |C| (no plane output)."""
-    prof = GEMM_PROFILE
+    ``c_hdr``: site header that only receives the partial maxima of |C| (no plane output).  ``repair``: the REPAIR launch of a
+    planes-only NT output (``Cout=None, write_c=False``): same arguments, workgroups leave at once unless the output site's planes
+    are unusable under the recorded scale, in which case they are rewritten with the exact scale of the recorded maxima."""
+    prof = GEMM_PROFILE if not repair else None          # (a repair launch does no work normally: not a GEMM of the roofline)
     if prof is not None:
         e0 = torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -569,7 +571,7 @@ def gemm_p(layout, M, N, K, A: "PT", B: "PT", Cout, ldc, c_pt: "PT" = None, writ
                               B.fptr(), B.ldf, None if Cout is None else Cout.data_ptr() + 4 * c_off, ldc,
                               None if c_pt is None else c_pt.pptr(), 0 if c_pt is None else c_pt.ld2,
                               (None if c_hdr is None else c_hdr.data_ptr()) if c_pt is None else c_pt.hdr.data_ptr(), c_scale_ptr,
-                              int(bool(write_c)),
+                              int(bool(write_c)) | (2 if repair else 0),
                               _ptr(bias), _ptr(row_scale), _ptr(residual),
                               ldr, res_period, activation, _ptr(aux), ldaux, float(drop_p), int(seed), int(site), int(splits),
                               _ptr(workspace), int(bool(accumulate)), _ptr(colsum_out), _stream()), "segmm_gemm_p")
