@@ -453,6 +453,20 @@ int segmm_layer_bwd(const segmm_phase_t* phase, const segmm_stream_t* streams, i
 int segmm_embed_bwd(const segmm_phase_t* phase, const segmm_stream_t* streams, int n_streams, void* const* events);
 int segmm_step_tail(const segmm_phase_t* phase, const segmm_stream_t* streams, int n_streams, void* const* events);
 /* bytes of p[0 .. bytes) = 0 on `stream` (the clears of the step path as a recordable command) */
+/* Small launches that keep the reference's remaining step variants free of host-side tensor ops, so that they can be recorded
+ * and replayed like the default step (round 5):
+ * segmm_bias_grad: learnable_bias (decoder_leave_focal.py:497-504,649-658) -- g_bias_bias[s] = sum_b dl[b, s] (rows in index
+ *   order), g_bias_weight[s] = (s + 1) g_bias_bias[s];
+ * segmm_focal_relabel: focal loss first in the loss list rewrites the labels in place (:534-535): gt > 0 -> 1, gt == -1 -> 0;
+ * segmm_rand_uniform / segmm_rand_ids: the noUser ablations' random user features in [0, 1) and random user ids in [lo, hi)
+ *   (main_for_seq_leave_earlystop_SegMM.py:275-280), segmm_rand_perm_rows: the noPos ablation's fresh permutation of 0 .. S-1 per
+ *   row (encoder.py:428-429; S <= 64, written as floats) -- drawn from the counter hash of the dropout streams (seed with bit
+ *   63 set: the device-side step words are XORed in): the reference's distributions, not torch's bit streams. */
+int segmm_bias_grad(const float* dl, int B, int S, float* g_bias_weight, float* g_bias_bias, segmm_stream_t stream);
+int segmm_focal_relabel(int64_t* gt, int64_t n, segmm_stream_t stream);
+int segmm_rand_uniform(float* out, int64_t n, uint64_t seed, uint32_t site, segmm_stream_t stream);
+int segmm_rand_ids(int64_t* out, int64_t n, int64_t lo, int64_t hi, uint64_t seed, uint32_t site, segmm_stream_t stream);
+int segmm_rand_perm_rows(float* out, int rows, int S, uint64_t seed, uint32_t site, segmm_stream_t stream);
 int segmm_fill_zero(void* p, int64_t bytes, segmm_stream_t stream);
 /* dst[0 .. bytes) = src[0 .. bytes), device to device, on `stream` (non-overlapping ranges) */
 int segmm_copy_bytes(void* dst, const void* src, int64_t bytes, segmm_stream_t stream);

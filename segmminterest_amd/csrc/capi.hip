@@ -223,6 +223,8 @@ static int attn_launch_fwd_pl(AttnArgs& a, hipStream_t s) {
 template <int DH>
 static int attn_launch_fwd(AttnArgs& a, hipStream_t s) {
     if (attn_fwd_pl_takes<DH>(a)) return attn_launch_fwd_pl<DH>(a, s);
+    SEGMM_REQUIRE(a.Qa, "attn_fwd: no fp32 views were given and the planes-in forward does not take this call (it needs dh %% 16 == 0, "
+                        "La %% 4 == 0, Lb %% 4 == 0, Lq <= 112, 4-byte aligned masks; knob ATT_FWD_PL)");
     const int Tp = ((a.La + 15) & ~15) + ((a.Lb + 15) & ~15);
     const int nqt = (a.Lq + 15) / 16;
     int wq, hpb;
@@ -300,7 +302,7 @@ static int attn_launch_bwd(AttnArgs& a, int phase, hipStream_t s) {
         // launches.  SEGMM_ATT_MERGE=0 restores them (A/B, tests)
         {
             const bool f16_takes_it = (DH % 16 == 0 && DH <= 48) && attn_f16() >= 2;
-            if (knob(K_ATT_MERGE) != 0 && phase == 4 && a.Lq <= 32 && nta > 0 && ntb > 0 && nta + ntb <= 4 && !f16_takes_it) {
+            if (!a.in.Qa && knob(K_ATT_MERGE) != 0 && phase == 4 && a.Lq <= 32 && nta > 0 && ntb > 0 && nta + ntb <= 4 && !f16_takes_it) {
                 const int nw = nta + ntb;
                 a.hpb = 3;
                 const dim3 grid(a.B * a.H), block(64 * nw);
@@ -363,6 +365,7 @@ static int attn_launch_bwd(AttnArgs& a, int phase, hipStream_t s) {
                     continue;
                 }
             }
+            SEGMM_REQUIRE(a.Qa, "attn_bwd: no fp32 views were given and the planes-in backward does not take this call (head dims 16, 32, 48)");
             Lq_p = Lq_small;
             lds = ((size_t)3 * Lq_p * (DH + 4) + 3 * Lq_p + (size_t)nw * 16 * 20 + 4 + (size_t)Lq_p * (DH / 4)) * 4 + Lq_p + Tp;
 #define FUSED(NWV) do { if (Lq_p == 16) hipLaunchKernelGGL((attn_bwd_fused_kernel<DH, NWV, true, 16>), grid, block, lds, s, a); \
@@ -492,7 +495,7 @@ __global__ void step_advance_kernel(StepState* st, float b1, float b2) {
 extern "C" {
 
 const char* segmm_last_error(void) { return g_segmm_err; }
-int segmm_abi_version(void) { return 26; }
+int segmm_abi_version(void) { return 27; }
 int segmm_attn_mode(int mode) { const int prev = attn_f16(); if (mode >= 0 && mode <= 2) g_knobs[K_ATTN].value = mode; return prev; }
 
 static PlaneOut plane_out(uint16_t* planes, int ld2, float* hdr, const float* scale_in) {
@@ -1523,6 +1526,44 @@ int segmm_probe_mfma_rate(int workgroups, int iters, float* scratch, double* flo
 }
 
 /* ---- recorded launch sequences (include/segmm_hip.h: "Recorded launch sequences") */
+int segmm_bias_grad(const float* dl, int B, int S, float* g_bias_weight, float* g_bias_bias, segmm_stream_t stream) {
+    SEGMM_REQUIRE(dl && g_bias_weight && g_bias_bias && B > 0 && S > 0, "bias_grad: null pointer / empty");
+    hipLaunchKernelGGL(bias_grad_kernel, dim3((S + 63) / 64), dim3(64), 0, (hipStream_t)stream, dl, B, S, g_bias_weight, g_bias_bias);
+    LAUNCH_CHECK();
+    return 0;
+}
+int segmm_focal_relabel(int64_t* gt, int64_t n, segmm_stream_t stream) {
+    SEGMM_REQUIRE(gt && n >= 0, "focal_relabel: null pointer");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(focal_relabel_kernel, dim3((unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (long long*)gt, (long long)n);
+    LAUNCH_CHECK();
+    return 0;
+}
+int segmm_rand_uniform(float* out, int64_t n, uint64_t seed, uint32_t site, segmm_stream_t stream) {
+    SEGMM_REQUIRE(out && n >= 0, "rand_uniform: null pointer");
+    if (n == 0) return 0;
+    const long long q = (n + 1) / 2;
+    hipLaunchKernelGGL(rand_uniform_kernel, dim3((unsigned)((q + 255) / 256 > 4096 ? 4096 : (q + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, (long long)n, make_drop(0.5f, seed, site));
+    LAUNCH_CHECK();
+    return 0;
+}
+int segmm_rand_ids(int64_t* out, int64_t n, int64_t lo, int64_t hi, uint64_t seed, uint32_t site, segmm_stream_t stream) {
+    SEGMM_REQUIRE(out && n >= 0 && hi > lo && hi - lo < (1ll << 31), "rand_ids: null pointer / empty or too wide a range");
+    if (n == 0) return 0;
+    const long long q = (n + 1) / 2;
+    hipLaunchKernelGGL(rand_ids_kernel, dim3((unsigned)((q + 255) / 256 > 1024 ? 1024 : (q + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (long long*)out, (long long)n, (long long)lo,
+                       (long long)hi, make_drop(0.5f, seed, site));
+    LAUNCH_CHECK();
+    return 0;
+}
+int segmm_rand_perm_rows(float* out, int rows, int S, uint64_t seed, uint32_t site, segmm_stream_t stream) {
+    SEGMM_REQUIRE(out && rows >= 0 && S >= 1 && S <= 64, "rand_perm_rows: null pointer / S = %d (1 .. 64)", S);
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(rand_perm_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, out, rows, S, make_drop(0.5f, seed, site));
+    LAUNCH_CHECK();
+    return 0;
+}
+
 int segmm_fill_zero(void* p, int64_t bytes, segmm_stream_t stream) {
     SEGMM_REQUIRE(p && bytes >= 0, "fill_zero: null pointer / negative size");
     if (bytes == 0) return 0;

@@ -296,4 +296,61 @@ __global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restric
     }
 }
 
+
+// ---------------------------------------------------------------- small kernels that keep the step free of torch ops (round 5)
+// learnable_bias (decoder_leave_focal.py:497-504,649-658: logits += (s + 1) bias_weight[s] + bias_bias[s]): its two gradients,
+// d bias_bias[s] = sum_b dl[b, s] (rows in index order: deterministic) and d bias_weight[s] = (s + 1) d bias_bias[s].
+__global__ void bias_grad_kernel(const float* __restrict__ dl, int B, int S, float* __restrict__ gbw, float* __restrict__ gbb) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    float t = 0.f;
+    for (int b = 0; b < B; ++b) t += dl[(size_t)b * S + s];
+    gbb[s] = t;
+    gbw[s] = (float)(s + 1) * t;
+}
+// focal loss first in the list: the reference rewrites the labels IN PLACE after the loss (decoder_leave_focal.py:534-535:
+// gt[gt > 0] = 1; gt[gt == -1] = 0)
+__global__ void focal_relabel_kernel(long long* __restrict__ gt, long long n) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long v = gt[i];
+        if (v > 0) gt[i] = 1;
+        else if (v == -1) gt[i] = 0;
+    }
+}
+// noUser / noUser_SelfAtt (main_for_seq_leave_earlystop_SegMM.py:275-280: torch.rand_like user features, random user ids): draws from
+// the counter hash of the dropout streams (24 random bits per float, ids by multiply-shift) -- the distribution of the reference's
+// draws, not its bit stream
+__global__ void rand_uniform_kernel(float* __restrict__ out, long long n, DropCfg d0) {
+    const DropCfg d = drop_live(d0);
+    for (long long q = blockIdx.x * (long long)blockDim.x + threadIdx.x; 2 * q < n; q += (long long)gridDim.x * blockDim.x) {
+        const uint2 r = drop_rand_quad(d, (uint64_t)q);
+        out[2 * q] = (float)(r.x >> 8) * (1.0f / 16777216.0f);
+        if (2 * q + 1 < n) out[2 * q + 1] = (float)(r.y >> 8) * (1.0f / 16777216.0f);
+    }
+}
+__global__ void rand_ids_kernel(long long* __restrict__ out, long long n, long long lo, long long hi, DropCfg d0) {
+    const DropCfg d = drop_live(d0);
+    for (long long q = blockIdx.x * (long long)blockDim.x + threadIdx.x; 2 * q < n; q += (long long)gridDim.x * blockDim.x) {
+        const uint2 r = drop_rand_quad(d, (uint64_t)q);
+        const unsigned long long span = (unsigned long long)(hi - lo);
+        out[2 * q] = lo + (long long)(((unsigned long long)r.x * span) >> 32);
+        if (2 * q + 1 < n) out[2 * q + 1] = lo + (long long)(((unsigned long long)r.y * span) >> 32);
+    }
+}
+// noPos (encoder.py:428-429: a fresh torch.randperm(S) per row): one wave per row, lane i < S draws a 32-bit key; its position in
+// the permutation is the number of lanes with a smaller (key, index) -- a uniformly random permutation
+__global__ void rand_perm_rows_kernel(float* __restrict__ out, int rows, int S, DropCfg d0) {
+    const DropCfg d = drop_live(d0);
+    const int lane = threadIdx.x & 63, row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const uint2 r = drop_rand_quad(d, (uint64_t)row * 64u + (uint64_t)lane);
+    const uint32_t key = lane < S ? r.x : 0xffffffffu;
+    int rank = 0;
+    for (int j = 0; j < S; ++j) {
+        const uint32_t kj = (uint32_t)__shfl((int)key, j, 64);
+        rank += (kj < key || (kj == key && j < lane)) ? 1 : 0;
+    }
+    if (lane < S) out[(size_t)row * S + rank] = (float)lane;          // out[row, :] is a permutation of 0 .. S-1 (as floats: frame positions)
+}
+
 }  // namespace segmm

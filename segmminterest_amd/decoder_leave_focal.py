@@ -357,9 +357,7 @@ class MultiScaleTemporalDetrLeaveFocal(nn.Module):
             if Sb != S:
                 H.fill_zero(gbb)
                 H.fill_zero(gbw)
-            E._colsum(st, dl, S, B, S, gbb)
-            pos = torch.arange(1, S + 1, device=dl.device, dtype=torch.float32)
-            gbw.view(-1)[:S].copy_(gbb.view(-1)[:S] * pos)
+            H.bias_grad(dl, B, S, gbw, gbb)          # d bias_bias[s] = sum_b dl[b, s], d bias_weight[s] = (s + 1) d bias_bias[s] (:497-504)
 
     # ------------------------------------------------------------------ forward (decoder_leave_focal.py:574-658)
     def forward(self, usr_image, usr_id, usr_mask, vid_image, vid_id, vid_mask, gt=None, mode="train", **kwargs):
@@ -414,8 +412,11 @@ class MultiScaleTemporalDetrLeaveFocal(nn.Module):
             out["loss"] = total
             out["logits"] = logits
             if self._loss_spec.has_focal:       # the reference rewrites gt in place (:534-535)
-                gt[gt > 0] = 1
-                gt[gt == -1] = 0
+                if gt.is_cuda and gt.dtype == torch.int64 and gt.is_contiguous():
+                    H.focal_relabel(gt)
+                else:
+                    gt[gt > 0] = 1
+                    gt[gt == -1] = 0
             out["gt"] = gt
             return out
         _, _, logits = HeadLossFn.apply(self, False, v1, v2, gt, *hp)

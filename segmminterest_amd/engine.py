@@ -41,6 +41,8 @@ def _j(prefix, name):
 # =============================================================================================== parameter store
 MLP_VARIANTS = ("CrossMLP", "SelfMLP", "w/oAtt")       # ablations that replace the encoder (encoder.py:392-400,503-511)
 K_MLP0 = 11                                             # dropout kinds 11.. : hidden layers of the ablation MLP_Block
+# streams of the device-side draws that replace the reference's host draws in a device-state / recorded step (same hash, own sites)
+SITE_NOUSER_FEAT, SITE_NOUSER_IDS, SITE_NOPOS = 3 * 4096 + 1, 3 * 4096 + 2, 3 * 4096 + 3
 POOL_BINS = 40                                          # nn.AdaptiveAvgPool1d(40), encoder.py:396
 
 
@@ -1119,8 +1121,16 @@ class BackboneRun:
             sv["vid_ids"] = ids
             fpos = None
             if "noPos" in self.abl:      # a fresh shuffle of the segment positions per row and per call, from torch's CPU
-                # generator exactly like the reference (encoder.py:428-429: B x torch.randperm(Lv))
-                fpos = torch.stack([torch.randperm(S) for _ in range(B)]).float().to(ids.device).contiguous()
+                # generator exactly like the reference (encoder.py:428-429: B x torch.randperm(Lv)) -- or, when the step's state
+                # lives on the device (Trainer(device_state=True): the step may be recorded), drawn on the device: the same
+                # distribution (a uniformly random permutation per row), another bit stream
+                live = st.__dict__.get("live_seed")
+                if live is not None and train and S <= 64:
+                    fpos = st.buf("nopos_fpos%d" % self.bi, (B, S))
+                    H.rand_perm_rows(fpos, B, S, live, SITE_NOPOS + 16 * self.bi)
+                else:
+                    H.torch_fallback("the noPos ablation's torch.randperm draws")
+                    fpos = torch.stack([torch.randperm(S) for _ in range(B)]).float().to(ids.device).contiguous()
             sv["frame_pos"] = fpos
             H.embed_id_vid(ids, st.p(P + "vid_proj.weight"), d // 2, st.p(P + "frameid_proj.weight"),
                            st.p(P + "frameid_proj.bias"), st.p(P + "vid_pe.weight") if use_pe else None, pre_v, B, S, frame_pos=fpos)

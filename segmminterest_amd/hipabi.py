@@ -15,7 +15,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SEGMM_LIB") or os.path.join(_HERE, "libsegmm_hip.so")      # SEGMM_LIB: A/B builds of the kernels
-ABI_VERSION = 26
+ABI_VERSION = 27
 
 _lib = None
 
@@ -88,6 +88,11 @@ SIGNATURES = {
     "segmm_colsum3": [_p, _p, _p, _i, _i64, _i, _p, _p, _p, _p, _p],
     "segmm_pool_tokens": [_p, _i, _p, _i, _p, _i, _i, _i, _p],
     "segmm_pool_tokens_bwd": [_p, _p, _i, _p, _i, _i, _i, _i, _p],
+    "segmm_bias_grad": [_p, _i, _i, _p, _p, _p],
+    "segmm_focal_relabel": [_p, _i64, _p],
+    "segmm_rand_uniform": [_p, _i64, _u64, _u32, _p],
+    "segmm_rand_ids": [_p, _i64, _i64, _i64, _u64, _u32, _p],
+    "segmm_rand_perm_rows": [_p, _i, _i, _u64, _u32, _p],
     "segmm_fill_zero": [_p, _i64, _p],
     "segmm_copy_bytes": [_p, _p, _i64, _p],
     "segmm_cmd_op_count": [],
@@ -970,6 +975,26 @@ def _adamw(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, p_off=0):
     _check(lib().segmm_adamw(p.data_ptr() + 4 * p_off, g.data_ptr() + 4 * p_off, m.data_ptr() + 4 * p_off,
                              v.data_ptr() + 4 * p_off, n, lr, beta1, beta2, eps, weight_decay, step, _stream()),
            "segmm_adamw")
+
+
+def bias_grad(dl, B, S, gbw, gbb):
+    _check(lib().segmm_bias_grad(_ptr(dl), int(B), int(S), _ptr(gbw), _ptr(gbb), _stream()), "segmm_bias_grad")
+
+
+def focal_relabel(gt):
+    _check(lib().segmm_focal_relabel(_ptr(gt), gt.numel(), _stream()), "segmm_focal_relabel")
+
+
+def rand_uniform(out, seed, site):
+    _check(lib().segmm_rand_uniform(_ptr(out), out.numel(), int(seed), int(site), _stream()), "segmm_rand_uniform")
+
+
+def rand_ids(out, lo, hi, seed, site):
+    _check(lib().segmm_rand_ids(_ptr(out), out.numel(), int(lo), int(hi), int(seed), int(site), _stream()), "segmm_rand_ids")
+
+
+def rand_perm_rows(out, rows, S, seed, site):
+    _check(lib().segmm_rand_perm_rows(_ptr(out), int(rows), int(S), int(seed), int(site), _stream()), "segmm_rand_perm_rows")
 
 
 def dropout_mult(out, n, p, seed, site):

@@ -733,11 +733,28 @@ class Trainer:
         if "noUser" in getattr(model.backbone1, "ablation_type", "ours"):
             # 'noUser' / 'noUser_SelfAtt' (main...SegMM.py:275-280, main...KuaiRand.py:254-258): the TRAINING forward sees
             # uniform-random user features and random user ids in [1, n_users); validation keeps the real ones
-            if usr is not None:
-                usr = torch.rand_like(usr)
+            live = st.__dict__.get("live_seed")
             n_users = self._n_users()
-            if n_users is not None:
-                usr_id = torch.randint(1, max(n_users, 2), usr_id.shape, device=usr_id.device)
+            if live is not None:
+                # device-side step state (the step may be recorded): the draws come from the library's counter hash, into persistent
+                # buffers -- the reference's distributions (U[0, 1) features, uniform ids), not torch's bit stream
+                if usr is not None:
+                    buf = self.__dict__.get("_nouser_feat")
+                    if buf is None or buf.shape != usr.shape or buf.device != usr.device:
+                        buf = self._nouser_feat = torch.empty_like(usr)
+                    H.rand_uniform(buf, live, E.SITE_NOUSER_FEAT)
+                    usr = buf
+                if n_users is not None:
+                    ib = self.__dict__.get("_nouser_ids")
+                    if ib is None or ib.shape != usr_id.shape or ib.device != usr_id.device:
+                        ib = self._nouser_ids = torch.empty_like(usr_id, dtype=torch.int64)
+                    H.rand_ids(ib, 1, max(n_users, 2), live, E.SITE_NOUSER_IDS)
+                    usr_id = ib
+            else:
+                if usr is not None:
+                    usr = torch.rand_like(usr)
+                if n_users is not None:
+                    usr_id = torch.randint(1, max(n_users, 2), usr_id.shape, device=usr_id.device)
         out = model(usr_image=usr, usr_id=usr_id, usr_mask=um, vid_image=vid,
                     vid_id=batch["photo_identity_id"], vid_mask=vm, gt=batch["label"], mode="train")
         if self.comm.active:
@@ -810,14 +827,8 @@ class Trainer:
         if not self.device_state:
             raise RuntimeError("record() needs Trainer(device_state=True): the per-step state must live on the device")
         model, st = self.model, self.model._store
-        for bb in (model.backbone1, getattr(model, "backbone2", None)):
-            abl = getattr(bb, "ablation_type", "ours") if bb is not None else "ours"
-            if "noUser" in abl or "noPos" in abl:
-                raise RuntimeError("record(): ablation %r draws random inputs on the host every step" % abl)
-        spec = getattr(model, "_loss_spec", None)
-        if (spec is not None and spec.has_focal) or model.bias_weight is not None or self._param_hooks():
-            raise RuntimeError("record(): focal loss (rewrites gt with torch ops), learnable_bias and parameter hooks keep torch "
-                               "kernels inside the step; use train_step")
+        if self._param_hooks():
+            raise RuntimeError("record(): parameter hooks only fire when the gradients travel through autograd; use train_step")
         for k, v in batch.items():
             if torch.is_tensor(v) and not v.is_contiguous():
                 raise RuntimeError("record(): batch[%r] is not contiguous" % k)

@@ -497,6 +497,84 @@ def test_recorded_step_equals_eager_device_state_step(kind, N, B, S, Lt, D, h):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["learnable_bias", "focal_first", "noUser", "noUser_SelfAtt", "noPos"])
+def test_recorded_step_covers_every_step_variant_of_the_reference(variant):
+    """Round 5: record() accepts the variants it used to refuse because they kept torch ops or host draws inside the step --
+    learnable_bias (decoder_leave_focal.py:497-504,649-658: segmm_bias_grad), focal loss first in the list (:534-535: labels rewritten
+    in place by segmm_focal_relabel), the noUser ablations (main...SegMM.py:275-280) and noPos (encoder.py:428-429), whose random
+    inputs are drawn on the device from the step's own state (the reference's distributions; another bit stream than torch's).
+    In the device-state mode the eager step makes the same draws: recorded and eager steps leave BIT-IDENTICAL parameters."""
+    import torch
+    from segmminterest_amd import hipabi as H
+    from segmminterest_amd.synth import make_batch
+    from segmminterest_amd.trainer import Trainer, default_args, init_model
+    dev = torch.device("cuda:0")
+    B, S, Lt, D, N, h = 32, 40, 8, 64, 3, 4
+    kind = "id" if variant == "noPos" else "image"
+    over = dict(num_layers_enc=N, d_model=D, nhead=h, input_type={"user": kind, "photo": kind}, exposure_prob=[1.0] * S)
+    if variant == "learnable_bias":
+        over["learnable_bias"] = 1
+    elif variant == "focal_first":
+        over["loss_type_list"] = ["focal", "interestBPR"]
+    else:
+        over["ablation_type"] = variant
+    margs = default_args(**over)
+    base = [make_batch(B, S, 1 if kind == "id" else Lt, D, n_users=50, n_items=500, seed=700 + i, features=kind != "id") for i in range(3)]
+
+    def run(recorded):
+        torch.manual_seed(11)
+        batches = [{k: v.to(dev).clone() for k, v in b.items()} for b in base]          # (focal rewrites the labels in place)
+        model = init_model(margs, n_users=50, n_items=500, input_dim=D, max_vid_len=S, max_usr_len=Lt).to(dev)
+        tr = Trainer(model, lr=1e-3, weight_decay=1e-4, device_state=True)
+        losses = []
+        if recorded:
+            tr.record(batches[0], warmup=2)
+        else:
+            for _ in range(3):
+                tr.train_step(batches[0])
+        for t in range(9):
+            out = tr.run_recorded(batches[t % 3]) if recorded else tr.train_step(batches[t % 3])
+            losses.append(float(out["loss"].detach()))
+        torch.cuda.synchronize()
+        return model._store.flat.detach().clone(), losses, [b["label"].clone() for b in batches]
+
+    pe, le, ge = run(False)
+    pr, lr_, gr = run(True)
+    assert torch.isfinite(pe).all() and le == lr_ and len(set(le)) > 1
+    assert torch.equal(pe, pr)
+    for a, b in zip(ge, gr):
+        assert torch.equal(a, b)
+    if variant == "focal_first":          # the labels were rewritten: no value above 1, no -1 left
+        assert int(ge[0].max()) <= 1 and int((ge[0] == -1).sum()) == 0
+
+
+@pytest.mark.gpu
+def test_device_draws_have_the_reference_distributions():
+    """segmm_rand_uniform / segmm_rand_ids / segmm_rand_perm_rows (the device-side stand-ins for torch.rand_like, torch.randint and
+    torch.randperm in recorded steps): uniform on [0, 1), uniform on [lo, hi), a uniformly random permutation per row."""
+    import torch
+    from segmminterest_amd import hipabi as H
+    dev = torch.device("cuda:0")
+    u = torch.empty(1 << 20, device=dev)
+    H.rand_uniform(u, 12345, 7)
+    assert float(u.min()) >= 0.0 and float(u.max()) < 1.0 and abs(float(u.mean()) - 0.5) < 2e-3 and abs(float(u.var()) - 1 / 12) < 2e-3
+    u2 = torch.empty_like(u)
+    H.rand_uniform(u2, 12346, 7)
+    assert not torch.equal(u, u2) and abs(float(((u - 0.5) * (u2 - 0.5)).mean())) < 1e-3
+    ids = torch.empty(1 << 18, dtype=torch.int64, device=dev)
+    H.rand_ids(ids, 1, 50, 99, 3)
+    assert int(ids.min()) == 1 and int(ids.max()) == 49
+    cnt = torch.bincount(ids, minlength=50)[1:].float()
+    assert float((cnt / cnt.mean() - 1).abs().max()) < 0.06
+    rows, S = 4096, 40
+    perm = torch.empty(rows, S, device=dev)
+    H.rand_perm_rows(perm, rows, S, 777, 5)
+    assert torch.equal(perm.sort(1).values, torch.arange(S, device=dev, dtype=torch.float32).expand(rows, S))
+    first = torch.bincount(perm[:, 0].long(), minlength=S).float()          # every value equally likely in every position
+    assert float((first / first.mean() - 1).abs().max()) < 0.4 and len({tuple(r.tolist()) for r in perm[:64]}) == 64
+
+
+@pytest.mark.gpu
 def test_record_refuses_what_a_replay_would_drop():
     """a recorded step replays C-ABI launches only, so record() must refuse every input whose handling needs a torch
     kernel inside the step -- uint8 / float masks, int32 ids, fp16 features -- instead of freezing the record-time result; the
