@@ -144,7 +144,9 @@ int segmm_split3(const float* x, uint16_t* planes, int64_t n, int64_t pstride, s
 int segmm_split3_transpose(const float* x, int R, int C, int ld, uint16_t* planes, int64_t pstride, segmm_stream_t stream);
 
 /* LayerNorm(d, eps) forward/backward (encoder.py:39-40,170-171,185-186,203,206,383-385,455,465).
- * forward: optional dropout on the output (embedding dropout, encoder.py:461,471).
+ * forward: optional dropout on the output (embedding dropout, encoder.py:461,471).  y == NULL with a plane output (round 5):
+ * PLANES ONLY -- the planes are written with the scale of the output's bound (max|gamma| sqrt(d) + max|beta|) / (1 - p), derived
+ * in the kernel (scale_in is ignored) and recorded in hdr[0]: no input can overflow it, so the consumers need no fp32 fallback.
  * backward: dy is first multiplied by the forward's output-dropout mask (drop_y_*); dx_drop (may be NULL) receives
  * dx times the mask of the residual-branch dropout "x = res + dropout(branch)" (drop_b_*), i.e. d(branch).
  * part_dgamma/part_dbeta: [nparts, d] per-workgroup partials, nparts = segmm_layernorm_bwd_parts(rows).

@@ -932,11 +932,11 @@ static int ln_fwd_launch(const float* x, const float* gamma, const float* beta, 
                          int64_t rows, int d, float eps, float drop_p, uint64_t seed, uint32_t site, float* amax,
                          uint16_t* planes, int ld2, float* hdr, const float* scale_in, const float* dot_w, const float* dot_b, float* dot_out,
                          segmm_stream_t stream) {
-    SEGMM_REQUIRE(x && gamma && beta && y && mean && rstd, "layernorm_fwd: null pointer");
+    SEGMM_REQUIRE(x && gamma && beta && (y || (planes && hdr)) && mean && rstd, "layernorm_fwd: null pointer");
     SEGMM_REQUIRE(!dot_w || (dot_out && aligned16(dot_w)), "layernorm_fwd_dot: head weight / output");
     PLANE_OUT_CHECK("layernorm_fwd", d);
     SEGMM_REQUIRE(d > 0 && d % 4 == 0 && d <= 256 * ROW_MAXV, "layernorm_fwd: d=%d unsupported", d);
-    SEGMM_REQUIRE(aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta), "layernorm_fwd: alignment");
+    SEGMM_REQUIRE(aligned16(x) && (!y || aligned16(y)) && aligned16(gamma) && aligned16(beta), "layernorm_fwd: alignment");
     if (rows <= 0) return 0;
     const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
     const DropCfg dc = make_drop(drop_p, seed, site);

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float* xr = x + row * d;
-    const float ps = plane_scale(po);
+    float ps = plane_scale(po);
     f32x4 v[V];
     float s = 0.f;
 #pragma unroll
@@ -106,6 +106,18 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
         const int c = lane * 4 + i * 256;
         v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (c < d) { v[i] = *(const f32x4*)(xr + c); s += v[i].x + v[i].y + v[i].z + v[i].w; }
+    }
+    if (y == nullptr) {
+        // PLANES ONLY (no fp32 copy a consumer could fall back on): the planes are written with the scale of the output's BOUND,
+        // |y| <= (max|gamma| sqrt(d - 1) + max|beta|) / (1 - p) for any input row -- it cannot overflow whatever the batch, needs no
+        // history and no repair pass, and sits ~sqrt(d) / 4 above the typical maximum (3 of the 9 binades of the consumers' window)
+        float gm = 0.f, bm = 0.f;
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const int c = lane * 4 + i * 256;
+            if (c < d) { gm = absmax4(gm, *(const f32x4*)(gamma + c)); bm = absmax4(bm, *(const f32x4*)(beta + c)); }
+        }
+        ps = f16_scale_of((wave_max(gm) * sqrtf((float)d) + wave_max(bm)) * drop.scale);
     }
     const float mean = wave_sum(s) / d;
     float q = 0.f;
@@ -126,7 +138,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
         if (c < d) {
             f32x4 o = (v[i] - mean) * rstd * *(const f32x4*)(gamma + c) + *(const f32x4*)(beta + c);
             if (drop.p > 0.f) o = drop_apply4(drop, ((uint64_t)row * d + c) >> 2, o);
-            *(f32x4*)(y + row * d + c) = o;
+            if (y) *(f32x4*)(y + row * d + c) = o;
             if (ps > 0.f) plane_store4_pair(po.p, po.ld2, row, c, o, ps);
             am = absmax4(am, o);
             if (dot_w) {

@@ -172,6 +172,7 @@ class ParamStore:
         # 1 (default): with the projection outputs Yv / Yu as planes ONLY (no fp32 copy: the planes-in backward reads them too, a repair
         # launch of the GEMM covers a wrong delayed scale); 2: planes beside the fp32 copy, forward only (measured -1.5 %); 0: off
         self.attn_pl = int(os.environ.get("SEGMM_ATT_PL", "1"))
+        self.eu_planes_only = os.environ.get("SEGMM_EU_PLANES_ONLY", "1") != "0"          # user embedding as planes only (N = 2, trainer's step)
         self.head_side = os.environ.get("SEGMM_HEAD_SIDE", "1") != "0"
         self.input_planes_only = os.environ.get("SEGMM_INPUT_PLANES_ONLY", "1") != "0"
         self.attn_two_streams = os.environ.get("SEGMM_ATTN_TWO_STREAMS", "0") == "1"
@@ -1085,7 +1086,17 @@ class BackboneRun:
         H.mark(H.PHASE_EMBED_FWD, self.bi)
         pre_u = _empty(ref, Mu, d)
         meu, reu = _empty(ref, Mu), _empty(ref, Mu)
-        Eu = new_act(st, am, Mu, d, planes=usr_is_operand, site=P + "Eu", delayed=self.delayed)
+        # The user embedding as PLANES ONLY (round 5): in the trainer's own step of a model whose first layer is not full (N = 2:
+        # BASELINE configs 2 / 4 / 5) nothing reads its fp32 values -- it is the operand of the fused user projection and of that
+        # projection's weight gradient -- so the LayerNorm writes the planes alone, with the scale of its output bound (no history,
+        # no overflow, no repair: segmm_layernorm_fwd with y = NULL), 157 MB less on the chain that bounds the forward
+        eu_po = bool(self.delayed and st.eu_planes_only and st.__dict__.get("_trusted") and not bb.id_usr and layered and self.N == 2 and
+                     self.mode != "self" and d % 32 == 0 and _FEW_TILES == 0)
+        if eu_po:
+            Eu = Act(None, am.new(P + "Eu"), Mu, d, torch.empty((Mu, 2 * d), dtype=torch.float16, device=st.flat.device))
+            Eu.po, Eu.no_f32 = H.PO(Eu.planes, 2 * d, Eu.hdr, None), True
+        else:
+            Eu = new_act(st, am, Mu, d, planes=usr_is_operand, site=P + "Eu", delayed=self.delayed)
         Yu0 = None
         fwd_side = st.overlap and st.fwd_side and not bb.id_usr and layered and self.mode != "self"
         if bb.id_usr:
@@ -1156,7 +1167,8 @@ class BackboneRun:
             H.mark(H.PHASE_LAYER_FWD, self.bi, i)
             Xv, Xu = self._layer_fwd(i, Xv, Xu, Yu_ready=Yu0 if i == 0 else None)
         am.close(st)
-        return Xv.t.view(B, S, d), Eu.t.view(B, Lt, d)
+        # (planes-only user embedding: there is no fp32 tensor to hand out -- the trainer's step, the only caller, ignores it)
+        return Xv.t.view(B, S, d), (Eu.t.view(B, Lt, d) if Eu.t is not None else Xv.t.new_empty(0))
 
     # ---------------------------------------------------------------- MLP ablations (encoder.py:392-400,503-511)
     def _mlp_fwd(self, X, M, tok):

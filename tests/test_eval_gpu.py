@@ -575,6 +575,43 @@ def test_device_draws_have_the_reference_distributions():
 
 
 @pytest.mark.gpu
+def test_user_embedding_as_planes_only_gives_the_same_step():
+    """Round 5: in the trainer's own step of an N = 2 model the user embedding exists as P32 planes only -- its LayerNorm writes them
+    with the scale of the output BOUND (segmm_layernorm_fwd, y = NULL), the fused user projection and its weight gradient read them
+    without an fp32 fallback (encoder.py:462-471 feeds encoder.py:95-104).  The step's loss and every gradient agree with the
+    step that keeps the fp32 embedding and its delayed-scale planes to the accuracy of the 22-bit operands; an outlier LayerNorm
+    gain (x 200 on one column) moves the bound, not the result."""
+    import torch
+    from segmminterest_amd.synth import make_batch
+    from segmminterest_amd.trainer import Trainer, default_args, init_model
+    dev = torch.device("cuda:0")
+    B, S, Lt, D, h = 64, 40, 100, 256, 8
+    margs = default_args(num_layers_enc=2, d_model=D, nhead=h, input_type={"user": "image", "photo": "image"}, exposure_prob=[1.0] * S)
+    batch = {k: v.to(dev) for k, v in make_batch(B, S, Lt, D, n_users=50, n_items=500, seed=77).items()}
+
+    def run(flag, outlier):
+        torch.manual_seed(3)
+        model = init_model(margs, n_users=50, n_items=500, input_dim=D, max_vid_len=S, max_usr_len=Lt).to(dev)
+        if outlier:
+            with torch.no_grad():
+                model.backbone1.usr_ln.weight[5] *= 200.0
+        tr = Trainer(model, lr=1e-3, weight_decay=1e-4, dropout=False)
+        model._store.eu_planes_only = flag
+        outs = []
+        for _ in range(3):          # step 1 calibrates the sites, steps 2 and 3 run on producer-written planes
+            o = tr.train_step(batch)
+            outs.append((float(o["loss"].detach()), model._store.gflat.detach().clone()))
+        return outs
+
+    for outlier in (False, True):
+        ref, got = run(False, outlier), run(True, outlier)
+        for (l0, g0), (l1, g1) in zip(ref, got):
+            assert abs(l0 - l1) <= 2e-5 * max(abs(l0), 1e-3), (l0, l1)
+            assert float((g0 - g1).abs().max()) <= 3e-5 * float(g0.abs().max())
+        assert torch.isfinite(got[-1][1]).all()
+
+
+@pytest.mark.gpu
 def test_record_refuses_what_a_replay_would_drop():
     """a recorded step replays C-ABI launches only, so record() must refuse every input whose handling needs a torch
     kernel inside the step -- uint8 / float masks, int32 ids, fp16 features -- instead of freezing the record-time result; the
