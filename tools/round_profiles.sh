@@ -1,5 +1,5 @@
 # Round checkpoint on the GPU box: every number the docs quote, in one call.   bash tools/round_profiles.sh <tag> <git sha>
-TAG=${1:-r4}; export GIT_SHA=${2:-unknown}
+TAG=${1:-r5}; export GIT_SHA=${2:-unknown}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
@@ -29,4 +29,10 @@ bash tools/pmc_run.sh ${TAG}_pmc_tn gemm_pl tools/gemm_p_one.py tn 3072 768 2048
 bash tools/pmc_run.sh ${TAG}_pmc_attn attn_ tools/attn_bench.py 3 > /dev/null 2>&1; grep -v "dq_kernel\|dkv_kernel\|D_kernel" gpurun_out/${TAG}_pmc_attn/summary.csv > $O/attention_pmc.csv
 python tools/attn_bench.py 20 > $O/attention_standalone.txt 2>&1; LQ=100 python tools/attn_bench.py 20 >> $O/attention_standalone.txt 2>&1; python tools/attn_bench_small.py >> $O/attention_standalone.txt 2>&1
 python tools/gemm_p_check.py > $O/gemm_p_standalone.txt 2>&1
+ls -la $O
+python tools/hipblaslt_yardstick.py 20 > $O/hipblaslt_yardstick.txt 2>&1
+python tools/gemm_out_variants.py 20 > $O/gemm_out_variants.txt 2>&1
+SEGMM_ATT_PL=0 python bench.py --steps 20 --warmup 5 $X > $O/bench_n1_att_pl0.json 2>/dev/null
+SEGMM_EU_PLANES_ONLY=0 python bench.py --steps 20 --warmup 5 $X > $O/bench_n1_eu_fp32.json 2>/dev/null
+bash tools/pmc_bin.sh ${TAG}_pmc_fwdpl attn_fwd_pl tools/probe/attn_pl_bench 3 > /dev/null 2>&1; cp gpurun_out/${TAG}_pmc_fwdpl/summary.csv $O/attention_fwd_pl_pmc.csv
 ls -la $O
