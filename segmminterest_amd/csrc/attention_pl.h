@@ -369,7 +369,7 @@ inline size_t attn_bwd_pl_lds_bytes(int QC, int nw, int /*Tp*/) {
 // dO and O still arrive as fp32 (staged and converted like before).  (A first version staged Q and the K tile by LDS-DMA: an
 // LDS-DMA tile on the critical path -- issue, land, ds_read -- was 24 us slower per launch than fragments straight to registers,
 // profiles/r5/attention_planes_in.txt.)
-template <int DH, int NW, bool ONE>
+template <int DH, int NW, bool ONE, bool WALK = false>
 __global__ __launch_bounds__(64 * NW, NW <= 4 ? SEGMM_ATT16_WPS : 4) void attn_bwd_pl_kernel(const AttnArgs p) {
     using C = AttnCfg<DH>;
     const DropCfg drop_ = drop_live(p.drop);
@@ -383,7 +383,16 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? SEGMM_ATT16_WPS : 4) void attn_b
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int l15 = lane & 15, g = lane >> 4;
-    const int wg = xcd_remap(blockIdx.x, gridDim.x), bh = p.hpb == 2 ? wg >> 1 : wg, b = bh / p.H, h = bh % p.H;
+    // A launch has one workgroup per (b, h, key block) -- except the REPAIR launch (WALK), which the host makes 512 workgroups
+    // wide: each walks its share of the heads if there is anything to repair, and normally all of them leave after two scalar
+    // loads.  (A full-width launch of workgroups that leave at once still has to be PLACED with 44 KB of LDS each beside the
+    // weight-gradient GEMM that holds 120 of a CU's 160 KB: 59 us on the main stream at config 2 for nothing.)  The stride is
+    // even, so a workgroup keeps its key block, its wave count and its verdict over all its heads: the `return`s below end it
+    // for good.  A separate instantiation: the loop around the body cost the one-head form 100 us (389 -> 495 us).
+    const int n_wg = (p.hpb == 2 ? 2 : 1) * p.B * p.H;
+    int wg_it = blockIdx.x;
+  do {
+    const int wg = WALK ? wg_it : xcd_remap(wg_it, n_wg), bh = p.hpb == 2 ? wg >> 1 : wg, b = bh / p.H, h = bh % p.H;
     const bool isa = p.hpb == 2 ? (wg & 1) == 0 : p.hpb == 0;
     const int La_p = round16(p.La), Lb_p = round16(p.Lb), Tp = La_p + Lb_p, nta = La_p >> 4, ntb = Lb_p >> 4;
     const int ntk = isa ? nta : ntb;                       // key tiles of the block
@@ -771,6 +780,11 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? SEGMM_ATT16_WPS : 4) void attn_b
             else if (p.amax_q) amax_commit(p.amax_q, am_q, blockIdx.x * nw + wave);
         }
     }
+    if constexpr (!WALK) break;
+    wg_it += gridDim.x;
+    if (wg_it >= n_wg) break;
+    __syncthreads();          // the next head's staging overwrites what was just read
+  } while (true);
 }
 
 }  // namespace segmm

@@ -98,7 +98,7 @@ static int attn_fill(AttnArgs& a, int B, int H, int dh, int Lq, int La, int Lb, 
 // launch path.  Knobs whose non-default values give WRONG results (timing probes) do not exist in this build: they are compiled
 // in by -DSEGMM_ATT_PROBE / -DSEGMM_GEMM_PROBE only.
 enum {
-    K_ATTN, K_ATT_FWD_PL, K_ATT_FWD_LDS, K_ATT_FWD_KSPLIT, K_ATT_FWD_LDS_PAD, K_ATT_FUSED_LAUNCH, K_ATT_MERGE, K_ATT_LDS_PAD, K_ATT_WAVES,
+    K_ATTN, K_ATT_FWD_PL, K_ATT_FWD_LDS, K_ATT_FWD_KSPLIT, K_ATT_FWD_LDS_PAD, K_ATT_FUSED_LAUNCH, K_ATT_MERGE, K_ATT_LDS_PAD, K_ATT_WAVES, K_ATT_REPAIR_WALK,
     K_ATT_HPB_FWD, K_ATT_HPB_DQ, K_ATT_HPB_DKV, K_L1NORM_REG, K_GEMM_BN, K_PL_VAR, K_PL_NJ, K_TN_VAR, K_COUNT
 };
 struct Knob { const char* name; int value; const char* doc; };
@@ -112,6 +112,7 @@ static Knob g_knobs[K_COUNT] = {
     {"ATT_MERGE", 1, "short heads: one workgroup per head for both key blocks in the fused backward"},
     {"ATT_LDS_PAD", 0, "probe: extra LDS bytes per backward workgroup"},
     {"ATT_WAVES", 4, "fused fp16x3 backward: waves per workgroup (key tiles in passes)"},
+    {"ATT_REPAIR_WALK", 512, "planes-in backward, repair launch: workgroups that walk the heads (0: one workgroup per head)"},
     {"ATT_HPB_FWD", 0, "forward workgroup shape heads | tiles << 8 (env: \"heads[,tiles]\"; 0: built-in)"},
     {"ATT_HPB_DQ", 0, "dQ kernel workgroup shape, as above"},
     {"ATT_HPB_DKV", 0, "dK/dV kernel workgroup shape, as above"},
@@ -333,7 +334,13 @@ static int attn_launch_bwd(AttnArgs& a, int phase, hipStream_t s) {
                     const int nwp = one && nw > 4 ? 4 : nw;
                     const size_t ldsp = attn_bwd_pl_lds_bytes<DH>(Lq_p, nwp, Tp);
                     const dim3 blockp(64 * nwp);
-#define FUSEDPL(NWV) do { if (one) hipLaunchKernelGGL((attn_bwd_pl_kernel<DH, NWV, true>), grid, blockp, ldsp, s, a); \
+                    // the repair launch: 512 workgroups that walk the heads (and normally leave at once) instead of one per head
+                    const bool walk = (a.pflags & ATT_REPAIR) != 0;
+                    const unsigned nwalk = (unsigned)knob(K_ATT_REPAIR_WALK) & ~1u;          // (even: a workgroup keeps its key block)
+                    const dim3 gridp(walk && nwalk && grid.x > nwalk ? nwalk : grid.x);
+#define FUSEDPL(NWV) do { if (walk) { if (one) hipLaunchKernelGGL((attn_bwd_pl_kernel<DH, NWV, true, true>), gridp, blockp, ldsp, s, a); \
+                                      else hipLaunchKernelGGL((attn_bwd_pl_kernel<DH, NWV, false, true>), gridp, blockp, ldsp, s, a); } \
+                          else if (one) hipLaunchKernelGGL((attn_bwd_pl_kernel<DH, NWV, true>), grid, blockp, ldsp, s, a); \
                           else hipLaunchKernelGGL((attn_bwd_pl_kernel<DH, NWV, false>), grid, blockp, ldsp, s, a); } while (0)
                     if (nwp <= 4) FUSEDPL(4);
                     else if (nwp <= 8) FUSEDPL(8);

@@ -508,6 +508,69 @@ def test_attention_bwd_on_input_planes(B, H_, dh, Lq, La, Lb, p, case):
         assert float((a_ - b_).abs().max()) <= 3e-6 * max(m, 1e-30), (name, float((a_ - b_).abs().max()) / max(m, 1e-30))
 
 
+@pytest.mark.parametrize("B,H_,bad", [(40, 16, 2.0 ** 30), (40, 16, 2.0 ** -30), (3, 16, 2.0 ** 30)])
+def test_attention_bwd_repair_launch_walks_the_heads(B, H_, bad):
+    """The planes-only protocol of the planes-in fused backward at the op level: outputs written with a delayed scale that is
+    2^30 off (overflow / below the fp16 window), segmm_site_fixup, then the REPAIR launch -- 512 workgroups wide, each walking
+    its share of the B * H = 640 heads (csrc/attention_pl.h) -- must leave exactly the planes of the fp32 gradients under the
+    exact scale of their maxima, and that scale in the header.  (B = 3: the repair launch at one workgroup per head.)"""
+    H = _abi()
+    dh, Lq, La, Lb, p = 48, 40, 40, 100, 0.1
+    d = H_ * dh
+    g = torch.Generator().manual_seed(B + 5)
+    nv, nu = 4, 2
+    Yv = (torch.randn(B * La, nv * d, generator=g) * 0.7).to(DEV)
+    Yu = (torch.randn(B * Lb, nu * d, generator=g) * 0.7).to(DEV)
+    mq = (torch.rand(B, Lq, generator=g) < 0.8).to(DEV)
+    mkb = (torch.rand(B, Lb, generator=g) < 0.7).to(DEV)
+    plv, hv = _site_planes(H, Yv, Yv.shape[0], nv * d)
+    plu, hu = _site_planes(H, Yu, Yu.shape[0], nu * d)
+    pin = dict(q=(plv, hv, 2 * nv * d), a=(plv, hv, 2 * nv * d), b=(plu, hu, 2 * nu * d))
+    views = ((Yv, 0), (Yv, d), nv * d, (Yv, 2 * d), (Yv, 3 * d), nv * d, (Yu, 0), (Yu, d), nu * d)
+    none_views = ((None, 0), (None, d), nv * d, (None, 2 * d), (None, 3 * d), nv * d, (None, 0), (None, d), nu * d)
+    O = torch.empty(B * Lq, d, device=DEV); lse = torch.empty(2, B, H_, Lq, device=DEV)
+    H.attn_fwd(B, H_, dh, Lq, La, Lb, *views, mq, mq, mkb, O, d, lse, drop_p=p, seed=11, site=3, pin=pin)
+    dO = torch.randn(B * Lq, d, generator=g).to(DEV)
+    Dv = torch.empty(B * H_ * Lq, device=DEV)
+
+    def bwd(dYv, dYu, planes=None):
+        H.attn_bwd(B, H_, dh, Lq, La, Lb, *(views if planes is None else none_views), mq, mq, mkb, lse, O, d, dO, d, Dv,
+                   (dYv, 0), (dYv, d), nv * d, (dYv, 2 * d), (dYv, 3 * d), nv * d, (dYu, 0), (dYu, d), nu * d,
+                   drop_p=p, seed=11, site=3, phase=4, pin=pin, planes=planes)
+    dYv, dYu = torch.zeros_like(Yv), torch.zeros_like(Yu)
+    bwd(dYv, dYu)                                              # fp32 gradients of the same kernel
+    import math
+
+    def scale_of(m):          # common.h f16_scale_of: the power of two with m * s in [2^14, 2^15)
+        return 2.0 ** (14 - math.floor(math.log2(m)))
+    sv, su = scale_of(float(dYv.abs().max())), scale_of(float(dYu.abs().max()))
+    ov, _, scv, _ = _po(H, B * La, nv * d, sv * bad)
+    ou, _, scu, _ = _po(H, B * Lb, nu * d, su * bad)
+    hov, hou = H.new_site(DEV)[0], H.new_site(DEV)[0]
+    pln = H.AttnPlanes()
+    bv, bu = ov.data_ptr(), ou.data_ptr()
+    pln.dqa, pln.dqb, pln.lddq2 = bv, bv + 4 * d, 2 * nv * d
+    pln.dka, pln.dva, pln.lddka2 = bv + 8 * d, bv + 12 * d, 2 * nv * d
+    pln.dkb, pln.dvb, pln.lddkb2 = bu, bu + 4 * d, 2 * nu * d
+    pln.hdr_q = pln.hdr_ka = hov.data_ptr()
+    pln.hdr_kb = hou.data_ptr()
+    pln.sin_q = pln.sin_ka = scv.data_ptr()
+    pln.sin_kb = scu.data_ptr()
+    pln.flags = H.ATTN_PLANES_ONLY
+    zv, zu = torch.zeros_like(Yv), torch.zeros_like(Yu)          # (no fp32 gradient is written under ATTN_PLANES_ONLY)
+    stats = torch.zeros(4, device=DEV)
+    bwd(zv, zu, planes=pln)
+    H.site_fixup(hov, hou, stats=stats)
+    assert float(hov[2]) != 0.0 and float(hou[2]) != 0.0 and float(stats[0]) == 2.0
+    pln.flags = H.ATTN_PLANES_ONLY | H.ATTN_REPAIR
+    bwd(zv, zu, planes=pln)
+    assert float(zv.abs().max()) == 0.0 and float(zu.abs().max()) == 0.0
+    rv, _ = _ref_planes(H, dYv, B * La, nv * d, sv)
+    ru, _ = _ref_planes(H, dYu, B * Lb, nu * d, su)
+    assert float(hov[0]) == sv and float(hou[0]) == su
+    assert torch.equal(ov, rv) and torch.equal(ou, ru)
+
+
 def test_scales_update():
     H = _abi()
     arena = H.new_site(DEV, 4)
