@@ -396,7 +396,15 @@ def attn_peak_tflops():
     return 157.3          # v_mfma_f32_16x16x4_f32 (exact fp32 products)
 
 
+ATTN_PIN_CALLS = 0          # attention calls that were handed input planes (bench.py names the kernels it measured by this)
+
+
 def attn_kernel_name():
+    if ATTN_PIN_CALLS:
+        return ("attn_fwd_pl_kernel + attn_bwd_pl_kernel (csrc/attention_pl.h): Q / K / V read from the projection GEMMs' P32 planes "
+                "(forward: K / V by LDS-DMA into a conflict-free rotated image, 9 key tiles over both key blocks; backward: dQ + dK + dV in "
+                "one kernel per key block, row fragments straight to registers, K^T read back transposed from LDS), 3 x "
+                "v_mfma_f32_16x16x16_f16 per product, O / dQ / dK / dV written as planes (the backward: planes only + a repair launch)")
     return ("attn_fwd (v_mfma_f32_16x16x4_f32, exact fp32 products) + attn_bwd_fused16 / attn_bwd_fused (dQ + dK + dV in one kernel per key "
             "block, S and dP computed once: 10 dh Lq T FLOP instead of 14; fp16x3 products -- 3 x v_mfma_f32_16x16x16_f16 -- for single-chunk "
             "launches with more than 32 queries, exact fp32 products otherwise)")
@@ -851,6 +859,8 @@ def attn_bwd(B, H, dh, Lq, La, Lb, Qa, Qb, ldq, Ka, Va, ldka, Kb, Vb, ldkb, mq, 
     def P(x):
         return 0 if (x is None or x[0] is None) else x[0].data_ptr() + 4 * x[1]
     if pin is not None:
+        global ATTN_PIN_CALLS
+        ATTN_PIN_CALLS += 1
         planes = planes if planes is not None else AttnPlanes()
         _fill_pin(planes, pin, Qa, Qb, Ka, Va, Kb, Vb)
     prof = ATTN_PROFILE
