@@ -34,5 +34,8 @@ python tools/hipblaslt_yardstick.py 20 > $O/hipblaslt_yardstick.txt 2>&1
 python tools/gemm_out_variants.py 20 > $O/gemm_out_variants.txt 2>&1
 SEGMM_ATT_PL=0 python bench.py --steps 20 --warmup 5 $X > $O/bench_n1_att_pl0.json 2>/dev/null
 SEGMM_EU_PLANES_ONLY=0 python bench.py --steps 20 --warmup 5 $X > $O/bench_n1_eu_fp32.json 2>/dev/null
+SEGMM_ATT_REPAIR_WALK=0 python bench.py --steps 20 --warmup 5 $X > $O/bench_n1_repair_walk0.json 2>/dev/null
+python bench.py --steps 20 --warmup 5 $X > $O/bench_n1_again.json 2>/dev/null
+python tools/tn_split_table.py 2>&1 | grep -v amdgpu.ids > $O/tn_split_table.txt
 bash tools/pmc_bin.sh ${TAG}_pmc_fwdpl attn_fwd_pl tools/probe/attn_pl_bench 3 > /dev/null 2>&1; cp gpurun_out/${TAG}_pmc_fwdpl/summary.csv $O/attention_fwd_pl_pmc.csv
 ls -la $O
