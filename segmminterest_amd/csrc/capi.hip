@@ -118,9 +118,9 @@ static Knob g_knobs[K_COUNT] = {
     {"ATT_HPB_DKV", 0, "dK/dV kernel workgroup shape, as above"},
     {"L1NORM_REG", 1, "L1 normalisation with the row held in registers"},
     {"GEMM_BN", 0, "on-the-fly GEMM: tile width override (0: built-in choice)"},
-    {"PL_VAR", 8, "plane NT GEMM: 8 gemm_pl_nt8 (round 3), 0-2 / 4 round-2 forms"},
+    {"PL_VAR", 8, "plane NT GEMM: 8 gemm_pl_nt8 (round 3); 1: the round-2 fallback kernel for every launch"},
     {"PL_NJ", 0, "plane NT GEMM: tile width in 64-column units (0: modelled choice)"},
-    {"TN_VAR", 8, "plane TN GEMM: 8 gemm_pl_tn8 (round 3), 0 round-2 form"},
+    {"TN_VAR", 8, "plane TN GEMM: 8 gemm_pl_tn8 (round 3); 0: the round-2 fallback kernel for every launch"},
 };
 static bool g_knobs_ready = false;
 static void knobs_init() {
@@ -758,7 +758,7 @@ int segmm_gemm_p(int layout, int M, int N, int K, const uint16_t* a_planes, int 
             SEGMM_REQUIRE(!residual && C, "gemm_p: accumulate and residual are exclusive");
             g.residual = C; g.ldr = ldc; g.res_period = M;
         }
-        const int pl_var = knob(K_PL_VAR);          // 8: gemm_pl_nt8 (round 3); 0-2, 4: round-2 forms (A/B)
+        const int pl_var = knob(K_PL_VAR);          // 8: gemm_pl_nt8 (round 3); anything else: the round-2 fallback kernel for every launch
 #ifdef SEGMM_STAMPS
         q.stamps = g_segmm_stamps;
 #endif
@@ -799,16 +799,8 @@ int segmm_gemm_p(int layout, int M, int N, int K, const uint16_t* a_planes, int 
         // the round-2 NT kernels below judge and fall back for operand A only: B must be an exact-split operand (weight planes)
         SEGMM_REQUIRE(!b_f32, "gemm_p NT: this launch (row-scaled output, residual with a d-activation, or an extent >= 2^31) runs on the "
                               "round-2 kernel, which has no fp32 fallback for operand B -- pass B without an fp32 copy (exact-split planes)");
-        if (pl_var == 4) {          // four-wave form: 128 x 256 tiles, two workgroups per CU
-            g.nbm = (M + QBM - 1) / QBM; g.nbn = (N + QBN - 1) / QBN;
-            hipLaunchKernelGGL(gemm_pl_nt4, dim3(g.nbm * g.nbn), dim3(256), 0, s, g, q);
-            LAUNCH_CHECK();
-            return 0;
-        }
         g.nbm = (M + PBM - 1) / PBM; g.nbn = (N + PBN - 1) / PBN;
-        if (pl_var == 0) hipLaunchKernelGGL(gemm_pl_nt<0>, dim3(g.nbm * g.nbn), dim3(512), 0, s, g, q);
-        else if (pl_var == 2) hipLaunchKernelGGL(gemm_pl_nt<2>, dim3(g.nbm * g.nbn), dim3(512), 0, s, g, q);
-        else hipLaunchKernelGGL(gemm_pl_nt<1>, dim3(g.nbm * g.nbn), dim3(512), 0, s, g, q);
+        hipLaunchKernelGGL(gemm_pl_nt, dim3(g.nbm * g.nbn), dim3(512), 0, s, g, q);
         LAUNCH_CHECK();
         return 0;
     }
@@ -844,7 +836,7 @@ int segmm_gemm_p(int layout, int M, int N, int K, const uint16_t* a_planes, int 
     const int tn_var = knob(K_TN_VAR);
     const bool tn8 = tn_var == 8 && M % PBM == 0 && N % PBN == 0 && !g.residual && (long long)M * (splits > 1 ? N : ldc) * 4 < (1ll << 31);
     if (tn8) hipLaunchKernelGGL(gemm_pl_tn8, dim3(g.nbm * g.nbn, 1, splits), dim3(512), 0, s, g, q);
-    else hipLaunchKernelGGL(gemm_pl_tn<0>, dim3(g.nbm * g.nbn, 1, splits), dim3(512), 0, s, g, q);
+    else hipLaunchKernelGGL(gemm_pl_tn, dim3(g.nbm * g.nbn, 1, splits), dim3(512), 0, s, g, q);
     LAUNCH_CHECK();
     if (splits > 1) {          // one combine launch for the slabs AND the folded column sums
         const long long n4 = (long long)M * (N / 4);

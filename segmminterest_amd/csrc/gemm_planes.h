@@ -153,8 +153,9 @@ __device__ __forceinline__ void epi_strip_emit(const GemmArgs& p, const PGemmX& 
 }
 
 // =============================================================================== NT: C[M,N] = A[M,K] . B[N,K]^T
-// VAR 0: the next k-tile's LDS-DMA is issued in front of the MFMA block; VAR 1: one DMA piece between every six MFMAs
-template <int VAR>
+// (round 2's form, kept as the fallback for launches gemm_pl_nt8 does not take: row-scaled outputs, a residual together with a
+// d-activation, extents of 2 GiB and more.  One DMA piece of the next k-tile between every six MFMAs; its A/B variants -- DMA in
+// front of the MFMA block, software-pipelining across the barrier, the four-wave 128 x 256 form -- were retired in round 5.)
 __global__ __launch_bounds__(512, 2) void gemm_pl_nt(const GemmArgs p, const PGemmX q) {
     __shared__ __attribute__((aligned(16))) char smem[2 * PSTAGE];      // 128 KB: two stages x (A 32 KB | B 32 KB)
     const int tid = threadIdx.x, lane = tid & 63;
@@ -288,64 +289,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_nt(const GemmArgs p, const PGe
         }
     };
 
-    // VAR 2: software-pipelined across the barrier.  The fragments of the SECOND k16 step of a tile are read before the
-    // end-of-tile barrier and multiplied after it: every wave leaves the barrier with 24 MFMAs ready to issue while the
-    // first fragments of the new tile come out of LDS, and the stage it has just finished reading is free for the DMA of the
-    // tile after next straight away.
-    struct Frags { f32x4 bh[2], bl[2], ah[4], al[4]; };
-    auto load_frags = [&](const char* st, int s, Frags& F) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            F.bh[j] = *(const f32x4*)(st + fb[0][s] + j * 4096);
-            F.bl[j] = *(const f32x4*)(st + fb[1][s] + j * 4096);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            F.ah[i] = *(const f32x4*)(st + fa[0][s] + i * 4096);
-            F.al[i] = *(const f32x4*)(st + fa[1][s] + i * 4096);
-        }
-    };
-    auto mma = [&](const Frags& F) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                f32x16 c = acc[i][j];
-                c = mfma_x<true>(F.al[i], F.bh[j], c);
-                c = mfma_x<true>(F.ah[i], F.bl[j], c);
-                c = mfma_x<true>(F.ah[i], F.bh[j], c);
-                acc[i][j] = c;
-            }
-    };
-
     stage(0, smem);
     dma_wait_barrier();
-    if (VAR == 2 && !slowA) {
-        Frags FA, FB;
-        load_frags(smem, 0, FB);
-        if (nkt > 1) { dmaA(1, smem + PSTAGE); dmaB(1, smem + PSTAGE); }
-        load_frags(smem, 1, FA);
-        mma(FB);
-        dma_wait_barrier();
-        for (int kt = 1; kt < nkt; ++kt) {
-            char* cur = smem + (kt & 1) * PSTAGE;
-            char* nxt = smem + ((kt + 1) & 1) * PSTAGE;
-            load_frags(cur, 0, FB);
-            if (kt + 1 < nkt) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    lds_dma16(rsA, nxt + (wave * 4 + i) * 1024, voa[i], (uint32_t)(kt + 1) * 128u);
-                    lds_dma16(rsB, nxt + PBM * 128 + (wave * 4 + i) * 1024, vob[i], (uint32_t)(kt + 1) * 128u);
-                }
-            }
-            mma(FA);                    // second half of the PREVIOUS tile, operands already in registers
-            load_frags(cur, 1, FA);
-            mma(FB);
-            dma_wait_barrier();
-        }
-        mma(FA);
-        dma_wait_barrier();
-    } else if (VAR == 1 && !slowA) {
+    if (!slowA) {
         for (int kt = 0; kt < nkt - 1; ++kt) {
             char* cur = smem + (kt & 1) * PSTAGE;
             char* nxt = smem + ((kt + 1) & 1) * PSTAGE;
@@ -404,161 +350,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_nt(const GemmArgs p, const PGe
     } else if (p.amax_out) amax_commit(p.amax_out, am, blockIdx.x * 8 + wave);
 }
 
-// =============================================================================== NT, four-wave form
-// Same product, tile arithmetic and epilogue as gemm_pl_nt, organised so that TWO workgroups share a CU and run out of phase:
-// while one stores its tile (the epilogue leaves the matrix pipe idle for ~20 % of a K = 768 tile) or sits at its barrier,
-// the other one's waves -- on the same four SIMDs -- keep the pipe busy.  128 x 256 tile, 4 waves side by side (128 x 64 each:
-// the same 4 x 2 grid of 32 x 32 accumulators), k advances in steps of 16 through a ring of THREE 24 KB stages
-// (A: 128 rows x 64 B | B: 256 rows x 64 B; a row of a stage = [16 hi | 16 lo] of one k16 step = four 16-byte chunks of the
-// operand's 128-byte P32 line), 72 KB of LDS per workgroup.  The DMA of step t + 2 is issued when step t starts, so a
-// load has two compute phases to land; "s_waitcnt vmcnt(6)" (the six DMA instructions of step t + 1 may still be in flight)
-// + ONE barrier per step.  Chunk c of row r sits at physical chunk c ^ ((r >> 2) & 3): 16 consecutive rows of a fragment
-// read cover all 16 sixteen-byte bank groups.
-constexpr int QBM = 128, QBN = 256;
-constexpr int QSTAGE = (QBM + QBN) * 64;          // bytes per k16 stage
-
-__device__ __forceinline__ void dma_wait_barrier_n6() {
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-}
-
-__global__ __launch_bounds__(256, 2) void gemm_pl_nt4(const GemmArgs p, const PGemmX q) {
-    __shared__ __attribute__((aligned(16))) char smem[3 * QSTAGE];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 31, lh = lane >> 5;
-    const int lb = xcd_remap(blockIdx.x, p.nbm * p.nbn);
-    const int m0 = (lb / p.nbn) * QBM, n0 = (lb % p.nbn) * QBN;
-    const int nks = p.K >> 4;
-
-    const float sa_hdr = q.A.hdr[0], sb = q.B.hdr[0];
-    const bool slowA = q.A.f32 != nullptr && !site_planes_ok(q.A.hdr, sa_hdr, lane);
-    float sa = sa_hdr;
-    if (slowA) sa = site_exact_scale(q.A.hdr, (float*)smem, tid, 256);
-
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    // ---- LDS-DMA: one wave-instruction = 16 rows x 64 B; wave w moves A pieces 2 w + i (i < 2) and B pieces 4 w + i (i < 4)
-    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(q.A.p, q.A.bytes), rsB = make_rsrc(q.B.p, q.B.bytes);
-    uint32_t voa[2], vob[4];
-    {
-        const int r16 = lane >> 2, pc = lane & 3;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int rowb = (wave * 4 + i) * 16 + r16;
-            const int cb = pc ^ ((rowb >> 2) & 3);                      // logical chunk that lands in this lane's physical slot
-            vob[i] = (uint32_t)min(n0 + rowb, p.N - 1) * (uint32_t)q.B.ld2 * 2u + (uint32_t)((cb & 1) * 16 + (cb >> 1) * 64);
-            if (i < 2) {
-                const int rowa = (wave * 2 + i) * 16 + r16;
-                const int ca = pc ^ ((rowa >> 2) & 3);
-                voa[i] = (uint32_t)min(m0 + rowa, p.M - 1) * (uint32_t)q.A.ld2 * 2u + (uint32_t)((ca & 1) * 16 + (ca >> 1) * 64);
-            }
-        }
-    }
-    auto dma = [&](int ks, char* st, bool withA) {
-        const uint32_t soff = (uint32_t)(ks >> 1) * 128u + (uint32_t)(ks & 1) * 32u;
-        if (withA) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) lds_dma16(rsA, st + (wave * 2 + i) * 1024, voa[i], soff);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) lds_dma16(rsB, st + QBM * 64 + (wave * 4 + i) * 1024, vob[i], soff);
-    };
-    // slow path for A: fp32 copy -> exact split -> the same LDS image (thread: row tid / 2, 8 consecutive k)
-    auto slow_stage_A = [&](int ks, char* st) {
-        const int row = tid >> 1, kc = tid & 1;
-        const float* src = q.A.f32 + (size_t)min(m0 + row, p.M - 1) * q.A.ldf + ks * 16 + kc * 8;
-        const f32x4 x0 = *(const f32x4*)src, x1 = *(const f32x4*)(src + 4);
-        uint32_t h0, l0, h1, l1, h2, l2, h3, l3;
-        splith_pair(x0.x, x0.y, sa, h0, l0); splith_pair(x0.z, x0.w, sa, h1, l1);
-        splith_pair(x1.x, x1.y, sa, h2, l2); splith_pair(x1.z, x1.w, sa, h3, l3);
-        const int sw = (row >> 2) & 3;
-        *(uint4*)(st + row * 64 + ((kc ^ sw) << 4)) = make_uint4(h0, h1, h2, h3);
-        *(uint4*)(st + row * 64 + (((2 + kc) ^ sw) << 4)) = make_uint4(l0, l1, l2, l3);
-    };
-
-    // ---- fragment reads: lane (li, lh) takes row li of a 32-row block, k = 8 lh .. 8 lh + 7 of the step: chunk lh (hi), 2 + lh (lo)
-    const int swz = (li >> 2) & 3;
-    const uint32_t fa_h = (uint32_t)(li * 64 + ((lh ^ swz) << 4)), fa_l = (uint32_t)(li * 64 + (((2 + lh) ^ swz) << 4));
-    const uint32_t fb_h = (uint32_t)(QBM * 64 + (wave * 64 + li) * 64 + ((lh ^ swz) << 4));
-    const uint32_t fb_l = (uint32_t)(QBM * 64 + (wave * 64 + li) * 64 + (((2 + lh) ^ swz) << 4));
-    auto compute = [&](const char* st) {
-        f32x4 bh[2], bl[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            bh[j] = *(const f32x4*)(st + fb_h + j * 2048);
-            bl[j] = *(const f32x4*)(st + fb_l + j * 2048);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const f32x4 ah = *(const f32x4*)(st + fa_h + i * 2048);
-            const f32x4 al = *(const f32x4*)(st + fa_l + i * 2048);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                f32x16 c = acc[i][j];
-                c = mfma_x<true>(al, bh[j], c);
-                c = mfma_x<true>(ah, bl[j], c);
-                c = mfma_x<true>(ah, bh[j], c);
-                acc[i][j] = c;
-            }
-        }
-    };
-
-    if (!slowA) {
-        dma(0, smem, true);
-        if (nks > 1) dma(1, smem + QSTAGE, true);
-        int st_c = 0, st_n = 2;                                        // stage being computed / stage the next DMA goes to
-        for (int ks = 0; ks < nks - 1; ++ks) {
-            dma_wait_barrier_n6();                                     // step ks has landed (step ks + 1 may be in flight); stage st_n is free
-            if (ks + 2 < nks) dma(ks + 2, smem + st_n * QSTAGE, true);
-            compute(smem + st_c * QSTAGE);
-            st_c = st_c == 2 ? 0 : st_c + 1;
-            st_n = st_n == 2 ? 0 : st_n + 1;
-        }
-        dma_wait_barrier();
-        compute(smem + st_c * QSTAGE);
-    } else {
-        for (int ks = 0; ks < nks; ++ks) {                             // rare path: synchronous, one stage
-            __syncthreads();
-            slow_stage_A(ks, smem);
-            dma(ks, smem, false);
-            dma_wait_barrier();
-            compute(smem);
-        }
-    }
-    __syncthreads();                                                   // every wave is done with the ring: the epilogue reuses it
-
-    float* Cs = (float*)smem + wave * (32 * 64);                       // 8 KB per wave
-    const float inv_ab = (1.f / sa) * (1.f / sb);
-    const float c_scale = (q.Cp && q.c_scale_in) ? *q.c_scale_in : 0.f;
-    float am = 0.f;
-#pragma unroll 1
-    for (int i = 0; i < 4; ++i) {
-        f32x16 c[2];
-        switch (i) {
-            case 0: c[0] = acc[0][0]; c[1] = acc[0][1]; break;
-            case 1: c[0] = acc[1][0]; c[1] = acc[1][1]; break;
-            case 2: c[0] = acc[2][0]; c[1] = acc[2][1]; break;
-            default: c[0] = acc[3][0]; c[1] = acc[3][1]; break;
-        }
-        epi_strip_write<2>(c, Cs, lane);
-        epi_strip_emit<false, 2>(p, q, Cs, lane, m0 + i * 32, n0 + wave * 64, inv_ab, c_scale, p.C, am);
-    }
-    if (q.c_hdr) {
-        site_commit(q.c_hdr, am, blockIdx.x * 4 + wave, c_scale);
-        if (c_scale > 0.f && scale_writer(blockIdx.x * 4 + wave)) q.c_hdr[0] = c_scale;
-    } else if (p.amax_out) amax_commit(p.amax_out, am, blockIdx.x * 4 + wave);
-}
-
 // =============================================================================== TN: C[M,N] = A[K,M]^T . B[K,N]
 // Weight gradients: dW[n_out, n_in] = dY[tokens, n_out]^T . X[tokens, n_in]; the contraction runs over the token axis, the
 // SLOW axis of both operands.  A k-tile = 32 tokens x 256 features per operand; a token's 256 features are one contiguous
@@ -577,7 +368,6 @@ __device__ __forceinline__ f32x4 lds_tr8(const char* a) {          // 8 tokens (
     return __builtin_bit_cast(f32x4, v);
 }
 
-template <int VAR>
 __global__ __launch_bounds__(512, 2) void gemm_pl_tn(const GemmArgs p, const PGemmX q) {
     __shared__ __attribute__((aligned(16))) char smem[2 * PSTAGE];      // two stages x (A: 32 tokens x 1 KB | B: 32 tokens x 1 KB)
     const int tid = threadIdx.x, lane = tid & 63;
