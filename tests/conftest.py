@@ -21,3 +21,14 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    path = os.environ.get("SEGMM_GRAD_ERR_LOG")
+    if not path:
+        return
+    from helpers import GRAD_ERRS
+    with open(path, "w") as f:
+        f.write("worst |grad - reference| / max|reference| over the live gradients of each whole-model test (tolerance: 3e-4)\n")
+        for label, (rel, name, scale) in sorted(GRAD_ERRS.items(), key=lambda kv: -kv[1][0]):
+            f.write("%.2e  %-45s max %.2e  %s\n" % (rel, name, scale, label))

@@ -1,14 +1,15 @@
 """Whole-model parity on the MI355X against the golden vectors captured from the real reference
 (tests/golden) and against the CPU oracle at larger sizes.  Tolerances: logits 1e-4 absolute
-(BASELINE.json north_star), losses 1e-4 relative, gradients 3e-4 of the tensor's max (fp32
-summation-order noise through up to 4 layers of backward; the CPU restatement itself sits at 2e-5)."""
+(BASELINE.json north_star), losses 1e-4 relative, gradients 5e-5 of the tensor's max (round 5; 3e-4 before: the observed worst
+case over every whole-model test is 1.6e-5 on one fixture and <= 7.5e-6 everywhere else, <= 4e-6 at full size --
+profiles/r5/grad_err_worst.txt, SEGMM_GRAD_ERR_LOG; the CPU restatement itself sits at 2e-5 against the reference)."""
 import os
 import sys
 
 import pytest
 import torch
 
-from helpers import MODEL_CASES, ROOT, build_model, call_model, load_case
+from helpers import MODEL_CASES, ROOT, build_model, call_model, load_case, note_grad_err
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -45,7 +46,8 @@ def test_forward_loss_backward_vs_reference_golden(name):
         assert got is not None, k
         scale = max(float(ref.abs().max()), 1e-6)
         e = float((got.cpu() - ref).abs().max())
-        assert e <= 3e-4 * scale + 2e-6, (k, e, scale)
+        note_grad_err(k, e, scale)
+        assert e <= 5e-5 * scale + 2e-6, (k, e, scale)
 
 
 @pytest.mark.parametrize("name", MODEL_CASES)
@@ -172,7 +174,7 @@ def test_parameter_gradients_travel_through_autograd():
     assert all(p.grad is None for p in model.parameters())
     for k, got in zip(live, grads):
         ref = g["grad"][k]
-        assert float((got.cpu() - ref).abs().max()) <= 3e-4 * max(float(ref.abs().max()), 1e-6) + 2e-6, k
+        assert float((got.cpu() - ref).abs().max()) <= 5e-5 * max(float(ref.abs().max()), 1e-6) + 2e-6, k
     name = "backbone1.encoder.layers.0.ff_vid.layers.0.weight"
     p, fired = named[name], []
     h1 = p.register_hook(lambda gr: gr * 2.0)
@@ -360,7 +362,8 @@ def test_baseline_config_widths_vs_oracle(case):
             assert p.grad is None, k
         else:
             scale = max(float(rgrads[k].abs().max()), 1e-7)
-            assert float((p.grad.cpu() - rgrads[k]).abs().max()) <= 3e-4 * scale + 1e-7, k
+            note_grad_err(k, float((p.grad.cpu() - rgrads[k]).abs().max()), scale)
+            assert float((p.grad.cpu() - rgrads[k]).abs().max()) <= 5e-5 * scale + 1e-7, k
 
 
 def test_full_size_batch_matches_oracle_on_a_row_subset():
@@ -445,7 +448,8 @@ def test_config1_sample_file_labels_vs_oracle():
             assert p.grad is None, k
         else:
             err = (p.grad.cpu() - rgrads[k]).abs().max().item()
-            assert err <= 3e-4 * max(rgrads[k].abs().max().item(), 1e-6), (k, err)
+            note_grad_err(k, err, rgrads[k].abs().max().item())
+            assert err <= 5e-5 * max(rgrads[k].abs().max().item(), 1e-6), (k, err)
     # leave-rank metrics (integer ranks): device path == numpy oracle on the SAME interests
     from segmminterest_amd.my_evaluation import TOP_K_leave_device
     interests = torch.sigmoid(out["logits"].detach())
@@ -554,7 +558,7 @@ def _cfg2_model(B, seed=1, scale_layers=2.0, scale_in=100.0, Din=768):
 
 
 def _check_live_grads(model, rgrads):
-    """Every live gradient within 3e-4 of its tensor's maximum.  interestBPR is invariant to a per-row shift of the logits, so
+    """Every live gradient within 5e-5 of its tensor's maximum.  interestBPR is invariant to a per-row shift of the logits, so
     the gradients that are SUMS of d loss / d logits over all tokens (head bias, the last LayerNorm's bias) are exactly zero in
     exact arithmetic and pure cancellation noise in fp32 -- in the oracle as well: an absolute floor of 1e-6 of the largest
     gradient in the model covers them."""
@@ -567,7 +571,9 @@ def _check_live_grads(model, rgrads):
         scale = float(rgrads[k].abs().max())
         e = float((p.grad.cpu() - rgrads[k]).abs().max())
         errs[k] = e / max(scale, 1e-30)
-        if e > 3e-4 * scale + 1e-6 * gmax:
+        if scale > 1e-6 * gmax:          # (the cancellation-noise tensors of the docstring are judged by the absolute floor)
+            note_grad_err(k, e, scale)
+        if e > 5e-5 * scale + 1e-6 * gmax:
             bad[k] = (e, scale, gmax)
     assert not bad, bad
     return errs
