@@ -508,18 +508,20 @@ def test_attention_bwd_on_input_planes(B, H_, dh, Lq, La, Lb, p, case):
         assert float((a_ - b_).abs().max()) <= 3e-6 * max(m, 1e-30), (name, float((a_ - b_).abs().max()) / max(m, 1e-30))
 
 
-@pytest.mark.parametrize("B,H_,bad,walk", [(40, 16, 2.0 ** 30, 512), (40, 16, 2.0 ** -30, 512), (3, 16, 2.0 ** 30, 512), (3, 16, 2.0 ** 30, 2),
-                                            (5, 16, 2.0 ** -30, 6)])
-def test_attention_bwd_repair_launch_walks_the_heads(request, B, H_, bad, walk):
+@pytest.mark.parametrize("B,H_,bad,walk,La,Lb", [(40, 16, 2.0 ** 30, 512, 40, 100), (40, 16, 2.0 ** -30, 512, 40, 100), (3, 16, 2.0 ** 30, 512, 40, 100),
+                                                  (3, 16, 2.0 ** 30, 2, 40, 100), (5, 16, 2.0 ** -30, 6, 40, 100), (36, 16, 2.0 ** 30, 512, 100, 40),
+                                                  (2, 16, 2.0 ** -30, 4, 100, 40)])
+def test_attention_bwd_repair_launch_walks_the_heads(request, B, H_, bad, walk, La, Lb):
     """The planes-only protocol of the planes-in fused backward at the op level: outputs written with a delayed scale that is
     2^30 off (overflow / below the fp16 window), segmm_site_fixup, then the REPAIR launch -- 512 workgroups wide, each walking
     its share of the B * H = 640 heads (csrc/attention_pl.h) -- must leave exactly the planes of the fp32 gradients under the
     exact scale of their maxima, and that scale in the header.  (B = 3 at the default width: the repair launch at one workgroup per
-    head; widths 2 and 6: two / six workgroups walk 24 / 14 heads each.)"""
+    head; widths 2 and 6: two / six workgroups walk 24 / 14 heads each.  La = 100: a multi-chunk query side -- the seven- /
+    three-wave forms of the kernel, one wave per key tile.)"""
     H = _abi()
     prev_walk = H.config_set("ATT_REPAIR_WALK", walk)
     request.addfinalizer(lambda: H.config_set("ATT_REPAIR_WALK", prev_walk))
-    dh, Lq, La, Lb, p = 48, 40, 40, 100, 0.1
+    dh, Lq, p = 48, La, 0.1
     d = H_ * dh
     g = torch.Generator().manual_seed(B + 5)
     nv, nu = 4, 2
