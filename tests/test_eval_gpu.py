@@ -426,6 +426,36 @@ def test_two_device_state_trainers_coexist():
 
 
 @pytest.mark.gpu
+def test_attention_input_modes_agree():
+    """SEGMM_ATT_PL (engine ``attn_pl``): 0 = the attention kernels read the fp32 views of the projection outputs (round 4),
+    1 = the projection GEMMs write planes ONLY and both attention kernels read them (default), 2 = planes beside fp32, forward
+    only.  Different kernels, same mathematics: with lr = 0 (identical parameters throughout) the loss and every gradient of the
+    fourth step -- sites calibrated, the planes paths active -- agree within 2e-5 of each tensor's maximum."""
+    import torch
+    from segmminterest_amd.synth import make_batch
+    from segmminterest_amd.trainer import Trainer, default_args, init_model
+    dev = torch.device("cuda:0")
+    B, S, Lt, D = 16, 20, 8, 64
+    margs = default_args(num_layers_enc=3, d_model=D, nhead=4, input_type={"user": "image", "photo": "image"}, exposure_prob=[1.0] * S)
+    batches = [{k: v.to(dev) for k, v in make_batch(B, S, Lt, D, seed=40 + i).items()} for i in range(2)]
+    res = {}
+    for mode in (0, 1, 2):
+        torch.manual_seed(5)
+        m = init_model(margs, n_users=1, n_items=1, input_dim=D, max_vid_len=S, max_usr_len=Lt).to(dev)
+        t = Trainer(m, lr=0.0, weight_decay=0.0, device_state=True)
+        m._store.attn_pl = mode
+        for i in range(4):
+            out = t.train_step(batches[i % 2])
+        torch.cuda.synchronize()
+        res[mode] = (float(out["loss"].detach()), {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None})
+    gmax = max(float(g.abs().max()) for g in res[0][1].values())          # (floor: gradients that are zero in exact arithmetic)
+    for mode in (1, 2):
+        assert abs(res[mode][0] - res[0][0]) <= 1e-5 * max(1.0, abs(res[0][0])), mode
+        for k, g0 in res[0][1].items():
+            assert float((res[mode][1][k] - g0).abs().max()) <= 2e-5 * float(g0.abs().max()) + 1e-6 * gmax, (mode, k)
+
+
+@pytest.mark.gpu
 def test_planes_only_input_needs_plane_consumers_d48():
     """D_in a multiple of 32 but d_model = 48 (3 heads of 16): the embedding weight gradient takes the on-the-fly
     kernel, which reads the fp32 copy of the L1-normalised features -- the planes-only input protocol must stay off, and
