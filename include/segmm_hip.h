@@ -220,13 +220,17 @@ typedef struct {
      * (overflow flag, maximum below the fp16 window, or no scale yet), in which case it rewrites them with the exact scale of
      * the recorded maxima. */
     int flags;
-    /* forward only (round 5): INPUT planes -- the P32 planes of the Q / K / V column slices as their producers (the fused
-     * projection GEMMs) wrote them, each addressing the same columns as its fp32 twin, with the headers of the sites they
-     * belong to (queries; key block a: K and V of one buffer; key block b).  When q_in is given (all of them must be, for the
-     * non-empty key blocks) and the shape qualifies (dh % 16 == 0, La % 4 == 0, Lb % 4 == 0, Lq <= 112), segmm_attn_fwd
-     * stages the planes by LDS-DMA and multiplies on the fp16 matrix cores (three partial products, the GEMM engine's
-     * arithmetic); a site whose planes are unusable is staged from the fp32 views with its exact scale inside the same launch.
-     * The fp32 views stay mandatory. */
+    /* forward and fused backward (round 5): INPUT planes -- the P32 planes of the Q / K / V column slices as their producers
+     * (the fused projection GEMMs) wrote them, each addressing the same columns as its fp32 twin, with the headers of the sites
+     * they belong to (queries; key block a: K and V of one buffer; key block b).  When qa_in / qb_in are given (all of the *_in
+     * fields must be, for the non-empty key blocks) and the shape qualifies (dh in {16, 32, 48}, La % 4 == 0, Lb % 4 == 0, at most
+     * 112 tokens per side), segmm_attn_fwd stages K / V by LDS-DMA and segmm_attn_bwd (fused phases 4-6) loads the fragments
+     * straight from the planes; every product runs on the fp16 matrix cores (three partial products, the GEMM engine's
+     * arithmetic).  The fp32 views (Qa ... Vb) may then be NULL -- a caller whose projection GEMMs write planes ONLY: a site
+     * whose planes are unusable under its header's scale must have been rewritten by its producer's repair launch
+     * (segmm_gemm_p, write_c bit 1), and the kernels take the exact scale of the recorded maxima like that launch did.  With
+     * fp32 views given, the forward stages such a site from them inside the same launch.  Shapes that do not qualify run the
+     * fp32-view kernels and refuse a call without views. */
     const uint16_t *qa_in, *qb_in; int ldq2_in; const float* hdr_q_in;
     const uint16_t *ka_in, *va_in; int ldka2_in; const float* hdr_ka_in;
     const uint16_t *kb_in, *vb_in; int ldkb2_in; const float* hdr_kb_in;
