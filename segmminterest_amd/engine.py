@@ -1714,7 +1714,7 @@ def next_seed(store=None) -> int:
     ``torch.manual_seed`` makes train-mode runs reproducible.  Data-parallel ranks seed torch identically (identical
     replicas), so the rank is mixed in: every rank drops different elements of its own rows.
     With a device-side step state the ARGUMENT is the same every step (bit 63 set: the kernels XOR in the seed words that
-    segmm_step_advance derives on the device), so that a captured step can be replayed."""
+    segmm_step_advance derives on the device), so that a recorded step can be replayed."""
     live = None if store is None else store.__dict__.get("live_seed")          # set by Trainer(device_state=True)
     if live is not None:
         return live
