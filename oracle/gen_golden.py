@@ -351,6 +351,14 @@ def gen_metrics(ev, outdir):
         res = {k: [] for k in ("JaccardSim", "ProbAUC", "LeaveMSE", "LeaveCTR", "LeaveCTR_view", "TOP_K", "view_lengths")}
         it = interests[rows]
         res = ev.main_eval_batch(args, it, gt[rows], (it > 0.5).float(), res, type="inference")
+        # the logits= branch (my_evaluation.py:307-318): softmax-inverse leave position -> MAES (a running sum), pred_leave
+        lg = torch.from_numpy(np.random.RandomState(7).randn(len(rows), S).astype(np.float32) * 2.0)
+        res_l = {"MAES": 0.0, "pred_leave": []}
+        res_l = ev.main_eval_batch(args, it, gt[rows], (it > 0.5).float(), res_l, type="inference", logits=lg)
+        res_l = ev.main_eval_batch(args, it[:7], gt[rows][:7], (it[:7] > 0.5).float(), res_l, type="inference", logits=lg[:7] * 0.25)
+    blob["meb_logits"] = lg.numpy()
+    blob["meb_maes"] = np.array(float(res_l["MAES"]), dtype=np.float64)
+    blob["meb_pred_leave"] = np.concatenate([np.asarray(x, dtype=np.int64) for x in res_l["pred_leave"]])
     blob["meb_rows"] = np.array(rows)
     for k, v in res.items():
         if k == "TOP_K":

@@ -14,6 +14,7 @@
 #include "gemm_split.h"
 #include "gemm_planes.h"
 #include "gemm_planes8.h"
+#include "gemm_planes4.h"
 #include "loss.h"
 #include "rowops.h"
 
@@ -118,9 +119,9 @@ static Knob g_knobs[K_COUNT] = {
     {"ATT_HPB_DKV", 0, "dK/dV kernel workgroup shape, as above"},
     {"L1NORM_REG", 1, "L1 normalisation with the row held in registers"},
     {"GEMM_BN", 0, "on-the-fly GEMM: tile width override (0: built-in choice)"},
-    {"PL_VAR", 8, "plane NT GEMM: 8 gemm_pl_nt8 (round 3); 1: the round-2 fallback kernel for every launch"},
+    {"PL_VAR", 4, "plane NT GEMM: 4 gemm_pl_nt4 (round 6: 128 x 256 tiles, two workgroups per CU); 8 gemm_pl_nt8 (round 3); 1: the round-2 fallback kernel for every launch"},
     {"PL_NJ", 0, "plane NT GEMM: tile width in 64-column units (0: modelled choice)"},
-    {"TN_VAR", 8, "plane TN GEMM: 8 gemm_pl_tn8 (round 3); 0: the round-2 fallback kernel for every launch"},
+    {"TN_VAR", 4, "plane TN GEMM: 4 gemm_pl_tn4 (round 6: 128 x 256 tiles, two workgroups per CU); 8 gemm_pl_tn8 (round 3); 0: the round-2 fallback kernel for every launch"},
 };
 static bool g_knobs_ready = false;
 static void knobs_init() {
@@ -762,13 +763,20 @@ int segmm_gemm_p(int layout, int M, int N, int K, const uint16_t* a_planes, int 
 #ifdef SEGMM_STAMPS
         q.stamps = g_segmm_stamps;
 #endif
-        if (pl_var == 8) {          // round-3 form: 16x16x32 MFMA, ping-pong wave groups, register epilogue (gemm_planes8.h)
+        if (pl_var == 8 || pl_var == 4) {          // round-3 / round-6 forms: 16x16x32 MFMA, register epilogue (gemm_planes8.h, gemm_planes4.h)
             // every epilogue access is a buffer operation with a 32-bit offset whose top bit masks out-of-range columns
             const long long lim = 1ll << 31;
             const bool fits = !row_scale && (long long)M * ldc * 4 < lim && (!aux || (long long)M * ldaux * 4 < lim) &&
                               (!residual || (long long)(res_period < M ? res_period : M) * ldr * 4 < lim) &&
                               (!c_planes || (long long)M * ldc2 * 2 < lim) &&
                               !(residual && (activation == EPI_DGELU || activation == EPI_DRELU));      // one extra operand per element
+            if (fits && pl_var == 4) {
+                // round 6: 128 x 256 tiles, four waves, two workgroups resident per CU (results bitwise those of gemm_pl_nt8)
+                g.nbm = (M + P4_BM - 1) / P4_BM; g.nbn = (N + P4_BN - 1) / P4_BN;
+                hipLaunchKernelGGL(gemm_pl_nt4, dim3(g.nbm * g.nbn), dim3(256), 0, s, g, q);
+                LAUNCH_CHECK();
+                return 0;
+            }
             if (fits) {
                 // tile width 64 NJ: the one that needs the fewest CU-rounds.  Measured tile times at K = 768 (stand-alone, round 3):
                 // 60.7 / 49 / 38 us for NJ = 4 / 3 / 2 = 15 + 11.4 NJ us -- a narrower tile carries the same A traffic, prologue and
@@ -832,10 +840,16 @@ int segmm_gemm_p(int layout, int M, int N, int K, const uint16_t* a_planes, int 
         }
     }
     q.colsum_out = colsum_out;
-    // round-3 form (gemm_planes8.h): whole 256 x 256 tiles, plain or split-K stores (no accumulate into C), 32-bit output offsets
+    // round-6 form (gemm_planes4.h): whole 128 x 256 tiles; round-3 form (gemm_planes8.h): whole 256 x 256 tiles; both: plain or
+    // split-K stores (no accumulate into C), 32-bit output offsets.  Everything else: the round-2 kernel
     const int tn_var = knob(K_TN_VAR);
-    const bool tn8 = tn_var == 8 && M % PBM == 0 && N % PBN == 0 && !g.residual && (long long)M * (splits > 1 ? N : ldc) * 4 < (1ll << 31);
-    if (tn8) hipLaunchKernelGGL(gemm_pl_tn8, dim3(g.nbm * g.nbn, 1, splits), dim3(512), 0, s, g, q);
+    const bool small_out = !g.residual && (long long)M * (splits > 1 ? N : ldc) * 4 < (1ll << 31);
+    const bool tn4 = tn_var == 4 && M % P4_BM == 0 && N % P4_BN == 0 && small_out;
+    const bool tn8 = (tn_var == 8 || tn_var == 4) && M % PBM == 0 && N % PBN == 0 && small_out;
+    if (tn4) {
+        g.nbm = M / P4_BM; g.nbn = N / P4_BN;
+        hipLaunchKernelGGL(gemm_pl_tn4, dim3(g.nbm * g.nbn, 1, splits), dim3(256), 0, s, g, q);
+    } else if (tn8) hipLaunchKernelGGL(gemm_pl_tn8, dim3(g.nbm * g.nbn, 1, splits), dim3(512), 0, s, g, q);
     else hipLaunchKernelGGL(gemm_pl_tn, dim3(g.nbm * g.nbn, 1, splits), dim3(512), 0, s, g, q);
     LAUNCH_CHECK();
     if (splits > 1) {          // one combine launch for the slabs AND the folded column sums

@@ -1,0 +1,820 @@
+// Plane GEMMs, round-6 form: FOUR-wave workgroups with a 128 x 256 output tile and 80 KB of LDS, so that TWO workgroups are
+// resident per CU (2 x 80 KB = the CU's 160 KB, 2 x 1 wave per SIMD at <= 256 registers).
+//
+// Why.  gemm_pl_nt8 / gemm_pl_tn8 (gemm_planes8.h) own their CU: 160 KB of LDS, 8 waves.  Their k-loop runs at 0.875 of the MFMA
+// issue rate, but 16 % of a tile's time is prologue (first operand pieces from a cold L2, two dependent header reads) and
+// epilogue (512 KB of stores through a 64 B / clock path) during which the matrix pipe of the CU has nothing to do
+// (profiles/r5/gemm_pl_nt_20480x3072x768_pmc.csv: 58 % MFMA busy).  Here the two resident workgroups are independent: their
+// tiles drift out of phase, one workgroup's prologue / epilogue runs beside the other's k-loop, and the pairing that
+// gemm_planes8.h builds with barriers between its two wave groups (one wave of a SIMD loads while its partner computes) is
+// what the hardware arbitration produces between the two workgroups' waves on a SIMD.  A tile of half the size also halves
+// the quantisation loss of launches with few tiles (config 4's 256-row shard: 120 tiles of 256 x 256 on 256 CUs).
+//
+// Same arithmetic, operand format (P32 planes), MFMA shape and order (v_mfma_f32_16x16x32_f16, hl + lh + hh per k32 block,
+// swapped operands: the accumulator tile is C^T), fallback / repair protocol and epilogue as gemm_pl_nt8: the results are
+// BITWISE those of gemm_pl_nt8 (same accumulation chain per element).
+//
+// NT kernel gemm_pl_nt4: waves as 1 (m) x 4 (n), 128 x 64 per wave (128 accumulator registers).  LDS:
+//     [0, 32 K)            A: two stages of 128 rows x 128 B (a k-tile of 32: [32 hi | 32 lo] per row), shared by the four waves
+//     [32 K, 80 K)         B: PRIVATE to each wave (wave wn reads only the rows [64 wn, +64) of the B tile): 12 KB per wave = a ring of
+//                          three half-tiles (32 rows x 128 B); a k-tile is two halves, so the ring holds 1.5 k-tiles
+// Because B is private, only A needs barriers: ONE s_barrier per k-tile (four in gemm_pl_nt8).  Per k-tile t and wave:
+//     X(t)                 s_waitcnt vmcnt(4): own pieces of A(t), B halves 2t, 2t+1 have landed; s_barrier
+//     4 pieces of A(t+1) -> stage (t+1) & 1            (last read before X(t): every wave retired its reads of tile t-1)
+//     8 + 8 ds_read_b128: B fragments of both halves, A fragments of rows 0-63; lgkmcnt(0)
+//     48 MFMAs (rows 0-63), with 4 + 4 pieces of B halves 2t+3, 2t+4 issued between them into the two slots just read
+//     8 ds_read_b128: A fragments of rows 64-127; lgkmcnt(0); 48 MFMAs
+// Every piece has a whole k-tile period (~2 us) to land; vmcnt counts in issue order: at X(t+1) only the 4 youngest pieces
+// (half 2t+4) may still be in flight.
+#pragma once
+#include "gemm_planes8.h"
+
+namespace segmm {
+
+constexpr int P4_BM = 128, P4_BN = 256;
+constexpr int P4_ASTAGE = P4_BM * 128;                 // 16 KB
+constexpr int P4_BOFF = 2 * P4_ASTAGE;                 // private B rings start here
+constexpr int P4_BHALF = 32 * 128;                     // 4 KB: 32 rows
+constexpr int P4_BRING = 3 * P4_BHALF;                 // 12 KB per wave
+#ifndef P4_LDS_PAD
+#define P4_LDS_PAD 0          // probe: extra LDS bytes (> 0 leaves ONE workgroup per CU)
+#endif
+#ifndef P4_EPI_PRIO
+#define P4_EPI_PRIO 3          // wave priority outside the k-loop (prologue, epilogue): their few instructions go in front of the partner workgroup's MFMA stream
+#endif
+#ifndef P4_STAGGER
+#define P4_STAGGER 0          // units of 512 cycles per k-tile that the late half of the first round sleeps (0: no stagger)
+#endif
+constexpr int P4_LDS = P4_BOFF + 4 * P4_BRING + P4_LDS_PAD;         // 80 KB
+constexpr int P4_EHALF = 32768;                        // epilogue: a quarter of the tile's extra operand (32 rows x 1 KB)
+constexpr int P4_PATCH = 2 * P4_EHALF;                 // epilogue: 4 KB transpose patch per wave behind the two E halves
+
+template <int N>
+__device__ __forceinline__ void wait_vm_barrier() {          // close a k-tile: all but the N youngest pieces landed, then the workgroup's barrier
+    __builtin_amdgcn_sched_barrier(0);
+    if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void wait_lgkm() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_pl_nt4(const GemmArgs p, const PGemmX q) {
+    constexpr int NJ = 4;
+    __shared__ __attribute__((aligned(16))) char smem[P4_LDS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave;                               // columns [64 wn, +64) of the tile; every wave owns all 128 rows
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int nkt = p.K >> 5;
+    const int lb = xcd_remap(blockIdx.x, p.nbm * p.nbn);
+    const int m0 = (lb / p.nbn) * P4_BM, n0 = (lb % p.nbn) * P4_BN;
+    STAMP(0);
+    if (P4_EPI_PRIO) __builtin_amdgcn_s_setprio(P4_EPI_PRIO);
+    // ---- REPAIR launch of a planes-only output (see gemm_pl_nt8): usable site -> leave at once, else recompute with the exact scale
+    float c_repair = 0.f;
+    if (q.repair) {
+        const float hc0 = q.c_hdr[0];
+        const uint32_t hc1 = __float_as_uint(q.c_hdr[1]);
+        const f32x4 amc = *(const f32x4*)(q.c_hdr + SITE_HDR + lane * 4);
+        const float m = wave_max(fmaxf(fmaxf(amc.x, amc.y), fmaxf(amc.z, amc.w)));
+        if (hc0 > 0.f && hc1 == 0u && (!(m > 0.f) || ((m * hc0 >= 0.25f || hc0 >= 0x1p60f) && m * hc0 < 65504.f))) return;
+        c_repair = f16_scale_of(m);
+    }
+
+    // ---- stagger: the workgroups of a launch start within a microsecond of each other, so the two that share a CU would run
+    // their prologues, k-loops and epilogues IN PHASE (measured: the epilogue then costs the same 14 % as in gemm_pl_nt8).  Half
+    // of the first round sleeps for about half a tile's k-loop; the offset then carries through the later rounds (a slot is
+    // refilled when its workgroup retires).  Speed only: nothing depends on which workgroups share a CU.
+#ifdef SEGMM_GEMM_PROBE
+    const int stag_units = (q.dbg >> 8) & 0xff, stag_pat = (q.dbg >> 16) & 3;
+#else
+    constexpr int stag_units = P4_STAGGER, stag_pat = 0;
+#endif
+    if (stag_units > 0 && (int)blockIdx.x < 512) {
+        const bool late = stag_pat == 0 ? (blockIdx.x & 256) != 0 : stag_pat == 1 ? (blockIdx.x & 8) != 0 : (blockIdx.x & 128) != 0;
+        if (late) {
+#pragma unroll 1
+            for (int i = 0; i < nkt * stag_units; ++i) __builtin_amdgcn_s_sleep(8);          // 8 x 64 cycles per unit and k-tile
+        }
+    }
+
+    // ---- LDS-DMA pieces (a wave-instruction moves 8 rows x 128 B).  A: piece 4 wave + i of 16 (tile rows 8 piece .. + 7);
+    // B: the wave's own 64 rows, piece pc of 8 (rows 64 wn + 8 pc .. + 7), half = pc >> 2.  Chunk swizzle on the SOURCE address.
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(q.A.p, q.A.bytes), rsB = make_rsrc(q.B.p, q.B.bytes);
+    const int r8 = lane >> 3;
+    uint32_t voa[4], vob[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ra = 8 * (4 * wave + i) + r8;
+        voa[i] = (uint32_t)min(m0 + ra, p.M - 1) * (uint32_t)q.A.ld2 * 2u + (uint32_t)(((lane & 7) ^ ((ra >> 1) & 7)) * 16);
+    }
+#pragma unroll
+    for (int pc = 0; pc < 8; ++pc) {
+        const int rb = 64 * wn + 8 * pc + r8;
+        vob[pc] = (uint32_t)min(n0 + rb, p.N - 1) * (uint32_t)q.B.ld2 * 2u + (uint32_t)(((lane & 7) ^ ((rb >> 1) & 7)) * 16);
+    }
+    char* const bring = smem + P4_BOFF + wave * P4_BRING;
+    auto dmaA = [&](int kt) {
+        char* st = smem + (kt & 1) * P4_ASTAGE + wave * 4096;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) lds_dma16(rsA, st + i * 1024, voa[i], (uint32_t)kt * 128u);
+    };
+    auto dmaB1 = [&](int kt, int pc, int slot) {          // one piece of B(kt) into half-slot `slot`
+        lds_dma16(rsB, bring + slot * P4_BHALF + (pc & 3) * 1024, vob[pc], (uint32_t)kt * 128u);
+    };
+    // ---- the first k-tiles leave NOW: A(0), B halves 0, 1 (slots 0, 1) and half 2 = lower half of tile 1 (slot 2)
+    dmaA(0);
+#pragma unroll
+    for (int pc = 0; pc < 8; ++pc) dmaB1(0, pc, pc >> 2);
+    if (nkt > 1) {
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc) dmaB1(1, pc, 2);
+    }
+
+    // ---- operand state (block-uniform): planes usable?  (all header words requested at once, judged like site_planes_ok)
+    auto uni = [](float x) { return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(x))); };
+    const float ha0 = q.A.hdr[0], ha1 = q.A.hdr[1], hb0 = q.B.hdr[0], hb1 = q.B.hdr[1];
+    const f32x4 ama = *(const f32x4*)(q.A.hdr + SITE_HDR + lane * 4), amb = *(const f32x4*)(q.B.hdr + SITE_HDR + lane * 4);
+    const float cs_in = (q.Cp && q.c_scale_in) ? *q.c_scale_in : 0.f;
+    const float sa_hdr = uni(ha0), sb_hdr = uni(hb0);
+    auto planes_ok = [&](float s, float flag, f32x4 v) {
+        const float m = wave_max(fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+        if (!(s > 0.f) || __float_as_uint(flag) != 0u) return false;
+        return !(m > 0.f) || ((m * s >= 0.25f || s >= 0x1p60f) && m * s < 65504.f);
+    };
+    const bool slowA = q.A.f32 != nullptr && !planes_ok(sa_hdr, uni(ha1), ama);
+    const bool slowB = q.B.f32 != nullptr && !planes_ok(sb_hdr, uni(hb1), amb);
+    const float c_scale = q.repair ? uni(c_repair) : uni(cs_in);
+
+    // ---- fragment read addressing (lane: row l15 of a 16-row block, logical chunk 4 plane + lq; physical = logical ^ swz)
+    const int swz = (l15 >> 1) & 7;
+    uint32_t fr[2];
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) fr[pl] = (uint32_t)(l15 * 128 + (((4 * pl + lq) ^ swz) << 4));
+
+    f32x4 acc[8][NJ];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // fragments: B of the whole k-tile (4 column blocks, hi + lo: 32 registers), A of TWO row blocks (the one being multiplied and
+    // the next one: 16 registers)
+    f32x4 bh[NJ], bl[NJ], ah[2], al[2];
+    auto rdA = [&](const char* st, int i, int buf) {
+        ah[buf] = *(const f32x4*)(st + fr[0] + i * 2048);
+        al[buf] = *(const f32x4*)(st + fr[1] + i * 2048);
+    };
+    auto rdB = [&](int j, const char* lo_half, const char* hi_half) {          // rows 0-31 / 32-63 of the wave's B rows
+        const char* b = ((j >> 1) ? hi_half : lo_half) + (j & 1) * 2048;
+        bh[j] = *(const f32x4*)(b + fr[0]);
+        bl[j] = *(const f32x4*)(b + fr[1]);
+    };
+    auto mma1 = [&](int r, int j, int buf) {
+        f32x4 c = acc[r][j];
+        c = mfma16(bh[j], al[buf], c);          // (B fragment, A fragment): the accumulator tile is C^T
+        c = mfma16(bl[j], ah[buf], c);
+        c = mfma16(bh[j], ah[buf], c);
+        acc[r][j] = c;
+    };
+
+    float sa = sa_hdr, sb = sb_hdr;
+    if (!(slowA || slowB)) {
+        // ---- the software-pipelined stream.  A wave is self-sufficient: between its own MFMAs it issues the two ds_reads of the
+        // NEXT row block's A fragments (double-buffered), the LDS-DMA pieces of later k-tiles (<= 2 per row block) and, in the last
+        // row block of a k-tile, the next tile's B fragments -- each right behind the last MFMA that reads the registers it
+        // replaces (the compiler places the counted lgkmcnt waits: program order below is pinned by sched_barriers).  Per k-tile t:
+        //     row blocks 0-1: pieces of B half 2t+3 -> the slot of half 2t;   2-3: B half 2t+4 -> the slot of half 2t+1
+        //     end of row block 6: vmcnt(4) lgkmcnt(0), s_barrier = X(t+1): A(t+1) is in LDS, every wave has read the last of A(t)
+        //     row block 7: A fragments of row block 0 of tile t+1; pieces of A(t+2) -> stage t & 1; B fragments of tile t+1
+        // Tiles beyond the last are requested through a zero-length descriptor (zeros land in slots nobody reads).
+        if (nkt > 1) dmaA(1); else { const __amdgpu_buffer_rsrc_t z = make_rsrc(q.A.p, 0); 
+#pragma unroll
+            for (int i = 0; i < 4; ++i) lds_dma16(z, smem + P4_ASTAGE + wave * 4096 + i * 1024, voa[i], 0u); }
+        if (nkt <= 1) {          // (keep the issue count of the prologue fixed: 4 + 8 + 4 + 4 pieces)
+            const __amdgpu_buffer_rsrc_t z = make_rsrc(q.B.p, 0);
+#pragma unroll
+            for (int pc = 0; pc < 4; ++pc) lds_dma16(z, bring + 2 * P4_BHALF + pc * 1024, vob[pc], 0u);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");          // A(0), B halves 0, 1 landed; half 2 and A(1) may fly
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        STAMP(1);
+        if (P4_EPI_PRIO) __builtin_amdgcn_s_setprio(0);
+        rdA(smem, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) rdB(j, bring, bring + P4_BHALF);
+        int s_lo = 0, s_hi = 1, s_nx = 2;          // half-slots of B halves 2t, 2t+1, 2t+2
+#pragma unroll 1
+        for (int t = 0; t < nkt; ++t) {
+            const char* sta = smem + (t & 1) * P4_ASTAGE;
+            const char* stn = smem + ((t + 1) & 1) * P4_ASTAGE;
+            const __amdgpu_buffer_rsrc_t rsB1 = make_rsrc(q.B.p, t + 1 < nkt ? q.B.bytes : 0u);
+            const __amdgpu_buffer_rsrc_t rsB2 = make_rsrc(q.B.p, t + 2 < nkt ? q.B.bytes : 0u);
+            const __amdgpu_buffer_rsrc_t rsA2 = make_rsrc(q.A.p, t + 2 < nkt ? q.A.bytes : 0u);
+            const uint32_t k1 = (uint32_t)(t + 1) * 128u, k2 = (uint32_t)(t + 2) * 128u;
+            char* const slot_lo = bring + s_lo * P4_BHALF;
+            char* const slot_hi = bring + s_hi * P4_BHALF;
+            const char* const slot_nx = bring + s_nx * P4_BHALF;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (i < 7) rdA(sta, i + 1, (i + 1) & 1);
+                else rdA(stn, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    mma1(i, j, i & 1);
+                    if (i == 7) rdB(j, slot_nx, slot_lo);          // tile t+1: half 2t+2 (slot_nx) | half 2t+3 (slot_lo, refilled in row blocks 0-1)
+                    if (i < 2 && (j & 1)) { const int pc = 2 * i + (j >> 1); lds_dma16(rsB1, slot_lo + pc * 1024, vob[4 + pc], k1); }
+                    if ((i == 2 || i == 3) && (j & 1)) { const int pc = 2 * (i - 2) + (j >> 1); lds_dma16(rsB2, slot_hi + pc * 1024, vob[pc], k2); }
+                    if (i == 7) lds_dma16(rsA2, smem + (t & 1) * P4_ASTAGE + wave * 4096 + j * 1024, voa[j], k2);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (i == 6) {          // X(t+1)
+                    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            const int s = s_lo; s_lo = s_nx; s_nx = s_hi; s_hi = s;          // halves 2t+2, 2t+3, 2t+4 sit in slot_nx, slot_lo, slot_hi
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (P4_EPI_PRIO) __builtin_amdgcn_s_setprio(P4_EPI_PRIO);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // the last (empty) requests have landed before the epilogue reuses the LDS
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    } else {
+        // ---- rare path (a delayed scale left its window): synchronous, operands split from the fp32 copies at the exact scale;
+        // A at [0, 16 K), B (all 256 rows, shared layout) at [16 K, 48 K)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the early pieces have landed before anything is restaged
+        if (slowA) sa = site_exact_scale(q.A.hdr, (float*)(smem + P4_LDS - 64), tid, 256);
+        if (slowB) sb = site_exact_scale(q.B.hdr, (float*)(smem + P4_LDS - 64), tid, 256);
+        auto slow_stage = [&](const PlaneOperand& op, float sc, int row0, int nrows, int ntrows, int kt, char* dst) {
+#pragma unroll 1
+            for (int j = tid; j < ntrows * 4; j += 256) {
+                const int row = j >> 2, kc = j & 3;
+                const float* src = op.f32 + (size_t)min(row0 + row, nrows - 1) * op.ldf + kt * 32 + kc * 8;
+                const f32x4 x0 = *(const f32x4*)src, x1 = *(const f32x4*)(src + 4);
+                uint32_t h0, l0, h1, l1, h2, l2, h3, l3;
+                splith_pair(x0.x, x0.y, sc, h0, l0); splith_pair(x0.z, x0.w, sc, h1, l1);
+                splith_pair(x1.x, x1.y, sc, h2, l2); splith_pair(x1.z, x1.w, sc, h3, l3);
+                const int sw = (row >> 1) & 7;
+                *(uint4*)(dst + row * 128 + ((kc ^ sw) << 4)) = make_uint4(h0, h1, h2, h3);
+                *(uint4*)(dst + row * 128 + (((4 + kc) ^ sw) << 4)) = make_uint4(l0, l1, l2, l3);
+            }
+        };
+        auto dma_rows = [&](__amdgpu_buffer_rsrc_t rs, const PlaneOperand& op, int row0, int nrows, int ntrows, int kt, char* dst) {
+#pragma unroll 1
+            for (int pc = wave; pc < ntrows / 8; pc += 4) {
+                const int row = pc * 8 + r8;
+                lds_dma16(rs, dst + pc * 1024, (uint32_t)min(row0 + row, nrows - 1) * (uint32_t)op.ld2 * 2u +
+                          (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) * 16), (uint32_t)kt * 128u);
+            }
+        };
+        const char* bsh = smem + P4_ASTAGE + wn * 64 * 128;
+#pragma unroll 1
+        for (int t = 0; t < nkt; ++t) {
+            __syncthreads();
+            if (slowA) slow_stage(q.A, sa, m0, p.M, P4_BM, t, smem); else dma_rows(rsA, q.A, m0, p.M, P4_BM, t, smem);
+            if (slowB) slow_stage(q.B, sb, n0, p.N, P4_BN, t, smem + P4_ASTAGE); else dma_rows(rsB, q.B, n0, p.N, P4_BN, t, smem + P4_ASTAGE);
+            dma_wait_barrier();
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) rdB(j, bsh, bsh + P4_BHALF);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                rdA(smem, i, i & 1);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) mma1(i, j, i & 1);
+            }
+        }
+        __syncthreads();
+    }
+    STAMP(2);
+
+    // ================================================================ epilogue (gemm_pl_nt8's, for one wave group)
+    // lane holds C[gm = m0 + 16 i + l15][gn = n0 + 64 wn + 16 j + 4 lq .. + 3] of tile (i, j).  The extra operand E (residual, or
+    // the aux tensor of an activation gradient) is staged by LDS-DMA, a quarter of the tile (32 rows x 1 KB) at a time, into
+    // the two 32 KB halves at the bottom of the LDS; the per-wave transpose patches sit behind them.  Every wave has passed
+    // the loop's last barrier with its LDS reads retired, so the k-loop's regions are free.
+    float am = 0.f;
+    if (SEGMM_GEMM_DBG(q) & 2) {
+        float t = 0.f;          // timing ablation: keep every accumulator alive, skip the epilogue
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) t += acc[i][j].x + acc[i][j].y + acc[i][j].z + acc[i][j].w;
+        if (t == 1.2345f) p.C[0] = 1.f;
+    } else {
+        const float inv_ab = (1.f / sa) * (1.f / sb);          // exact powers of two
+        const int epi = p.epi;
+        const bool has_res = p.residual != nullptr, has_drop = p.drop.p > 0.f;
+        const DropCfg drop_e = drop_live(p.drop);
+        const bool aux_r = epi == EPI_DGELU || epi == EPI_DRELU, aux_w = epi == EPI_GELU;
+        const bool planes = c_scale > 0.f && q.Cp != nullptr;
+        const bool store_c = q.write_c && !(SEGMM_GEMM_DBG(q) & 1);
+        const bool periodic = has_res && p.res_period < p.M;
+        const int res_rows = has_res ? min(p.res_period, p.M) : 0;
+        const bool has_e = has_res || aux_r;
+        auto ext = [&](bool on, long long rows, long long ld, long long elt) -> uint32_t {      // view extent in bytes (0: absent)
+            if (!on || rows <= 0) return 0u;
+            return (uint32_t)(((rows - 1) * ld + p.N) * elt);          // < 2^31 (checked by the host)
+        };
+        const __amdgpu_buffer_rsrc_t rsC = make_rsrc(p.C, ext(store_c, p.M, p.ldc, 4));
+        const __amdgpu_buffer_rsrc_t rsAuxW = make_rsrc(p.aux, ext(aux_w, p.M, p.ldaux, 4));
+        const __amdgpu_buffer_rsrc_t rsE = aux_r ? make_rsrc(p.aux, ext(true, p.M, p.ldaux, 4)) : make_rsrc(p.residual, ext(has_res, res_rows, p.ldr, 4));
+        const int ldE = aux_r ? p.ldaux : p.ldr;
+        const __amdgpu_buffer_rsrc_t rsPl = make_rsrc(q.Cp, planes ? (uint32_t)((((long long)p.M - 1) * q.ldc2 + 2ll * p.N) * 2) : 0u);
+        const int ns = (store_c ? 1 : 0) + (planes ? 1 : 0) + (aux_w ? 1 : 0);          // store instructions per float4
+
+        const int gm0 = m0 + l15;
+        const int gn0 = n0 + wn * 16 * NJ + 4 * lq;
+        uint32_t colmask[NJ];          // 0 or BUF_OOB: columns beyond N are pushed out of every descriptor's range
+        f32x4 bias4[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int gn = gn0 + 16 * j;
+            colmask[j] = gn < p.N ? 0u : BUF_OOB;
+            bias4[j] = (p.bias && gn < p.N) ? *(const f32x4*)(p.bias + gn) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const bool full_tile = m0 + P4_BM <= p.M && n0 + P4_BN <= p.N;
+        // E quarter qq -> half (qq & 1): slot s = tile row - 32 qq at byte s * 1024; 16-byte chunk c of the row at physical chunk
+        // c ^ (row & 15) (conflict-free ds_read_b128 of the accumulator layout); the permutation is applied to the DMA source
+        auto dmaE = [&](int qq) {
+            char* dst = smem + (qq & 1) * P4_EHALF;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int slot = wave * 8 + k;
+                const int R = qq * 32 + slot;          // tile row (wave-uniform)
+                const int gmR = m0 + R;
+                const int er = aux_r ? gmR : (periodic ? gmR % p.res_period : gmR);
+                const int ch = lane ^ (R & 15);
+                const uint32_t vo = (ch < 16 * NJ && n0 + 4 * ch < p.N) ? (uint32_t)ch * 16u : BUF_OOB;
+                lds_dma16(rsE, dst + slot * 1024, vo, ((uint32_t)er * (uint32_t)ldE + (uint32_t)n0) * 4u);
+            }
+        };
+        auto vmwait = [&](int kind) {          // kind 0: 8 newer ops; 1: S + 8; 2: S newer ops, S = 8 ns store instructions of the last quarter
+            __builtin_amdgcn_sched_barrier(0);
+            if (kind == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (ns == 1) { if (kind == 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+            else if (ns == 2) { if (kind == 1) asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }
+            else if (ns == 3) { if (kind == 1) asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); }
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        // ---- stores: every 16-row x 64-column strip passes through the wave's 4 KB patch (chunk c of row r at physical chunk
+        // c ^ r) and leaves as whole 256-byte row segments: lane (lq, l15) of pass t stores row 4 t + lq, columns 4 l15 .. + 3
+        char* trp = smem + P4_PATCH + wave * 4096;
+        const uint32_t tr_w = (uint32_t)(l15 * 256);
+        const int gnT = n0 + wn * 16 * NJ + 4 * l15;
+        const uint32_t tmask = (l15 < 4 * NJ && gnT < p.N) ? 0u : BUF_OOB;
+        const uint32_t oCT = (((uint32_t)(m0 + lq) * (uint32_t)p.ldc + (uint32_t)gnT) * 4u) | tmask;
+        const uint32_t oAuxT = (((uint32_t)(m0 + lq) * (uint32_t)p.ldaux + (uint32_t)gnT) * 4u) | tmask;
+        auto tr_put = [&](int j, f32x4 v) { *(f32x4*)(trp + tr_w + (((lq + 4 * j) ^ l15) << 4)) = v; };
+        auto tr_get = [&](int t) { const int r = 4 * t + lq; return *(const f32x4*)(trp + r * 256 + (((l15 ^ r) & 15) << 4)); };
+        const uint32_t oPlT = (((uint32_t)(m0 + lq) * (uint32_t)q.ldc2 + (uint32_t)((((gnT & ~7) >> 5) << 6) + ((gnT & ~7) & 31) + ((l15 & 1) ? 32 : 0))) * 2u) | tmask;
+
+        if (has_e) { dmaE(0); dmaE(1); }
+        const uint32_t e_lane = (uint32_t)(l15 * 1024);          // + 16384 for odd row blocks; chunk ((16 wn + 4 j + lq) ^ l15) * 16
+        auto row_loop = [&](auto act_tag, auto drop_tag, auto pl_tag) {
+            constexpr int ACT = decltype(act_tag)::value;          // 0 none, 1 ReLU / ReLU', 2 GELU / GELU'
+            constexpr bool DROP = decltype(drop_tag)::value, PLANES = decltype(pl_tag)::value;
+#pragma unroll 1
+            for (int i = 0; i < 8; ++i) {
+                if (has_e && (i & 1) == 0) vmwait(i == 0 ? 0 : (i == 6 ? 2 : 1));          // quarter i / 2 has landed (all waves: barrier)
+                f32x4 c[NJ];
+                switch (i) {
+                    case 0: for (int j = 0; j < NJ; ++j) c[j] = acc[0][j]; break;
+                    case 1: for (int j = 0; j < NJ; ++j) c[j] = acc[1][j]; break;
+                    case 2: for (int j = 0; j < NJ; ++j) c[j] = acc[2][j]; break;
+                    case 3: for (int j = 0; j < NJ; ++j) c[j] = acc[3][j]; break;
+                    case 4: for (int j = 0; j < NJ; ++j) c[j] = acc[4][j]; break;
+                    case 5: for (int j = 0; j < NJ; ++j) c[j] = acc[5][j]; break;
+                    case 6: for (int j = 0; j < NJ; ++j) c[j] = acc[6][j]; break;
+                    default: for (int j = 0; j < NJ; ++j) c[j] = acc[7][j]; break;
+                }
+                const int gm = gm0 + 16 * i;
+                const uint32_t rowmask = gm < p.M ? 0xffffffffu : 0u;
+                const uint32_t soC = (uint32_t)i * 16u * (uint32_t)p.ldc * 4u, soAux = (uint32_t)i * 16u * (uint32_t)p.ldaux * 4u;
+                const char* ebuf = smem + ((i >> 1) & 1) * P4_EHALF + e_lane + (i & 1) * 16384;
+                f32x4 e[NJ];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) e[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (has_e) {
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) e[j] = *(const f32x4*)(ebuf + (((4 * NJ * wn + 4 * j + lq) ^ l15) << 4));
+                }
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    f32x4 v = c[j] * inv_ab + bias4[j];
+                    if (ACT == 2) {
+                        if (epi == EPI_GELU) {
+                            tr_put(j, v);          // the pre-activation leaves through the transpose patch below
+                            v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
+                        } else {
+                            v.x *= gelu_erf_grad(e[j].x); v.y *= gelu_erf_grad(e[j].y); v.z *= gelu_erf_grad(e[j].z); v.w *= gelu_erf_grad(e[j].w);
+                        }
+                    } else if (ACT == 1) {
+                        if (epi == EPI_RELU) {
+                            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                        } else {
+                            v.x = e[j].x > 0.f ? v.x : 0.f; v.y = e[j].y > 0.f ? v.y : 0.f; v.z = e[j].z > 0.f ? v.z : 0.f; v.w = e[j].w > 0.f ? v.w : 0.f;
+                        }
+                    }
+                    if (DROP) v = drop_apply4(drop_e, ((uint64_t)gm * (uint64_t)p.N + (uint64_t)(gn0 + 16 * j)) >> 2, v);
+                    if (ACT == 0) v += e[j];                    // e = 0 without a residual
+                    else if (has_res) v += e[j];                // (e is the aux tensor of an activation gradient otherwise)
+                    c[j] = v;
+                    {          // running max |v| over the elements that exist (branch-free)
+                        const uint32_t mk = rowmask & ~((int32_t)colmask[j] >> 31);
+                        const float mx = __uint_as_float(__float_as_uint(v.x) & mk), my = __uint_as_float(__float_as_uint(v.y) & mk);
+                        const float mz = __uint_as_float(__float_as_uint(v.z) & mk), mw = __uint_as_float(__float_as_uint(v.w) & mk);
+                        asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(am) : "v"(mx), "v"(my));
+                        asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(am) : "v"(mz), "v"(mw));
+                    }
+                }
+                if (ACT == 2 && epi == EPI_GELU) {          // the pre-activations (put above), as whole row segments
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) buf_store4(rsAuxW, oAuxT, soAux + (uint32_t)(4 * t) * (uint32_t)p.ldaux * 4u, tr_get(t));
+                }
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) tr_put(j, c[j]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const f32x4 v = tr_get(t);
+                    buf_store4(rsC, oCT, soC + (uint32_t)(4 * t) * (uint32_t)p.ldc * 4u, v);
+                    if (PLANES) {
+                        uint32_t h0, l0, h1, l1;
+                        splith_pair(v.x, v.y, c_scale, h0, l0);
+                        splith_pair(v.z, v.w, c_scale, h1, l1);
+                        const bool oddl = (l15 & 1) != 0;
+                        const uint32_t r0 = dpp_swap1(oddl ? h0 : l0), r1 = dpp_swap1(oddl ? h1 : l1);
+                        const u32x4_t w = oddl ? u32x4_t{r0, r1, l0, l1} : u32x4_t{h0, h1, r0, r1};
+                        buf_store4u(rsPl, oPlT, (uint32_t)(16 * i + 4 * t) * (uint32_t)q.ldc2 * 2u, w);
+                    }
+                }
+                if (has_e && (i & 1) == 1 && i < 5) {          // both row blocks of the quarter are read: refill its half with quarter + 2
+                    end_load_segment();
+                    dmaE((i >> 1) + 2);
+                }
+            }
+        };
+        // whole tile, no activation, no dropout, no plane output (the fused projections, the input-gradient GEMMs): unrolled
+        auto fast_loop = [&](auto e_tag) {
+            constexpr bool HAS_E = decltype(e_tag)::value;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (HAS_E && (i & 1) == 0) vmwait(i == 0 ? 0 : (i == 6 ? 2 : 1));
+                const uint32_t soC = (uint32_t)i * 16u * (uint32_t)p.ldc * 4u;
+                const char* ebuf = smem + ((i >> 1) & 1) * P4_EHALF + e_lane + (i & 1) * 16384;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    f32x4 v = acc[i][j] * inv_ab + bias4[j];
+                    if (HAS_E) v += *(const f32x4*)(ebuf + (((4 * NJ * wn + 4 * j + lq) ^ l15) << 4));
+                    asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(am) : "v"(v.x), "v"(v.y));
+                    asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(am) : "v"(v.z), "v"(v.w));
+                    tr_put(j, v);
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) buf_store4(rsC, oCT, soC + (uint32_t)(4 * t) * (uint32_t)p.ldc * 4u, tr_get(t));
+                if (HAS_E && (i & 1) == 1 && i < 5) {
+                    end_load_segment();
+                    dmaE((i >> 1) + 2);
+                }
+            }
+        };
+        const bool fast = full_tile && epi == EPI_NONE && !has_drop && !planes;
+        if (fast) {
+            if (has_e) fast_loop(std::true_type{}); else fast_loop(std::false_type{});
+        } else {
+            using A0 = std::integral_constant<int, 0>; using A1 = std::integral_constant<int, 1>; using A2 = std::integral_constant<int, 2>;
+            using T = std::true_type; using F = std::false_type;
+            auto pick = [&](auto act_tag) {
+                if (has_drop) { if (planes) row_loop(act_tag, T{}, T{}); else row_loop(act_tag, T{}, F{}); }
+                else { if (planes) row_loop(act_tag, F{}, T{}); else row_loop(act_tag, F{}, F{}); }
+            };
+            if (epi == EPI_GELU || epi == EPI_DGELU) pick(A2{});
+            else if (epi == EPI_RELU || epi == EPI_DRELU) pick(A1{});
+            else pick(A0{});
+        }
+    }
+    STAMP(3);
+    if (q.repair) return;          // (the header keeps the first launch's verdict)
+    if (q.c_hdr) {
+        site_commit(q.c_hdr, am, blockIdx.x * 4 + wave, c_scale);
+        if (c_scale > 0.f && scale_writer(blockIdx.x * 4 + wave)) q.c_hdr[0] = c_scale;
+    } else if (p.amax_out) amax_commit(p.amax_out, am, blockIdx.x * 4 + wave);
+}
+
+}  // namespace segmm
+
+namespace segmm {
+
+// =============================================================================== TN, round-6 form
+// Weight gradients gW[M, N] = A[K, M]^T . B[K, N] over the token axis K (split-K over blockIdx.z), in the structure of gemm_pl_nt4:
+// 128 (A features) x 256 (B features) tile, four waves as 1 x 4, two workgroups per CU, the software-pipelined stream.  Operand
+// handling is gemm_pl_tn8's: a k-tile is 32 token rows, fragments by ds_read_b64_tr_b16 (hardware transpose: a lane ends up with
+// 8 consecutive tokens of ITS feature).  What is laid out differently:
+//     A (shared):  32 tokens x 512 B (128 features x [hi | lo]) per stage; one LDS-DMA instruction moves TWO token rows
+//     B (private): wave wn stages only ITS 64 features: 256 B per token; the ring's three half-slots hold 16 tokens each (4 KB; a
+//                  k-tile is the halves 2t = tokens 0-15 and 2t+1 = tokens 16-31); one LDS-DMA instruction moves FOUR token rows
+// LDS image of a token row (512 / 256 B): pieces of 64 B (piece = 2 * feature block + plane); piece c of token t sits at physical
+// piece c ^ (t & 3), and inside a piece the two 32-byte halves are swapped for tokens with bit 3 set -- gemm_pl_tn8's permutation
+// (row pitches of 512 and 256 B are multiples of the 256-byte bank period, like its 1 KB): conflict-free transposed reads.
+// Same MFMA order per element and the same split ranges as gemm_pl_tn8: the results are BITWISE its results.
+// LDS-DMA written as inline asm.  hipcc's waitcnt pass puts an s_waitcnt vmcnt(0) in front of every ds_read_b64_tr_b16 that follows an
+// LDS-DMA builtin it has seen (it cannot tell which LDS bytes the DMA writes; plain ds_read_b128 loads are not treated that way) --
+// inside a loop that keeps 12 pieces in flight that drains the whole prefetch at every fragment read (first build of this kernel:
+// 0.55x of gemm_pl_tn8).  The asm form is invisible to the pass; every RAW / WAR between a piece and the reads of its bytes is
+// ordered by the explicit s_waitcnt vmcnt(N) + s_barrier of the stream, as in the NT kernel.  (No other code of the kernel uses M0.)
+__device__ __forceinline__ u32x4_t rsrc_words(const void* p, uint32_t bytes) {
+    const uint64_t a = (uint64_t)p;
+    return u32x4_t{(uint32_t)a, (uint32_t)(a >> 32) & 0xffffu, bytes, 0x00020000u};
+}
+__device__ __forceinline__ void lds_dma16_asm(u32x4_t r, const void* lds_wave_base, uint32_t voff, uint32_t soff) {
+    const uint32_t la = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)lds_wave_base;
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" :: "v"(voff), "s"(r), "s"(la), "s"(soff) : "memory");
+}
+__device__ __forceinline__ f32x4 lds_tr8s(const char* a, int stride4) {          // 8 tokens (two 4-token blocks, stride4 bytes apart) of this lane's feature
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a + stride4));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(f32x4, v);
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_pl_tn4(const GemmArgs p, const PGemmX q) {
+    constexpr int NJ = 4;
+    __shared__ __attribute__((aligned(16))) char smem[P4_LDS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int ntile = p.nbm * p.nbn;
+    const int lg = xcd_remap(blockIdx.x + ntile * blockIdx.z, ntile * gridDim.z);          // tiles of one token slab meet in one L2
+    const int kz = lg / ntile, lb = lg - kz * ntile;
+    const int m0 = (lb / p.nbn) * P4_BM, n0 = (lb % p.nbn) * P4_BN;
+    const int kbeg = kz * p.k_per_split;
+    const int kend = min(p.K, kbeg + p.k_per_split);
+    const int nkt = (kend - kbeg + 31) >> 5;
+    const bool do_colsum = q.colsum_out != nullptr && (lb % p.nbn) == 0;
+    if (P4_EPI_PRIO) __builtin_amdgcn_s_setprio(P4_EPI_PRIO);
+
+    // ---- LDS-DMA.  A: piece 4 wave + i of 16 = tokens 2 piece, 2 piece + 1 (lanes 0-31 / 32-63), 32 chunks of 16 B per token;
+    // B: piece pc of 8 = tokens 4 pc .. 4 pc + 3 (16 lanes each), 16 chunks per token, half = pc >> 2.
+    // physical chunk l of token t holds logical piece (l >> 2) ^ (t & 3), chunk (l & 3) ^ (2 * bit 3 of t)
+    const u32x4_t rsA = rsrc_words(q.A.p, q.A.bytes), rsB = rsrc_words(q.B.p, q.B.bytes);
+    uint32_t voa[4], vob[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int tok = 2 * (4 * wave + i) + (lane >> 5), l = lane & 31;
+        voa[i] = (uint32_t)tok * (uint32_t)q.A.ld2 * 2u + (uint32_t)m0 * 4u + (uint32_t)((((l >> 2) ^ (tok & 3)) << 6) + (((l & 3) ^ (((tok >> 3) & 1) << 1)) << 4));
+    }
+#pragma unroll
+    for (int pc = 0; pc < 8; ++pc) {
+        const int tok = 4 * pc + (lane >> 4), l = lane & 15;
+        vob[pc] = (uint32_t)tok * (uint32_t)q.B.ld2 * 2u + (uint32_t)(n0 + 64 * wn) * 4u + (uint32_t)((((l >> 2) ^ (tok & 3)) << 6) + (((l & 3) ^ (((tok >> 3) & 1) << 1)) << 4));
+    }
+    char* const bring = smem + P4_BOFF + wave * P4_BRING;
+    const uint32_t ka = (uint32_t)q.A.ld2 * 64u, kb = (uint32_t)q.B.ld2 * 64u;          // bytes per k-tile of 32 token rows
+    const uint32_t ka0 = (uint32_t)kbeg * (uint32_t)q.A.ld2 * 2u, kb0 = (uint32_t)kbeg * (uint32_t)q.B.ld2 * 2u;
+    // ---- the first k-tiles leave NOW: A(0), B halves 0, 1 (slots 0, 1), half 2 = tokens 0-15 of tile 1 (slot 2), A(1)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) lds_dma16_asm(rsA, smem + wave * 4096 + i * 1024, voa[i], ka0);
+#pragma unroll
+    for (int pc = 0; pc < 8; ++pc) lds_dma16_asm(rsB, bring + (pc >> 2) * P4_BHALF + (pc & 3) * 1024, vob[pc], kb0);
+    {
+        const u32x4_t rsB1 = rsrc_words(q.B.p, nkt > 1 ? q.B.bytes : 0u), rsA1 = rsrc_words(q.A.p, nkt > 1 ? q.A.bytes : 0u);
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc) lds_dma16_asm(rsB1, bring + 2 * P4_BHALF + pc * 1024, vob[pc], kb0 + kb);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) lds_dma16_asm(rsA1, smem + P4_ASTAGE + wave * 4096 + i * 1024, voa[i], ka0 + ka);
+    }
+
+    // ---- operand state (all header words requested at once)
+    auto uni = [](float x) { return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(x))); };
+    const float ha0 = q.A.hdr[0], ha1 = q.A.hdr[1], hb0 = q.B.hdr[0], hb1 = q.B.hdr[1];
+    const f32x4 ama = *(const f32x4*)(q.A.hdr + SITE_HDR + lane * 4), amb = *(const f32x4*)(q.B.hdr + SITE_HDR + lane * 4);
+    const float sa0 = uni(ha0), sb0 = uni(hb0);
+    auto planes_ok = [&](float s, float flag, f32x4 v) {
+        const float m = wave_max(fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+        if (!(s > 0.f) || __float_as_uint(flag) != 0u) return false;
+        return !(m > 0.f) || ((m * s >= 0.25f || s >= 0x1p60f) && m * s < 65504.f);
+    };
+    const bool slowA = q.A.f32 != nullptr && !planes_ok(sa0, uni(ha1), ama);          // delayed scale outside its window: fp32 fallback
+    const bool slowB = q.B.f32 != nullptr && !planes_ok(sb0, uni(hb1), amb);
+    float sa = sa0, sb = sb0;
+
+    // ---- transposed fragment reads: lane = (lq: token octet, qq = (lane >> 2) & 3: token inside a 4-block, pp = lane & 3)
+    const int qq = (lane >> 2) & 3, pp = lane & 3;
+    const uint32_t hsw = (uint32_t)((lq & 1) << 5);          // tokens with bit 3 set: the 32-byte halves of a piece are swapped
+    const uint32_t base_a = (uint32_t)((8 * lq + qq) * 512 + 8 * pp);
+    const uint32_t base_b = (uint32_t)((8 * (lq & 1) + qq) * 256 + 8 * pp);          // inside the half-slot of token octets (lq >> 1)
+    // A tile i (16 features), plane pl: base_a + (((2 (i >> 1) + pl) ^ qq) << 6) + ((32 (i & 1)) ^ hsw); B tile j likewise on base_b.
+    // The XOR with qq touches the two low bits of the piece index only: four per-lane offsets xa[v], v = 2 (feature block & 1) + plane,
+    // a constant 256 B per feature-block pair, and the per-lane half offset
+    uint32_t xa[4], xb[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) { xa[v] = base_a + (uint32_t)((v ^ qq) << 6); xb[v] = base_b + (uint32_t)((v ^ qq) << 6); }
+    const uint32_t hh[2] = {hsw, 32u ^ hsw};
+    auto frag_off = [&](int i, int pl, const uint32_t* x) -> uint32_t {
+        const int fbk = i >> 1;
+        return x[2 * (fbk & 1) + pl] + (uint32_t)((fbk >> 1) * 256) + hh[i & 1];
+    };
+
+    f32x4 acc[8][NJ];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 accb[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    f32x4 bh[NJ], bl[NJ], ah[2], al[2];
+    auto rdA = [&](const char* st, int i, int buf) {
+        ah[buf] = lds_tr8s(st + frag_off(i, 0, xa), 2048);
+        al[buf] = lds_tr8s(st + frag_off(i, 1, xa), 2048);
+    };
+    // B: token octets 0, 1 (lanes lq < 2) in half `h0`, octets 2, 3 in half `h1`: a per-lane base
+    auto rdB = [&](int j, const char* lane_half) {
+        bh[j] = lds_tr8s(lane_half + frag_off(j, 0, xb), 1024);
+        bl[j] = lds_tr8s(lane_half + frag_off(j, 1, xb), 1024);
+    };
+    auto mma1 = [&](int r, int j, int buf) {
+        f32x4 c = acc[r][j];
+        c = mfma16(bh[j], al[buf], c);
+        c = mfma16(bl[j], ah[buf], c);
+        c = mfma16(bh[j], ah[buf], c);
+        acc[r][j] = c;
+    };
+    const f32x4 ones = __builtin_bit_cast(f32x4, make_uint4(0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u));      // 8 x fp16 1.0
+    auto colsum1 = [&](int i, int buf) {          // the column sums of A tile i ride along in wave i >> 1 of the first column tile's workgroup
+        if ((i >> 1) == wn) {
+            f32x4 cb = accb[i & 1];
+            cb = mfma16(ones, al[buf], cb);
+            cb = mfma16(ones, ah[buf], cb);
+            accb[i & 1] = cb;
+        }
+    };
+
+    auto k_loop = [&](auto cs_tag) {
+        constexpr bool CS = decltype(cs_tag)::value;
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");          // A(0), B halves 0, 1 landed; half 2 and A(1) may fly
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (P4_EPI_PRIO) __builtin_amdgcn_s_setprio(0);
+        int s_lo = 0, s_hi = 1, s_nx = 2;          // half-slots of B halves 2t, 2t+1, 2t+2
+        rdA(smem, 0, 0);
+        {
+            const char* lh = bring + ((lq >> 1) ? s_hi : s_lo) * P4_BHALF;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) rdB(j, lh);
+        }
+#pragma unroll 1
+        for (int t = 0; t < nkt; ++t) {
+            const char* sta = smem + (t & 1) * P4_ASTAGE;
+            const char* stn = smem + ((t + 1) & 1) * P4_ASTAGE;
+            const u32x4_t rsB1 = rsrc_words(q.B.p, t + 1 < nkt ? q.B.bytes : 0u);
+            const u32x4_t rsB2 = rsrc_words(q.B.p, t + 2 < nkt ? q.B.bytes : 0u);
+            const u32x4_t rsA2 = rsrc_words(q.A.p, t + 2 < nkt ? q.A.bytes : 0u);
+            const uint32_t kb1 = kb0 + (uint32_t)(t + 1) * kb, kb2 = kb0 + (uint32_t)(t + 2) * kb, ka2 = ka0 + (uint32_t)(t + 2) * ka;
+            char* const slot_lo = bring + s_lo * P4_BHALF;
+            char* const slot_hi = bring + s_hi * P4_BHALF;
+            // tile t+1: tokens 0-15 = half 2t+2 (slot s_nx), tokens 16-31 = half 2t+3 (slot s_lo, refilled below)
+            const char* const next_half = bring + ((lq >> 1) ? s_lo : s_nx) * P4_BHALF;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (i < 7) rdA(sta, i + 1, (i + 1) & 1);
+                else rdA(stn, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (CS) colsum1(i, i & 1);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    mma1(i, j, i & 1);
+                    if (i == 7) rdB(j, next_half);
+                    // pieces: every B fragment of tile t has been read once mma(0, 3) is issued -- both half-slots are free from there
+                    const int sl = 4 * i + j - 3;          // 0, 2, 4, .. 14 -> pieces 0 .. 7
+                    if (sl >= 0 && sl < 16 && (sl & 1) == 0) {
+                        const int pc = sl >> 1;
+                        if (pc < 4) lds_dma16_asm(rsB1, slot_lo + pc * 1024, vob[4 + pc], kb1);          // half 2t+3: tokens 16-31 of tile t+1
+                        else lds_dma16_asm(rsB2, slot_hi + (pc - 4) * 1024, vob[pc - 4], kb2);          // half 2t+4: tokens 0-15 of tile t+2
+                    }
+                    if (i == 7) lds_dma16_asm(rsA2, smem + (t & 1) * P4_ASTAGE + wave * 4096 + j * 1024, voa[j], ka2);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (i == 6) {          // X(t+1)
+                    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            const int s = s_lo; s_lo = s_nx; s_nx = s_hi; s_hi = s;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (P4_EPI_PRIO) __builtin_amdgcn_s_setprio(P4_EPI_PRIO);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    if (!(slowA || slowB)) {
+        if (do_colsum) k_loop(std::true_type{}); else k_loop(std::false_type{});
+    } else {
+        // ---- rare path (a delayed scale left its window): synchronous; the stage is written by ds_write from the operand's fp32 copy,
+        // split with the exact scale of its recorded maxima (A: 32 tokens x 128 features by the workgroup; B: each wave its own 64 features)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the early pieces have landed before anything is restaged
+        if (slowA) sa = site_exact_scale(q.A.hdr, (float*)(smem + P4_LDS - 64), tid, 256);
+        if (slowB) sb = site_exact_scale(q.B.hdr, (float*)(smem + P4_LDS - 64), tid, 256);
+        auto put = [&](char* row, int f, f32x4 x, float sc, int t) {          // 4 features f .. f+3 (f % 4 == 0, relative to the staged row) of token t
+            uint32_t hh0, l0, hh1, l1;
+            splith_pair(x.x, x.y, sc, hh0, l0); splith_pair(x.z, x.w, sc, hh1, l1);
+            const int b = f >> 5, g8 = (f & 31) >> 2, cp = (g8 >> 1) ^ (((t >> 3) & 1) << 1), sw = t & 3;
+            *(uint2*)(row + (((2 * b) ^ sw) << 6) + (cp << 4) + ((g8 & 1) << 3)) = make_uint2(hh0, hh1);
+            *(uint2*)(row + (((2 * b + 1) ^ sw) << 6) + (cp << 4) + ((g8 & 1) << 3)) = make_uint2(l0, l1);
+        };
+#pragma unroll 1
+        for (int t = 0; t < nkt; ++t) {
+            __syncthreads();
+            const int k0 = kbeg + t * 32;
+            if (slowA) {
+#pragma unroll 1
+                for (int e = tid; e < 32 * 32; e += 256) {          // 32 tokens x 32 float4
+                    const int tk = e >> 5, f = (e & 31) * 4;
+                    f32x4 x = {0.f, 0.f, 0.f, 0.f};
+                    if (k0 + tk < kend && m0 + f < p.M) x = *(const f32x4*)(q.A.f32 + (size_t)(k0 + tk) * q.A.ldf + m0 + f);
+                    put(smem + tk * 512, f, x, sa, tk);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) lds_dma16_asm(rsA, smem + wave * 4096 + i * 1024, voa[i], ka0 + (uint32_t)t * ka);
+            }
+            if (slowB) {
+#pragma unroll 1
+                for (int e = lane; e < 32 * 16; e += 64) {          // 32 tokens x 16 float4 of the wave's 64 features
+                    const int tk = e >> 4, f = (e & 15) * 4;
+                    f32x4 x = {0.f, 0.f, 0.f, 0.f};
+                    if (k0 + tk < kend && n0 + 64 * wn + f < p.N) x = *(const f32x4*)(q.B.f32 + (size_t)(k0 + tk) * q.B.ldf + n0 + 64 * wn + f);
+                    put(bring + (tk >> 4) * P4_BHALF + (tk & 15) * 256, f, x, sb, tk);
+                }
+            } else {
+#pragma unroll
+                for (int pc = 0; pc < 8; ++pc) lds_dma16_asm(rsB, bring + (pc >> 2) * P4_BHALF + (pc & 3) * 1024, vob[pc], kb0 + (uint32_t)t * kb);
+            }
+            dma_wait_barrier();
+            const char* lh = bring + (lq >> 1) * P4_BHALF;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) rdB(j, lh);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                rdA(smem, i, i & 1);
+                if (do_colsum) colsum1(i, i & 1);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) mma1(i, j, i & 1);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- outputs
+    const bool split = gridDim.z > 1;
+    const float inv_a = 1.f / sa;
+    if (do_colsum && lq == 0) {          // every row of accb holds the column sums: lanes of column group 0 own 16 features each
+        float* dst = split ? q.colsum_ws + (size_t)kz * p.M : q.colsum_out;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int m = m0 + 16 * (2 * wn + e) + l15;
+            if (m < p.M) dst[m] = accb[e].x * inv_a;
+        }
+    }
+    const float inv_ab = inv_a * (1.f / sb);
+    float* Cout = split ? p.C + (size_t)kz * (size_t)p.slab_stride : p.C;
+    const __amdgpu_buffer_rsrc_t rsC = make_rsrc(Cout, (uint32_t)((((long long)p.M - 1) * p.ldc + p.N) * 4));
+    // whole 256-byte row segments through the wave's transpose patch (see gemm_pl_nt8)
+    char* trp = smem + P4_PATCH + wave * 4096;
+    const int gnT = n0 + wn * 64 + 4 * l15;
+    const uint32_t oCT = (((uint32_t)(m0 + lq) * (uint32_t)p.ldc + (uint32_t)gnT) * 4u) | (gnT < p.N ? 0u : BUF_OOB);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *(f32x4*)(trp + l15 * 256 + (((lq + 4 * j) ^ l15) << 4)) = acc[i][j] * inv_ab;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int r = 4 * t + lq;
+            buf_store4(rsC, oCT, (uint32_t)(16 * i + 4 * t) * (uint32_t)p.ldc * 4u, *(const f32x4*)(trp + r * 256 + (((l15 ^ r) & 15) << 4)));
+        }
+    }
+}
+
+}  // namespace segmm

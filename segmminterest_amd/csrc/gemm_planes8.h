@@ -65,7 +65,9 @@ constexpr uint32_t BUF_OOB = 0x80000000u;          // a byte offset no descripto
 #ifdef SEGMM_STAMPS
 // diagnostic build only: shader-clock / real-time stamps of the kernel's sections, 8 x u64 per workgroup
 #define STAMP(k) do { if (q.stamps && threadIdx.x == 0) { q.stamps[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
-                                                           if ((k) == 0 || (k) == 3) q.stamps[(size_t)blockIdx.x * 8 + 4 + ((k) ? 1 : 0)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+                                                           if ((k) == 0 || (k) == 3) q.stamps[(size_t)blockIdx.x * 8 + 4 + ((k) ? 1 : 0)] = __builtin_amdgcn_s_memrealtime(); \
+                                                           if ((k) == 0) q.stamps[(size_t)blockIdx.x * 8 + 6] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 32); \
+                                                           if ((k) == 2) q.stamps[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define STAMP(k) do { } while (0)
 #endif

@@ -1274,12 +1274,28 @@ class BackboneRun:
                       Kb=g(cu, "t2t_proj.1"), Vb=g(cu, "t2t_proj.2"), ldkb=ldu, La=S, Lb=0 if mode == "cross" else Lt)
         return vq, uq
 
+    def _attn_calls(self):
+        """(Lq, La, Lb) of every attention call a pass of this backbone makes (video queries of every live layer; user queries
+        of the full layers) -- what ``attn_fwd_pl_takes`` / the planes-in backward of ``capi.hip`` are asked with."""
+        S, Lt, mode = self.S, self.Lt, self.mode
+        calls = [(S, 0 if mode == "cross" else S, 0 if mode == "self" else Lt)]
+        if self.N >= 3 and mode != "self":          # layers 0 .. N-3 are full: the user tokens query too
+            calls.append((Lt, S, 0 if mode == "cross" else Lt))
+        return calls
+
     def _attn_planes_in(self):
         """Do the attention kernels of this pass read the Q / K / V planes of the fused projection GEMMs (csrc/attention_pl.h)?
-        Training passes with delayed scales on the plane engine, shapes both planes-in kernels take (SEGMM_ATT_PL=0: never)."""
+        Training passes with delayed scales on the plane engine, and ONLY when every attention call of the pass is one the planes-in
+        forward takes -- the gate of ``attn_fwd_pl_takes`` (capi.hip) restated per call: Lq <= 112 (7 query tiles), La + Lb <= 192
+        (12 key tiles), lengths % 4, knob ATT_FWD_PL.  A layer whose projection outputs exist as planes ONLY cannot fall back to the
+        fp32-operand kernels, so a single refused call keeps the fp32 buffers for the whole pass (SEGMM_ATT_PL=0: never)."""
         st = self.store
-        return bool(self.delayed and st.engine_p and st.attn_pl and st.attn_fused and self.dh % 16 == 0 and self.dh <= 48 and
-                    self.S % 4 == 0 and self.Lt % 4 == 0 and max(self.S, self.Lt) <= 112 and self.d % 32 == 0 and _FEW_TILES == 0)
+        if not (self.delayed and st.engine_p and st.attn_pl and st.attn_fused and self.dh % 16 == 0 and self.dh <= 48 and
+                self.d % 32 == 0 and _FEW_TILES == 0):
+            return False
+        if H.knob("ATT_FWD_PL") == 0:
+            return False
+        return all(Lq <= 112 and La + Lb <= 192 and La % 4 == 0 and Lb % 4 == 0 for (Lq, La, Lb) in self._attn_calls())
 
     def _proj_act(self, i, which, rows, cols):
         """The fused projection output Yv / Yu of layer i as an Act.  With the planes-in attention and a calibrated site its producer

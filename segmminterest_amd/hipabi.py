@@ -630,10 +630,21 @@ def step_get():
 
 def config_set(name, value):
     """``segmm_config_set``: set the tuning knob ``name`` (without the SEGMM_ prefix; see :func:`config_dump`); returns the previous value."""
+    _KNOBS.clear()
     r = int(lib().segmm_config_set(name.encode(), int(value)))
     if r < 0 and name not in config_dump():
         _check(r, "segmm_config_set")
     return r
+
+
+_KNOBS = {}
+
+
+def knob(name):
+    """Current value of one tuning knob (cached; ``config_set`` drops the cache)."""
+    if not _KNOBS:
+        _KNOBS.update({k: v[0] for k, v in config_dump().items()})
+    return _KNOBS[name]
 
 
 def config_dump():

@@ -232,6 +232,20 @@ def main_eval_batch(args, interests, ground_truths, pred_labels, results_list, t
             evaluations = TOP_K_leave(x, view_lengths, mb, permutation=args.TOP_K_permutation)
         for k, v in evaluations.items():
             results_list.setdefault(k, []).append(float(v))
+    if logits is not None:
+        # my_evaluation.py:307-318: the leave position predicted from the raw logits -- p_leave = normalised 1 / softmax(logits),
+        # expected position sum(p_leave * [0 .. S-1]) truncated to int -- against the view lengths: 'MAES' is a RUNNING SUM of
+        # batch MAE * batch size, 'pred_leave' collects the int predictions.  (The reference's `print` of the sum is not reproduced;
+        # its literal 40 positions is the segment axis S of the logits.)
+        lg = logits.detach().float()
+        inv_sm = 1.0 / torch.softmax(lg, dim=1)
+        leave_p = inv_sm / inv_sm.sum(dim=1, keepdim=True)
+        pos = torch.arange(lg.shape[1], dtype=torch.float32, device=lg.device)
+        pred_leave = torch.sum(leave_p * pos, dim=1).int().cpu()
+        view_len = (ground_truths == 1).sum(dim=1).cpu()
+        mae = float((view_len.to(torch.float64) - pred_leave.to(torch.float64)).abs().mean())
+        results_list["MAES"] += mae * int(interests.shape[0])
+        results_list["pred_leave"].append(pred_leave)
     per_row = [k for k in results_list if k in ("JaccardSim", "LeaveMSE", "LeaveCTR", "LeaveCTR_view")]
     if per_row:
         it, sp, gt_, mk = interests.cpu(), survival_probs.cpu(), ground_truths.cpu(), mask_batch.cpu()

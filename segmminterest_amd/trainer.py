@@ -814,7 +814,7 @@ class Trainer:
         return out
 
     # ---- the step as recorded launch sequences replayed from C (include/segmm_hip.h "Recorded launch sequences")
-    def record(self, batch: Dict[str, torch.Tensor], warmup: int = 3):
+    def record(self, batch: Dict[str, torch.Tensor], warmup: int = 3, prev_batch: Optional[Dict[str, torch.Tensor]] = None):
         """Record the launch sequence of one training step on ``batch``'s shapes: ``warmup`` eager steps (site scales calibrated,
         every persistent buffer allocated, both streams created), then ONE more eager step during which every C-ABI call is
         recorded -- entry point, arguments, stream slot, fork / join points of the two streams -- split into the phases of the
@@ -823,7 +823,10 @@ class Trainer:
         (``device_state``): the recorded arguments are valid for every later step, except the batch's own tensors, whose
         addresses are patched per step.  ``run_recorded(batch)`` then enqueues a step with one C call per phase
         (segmm_step_begin, segmm_embed_fwd, segmm_layer_fwd, ...): the eager two-stream schedule without the per-launch host
-        work.  Results are bit-identical to ``train_step`` in the same mode."""
+        work.  Results are bit-identical to ``train_step`` in the same mode.
+        ``prev_batch``: the batch of the ``train_step`` that ran immediately before (same shapes, other tensors).  With it NO
+        warm-up step runs -- the caller has already stepped (the sites are calibrated) -- so the only optimisation step ``record``
+        takes is the recorded one, on ``batch``: what an epoch loop needs (:func:`fit` with ``recorded=True``)."""
         if not self.device_state:
             raise RuntimeError("record() needs Trainer(device_state=True): the per-step state must live on the device")
         model, st = self.model, self.model._store
@@ -843,10 +846,18 @@ class Trainer:
         # the step may name tensors of the PREVIOUS step's batch (id mode: the rows the last backward scattered into the table
         # gradient are cleared by id list): the last warm-up step runs on a copy of the batch, so that such pointers can be told
         # from the current batch's and re-based to the previous batch at replay
-        prev = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
-        for _ in range(max(warmup - 1, 0)):
-            self.train_step(batch)
-        self.train_step(prev)
+        if prev_batch is not None:
+            for k, v in batch.items():
+                if torch.is_tensor(v):
+                    pv = prev_batch.get(k)
+                    if not torch.is_tensor(pv) or pv.shape != v.shape or pv.dtype != v.dtype or (v.numel() and pv.data_ptr() == v.data_ptr()):
+                        raise RuntimeError("record(prev_batch=...): prev_batch[%r] must be another tensor of the same shape and dtype" % k)
+            prev = prev_batch
+        else:
+            prev = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+            for _ in range(max(warmup - 1, 0)):
+                self.train_step(batch)
+            self.train_step(prev)
         torch.cuda.synchronize()
         main = H._stream()
         side = st.side_stream().cuda_stream
@@ -953,6 +964,69 @@ class Trainer:
             pos = e
         return pos == st.n_live
 
+    @torch.no_grad()
+    def test_model(self, test_batches, eval_type_list, ckpt: Optional["CheckPointer"] = None, threshold: float = 0.5, top_k_mask: int = 0,
+                   top_k_permutation: int = 1, save_logits: bool = False, train_videos: Optional[set] = None, draw_case: int = 0):
+        """The test phase of the reference trainer (main_for_seq_leave_earlystop_SegMM.py:365-459): reload the BEST checkpoint
+        (``ckpt.load_checkpoint(model, optimizer, mode='best')``, :366-367), eval mode, ``mode="inference"`` over the test split,
+        interests = sigmoid(logits) * exposure_prob (:402-403), pred_label = interests > threshold (:404), every batch through
+        ``main_eval_batch`` (:415), then ``compute_final_result`` (:434).  ``train_videos`` (the reference's ``--eval_cold``
+        set of photo ids seen in training, :417-427): also the cold / hot splits.  ``save_logits`` (:412-414): the
+        [interests | gt | user_id | photo_id] rows.  Returns a dict {"final", "results_list"[, "cold_final", "hot_final",
+        "cold_count_inter", "hot_count_inter"][, "saved_logits"]}."""
+        import argparse
+        from .my_evaluation import main_eval_batch
+        model = self.model
+        if ckpt is not None:
+            load_dict = ckpt.load_checkpoint(model, self.opt, mode="best")
+            model.load_state_dict(load_dict["model"])
+        model.eval()
+        margs = argparse.Namespace(TOP_K_mask=top_k_mask, TOP_K_permutation=top_k_permutation, draw_case=draw_case)
+
+        def fresh():
+            r = {}
+            for eval_type in eval_type_list:
+                r[eval_type] = []
+                r["view_lengths"] = []
+            return r
+
+        results_list = fresh()
+        cold = train_videos is not None
+        cold_results, hot_results, cold_n, hot_n = (fresh(), fresh(), 0, 0) if cold else (None, None, 0, 0)
+        saved = []
+        exposure = None
+        for batch in test_batches:
+            out = self.eval_step(batch, mode="inference")
+            logits = out["logits"]
+            if exposure is None:
+                exposure = torch.tensor(model.exposure_prob, dtype=torch.float32, device=logits.device)[: logits.shape[1]]
+            interests = torch.sigmoid(logits) * exposure
+            pred_label = torch.where(interests > threshold, 1.0, 0.0)
+            gt = out["gt"]
+            if save_logits:
+                saved.append(torch.cat((interests.cpu(), gt.cpu().to(torch.float32), batch["user_id"].reshape(-1, 1).cpu().to(torch.float32),
+                                        batch["photo_id"].reshape(-1, 1).cpu().to(torch.float32)), dim=1))
+            results_list = main_eval_batch(margs, interests, gt, pred_label, results_list, type="inference")
+            if cold:
+                pids = batch["photo_id"].reshape(-1).cpu().tolist()
+                ci = [i for i, p_ in enumerate(pids) if p_ not in train_videos]
+                hi = [i for i, p_ in enumerate(pids) if p_ in train_videos]
+                cold_n += len(ci)
+                hot_n += len(hi)
+                if ci:          # (the reference indexes with an empty tensor and lets main_eval_batch see 0 rows; nothing is appended then)
+                    ix = torch.tensor(ci, device=interests.device)
+                    cold_results = main_eval_batch(margs, interests[ix], gt[ix], pred_label[ix], cold_results, type="inference")
+                if hi:
+                    ix = torch.tensor(hi, device=interests.device)
+                    hot_results = main_eval_batch(margs, interests[ix], gt[ix], pred_label[ix], hot_results, type="inference")
+        res = {"final": compute_final_result(results_list), "results_list": results_list}
+        if cold:
+            res.update(cold_final=compute_final_result(cold_results), hot_final=compute_final_result(hot_results),
+                       cold_count_inter=cold_n, hot_count_inter=hot_n)
+        if save_logits:
+            res["saved_logits"] = torch.cat(saved, dim=0) if saved else torch.empty((0, 0))
+        return res
+
     def fit(self, train_batches, valid_batches, epochs, **kw):
         """The reference's train / validate / checkpoint / early-stop loop (module-level :func:`fit`)."""
         return fit(self, train_batches, valid_batches, epochs, **kw)
@@ -1012,15 +1086,36 @@ def early_stop_reached(metric_history: List[float], early_stop: int) -> bool:
     return len(m) - m.index(max(m)) > early_stop
 
 
+def compute_final_result(results_list):
+    """``compute_final_result`` of the reference trainer (main_for_seq_leave_earlystop_SegMM.py:188-210): LeaveMSE = mean squared
+    error of the predicted against the true view lengths, every other list its mean; 'TOP_K' and 'view_lengths' carry no number."""
+    final = {}
+    if "LeaveMSE" in results_list:
+        vl, pv = results_list["view_lengths"], results_list["LeaveMSE"]
+        final["LeaveMSE"] = float(sum((float(a) - float(b)) ** 2 for a, b in zip(vl, pv)) / len(vl)) if vl else float("nan")
+    for eval_type, vals in results_list.items():
+        if eval_type in ("TOP_K", "LeaveMSE", "view_lengths"):
+            continue
+        if not isinstance(vals, list) or not vals:
+            continue
+        final[eval_type] = sum(vals) / len(vals)
+    return final
+
+
 def fit(trainer: "Trainer", train_batches, valid_batches, epochs: int, valid_step: int = 30, early_stop: int = 0,
         main_metric: str = "NDCG@5", ckpt: Optional["CheckPointer"] = None, logging_step: int = 0, log=None,
-        permutation: int = 1, top_k_mask: bool = False, metrics=None):
+        permutation: int = 1, top_k_mask: bool = False, metrics=None, recorded: bool = False, eager_steps: int = 3):
     """The train / validate / checkpoint / early-stop loop of the reference trainer around ``Trainer.train_step``
     (main_for_seq_leave_earlystop_SegMM.py:247-354): one validation over ``valid_batches`` BEFORE training, then per epoch every
     ``valid_step`` local steps a validation whose ``main_metric`` (mean over the validation batches, :179-181) drives
     ``ckpt.save_checkpoint(..., metric_vals={"main_metric": ...})`` (:333) and the early-stop tests (:336-352).
     ``train_batches``: a list of batch dicts, or a callable ``epoch -> iterable of batch dicts`` (an epoch of the DataLoader).
     The loss is read on the host only where the reference's bookkeeping needs a number (validation points, logging steps).
+    ``recorded=True`` (needs ``Trainer(device_state=True)``; single process or data parallel): the first ``eager_steps`` steps run
+    launch by launch (they calibrate the delayed scales), the next step is RECORDED while it runs (``Trainer.record`` with the
+    previous batch: no extra optimisation step), every later batch of the same shapes is enqueued from the recorded launch
+    sequences (``run_recorded``: one C call per phase, bit-identical to the eager step); a batch of another shape (the short last
+    batch of an epoch) takes the eager step.  Every batch is still stepped on exactly once, in order.
     Returns the history dict the reference calls ``total_valid_loss_metrics`` (+ "stopped_epoch", "global_step")."""
     metrics = list(metrics) if metrics is not None else ["valid_loss", "HR@1", "HR@3", "HR@5", "HR@10", "NDCG@1", "NDCG@3", "NDCG@5", "NDCG@10"]
     hist: Dict[str, list] = {"train_loss": [0.0]}
@@ -1033,16 +1128,38 @@ def fit(trainer: "Trainer", train_batches, valid_batches, epochs: int, valid_ste
             hist[k].append(vm[k])
         return vm
 
+    if recorded and not trainer.device_state:
+        raise RuntimeError("fit(recorded=True) needs Trainer(device_state=True)")
+
+    def shapes_of(b):
+        return {k: (tuple(v.shape), v.dtype) for k, v in b.items() if torch.is_tensor(v) and v.numel()}
+
+    def step(batch, prev, n_done):
+        """One optimisation step on ``batch``: eager, recording, or from the recording."""
+        if not recorded:
+            return trainer.train_step(batch)
+        r = trainer.__dict__.get("_recorded")
+        if r is not None:
+            if shapes_of(batch) == r["spans"] and all(v.is_contiguous() for v in batch.values() if torch.is_tensor(v)):
+                return trainer.run_recorded(batch)
+            return trainer.train_step(batch)
+        if n_done >= eager_steps and prev is not None and shapes_of(prev) == shapes_of(batch):
+            return trainer.record(batch, prev_batch=prev)
+        return trainer.train_step(batch)
+
     validate()                                           # "Evaluation Before Training" (:247-249)
     global_step, stop, stopped_epoch = 0, False, None
+    prev_batch = None
     for epoch in range(epochs):
         if stop:
             break
         it = train_batches(epoch) if callable(train_batches) else train_batches
         epoch_losses = []
         for local_step, batch in enumerate(it):
-            out = trainer.train_step(batch)
-            epoch_losses.append(out["loss"].detach())
+            out = step(batch, prev_batch, global_step)
+            prev_batch = batch
+            # (a recorded step returns the SAME loss tensor every step: keep a copy where the epoch mean is going to be logged)
+            epoch_losses.append(out["loss"].detach().clone() if (recorded and log is not None) else out["loss"].detach())
             global_step += 1
             if logging_step and (local_step + 1) % logging_step == 0 and log is not None:
                 log("Train_loss: %f, Global_step: %d" % (float(epoch_losses[-1]), global_step))

@@ -156,3 +156,25 @@ def test_config_table_is_listed_and_settable():
     H.config_set("ATT_WAVES", prev)
     with pytest.raises(RuntimeError):
         H.config_set("NO_SUCH_KNOB", 1)
+
+
+def test_main_eval_batch_logits_branch_matches_reference_kat():
+    """main_eval_batch(..., logits=) (my_evaluation.py:307-318): 'MAES' running sum and the int leave positions equal the values
+    the reference produced for the same inputs (tests/golden/metrics_kat.npz, oracle/gen_golden.py gen_metrics), host tensors."""
+    import argparse
+    import numpy as np
+    from helpers import GOLDEN
+    from segmminterest_amd import main_eval_batch
+    z = np.load(os.path.join(GOLDEN, "metrics_kat.npz"))
+    rows = z["meb_rows"]
+    it, gt = torch.from_numpy(z["interests"][rows]), torch.from_numpy(z["gt"][rows])
+    lg = torch.from_numpy(z["meb_logits"])
+    args = argparse.Namespace(TOP_K_mask=0, TOP_K_permutation=0, draw_case=0)
+    res = {"MAES": 0.0, "pred_leave": []}
+    res = main_eval_batch(args, it, gt, (it > 0.5).float(), res, type="inference", logits=lg)
+    res = main_eval_batch(args, it[:7], gt[:7], (it[:7] > 0.5).float(), res, type="inference", logits=lg[:7] * 0.25)
+    assert abs(float(res["MAES"]) - float(z["meb_maes"])) < 1e-9
+    assert np.array_equal(torch.cat(res["pred_leave"]).numpy().astype(np.int64), z["meb_pred_leave"])
+    # without logits nothing of the branch is touched
+    res2 = main_eval_batch(args, it, gt, (it > 0.5).float(), {"MAES": 0.0, "pred_leave": []}, type="inference")
+    assert res2["MAES"] == 0.0 and res2["pred_leave"] == []

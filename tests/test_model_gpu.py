@@ -847,3 +847,97 @@ def test_fit_loop_validates_checkpoints_and_stops_early(tmp_path):
     tr0 = Trainer(model, lr=0.0, weight_decay=0.0, dropout=False)
     hist0 = tr0.fit(train, valid, epochs=5, valid_step=1, early_stop=2, main_metric="NDCG@5", permutation=0)
     assert hist0["stopped_epoch"] == 0 and len(hist0["NDCG@5"]) == 3 and len(set(hist0["NDCG@5"])) == 1
+
+
+@pytest.mark.parametrize("S,Lt", [(80, 100), (100, 100)])
+def test_long_token_axes_train_steps_keep_the_fp32_projection_buffers(S, Lt):
+    """Long token axes.  The engine's planes-only switch for the projection outputs now restates the C gate of the
+    planes-in attention forward per call (La + Lb <= 192, Lq <= 112).  (80, 100): 180 keys, the longest joint axis the attention
+    kernels are built for (192 PADDED keys) -- four AdamW steps through the calibration of the sites, the loss of every step
+    against the CPU oracle's own train loop (dropout 0).  (100, 100): 224 padded keys -- refused by the attention kernels
+    themselves on the FIRST step with a message that says so (never a silent change of path at step 2)."""
+    import segmm_oracle as O
+    from segmminterest_amd.synth import make_batch, l1_normalize
+    from segmminterest_amd.trainer import Trainer
+    B, D, N, h = 6, 64, 3, 4
+    cfg = dict(N=N, h=h, S=S, d=D, D_in=D, Lt=Lt, user="image", photo="image", loss_type_list=["interestBPR"],
+               loss_weight={"interestBPR": 1.0, "mse": 1.0}, exposure_prob=[1.0] * S)
+    torch.manual_seed(5)
+    model = build_model(cfg)
+    for m in model.modules():          # train mode (delayed scales, planes from the producers) without the dropout draws
+        for a in ("dropout_p", "inner_dropout"):
+            if isinstance(getattr(m, a, None), float):
+                setattr(m, a, 0.0)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    b = make_batch(B, S, Lt, D, seed=9)
+    inp = dict(usr_image=l1_normalize(b["user"]), usr_id=b["user_identity_id"], usr_mask=b["user_mask"],
+               vid_image=l1_normalize(b["photo"]), vid_id=b["photo_identity_id"], vid_mask=b["photo_mask"], gt=b["label"])
+    ref_losses = O.train_steps(sd, cfg, inp, 4, skip_dead=True)[1] if S + Lt <= 192 else None
+    model = model.cuda()
+    tr = Trainer(model)
+    batch = dict(user=inp["usr_image"].to(DEV), photo=inp["vid_image"].to(DEV), user_mask=inp["usr_mask"].to(DEV),
+                 photo_mask=inp["vid_mask"].to(DEV), label=inp["gt"].to(DEV), user_identity_id=inp["usr_id"].to(DEV),
+                 photo_identity_id=inp["vid_id"].to(DEV))
+    tr.normalize = lambda key, x, *a, **k: x             # already L1-normalised
+    if S + Lt > 192:
+        with pytest.raises(RuntimeError, match="not built"):
+            tr.train_step(batch)
+        return
+    got = [float(tr.train_step(batch)["loss"]) for _ in range(4)]
+    assert model.training
+    for s, (a, r) in enumerate(zip(got, ref_losses)):
+        assert abs(a - r) <= 2e-4 * max(1.0, abs(r)), (s, got, ref_losses)
+
+
+def test_fit_recorded_equals_fit_eager_and_test_phase_reloads_the_best_checkpoint(tmp_path):
+    """fit(recorded=True): the epoch loop on the recorded launch sequences (3 eager steps, one recording step, replays; the short
+    last batch of an epoch eager) leaves the parameters, the validation history and the checkpoints of the eager loop -- every
+    batch stepped on once, in order.  Then the reference's test phase (main...SegMM.py:365-459): Trainer.test_model reloads the
+    best checkpoint and evaluates the test split; its numbers equal main_eval_batch + compute_final_result applied by hand."""
+    import argparse
+    from segmminterest_amd import main_eval_batch
+    from segmminterest_amd.synth import make_batch
+    from segmminterest_amd.trainer import CheckPointer, Trainer, compute_final_result
+    cfg, g, _, _, _ = _loaded("img_d32_N2")
+    mk = lambda s, b=16: {k: v.to(DEV) for k, v in make_batch(b, cfg["S"], cfg["Lt"], cfg["D_in"], seed=s).items()}
+    train = [mk(s) for s in range(7)] + [mk(50, 8)]          # the last batch of an epoch is short
+    valid, test = [mk(100), mk(101)], [mk(200), mk(201, 8)]
+    runs = {}
+    for mode in ("eager", "recorded"):
+        model = build_model(cfg)
+        model.load_state_dict(g["sd"])
+        model = model.cuda()
+        tr = Trainer(model, lr=1e-3, device_state=True, dropout=False)
+        ck = CheckPointer("main_metric", str(tmp_path / mode), mode="max")
+        hist = tr.fit(train, valid, epochs=2, valid_step=3, main_metric="NDCG@5", ckpt=ck, permutation=0, recorded=(mode == "recorded"))
+        if mode == "recorded":
+            assert tr.__dict__.get("_recorded") is not None
+        runs[mode] = (tr, ck, hist, {k: v.detach().clone() for k, v in model.state_dict().items()})
+    (tr_e, ck_e, h_e, sd_e), (tr_r, ck_r, h_r, sd_r) = runs["eager"], runs["recorded"]
+    assert h_e["global_step"] == h_r["global_step"] == 16
+    for k in ("valid_loss", "NDCG@5", "HR@1", "train_loss"):
+        assert h_e[k] == h_r[k], k
+    for k in sd_e:
+        assert torch.equal(sd_e[k], sd_r[k]), k
+    assert ck_e.best_metric == ck_r.best_metric
+    # ---- test phase
+    evals = ["JaccardSim", "ProbAUC", "LeaveMSE", "LeaveCTR", "TOP_K"]
+    res = tr_r.test_model(test, evals, ckpt=ck_r, top_k_permutation=0, save_logits=True, train_videos=set(int(x) for x in test[0]["photo_id"].reshape(-1).tolist()))
+    best = torch.load([str(p) for p in (tmp_path / "recorded").iterdir() if "best" in p.name][0], map_location="cpu", weights_only=False)
+    for k, v in tr_r.model.state_dict().items():
+        assert torch.equal(v.cpu(), best["model"][k]), k
+    margs = argparse.Namespace(TOP_K_mask=0, TOP_K_permutation=0, draw_case=0)
+    rl = {}
+    for e in evals:
+        rl[e] = []
+        rl["view_lengths"] = []
+    for b in test:
+        out = tr_r.eval_step(b, mode="inference")
+        interests = torch.sigmoid(out["logits"]) * torch.tensor(tr_r.model.exposure_prob, device=DEV)[: out["logits"].shape[1]]
+        rl = main_eval_batch(margs, interests, out["gt"], (interests > 0.5).float(), rl, type="inference")
+    want = compute_final_result(rl)
+    assert set(res["final"]) == set(want) and {"JaccardSim", "ProbAUC", "LeaveMSE", "LeaveCTR", "HR@1", "NDCG@10"} <= set(want)
+    for k in want:
+        assert res["final"][k] == want[k], k
+    assert res["saved_logits"].shape == (24, 2 * cfg["S"] + 2)
+    assert res["cold_count_inter"] + res["hot_count_inter"] == 24 and res["hot_count_inter"] >= 16
