@@ -33,6 +33,7 @@ Prints ONE JSON line (rank 0) with the driver contract fields plus
                   loop does); PCIe-inclusive, reported beside `value`, never as `value`.
 """
 import argparse
+import math
 import json
 import os
 import socket
@@ -99,6 +100,8 @@ def parse_args():
                     help="gloo: CPU-staged collectives, lets several ranks share one GPU (CI rehearsal of the N > 1 path)")
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the sustained leg (value_sustained: >= 2000 steps / >= 8 s in one window)")
+    ap.add_argument("--no-index-leg", action="store_true", help="skip the index-input leg (value_index_input: the product's input path)")
     ap.add_argument("--no-f32-engine", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=128)
     ap.add_argument("--cpu-steps", type=int, default=10)
@@ -237,6 +240,73 @@ def cpu_baseline(args, w, h):
             "sample": "median of %d timed steps (%d warm-up) of B=%d rows, same S/D/Lt/N, dropout 0.1, dead layers executed like the "
                       "reference, torch-CPU %d threads of %d host threads%s"
                       % (args.cpu_steps, args.cpu_warmup, Bc, cores, host, sweep or " (more threads ran slower on this box)")}
+
+
+def csrc_sha16():
+    """Hash of the kernel sources this tree builds the library from (what a committed PMC pass must have been measured on)."""
+    import hashlib
+    d = os.path.join(ROOT, "segmminterest_amd", "csrc")
+    hsh = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip", ".inc")):
+            with open(os.path.join(d, f), "rb") as fh:
+                hsh.update(f.encode() + b"\0" + fh.read())
+    return hsh.hexdigest()[:16]
+
+
+class SmiSampler:
+    """Clock / power of ONE GPU from sysfs (hwmon freq1_input, power1_average | power1_input), sampled by a thread while a leg runs."""
+
+    def __init__(self, torch_dev):
+        import glob
+        import threading
+        self.files, self.rows, self._stop, self._thr = None, [], threading.Event(), None
+        try:
+            import torch
+            pr = torch.cuda.get_device_properties(torch_dev)
+            addr = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+            hw = glob.glob("/sys/bus/pci/devices/%s/hwmon/hwmon*" % addr)
+        except Exception:
+            hw = []
+        if not hw:          # a box that shows one card: take it
+            hw = [h for h in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*") if os.path.exists(os.path.join(h, "freq1_input"))]
+            hw = hw if len(hw) == 1 else []
+        if hw:
+            f = os.path.join(hw[0], "freq1_input")
+            pw = [os.path.join(hw[0], n) for n in ("power1_average", "power1_input") if os.path.exists(os.path.join(hw[0], n))]
+            if os.path.exists(f):
+                self.files = (f, pw[0] if pw else None)
+
+    def _run(self):
+        while not self._stop.wait(0.25):
+            try:
+                mhz = int(open(self.files[0]).read()) / 1e6
+                w = int(open(self.files[1]).read()) / 1e6 if self.files[1] else None
+                self.rows.append((mhz, w))
+            except Exception:
+                pass
+
+    def __enter__(self):
+        if self.files:
+            import threading
+            self._thr = threading.Thread(target=self._run, daemon=True)
+            self._thr.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop.set()
+        if self._thr is not None:
+            self._thr.join()
+
+    def summary(self):
+        if not self.rows:
+            return None
+        mhz = [r[0] for r in self.rows]
+        w = [r[1] for r in self.rows if r[1] is not None]
+        out = {"samples": len(mhz), "sclk_MHz_mean": round(sum(mhz) / len(mhz), 1), "sclk_MHz_min": round(min(mhz), 1), "sclk_MHz_max": round(max(mhz), 1)}
+        if w:
+            out.update(power_W_mean=round(sum(w) / len(w), 1), power_W_max=round(max(w), 1))
+        return out
 
 
 def union_ms(intervals):
@@ -414,6 +484,26 @@ def main():
     elapsed = win[len(win) // 2]
     rows_per_s = world * B * args.steps / elapsed
 
+    # ---- sustained leg: the SAME step in ONE window of >= 2000 steps and >= 8 s (at most ~15 s), bracketed like the windows above,
+    # with the GPU's clock and power sampled from sysfs while it runs: what the part holds once it is warm and power-managed
+    sustained = None
+    if not args.no_sustained:
+        step_s = elapsed / args.steps
+        n_sus = int(min(max(2000, math.ceil(8.0 / step_s)), max(math.ceil(15.0 / step_s), 200)))
+        with SmiSampler(dev) as smi:
+            barrier()
+            ts0 = time.perf_counter()
+            run(trainer, n_sus, args.warmup + len(win) * args.steps)
+            barrier()
+            ts = time.perf_counter() - ts0
+        tt = torch.tensor([ts], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        ts = float(tt[0])
+        sustained = {"value": round(world * B * n_sus / ts, 2), "steps": n_sus, "seconds": round(ts, 3), "ms_per_step": round(1e3 * ts / n_sus, 4),
+                     "smi": smi.summary(), "note": "one window of `steps` steps after the timed windows, same step mode; smi = hwmon freq1_input / "
+                                                   "power1 of this GPU every 0.25 s during the window (null: sysfs not readable here)"}
+
     if inst is None:
         inst = instrumented(args.warmup + len(win) * args.steps)
     psteps, prof, aprof, kprof, prof_elapsed = inst
@@ -437,6 +527,7 @@ def main():
         rec = {
             "metric": "train interactions/sec (segment-Transformer, B=512·S=40·D=768)",
             "value": round(rows_per_s, 2), "value_min": round(world * B * args.steps / win[-1], 2), "value_max": round(world * B * args.steps / win[0], 2),
+            "value_sustained": sustained["value"] if sustained else None, "sustained": sustained,
             "windows": len(win), "unit": "interactions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "host_enqueue_ms_per_step": round(host_ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": dtype, "data": "synthetic",
@@ -509,9 +600,11 @@ def main():
             elif engine == "f16x3":
                 peak, kname = PEAK_BF16_MFMA_TFLOPS / 3.0, "gemm_split_mfma<F16> (3 x v_mfma_f32_32x32x16_f16 per product, operands split on the fly)"
             elif engine == "f16x3p":
-                peak, kname = PEAK_BF16_MFMA_TFLOPS / 3.0, ("gemm_pl_nt8 / gemm_pl_tn8 (3 x v_mfma_f32_16x16x32_f16 per product, scaled 2-term fp16 split = 22-bit "
-                                                            "operands PRE-SPLIT by their producers, LDS-DMA staging with counted waits, ping-pong wave groups, "
-                                                            "256 x 256 tiles; few-tile launches on gemm_split_mfma; incl. split-K combine)")
+                nt_k, tn_k = "gemm_pl_nt%d" % hipabi.knob("PL_VAR"), "gemm_pl_tn%d" % hipabi.knob("TN_VAR")
+                peak, kname = PEAK_BF16_MFMA_TFLOPS / 3.0, ("%s / %s (3 x v_mfma_f32_16x16x32_f16 per product, scaled 2-term fp16 split = 22-bit "
+                                                            "operands PRE-SPLIT by their producers, LDS-DMA staging with counted waits; round 6: 128 x 256 "
+                                                            "tiles, four waves, two workgroups resident per CU, software-pipelined wave stream; "
+                                                            "few-tile launches on gemm_split_mfma; incl. split-K combine)" % (nt_k, tn_k))
             else:
                 peak, kname = PEAK_F32_MFMA_TFLOPS, "gemm_f32_mfma (v_mfma_f32_32x32x2_f32)"
             alg_bytes = sum(4.0 * (M * K + Nn * K + M * Nn) for (_, M, Nn, K, _, _) in prof) / max(len(prof), 1)
@@ -522,8 +615,13 @@ def main():
                     tj = json.load(f)
                 # only a pass over THIS engine's kernels on THIS workload's launch shapes counts (the committed pass is config 2)
                 if tj.get("engine") == engine and args.config == 2 and not (args.batch or args.dim or args.layers or args.segments or args.global_batch):
-                    traffic = round(tj["hbm_bytes_per_launch"])
-                    traffic_note = "; traffic = mean HBM-side bytes per GEMM launch from profiles/hbm_traffic.json (git %s; %s)" % (tj.get("git", "?"), tj["method"])
+                    # ... and only a pass over THESE kernels: the file carries the hash of csrc/ it was measured on (tools/traffic_pass.sh)
+                    if tj.get("csrc_sha16") == csrc_sha16():
+                        traffic = round(tj["hbm_bytes_per_launch"])
+                        traffic_note = "; traffic = mean HBM-side bytes per GEMM launch from profiles/hbm_traffic.json (kernel sources %s; %s)" % (tj["csrc_sha16"], tj["method"])
+                    else:
+                        traffic_note = ("; traffic = null: profiles/hbm_traffic.json was measured on other kernel sources (csrc hash %s, this tree %s) -- "
+                                        "re-run tools/traffic_pass.sh" % (tj.get("csrc_sha16", tj.get("git", "?")), csrc_sha16()))
             # weight-gradient GEMMs enqueued beside the attention backward share the chip with it: that part of the GEMM-busy time
             shared_ms = overlap_ms([(base.elapsed_time(e0), base.elapsed_time(e1)) for (_, _, _, _, e0, e1) in prof],
                                    [(base.elapsed_time(e0), base.elapsed_time(e1)) for (*_, e0, e1) in aprof]) if aprof else 0.0
@@ -532,7 +630,7 @@ def main():
                                "launches": len(prof), "profiled_steps": psteps, "gemm_busy_ms_per_step": round(gemm_ms / psteps, 4),
                                "gemm_busy_shared_with_attention_ms_per_step": round(shared_ms / psteps, 4),
                                "ms_per_step_with_events": round(1e3 * prof_elapsed / psteps, 4),
-                               "note": "achieved = algorithmic 2MNK of every GEMM launch of the instrumented pass (the same steps enqueued launch by launch with "
+                               "note": "achieved / frac = the dominant kernel family's algorithmic 2MNK / the SUM of its launches' own HIP-event durations (per_kernel[0]); achieved_union = algorithmic 2MNK of every GEMM launch of the instrumented pass (the same steps enqueued launch by launch with "
                                        "an event pair per GEMM, outside the timed region) / union of their HIP-event intervals (weight-gradient GEMMs overlap input-gradient GEMMs on a "
                                        "second stream, and -- round 4, segment axes > 32 -- the attention backward: gemm_busy_shared_with_attention_ms_per_step of the union is "
                                        "time in which attention launches hold part of the CUs, so the same kernels read a LOWER rate here than in rounds 1-3 while the step got faster); "
@@ -543,7 +641,10 @@ def main():
             # --stats average duration gives) -- comparable from round to round whatever the two-stream schedule does to the union
             fam = {}
             for (lay, M, Nn, K, e0, e1) in prof:
-                name = ("gemm_pl_" if lay >= 10 else "gemm_split_mfma/") + ("nt", "nn", "tn")[lay % 10] + ("8 (+ splitk_reduce share excluded)" if lay == 12 else "8" if lay >= 10 else "")
+                if lay >= 10:
+                    name = "gemm_pl_" + ("nt", "nn", "tn")[lay % 10] + str(hipabi.knob("TN_VAR" if lay == 12 else "PL_VAR")) + (" (+ splitk_reduce share excluded)" if lay == 12 else "")
+                else:
+                    name = "gemm_split_mfma/" + ("nt", "nn", "tn")[lay % 10]
                 a = fam.setdefault(name, [0, 0.0, 0.0])
                 a[0] += 1
                 a[1] += 2.0 * M * Nn * K
@@ -553,6 +654,12 @@ def main():
                  "avg_us": round(1e3 * v[2] / v[0], 1), "ms_per_step": round(v[2] / psteps, 4),
                  "TFLOP/s": round(v[1] / (v[2] * 1e-3) / 1e12, 1), "frac": round(v[1] / (v[2] * 1e-3) / 1e12 / peak, 4)}
                 for k, v in sorted(fam.items(), key=lambda kv: -kv[1][2])]
+            # `achieved` / `frac` of the line = the DOMINANT kernel's own figure (the family with the most kernel time per step:
+            # its algorithmic FLOPs / the sum of its launches' own durations); the union-of-intervals view of ALL GEMM launches,
+            # which counts time shared between the two streams once, stays beside it as achieved_union / frac_union
+            dom = rec["roofline"]["per_kernel"][0]
+            rec["roofline"].update(achieved_union=rec["roofline"]["achieved"], frac_union=rec["roofline"]["frac"], dominant_kernel=dom["kernel"],
+                                   achieved=dom["TFLOP/s"], frac=dom["frac"], avg_launch_us=dom["avg_us"])
             if aprof:
                 afam = {}
                 for (kind_, B_, H_, dh_, Lq_, La_, Lb_, e0, e1) in aprof:
@@ -591,15 +698,23 @@ def main():
             abase = aprof[0][7]
             att_ms = union_ms((abase.elapsed_time(e0), abase.elapsed_time(e1)) for (*_, e0, e1) in aprof)
             att_tf = att_flops / (att_ms * 1e-3) / 1e12 if att_ms > 0 else 0.0
-            apeak = hipabi.attn_peak_tflops()
+            # priced against the instruction the measured kernels ISSUE: the planes-in kernels (ATTN_PIN_CALLS) form every product from
+            # three fp16 MFMAs -- the fp16x3 bound of the GEMMs, dense fp16 peak / 3; the fp32-operand kernels the exact-fp32 MFMA.  The
+            # exact-fp32 peak (what BASELINE.json's north_star prices the attention against) stays as a labelled comparison
+            pin = bool(hipabi.ATTN_PIN_CALLS)
+            apeak = PEAK_BF16_MFMA_TFLOPS / 3.0 if pin else hipabi.attn_peak_tflops()
             att_shared = overlap_ms([(abase.elapsed_time(e0), abase.elapsed_time(e1)) for (*_, e0, e1) in aprof],
                                     [(abase.elapsed_time(e0), abase.elapsed_time(e1)) for (_, _, _, _, e0, e1) in prof]) if prof else 0.0
             rec["roofline_attention"] = {"bound": "mfma", "kernel": hipabi.attn_kernel_name(), "achieved": round(att_tf, 2), "peak": round(apeak, 1),
                                          "unit": "TFLOP/s", "frac": round(att_tf / apeak, 4), "ms_per_step": round(att_ms / psteps, 4),
                                          "ms_per_step_shared_with_gemms": round(att_shared / psteps, 4),
+                                         "north_star_frac_of_f32_mfma_peak": round(att_tf / hipabi.attn_peak_tflops(), 4),
                                          "note": "unpadded algorithmic FLOPs (4 dh Lq T forward + 10 dh Lq T backward per (b, head)) / union of the "
-                                                 "attention launches' HIP-event intervals; peak = the exact-fp32 MFMA's (the backward's fp16x3 "
-                                                 "products have a 5x higher bound). A head is 69 KB of operands for 5 MFLOP: NEITHER matrix-core "
+                                                 "attention launches' HIP-event intervals; peak = " +
+                                                 ("the fp16x3 bound (dense fp16 MFMA peak / 3 products; the kernels issue v_mfma_f32_16x16x16_f16, whose "
+                                                  "own rate is half the x32 form's: 417 TF per product)" if pin else "the exact-fp32 MFMA's") +
+                                                 "; north_star_frac_of_f32_mfma_peak = the same rate against the exact-fp32 MFMA peak (157.3 TF), the figure "
+                                                 "BASELINE.json's 60 % target is worded in. A head is 69 KB of operands for 5 MFLOP: NEITHER matrix-core "
                                                  "bound is the binding one for these kernels -- `hbm` below is the tighter bound, and the kernels "
                                                  "sit at a third of it because they are latency-bound chains at 3-4 waves per SIMD (DESIGN.md §9)"}
             # the same launches against HBM: a head is 69 KB of operands for 5 MFLOP, so the tensors' one-pass bytes bound the kernels too
@@ -682,6 +797,59 @@ def main():
                                "h2d_bytes_per_step": nbytes, "h2d_GBs": round(nbytes * hsteps / th / 1e9, 1),
                                "note": "same step with the two feature tensors copied from pinned host memory every step (copy stream one "
                                        "batch ahead); PCIe-inclusive, NOT `value` -- the product path keeps features resident (--input index)"}
+
+    # ---- the same step fed by INDEX batches from a device-resident feature table (N = 1): the product's input path (SURVEY §8 f-1:
+    # gather + pad + mask + L1 normalisation in one kernel, feature_store.py) -- nothing crosses PCIe per step but the indices
+    if world == 1 and not args.no_index_leg and not w["id_mode"] and args.input == "features":
+        from segmminterest_amd.feature_store import ResidentFeatureTable
+        gi = torch.Generator(device="cpu").manual_seed(99)
+        table = ResidentFeatureTable(torch.rand((200000, Din), generator=gi).to(dev))
+        torch.manual_seed(1234)
+        m_ix = init_model(margs, n_users=args.n_users, n_items=args.n_items, input_dim=Din, max_vid_len=S, max_usr_len=Lt).to(dev)
+        t_ix = Trainer(m_ix, lr=1e-3, weight_decay=1e-4, comm=DPComm(), overlap=not args.no_overlap, feature_table=table,
+                       device_state=args.device_state or args.recorded)
+        ib = []
+        for i in range(max(args.batches, 1)):
+            b = make_batch(B, S, Lt, Din, n_users=args.n_users, n_items=args.n_items, seed=1234 + 1000 * i, features=False)
+            g2 = torch.Generator().manual_seed(4321 + 1000 * i)
+            pidx = torch.randint(0, 200000, (B, S), generator=g2)
+            pidx[~b["photo_mask"]] = -1
+            uidx = torch.randint(0, 200000, (B, Lt), generator=g2)
+            uidx[~b["user_mask"]] = -1
+            b["photo_idx"], b["user_idx"] = pidx, uidx
+            ib.append({k: v.to(dev) for k, v in b.items()})
+
+        def run_ix(n, start=0):
+            for i in range(n):
+                bb = ib[(start + i) % len(ib)]
+                if t_ix.__dict__.get("_recorded") is not None:
+                    t_ix.run_recorded(bb)
+                else:
+                    t_ix.train_step(bb)
+
+        run_ix(3)
+        if args.recorded:
+            try:
+                t_ix.record(ib[0], warmup=2)
+            except RuntimeError as e:
+                sys.stderr.write("bench.py: index leg: record() refused (%s); per-launch step\n" % e)
+        run_ix(args.warmup)
+        wins = []
+        for wi in range(3):
+            barrier()
+            ti0 = time.perf_counter()
+            run_ix(args.steps, wi * args.steps)
+            barrier()
+            wins.append(time.perf_counter() - ti0)
+        ti = sorted(wins)[1]
+        if rec is not None:
+            rec["value_index_input"] = round(B * args.steps / ti, 2)
+            rec["index_input"] = {"value": round(B * args.steps / ti, 2), "unit": "interactions/s", "ms_per_step": round(1e3 * ti / args.steps, 4), "windows": 3,
+                                  "note": "the same model and step mode with batches of row INDICES into a device-resident feature table of "
+                                          "200 000 rows (feature_store.ResidentFeatureTable; segmm_gather_l1 gathers, pads, masks and "
+                                          "L1-normalises in one launch): the product's input path, median of 3 windows of `steps` steps"}
+        del t_ix, m_ix, table, ib
+        torch.cuda.empty_cache()
 
     # ---- the same step on the exact-fp32 MFMA engine, same run (N = 1): the strict-fp32 number next to the headline
     if world == 1 and not args.no_f32_engine and not w["id_mode"] and engine != "f32":

@@ -286,9 +286,17 @@ int segmm_embed_id_bwd(const float* dpre, int tokens_per_row, int ld, int col0, 
 /* order[k] = index of the k-th smallest id, equal ids in index order (torch.argsort(ids, stable=True), which
  * segmm_embed_id_bwd needs as `order`); n <= 8192, one workgroup, no host sync. */
 int segmm_argsort_ids(const int64_t* ids, int n, int32_t* order, segmm_stream_t stream);
+/* The same for any n <= 2^24: beyond 8192 ids the bitonic network runs over `keys_ws` (caller-owned, next power of two >= n
+ * 64-bit words), chunks of 8192 keys per workgroup in LDS, larger strides as global compare-exchange launches (round 6: the
+ * gathered id list of a data-parallel node outgrows one workgroup from 8 ranks x 2048 rows on). */
+int segmm_argsort_ids_ws(const int64_t* ids, int n, int32_t* order, uint64_t* keys_ws, segmm_stream_t stream);
 /* table[ids[k], :] = 0 for k < n (ids outside [0, n_rows) are skipped): the rows a previous segmm_embed_id_bwd scattered into a
  * dense [n_rows, width] table gradient, cleared without re-filling the table. */
 int segmm_zero_rows(float* table, int width, const int64_t* ids, int n, int64_t n_rows, segmm_stream_t stream);
+/* Data parallel: the all-gathered label statistics of G ranks -- G records [v (B) | v2 (B) | norms (3)] in rank order -- split into
+ * v_all / v2_all [G * B] (what segmm_loss_fwd_bwd takes as the global view lengths, decoder_leave_focal.py:163-221 on the GLOBAL
+ * batch) and the three normalisers summed over the ranks in rank order.  One launch; no torch kernel inside the DP step. */
+int segmm_label_stats_unpack(const float* gathered, int G, int B, float* v_all, float* v2_all, float* norms, segmm_stream_t stream);
 int segmm_pe_grad(const float* dpre, int ld, int B, int S, int d, float* dpe, int accumulate, segmm_stream_t stream);
 
 /* The loss scalars of compute_loss (decoder_leave_focal.py:490-572) from the per-row terms segmm_loss_fwd_bwd wrote:

@@ -503,7 +503,7 @@ __global__ void step_advance_kernel(StepState* st, float b1, float b2) {
 extern "C" {
 
 const char* segmm_last_error(void) { return g_segmm_err; }
-int segmm_abi_version(void) { return 27; }
+int segmm_abi_version(void) { return 28; }
 int segmm_attn_mode(int mode) { const int prev = attn_f16(); if (mode >= 0 && mode <= 2) g_knobs[K_ATTN].value = mode; return prev; }
 
 static PlaneOut plane_out(uint16_t* planes, int ld2, float* hdr, const float* scale_in) {
@@ -1287,6 +1287,37 @@ int segmm_argsort_ids(const int64_t* ids, int n, int32_t* order, segmm_stream_t 
     while (np2 < n) np2 <<= 1;
     hipLaunchKernelGGL(argsort_ids_kernel, dim3(1), dim3(np2 >= 2048 ? 1024 : (np2 >= 128 ? np2 / 2 : 64)), (size_t)np2 * 8, (hipStream_t)stream,
                        (const long long*)ids, n, np2, (int*)order);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int segmm_argsort_ids_ws(const int64_t* ids, int n, int32_t* order, uint64_t* keys_ws, segmm_stream_t stream) {
+    SEGMM_REQUIRE(ids && order && n >= 0 && n <= (1 << 24), "argsort_ids_ws: 0 <= n <= 2^24 (n=%d)", n);
+    if (n <= ARGSORT_MAX) return segmm_argsort_ids(ids, n, order, stream);
+    SEGMM_REQUIRE(keys_ws && (((uintptr_t)keys_ws) & 7u) == 0, "argsort_ids_ws: %d ids need a workspace of the next power of two x 8 bytes", n);
+    int np2 = 2 * ARGSORT_MAX;
+    while (np2 < n) np2 <<= 1;
+    hipStream_t s = (hipStream_t)stream;
+    static bool optin = false;          // 64 KB of dynamic LDS: at the default limit, the opt-in is harmless
+    if (!optin) { (void)hipFuncSetAttribute((const void*)argsort_chunk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ARGSORT_MAX * 8); optin = true; }
+    unsigned long long* keys = (unsigned long long*)keys_ws;
+    hipLaunchKernelGGL(argsort_keys_init_kernel, dim3(np2 / 256), dim3(256), 0, s, (const long long*)ids, n, np2, keys);
+    hipLaunchKernelGGL(argsort_chunk_kernel, dim3(np2 / ARGSORT_MAX), dim3(1024), (size_t)ARGSORT_MAX * 8, s, keys, 2);
+    for (int k = 2 * ARGSORT_MAX; k <= np2; k <<= 1) {
+        for (int j = k >> 1; j >= ARGSORT_MAX; j >>= 1)
+            hipLaunchKernelGGL(argsort_global_step_kernel, dim3(np2 / 512), dim3(256), 0, s, keys, np2, k, j);
+        hipLaunchKernelGGL(argsort_chunk_kernel, dim3(np2 / ARGSORT_MAX), dim3(1024), (size_t)ARGSORT_MAX * 8, s, keys, k);
+    }
+    hipLaunchKernelGGL(argsort_keys_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const unsigned long long*)keys, n, (int*)order);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int segmm_label_stats_unpack(const float* gathered, int G, int B, float* v_all, float* v2_all, float* norms, segmm_stream_t stream) {
+    SEGMM_REQUIRE(gathered && v_all && v2_all && norms && G > 0 && B > 0, "label_stats_unpack: arguments");
+    int blocks = (G * B + 255) / 256;
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(label_stats_unpack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, gathered, G, B, v_all, v2_all, norms);
     LAUNCH_CHECK();
     return 0;
 }

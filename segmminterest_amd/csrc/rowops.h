@@ -489,6 +489,72 @@ __global__ __launch_bounds__(1024) void argsort_ids_kernel(const long long* __re
     for (int i = threadIdx.x; i < n; i += blockDim.x) order[i] = (int)(keys[i] & 0xFFFFFFFFull);
 }
 
+// ---- the same argsort for MORE than ARGSORT_MAX ids (a data-parallel node whose gathered id list outgrows one workgroup: 8 ranks x
+// 2048 rows and up): the bitonic network over a key array in global memory (caller's workspace, npow2 x u64), chunks of
+// ARGSORT_MAX keys sorted / merged in LDS by one workgroup each, the strides >= ARGSORT_MAX as one global compare-exchange
+// launch per stride.  Directions come from the GLOBAL index, so the chunk kernels are the single-workgroup network restricted
+// to a chunk.  Deterministic, no host sync: 5 launches for 16 384 ids, 8 for 32 768.
+__global__ __launch_bounds__(256) void argsort_keys_init_kernel(const long long* __restrict__ ids, int n, int npow2, unsigned long long* __restrict__ keys) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= npow2) return;
+    const unsigned long long id = i < n ? ((unsigned long long)ids[i] & 0xFFFFFFFFull) ^ 0x80000000ull : 0xFFFFFFFFull;
+    keys[i] = i < n ? ((id << 32) | (unsigned)i) : 0xFFFFFFFFFFFFFFFFull;
+}
+// one chunk of ARGSORT_MAX keys per workgroup: kfirst == 2: the whole network up to k = ARGSORT_MAX (a sorted chunk, ascending or
+// descending by the chunk's position); kfirst > ARGSORT_MAX: only the strides j < ARGSORT_MAX of stage k = kfirst (the tail of a merge)
+__global__ __launch_bounds__(1024) void argsort_chunk_kernel(unsigned long long* __restrict__ gkeys, int kfirst) {
+    extern __shared__ unsigned long long keys[];
+    const int base = blockIdx.x * ARGSORT_MAX;
+    for (int i = threadIdx.x; i < ARGSORT_MAX; i += blockDim.x) keys[i] = gkeys[base + i];
+    __syncthreads();
+    const int klast = kfirst == 2 ? ARGSORT_MAX : kfirst;
+    for (int k = kfirst; k <= klast; k <<= 1) {
+        for (int j = (k > ARGSORT_MAX ? ARGSORT_MAX : k) >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < (ARGSORT_MAX >> 1); t += blockDim.x) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int l = i | j;
+                const bool up = ((base + i) & k) == 0;
+                const unsigned long long a = keys[i], b = keys[l];
+                if ((a > b) == up) { keys[i] = b; keys[l] = a; }
+            }
+            __syncthreads();
+        }
+        if (k >= ARGSORT_MAX) break;
+    }
+    for (int i = threadIdx.x; i < ARGSORT_MAX; i += blockDim.x) gkeys[base + i] = keys[i];
+}
+__global__ __launch_bounds__(256) void argsort_global_step_kernel(unsigned long long* __restrict__ keys, int npow2, int k, int j) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= (npow2 >> 1)) return;
+    const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+    const int l = i | j;
+    const bool up = (i & k) == 0;
+    const unsigned long long a = keys[i], b = keys[l];
+    if ((a > b) == up) { keys[i] = b; keys[l] = a; }
+}
+__global__ __launch_bounds__(256) void argsort_keys_finish_kernel(const unsigned long long* __restrict__ keys, int n, int* __restrict__ order) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) order[i] = (int)(keys[i] & 0xFFFFFFFFull);
+}
+
+// Data-parallel label statistics: `gathered` = G records [v (B) | v2 (B) | norms (3)] in rank order (one all-gather).  Splits them
+// into the contiguous v_all / v2_all [G * B] the loss kernel takes and sums the three normalisers over the ranks, in rank order
+// (counts: exact in fp32).  One launch instead of three strided ATen kernels inside the step.
+__global__ __launch_bounds__(256) void label_stats_unpack_kernel(const float* __restrict__ gathered, int G, int B, float* __restrict__ v_all,
+                                                                  float* __restrict__ v2_all, float* __restrict__ norms) {
+    const int n = 2 * B + 3;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < G * B; i += gridDim.x * 256) {
+        const int g = i / B, b = i - g * B;
+        v_all[i] = gathered[(size_t)g * n + b];
+        v2_all[i] = gathered[(size_t)g * n + B + b];
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 3) {
+        float s = 0.f;
+        for (int g = 0; g < G; ++g) s += gathered[(size_t)g * n + 2 * B + threadIdx.x];
+        norms[threadIdx.x] = s;
+    }
+}
+
 // table[ids[k]][:] = 0 for every k (ids outside the table are skipped): clears the rows the previous step scattered into a
 // dense embedding-table gradient instead of re-filling the whole table
 __global__ __launch_bounds__(64) void zero_rows_kernel(float* __restrict__ table, int width, const long long* __restrict__ ids, long long n_rows) {

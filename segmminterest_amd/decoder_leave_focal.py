@@ -211,6 +211,7 @@ class MultiScaleTemporalDetrLeaveFocal(nn.Module):
         self._store = E.ParamStore(self)
         self._loss_spec = LossSpec(model_cfg) if getattr(model_cfg, "loss_type_list", None) else None
         self._dp_hook = None
+        self._dp_stats_bufs = None
         self._stats = None
         self._consts = {}
         backbone1._store, backbone1._prefix = self._store, "backbone1."
@@ -240,9 +241,13 @@ class MultiScaleTemporalDetrLeaveFocal(nn.Module):
 
     def _label_stats(self, gt, B, S):
         """(view lengths of all rows, second length vector, 3 normalisers) -- global under data parallelism."""
-        v = torch.empty(B, device=gt.device)
-        v2s = torch.empty(B, device=gt.device)
-        norms = torch.empty(3, device=gt.device)
+        bufs = getattr(self, "_dp_stats_bufs", None)
+        if self._dp_hook is not None and bufs is not None and gt.is_cuda:
+            v, v2s, norms = bufs(B, gt.device)          # data parallel: straight into the record the all-gather sends
+        else:
+            v = torch.empty(B, device=gt.device)
+            v2s = torch.empty(B, device=gt.device)
+            norms = torch.empty(3, device=gt.device)
         H.label_stats(gt, B, S, int(self._loss_spec.has_focal), v, v2s, norms)
         if self._dp_hook is not None:
             return self._dp_hook(v, v2s, norms)

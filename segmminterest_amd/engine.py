@@ -296,6 +296,15 @@ class ParamStore:
         """Allocation context of the step that is being RECORDED (Trainer.record): every tensor allocated while it is open -- by
         any thread: the autograd engine runs the backward on its own -- comes from the private memory pool ``pool``, which the
         trainer keeps for the life of the recording, so the addresses the recorded commands name stay reserved for the replays."""
+        # torch's PUBLIC context (torch.cuda.use_mem_pool) routes the calling thread only; the backward of the recorded step
+        # allocates on the autograd engine's thread.  The allocator hooks that route EVERY thread are the ones CUDA-graph capture
+        # itself uses (torch/cuda/graphs.py); they are private, so their presence is checked and the failure says what to do.
+        need = ("_cuda_beginAllocateToPool", "_cuda_endAllocateToPool", "_cuda_releasePool")
+        missing = [n for n in need if not hasattr(torch._C, n)]
+        if missing:
+            raise RuntimeError("Trainer.record(): torch %s has no torch._C.%s (the all-thread allocate-to-pool hooks of torch 2.1 - 2.10 that "
+                               "the recording uses to pin the step's buffers); use the per-launch step (Trainer.train_step / fit(recorded=False)) "
+                               "with this torch build" % (torch.__version__, ", torch._C.".join(missing)))
         dev = self.flat.device.index if self.flat.device.index is not None else torch.cuda.current_device()
         torch._C._cuda_beginAllocateToPool(dev, pool.id)          # every allocation of every thread and stream
         try:
@@ -1681,11 +1690,11 @@ class BackboneRun:
                     _colsum(st, gpe, d, L, dh_, st.g(P + "frameid_proj.weight", gbuf).view(-1), x_off=dh_, w=pos)
             if pending is not None:
                 ids_all, rows_all = pending()
-                order = _argsort_ids(ids_all)
+                order = _argsort_ids(ids_all, st)
                 H.embed_id_bwd(rows_all, 1, width, 0, width, order, ids_all, gtab, ids_all.numel())
                 touched = ids_all
             else:
-                order = _argsort_ids(ids)
+                order = _argsort_ids(ids, st)
                 H.embed_id_bwd(dpre, L, d, 0, width, order, ids, gtab, B)
                 touched = ids
             # (a dense all-reduce of the table under data parallelism adds the OTHER ranks' rows: no row list then)
@@ -1705,11 +1714,16 @@ class BackboneRun:
                 _colsum(st, gpe, d, L, d, st.g(P + "%s_proj.bias" % side, gbuf))
 
 
-def _argsort_ids(ids):
-    """Stable argsort of a batch's table ids as int32: the library's one-launch kernel up to 8192 ids, torch beyond."""
+def _argsort_ids(ids, store=None):
+    """Stable argsort of a batch's table ids as int32 by the library's kernels: one launch up to 8192 ids, the multi-workgroup
+    network over a persistent workspace of the store beyond (the gathered id list of a data-parallel node: G x B ids -- a
+    recorded step replays it like any other launch).  Only ids that are not int64 take torch's argsort."""
     ids = ids.reshape(-1).contiguous()
-    if ids.numel() <= H.ARGSORT_MAX and ids.dtype == torch.int64:
-        return H.argsort_ids(ids)
+    if ids.dtype == torch.int64 and ids.numel() <= (1 << 24):
+        ws = None
+        if ids.numel() > H.ARGSORT_MAX and store is not None:
+            ws = store.buf("argsort_ws", (H.argsort_ws_words(ids.numel()),), torch.int64)
+        return H.argsort_ids(ids, ws=ws)
     H.torch_fallback("the argsort of %d table ids (%s)" % (ids.numel(), str(ids.dtype).replace("torch.", "")))
     return torch.argsort(ids, stable=True).to(torch.int32)
 

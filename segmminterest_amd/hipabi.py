@@ -15,7 +15,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SEGMM_LIB") or os.path.join(_HERE, "libsegmm_hip.so")      # SEGMM_LIB: A/B builds of the kernels
-ABI_VERSION = 27
+ABI_VERSION = 28
 
 _lib = None
 
@@ -74,6 +74,8 @@ SIGNATURES = {
     "segmm_embed_id_bwd": [_p, _i, _i, _i, _i, _p, _p, _p, _i, _i64, _p],
     "segmm_pe_grad": [_p, _i, _i, _i, _i, _p, _i, _p],
     "segmm_argsort_ids": [_p, _i, _p, _p],
+    "segmm_argsort_ids_ws": [_p, _i, _p, _p, _p],
+    "segmm_label_stats_unpack": [_p, _i, _i, _p, _p, _p, _p],
     "segmm_zero_rows": [_p, _i, _p, _i, _i64, _p],
     "segmm_label_stats": [_p, _i, _i, _i, _p, _p, _p, _p],
     "segmm_loss_fwd_bwd": [_i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p],
@@ -895,12 +897,38 @@ def attn_bwd(B, H, dh, Lq, La, Lb, Qa, Qb, ldq, Ka, Va, ldka, Kb, Vb, ldkb, mq, 
 ARGSORT_MAX = 8192
 
 
-def argsort_ids(ids, out=None):
-    """Stable argsort of int64 ids (n <= ARGSORT_MAX) as int32, one launch (torch.argsort(ids, stable=True) is five)."""
+def label_stats_unpack(gathered, G, B, v_all, v2_all, norms):
+    """``segmm_label_stats_unpack``: G gathered records [v | v2 | norms] -> v_all, v2_all [G * B], norms summed in rank order."""
+    _check(lib().segmm_label_stats_unpack(gathered.data_ptr(), int(G), int(B), v_all.data_ptr(), v2_all.data_ptr(), norms.data_ptr(), _stream()),
+           "segmm_label_stats_unpack")
+
+
+def argsort_ws_words(n):
+    """64-bit words of workspace ``argsort_ids`` needs for ``n`` ids (0 up to ARGSORT_MAX: one workgroup sorts in LDS)."""
+    if n <= ARGSORT_MAX:
+        return 0
+    w = 2 * ARGSORT_MAX
+    while w < n:
+        w <<= 1
+    return w
+
+
+def argsort_ids(ids, out=None, ws=None):
+    """Stable argsort of int64 ids as int32 (``torch.argsort(ids, stable=True)`` is five ATen launches): one launch up to
+    ARGSORT_MAX ids; beyond, the multi-workgroup bitonic network over ``ws`` (int64 tensor of ``argsort_ws_words(n)`` words;
+    allocated here when not given -- a recorded step passes a persistent one)."""
     n = ids.numel()
     if out is None:
         out = torch.empty((n,), dtype=torch.int32, device=ids.device)
-    _check(lib().segmm_argsort_ids(ids.data_ptr(), int(n), out.data_ptr(), _stream()), "segmm_argsort_ids")
+    if n <= ARGSORT_MAX:
+        _check(lib().segmm_argsort_ids(ids.data_ptr(), int(n), out.data_ptr(), _stream()), "segmm_argsort_ids")
+        return out
+    need = argsort_ws_words(n)
+    if ws is None:
+        ws = torch.empty((need,), dtype=torch.int64, device=ids.device)
+    if ws.numel() < need or ws.dtype != torch.int64:
+        raise RuntimeError("argsort_ids: %d ids need %d int64 words of workspace" % (n, need))
+    _check(lib().segmm_argsort_ids_ws(ids.data_ptr(), int(n), out.data_ptr(), ws.data_ptr(), _stream()), "segmm_argsort_ids_ws")
     return out
 
 

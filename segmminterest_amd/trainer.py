@@ -238,6 +238,12 @@ class DPComm:
             b = bufs[key] = torch.empty(shape, dtype=dtype, device=device)
         return b
 
+    def label_stats_buffers(self, B, device):
+        """(v, v2, norms) as views of the persistent send record of :meth:`global_label_stats`: the statistics kernel writes where
+        the all-gather reads, nothing is packed."""
+        mine = self._pbuf("ls_mine", (2 * B + 3,), torch.float32, device)
+        return mine[:B], mine[B:2 * B], mine[2 * B:]
+
     def global_label_stats(self, v, v2, norms):
         """(v_all, v2_all, norms_global): all-gather the per-row view lengths, sum the 3 normalisers.  Returns the triple
         (single process) or a closure that waits for the asynchronous collective and returns it."""
@@ -255,9 +261,13 @@ class DPComm:
         state = {}
 
         def start():
-            mine[:B].copy_(v)
-            mine[B:2 * B].copy_(v2)
-            mine[2 * B:].copy_(norms)
+            # (the statistics kernel normally wrote straight into `mine` -- label_stats_buffers; a caller's own tensors are copied
+            # by the library's copy kernel: no torch kernel inside the data-parallel step)
+            if v.data_ptr() != mine.data_ptr():
+                cp = H.copy_bytes if mine.is_cuda else (lambda d_, s_: d_.copy_(s_))
+                cp(mine[:B], v.contiguous())
+                cp(mine[B:2 * B], v2.contiguous())
+                cp(mine[2 * B:], norms.contiguous())
             if self.host_staged and mine.is_cuda:
                 hg = torch.empty((G * n,), dtype=mine.dtype)
                 self.dist.all_gather_into_tensor(hg, mine.cpu(), group=self.group)
@@ -270,10 +280,13 @@ class DPComm:
             work = state.pop("work", None)
             if work is not None:
                 work.wait()          # stream-level wait on the communication stream, no host sync
-            g = gathered.view(G, n)
-            v_all.view(G, B).copy_(g[:, :B])
-            v2_all.view(G, B).copy_(g[:, B:2 * B])
-            torch.sum(g[:, 2 * B:], 0, out=norms_g)          # counts: exact in fp32 below 2^24
+            if gathered.is_cuda:
+                H.label_stats_unpack(gathered, G, B, v_all, v2_all, norms_g)          # one launch: split + rank-ordered sum of the counts
+            else:
+                g = gathered.view(G, n)
+                v_all.view(G, B).copy_(g[:, :B])
+                v2_all.view(G, B).copy_(g[:, B:2 * B])
+                torch.sum(g[:, 2 * B:], 0, out=norms_g)          # counts: exact in fp32 below 2^24
             return v_all, v2_all, norms_g
         H.host_action(start)
         return lambda: H.host_action(finish)
@@ -405,6 +418,7 @@ class Trainer:
         self.overlap = overlap
         st = model._store
         model._dp_hook = self.comm.global_label_stats if self.comm.active else None
+        model._dp_stats_bufs = self.comm.label_stats_buffers if self.comm.active else None
         st.bucket_hook = self._on_bucket if self.comm.active else None
         # id mode under DP: the embedding tables' gradients travel as B rows per rank (DPComm.gather_rows) and their flat
         # ranges are cut out of the dense all-reduce; ``sparse_tables=False`` keeps the dense all-reduce (A/B, tests)
@@ -865,6 +879,11 @@ class Trainer:
         aux = st.__dict__.get("_aux_stream")
         rec = H.Recorder(main, side, aux.cuda_stream if aux is not None else 0)
         H.RECORDER = rec
+        # The recorded step must carry the per-step weight split (segmm_wsplit_p32): ParamStore.refresh_planes skips it when the planes
+        # are current -- which they are when an EVALUATION pass ran since the last optimizer step (it split the new weights itself).
+        # A step recorded in that state would replay on stale weight planes for ever (found by fit(recorded=True): validation, then
+        # record).  Force the split into the recording.
+        st._planes_key = None
         try:
             with st.rec_pool(pool):
                 out = self.train_step(batch)

@@ -645,7 +645,7 @@ def test_user_embedding_as_planes_only_gives_the_same_step():
 def test_record_refuses_what_a_replay_would_drop():
     """a recorded step replays C-ABI launches only, so record() must refuse every input whose handling needs a torch
     kernel inside the step -- uint8 / float masks, int32 ids, fp16 features -- instead of freezing the record-time result; the
-    torch fallbacks themselves raise while a step is being recorded (argsort of more than ARGSORT_MAX ids); a change of the
+    torch fallbacks themselves raise while a step is being recorded (argsort of ids that are not int64); a change of the
     optimizer's hyperparameters after record() makes run_recorded() refuse (they are recorded by value); and the relocation
     table is built from pointer slots only."""
     import torch
@@ -671,13 +671,14 @@ def test_record_refuses_what_a_replay_would_drop():
     H.RECORDER = H.Recorder(H._stream(), 0)
     try:
         with pytest.raises(RuntimeError, match="argsort"):
-            E._argsort_ids(torch.arange(H.ARGSORT_MAX + 8, device=dev))
+            E._argsort_ids(torch.arange(H.ARGSORT_MAX + 8, device=dev, dtype=torch.int32))          # (int64 ids of any count: library kernels)
         with pytest.raises(RuntimeError, match="mask"):
             E._mask_u8(torch.ones(4, 4, dtype=torch.uint8, device=dev))
         assert E._mask_u8(torch.ones(4, 4, dtype=torch.bool, device=dev)).dtype == torch.uint8          # zero-copy: fine
     finally:
         H.RECORDER = None
-    assert E._argsort_ids(torch.arange(H.ARGSORT_MAX + 8, device=dev)).numel() == H.ARGSORT_MAX + 8          # eager: torch's sort
+    big = torch.randint(0, 5000, (2 * H.ARGSORT_MAX + 8,), device=dev)          # beyond one workgroup: the multi-workgroup network, no torch kernel
+    assert torch.equal(E._argsort_ids(big, model._store).long(), torch.argsort(big, stable=True))
     tr.record(batch, warmup=2)
     r = tr._recorded
     kinds = set()

@@ -178,3 +178,16 @@ def test_main_eval_batch_logits_branch_matches_reference_kat():
     # without logits nothing of the branch is touched
     res2 = main_eval_batch(args, it, gt, (it > 0.5).float(), {"MAES": 0.0, "pred_leave": []}, type="inference")
     assert res2["MAES"] == 0.0 and res2["pred_leave"] == []
+
+
+def test_record_pool_hooks_are_checked_before_use(monkeypatch):
+    """The recording pins its buffers with torch's all-thread allocate-to-pool hooks (private: torch._C._cuda_*AllocateToPool).  Where a
+    torch build lacks them, ParamStore.rec_pool must fail BEFORE touching the allocator, with a message that names the way out."""
+    from segmminterest_amd import engine as E
+
+    class _S:
+        flat = torch.zeros(1)
+    monkeypatch.delattr(torch._C, "_cuda_beginAllocateToPool", raising=False)
+    with pytest.raises(RuntimeError, match="train_step"):
+        with E.ParamStore.rec_pool(_S(), pool=None):
+            pass

@@ -173,8 +173,10 @@ def test_dropout_hash_rate_and_independence():
         assert abs(var - ref) < 0.02 * ref, (p, var, ref)
 
 
-@pytest.mark.parametrize("n", [1, 2, 7, 64, 1000, 1024, 4097, 8192])
+@pytest.mark.parametrize("n", [1, 2, 7, 64, 1000, 1024, 4097, 8192, 8193, 12000, 16384, 16385, 40000, 65536])
 def test_argsort_ids_is_torch_stable_argsort(n):
+    """One workgroup up to 8192 ids (config 3 on 8 ranks sits exactly on the edge); beyond, the multi-workgroup network over a
+    workspace (round 6: 8192 + 1, 16384, 16384 + 1, a non-power-of-two and 65536 ids)."""
     H = _abi()
     g = torch.Generator().manual_seed(n)
     ids = torch.randint(0, max(2, n // 3), (n,), generator=g)          # many duplicates: stability matters

@@ -2,7 +2,7 @@
 # alternating runs (a b a b), one JSON line per run in gpurun_out/<tag>.jsonl
 TAG=$1; A=$2; B=$3; shift 3
 [ "$1" = "--" ] && shift
-X="--no-cpu-baseline --no-f32-engine --no-host-fed --no-probe"
+X="--no-cpu-baseline --no-f32-engine --no-host-fed --no-probe --no-sustained --no-index-leg"
 O=gpurun_out/$TAG.jsonl; : > $O
 for i in 1 2; do
   for E in "$A" "$B"; do

@@ -1,6 +1,6 @@
 # Same-box sweep of environment settings on the bench:  bash tools/ab_envs.sh <out tag> "<bench args>" "VAR=a" "VAR=b" ...   (two rounds, alternating)
 TAG=$1; ARGS=$2; shift 2
-X="--no-cpu-baseline --no-f32-engine --no-host-fed --no-probe"
+X="--no-cpu-baseline --no-f32-engine --no-host-fed --no-probe --no-sustained --no-index-leg"
 O=gpurun_out/$TAG.jsonl; : > $O
 for i in 1 2; do
   for E in "$@"; do

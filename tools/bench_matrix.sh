@@ -1,7 +1,7 @@
 # Step-mode matrix on one GPU box: configs 2 / 3 / 4 (256 rows) / 5, eager vs recorded, plain and through the forced one-rank DP machinery.
 #   bash tools/bench_matrix.sh <out dir under gpurun_out>
 O=gpurun_out/${1:-matrix}; mkdir -p $O
-X="--no-cpu-baseline --no-f32-engine --no-host-fed --no-probe"
+X="--no-cpu-baseline --no-f32-engine --no-host-fed --no-probe --no-sustained --no-index-leg"
 for cfg in "2" "3" "4 --global-batch 256" "5"; do
   tag=$(echo $cfg | tr -d ' -' ); 
   for mode in "--eager" ""; do

@@ -4,7 +4,7 @@ TAG=${1:-r2}; shift
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/bench.py --steps 5 --warmup 2 --windows 2 --no-cpu-baseline --no-f32-engine --no-host-fed --no-probe "$@" > $R/gpurun_out/prof_bench_$TAG.log 2>&1
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/bench.py --steps 5 --warmup 2 --windows 2 --no-cpu-baseline --no-f32-engine --no-host-fed --no-probe --no-sustained --no-index-leg "$@" > $R/gpurun_out/prof_bench_$TAG.log 2>&1
 cd $R
 F=$(find gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1)
 cp "$F" gpurun_out/prof_${TAG}_kernel_stats.csv

@@ -4,7 +4,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
-X="--no-cpu-baseline --no-f32-engine --no-host-fed --no-probe"
+X="--no-cpu-baseline --no-f32-engine --no-host-fed --no-probe --no-sustained --no-index-leg"
 python bench.py --steps 20 --warmup 5 > $O/bench_n1.json 2> $O/bench_n1.err
 python bench.py --eager --steps 20 --warmup 5 $X > $O/bench_n1_eager.json 2>/dev/null
 SEGMM_SCALING=exact python bench.py --steps 20 --warmup 5 $X > $O/bench_n1_exact_scaling.json 2>/dev/null

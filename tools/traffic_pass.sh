@@ -9,13 +9,18 @@ OUT=$R/gpurun_out/traffic_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 400 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-f32-engine --no-host-fed --no-probe > $OUT/$C.log 2>&1 || exit 1
+  timeout -k 10 400 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-f32-engine --no-host-fed --no-probe --no-sustained --no-index-leg > $OUT/$C.log 2>&1 || exit 1
 done
 cd $R
 GIT=${GIT_SHA:-unknown}
 python3 - "$OUT" "$GIT" <<'PY'
-import collections, csv, glob, json, os, sys
+import collections, csv, glob, hashlib, json, os, sys
 out, git = sys.argv[1], sys.argv[2]
+hsh = hashlib.sha256()          # the kernel sources this pass ran on: bench.py emits `traffic` only for a matching tree (bench.csrc_sha16)
+for f in sorted(os.listdir("segmminterest_amd/csrc")):
+    if f.endswith((".h", ".hip", ".inc")):
+        hsh.update(f.encode() + b"\0" + open(os.path.join("segmminterest_amd/csrc", f), "rb").read())
+csrc = hsh.hexdigest()[:16]
 acc = collections.OrderedDict()
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for f in sorted(glob.glob("%s/%s/**/*counter_collection.csv" % (out, c), recursive=True)):
@@ -39,7 +44,7 @@ g = [r for r in rows if "gemm_split_mfma" in r[0] or "gemm_f32_mfma" in r[0] or 
 engine = os.environ.get("SEGMM_GEMM", "f16x3p")
 n = sum(r[1] for r in g)
 tot = sum((r[3] + r[4]) * r[1] for r in g)
-json.dump({"kernel": "every GEMM dispatch of the run (gemm_pl_nt / gemm_pl_tn / gemm_split_mfma / gemm_f32_mfma)", "engine": engine, "git": git, "launches": n,
+json.dump({"kernel": "every GEMM dispatch of the run (gemm_pl_nt / gemm_pl_tn / gemm_split_mfma / gemm_f32_mfma)", "engine": engine, "git": git, "csrc_sha16": csrc, "launches": n,
            "hbm_bytes_per_launch": tot / max(n, 1), "read_bytes_per_launch": sum(r[3] * r[1] for r in g) / max(n, 1),
            "write_bytes_per_launch": sum(r[4] * r[1] for r in g) / max(n, 1),
            "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over bench.py --steps 3 --warmup 1; "
