@@ -119,9 +119,9 @@ static Knob g_knobs[K_COUNT] = {
     {"ATT_HPB_DKV", 0, "dK/dV kernel workgroup shape, as above"},
     {"L1NORM_REG", 1, "L1 normalisation with the row held in registers"},
     {"GEMM_BN", 0, "on-the-fly GEMM: tile width override (0: built-in choice)"},
-    {"PL_VAR", 4, "plane NT GEMM: 4 gemm_pl_nt4 (round 6: 128 x 256 tiles, two workgroups per CU); 8 gemm_pl_nt8 (round 3); 1: the round-2 fallback kernel for every launch"},
+    {"PL_VAR", 4, "plane NT GEMM: 4 gemm_pl_nt4 (round 6: 128 x 256 tiles, two workgroups per CU) for K >= 768, gemm_pl_nt8 below; 44 gemm_pl_nt4 always; 8 gemm_pl_nt8 (round 3); 1: the round-2 fallback kernel for every launch"},
     {"PL_NJ", 0, "plane NT GEMM: tile width in 64-column units (0: modelled choice)"},
-    {"TN_VAR", 4, "plane TN GEMM: 4 gemm_pl_tn4 (round 6: 128 x 256 tiles, two workgroups per CU); 8 gemm_pl_tn8 (round 3); 0: the round-2 fallback kernel for every launch"},
+    {"TN_VAR", 8, "plane TN GEMM: 8 gemm_pl_tn8 (round 3), gemm_pl_tn4 (round 6: 128 x 256 tiles, two workgroups per CU) where M is a multiple of 128 only; 4 gemm_pl_tn4 wherever it fits; 0: the round-2 fallback kernel for every launch"},
 };
 static bool g_knobs_ready = false;
 static void knobs_init() {
@@ -763,15 +763,19 @@ int segmm_gemm_p(int layout, int M, int N, int K, const uint16_t* a_planes, int 
 #ifdef SEGMM_STAMPS
         q.stamps = g_segmm_stamps;
 #endif
-        if (pl_var == 8 || pl_var == 4) {          // round-3 / round-6 forms: 16x16x32 MFMA, register epilogue (gemm_planes8.h, gemm_planes4.h)
+        if (pl_var == 8 || pl_var == 4 || pl_var == 44) {          // round-3 / round-6 forms: 16x16x32 MFMA, register epilogue (gemm_planes8.h, gemm_planes4.h)
             // every epilogue access is a buffer operation with a 32-bit offset whose top bit masks out-of-range columns
             const long long lim = 1ll << 31;
             const bool fits = !row_scale && (long long)M * ldc * 4 < lim && (!aux || (long long)M * ldaux * 4 < lim) &&
                               (!residual || (long long)(res_period < M ? res_period : M) * ldr * 4 < lim) &&
                               (!c_planes || (long long)M * ldc2 * 2 < lim) &&
                               !(residual && (activation == EPI_DGELU || activation == EPI_DRELU));      // one extra operand per element
-            if (fits && pl_var == 4) {
-                // round 6: 128 x 256 tiles, four waves, two workgroups resident per CU (results bitwise those of gemm_pl_nt8)
+            // round 6: 128 x 256 tiles, four waves, two workgroups resident per CU (results bitwise those of gemm_pl_nt8).  Taken for
+            // K >= 768: in the step it wins at configs 2 / 4 / 5 (K = 768 .. 3072: +0.7 % of the step, the NT launches 191 -> 175 us) and
+            // loses at config 3 (K = 512, N = 512 .. 2048: 195.7 -> 192.3 k interactions/s -- a short k-loop leaves the second resident
+            // workgroup less to hide, and gemm_pl_nt8's 192-wide tiles fit N = 512 better) -- profiles/r6/ab_kernel_generations.txt.
+            // SEGMM_PL_VAR=44 forces it for every launch (tests, A/B)
+            if (fits && (pl_var == 44 || (pl_var == 4 && K >= 768))) {
                 g.nbm = (M + P4_BM - 1) / P4_BM; g.nbn = (N + P4_BN - 1) / P4_BN;
                 hipLaunchKernelGGL(gemm_pl_nt4, dim3(g.nbm * g.nbn), dim3(256), 0, s, g, q);
                 LAUNCH_CHECK();
@@ -844,8 +848,22 @@ int segmm_gemm_p(int layout, int M, int N, int K, const uint16_t* a_planes, int 
     // split-K stores (no accumulate into C), 32-bit output offsets.  Everything else: the round-2 kernel
     const int tn_var = knob(K_TN_VAR);
     const bool small_out = !g.residual && (long long)M * (splits > 1 ? N : ldc) * 4 < (1ll << 31);
-    const bool tn4 = tn_var == 4 && M % P4_BM == 0 && N % P4_BN == 0 && small_out;
-    const bool tn8 = (tn_var == 8 || tn_var == 4) && M % PBM == 0 && N % PBN == 0 && small_out;
+    // Stand-alone gemm_pl_tn4 is the faster kernel (+4 .. 37 %, profiles/r6/gemm4_standalone.txt); in the step it LOSES 2.1-2.5 % at
+    // config 2 and is even at configs 3 / 4: its 504 workgroups take one slot of EVERY CU at once, and the main stream's GEMM beside
+    // it then runs one workgroup per CU next to a weight-gradient workgroup instead of two of its own (step timelines in
+    // profiles/r6/).  Default: gemm_pl_tn8 where it fits, gemm_pl_tn4 for matrices that are whole 128- but not 256-row tiles
+    bool tn8 = (tn_var == 8 || tn_var == 4) && M % PBM == 0 && N % PBN == 0 && small_out;
+    bool tn4 = (tn_var == 4 || (tn_var == 8 && !tn8)) && M % P4_BM == 0 && N % P4_BN == 0 && small_out;
+#ifdef SEGMM_TN4_RULE_PROBE
+    {          // probe: which weight-gradient launches take the round-6 kernel (SEGMM_TN4_RULE: 1 K >= 50000, 2 M N <= 768^2, 3 either, 4 K < 50000 && M N > 768^2)
+        static const int rule = getenv("SEGMM_TN4_RULE") ? atoi(getenv("SEGMM_TN4_RULE")) : 0;
+        const bool fits4 = M % P4_BM == 0 && N % P4_BN == 0 && small_out;
+        const bool longk = K >= 50000, fewt = (long long)M * N <= 768ll * 768;
+        bool want = false;
+        if (rule == 1) want = longk; else if (rule == 2) want = fewt; else if (rule == 3) want = longk || fewt; else if (rule == 4) want = !longk && !fewt;
+        if (rule && fits4) tn4 = want;
+    }
+#endif
     if (tn4) {
         g.nbm = M / P4_BM; g.nbn = N / P4_BN;
         hipLaunchKernelGGL(gemm_pl_tn4, dim3(g.nbm * g.nbn, 1, splits), dim3(256), 0, s, g, q);

@@ -64,6 +64,8 @@ def test_adamw_steps_torch_optimizer_dropin(name):
     cfg, g, nograd, extra, model = _loaded(name)
     opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-4)
 
+    counts = {"all": 0, "loose": 0}
+
     def check(k, got, ref, base, steps):
         # Adam normalises g/sqrt(v): where the gradient is rounding noise its SIGN decides a full
         # lr-sized step in either direction, so such elements can only be pinned to 2*lr*steps.
@@ -73,7 +75,10 @@ def test_adamw_steps_torch_optimizer_dropin(name):
         gabs = g["grad"][k].abs()
         solid = gabs > max(1e-5, 2e-3 * float(gabs.max()))
         err = (got - ref).abs()
+        lim_solid = base + 1e-4 * ref.abs()
         lim = torch.where(solid, torch.full_like(err, base), torch.full_like(err, 2.2e-3 * steps)) + 1e-4 * ref.abs()
+        counts["all"] += err.numel()
+        counts["loose"] += int(((~solid) & (err > lim_solid)).sum())          # noise-floor elements that NEED the loose bound
         bad = err > lim
         if bool(bad.any()):
             i = int((err - lim).argmax())
@@ -87,8 +92,12 @@ def test_adamw_steps_torch_optimizer_dropin(name):
         opt.step()
         if step in (1, 3):
             ref = g["adam%d" % step]
+            counts["all"] = counts["loose"] = 0
             for k, p in model.named_parameters():
                 check(k, p.detach().cpu(), ref[k], 3e-5 * step, step)
+            # the loose bound is an exception, not the rule: over the 12 fixtures at most 0.46 % of a model's live elements take it
+            # (gpurun_out/adam_noise.txt, tools/probe/adam_noise_probe.py: 0 .. 66 elements of 6 k .. 33 k); 1 % is the ceiling
+            assert counts["loose"] <= 0.01 * counts["all"], (step, counts)
     for k, p in model.named_parameters():
         if k in nograd:
             assert torch.equal(p.detach().cpu(), g["sd"][k]), k
@@ -310,7 +319,7 @@ def test_full_width_config_vs_oracle(B, S, Lt, D, N):
             assert p.grad is None, k
         else:
             scale = max(float(rgrads[k].abs().max()), 1e-7)
-            assert float((p.grad.cpu() - rgrads[k]).abs().max()) <= 2e-4 * scale + 1e-7, k
+            assert float((p.grad.cpu() - rgrads[k]).abs().max()) <= 5e-5 * scale + 1e-7, k
 
 
 def _ref_args(N, d, h, S, user, photo):

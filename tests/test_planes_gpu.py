@@ -47,6 +47,27 @@ def _po(H, rows, cols, scale):
     return pl, hdr, sc, H.PO(pl, 2 * cols, hdr, sc.data_ptr())
 
 
+@pytest.fixture(autouse=True, params=["default", "round6", "round3"])
+def gemm_generation(request):
+    """Every test of this module runs on each generation of the plane GEMM kernels: the library's own choice per launch, the round-6
+    kernels wherever they fit (gemm_pl_nt4 / gemm_pl_tn4: 128 x 256 tiles, two workgroups per CU; knobs PL_VAR = 44, TN_VAR = 4) and
+    the round-3 kernels (gemm_pl_nt8 / gemm_pl_tn8).  The generations give bitwise the same results (tools/probe/gemm4_bench.hip);
+    here each is held to the same references."""
+    if request.param == "default" or not request.node.name.startswith(("test_gemm_p", "test_low_scale", "test_delayed_scaling_matches")):
+        if request.param != "default":
+            pytest.skip("not a GEMM-kernel test: runs once")
+        yield
+        return
+    H = _abi()
+    pl, tn = (44, 4) if request.param == "round6" else (8, 8)
+    prev = H.config_set("PL_VAR", pl), H.config_set("TN_VAR", tn)
+    try:
+        yield
+    finally:
+        H.config_set("PL_VAR", prev[0])
+        H.config_set("TN_VAR", prev[1])
+
+
 # ------------------------------------------------------------------ GEMM kernels
 @pytest.mark.parametrize("M,N,K", [(256, 256, 32), (1024, 768, 768), (300, 96, 64), (20480, 768, 768), (37, 32, 160)])
 def test_gemm_p_nt_matches_fp64_and_on_the_fly(M, N, K):
