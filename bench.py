@@ -583,6 +583,14 @@ def main():
             flops = sum(2.0 * M * Nn * K for (_, M, Nn, K, _, _) in prof)
             K_typ = max((K for (lay, _, _, K, _, _) in prof if lay == 10), default=768)          # contraction width of the NT launches
 
+            def tn_gen(M, Nn):          # ... and which TN generation (knob TN_VAR: 8 = round-6 kernel for few-tile / 128-row matrices)
+                v = hipabi.knob("TN_VAR")
+                f8, f4 = M % 256 == 0 and Nn % 256 == 0, M % 128 == 0 and Nn % 256 == 0
+                few = ((M + 255) // 256) * ((Nn + 255) // 256) <= 9
+                if f4 and (v == 4 or (v == 8 and (few or not f8))):
+                    return 4
+                return 8 if f8 and v in (4, 8, 88) else 0
+
             def nt_gen(K):          # which NT kernel generation capi.hip picks (knob PL_VAR: 4 = round-6 kernel for K >= 768)
                 v = hipabi.knob("PL_VAR")
                 return 4 if (v == 44 or (v == 4 and K >= 768)) else 8 if v in (4, 8) else v
@@ -605,7 +613,7 @@ def main():
             elif engine == "f16x3":
                 peak, kname = PEAK_BF16_MFMA_TFLOPS / 3.0, "gemm_split_mfma<F16> (3 x v_mfma_f32_32x32x16_f16 per product, operands split on the fly)"
             elif engine == "f16x3p":
-                nt_k, tn_k = "gemm_pl_nt%d" % nt_gen(K_typ), "gemm_pl_tn%d" % hipabi.knob("TN_VAR")
+                nt_k, tn_k = "gemm_pl_nt%d" % nt_gen(K_typ), "gemm_pl_tn8 / gemm_pl_tn4"
                 peak, kname = PEAK_BF16_MFMA_TFLOPS / 3.0, ("%s / %s (3 x v_mfma_f32_16x16x32_f16 per product, scaled 2-term fp16 split = 22-bit "
                                                             "operands PRE-SPLIT by their producers, LDS-DMA staging with counted waits; round 6: 128 x 256 "
                                                             "tiles, four waves, two workgroups resident per CU, software-pipelined wave stream; "
@@ -647,7 +655,7 @@ def main():
             fam = {}
             for (lay, M, Nn, K, e0, e1) in prof:
                 if lay >= 10:
-                    name = "gemm_pl_" + ("nt", "nn", "tn")[lay % 10] + str(hipabi.knob("TN_VAR") if lay == 12 else nt_gen(K)) + (" (+ splitk_reduce share excluded)" if lay == 12 else "")
+                    name = "gemm_pl_" + ("nt", "nn", "tn")[lay % 10] + str(tn_gen(M, Nn) if lay == 12 else nt_gen(K)) + (" (+ splitk_reduce share excluded)" if lay == 12 else "")
                 else:
                     name = "gemm_split_mfma/" + ("nt", "nn", "tn")[lay % 10]
                 a = fam.setdefault(name, [0, 0.0, 0.0])

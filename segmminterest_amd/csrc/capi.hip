@@ -121,7 +121,7 @@ static Knob g_knobs[K_COUNT] = {
     {"GEMM_BN", 0, "on-the-fly GEMM: tile width override (0: built-in choice)"},
     {"PL_VAR", 4, "plane NT GEMM: 4 gemm_pl_nt4 (round 6: 128 x 256 tiles, two workgroups per CU) for K >= 768, gemm_pl_nt8 below; 44 gemm_pl_nt4 always; 8 gemm_pl_nt8 (round 3); 1: the round-2 fallback kernel for every launch"},
     {"PL_NJ", 0, "plane NT GEMM: tile width in 64-column units (0: modelled choice)"},
-    {"TN_VAR", 8, "plane TN GEMM: 8 gemm_pl_tn8 (round 3), gemm_pl_tn4 (round 6: 128 x 256 tiles, two workgroups per CU) where M is a multiple of 128 only; 4 gemm_pl_tn4 wherever it fits; 0: the round-2 fallback kernel for every launch"},
+    {"TN_VAR", 8, "plane TN GEMM: 8 gemm_pl_tn4 (round 6: 128 x 256 tiles, two workgroups per CU) for few-tile and 128-row matrices, gemm_pl_tn8 (round 3) otherwise; 4 gemm_pl_tn4 wherever it fits; 88 gemm_pl_tn8 wherever it fits; 0: the round-2 fallback kernel for every launch"},
 };
 static bool g_knobs_ready = false;
 static void knobs_init() {
@@ -848,22 +848,17 @@ int segmm_gemm_p(int layout, int M, int N, int K, const uint16_t* a_planes, int 
     // split-K stores (no accumulate into C), 32-bit output offsets.  Everything else: the round-2 kernel
     const int tn_var = knob(K_TN_VAR);
     const bool small_out = !g.residual && (long long)M * (splits > 1 ? N : ldc) * 4 < (1ll << 31);
-    // Stand-alone gemm_pl_tn4 is the faster kernel (+4 .. 37 %, profiles/r6/gemm4_standalone.txt); in the step it LOSES 2.1-2.5 % at
-    // config 2 and is even at configs 3 / 4: its 504 workgroups take one slot of EVERY CU at once, and the main stream's GEMM beside
-    // it then runs one workgroup per CU next to a weight-gradient workgroup instead of two of its own (step timelines in
-    // profiles/r6/).  Default: gemm_pl_tn8 where it fits, gemm_pl_tn4 for matrices that are whole 128- but not 256-row tiles
-    bool tn8 = (tn_var == 8 || tn_var == 4) && M % PBM == 0 && N % PBN == 0 && small_out;
-    bool tn4 = (tn_var == 4 || (tn_var == 8 && !tn8)) && M % P4_BM == 0 && N % P4_BN == 0 && small_out;
-#ifdef SEGMM_TN4_RULE_PROBE
-    {          // probe: which weight-gradient launches take the round-6 kernel (SEGMM_TN4_RULE: 1 K >= 50000, 2 M N <= 768^2, 3 either, 4 K < 50000 && M N > 768^2)
-        static const int rule = getenv("SEGMM_TN4_RULE") ? atoi(getenv("SEGMM_TN4_RULE")) : 0;
-        const bool fits4 = M % P4_BM == 0 && N % P4_BN == 0 && small_out;
-        const bool longk = K >= 50000, fewt = (long long)M * N <= 768ll * 768;
-        bool want = false;
-        if (rule == 1) want = longk; else if (rule == 2) want = fewt; else if (rule == 3) want = longk || fewt; else if (rule == 4) want = !longk && !fewt;
-        if (rule && fits4) tn4 = want;
-    }
-#endif
+    // Stand-alone gemm_pl_tn4 is the faster kernel (+4 .. 37 %, profiles/r6/gemm4_standalone.txt).  In the step (config 2, same-box A/Bs,
+    // profiles/r6/ab_kernel_generations.txt) it LOSES 2.1-2.5 % when every weight gradient takes it -- its 504 workgroups hold one slot of
+    // EVERY CU at once, and the main stream's input-gradient GEMM beside it then runs one workgroup per CU next to a weight-gradient
+    // workgroup instead of two of its own -- and WINS +0.5 .. 1.5 % when only the few-tile matrices take it (768 x 768: 9 tiles of
+    // 256 x 256, 28 splits: short k-loops whose prologue / epilogue the second resident workgroup hides; the row kernels of the step's
+    // tail fit beside them).  Default (TN_VAR 8): gemm_pl_tn4 for at most 9 tiles of 256 x 256 and for matrices that are whole 128-
+    // but not 256-row tiles, gemm_pl_tn8 otherwise; 4: gemm_pl_tn4 wherever it fits; 88: gemm_pl_tn8 wherever it fits
+    const bool fits8 = M % PBM == 0 && N % PBN == 0 && small_out, fits4 = M % P4_BM == 0 && N % P4_BN == 0 && small_out;
+    const bool few = (long long)((M + PBM - 1) / PBM) * ((N + PBN - 1) / PBN) <= 9;
+    const bool tn4 = fits4 && (tn_var == 4 || (tn_var == 8 && (few || !fits8)));
+    const bool tn8 = !tn4 && fits8 && (tn_var == 8 || tn_var == 88 || tn_var == 4);
     if (tn4) {
         g.nbm = M / P4_BM; g.nbn = N / P4_BN;
         hipLaunchKernelGGL(gemm_pl_tn4, dim3(g.nbm * g.nbn, 1, splits), dim3(256), 0, s, g, q);

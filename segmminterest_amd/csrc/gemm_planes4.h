@@ -97,10 +97,16 @@ __global__ __launch_bounds__(256, 2) void gemm_pl_nt4(const GemmArgs p, const PG
     constexpr int stag_units = P4_STAGGER, stag_pat = 0;
 #endif
     if (stag_units > 0 && (int)blockIdx.x < 512) {
-        const bool late = stag_pat == 0 ? (blockIdx.x & 256) != 0 : stag_pat == 1 ? (blockIdx.x & 8) != 0 : (blockIdx.x & 128) != 0;
-        if (late) {
+        if (stag_pat == 3) {          // every workgroup of the first round: a sixteenth-grained delay from a hash of its id
+            const int sx = (int)(((uint32_t)blockIdx.x * 2654435761u) >> 28);
 #pragma unroll 1
-            for (int i = 0; i < nkt * stag_units; ++i) __builtin_amdgcn_s_sleep(8);          // 8 x 64 cycles per unit and k-tile
+            for (int i = 0; i < (nkt * stag_units * sx) >> 4; ++i) __builtin_amdgcn_s_sleep(8);
+        } else {
+            const bool late = stag_pat == 0 ? (blockIdx.x & 256) != 0 : stag_pat == 1 ? (blockIdx.x & 8) != 0 : (blockIdx.x & 128) != 0;
+            if (late) {
+#pragma unroll 1
+                for (int i = 0; i < nkt * stag_units; ++i) __builtin_amdgcn_s_sleep(8);          // 8 x 64 cycles per unit and k-tile
+            }
         }
     }
 
@@ -496,12 +502,23 @@ __global__ __launch_bounds__(256, 2) void gemm_pl_nt4(const GemmArgs p, const PG
             for (int i = 0; i < 8; ++i) {
                 if (HAS_E && (i & 1) == 0) vmwait(i == 0 ? 0 : (i == 6 ? 2 : 1));
                 const uint32_t soC = (uint32_t)i * 16u * (uint32_t)p.ldc * 4u;
-                put_block(i);
                 f32x4 g4[4];          // (the four reads before the first store: see row_loop)
+                if (SEGMM_GEMM_DBG(q) & 8) {          // timing ablation: no LDS transposition (wrong layout)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) g4[t] = tr_get(t);
+                    for (int t = 0; t < 4; ++t) { g4[t] = acc[i][t] * inv_ab + bias4[t]; am = fmaxf(am, g4[t].x); }
+                } else {
+                    put_block(i);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) buf_store4(rsC, oCT, soC + (uint32_t)(4 * t) * (uint32_t)p.ldc * 4u, g4[t]);
+                    for (int t = 0; t < 4; ++t) g4[t] = tr_get(t);
+                }
+                if (SEGMM_GEMM_DBG(q) & 4) {          // timing ablation: no store instructions
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) am = fmaxf(am, g4[t].x + g4[t].y + g4[t].z + g4[t].w);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) buf_store4(rsC, oCT, soC + (uint32_t)(4 * t) * (uint32_t)p.ldc * 4u, g4[t]);
+                }
+                STAMPX(i);
                 if (HAS_E && (i & 1) == 1 && i < 5) {
                     end_load_segment();
                     dmaE((i >> 1) + 2);
@@ -831,7 +848,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pl_tn4(const GemmArgs p, const PG
             g4[t] = *(const f32x4*)(trp + r * 256 + (((l15 ^ r) & 15) << 4));
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) buf_store4(rsC, oCT, (uint32_t)(16 * i + 4 * t) * (uint32_t)p.ldc * 4u, g4[t]);
+        for (int t = 0; t < 4; ++t) buf_store4k(rsC, oCT, (uint32_t)(16 * i + 4 * t) * (uint32_t)p.ldc * 4u, g4[t]);
     }
 }
 

@@ -50,12 +50,26 @@ typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 // exist with a register there) -- on gfx950 it does: with soffset in an SGPR and the next v_pk_fma_f32 reusing the data
 // registers, lanes 12-15 stored the NEXT float4's .y/.w (tools/probe/dbg_fast.py).  The wait states are written out, in an asm
 // statement that READS the data registers, so no write to them can be scheduled in front of it.
-__device__ __forceinline__ void buf_store4u(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, u32x4_t v) {
-    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, (int)soff, 0);
+// Cache policy of the NT kernels' epilogue stores: nt (aux bit 1).  The outputs of a GEMM are written once and read by a LATER kernel;
+// kept in the XCD's L2 like ordinary stores they push out the operand panels the other workgroups of the launch are still reading
+// (tools/probe/gemm4_bench.hip, -DSEGMM_STORE_AUX=0 / 2 / 16: gemm_pl_nt4 20480 x 3072 x 768 228.4 -> 215.7 us, 51200 x 768 x 768
+// 150.0 -> 133.8 us; gemm_pl_nt8 +2 .. 7 %; sc1 alone +1.5 %; in the step +0.4 % -- the consumers find the data in the Infinity
+// Cache).  The split-K slabs of the TN kernels are read back by splitk_reduce at once: they keep the default policy (buf_store4k).
+#ifndef SEGMM_STORE_AUX
+#define SEGMM_STORE_AUX 2          // 0 default policy, 1 sc0, 2 nt, 16 sc1
+#endif
+template <int AUX>
+__device__ __forceinline__ void buf_store4u_aux(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, u32x4_t v) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, (int)soff, AUX);
     asm volatile("s_nop 3" :: "v"(v));
 }
+// (same-box check of small outputs, 20480 x 768 x 768 = 63 MB: 60.3 us default, 57.9 us nt -- no size threshold needed)
+__device__ __forceinline__ void buf_store4u(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, u32x4_t v) { buf_store4u_aux<SEGMM_STORE_AUX>(r, voff, soff, v); }
 __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, f32x4 v) {
     buf_store4u(r, voff, soff, __builtin_bit_cast(u32x4_t, v));
+}
+__device__ __forceinline__ void buf_store4k(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, f32x4 v) {          // "keep": default cache policy
+    buf_store4u_aux<0>(r, voff, soff, __builtin_bit_cast(u32x4_t, v));
 }
 __device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
     return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
@@ -68,8 +82,11 @@ constexpr uint32_t BUF_OOB = 0x80000000u;          // a byte offset no descripto
                                                            if ((k) == 0 || (k) == 3) q.stamps[(size_t)blockIdx.x * 8 + 4 + ((k) ? 1 : 0)] = __builtin_amdgcn_s_memrealtime(); \
                                                            if ((k) == 0) q.stamps[(size_t)blockIdx.x * 8 + 6] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 32); \
                                                            if ((k) == 2) q.stamps[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+// second region (16 x u64 per workgroup behind the 8 x u64 records): finer stamps inside a section
+#define STAMPX(k) do { if (q.stamps && threadIdx.x == 0) q.stamps[(size_t)gridDim.x * 8 + (size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define STAMP(k) do { } while (0)
+#define STAMPX(k) do { } while (0)
 #endif
 
 #ifndef SEGMM_SETPRIO
@@ -781,7 +798,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_tn8(const GemmArgs p, const PG
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int r = 4 * t + lq;
-            buf_store4(rsC, oCT, (uint32_t)(16 * i + 4 * t) * (uint32_t)p.ldc * 4u, *(const f32x4*)(trp + r * 256 + (((l15 ^ r) & 15) << 4)));
+            buf_store4k(rsC, oCT, (uint32_t)(16 * i + 4 * t) * (uint32_t)p.ldc * 4u, *(const f32x4*)(trp + r * 256 + (((l15 ^ r) & 15) << 4)));
         }
     }
 }

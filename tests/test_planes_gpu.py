@@ -59,7 +59,7 @@ def gemm_generation(request):
         yield
         return
     H = _abi()
-    pl, tn = (44, 4) if request.param == "round6" else (8, 8)
+    pl, tn = (44, 4) if request.param == "round6" else (8, 88)
     prev = H.config_set("PL_VAR", pl), H.config_set("TN_VAR", tn)
     try:
         yield

@@ -151,13 +151,20 @@ int main(int argc, char** argv) {
             if ((var == 8 && (which == 4 || !tn8_ok)) || (var == 4 && which == 8) || sh.layout != 0) continue;
             const int nwg = var == 8 ? ((M + 255) / 256) * ((N + 255) / 256) : ((M + 127) / 128) * ((N + 255) / 256);
             unsigned long long* st;
-            CK(hipMalloc(&st, (size_t)nwg * 64)); CK(hipMemset(st, 0, (size_t)nwg * 64));
+            CK(hipMalloc(&st, (size_t)nwg * 192)); CK(hipMemset(st, 0, (size_t)nwg * 192));
             q.stamps = st; q.dbg = dbg;
             float us = 0.f;
             if (run(var, var == 8 ? C8 : C4, us)) return 1;
             q.stamps = nullptr;
-            std::vector<unsigned long long> hs((size_t)nwg * 8);
-            CK(hipMemcpy(hs.data(), st, (size_t)nwg * 64, hipMemcpyDeviceToHost));
+            std::vector<unsigned long long> hs((size_t)nwg * 24);
+            CK(hipMemcpy(hs.data(), st, (size_t)nwg * 192, hipMemcpyDeviceToHost));
+            if (var == 4) {          // finer stamps of the epilogue: cycles from the end of the k-loop to the end of each row block
+                double d[8] = {0};
+                for (int w = 0; w < nwg; ++w) for (int k = 0; k < 8; ++k) d[k] += (double)(hs[(size_t)nwg * 8 + (size_t)w * 16 + k] - hs[(size_t)w * 8 + 2]);
+                printf("      epilogue row blocks (cycles after loop end):");
+                for (int k = 0; k < 8; ++k) printf(" %.0f", d[k] / nwg);
+                printf("\n");
+            }
             CK(hipFree(st));
             unsigned long long t00 = ~0ull;
             for (int w = 0; w < nwg; ++w) if (hs[w * 8 + 4] < t00) t00 = hs[w * 8 + 4];
