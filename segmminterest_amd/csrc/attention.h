@@ -475,7 +475,7 @@ __global__ __launch_bounds__(ATT_MAX_THREADS) void attn_fwd_kernel(const AttnArg
 // are bit-identical, with several the softmax sums are merged in another order (differences at the 1e-7 level).
 constexpr uint32_t ATT_BUF_OOB = 0x80000000u;
 __device__ __forceinline__ void att_lds_dma16(__amdgpu_buffer_rsrc_t r, void* lds_wave_base, uint32_t voff, uint32_t soff) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, (int)soff, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, (int)soff, 0, SEGMM_ATT_AUX);
 }
 template <int DH> __host__ __device__ constexpr int att_lds_chunks(int rows) { return ((rows * (DH / 4 + 1)) + 63) & ~63; }      // 16-byte chunks of one staged array
 template <int DH>

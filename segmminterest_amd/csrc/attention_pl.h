@@ -466,10 +466,10 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? SEGMM_ATT16_WPS : 4) void attn_b
         const uint32_t ko = soK0 + (uint32_t)kr * ldk2b, vo = soV0 + (uint32_t)kr * ldk2b;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            kraw_[i][0] = __builtin_bit_cast(u32x2a, __builtin_amdgcn_raw_buffer_load_b64(rsKV, (int)(ko + fco[i]), 0, 0));
-            kraw_[i][1] = __builtin_bit_cast(u32x2a, __builtin_amdgcn_raw_buffer_load_b64(rsKV, (int)(ko + fco[i] + 64u), 0, 0));
-            vraw_[i][0] = __builtin_bit_cast(u32x2a, __builtin_amdgcn_raw_buffer_load_b64(rsKV, (int)(vo + fco[i]), 0, 0));
-            vraw_[i][1] = __builtin_bit_cast(u32x2a, __builtin_amdgcn_raw_buffer_load_b64(rsKV, (int)(vo + fco[i] + 64u), 0, 0));
+            kraw_[i][0] = __builtin_bit_cast(u32x2a, __builtin_amdgcn_raw_buffer_load_b64(rsKV, (int)(ko + fco[i]), 0, SEGMM_ATT_AUX));
+            kraw_[i][1] = __builtin_bit_cast(u32x2a, __builtin_amdgcn_raw_buffer_load_b64(rsKV, (int)(ko + fco[i] + 64u), 0, SEGMM_ATT_AUX));
+            vraw_[i][0] = __builtin_bit_cast(u32x2a, __builtin_amdgcn_raw_buffer_load_b64(rsKV, (int)(vo + fco[i]), 0, SEGMM_ATT_AUX));
+            vraw_[i][1] = __builtin_bit_cast(u32x2a, __builtin_amdgcn_raw_buffer_load_b64(rsKV, (int)(vo + fco[i] + 64u), 0, SEGMM_ATT_AUX));
         }
         kraw = mkx[kr];                                                     // this lane's key flag (key 16 tl + l15 of the block)
     };
@@ -579,8 +579,8 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? SEGMM_ATT16_WPS : 4) void attn_b
                 if (i < QC * (DH / 4) && q < nq) {
                     const size_t row = (size_t)b * p.Lq + q0 + q;
                     const uint32_t qo = (uint32_t)row * ldq2b + p32_chunk_off(col0 + c);
-                    qh[u] = __builtin_bit_cast(u32x2a, __builtin_amdgcn_raw_buffer_load_b64(rsQ, (int)qo, 0, 0));
-                    ql[u] = __builtin_bit_cast(u32x2a, __builtin_amdgcn_raw_buffer_load_b64(rsQ, (int)(qo + 64u), 0, 0));
+                    qh[u] = __builtin_bit_cast(u32x2a, __builtin_amdgcn_raw_buffer_load_b64(rsQ, (int)qo, 0, SEGMM_ATT_AUX));
+                    ql[u] = __builtin_bit_cast(u32x2a, __builtin_amdgcn_raw_buffer_load_b64(rsQ, (int)(qo + 64u), 0, SEGMM_ATT_AUX));
                     vo[u] = *(const f32x4*)(p.dO + row * p.lddo + col0 + c);
                     oo[u] = *(const f32x4*)(p.O + row * p.ldo + col0 + c);
                 }

@@ -26,6 +26,48 @@ int segmm_fail(int code, const char* fmt, ...);
 
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
+// ---- streaming row traffic.  The row kernels read and write every byte once; with the default cache policy those bytes pass through
+// the XCD's L2 like anything else and push out the operand panels of the GEMMs that run beside them on the other stream.
+// SEGMM_ROW_NT: 0 default policy, 1 nontemporal loads / stores for the LayerNorm kernels' fp32 rows, 2 also for the L1 normalisation,
+// the column sums and the split-K combine (plane outputs stay cacheable: the next GEMM reads them at once)
+#ifndef SEGMM_ROW_NT
+#define SEGMM_ROW_NT 2
+#endif
+#ifndef SEGMM_ATT_AUX
+#define SEGMM_ATT_AUX 0          // probe: cache policy of the planes-in attention kernels' operand loads (2 nt)
+#endif
+#ifndef SEGMM_E_AUX
+#define SEGMM_E_AUX 0          // probe: cache policy of the GEMM epilogue's extra-operand loads (2 nt)
+#endif
+__device__ __forceinline__ f32x4 ld_row4(const float* p) {
+#if SEGMM_ROW_NT >= 1
+    return __builtin_nontemporal_load((const f32x4*)p);
+#else
+    return *(const f32x4*)p;
+#endif
+}
+__device__ __forceinline__ void st_row4(float* p, f32x4 v) {
+#if SEGMM_ROW_NT >= 1
+    __builtin_nontemporal_store(v, (f32x4*)p);
+#else
+    *(f32x4*)p = v;
+#endif
+}
+__device__ __forceinline__ f32x4 ld_row4b(const float* p) {
+#if SEGMM_ROW_NT >= 2
+    return __builtin_nontemporal_load((const f32x4*)p);
+#else
+    return *(const f32x4*)p;
+#endif
+}
+__device__ __forceinline__ void st_row4b(float* p, f32x4 v) {
+#if SEGMM_ROW_NT >= 2
+    __builtin_nontemporal_store(v, (f32x4*)p);
+#else
+    *(f32x4*)p = v;
+#endif
+}
+
 // ---------------------------------------------------------------- counter-based dropout stream
 // Dropout masks are a pure function of (seed, site, element index), so the backward kernels
 // regenerate them instead of storing them.  The generator is a stateless integer hash (two chained

@@ -240,14 +240,14 @@ __global__ __launch_bounds__(256) void splitk_reduce(const float* __restrict__ s
          i += (long long)gridDim.x * blockDim.x) {
         const int m = (int)(i / n4), n = (int)(i % n4) << 2;
         const float* p0 = slabs + (size_t)m * N + n;
-        f32x4 s = *(const f32x4*)p0;
+        f32x4 s = ld_row4b(p0);
         int z = 1;
         for (; z + 4 <= splits; z += 4) {          // four slab loads in flight, summed in slab order
-            const f32x4 a = *(const f32x4*)(p0 + (size_t)z * slab_stride), b = *(const f32x4*)(p0 + (size_t)(z + 1) * slab_stride);
-            const f32x4 c = *(const f32x4*)(p0 + (size_t)(z + 2) * slab_stride), d = *(const f32x4*)(p0 + (size_t)(z + 3) * slab_stride);
+            const f32x4 a = ld_row4b(p0 + (size_t)z * slab_stride), b = ld_row4b(p0 + (size_t)(z + 1) * slab_stride);
+            const f32x4 c = ld_row4b(p0 + (size_t)(z + 2) * slab_stride), d = ld_row4b(p0 + (size_t)(z + 3) * slab_stride);
             s += a; s += b; s += c; s += d;
         }
-        for (; z < splits; ++z) s += *(const f32x4*)(p0 + (size_t)z * slab_stride);
+        for (; z < splits; ++z) s += ld_row4b(p0 + (size_t)z * slab_stride);
         float* c = C + (size_t)m * ldc + n;
         if (accumulate) s += *(const f32x4*)c;
         *(f32x4*)c = s;

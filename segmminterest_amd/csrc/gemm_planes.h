@@ -58,6 +58,9 @@ constexpr int PSTAGE = (PBM + PBN) * 128;      // bytes per stage
 __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t r, void* lds_wave_base, uint32_t voff, uint32_t soff) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, (int)soff, 0, 0);
 }
+__device__ __forceinline__ void lds_dma16e(__amdgpu_buffer_rsrc_t r, void* lds_wave_base, uint32_t voff, uint32_t soff) {          // the epilogue's extra operand: read once
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, (int)soff, 0, SEGMM_E_AUX);
+}
 __device__ __forceinline__ void dma_wait_barrier() {
     __builtin_amdgcn_sched_barrier(0);          // MFMAs are register-only: without this the scheduler sinks them below the barrier
 #ifndef SEGMM_PROBE_BAR          // timing probes only (results are wrong): 1 no s_barrier, 2 no DMA wait, 3 neither

@@ -364,7 +364,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pl_nt4(const GemmArgs p, const PG
                 const int er = aux_r ? gmR : (periodic ? gmR % p.res_period : gmR);
                 const int ch = lane ^ (R & 15);
                 const uint32_t vo = (ch < 16 * NJ && n0 + 4 * ch < p.N) ? (uint32_t)ch * 16u : BUF_OOB;
-                lds_dma16(rsE, dst + slot * 1024, vo, ((uint32_t)er * (uint32_t)ldE + (uint32_t)n0) * 4u);
+                lds_dma16e(rsE, dst + slot * 1024, vo, ((uint32_t)er * (uint32_t)ldE + (uint32_t)n0) * 4u);
             }
         };
         auto vmwait = [&](int kind) {          // kind 0: 8 newer ops; 1: S + 8; 2: S newer ops, S = 8 ns store instructions of the last quarter
@@ -475,7 +475,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pl_nt4(const GemmArgs p, const PG
                         const bool oddl = (l15 & 1) != 0;
                         const uint32_t r0 = dpp_swap1(oddl ? h0 : l0), r1 = dpp_swap1(oddl ? h1 : l1);
                         const u32x4_t w = oddl ? u32x4_t{r0, r1, l0, l1} : u32x4_t{h0, h1, r0, r1};
-                        buf_store4u(rsPl, oPlT, (uint32_t)(16 * i + 4 * t) * (uint32_t)q.ldc2 * 2u, w);
+                        buf_store4u_aux<SEGMM_PLANE_AUX>(rsPl, oPlT, (uint32_t)(16 * i + 4 * t) * (uint32_t)q.ldc2 * 2u, w);
                     }
                 }
                 if (has_e && (i & 1) == 1 && i < 5) {          // both row blocks of the quarter are read: refill its half with quarter + 2

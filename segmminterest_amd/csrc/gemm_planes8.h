@@ -58,6 +58,9 @@ typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 #ifndef SEGMM_STORE_AUX
 #define SEGMM_STORE_AUX 2          // 0 default policy, 1 sc0, 2 nt, 16 sc1
 #endif
+#ifndef SEGMM_PLANE_AUX
+#define SEGMM_PLANE_AUX SEGMM_STORE_AUX          // probe: cache policy of the plane OUTPUT stores (the next GEMM / attention reads them at once)
+#endif
 template <int AUX>
 __device__ __forceinline__ void buf_store4u_aux(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, u32x4_t v) {
     __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, (int)soff, AUX);
@@ -380,7 +383,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_nt8(const GemmArgs p, const PG
                 const int er = aux_r ? gmR : (periodic ? gmR % p.res_period : gmR);
                 const int ch = lane ^ (R & 15);
                 const uint32_t vo = (ch < 16 * NJ && n0 + 4 * ch < p.N) ? (uint32_t)ch * 16u : BUF_OOB;
-                lds_dma16(rsE, dst + slot * 1024, vo, ((uint32_t)er * (uint32_t)ldE + (uint32_t)n0) * 4u);
+                lds_dma16e(rsE, dst + slot * 1024, vo, ((uint32_t)er * (uint32_t)ldE + (uint32_t)n0) * 4u);
             }
         };
         auto vmwait = [&](int kind) {          // kind 0: 8 newer ops; 1: S + 8; 2: S newer ops, S = 8 ns store instructions of the last quarter
@@ -493,7 +496,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_nt8(const GemmArgs p, const PG
                         const bool oddl = (l15 & 1) != 0;
                         const uint32_t r0 = dpp_swap1(oddl ? h0 : l0), r1 = dpp_swap1(oddl ? h1 : l1);
                         const u32x4_t w = oddl ? u32x4_t{r0, r1, l0, l1} : u32x4_t{h0, h1, r0, r1};
-                        buf_store4u(rsPl, oPlT, (uint32_t)(16 * i + 4 * t) * (uint32_t)q.ldc2 * 2u, w);
+                        buf_store4u_aux<SEGMM_PLANE_AUX>(rsPl, oPlT, (uint32_t)(16 * i + 4 * t) * (uint32_t)q.ldc2 * 2u, w);
                     }
                 }
                 if (has_e && (i & 1) == 1 && i < 5) {          // both row blocks of the quarter are read: refill its half with quarter + 2

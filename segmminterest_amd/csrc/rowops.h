@@ -5,7 +5,6 @@
 #include "common.h"
 
 namespace segmm {
-
 constexpr int ROW_MAXV = 8;      // float4 per lane kept in registers => d <= 2048
 
 // ---------------------------------------------------------------- a1: x / (sum|x| + 1e-6)
@@ -56,7 +55,7 @@ __global__ __launch_bounds__(256) void l1norm_reg_kernel(const float* __restrict
     for (int i = 0; i < V; ++i) {
         const int c = lane * 4 + i * 256;
         v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (c < D) { v[i] = *(const f32x4*)(xr + c); s += fabsf(v[i].x) + fabsf(v[i].y) + fabsf(v[i].z) + fabsf(v[i].w); }
+        if (c < D) { v[i] = ld_row4b(xr + c); s += fabsf(v[i].x) + fabsf(v[i].y) + fabsf(v[i].z) + fabsf(v[i].w); }
     }
     s = wave_sum(s);
     const float inv = 1.0f / (s + 1e-6f);
@@ -71,7 +70,7 @@ __global__ __launch_bounds__(256) void l1norm_reg_kernel(const float* __restrict
             if (c < D) {
                 f32x4 o = v[i];
                 o.x /= den; o.y /= den; o.z /= den; o.w /= den;
-                if (y) *(f32x4*)(y + row * D + c) = o;
+                if (y) st_row4b(y + row * D + c, o);
                 if (ps > 0.f) plane_store4_pair(po.p, po.ld2, row, c, o, ps);
                 am = absmax4(am, o);
             }
@@ -105,7 +104,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     for (int i = 0; i < V; ++i) {
         const int c = lane * 4 + i * 256;
         v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (c < d) { v[i] = *(const f32x4*)(xr + c); s += v[i].x + v[i].y + v[i].z + v[i].w; }
+        if (c < d) { v[i] = ld_row4(xr + c); s += v[i].x + v[i].y + v[i].z + v[i].w; }
     }
     if (y == nullptr) {
         // PLANES ONLY (no fp32 copy a consumer could fall back on): the planes are written with the scale of the output's BOUND,
@@ -138,7 +137,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
         if (c < d) {
             f32x4 o = (v[i] - mean) * rstd * *(const f32x4*)(gamma + c) + *(const f32x4*)(beta + c);
             if (drop.p > 0.f) o = drop_apply4(drop, ((uint64_t)row * d + c) >> 2, o);
-            if (y) *(f32x4*)(y + row * d + c) = o;
+            if (y) st_row4(y + row * d + c, o);
             if (ps > 0.f) plane_store4_pair(po.p, po.ld2, row, c, o, ps);
             am = absmax4(am, o);
             if (dot_w) {
@@ -196,9 +195,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
             const int c = lane * 4 + i * 256;
             g[i] = f32x4{0.f, 0.f, 0.f, 0.f}; xh[i] = g[i];
             if (c < d) {
-                f32x4 t = dy_col ? *(const f32x4*)(dy_col + c) * dy[row] : *(const f32x4*)(dy + row * d + c);
+                f32x4 t = dy_col ? *(const f32x4*)(dy_col + c) * dy[row] : ld_row4(dy + row * d + c);
                 if (drop_y.p > 0.f) t = drop_apply4(drop_y, ((uint64_t)row * d + c) >> 2, t);
-                xh[i] = (*(const f32x4*)(x + row * d + c) - mu) * rs;
+                xh[i] = (ld_row4(x + row * d + c) - mu) * rs;
                 ab[i] += t;
                 ag[i] += t * xh[i];
                 g[i] = t * gm[i];
@@ -214,11 +213,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
             const int c = lane * 4 + i * 256;
             if (c < d) {
                 const f32x4 o = (g[i] - s1 - xh[i] * s2) * rs;
-                *(f32x4*)(dx + row * d + c) = o;
+                st_row4(dx + row * d + c, o);
                 f32x4 od = o;
                 if (dx_drop) {
                     if (drop_branch.p > 0.f) od = drop_apply4(drop_branch, ((uint64_t)row * d + c) >> 2, o);
-                    *(f32x4*)(dx_drop + row * d + c) = od;
+                    st_row4(dx_drop + row * d + c, od);
                 }
                 if (ps > 0.f) plane_store4_pair(po.p, po.ld2, row, c, od, ps);
                 as[i] += od;
@@ -267,7 +266,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (n < N) {
         for (long long r = r0 + ty; r < r1; r += 4) {
-            f32x4 v = *(const f32x4*)(X + r * ld + n);
+            f32x4 v = ld_row4b(X + r * ld + n);
             if (w) v *= w[r];
             acc += v;
         }
@@ -312,7 +311,7 @@ __global__ __launch_bounds__(256) void colsum_partial3_kernel(Colsum3 a, int ld,
     const long long r1 = min(M, r0 + rows_per_chunk);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (n < N)
-        for (long long r = r0 + ty; r < r1; r += 4) acc += *(const f32x4*)(X + r * ld + n);
+        for (long long r = r0 + ty; r < r1; r += 4) acc += ld_row4b(X + r * ld + n);
     red[ty][tx] = acc;
     __syncthreads();
     if (ty == 0 && n < N)
