@@ -581,19 +581,19 @@ def main():
                                                     "launches_per_step": v[2] / psteps} for k, v in by.items()}
         if prof and "roofline" not in rec:
             flops = sum(2.0 * M * Nn * K for (_, M, Nn, K, _, _) in prof)
-            K_typ = max((K for (lay, _, _, K, _, _) in prof if lay == 10), default=768)          # contraction width of the NT launches
+            K_typ = max((K for (lay, _, Nn_, K, _, _) in prof if lay == 10 and Nn_ >= 768), default=512)          # contraction width of the NT launches
 
             def tn_gen(M, Nn):          # ... and which TN generation (knob TN_VAR: 8 = round-6 kernel for few-tile / 128-row matrices)
                 v = hipabi.knob("TN_VAR")
                 f8, f4 = M % 256 == 0 and Nn % 256 == 0, M % 128 == 0 and Nn % 256 == 0
-                few = ((M + 255) // 256) * ((Nn + 255) // 256) <= 9
+                few = ((M + 255) // 256) * ((Nn + 255) // 256) <= 9 and M >= 768 and Nn >= 768
                 if f4 and (v == 4 or (v == 8 and (few or not f8))):
                     return 4
                 return 8 if f8 and v in (4, 8, 88) else 0
 
-            def nt_gen(K):          # which NT kernel generation capi.hip picks (knob PL_VAR: 4 = round-6 kernel for K >= 768)
+            def nt_gen(K, Nn=768):          # which NT kernel generation capi.hip picks (knob PL_VAR: 4 = round-6 kernel for K >= 768 and N >= 768)
                 v = hipabi.knob("PL_VAR")
-                return 4 if (v == 44 or (v == 4 and K >= 768)) else 8 if v in (4, 8) else v
+                return 4 if (v == 44 or (v == 4 and K >= 768 and Nn >= 768)) else 8 if v in (4, 8, 44) else v
             if os.environ.get("SEGMM_DUMP_GEMMS"):          # per-shape table of the instrumented pass (diagnostic)
                 agg = {}
                 for (lay, M, Nn, K, e0, e1) in prof:
@@ -655,7 +655,7 @@ def main():
             fam = {}
             for (lay, M, Nn, K, e0, e1) in prof:
                 if lay >= 10:
-                    name = "gemm_pl_" + ("nt", "nn", "tn")[lay % 10] + str(tn_gen(M, Nn) if lay == 12 else nt_gen(K)) + (" (+ splitk_reduce share excluded)" if lay == 12 else "")
+                    name = "gemm_pl_" + ("nt", "nn", "tn")[lay % 10] + str(tn_gen(M, Nn) if lay == 12 else nt_gen(K, Nn)) + (" (+ splitk_reduce share excluded)" if lay == 12 else "")
                 else:
                     name = "gemm_split_mfma/" + ("nt", "nn", "tn")[lay % 10]
                 a = fam.setdefault(name, [0, 0.0, 0.0])

@@ -119,7 +119,7 @@ static Knob g_knobs[K_COUNT] = {
     {"ATT_HPB_DKV", 0, "dK/dV kernel workgroup shape, as above"},
     {"L1NORM_REG", 1, "L1 normalisation with the row held in registers"},
     {"GEMM_BN", 0, "on-the-fly GEMM: tile width override (0: built-in choice)"},
-    {"PL_VAR", 4, "plane NT GEMM: 4 gemm_pl_nt4 (round 6: 128 x 256 tiles, two workgroups per CU) for K >= 768, gemm_pl_nt8 below; 44 gemm_pl_nt4 always; 8 gemm_pl_nt8 (round 3); 1: the round-2 fallback kernel for every launch"},
+    {"PL_VAR", 4, "plane NT GEMM: 4 gemm_pl_nt4 (round 6: 128 x 256 tiles, two workgroups per CU) for K >= 768 and N >= 768, gemm_pl_nt8 otherwise; 44 gemm_pl_nt4 always; 8 gemm_pl_nt8 (round 3); 1: the round-2 fallback kernel for every launch"},
     {"PL_NJ", 0, "plane NT GEMM: tile width in 64-column units (0: modelled choice)"},
     {"TN_VAR", 8, "plane TN GEMM: 8 gemm_pl_tn4 (round 6: 128 x 256 tiles, two workgroups per CU) for few-tile and 128-row matrices, gemm_pl_tn8 (round 3) otherwise; 4 gemm_pl_tn4 wherever it fits; 88 gemm_pl_tn8 wherever it fits; 0: the round-2 fallback kernel for every launch"},
 };
@@ -771,11 +771,11 @@ int segmm_gemm_p(int layout, int M, int N, int K, const uint16_t* a_planes, int 
                               (!c_planes || (long long)M * ldc2 * 2 < lim) &&
                               !(residual && (activation == EPI_DGELU || activation == EPI_DRELU));      // one extra operand per element
             // round 6: 128 x 256 tiles, four waves, two workgroups resident per CU (results bitwise those of gemm_pl_nt8).  Taken for
-            // K >= 768: in the step it wins at configs 2 / 4 / 5 (K = 768 .. 3072: +0.7 % of the step, the NT launches 191 -> 175 us) and
+            // K >= 768 and N >= 768 (config 3's input-gradient GEMMs have K = 2048 .. 3072 but N = 512: they lose on it too): in the step it wins at configs 2 / 4 / 5 (K = 768 .. 3072: +0.7 % of the step, the NT launches 191 -> 175 us) and
             // loses at config 3 (K = 512, N = 512 .. 2048: 195.7 -> 192.3 k interactions/s -- a short k-loop leaves the second resident
             // workgroup less to hide, and gemm_pl_nt8's 192-wide tiles fit N = 512 better) -- profiles/r6/ab_kernel_generations.txt.
             // SEGMM_PL_VAR=44 forces it for every launch (tests, A/B)
-            if (fits && (pl_var == 44 || (pl_var == 4 && K >= 768))) {
+            if (fits && (pl_var == 44 || (pl_var == 4 && K >= 768 && N >= 768))) {
                 g.nbm = (M + P4_BM - 1) / P4_BM; g.nbn = (N + P4_BN - 1) / P4_BN;
                 hipLaunchKernelGGL(gemm_pl_nt4, dim3(g.nbm * g.nbn), dim3(256), 0, s, g, q);
                 LAUNCH_CHECK();
@@ -853,10 +853,11 @@ int segmm_gemm_p(int layout, int M, int N, int K, const uint16_t* a_planes, int 
     // EVERY CU at once, and the main stream's input-gradient GEMM beside it then runs one workgroup per CU next to a weight-gradient
     // workgroup instead of two of its own -- and WINS +0.5 .. 1.5 % when only the few-tile matrices take it (768 x 768: 9 tiles of
     // 256 x 256, 28 splits: short k-loops whose prologue / epilogue the second resident workgroup hides; the row kernels of the step's
-    // tail fit beside them).  Default (TN_VAR 8): gemm_pl_tn4 for at most 9 tiles of 256 x 256 and for matrices that are whole 128-
+    // tail fit beside them).  Default (TN_VAR 8): gemm_pl_tn4 for at most 9 tiles of 256 x 256 of width >= 768 and for matrices that are whole 128-
     // but not 256-row tiles, gemm_pl_tn8 otherwise; 4: gemm_pl_tn4 wherever it fits; 88: gemm_pl_tn8 wherever it fits
     const bool fits8 = M % PBM == 0 && N % PBN == 0 && small_out, fits4 = M % P4_BM == 0 && N % P4_BN == 0 && small_out;
-    const bool few = (long long)((M + PBM - 1) / PBM) * ((N + PBN - 1) / PBN) <= 9;
+    // (few-tile AND at least 768 wide: config 3's d = 512 matrices -- 4 .. 12 tiles -- read 187.9 k/s with gemm_pl_tn4 against 191.7 k/s)
+    const bool few = (long long)((M + PBM - 1) / PBM) * ((N + PBN - 1) / PBN) <= 9 && M >= 768 && N >= 768;
     const bool tn4 = fits4 && (tn_var == 4 || (tn_var == 8 && (few || !fits8)));
     const bool tn8 = !tn4 && fits8 && (tn_var == 8 || tn_var == 88 || tn_var == 4);
     if (tn4) {

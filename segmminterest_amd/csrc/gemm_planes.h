@@ -58,6 +58,12 @@ constexpr int PSTAGE = (PBM + PBN) * 128;      // bytes per stage
 __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t r, void* lds_wave_base, uint32_t voff, uint32_t soff) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, (int)soff, 0, 0);
 }
+#ifndef SEGMM_TN_AUX
+#define SEGMM_TN_AUX 0          // probe: cache policy of the weight-gradient GEMMs' operand loads (2 nt)
+#endif
+__device__ __forceinline__ void lds_dma16t(__amdgpu_buffer_rsrc_t r, void* lds_wave_base, uint32_t voff, uint32_t soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, (int)soff, 0, SEGMM_TN_AUX);
+}
 __device__ __forceinline__ void lds_dma16e(__amdgpu_buffer_rsrc_t r, void* lds_wave_base, uint32_t voff, uint32_t soff) {          // the epilogue's extra operand: read once
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, (int)soff, 0, SEGMM_E_AUX);
 }

@@ -575,7 +575,11 @@ __device__ __forceinline__ u32x4_t rsrc_words(const void* p, uint32_t bytes) {
 }
 __device__ __forceinline__ void lds_dma16_asm(u32x4_t r, const void* lds_wave_base, uint32_t voff, uint32_t soff) {
     const uint32_t la = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)lds_wave_base;
+    #if SEGMM_TN_AUX == 2
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen nt lds" :: "v"(voff), "s"(r), "s"(la), "s"(soff) : "memory");
+#else
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" :: "v"(voff), "s"(r), "s"(la), "s"(soff) : "memory");
+#endif
 }
 __device__ __forceinline__ f32x4 lds_tr8s(const char* a, int stride4) {          // 8 tokens (two 4-token blocks, stride4 bytes apart) of this lane's feature
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a);

@@ -618,13 +618,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pl_tn8(const GemmArgs p, const PG
         char* st = smem + (kt & 1) * PSTAGE + t0 * 1024;
         const uint32_t so = (uint32_t)(kbeg + kt * 32 + t0) * (uint32_t)q.A.ld2 * 2u + (uint32_t)m0 * 4u;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) lds_dma16(rsA, st + i * 1024, inrow0 ^ (uint32_t)(i << 6), so + (uint32_t)i * (uint32_t)q.A.ld2 * 2u);
+        for (int i = 0; i < 4; ++i) lds_dma16t(rsA, st + i * 1024, inrow0 ^ (uint32_t)(i << 6), so + (uint32_t)i * (uint32_t)q.A.ld2 * 2u);
     };
     auto dmaB_pl = [&](int kt) {
         char* st = smem + (kt & 1) * PSTAGE + 32768 + t0 * 1024;
         const uint32_t so = (uint32_t)(kbeg + kt * 32 + t0) * (uint32_t)q.B.ld2 * 2u + (uint32_t)n0 * 4u;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) lds_dma16(rsB, st + i * 1024, inrow0 ^ (uint32_t)(i << 6), so + (uint32_t)i * (uint32_t)q.B.ld2 * 2u);
+        for (int i = 0; i < 4; ++i) lds_dma16t(rsB, st + i * 1024, inrow0 ^ (uint32_t)(i << 6), so + (uint32_t)i * (uint32_t)q.B.ld2 * 2u);
     };
     dmaA_pl(0);
     dmaB_pl(0);
