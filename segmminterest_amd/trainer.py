@@ -154,6 +154,10 @@ class FusedAdamW:
 
     def step_range(self, start, end, gbuf=None):
         st = self._state()
+        if self.__dict__.get("device_state", False) and self.__dict__.get("_step_state") is not None:
+            # the bound step state is a process-global host pointer read when a launch is MADE; a direct opt.step() /
+            # step_range() between two trainers' steps must not pick up the other trainer's seed words and bias corrections
+            H.step_bind(self._step_state)
         if end > start:
             # device_state: the bias corrections come from the device-side step count (segmm_step_advance), step = -1
             H.adamw(st.flat, st.gflat if gbuf is None else gbuf, self.m, self.v, end - start, self.lr, self.betas[0], self.betas[1],
@@ -573,6 +577,14 @@ class Trainer:
             E.join_aux(self.model._store)
             for _, _, _, _, _, flags in stale:
                 flags.zero_()
+            #  the failed step had already advanced the DEVICE step count (segmm_step_advance at its head) while
+            # opt.step_count never moved, and THIS step has advanced it once more: put it back to step_count + 1, the number of the
+            # step that is running, so its bias corrections are right again.  What cannot be taken back and is accepted: the failed step's early pass applied one g = 0 AdamW
+            # update (weight decay + moment decay) to the table rows outside its batch.
+            if self.device_state:
+                H.step_bind(self._step_state)
+                seed, _, _ = H.step_get()
+                H.step_set(seed, self.opt.step_count + 1, *self.opt.betas)
         if self.comm.active or not self.table_two_pass or self._param_hooks():
             return
         model, st = self.model, self.model._store

@@ -812,3 +812,57 @@ def test_step_schedule_knobs_do_not_change_the_step(device_state):
     for x, y in zip(a, b):
         assert torch.equal(x, y)
 
+
+
+@pytest.mark.gpu
+def test_failed_step_after_the_early_table_pass_leaves_the_step_counts_aligned():
+    """a step that fails between the early table pass and opt.step() (here: a forward that raises) has advanced the
+    DEVICE step count but not the host's.  The next step must run with the right count again: after one failed and two good steps
+    the device count equals opt.step_count, and the parameters of the rows that DID get gradients follow the bias corrections of
+    steps 1 and 2 (they equal a trainer that never failed, except for the one extra weight-decay pass on the rows outside the
+    failed batch, which is documented as accepted)."""
+    import torch
+    from segmminterest_amd import hipabi as H
+    from segmminterest_amd.synth import make_batch
+    from segmminterest_amd.trainer import Trainer, default_args, init_model
+    dev = torch.device("cuda:0")
+    B, S, D, N, h = 32, 20, 64, 2, 4
+    margs = default_args(num_layers_enc=N, d_model=D, nhead=h, input_type={"user": "id", "photo": "id"}, exposure_prob=[1.0] * S)
+    batches = [{k: v.to(dev) for k, v in make_batch(B, S, 1, D, n_users=50, n_items=2000, seed=500 + i, features=False).items()} for i in range(3)]
+
+    def build():
+        torch.manual_seed(4)
+        model = init_model(margs, n_users=50, n_items=2000, input_dim=D, max_vid_len=S, max_usr_len=1).to(dev)
+        return model, Trainer(model, device_state=True, dropout=False)
+
+    model, tr = build()
+    if not tr.table_two_pass:
+        pytest.skip("two-pass table update off")
+    orig = tr._train_step
+
+    def boom(*a, **k):
+        raise RuntimeError("injected forward failure")
+    tr._train_step = boom
+    with pytest.raises(RuntimeError, match="injected"):
+        tr.train_step(batches[0])
+    tr._train_step = orig
+    assert tr.opt.step_count == 0
+    tr.train_step(batches[1])
+    tr.train_step(batches[2])
+    torch.cuda.synchronize()
+    H.step_bind(tr._step_state)
+    _, dev_step, _ = H.step_get()
+    assert tr.opt.step_count == 2 and dev_step == 2, (tr.opt.step_count, dev_step)
+    # a trainer that never failed: the same parameters up to what the one extra g = 0 pass over the item table (weight decay
+    # lr * wd = 1e-7 relative on rows outside the failed batch) propagates into the two steps -- far below one lr step (1e-3);
+    # with the device count left at 3 instead of 2 the bias corrections would move every parameter by ~30 % of a step
+    model2, tr2 = build()
+    tr2.train_step(batches[1])
+    tr2.train_step(batches[2])
+    torch.cuda.synchronize()
+    st, st2 = model._store, model2._store
+    for n in st.live_names:
+        if st._params[n].dim() < 2 or n.startswith("stage_mlp"):          # (shift-invariant / near-zero-gradient parameters: the sign of a ~0 gradient moves them by +-lr)
+            continue
+        o, k = st.index[n]
+        assert float((st.flat[o:o + k] - st2.flat[o:o + k]).abs().max()) < 1e-4, n
