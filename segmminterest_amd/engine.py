@@ -656,11 +656,15 @@ def _splits_for(M, N, K):
 _SPLIT_TARGET_P = int(os.environ.get("SEGMM_SPLIT_TARGET_P", "256"))     # workgroups a plane-operand weight gradient aims for
 
 
+_SPLIT_TARGET_FEW = int(os.environ.get("SEGMM_SPLIT_TARGET_FEW", "256"))     # ... of the few-tile matrices that take gemm_pl_tn4 (capi.hip: <= 9 tiles, width >= 768)
+
+
 def _splits_for_p(M, N, K):
     """Split-K factor of a plane-operand weight-gradient GEMM (256 x 256 tiles, one workgroup per CU): fill the 256 CUs once."""
     tiles = ((M + 255) // 256) * ((N + 255) // 256)
     ktiles = (K + 31) // 32
-    return max(1, min(64, ktiles, _SPLIT_TARGET_P // tiles if tiles <= _SPLIT_TARGET_P else 1))
+    target = _SPLIT_TARGET_FEW if (tiles <= 9 and M >= 768 and N >= 768) else _SPLIT_TARGET_P
+    return max(1, min(64, ktiles, target // tiles if tiles <= target else 1))
 
 
 @contextlib.contextmanager

@@ -191,3 +191,69 @@ def test_record_pool_hooks_are_checked_before_use(monkeypatch):
     with pytest.raises(RuntimeError, match="train_step"):
         with E.ParamStore.rec_pool(_S(), pool=None):
             pass
+
+
+def test_compute_final_result_matches_the_reference_rule():
+    """compute_final_result (main_for_seq_leave_earlystop_SegMM.py:188-210): LeaveMSE = MSE(view_lengths, predictions), every other list
+    its mean, 'TOP_K' / 'view_lengths' carry no number of their own."""
+    from segmminterest_amd.trainer import compute_final_result
+    rl = {"JaccardSim": [0.5, 1.0], "ProbAUC": [0.75], "LeaveMSE": [2.0, 5.0, 3.0], "view_lengths": [1.0, 5.0, 6.0], "LeaveCTR": [0.1, 0.3],
+          "TOP_K": [], "HR@1": [1.0, 0.0, 0.0, 1.0], "NDCG@5": [0.5]}
+    out = compute_final_result(rl)
+    assert set(out) == {"JaccardSim", "ProbAUC", "LeaveMSE", "LeaveCTR", "HR@1", "NDCG@5"}
+    assert out["LeaveMSE"] == pytest.approx(((1 - 2) ** 2 + 0 + (6 - 3) ** 2) / 3.0)
+    assert out["JaccardSim"] == 0.75 and out["ProbAUC"] == 0.75 and out["HR@1"] == 0.5 and out["NDCG@5"] == 0.5
+    assert out["LeaveCTR"] == pytest.approx(0.2)
+
+
+def test_fit_recorded_chooses_the_step_mode_per_batch():
+    """fit(recorded=True): eager for the first ``eager_steps`` batches, ONE recording step (with the previous batch, so that no extra
+    optimisation step is taken), replays for batches of the recorded shapes, the eager step for a batch of another shape -- and every
+    batch exactly once, in order.  (Host logic only: a stand-in trainer notes what is called.)"""
+    from segmminterest_amd.trainer import fit
+
+    class _Comm:
+        rank = 0
+
+    class _T:
+        device_state, comm = True, _Comm()
+
+        def __init__(self):
+            self.calls = []
+
+        def valid_model(self, batches, metrics, permutation, top_k_mask):
+            return {k: 0.0 for k in metrics}
+
+        def _out(self, kind, b):
+            self.calls.append((kind, int(b["x"][0, 0])))
+            return {"loss": torch.tensor(0.0)}
+
+        def train_step(self, b):
+            return self._out("eager", b)
+
+        def record(self, b, prev_batch=None):
+            assert prev_batch is not None and prev_batch is not b
+            self._recorded = {"spans": {k: (tuple(v.shape), v.dtype) for k, v in b.items()}}
+            return self._out("record", b)
+
+        def run_recorded(self, b):
+            return self._out("replay", b)
+
+    mk = lambda i, rows=4: {"x": torch.full((rows, 3), float(i))}
+    train = [mk(0), mk(1), mk(2), mk(3), mk(4), mk(5, rows=2), mk(6)]
+    t = _T()
+    hist = fit(t, train, [mk(9)], epochs=2, valid_step=100, recorded=True)
+    kinds = [k for k, _ in t.calls]
+    assert [i for _, i in t.calls] == [0, 1, 2, 3, 4, 5, 6] * 2 and hist["global_step"] == 14
+    assert kinds[:7] == ["eager", "eager", "eager", "record", "replay", "eager", "replay"]
+    assert kinds[7:] == ["replay"] * 5 + ["eager", "replay"]
+    with pytest.raises(RuntimeError, match="device_state"):
+        t2 = _T()
+        t2.device_state = False
+        fit(t2, train, [mk(9)], epochs=1, recorded=True)
+
+
+def test_argsort_workspace_words():
+    from segmminterest_amd import hipabi as H
+    assert H.argsort_ws_words(1) == 0 and H.argsort_ws_words(H.ARGSORT_MAX) == 0
+    assert H.argsort_ws_words(H.ARGSORT_MAX + 1) == 2 * H.ARGSORT_MAX and H.argsort_ws_words(16384) == 16384 and H.argsort_ws_words(16385) == 32768
