@@ -463,6 +463,65 @@ def test_attention_fwd_on_input_planes(B, H_, dh, Lq, La, Lb, p, case):
     assert torch.equal(O2, O1) and torch.equal(pl_o, ref_pl) and float(hdr_o[0]) == 2.0 ** 12
 
 
+@pytest.mark.parametrize("H_,dh,Lq,La,Lb,R", [(16, 48, 40, 40, 100, 13), (16, 48, 40, 40, 100, 18), (4, 32, 20, 20, 12, 13),
+                                              (16, 48, 40, 40, 100, -13)])
+def test_attention_fwd_planes_only_with_site_scales_far_apart(H_, dh, Lq, La, Lb, R):
+    e_all, e_row0, share = _scale_gap_errors(H_, dh, Lq, La, Lb, R)
+    assert e_all <= 3e-6, e_all
+    assert e_row0 <= (Lb if R > 0 else La) * 2.0 ** (abs(R) - 37) + 3e-6, (e_row0, share)
+
+
+def _scale_gap_errors(H_, dh, Lq, La, Lb, R):
+    """Planes ONLY (no fp32 views: nothing to restage from) with the two key blocks' site scales 2^|R| apart (R > 0: the user
+    block's K / V are 2^-R of the video block's; R < 0 the other way round).  One accumulator serves both blocks of O = P V: the
+    P terms of the small-magnitude block are split with SP = 2^(14 - |R|), which costs that block's P an ABSOLUTE error of at most
+    2^(|R| - 39) per key -- and its V are 2^-|R| of the other block's, so against the output's maximum the loss is ~L 2^-39 whatever
+    R is.  Checked against fp64: all rows to 3e-6 of the maximum; the rows of batch row 0, whose large-magnitude
+    block is masked out entirely (the output IS the small block's), to L 2^(|R| - 37) + 3e-6 of THEIR maximum.
+    Returns (max error / max |O|, the same over batch row 0 alone, max |O[0]| / max |O|)."""
+    H = _abi()
+    B, d = 3, H_ * dh
+    g = torch.Generator().manual_seed(R * 7 + Lq + 1000)
+    nv, nu = 4, 2
+    fa, fb = (1.0, 2.0 ** -R) if R > 0 else (2.0 ** R, 1.0)
+    Yv = (torch.randn(B * La, nv * d, generator=g) * 0.7).to(DEV)
+    Yu = (torch.randn(B * Lb, nu * d, generator=g) * 0.7).to(DEV)
+    Yv[:, 2 * d:] *= fa          # K / V columns of the video block (the Q columns keep their size: the logits stay O(1) ...
+    Yu *= fb
+    Qs = (torch.randn(B * Lq, nv * d, generator=g) * 0.7).to(DEV)
+    Qs[:, :d] /= fa; Qs[:, d:2 * d] /= fb          # ... because each block's query projection grows as its keys shrink)
+    mq = torch.ones(B, Lq, dtype=torch.bool, device=DEV)
+    mka = (torch.rand(B, La, generator=g) < 0.8).to(DEV)
+    mkb = (torch.rand(B, Lb, generator=g) < 0.7).to(DEV)
+    (mka if R > 0 else mkb)[0] = False          # batch row 0: the large-magnitude block contributes nothing
+    # the Q site holds both projections (one buffer, one scale): give each its own site here so that the scale of Q is not the issue
+    plv, hv = _site_planes(H, Yv[:, 2 * d:].contiguous(), B * La, 2 * d)
+    plu, hu = _site_planes(H, Yu, B * Lb, nu * d)
+    assert max(float(hv[0]) / float(hu[0]), float(hu[0]) / float(hv[0])) >= 2.0 ** (abs(R) - 1)
+    # logits O(1) need |Q| ~ 1 / |K|: Q of the two blocks differ by 2^|R| as well; scale Q's site to its maxima (one site)
+    plq, hq = _site_planes(H, Qs, B * Lq, nv * d)
+    none = lambda off: (None, off)
+    O = torch.full((B * Lq, d), float("nan"), device=DEV)
+    lse = torch.full((2, B, H_, Lq), float("nan"), device=DEV)
+    pin = dict(q=(plq, hq, 2 * nv * d), a=(plv, hv, 2 * 2 * d), b=(plu, hu, 2 * nu * d))
+    H.attn_fwd(B, H_, dh, Lq, La, Lb, none(0), none(d), nv * d, none(0), none(d), 2 * d, none(0), none(d), nu * d, mq, mka, mkb,
+               O, d, lse, drop_p=0.0, seed=11, site=3, pin=pin)
+    assert torch.isfinite(O).all()
+    # fp64 reference on the values the planes hold (hi + lo under the site scale: the operands the kernel was given)
+    def held(pl, hdr, rows, cols):
+        v = pl.view(rows, cols // 32, 2, 32).double()
+        return ((v[:, :, 0] + v[:, :, 1]) / float(hdr[0])).reshape(rows, cols)
+    Qh, Vh, Uh = held(plq, hq, B * Lq, nv * d), held(plv, hv, B * La, 2 * d), held(plu, hu, B * Lb, nu * d)
+    sl = lambda Y, k, L, n: Y.view(B, L, n * d)[:, :, k * d:(k + 1) * d]
+    from test_ops_gpu import _attn_ref
+    ref = _attn_ref(sl(Qh, 0, Lq, nv), sl(Qh, 1, Lq, nv), sl(Vh, 0, La, 2), sl(Vh, 1, La, 2), sl(Uh, 0, Lb, nu), sl(Uh, 1, Lb, nu),
+                    mq, mka, mkb, H_)
+    err = (O.view(B, Lq, d).double() - ref).abs()
+    omax, o0 = float(ref.abs().max()), float(ref[0].abs().max())
+    assert o0 > 0
+    return float(err.max()) / omax, float(err[0].max()) / o0, o0 / omax
+
+
 @pytest.mark.parametrize("B,H_,dh,Lq,La,Lb,p,case", [
     (4, 16, 48, 40, 40, 100, 0.1, "ok"), (3, 16, 48, 40, 40, 100, 0.0, "ok"), (2, 16, 48, 100, 40, 100, 0.1, "ok"),
     (5, 8, 32, 20, 20, 12, 0.1, "ok"), (3, 4, 48, 40, 0, 100, 0.1, "ok"), (3, 4, 48, 40, 40, 0, 0.1, "ok"),
