@@ -42,6 +42,9 @@ constexpr int P4_BRING = 3 * P4_BHALF;                 // 12 KB per wave
 #ifndef P4_EPI_PRIO
 #define P4_EPI_PRIO 3          // wave priority outside the k-loop (prologue, epilogue): their few instructions go in front of the partner workgroup's MFMA stream
 #endif
+#ifndef P4_NGROUP
+#define P4_NGROUP 4          // column tiles per group of the NT tile order (0: one row-major sweep over all column tiles)
+#endif
 #ifndef P4_STAGGER
 #define P4_STAGGER 0          // units of 512 cycles per k-tile that the late half of the first round sleeps (0: no stagger)
 #endif
@@ -73,7 +76,25 @@ __global__ __launch_bounds__(256, 2) void gemm_pl_nt4(const GemmArgs p, const PG
     const int l15 = lane & 15, lq = lane >> 4;
     const int nkt = p.K >> 5;
     const int lb = xcd_remap(blockIdx.x, p.nbm * p.nbn);
-    const int m0 = (lb / p.nbn) * P4_BM, n0 = (lb % p.nbn) * P4_BN;
+    // tile order: groups of P4_NGROUP column tiles, row-major inside a group.  An XCD's 64 resident workgroups then cover
+    // 64 / P4_NGROUP row panels x P4_NGROUP column panels: the B panels of the group (786 KB each at K = 768) stay in its 4 MB L2
+    // while the A panels stream past once per group -- with all 12 column tiles of N = 3072 in one row-major sweep the 9.4 MB of
+    // B fell out of L2 between row panels and was fetched again ~30 times per launch (profiles/r6/gemm4_tile_order.txt).
+    int mt = lb / p.nbn, nt_ = lb - mt * p.nbn;
+    {
+#ifdef SEGMM_GEMM_PROBE
+        const int gc = ((q.dbg >> 20) & 15) ? ((q.dbg >> 20) & 15) - 1 : P4_NGROUP;          // probe: dbg bits 20-23 = group width + 1
+#else
+        constexpr int gc = P4_NGROUP;
+#endif
+        if (gc > 0 && p.nbn > gc) {
+            const int gsz = gc * p.nbm, g = lb / gsz, rem = lb - g * gsz;
+            const int wdt = min(gc, p.nbn - g * gc);
+            mt = rem / wdt;
+            nt_ = g * gc + (rem - mt * wdt);
+        }
+    }
+    const int m0 = mt * P4_BM, n0 = nt_ * P4_BN;
     STAMP(0);
     if (P4_EPI_PRIO) __builtin_amdgcn_s_setprio(P4_EPI_PRIO);
     // ---- REPAIR launch of a planes-only output (see gemm_pl_nt8): usable site -> leave at once, else recompute with the exact scale
