@@ -69,7 +69,9 @@ def gemm_generation(request):
 
 
 # ------------------------------------------------------------------ GEMM kernels
-@pytest.mark.parametrize("M,N,K", [(256, 256, 32), (1024, 768, 768), (300, 96, 64), (20480, 768, 768), (37, 32, 160)])
+# (N > 1024: more than four column tiles of gemm_pl_nt4 -- its grouped tile order, P4_NGROUP, with full, partial and single-tile last groups)
+@pytest.mark.parametrize("M,N,K", [(256, 256, 32), (1024, 768, 768), (300, 96, 64), (20480, 768, 768), (37, 32, 160),
+                                   (640, 1280, 96), (384, 3072, 64), (300, 2304, 768), (130, 1536, 768)])
 def test_gemm_p_nt_matches_fp64_and_on_the_fly(M, N, K):
     H = _abi()
     A, W = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=0.02)
