@@ -1,10 +1,10 @@
 # HBM-side traffic of gemm_pl_nt4 under the tile orders of P4_NGROUP (probe build: dbg bits 20-23 = group width + 1), one shape.
-# usage (GPU box): bash tools/probe/pmc_tile_order.sh [shape] [binary built with -DSEGMM_GEMM_PROBE]
-SHAPE=${1:-NT_20480x3072x768}; BIN=${2:-build/probe/g4_p}
-R=$GRAFT_REPO_ROOT; TAG=r6/tile_order
-mkdir -p $R/gpurun_out/$TAG
+# usage (GPU box): bash tools/probe/pmc_tile_order.sh [shape] [binary built with -DSEGMM_GEMM_PROBE] [group widths, default "0 3 4 6"]
+SHAPE=${1:-NT_20480x3072x768}; BIN=${2:-build/probe/g4_p}; GS=${3:-0 3 4 6}
+R=$GRAFT_REPO_ROOT; TAG=r6/tile_order_$SHAPE
+rm -rf $R/gpurun_out/$TAG; mkdir -p $R/gpurun_out/$TAG
 cd /tmp && export TMPDIR=/tmp
-for G in 0 3 4 6; do
+for G in $GS; do
   D=$(( (G + 1) << 20 ))
   for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
     N=$(echo $C | cut -c1-5)
@@ -15,7 +15,7 @@ cd $R
 python3 - <<PY
 import csv, glob, collections
 print("shape $SHAPE: per launch of gemm_pl_nt4 (FETCH_SIZE KiB x 2 on gfx950, WRITE_SIZE KiB)")
-for G in (0, 3, 4, 6):
+for G in [int(g) for g in "$GS".split()]:
     acc = collections.defaultdict(list)
     for f in glob.glob("gpurun_out/$TAG/g%d_*/**/*counter_collection.csv" % G, recursive=True):
         for r in csv.DictReader(open(f)):
