@@ -99,7 +99,7 @@ static int attn_fill(AttnArgs& a, int B, int H, int dh, int Lq, int La, int Lb, 
 // launch path.  Knobs whose non-default values give WRONG results (timing probes) do not exist in this build: they are compiled
 // in by -DSEGMM_ATT_PROBE / -DSEGMM_GEMM_PROBE only.
 enum {
-    K_ATTN, K_ATT_FWD_PL, K_ATT_FWD_LDS, K_ATT_FWD_KSPLIT, K_ATT_FWD_LDS_PAD, K_ATT_FUSED_LAUNCH, K_ATT_MERGE, K_ATT_LDS_PAD, K_ATT_WAVES, K_ATT_REPAIR_WALK,
+    K_ATTN, K_ATT_FWD_PL, K_ATT_FWD_LDS, K_ATT_FWD_KSPLIT, K_ATT_FWD_LDS_PAD, K_ATT_FUSED_LAUNCH, K_ATT_MERGE, K_ATT_LDS_PAD, K_ATT_WAVES, K_ATT_WAVES_PL, K_ATT_REPAIR_WALK,
     K_ATT_HPB_FWD, K_ATT_HPB_DQ, K_ATT_HPB_DKV, K_L1NORM_REG, K_GEMM_BN, K_PL_VAR, K_PL_NJ, K_TN_VAR, K_COUNT
 };
 struct Knob { const char* name; int value; const char* doc; };
@@ -113,6 +113,7 @@ static Knob g_knobs[K_COUNT] = {
     {"ATT_MERGE", 1, "short heads: one workgroup per head for both key blocks in the fused backward"},
     {"ATT_LDS_PAD", 0, "probe: extra LDS bytes per backward workgroup"},
     {"ATT_WAVES", 4, "fused fp16x3 backward: waves per workgroup (key tiles in passes)"},
+    {"ATT_WAVES_PL", 3, "planes-in fused backward: waves per workgroup, 1..4 (3: 40.7 KB of LDS -> four workgroups per CU for a 100-key block too)"},
     {"ATT_REPAIR_WALK", 512, "planes-in backward, repair launch: workgroups that walk the heads (0: one workgroup per head)"},
     {"ATT_HPB_FWD", 0, "forward workgroup shape heads | tiles << 8 (env: \"heads[,tiles]\"; 0: built-in)"},
     {"ATT_HPB_DQ", 0, "dQ kernel workgroup shape, as above"},
@@ -332,7 +333,11 @@ static int attn_launch_bwd(AttnArgs& a, int phase, hipStream_t s) {
             lds += (size_t)lds_pad;
             if constexpr (DH % 16 == 0 && DH <= 48) {
                 if (a.in.Qa) {          // round 5: Q / K / V from the projection GEMMs' planes (attention_pl.h); always in passes of <= 4 waves
-                    const int nwp = one && nw > 4 ? 4 : nw;
+                    // (single chunk: the key tiles of a block in passes over <= ATT_WAVES_PL waves.  Three: the 7 tiles of a 100-key block as 3 + 3 + 1,
+                    // 40.7 instead of 44.0 KB of LDS -> FOUR workgroups per CU like the 40-key block; same time stand-alone, 494 -> 480 us beside
+                    // the weight-gradient GEMMs of the step, +0.5 % of the step: profiles/r6/att_waves_ab.txt.  Results do not depend on it.)
+                    const int wcap_pl = knob(K_ATT_WAVES_PL) >= 1 && knob(K_ATT_WAVES_PL) <= 4 ? knob(K_ATT_WAVES_PL) : 3;
+                    const int nwp = one && nw > wcap_pl ? wcap_pl : nw;
                     const size_t ldsp = attn_bwd_pl_lds_bytes<DH>(Lq_p, nwp, Tp);
                     const dim3 blockp(64 * nwp);
                     // the repair launch: 512 workgroups that walk the heads (and normally leave at once) instead of one per head

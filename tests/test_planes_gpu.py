@@ -590,6 +590,42 @@ def test_attention_bwd_on_input_planes(B, H_, dh, Lq, La, Lb, p, case):
         assert float((a_ - b_).abs().max()) <= 3e-6 * max(m, 1e-30), (name, float((a_ - b_).abs().max()) / max(m, 1e-30))
 
 
+def test_attention_bwd_on_input_planes_is_independent_of_the_wave_count(request):
+    """Knob ATT_WAVES_PL (waves per workgroup of the single-chunk planes-in backward: a wave walks its key tiles in passes; default 3 =
+    four workgroups per CU): dQ is accumulated in key-tile order whatever wave owns a tile, so 1, 2, 3 and 4 waves give BIT-identical
+    gradients."""
+    H = _abi()
+    prev = H.config_set("ATT_WAVES_PL", 4)
+    request.addfinalizer(lambda: H.config_set("ATT_WAVES_PL", prev))
+    assert prev == 3
+    B, H_, dh, Lq, La, Lb, p = 3, 16, 48, 40, 40, 100, 0.1
+    d = H_ * dh
+    g = torch.Generator().manual_seed(77)
+    nv, nu = 4, 2
+    Yv = (torch.randn(B * La, nv * d, generator=g) * 0.7).to(DEV)
+    Yu = (torch.randn(B * Lb, nu * d, generator=g) * 0.7).to(DEV)
+    mq = (torch.rand(B, Lq, generator=g) < 0.8).to(DEV)
+    mkb = (torch.rand(B, Lb, generator=g) < 0.7).to(DEV)
+    plv, hv = _site_planes(H, Yv, Yv.shape[0], nv * d)
+    plu, hu = _site_planes(H, Yu, Yu.shape[0], nu * d)
+    pin = dict(q=(plv, hv, 2 * nv * d), a=(plv, hv, 2 * nv * d), b=(plu, hu, 2 * nu * d))
+    views = ((Yv, 0), (Yv, d), nv * d, (Yv, 2 * d), (Yv, 3 * d), nv * d, (Yu, 0), (Yu, d), nu * d)
+    O = torch.empty(B * Lq, d, device=DEV); lse = torch.empty(2, B, H_, Lq, device=DEV)
+    H.attn_fwd(B, H_, dh, Lq, La, Lb, *views, mq, mq, mkb, O, d, lse, drop_p=p, seed=11, site=3, pin=pin)
+    dO = torch.randn(B * Lq, d, generator=g).to(DEV)
+    Dv = torch.empty(B * H_ * Lq, device=DEV)
+    outs = []
+    for w in (4, 3, 2, 1):
+        H.config_set("ATT_WAVES_PL", w)
+        dYv, dYu = torch.full_like(Yv, float("nan")), torch.full_like(Yu, float("nan"))
+        H.attn_bwd(B, H_, dh, Lq, La, Lb, *views, mq, mq, mkb, lse, O, d, dO, d, Dv, (dYv, 0), (dYv, d), nv * d, (dYv, 2 * d), (dYv, 3 * d),
+                   nv * d, (dYu, 0), (dYu, d), nu * d, drop_p=p, seed=11, site=3, phase=4, pin=pin)
+        assert torch.isfinite(dYv).all() and torch.isfinite(dYu).all()
+        outs.append((dYv, dYu))
+    for dYv, dYu in outs[1:]:
+        assert torch.equal(dYv, outs[0][0]) and torch.equal(dYu, outs[0][1])
+
+
 @pytest.mark.parametrize("B,H_,bad,walk,La,Lb", [(40, 16, 2.0 ** 30, 512, 40, 100), (40, 16, 2.0 ** -30, 512, 40, 100), (3, 16, 2.0 ** 30, 512, 40, 100),
                                                   (3, 16, 2.0 ** 30, 2, 40, 100), (5, 16, 2.0 ** -30, 6, 40, 100), (36, 16, 2.0 ** 30, 512, 100, 40),
                                                   (2, 16, 2.0 ** -30, 4, 100, 40)])
