@@ -44,7 +44,11 @@ class InteractionAggregation(_FusedOnly):
 
 
 class LossSpec:
-    """Static description of ``compute_loss`` for one model_cfg (decoder_leave_focal.py:490-572)."""
+    """Static description of ``compute_loss`` for one model_cfg (decoder_leave_focal.py:490-572).
+
+    One difference in error behaviour: a batch in which EVERY row is fully watched has no BPR negative -- the reference raises there
+    (``neg_pred.max()`` of an empty tensor, decoder_leave_focal.py:213); the device-side loss returns ``interestBPR`` = 0 with zero
+    gradients (it has no host synchronisation to raise from)."""
 
     def __init__(self, model_cfg, S_hint=40):
         lst = list(model_cfg.loss_type_list)

@@ -322,6 +322,68 @@ def test_full_width_config_vs_oracle(B, S, Lt, D, N):
             assert float((p.grad.cpu() - rgrads[k]).abs().max()) <= 5e-5 * scale + 1e-7, k
 
 
+@pytest.mark.parametrize("B", [4, 1])
+def test_edge_rows_vs_oracle(B):
+    """Rows at the ends of the input domain, BASELINE config 2's widths (d = 768, h = 16, S = 40, Lt = 100, N = 2), against the CPU oracle:
+    a user with NO history tokens (every user key padded: the video queries' cross-attention block is all -10000), a two-segment video
+    left in its first segment, a fully watched video of maximum length with a full history, a maximum-length video left in its last
+    segment -- and a batch of ONE row.  Two passes: the first runs every tensor site uncalibrated (exact scales, fp32 operands), the
+    second on the delayed scales and the planes-in attention kernels."""
+    import argparse
+    import segmm_oracle as O
+    import segmminterest_amd as M
+    from segmminterest_amd.synth import make_batch, l1_normalize
+    S, Lt, D, N = 40, 100, 768, 2
+    torch.manual_seed(0)
+    args = argparse.Namespace(debug=0, num_layers_enc=N, ablation_type="ours", d_model=D, nhead=16,
+                              input_type={"user": "image", "photo": "image"}, learnable_bias=0, exposure_prob=[1.0] * S,
+                              fusion_heads=2, loss_type_list=["interestBPR"], loss_weight={"interestBPR": 1.0, "mse": 1.0}, mask_loss=0)
+    bb = M.SegFormerX(d_model_in=D, d_model_lvls=[D] * N, num_head_lvls=[16] * N, ff_dim_lvls=[D] * N, input_vid_dim=D,
+                      input_usr_dim=D, max_vid_len=S, max_usr_len=Lt, sr_ratio_lvls=[1] * N, use_patch_merge=[False] * N,
+                      output_layers=[-1], model_cfg=args)
+    model = M.MultiScaleTemporalDetrLeaveFocal(bb, None, None, torch.nn.Identity(), args)
+    with torch.no_grad():
+        for n_, p in model.named_parameters():
+            if p.dim() == 2 and "proj" in n_ and "backbone1.vid_proj" not in n_ and "backbone1.usr_proj" not in n_:
+                p.mul_(2.0)
+            if n_.endswith("vid_proj.weight") or n_.endswith("usr_proj.weight"):
+                p.mul_(100.0)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    b = make_batch(4, S, Lt, D, seed=11)
+    pos = torch.arange(S)
+    lab = b["label"]
+    # row 0: no user history at all (an ordinary video)
+    b["user_mask"][0] = False; b["user"][0] = 0.0
+    # row 1: two segments, left in the first
+    lab[1] = torch.where(pos == 0, 0, torch.where(pos == 1, -1, -2))
+    # row 2: fully watched, maximum length, full history
+    lab[2] = 1; b["user_mask"][2] = True; b["user"][2] = torch.rand(Lt, D, generator=torch.Generator().manual_seed(5))
+    # row 3: maximum length, left in the last segment
+    lab[3] = torch.where(pos == S - 1, 0, 1)
+    b["photo_mask"] = lab != -2
+    b["photo"] = torch.rand(4, S, D, generator=torch.Generator().manual_seed(6)) * b["photo_mask"][:, :, None]
+    sel = slice(3, 4) if B == 1 else slice(0, 4)          # (a batch of fully watched rows only has no BPR negative: the reference raises)
+    inp = dict(usr_image=l1_normalize(b["user"])[sel], usr_id=b["user_identity_id"][sel], usr_mask=b["user_mask"][sel],
+               vid_image=l1_normalize(b["photo"])[sel], vid_id=b["photo_identity_id"][sel], vid_mask=b["photo_mask"][sel], gt=lab[sel])
+    cfg = dict(N=N, h=16, S=S, user="image", photo="image", loss_type_list=["interestBPR"], loss_weight={"interestBPR": 1.0, "mse": 1.0},
+               exposure_prob=[1.0] * S)
+    ref, rgrads = O.forward_backward(sd, cfg, inp)
+    assert torch.isfinite(ref["logits"]).all() and torch.isfinite(ref["loss"]).all()
+    model = model.cuda().eval()
+    for it in range(2):
+        model.zero_grad(set_to_none=True)
+        out = call_model(model, inp, "train", DEV)
+        assert (out["logits"].cpu() - ref["logits"].detach()).abs().max().item() < 1e-4, it
+        assert abs(float(out["loss"].detach()) - float(ref["loss"].detach())) < 1e-4, it
+        out["loss"].backward()
+        for k, p in model.named_parameters():
+            if rgrads[k] is None:
+                assert p.grad is None, (it, k)
+            else:
+                scale = max(float(rgrads[k].abs().max()), 1e-7)
+                assert float((p.grad.cpu() - rgrads[k]).abs().max()) <= 5e-5 * scale + 1e-7, (it, k)
+
+
 def _ref_args(N, d, h, S, user, photo):
     import argparse
     return argparse.Namespace(debug=0, num_layers_enc=N, ablation_type="ours", d_model=d, nhead=h,
