@@ -23,6 +23,7 @@ from typing import Dict, List, Optional
 
 import os
 
+import ctypes
 import torch
 import torch.nn as nn
 
@@ -940,9 +941,57 @@ class Trainer:
                               hyper=(self.opt.lr, self.opt.wd, tuple(self.opt.betas), self.opt.eps))
         return out
 
-    def run_recorded(self, batch: Dict[str, torch.Tensor]):
+    def _timed_plan(self, r):
+        """The recorded phases cut at every GEMM / attention command (bench.py's timed replay): [("host", fn) | ("run", Phase) |
+        ("timed", Phase of ONE command, stream slot, record)], record = the tuple hipabi's GEMM_PROFILE / ATTN_PROFILE entries
+        start with.  The sub-phases alias the recorded command arrays (the per-step re-basing of batch pointers reaches them)."""
+        plan = r.get("timed_plan")
+        if plan is not None:
+            return plan
+        names = {v: k for k, v in H.op_ids().items()}
+        plan = []
+        for ph, arr in r["phases"]:
+            if arr is None:
+                plan.append(("host", ph))
+                continue
+            def sub(lo, hi, ph=ph, arr=arr):
+                return H.Phase(kind=ph.kind, backbone=ph.backbone, layer=ph.layer, n_cmds=hi - lo,
+                               cmds=ctypes.cast(ctypes.byref(arr, lo * ctypes.sizeof(H.Cmd)), ctypes.POINTER(H.Cmd)))
+            lo = 0
+            for ci in range(ph.n_cmds):
+                c = arr[ci]
+                nm = names.get(c.op)
+                rec = None
+                if nm == "segmm_gemm_p":
+                    if not (c.a[20].i & 2):          # (a repair launch does no work normally: not a GEMM of the roofline)
+                        rec = ("gemm", (10 + c.a[0].i, c.a[1].i, c.a[2].i, c.a[3].i))
+                elif nm in ("segmm_gemm", "segmm_gemm_h"):
+                    rec = ("gemm", (c.a[0].i, c.a[1].i, c.a[2].i, c.a[3].i))
+                elif nm == "segmm_attn_fwd":
+                    rec = ("attn", ("fwd",) + tuple(c.a[k].i for k in range(6)))
+                elif nm == "segmm_attn_bwd":
+                    phase = c.a[39].i
+                    repair = bool(c.a[40].p) and bool(H.AttnPlanes.from_address(c.a[40].p).flags & H.ATTN_REPAIR)
+                    kind = "bwd" if phase == 0 else "bwd4r" if repair else "bwd4" if phase >= 4 else "bwd%d" % phase
+                    B_, H_, dh_, Lq_, La_, Lb_ = (c.a[k].i for k in range(6))
+                    rec = ("attn", (kind, B_, H_, dh_, Lq_, 0 if phase == 6 else La_, 0 if phase == 5 else Lb_))
+                if rec is None:
+                    continue
+                if ci > lo:
+                    plan.append(("run", sub(lo, ci)))
+                plan.append(("timed", sub(ci, ci + 1), c.stream, rec))
+                lo = ci + 1
+            if ph.n_cmds > lo:
+                plan.append(("run", sub(lo, ph.n_cmds)))
+        r["timed_plan"] = plan
+        return plan
+
+    def run_recorded(self, batch: Dict[str, torch.Tensor], timed=None):
         """One training step from the recorded launch sequences (see :meth:`record`): patch the batch's addresses, then one C
-        call per phase.  Must be called with torch's current stream = the stream ``record`` ran on."""
+        call per phase.  Must be called with torch's current stream = the stream ``record`` ran on.
+        ``timed`` = (gemm list, attention list): the same launch sequence with the phases cut at every GEMM / attention command and
+        a HIP-event pair around each on the command's own stream -- entries like hipabi.GEMM_PROFILE / ATTN_PROFILE; bench.py's
+        roofline pass (a few more C calls and event records per step; results identical)."""
         r = self.__dict__.get("_recorded")
         if r is None:
             raise RuntimeError("run_recorded() before record()")
@@ -962,7 +1011,23 @@ class Trainer:
         main, table = r["main"], r["table"]
         if H._stream() != main:
             raise RuntimeError("run_recorded(): the current stream is not the stream the step was recorded on")
-        for ph, arr in r["phases"]:
+        if timed is not None:
+            streams = r.get("timed_streams")
+            if streams is None:
+                streams = r["timed_streams"] = [torch.cuda.current_stream()] + [torch.cuda.ExternalStream(int(h)) for h in list(table[0])[1:]]
+            for item in self._timed_plan(r):
+                if item[0] == "host":
+                    item[1]()
+                elif item[0] == "run":
+                    H.run_phase(item[1], table)
+                else:
+                    _, ph1, slot, (fam, head) = item
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(streams[slot])
+                    H.run_phase(ph1, table)
+                    e1.record(streams[slot])
+                    timed[0 if fam == "gemm" else 1].append(head + (e0, e1))
+        for ph, arr in (r["phases"] if timed is None else ()):
             if arr is None:
                 ph()          # a host action of the step (data-parallel collective / wait), at its place in the launch order
             else:

@@ -497,6 +497,7 @@ def test_recorded_step_equals_eager_device_state_step(kind, N, B, S, Lt, D, h):
         model = init_model(margs, n_users=50, n_items=500, input_dim=D, max_vid_len=S, max_usr_len=Lt).to(dev)
         tr = Trainer(model, lr=1e-3, weight_decay=1e-4, device_state=True)
         losses, evals = [], []
+        timed = ([], [])
         if recorded:
             tr.record(batches[0], warmup=3)          # 3 eager steps + the recorded one
         else:
@@ -504,7 +505,9 @@ def test_recorded_step_equals_eager_device_state_step(kind, N, B, S, Lt, D, h):
                 tr.train_step(batches[0])
         for t in range(T):
             # (steps 8 and 15 of the recorded run are enqueued from Python: the two ways of stepping can be mixed)
-            out = tr.run_recorded(batches[t % 4]) if (recorded and t not in (8, 15)) else tr.train_step(batches[t % 4])
+            # (... and steps 3 and 12 are TIMED replays: the phases cut at every GEMM / attention command with an event pair around it)
+            out = (tr.run_recorded(batches[t % 4], timed=timed if t in (3, 12) else None) if (recorded and t not in (8, 15))
+                   else tr.train_step(batches[t % 4]))
             losses.append(float(out["loss"].detach()))
             if t in (5, 11):
                 evals.append(tr.eval_step(batches[3], mode="inference")["logits"].detach().clone())
@@ -516,6 +519,11 @@ def test_recorded_step_equals_eager_device_state_step(kind, N, B, S, Lt, D, h):
             kinds = [ph.kind for ph, _ in tr._recorded["phases"]]
             assert kinds[0] == H.PHASE_STEP_BEGIN and kinds[-1] == H.PHASE_STEP_TAIL and H.PHASE_LAYER_FWD in kinds and H.PHASE_LAYER_BWD in kinds
             assert len(tr._recorded["relocs"]) >= 3
+            tg, ta = timed          # two timed steps: every GEMM (layout, M, N, K) and attention launch of the step, with live events
+            assert len(tg) >= 2 * 10 and len(tg) % 2 == 0 and len(ta) >= 2 * 2 and len(ta) % 2 == 0
+            assert tg[:len(tg) // 2] == [] or [g[:4] for g in tg[:len(tg) // 2]] == [g[:4] for g in tg[len(tg) // 2:]]
+            assert all(g[4].elapsed_time(g[5]) > 0 for g in tg) and all(a[7].elapsed_time(a[8]) > 0 for a in ta)
+            assert {a[0] for a in ta} <= {"fwd", "bwd", "bwd4", "bwd4r", "bwd1", "bwd2", "bwd3"} and "fwd" in {a[0] for a in ta}
         return model._store.flat.detach().clone(), tr.opt.m.clone(), tr.opt.v.clone(), losses, evals, seed
 
     pe, me, ve, le, ee, se = run(False)
