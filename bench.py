@@ -21,8 +21,9 @@ Workloads (BASELINE.json configs):
                         timed step (segmm_gather_l1: gather + pad + mask + L1 normalisation); reports the gather's GB/s.
 
 Prints ONE JSON line (rank 0) with the driver contract fields plus
-  roofline     -- the dominant kernel: algorithmic FLOPs (or bytes) per launch / HIP-event duration, measured live in an
-                  instrumented pass of the same steps, vs the peak of the instruction used (MI355X_MICROARCH.md)
+  roofline     -- the dominant kernel: algorithmic FLOPs (or bytes) per launch / HIP-event duration on the launch's own stream,
+                  measured live in a timed replay of the recorded step (`measured_in`; eager step modes: the same steps enqueued
+                  launch by launch), vs the peak of the instruction used (MI355X_MICROARCH.md)
   cpu_baseline -- the CPU oracle's train step (what the reference executes, dead layers and dropout included) timed on this
                   box's host cores on a bounded sample of the same workload (3 warm-up + 10 timed steps, median).
                   roofline.sustained_probe: the fp16 matrix-core rate this GPU sustains on random operand bits, registers only
