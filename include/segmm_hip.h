@@ -149,7 +149,8 @@ int segmm_split3_transpose(const float* x, int R, int C, int ld, uint16_t* plane
  * in the kernel (scale_in is ignored) and recorded in hdr[0]: no input can overflow it, so the consumers need no fp32 fallback.
  * backward: dy is first multiplied by the forward's output-dropout mask (drop_y_*); dx_drop (may be NULL) receives
  * dx times the mask of the residual-branch dropout "x = res + dropout(branch)" (drop_b_*), i.e. d(branch).
- * part_dgamma/part_dbeta: [nparts, d] per-workgroup partials, nparts = segmm_layernorm_bwd_parts(rows).
+ * part_dgamma/part_dbeta: [nparts, d] per-workgroup partials, nparts = segmm_layernorm_bwd_parts(rows, d)
+ * (one round of the workgroups that are resident at that row width: 768 at d = 768).
  * part_dsum (optional, same shape): partial column sums of the forwarded gradient (dx_drop if given, else dx) =
  * the bias gradient of the Linear whose output entered the LayerNorm through the residual branch. */
 int segmm_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
@@ -161,7 +162,7 @@ int segmm_layernorm_fwd_dot(const float* x, const float* gamma, const float* bet
                             int64_t rows, int d, float eps, float drop_p, uint64_t seed, uint32_t site, float* amax,
                             uint16_t* planes, int ld2, float* hdr, const float* scale_in, const float* dot_w, const float* dot_b,
                             float* dot_out, segmm_stream_t stream);
-int segmm_layernorm_bwd_parts(int64_t rows);
+int segmm_layernorm_bwd_parts(int64_t rows, int d);
 int segmm_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                         float* dx, float* dx_drop, float* part_dgamma, float* part_dbeta, float* part_dsum, int64_t rows,
                         int d, float drop_y_p, uint32_t drop_y_site, float drop_b_p, uint32_t drop_b_site, uint64_t seed,
@@ -174,11 +175,11 @@ int segmm_layernorm_bwd_outer(const float* dy_row, const float* dy_col, const fl
                               int d, float drop_y_p, uint32_t drop_y_site, float drop_b_p, uint32_t drop_b_site, uint64_t seed,
                               float* amax, uint16_t* planes, int ld2, float* hdr, const float* scale_in, segmm_stream_t stream);
 /* The embedding LayerNorms' backward (encoder.py:450-471: y = LN(proj(x) + pe[s])): the same launch on a grid of
- * segmm_layernorm_bwd_pos_parts(rows, period) workgroups (0: no such grid; part_dgamma / part_dbeta / part_dsum then have that
+ * segmm_layernorm_bwd_pos_parts(rows, period, d) workgroups (0: no such grid; part_dgamma / part_dbeta / part_dsum then have that
  * many rows) whose waves each walk rows of ONE position s = row mod period, and leave their sum of dx in part_pos[4 * parts, d]
  * (partial row p holds position p mod period).  segmm_colsum_pos: out[s, :] = sum of the partial rows p = s (mod period), in
  * index order -- the positional-embedding gradient without a second pass over dx. */
-int segmm_layernorm_bwd_pos_parts(int64_t rows, int period);
+int segmm_layernorm_bwd_pos_parts(int64_t rows, int period, int d);
 int segmm_layernorm_bwd_pos(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                             float* dx, float* dx_drop, float* part_dgamma, float* part_dbeta, float* part_dsum, int64_t rows,
                             int d, float drop_y_p, uint32_t drop_y_site, float drop_b_p, uint32_t drop_b_site, uint64_t seed,

@@ -100,7 +100,7 @@ static int attn_fill(AttnArgs& a, int B, int H, int dh, int Lq, int La, int Lb, 
 // in by -DSEGMM_ATT_PROBE / -DSEGMM_GEMM_PROBE only.
 enum {
     K_ATTN, K_ATT_FWD_PL, K_ATT_FWD_LDS, K_ATT_FWD_KSPLIT, K_ATT_FWD_LDS_PAD, K_ATT_FUSED_LAUNCH, K_ATT_MERGE, K_ATT_LDS_PAD, K_ATT_WAVES, K_ATT_WAVES_PL, K_ATT_REPAIR_WALK,
-    K_ATT_HPB_FWD, K_ATT_HPB_DQ, K_ATT_HPB_DKV, K_L1NORM_REG, K_GEMM_BN, K_PL_VAR, K_PL_NJ, K_TN_VAR, K_COUNT
+    K_ATT_HPB_FWD, K_ATT_HPB_DQ, K_ATT_HPB_DKV, K_L1NORM_REG, K_GEMM_BN, K_PL_VAR, K_PL_NJ, K_TN_VAR, K_LN_BWD_PARTS, K_COUNT
 };
 struct Knob { const char* name; int value; const char* doc; };
 static Knob g_knobs[K_COUNT] = {
@@ -123,6 +123,7 @@ static Knob g_knobs[K_COUNT] = {
     {"PL_VAR", 4, "plane NT GEMM: 4 gemm_pl_nt4 (round 6: 128 x 256 tiles, two workgroups per CU) for K >= 768 and N >= 768, gemm_pl_nt8 otherwise; 44 gemm_pl_nt4 always; 8 gemm_pl_nt8 (round 3); 1: the round-2 fallback kernel for every launch"},
     {"PL_NJ", 0, "plane NT GEMM: tile width in 64-column units (0: modelled choice)"},
     {"TN_VAR", 8, "plane TN GEMM: 8 gemm_pl_tn4 (round 6: 128 x 256 tiles, two workgroups per CU) for few-tile and 128-row matrices, gemm_pl_tn8 (round 3) otherwise; 4 gemm_pl_tn4 wherever it fits; 88 gemm_pl_tn8 wherever it fits; 0: the round-2 fallback kernel for every launch"},
+    {"LN_BWD_PARTS", 0, "LayerNorm backward: most workgroups (= partial rows of its column sums) per launch; 0: as many four-wave workgroups as are resident at the row width (768 at d = 768: one full round, no under-occupied tail)"},
 };
 static bool g_knobs_ready = false;
 static void knobs_init() {
@@ -508,7 +509,7 @@ __global__ void step_advance_kernel(StepState* st, float b1, float b2) {
 extern "C" {
 
 const char* segmm_last_error(void) { return g_segmm_err; }
-int segmm_abi_version(void) { return 28; }
+int segmm_abi_version(void) { return 29; }
 int segmm_attn_mode(int mode) { const int prev = attn_f16(); if (mode >= 0 && mode <= 2) g_knobs[K_ATTN].value = mode; return prev; }
 
 static PlaneOut plane_out(uint16_t* planes, int ld2, float* hdr, const float* scale_in) {
@@ -993,9 +994,20 @@ int segmm_layernorm_fwd_dot(const float* x, const float* gamma, const float* bet
     return ln_fwd_launch(x, gamma, beta, y, mean, rstd, rows, d, eps, drop_p, seed, site, amax, planes, ld2, hdr, scale_in, dot_w, dot_b, dot_out, stream);
 }
 
-int segmm_layernorm_bwd_parts(int64_t rows) {
+// Workgroups of a LayerNorm-backward launch = partial rows of its column sums.  A workgroup is four waves that walk rows; what is resident
+// per CU follows the kernel's registers at the row width (layernorm_bwd_kernel<V>: 82 / 116 / 152 / 174 / 372 registers for V = 1 / 2 / 3 /
+// 4 / 8).  The launch asks for exactly ONE round of resident workgroups: with 1024 workgroups at d = 768 (768 resident) the last 256 ran
+// alone, one per CU, at 40 % of the bandwidth -- 133 -> 110 us at 51 200 rows (4.7 -> 5.7 TB/s), 59 -> 47 us at 20 480 rows, +0.8 % of the
+// step (profiles/r6/ln_parts_ab.txt).  Knob LN_BWD_PARTS overrides (A/B).
+static int ln_bwd_cap(int d) {
+    const int k = knob(K_LN_BWD_PARTS);
+    if (k >= 64) return k;
+    return d <= 512 ? 1024 : d <= 768 ? 768 : d <= 1024 ? 512 : 256;
+}
+int segmm_layernorm_bwd_parts(int64_t rows, int d) {
     int64_t b = (rows + 3) / 4;
-    if (b > 1024) b = 1024;          // ~3 workgroups per CU are resident (130 VGPR at d = 768): more parts only grow the partial buffers
+    const int cap = ln_bwd_cap(d);
+    if (b > cap) b = cap;
     if (b < 1) b = 1;
     return (int)b;
 }
@@ -1022,7 +1034,7 @@ int segmm_layernorm_bwd(const float* dy, const float* x, const float* mean, cons
                         int d, float drop_y_p, uint32_t drop_y_site, float drop_b_p, uint32_t drop_b_site, uint64_t seed,
                         float* amax, uint16_t* planes, int ld2, float* hdr, const float* scale_in, segmm_stream_t stream) {
     return ln_bwd_launch(dy, x, mean, rstd, gamma, dx, dx_drop, part_dgamma, part_dbeta, part_dsum, rows, d, drop_y_p, drop_y_site, drop_b_p,
-                         drop_b_site, seed, amax, planes, ld2, hdr, scale_in, nullptr, segmm_layernorm_bwd_parts(rows), stream);
+                         drop_b_site, seed, amax, planes, ld2, hdr, scale_in, nullptr, segmm_layernorm_bwd_parts(rows, d), stream);
 }
 
 int segmm_layernorm_bwd_outer(const float* dy_row, const float* dy_col, const float* x, const float* mean, const float* rstd, const float* gamma,
@@ -1031,16 +1043,17 @@ int segmm_layernorm_bwd_outer(const float* dy_row, const float* dy_col, const fl
                               float* amax, uint16_t* planes, int ld2, float* hdr, const float* scale_in, segmm_stream_t stream) {
     SEGMM_REQUIRE(dy_row && dy_col, "layernorm_bwd_outer: null pointer");
     return ln_bwd_launch(dy_row, x, mean, rstd, gamma, dx, dx_drop, part_dgamma, part_dbeta, part_dsum, rows, d, drop_y_p, drop_y_site, drop_b_p,
-                         drop_b_site, seed, amax, planes, ld2, hdr, scale_in, nullptr, segmm_layernorm_bwd_parts(rows), stream, dy_col);
+                         drop_b_site, seed, amax, planes, ld2, hdr, scale_in, nullptr, segmm_layernorm_bwd_parts(rows, d), stream, dy_col);
 }
 
 // workgroups (4 waves each) of the per-position form: the wave stride 4 * parts must be a multiple of the sequence length
-int segmm_layernorm_bwd_pos_parts(int64_t rows, int period) {
+int segmm_layernorm_bwd_pos_parts(int64_t rows, int period, int d) {
     if (period <= 0 || rows <= 0 || rows % period) return 0;
     int g = period % 4 == 0 ? 4 : (period % 2 == 0 ? 2 : 1);
     const int unit = period / g;                     // parts must be a multiple of this
     int64_t want = (rows + 3) / 4;
-    if (want > 1024) want = 1024;
+    const int cap = ln_bwd_cap(d);
+    if (want > cap) want = cap;
     const int64_t k = want / unit;
     return k < 1 ? (unit <= 1024 ? unit : 0) : (int)(k * unit);
 }
@@ -1050,7 +1063,7 @@ int segmm_layernorm_bwd_pos(const float* dy, const float* x, const float* mean, 
                             int d, float drop_y_p, uint32_t drop_y_site, float drop_b_p, uint32_t drop_b_site, uint64_t seed,
                             float* amax, uint16_t* planes, int ld2, float* hdr, const float* scale_in, float* part_pos, int period,
                             segmm_stream_t stream) {
-    const int parts = segmm_layernorm_bwd_pos_parts(rows, period);
+    const int parts = segmm_layernorm_bwd_pos_parts(rows, period, d);
     SEGMM_REQUIRE(part_pos && parts > 0 && (4 * parts) % period == 0, "layernorm_bwd_pos: %lld rows with period %d have no per-position grid", (long long)rows, period);
     return ln_bwd_launch(dy, x, mean, rstd, gamma, dx, dx_drop, part_dgamma, part_dbeta, part_dsum, rows, d, drop_y_p, drop_y_site, drop_b_p,
                          drop_b_site, seed, amax, planes, ld2, hdr, scale_in, part_pos, parts, stream);

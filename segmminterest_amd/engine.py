@@ -936,8 +936,8 @@ def _ln_bwd(store, dy, x, mean, rstd, gname, bname, gbuf, dx, dx_drop, rows, d, 
     it leaves are returned ([4 * parts, d], partial row p = position p mod L; None when no such grid exists) -- the
     positional-embedding gradient then is a sum over ~40 partial rows per position instead of a pass over dx."""
     # (worth it when the second pass it saves is long: short sequences / small tensors keep the plain column sum)
-    pparts = H.layernorm_bwd_pos_parts(rows, pos_period) if (pos_period >= 8 and store.ln_pos and rows * d >= (1 << 23)) else 0
-    parts = pparts if pparts > 0 else H.layernorm_bwd_parts(rows)
+    pparts = H.layernorm_bwd_pos_parts(rows, pos_period, d) if (pos_period >= 8 and store.ln_pos and rows * d >= (1 << 23)) else 0
+    parts = pparts if pparts > 0 else H.layernorm_bwd_parts(rows, d)
     # partial buffers named after the parameter so that their reductions MAY run on the side stream (SEGMM_LN_SIDE=1;
     # measured 2 % slower than keeping these tiny launches on the main stream, so off by default)
     pg = store.buf("ln_pg:" + gname, (parts, d))

@@ -15,7 +15,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SEGMM_LIB") or os.path.join(_HERE, "libsegmm_hip.so")      # SEGMM_LIB: A/B builds of the kernels
-ABI_VERSION = 28
+ABI_VERSION = 29
 
 _lib = None
 
@@ -53,10 +53,10 @@ SIGNATURES = {
     "segmm_split3_transpose": [_p, _i, _i, _i, _p, _i64, _p],
     "segmm_layernorm_fwd": [_p, _p, _p, _p, _p, _p, _i64, _i, _f, _f, _u64, _u32, _p, _p, _i, _p, _p, _p],
     "segmm_layernorm_fwd_dot": [_p, _p, _p, _p, _p, _p, _i64, _i, _f, _f, _u64, _u32, _p, _p, _i, _p, _p, _p, _p, _p, _p],
-    "segmm_layernorm_bwd_parts": [_i64],
+    "segmm_layernorm_bwd_parts": [_i64, _i],
     "segmm_layernorm_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _f, _u32, _f, _u32, _u64, _p, _p, _i, _p, _p, _p],
     "segmm_layernorm_bwd_outer": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _f, _u32, _f, _u32, _u64, _p, _p, _i, _p, _p, _p],
-    "segmm_layernorm_bwd_pos_parts": [_i64, _i],
+    "segmm_layernorm_bwd_pos_parts": [_i64, _i, _i],
     "segmm_layernorm_bwd_pos": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _f, _u32, _f, _u32, _u64, _p, _p, _i, _p, _p, _p, _i, _p],
     "segmm_colsum_pos": [_p, _i, _i, _i, _p, _p],
     "segmm_colsum_chunks": [_i64],
@@ -741,8 +741,8 @@ def layernorm_fwd_dot(x, gamma, beta, y, mean, rstd, dot_w, dot_b, dot_out, eps=
            "segmm_layernorm_fwd_dot")
 
 
-def layernorm_bwd_parts(rows):
-    return lib().segmm_layernorm_bwd_parts(rows)
+def layernorm_bwd_parts(rows, d):
+    return lib().segmm_layernorm_bwd_parts(rows, d)
 
 
 def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dx_drop, part_dgamma, part_dbeta, drop_y_p=0.0, drop_y_site=0,
@@ -766,8 +766,8 @@ def layernorm_bwd_outer(dy_row, dy_col, x, mean, rstd, gamma, dx, dx_drop, part_
            "segmm_layernorm_bwd_outer")
 
 
-def layernorm_bwd_pos_parts(rows, period):
-    return lib().segmm_layernorm_bwd_pos_parts(rows, period)
+def layernorm_bwd_pos_parts(rows, period, d):
+    return lib().segmm_layernorm_bwd_pos_parts(rows, period, d)
 
 
 def layernorm_bwd_pos(dy, x, mean, rstd, gamma, dx, dx_drop, part_dgamma, part_dbeta, part_pos, period, drop_y_p=0.0, drop_y_site=0,

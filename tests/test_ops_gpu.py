@@ -220,7 +220,7 @@ def test_layernorm_fwd_bwd(rows, d):
     assert (y.double() - ref).abs().max().item() < 5e-6
     dy = _rand(rows, d, seed=23)
     ref.backward(dy.double())
-    parts = H.layernorm_bwd_parts(rows)
+    parts = H.layernorm_bwd_parts(rows, d)
     dx = torch.empty_like(x)
     pg, pb = torch.empty(parts, d, device=DEV), torch.empty(parts, d, device=DEV)
     H.layernorm_bwd(dy, x, mean, rstd, gamma, dx, None, pg, pb)
@@ -246,7 +246,7 @@ def test_layernorm_dropout_roundtrip():
     assert torch.allclose(y, ref, atol=1e-5)
     # backward: dy masked by the same stream; dx_drop masked by the branch stream
     dy = _rand(rows, d, seed=25)
-    parts = H.layernorm_bwd_parts(rows)
+    parts = H.layernorm_bwd_parts(rows, d)
     dx, dxd = torch.empty_like(x), torch.empty_like(x)
     pg, pb = torch.empty(parts, d, device=DEV), torch.empty(parts, d, device=DEV)
     H.layernorm_bwd(dy, x, mean, rstd, gamma, dx, dxd, pg, pb, drop_y_p=p, drop_y_site=9, drop_b_p=p, drop_b_site=4, seed=3)
@@ -633,7 +633,7 @@ def test_fused_amax_producers():
     H.layernorm_fwd(x, gamma, beta, y, mean, rstd, drop_p=0.1, seed=5, site=3, amax=am)
     assert am.max().item() == y.abs().max().item()
     dy = _rand(rows, d, seed=33) * 1e-6
-    parts = H.layernorm_bwd_parts(rows)
+    parts = H.layernorm_bwd_parts(rows, d)
     dx, dxd = torch.empty_like(x), torch.empty_like(x)
     pg, pb = torch.empty(parts, d, device=DEV), torch.empty(parts, d, device=DEV)
     am.zero_()
@@ -881,11 +881,11 @@ def test_layernorm_bwd_per_position_sums(B, L, d):
     gamma = (1 + 0.1 * torch.randn(d, generator=g)).to(DEV)
     mean = x.mean(-1)
     rstd = 1.0 / torch.sqrt(x.var(-1, unbiased=False) + 1e-12)
-    parts0 = H.layernorm_bwd_parts(rows)
+    parts0 = H.layernorm_bwd_parts(rows, d)
     dx0 = torch.empty_like(x)
     pg0, pb0 = torch.empty(parts0, d, device=DEV), torch.empty(parts0, d, device=DEV)
     H.layernorm_bwd(dy, x, mean, rstd, gamma, dx0, None, pg0, pb0, drop_y_p=0.1, drop_y_site=3, seed=11)
-    parts = H.layernorm_bwd_pos_parts(rows, L)
+    parts = H.layernorm_bwd_pos_parts(rows, L, d)
     assert parts > 0 and (4 * parts) % L == 0 and parts <= 1024
     dx = torch.empty_like(x)
     pg, pb = torch.empty(parts, d, device=DEV), torch.empty(parts, d, device=DEV)
@@ -900,5 +900,5 @@ def test_layernorm_bwd_per_position_sums(B, L, d):
     for a, b in ((pg, pg0), (pb, pb0)):
         ra, rb = a.double().sum(0), b.double().sum(0)
         assert (ra - rb).abs().max().item() < 1e-5 * max(1.0, rb.abs().max().item())
-    assert H.layernorm_bwd_pos_parts(rows + 1, L) == 0 or (rows + 1) % L == 0
+    assert H.layernorm_bwd_pos_parts(rows + 1, L, d) == 0 or (rows + 1) % L == 0
 

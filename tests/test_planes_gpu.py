@@ -314,7 +314,7 @@ def test_rowop_producers_write_the_split_pass_planes():
     assert torch.equal(out, out2)                       # the fp32 output does not depend on the plane output
     # LayerNorm backward: planes of the forwarded (dropped) gradient
     dy = _rand(rows, d, seed=23)
-    parts = H.layernorm_bwd_parts(rows)
+    parts = H.layernorm_bwd_parts(rows, d)
     dx, dxd = torch.empty_like(x), torch.empty_like(x)
     pg, pb = torch.empty(parts, d, device=DEV), torch.empty(parts, d, device=DEV)
     pl, hdr, sc, po = _po(H, rows, d, 2.0 ** 11)

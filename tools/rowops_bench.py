@@ -31,7 +31,7 @@ for rows in (20480, 51200):
     am = torch.zeros(H.AMAX_SLOTS, device=dev)
     us = timeit(lambda: H.layernorm_fwd(x, g, b, y, mean, rstd, drop_p=0.1, seed=1, site=2, amax=am))
     print("ln_fwd  rows %6d  %7.1f us  %5.2f TB/s (8 B/elem)" % (rows, us, rows * d * 8 / us / 1e6))
-    parts = H.layernorm_bwd_parts(rows)
+    parts = H.layernorm_bwd_parts(rows, d)
     pg, pb, ps = (torch.empty(parts, d, device=dev) for _ in range(3))
     us = timeit(lambda: H.layernorm_bwd(dy, x, mean, rstd, g, dx, dxd, pg, pb, drop_b_p=0.1, drop_b_site=3, seed=1, amax=am, part_dsum=ps))
     print("ln_bwd  rows %6d  %7.1f us  %5.2f TB/s (16 B/elem)  parts %d" % (rows, us, rows * d * 16 / us / 1e6, parts))
